@@ -1,0 +1,219 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The wrapped library is the CPU restatement of the reference path (see armour_oracle.cpp header).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+MAXJ = 7
+
+
+class ArmourRobot(C.Structure):
+    _fields_ = [
+        ("num_joints", C.c_int32), ("num_factors", C.c_int32),
+        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXJ),
+        ("trans", C.c_double * ((MAXJ + 1) * 3)), ("rots", C.c_double * (MAXJ * 3)),
+        ("mass", C.c_double * MAXJ), ("mass_uncertainty", C.c_double),
+        ("com", C.c_double * (MAXJ * 3)),
+        ("inertia", C.c_double * (MAXJ * 9)), ("inertia_uncertainty", C.c_double),
+        ("friction", C.c_double * MAXJ), ("damping", C.c_double * MAXJ), ("armature", C.c_double * MAXJ),
+        ("state_limits_lb", C.c_double * MAXJ), ("state_limits_ub", C.c_double * MAXJ),
+        ("speed_limits", C.c_double * MAXJ), ("torque_limits", C.c_double * MAXJ),
+        ("gravity", C.c_double),
+        ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
+        ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
+    ]
+
+
+class ArmourParams(C.Structure):
+    _fields_ = [
+        ("num_time_steps", C.c_int32), ("reserved", C.c_int32),
+        ("duration", C.c_double), ("k_range", C.c_double * MAXJ),
+        ("simplify_threshold", C.c_double), ("t_plan", C.c_double), ("cost_scale", C.c_double),
+        ("collision_violation_threshold", C.c_double), ("torque_violation_threshold", C.c_double),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams)]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_problem.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_int, dp, C.c_int]
+        L.oracle_num_constraints.argtypes = [C.c_void_p]
+        L.oracle_build_ms.argtypes = [C.c_void_p]
+        L.oracle_build_ms.restype = C.c_double
+        L.oracle_eval_g_jac.argtypes = [C.c_void_p, dp, dp, dp, C.c_int]
+        L.oracle_time_eval.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, dp, dp, C.c_int]
+        L.oracle_time_eval.restype = C.c_double
+        L.oracle_get_bounds.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.oracle_eval_f.argtypes = [C.c_void_p, dp]
+        L.oracle_eval_f.restype = C.c_double
+        L.oracle_eval_grad_f.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_get_torque_radius.argtypes = [C.c_void_p, dp]
+        L.oracle_get_link_generators.argtypes = [C.c_void_p, dp]
+        L.oracle_get_hyperplanes.argtypes = [C.c_void_p, dp, dp, dp]
+        L.oracle_pz_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_pz_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint64), dp]
+        L.oracle_table_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 4
+        L.oracle_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.oracle_slice_torque.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_slice_links.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def kinova_robot():
+    """RT/KinovaWithoutGripperInfo.h constants (same data as include/armour_robot_kinova.h)."""
+    r = ArmourRobot()
+    lib().oracle_fill_kinova(C.byref(r))
+    return r
+
+
+def default_params(T=128):
+    p = ArmourParams()
+    lib().oracle_fill_default_params(C.byref(p), T)
+    return p
+
+
+class Oracle:
+    """One planning problem on the CPU restatement: set_problem (P1) then eval_g_jac (P2)."""
+
+    def __init__(self, robot=None, params=None, T=128):
+        self.robot = robot if robot is not None else kinova_robot()
+        self.params = params if params is not None else default_params(T)
+        self.T = self.params.num_time_steps
+        self.J = self.robot.num_joints
+        self.n = self.robot.num_factors
+        self.h = lib().oracle_create(C.byref(self.robot), C.byref(self.params))
+        self.O = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_destroy(self.h)
+            self.h = None
+
+    def set_problem(self, q0, qd0, qdd0, q_des, obstacles, threads=0):
+        q0, qd0, qdd0, q_des = [np.ascontiguousarray(a, dtype=np.float64) for a in (q0, qd0, qdd0, q_des)]
+        obs = np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 12)
+        self.O = obs.shape[0]
+        if self.O == 0:
+            obs = np.zeros((1, 12))
+        rc = lib().oracle_set_problem(self.h, _dp(q0), _dp(qd0), _dp(qdd0), _dp(q_des), self.O, _dp(obs), threads)
+        if rc != 0:
+            raise RuntimeError("oracle_set_problem failed")
+        self.m = lib().oracle_num_constraints(self.h)
+        return self
+
+    @property
+    def build_ms(self):
+        return lib().oracle_build_ms(self.h)
+
+    def eval_g_jac(self, k, want_g=True, want_jac=True, threads=0):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        g = np.zeros(self.m) if want_g else None
+        jac = np.zeros((self.m, self.n)) if want_jac else None
+        lib().oracle_eval_g_jac(self.h, _dp(k), _dp(g) if want_g else None, _dp(jac) if want_jac else None, threads)
+        return g, jac
+
+    def time_eval(self, ks, reps, threads=0):
+        ks = np.ascontiguousarray(ks, dtype=np.float64).reshape(-1, self.n)
+        g = np.zeros(self.m)
+        jac = np.zeros((self.m, self.n))
+        return lib().oracle_time_eval(self.h, _dp(ks), ks.shape[0], reps, _dp(g), _dp(jac), threads)
+
+    def bounds(self):
+        xl, xu = np.zeros(self.n), np.zeros(self.n)
+        gl, gu = np.zeros(self.m), np.zeros(self.m)
+        lib().oracle_get_bounds(self.h, _dp(xl), _dp(xu), _dp(gl), _dp(gu))
+        return xl, xu, gl, gu
+
+    def eval_f(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        return lib().oracle_eval_f(self.h, _dp(k))
+
+    def eval_grad_f(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        out = np.zeros(self.n)
+        lib().oracle_eval_grad_f(self.h, _dp(k), _dp(out))
+        return out
+
+    def torque_radius(self):
+        out = np.zeros((self.n, self.T))
+        lib().oracle_get_torque_radius(self.h, _dp(out))
+        return out
+
+    def link_generators(self):
+        out = np.zeros((self.T, self.J, 3, 6))
+        lib().oracle_get_link_generators(self.h, _dp(out))
+        return out
+
+    def hyperplanes(self):
+        A = np.zeros((self.T, self.J, self.O, 36, 3))
+        d = np.zeros((self.T, self.J, self.O, 36))
+        delta = np.zeros((self.T, self.J, self.O, 36))
+        lib().oracle_get_hyperplanes(self.h, _dp(A), _dp(d), _dp(delta))
+        return A, d, delta
+
+    def pz(self, which, i, t):
+        """which: 'link' | 'torque' | 'disturbance' -> (center, indep, keys[M], coeffs[M, sz])."""
+        w = {"link": 0, "torque": 1, "disturbance": 2}[which]
+        sz = 3 if w == 0 else 1
+        M = lib().oracle_pz_size(self.h, w, i, t)
+        center, indep = np.zeros(sz), np.zeros(sz)
+        keys = np.zeros(max(M, 1), dtype=np.uint64)
+        coeffs = np.zeros((max(M, 1), sz))
+        lib().oracle_pz_get(self.h, w, i, t, _dp(center), _dp(indep), keys.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(coeffs))
+        return center, indep, keys[:M], coeffs[:M]
+
+    def table_sizes(self):
+        v = [C.c_int64() for _ in range(4)]
+        lib().oracle_table_sizes(self.h, *[C.byref(x) for x in v])
+        return dict(sum_link=v[0].value, sum_torque=v[1].value, max_link=v[2].value, max_torque=v[3].value)
+
+    def stats(self):
+        out = (C.c_uint64 * 6)()
+        lib().oracle_stats(self.h, out)
+        keys = ["mul_calls", "mul_pairs", "simplify_calls", "simplify_terms", "max_raw_terms", "max_out_terms"]
+        return dict(zip(keys, [int(x) for x in out]))
+
+    def slice_torque(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        out = np.zeros((self.T, self.n))
+        lib().oracle_slice_torque(self.h, _dp(k), _dp(out))
+        return out
+
+    def slice_links(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        out = np.zeros((self.T, self.J, 3))
+        lib().oracle_slice_links(self.h, _dp(k), _dp(out))
+        return out
+
+
+def max_threads():
+    return lib().oracle_max_threads()
