@@ -1,0 +1,114 @@
+"""ctypes binding of armour_amd/lib/libarmour_hip.so (the C ABI in include/armour_hip.h).
+
+There is no CPU path: if the shared library is missing or fails to load this module raises, and
+`armour_create` fails with ARMOUR_EDEVICE when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarmour_hip.so")
+
+MAXJ = 7
+
+OK, EINVAL, EDEVICE, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
+
+
+class ArmourRobot(C.Structure):
+    _fields_ = [
+        ("num_joints", C.c_int32), ("num_factors", C.c_int32),
+        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXJ),
+        ("trans", C.c_double * ((MAXJ + 1) * 3)), ("rots", C.c_double * (MAXJ * 3)),
+        ("mass", C.c_double * MAXJ), ("mass_uncertainty", C.c_double),
+        ("com", C.c_double * (MAXJ * 3)),
+        ("inertia", C.c_double * (MAXJ * 9)), ("inertia_uncertainty", C.c_double),
+        ("friction", C.c_double * MAXJ), ("damping", C.c_double * MAXJ), ("armature", C.c_double * MAXJ),
+        ("state_limits_lb", C.c_double * MAXJ), ("state_limits_ub", C.c_double * MAXJ),
+        ("speed_limits", C.c_double * MAXJ), ("torque_limits", C.c_double * MAXJ),
+        ("gravity", C.c_double),
+        ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
+        ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
+    ]
+
+
+class ArmourParams(C.Structure):
+    _fields_ = [
+        ("num_time_steps", C.c_int32), ("reserved", C.c_int32),
+        ("duration", C.c_double), ("k_range", C.c_double * MAXJ),
+        ("simplify_threshold", C.c_double), ("t_plan", C.c_double), ("cost_scale", C.c_double),
+        ("collision_violation_threshold", C.c_double), ("torque_violation_threshold", C.c_double),
+    ]
+
+
+class ArmourLimits(C.Structure):
+    _fields_ = [
+        ("max_batch", C.c_int32), ("max_obstacles", C.c_int32), ("link_monomials", C.c_int32),
+        ("torque_monomials", C.c_int32), ("work_monomials", C.c_int32), ("raw_terms", C.c_int32),
+    ]
+
+
+# every symbol include/armour_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "armour_robot_kinova_gen3_no_gripper", "armour_params_default", "armour_create", "armour_destroy",
+    "armour_last_error", "armour_device_available", "armour_set_problems", "armour_get_sizes",
+    "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
+    "armour_eval_g_jac_device", "armour_check_feasible", "armour_get_torque_radius",
+    "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
+    "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
+]
+
+_lib = None
+
+
+def load():
+    """Load libarmour_hip.so (raises OSError with build instructions if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `make -C armour_amd/csrc` (hipcc, gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU path.")
+    L = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.armour_robot_kinova_gen3_no_gripper.argtypes = [C.POINTER(ArmourRobot)]
+    L.armour_robot_kinova_gen3_no_gripper.restype = None
+    L.armour_params_default.argtypes = [C.POINTER(ArmourParams), C.c_int32]
+    L.armour_params_default.restype = None
+    L.armour_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams), C.POINTER(ArmourLimits), C.c_int32, C.POINTER(vp)]
+    L.armour_destroy.argtypes = [vp]
+    L.armour_destroy.restype = None
+    L.armour_last_error.restype = C.c_char_p
+    L.armour_set_problems.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, dp]
+    L.armour_get_sizes.argtypes = [vp, ip, ip, ip]
+    L.armour_get_bounds.argtypes = [vp, dp, dp, dp, dp]
+    L.armour_eval_f.argtypes = [vp, dp, dp]
+    L.armour_eval_grad_f.argtypes = [vp, dp, dp]
+    L.armour_eval_g_jac.argtypes = [vp, dp, dp, dp]
+    L.armour_eval_g_jac_device.argtypes = [vp, vp, vp, vp, vp]
+    L.armour_check_feasible.argtypes = [vp, dp, ip]
+    L.armour_get_torque_radius.argtypes = [vp, dp]
+    L.armour_get_link_generators.argtypes = [vp, dp]
+    L.armour_get_link_centers.argtypes = [vp, dp, dp]
+    L.armour_get_pz.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, C.POINTER(C.c_uint64), dp, C.c_int32]
+    L.armour_get_table_sizes.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.armour_get_hyperplanes.argtypes = [vp, dp, dp, dp]
+    L.armour_get_build_ms.argtypes = [vp, dp]
+    L.armour_p2_kernel_name.restype = C.c_char_p
+    L.armour_debug_load_tables.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, ip, dp, C.POINTER(C.c_uint64), dp,
+                                           C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]
+    _lib = L
+    return L
+
+
+class ArmourError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"armour error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc < 0:
+        raise ArmourError(rc, load().armour_last_error().decode())
+    return rc

@@ -1,0 +1,464 @@
+// C ABI of libarmour_hip.so (see include/armour_hip.h): handle lifetime, device-table ownership, the
+// NLP-callback entry points and the host-side closed forms (bounds, cost, feasibility re-check).
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+#include "../../include/armour_robot_kinova.h"
+#include "bezier.h"
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void armour_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* armour_last_error(void) { return g_err; }
+
+extern "C" void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_no_gripper(robot); }
+extern "C" void armour_params_default(ArmourParams* params, int32_t T) { armour_fill_default_params(params, T); }
+
+extern "C" int armour_device_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+template <class Tp>
+static int dev_alloc(Tp** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(Tp)));
+    return ARMOUR_OK;
+}
+template <class Tp>
+static void dev_free(Tp** p) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+static int ensure_capacity(ArmourPlanner* h, int B, int O) {
+    if (B <= h->allocB && O <= h->allocO) return ARMOUR_OK;
+    const int nb = B > h->allocB ? B : h->allocB, no = O > h->allocO ? O : h->allocO;
+    const size_t nl = (size_t)nb * h->J * h->T, nt = (size_t)nb * h->n * h->T;
+    int rc;
+#define TRY(x) if ((rc = (x)) != ARMOUR_OK) return rc
+    TRY(dev_alloc(&h->d_link_count, nl));
+    TRY(dev_alloc(&h->d_link_center, nl * 3));
+    TRY(dev_alloc(&h->d_link_indep, nl * 3));
+    TRY(dev_alloc(&h->d_link_keys, nl * h->lim.link_monomials));
+    TRY(dev_alloc(&h->d_link_coeff, nl * h->lim.link_monomials * 3));
+    TRY(dev_alloc(&h->d_tq_count, nt));
+    TRY(dev_alloc(&h->d_tq_center, nt));
+    TRY(dev_alloc(&h->d_tq_indep, nt));
+    TRY(dev_alloc(&h->d_tq_keys, nt * h->lim.torque_monomials));
+    TRY(dev_alloc(&h->d_tq_coeff, nt * h->lim.torque_monomials));
+    TRY(dev_alloc(&h->d_planes, (size_t)nb * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * h->J * h->T * (size_t)no));
+    TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
+    const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
+    TRY(dev_alloc(&h->d_k, (size_t)nb * h->n));
+    TRY(dev_alloc(&h->d_g, (size_t)nb * mmax));
+    TRY(dev_alloc(&h->d_jac, (size_t)nb * mmax * h->n));
+#undef TRY
+    h->allocB = nb;
+    h->allocO = no;
+    return ARMOUR_OK;
+}
+
+P2Tables armour_make_tables(const ArmourPlanner* h) {
+    P2Tables tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.B = h->B; tb.T = h->T; tb.J = h->J; tb.n = h->n; tb.O = h->O; tb.Q = h->Q; tb.m = h->m;
+    tb.capL = h->lim.link_monomials; tb.capT = h->lim.torque_monomials;
+    tb.link_count = h->d_link_count; tb.link_center = h->d_link_center; tb.link_indep = h->d_link_indep;
+    tb.link_keys = h->d_link_keys; tb.link_coeff = h->d_link_coeff;
+    tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
+    tb.tq_keys = h->d_tq_keys; tb.tq_coeff = h->d_tq_coeff;
+    tb.planes = h->d_planes; tb.bez = h->d_bez;
+    for (int i = 0; i < ARMOUR_MAX_FACTORS; i++) tb.k_range[i] = h->params.k_range[i];
+    tb.duration = h->params.duration;
+    return tb;
+}
+
+extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* params, const ArmourLimits* limits,
+                             int32_t device, ArmourPlanner** out) {
+    if (!robot || !params || !out) { armour_set_error("armour_create: null argument"); return ARMOUR_EINVAL; }
+    if (robot->num_joints < 1 || robot->num_joints > ARMOUR_MAX_JOINTS || robot->num_factors < 1 ||
+        robot->num_factors > robot->num_joints) {
+        armour_set_error("armour_create: unsupported robot (joints=%d, factors=%d; max %d)", robot->num_joints,
+                         robot->num_factors, ARMOUR_MAX_JOINTS);
+        return ARMOUR_EINVAL;
+    }
+    if (params->num_time_steps < 2 || (params->num_time_steps & 1)) {
+        armour_set_error("armour_create: num_time_steps must be even and >= 2 (RT/Parameters.h:16)");
+        return ARMOUR_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        armour_set_error("armour_create: no HIP device visible -- libarmour_hip has no CPU path");
+        return ARMOUR_EDEVICE;
+    }
+    if (device < 0 || device >= ndev) { armour_set_error("armour_create: device %d out of range (%d visible)", device, ndev); return ARMOUR_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    ArmourPlanner* h = new (std::nothrow) ArmourPlanner();
+    if (!h) { armour_set_error("out of host memory"); return ARMOUR_EINVAL; }
+    h->robot = *robot;
+    h->params = *params;
+    ArmourLimits lim;
+    memset(&lim, 0, sizeof(lim));
+    if (limits) lim = *limits;
+    if (lim.max_batch <= 0) lim.max_batch = 1;
+    if (lim.max_obstacles <= 0) lim.max_obstacles = 40;
+    if (lim.link_monomials <= 0) lim.link_monomials = 32;
+    if (lim.torque_monomials <= 0) lim.torque_monomials = 128;
+    if (lim.work_monomials <= 0) lim.work_monomials = 1024;
+    if (lim.raw_terms <= 0) lim.raw_terms = 4096;
+    h->lim = lim;
+    h->ub = armour_ultimate_bound(robot);
+    h->device = device;
+    h->T = params->num_time_steps; h->J = robot->num_joints; h->n = robot->num_factors;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { armour_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete h; return ARMOUR_EDEVICE; }
+    *out = h;
+    return ARMOUR_OK;
+}
+
+extern "C" void armour_destroy(ArmourPlanner* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    armour_p1_free(h);
+    dev_free(&h->d_link_count); dev_free(&h->d_link_center); dev_free(&h->d_link_indep);
+    dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
+    dev_free(&h->d_tq_count); dev_free(&h->d_tq_center); dev_free(&h->d_tq_indep);
+    dev_free(&h->d_tq_keys); dev_free(&h->d_tq_coeff);
+    dev_free(&h->d_planes); dev_free(&h->d_bez);
+    dev_free(&h->d_k); dev_free(&h->d_g); dev_free(&h->d_jac);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, const double* qd0, const double* qdd0,
+                             const double* q_des) {
+    if (!h || !q0 || !qd0 || !qdd0 || !q_des) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    if (B < 1 || O < 0) { armour_set_error("bad batch/obstacle count (B=%d, O=%d)", B, O); return ARMOUR_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    h->ready = false;
+    int rc = ensure_capacity(h, B, O);
+    if (rc != ARMOUR_OK) return rc;
+    h->B = B; h->O = O; h->Q = h->J * h->T * O;
+    h->m = h->n * h->T + h->Q + 4 * h->n;
+    const size_t bn = (size_t)B * h->n;
+    h->h_q0.assign(q0, q0 + bn); h->h_qd0.assign(qd0, qd0 + bn);
+    h->h_qdd0.assign(qdd0, qdd0 + bn); h->h_qdes.assign(q_des, q_des + bn);
+    // Bezier scalars: q0, Tqd0 = qd0*DURATION, TTqdd0 = qdd0*DURATION^2 (RT/Trajectory.cu:22-26)
+    std::vector<double> bz((size_t)B * 3 * h->n);
+    const double D = h->params.duration;
+    for (int b = 0; b < B; b++)
+        for (int i = 0; i < h->n; i++) {
+            bz[((size_t)b * 3 + 0) * h->n + i] = q0[b * h->n + i];
+            bz[((size_t)b * 3 + 1) * h->n + i] = qd0[b * h->n + i] * D;
+            bz[((size_t)b * 3 + 2) * h->n + i] = qdd0[b * h->n + i] * D * D;
+        }
+    HIPCHK(hipMemcpy(h->d_bez, bz.data(), bz.size() * sizeof(double), hipMemcpyHostToDevice));
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
+                                   const double* qdd0, const double* q_des, const double* obstacles) {
+    int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
+    if (rc != ARMOUR_OK) return rc;
+    if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
+    rc = armour_p1_build(h, obstacles);
+    if (rc != ARMOUR_OK) return rc;
+    h->ready = true;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
+                                        const double* qdd0, const double* q_des, const int32_t* link_count,
+                                        const double* link_center, const uint64_t* link_keys, const double* link_coeffs,
+                                        int32_t cap_l, const int32_t* torque_count, const double* torque_center,
+                                        const uint64_t* torque_keys, const double* torque_coeffs, int32_t cap_t,
+                                        const double* A, const double* d, const double* delta, const double* torque_radius) {
+    int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
+    if (rc != ARMOUR_OK) return rc;
+    const int J = h->J, T = h->T, n = h->n, capL = h->lim.link_monomials, capT = h->lim.torque_monomials;
+    const size_t nl = (size_t)B * J * T, nt = (size_t)B * n * T;
+    // centres arrive as [..][2][sz]: slot 0 = centre, slot 1 = independent radius
+    std::vector<double> lc(nl * 3), li(nl * 3), lco(nl * capL * 3, 0.0), tc(nt), ti(nt), tco(nt * capT, 0.0);
+    std::vector<uint32_t> lk(nl * capL, 0), tk(nt * capT, 0);
+    for (size_t i = 0; i < nl; i++) {
+        if (link_count[i] > capL) { armour_set_error("link PZ %zu has %d monomials > capacity %d", i, link_count[i], capL); return ARMOUR_ECAPACITY; }
+        for (int e = 0; e < 3; e++) { lc[i * 3 + e] = link_center[(i * 2) * 3 + e]; li[i * 3 + e] = link_center[(i * 2 + 1) * 3 + e]; }
+        for (int mo = 0; mo < link_count[i]; mo++) {
+            lk[i * capL + mo] = (uint32_t)link_keys[i * cap_l + mo];
+            for (int e = 0; e < 3; e++) lco[(i * capL + mo) * 3 + e] = link_coeffs[(i * cap_l + mo) * 3 + e];
+        }
+    }
+    for (size_t i = 0; i < nt; i++) {
+        if (torque_count[i] > capT) { armour_set_error("torque PZ %zu has %d monomials > capacity %d", i, torque_count[i], capT); return ARMOUR_ECAPACITY; }
+        tc[i] = torque_center[i * 2]; ti[i] = torque_center[i * 2 + 1];
+        for (int mo = 0; mo < torque_count[i]; mo++) { tk[i * capT + mo] = (uint32_t)torque_keys[i * cap_t + mo]; tco[i * capT + mo] = torque_coeffs[i * cap_t + mo]; }
+    }
+    // reference layout [b][t][l][o][p] -> planes[b][c][p][(l*T+t)*O+o]
+    const size_t Q = (size_t)h->Q;
+    std::vector<double> pl((size_t)B * 5 * 36 * Q);
+    for (int b = 0; b < B; b++)
+        for (int t = 0; t < T; t++)
+            for (int l = 0; l < J; l++)
+                for (int o = 0; o < O; o++)
+                    for (int p = 0; p < 36; p++) {
+                        const size_t src = ((((size_t)b * T + t) * J + l) * O + o) * 36 + p;
+                        const size_t q = ((size_t)l * T + t) * O + o;
+                        double* base = &pl[(size_t)b * 5 * 36 * Q + (size_t)p * Q + q];
+                        base[0 * 36 * Q] = A[src * 3 + 0]; base[1 * 36 * Q] = A[src * 3 + 1]; base[2 * 36 * Q] = A[src * 3 + 2];
+                        base[3 * 36 * Q] = d[src]; base[4 * 36 * Q] = delta[src];
+                    }
+#define UP(dst, vec) HIPCHK(hipMemcpy(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
+    HIPCHK(hipMemcpy(h->d_link_count, link_count, nl * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_tq_count, torque_count, nt * sizeof(int), hipMemcpyHostToDevice));
+    UP(h->d_link_center, lc); UP(h->d_link_indep, li); UP(h->d_link_keys, lk); UP(h->d_link_coeff, lco);
+    UP(h->d_tq_center, tc); UP(h->d_tq_indep, ti); UP(h->d_tq_keys, tk); UP(h->d_tq_coeff, tco);
+    if (!pl.empty()) UP(h->d_planes, pl);
+#undef UP
+    h->h_torque_radius.assign(torque_radius, torque_radius + (size_t)B * n * T);
+    h->h_link_gens.assign((size_t)B * T * J * 18, 0.0);
+    h->ready = true;
+    return ARMOUR_OK;
+}
+
+#define NEED_READY(h)                                                                        \
+    if (!(h)) { armour_set_error("null handle"); return ARMOUR_EINVAL; }                     \
+    if (!(h)->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
+
+extern "C" int armour_get_sizes(const ArmourPlanner* h, int32_t* B, int32_t* n, int32_t* m) {
+    NEED_READY(h);
+    if (B) *B = h->B;
+    if (n) *n = h->n;
+    if (m) *m = h->m;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_bounds(ArmourPlanner* h, double* x_l, double* x_u, double* g_l, double* g_u) {
+    NEED_READY(h);
+    const int T = h->T, n = h->n;
+    if (x_l) for (int i = 0; i < n; i++) x_l[i] = -1.0;
+    if (x_u) for (int i = 0; i < n; i++) x_u[i] = 1.0;
+    if (!g_l || !g_u) return ARMOUR_OK;
+    for (int b = 0; b < h->B; b++) {
+        double* gl = g_l + (size_t)b * h->m;
+        double* gu = g_u + (size_t)b * h->m;
+        const double* tr = &h->h_torque_radius[(size_t)b * n * T];
+        for (int t = 0; t < T; t++)
+            for (int j = 0; j < n; j++) {
+                gl[t * n + j] = -h->robot.torque_limits[j] + tr[j * T + t];
+                gu[t * n + j] = h->robot.torque_limits[j] - tr[j * T + t];
+            }
+        size_t off = (size_t)n * T;
+        for (size_t i = off; i < off + (size_t)h->Q; i++) { gl[i] = -1e19; gu[i] = 0; }
+        off += h->Q;
+        for (int rep = 0; rep < 2; rep++, off += n)
+            for (int i = 0; i < n; i++) { gl[off + i] = h->robot.state_limits_lb[i] + h->ub.qe; gu[off + i] = h->robot.state_limits_ub[i] - h->ub.qe; }
+        for (int rep = 0; rep < 2; rep++, off += n)
+            for (int i = 0; i < n; i++) { gl[off + i] = -h->robot.speed_limits[i] + h->ub.qde; gu[off + i] = h->robot.speed_limits[i] - h->ub.qde; }
+    }
+    return ARMOUR_OK;
+}
+
+static double wrap_to_pi(double a) {
+    const double pi = 3.14159265358979323846;
+    while (a < -pi) a += 2 * pi;
+    while (a > pi) a -= 2 * pi;
+    return a;
+}
+
+extern "C" int armour_eval_f(ArmourPlanner* h, const double* k, double* f) {
+    NEED_READY(h);
+    const int n = h->n;
+    const double D = h->params.duration;
+    for (int b = 0; b < h->B; b++) {
+        double obj = 0;
+        for (int pass = 0; pass < 2; pass++)  // continuous joints first, as RT/NLPclass.cu:225-231 sums them
+            for (int i = 0; i < n; i++) {
+                if ((h->robot.continuous[i] != 0) != (pass == 0)) continue;
+                const size_t ix = (size_t)b * n + i;
+                const double qp = bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], h->params.t_plan);
+                const double e = h->robot.continuous[i] ? wrap_to_pi(h->h_qdes[ix] - qp) : (h->h_qdes[ix] - qp);
+                obj += e * e;
+            }
+        f[b] = obj * h->params.cost_scale;
+    }
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_eval_grad_f(ArmourPlanner* h, const double* k, double* grad_f) {
+    NEED_READY(h);
+    const int n = h->n;
+    const double D = h->params.duration, tp = h->params.t_plan;
+    for (int b = 0; b < h->B; b++)
+        for (int i = 0; i < n; i++) {
+            const size_t ix = (size_t)b * n + i;
+            const double qp = bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], tp);
+            const double dk = (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[i];
+            const double e = h->robot.continuous[i] ? wrap_to_pi(qp - h->h_qdes[ix]) : (qp - h->h_qdes[ix]);
+            grad_f[ix] = 2 * e * dk * h->params.cost_scale;
+        }
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, double* d_jac, void* stream) {
+    NEED_READY(h);
+    if (!d_k) { armour_set_error("d_k is null"); return ARMOUR_EINVAL; }
+    const P2Tables tb = armour_make_tables(h);
+    return armour_p2_launch(tb, d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
+}
+
+extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac) {
+    NEED_READY(h);
+    if (!k) { armour_set_error("k is null"); return ARMOUR_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bn = (size_t)h->B * h->n, bm = (size_t)h->B * h->m;
+    HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const P2Tables tb = armour_make_tables(h);
+    int rc = armour_p2_launch(tb, h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
+    if (rc != ARMOUR_OK) return rc;
+    if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible) {
+    NEED_READY(h);
+    const int T = h->T, n = h->n;
+    const double tt = h->params.torque_violation_threshold, ct = h->params.collision_violation_threshold;
+    for (int b = 0; b < h->B; b++) {
+        const double* gb = g + (size_t)b * h->m;
+        const double* tr = &h->h_torque_radius[(size_t)b * n * T];
+        bool ok = true;
+        for (int t = 0; t < T && ok; t++)
+            for (int j = 0; j < n; j++) {
+                const double v = gb[t * n + j];
+                if (v < -h->robot.torque_limits[j] + tr[j * T + t] - tt || v > h->robot.torque_limits[j] - tr[j * T + t] + tt) { ok = false; break; }
+            }
+        size_t off = (size_t)n * T;
+        for (size_t i = 0; i < (size_t)h->Q && ok; i++)
+            if (gb[off + i] > ct) ok = false;
+        off += h->Q;
+        for (int rep = 0; rep < 2 && ok; rep++, off += n)
+            for (int i = 0; i < n; i++)
+                if (gb[off + i] < h->robot.state_limits_lb[i] + h->ub.qe || gb[off + i] > h->robot.state_limits_ub[i] - h->ub.qe) { ok = false; break; }
+        for (int rep = 0; rep < 2 && ok; rep++, off += n)
+            for (int i = 0; i < n; i++)
+                if (gb[off + i] < -h->robot.speed_limits[i] + h->ub.qde || gb[off + i] > h->robot.speed_limits[i] - h->ub.qde) { ok = false; break; }
+        feasible[b] = ok ? 1 : 0;
+    }
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_torque_radius(ArmourPlanner* h, double* out) {
+    NEED_READY(h);
+    memcpy(out, h->h_torque_radius.data(), h->h_torque_radius.size() * sizeof(double));
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_link_generators(ArmourPlanner* h, double* out) {
+    NEED_READY(h);
+    memcpy(out, h->h_link_gens.data(), h->h_link_gens.size() * sizeof(double));
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_link_centers(ArmourPlanner* h, const double* k, double* centers) {
+    NEED_READY(h);
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bn = (size_t)h->B * h->n, cnt = (size_t)h->B * h->T * h->J * 3;
+    HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const P2Tables tb = armour_make_tables(h);
+    // d_jac is at least B*m*n >= B*T*J*3 doubles; reuse it as scratch
+    int rc = armour_p2_slice_links_launch(tb, h->d_k, h->d_jac, h->stream);
+    if (rc != ARMOUR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(centers, h->d_jac, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_pz(ArmourPlanner* h, int32_t b, int32_t which, int32_t i, int32_t t, double* center,
+                             uint64_t* keys, double* coeffs, int32_t capacity) {
+    NEED_READY(h);
+    if (b < 0 || b >= h->B || t < 0 || t >= h->T || which < 0 || which > 1 || i < 0 || i >= (which == 0 ? h->J : h->n)) {
+        armour_set_error("armour_get_pz: index out of range");
+        return ARMOUR_EINVAL;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int sz = which == 0 ? 3 : 1;
+    const int cap = which == 0 ? h->lim.link_monomials : h->lim.torque_monomials;
+    const size_t idx = which == 0 ? ((size_t)b * h->J + i) * h->T + t : ((size_t)b * h->n + i) * h->T + t;
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, (which == 0 ? h->d_link_count : h->d_tq_count) + idx, sizeof(int), hipMemcpyDeviceToHost));
+    if (center) {
+        // [0..sz) centre, [sz..2sz) independent radius
+        HIPCHK(hipMemcpy(center, (which == 0 ? h->d_link_center : h->d_tq_center) + idx * sz, sz * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(center + sz, (which == 0 ? h->d_link_indep : h->d_tq_indep) + idx * sz, sz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (keys && coeffs) {
+        if (capacity < cnt) { armour_set_error("armour_get_pz: capacity %d < count %d", capacity, cnt); return ARMOUR_EINVAL; }
+        std::vector<uint32_t> k32(cnt > 0 ? cnt : 1);
+        if (cnt > 0) {
+            HIPCHK(hipMemcpy(k32.data(), (which == 0 ? h->d_link_keys : h->d_tq_keys) + idx * cap, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(coeffs, (which == 0 ? h->d_link_coeff : h->d_tq_coeff) + idx * cap * sz, (size_t)cnt * sz * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        for (int mo = 0; mo < cnt; mo++) keys[mo] = k32[mo];
+    }
+    return cnt;
+}
+
+extern "C" int armour_get_table_sizes(ArmourPlanner* h, int64_t* out4) {
+    NEED_READY(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t nl = (size_t)h->B * h->J * h->T, nt = (size_t)h->B * h->n * h->T;
+    std::vector<int> lc(nl), tc(nt);
+    HIPCHK(hipMemcpy(lc.data(), h->d_link_count, nl * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tc.data(), h->d_tq_count, nt * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t sl = 0, st = 0, ml = 0, mt = 0;
+    for (int v : lc) { sl += v; if (v > ml) ml = v; }
+    for (int v : tc) { st += v; if (v > mt) mt = v; }
+    out4[0] = sl; out4[1] = st; out4[2] = ml; out4[3] = mt;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, double* delta) {
+    NEED_READY(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int B = h->B, T = h->T, J = h->J, O = h->O;
+    const size_t Q = (size_t)h->Q;
+    std::vector<double> pl((size_t)B * 5 * 36 * Q);
+    if (pl.empty()) return ARMOUR_OK;
+    HIPCHK(hipMemcpy(pl.data(), h->d_planes, pl.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++)
+        for (int t = 0; t < T; t++)
+            for (int l = 0; l < J; l++)
+                for (int o = 0; o < O; o++)
+                    for (int p = 0; p < 36; p++) {
+                        const size_t dst = ((((size_t)b * T + t) * J + l) * O + o) * 36 + p;
+                        const size_t q = ((size_t)l * T + t) * O + o;
+                        const double* base = &pl[(size_t)b * 5 * 36 * Q + (size_t)p * Q + q];
+                        if (A) { A[dst * 3 + 0] = base[0]; A[dst * 3 + 1] = base[1 * 36 * Q]; A[dst * 3 + 2] = base[2 * 36 * Q]; }
+                        if (d) d[dst] = base[3 * 36 * Q];
+                        if (delta) delta[dst] = base[4 * 36 * Q];
+                    }
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_build_ms(ArmourPlanner* h, double* ms) {
+    NEED_READY(h);
+    *ms = h->build_ms;
+    return ARMOUR_OK;
+}

@@ -1,0 +1,99 @@
+// Shared definitions of libarmour_hip.so: the planner handle, the device tables the kernels read,
+// and error plumbing.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/armour_hip.h"
+
+#define ARMOUR_NPLANES 36
+#define ARMOUR_PLANE_COMPONENTS 5  // Ax, Ay, Az, d, delta
+
+void armour_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            armour_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return ARMOUR_EDEVICE;                                                                       \
+        }                                                                                                \
+    } while (0)
+
+// Reach-set tables of B problems as the P2 kernel reads them (all device pointers).
+//
+// Final link / torque PZs hold only k-dependent monomials (key < 2^(2n)); keys are stored as u32.
+//   link  index: (b*J + l)*T + t     torque index: (b*n + j)*T + t
+// Half-space table: planes[b][c][p][q], c in {Ax,Ay,Az,d,delta}, p in [0,36), q = (l*T + t)*O + o --
+// the obstacle/time/link index is the fastest axis so that a wave reads 64 consecutive q with one
+// coalesced 512-B request per component and plane, and so that q is also the output row order of the
+// collision block (RT/NLPclass.cu:117-164: g[nT + (l*T+t)*O + o]).
+struct P2Tables {
+    int B, T, J, n, O, Q, m;
+    int capL, capT;
+    const int* link_count;
+    const double* link_center;  // [..][3]
+    const double* link_indep;   // [..][3]
+    const uint32_t* link_keys;  // [..][capL]
+    const double* link_coeff;   // [..][capL][3]
+    const int* tq_count;
+    const double* tq_center;    // [..]
+    const double* tq_indep;     // [..]
+    const uint32_t* tq_keys;    // [..][capT]
+    const double* tq_coeff;     // [..][capT]
+    const double* planes;       // [B][5][36][Q]
+    const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0
+    double k_range[ARMOUR_MAX_FACTORS];
+    double duration;
+};
+
+struct ArmourPlanner {
+    ArmourRobot robot;
+    ArmourParams params;
+    ArmourLimits lim;
+    ArmourUltimateBound ub;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int T = 0, J = 0, n = 0;
+    // current problem set
+    int B = 0, O = 0, Q = 0, m = 0;
+    bool ready = false;
+    std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
+    std::vector<double> h_torque_radius;              // [B][n][T]
+    std::vector<double> h_link_gens;                  // [B][T][J][18]
+    // device tables (sized for allocB x allocO)
+    int allocB = 0, allocO = 0;
+    int* d_link_count = nullptr;
+    double* d_link_center = nullptr;
+    double* d_link_indep = nullptr;
+    uint32_t* d_link_keys = nullptr;
+    double* d_link_coeff = nullptr;
+    int* d_tq_count = nullptr;
+    double* d_tq_center = nullptr;
+    double* d_tq_indep = nullptr;
+    uint32_t* d_tq_keys = nullptr;
+    double* d_tq_coeff = nullptr;
+    double* d_planes = nullptr;
+    double* d_bez = nullptr;
+    // staging for the host-pointer API
+    double* d_k = nullptr;
+    double* d_g = nullptr;
+    double* d_jac = nullptr;
+    double build_ms = 0;
+    // P1 workspace (p1_reach.hip)
+    void* p1 = nullptr;
+};
+
+// p2_eval.hip
+int armour_p2_launch(const P2Tables& tb, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
+int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
+P2Tables armour_make_tables(const ArmourPlanner* h);
+
+// p1_reach.hip
+int armour_p1_build(ArmourPlanner* h, const double* obstacles);
+void armour_p1_free(ArmourPlanner* h);

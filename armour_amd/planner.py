@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's planner interface for the hot path.
+
+`ArmourNLP` keeps the method names and argument meaning of the reference's `armtd_NLP : Ipopt::TNLP`
+(RT/NLPclass.h; RT/ = kinova_src/kinova_simulator_interfaces/kinova_planner_realtime/) so that the parity
+tests read like calls into the reference:
+
+    nlp = ArmourNLP(T=100)                      # Obstacles ctor + KinematicsDynamics ctor
+    nlp.set_parameters(q0, qd0, qdd0, q_des, obstacles)   # P1: armour_main.cu:86-216 + set_parameters
+    n, m, nnz = nlp.get_nlp_info()
+    g = nlp.eval_g(x); J = nlp.eval_jac_g(x)    # NLPclass.cu:272-396 (one fused device launch each)
+
+and `eval_constraint(k)` returns the MATLAB callback shape `[h, heq, grad_h, grad_heq]` of
+KSI/uarmtd_planner.m:776-796.  All arithmetic happens in libarmour_hip.so on the MI355X; this file only
+marshals numpy arrays across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArmourLimits, ArmourParams, ArmourRobot, check
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def kinova_robot():
+    r = ArmourRobot()
+    _lib.load().armour_robot_kinova_gen3_no_gripper(C.byref(r))
+    return r
+
+
+def default_params(T=128):
+    p = ArmourParams()
+    _lib.load().armour_params_default(C.byref(p), T)
+    return p
+
+
+class ArmourNLP:
+    """B independent planning problems on one MI355X (B = 1 is the reference's use)."""
+
+    def __init__(self, robot=None, params=None, T=128, device=0, limits=None):
+        self.L = _lib.load()
+        self.robot = robot if robot is not None else kinova_robot()
+        self.params = params if params is not None else default_params(T)
+        self.T = self.params.num_time_steps
+        self.J = self.robot.num_joints
+        self.n = self.robot.num_factors
+        self.limits = limits if limits is not None else ArmourLimits()
+        h = C.c_void_p()
+        check(self.L.armour_create(C.byref(self.robot), C.byref(self.params), C.byref(self.limits), device, C.byref(h)))
+        self.h = h
+        self.B = 0
+        self.O = 0
+        self.m = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.armour_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ P1
+    def set_parameters(self, q0, qd0, qdd0, q_des, obstacles):
+        """Build the reach sets (RT/armour_main.cu:86-216).  Single problem: q0.. are [n], obstacles [O,12];
+        batch: q0.. are [B,n], obstacles [B,O,12]."""
+        q0, qd0, qdd0, q_des = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in (q0, qd0, qdd0, q_des)]
+        obs = np.asarray(obstacles, dtype=np.float64)
+        B = q0.shape[0]
+        obs = np.ascontiguousarray(obs.reshape(B, -1, 12)) if obs.size else np.zeros((B, 0, 12))
+        O = obs.shape[1]
+        for a in (q0, qd0, qdd0, q_des):
+            if a.shape != (B, self.n):
+                raise ValueError(f"expected shape ({B},{self.n}), got {a.shape}")
+        self._obs = obs
+        check(self.L.armour_set_problems(self.h, B, O, _dp(q0), _dp(qd0), _dp(qdd0), _dp(q_des), _dp(obs) if O else None))
+        self._after_set(B, O)
+        return self
+
+    def _after_set(self, B, O):
+        b, n, m = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.armour_get_sizes(self.h, C.byref(b), C.byref(n), C.byref(m)))
+        self.B, self.O, self.m = b.value, O, m.value
+
+    def debug_load_tables(self, q0, qd0, qdd0, q_des, tables):
+        """Test hook: load reach-set tables built elsewhere (see include/armour_hip.h)."""
+        q0, qd0, qdd0, q_des = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in (q0, qd0, qdd0, q_des)]
+        t = {k: np.ascontiguousarray(v) for k, v in tables.items()}
+        B, O = q0.shape[0], t["A"].shape[3]
+        u64 = C.POINTER(C.c_uint64)
+        i32 = C.POINTER(C.c_int32)
+        check(self.L.armour_debug_load_tables(
+            self.h, B, O, _dp(q0), _dp(qd0), _dp(qdd0), _dp(q_des),
+            t["link_count"].ctypes.data_as(i32), _dp(t["link_center"]), t["link_keys"].ctypes.data_as(u64), _dp(t["link_coeffs"]), t["link_keys"].shape[-1],
+            t["torque_count"].ctypes.data_as(i32), _dp(t["torque_center"]), t["torque_keys"].ctypes.data_as(u64), _dp(t["torque_coeffs"]), t["torque_keys"].shape[-1],
+            _dp(t["A"]), _dp(t["d"]), _dp(t["delta"]), _dp(t["torque_radius"])))
+        self._after_set(B, O)
+        return self
+
+    # ------------------------------------------------------------------ TNLP surface
+    def get_nlp_info(self):
+        """(n, m, nnz_jac_g) -- RT/NLPclass.cu:62-82 (dense Jacobian)."""
+        return self.n, self.m, self.m * self.n
+
+    def get_bounds_info(self):
+        """x_l, x_u [n]; g_l, g_u [B,m] -- RT/NLPclass.cu:87-165."""
+        xl, xu = np.zeros(self.n), np.zeros(self.n)
+        gl, gu = np.zeros((self.B, self.m)), np.zeros((self.B, self.m))
+        check(self.L.armour_get_bounds(self.h, _dp(xl), _dp(xu), _dp(gl), _dp(gu)))
+        return xl, xu, gl, gu
+
+    def get_starting_point(self):
+        """x = 0 -- RT/NLPclass.cu:170-202."""
+        return np.zeros((self.B, self.n))
+
+    def _k(self, x):
+        k = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.B, self.n))
+        return k
+
+    def eval_f(self, x):
+        f = np.zeros(self.B)
+        check(self.L.armour_eval_f(self.h, _dp(self._k(x)), _dp(f)))
+        return f
+
+    def eval_grad_f(self, x):
+        gf = np.zeros((self.B, self.n))
+        check(self.L.armour_eval_grad_f(self.h, _dp(self._k(x)), _dp(gf)))
+        return gf
+
+    def eval_g(self, x):
+        g = np.zeros((self.B, self.m))
+        check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), _dp(g), None))
+        return g
+
+    def eval_jac_g(self, x):
+        """values[B, m, n] (row-major, row = constraint) -- RT/NLPclass.cu:330-396."""
+        jac = np.zeros((self.B, self.m, self.n))
+        check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), None, _dp(jac)))
+        return jac
+
+    def eval_g_jac(self, x):
+        g = np.zeros((self.B, self.m))
+        jac = np.zeros((self.B, self.m, self.n))
+        check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), _dp(g), _dp(jac)))
+        return g, jac
+
+    def eval_g_jac_device(self, d_k, d_g, d_jac, stream=0):
+        """Asynchronous, device pointers (ints), e.g. torch tensors' .data_ptr(); stream = hipStream_t as int."""
+        check(self.L.armour_eval_g_jac_device(self.h, d_k, d_g, d_jac, stream))
+
+    def finalize_solution(self, g):
+        """feasible[B] from g[B,m] with the reference's slack thresholds -- RT/NLPclass.cu:422-538."""
+        g = np.ascontiguousarray(np.asarray(g, dtype=np.float64).reshape(self.B, self.m))
+        feas = np.zeros(self.B, dtype=np.int32)
+        check(self.L.armour_check_feasible(self.h, _dp(g), feas.ctypes.data_as(C.POINTER(C.c_int32))))
+        return feas.astype(bool)
+
+    # ------------------------------------------------------------------ MATLAB callback shape
+    def eval_constraint(self, k, b=0):
+        """[h, heq, grad_h, grad_heq] with h <= 0 feasible and grad_h sized n_k x n_constraints
+        (KSI/uarmtd_planner.m:776-796).  Two-sided rows g_l <= g <= g_u are split into g - g_u <= 0 and
+        g_l - g <= 0; collision rows (g_l = -1e19) contribute only g <= 0."""
+        x = np.zeros((self.B, self.n))
+        x[b] = k
+        g, jac = self.eval_g_jac(x)
+        _, _, gl, gu = self.get_bounds_info()
+        g, jac, gl, gu = g[b], jac[b], gl[b], gu[b]
+        two_sided = gl > -1e18
+        h = np.concatenate([g - gu, (gl - g)[two_sided]])
+        grad_h = np.concatenate([jac, -jac[two_sided]], axis=0).T
+        return h, np.zeros(0), grad_h, np.zeros((self.n, 0))
+
+    # ------------------------------------------------------------------ diagnostics / tables
+    def torque_radius(self):
+        out = np.zeros((self.B, self.n, self.T))
+        check(self.L.armour_get_torque_radius(self.h, _dp(out)))
+        return out
+
+    def link_generators(self):
+        out = np.zeros((self.B, self.T, self.J, 3, 6))
+        check(self.L.armour_get_link_generators(self.h, _dp(out)))
+        return out
+
+    def link_centers(self, x):
+        out = np.zeros((self.B, self.T, self.J, 3))
+        check(self.L.armour_get_link_centers(self.h, _dp(self._k(x)), _dp(out)))
+        return out
+
+    def pz(self, which, i, t, b=0):
+        """which: 'link' | 'torque' -> (center, indep, keys[M], coeffs[M, sz])."""
+        w = {"link": 0, "torque": 1}[which]
+        sz = 3 if w == 0 else 1
+        cap = 4096
+        cen = np.zeros(2 * sz)
+        keys = np.zeros(cap, dtype=np.uint64)
+        co = np.zeros((cap, sz))
+        cnt = check(self.L.armour_get_pz(self.h, b, w, i, t, _dp(cen), keys.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(co), cap))
+        return cen[:sz], cen[sz:], keys[:cnt], co[:cnt]
+
+    def table_sizes(self):
+        out = (C.c_int64 * 4)()
+        check(self.L.armour_get_table_sizes(self.h, out))
+        return dict(sum_link=out[0], sum_torque=out[1], max_link=out[2], max_torque=out[3])
+
+    def hyperplanes(self):
+        A = np.zeros((self.B, self.T, self.J, self.O, 36, 3))
+        d = np.zeros((self.B, self.T, self.J, self.O, 36))
+        delta = np.zeros((self.B, self.T, self.J, self.O, 36))
+        check(self.L.armour_get_hyperplanes(self.h, _dp(A), _dp(d), _dp(delta)))
+        return A, d, delta
+
+    @property
+    def build_ms(self):
+        v = C.c_double()
+        check(self.L.armour_get_build_ms(self.h, C.byref(v)))
+        return v.value
+
+    def algorithmic_bytes(self):
+        """B_alg of one fused eval over all B problems:
+        1440*T*J*O per problem + 32*SumM_link + 16*SumM_torque + 8*m*(1+n) per problem."""
+        ts = self.table_sizes()
+        return (1440 * self.T * self.J * self.O * self.B + 32 * ts["sum_link"] + 16 * ts["sum_torque"]
+                + 8 * self.m * (1 + self.n) * self.B)

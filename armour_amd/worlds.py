@@ -1,0 +1,56 @@
+"""Deterministic synthetic planning problems.
+
+Random obstacle worlds and initial states for the Kinova Gen3 7-DOF arm, in the input format of the
+reference planner: q0, qd0, qdd0, q_des (7 doubles each) and obstacles as column-major Z=[c g1 g2 g3]
+(12 doubles, KSI/uarmtd_planner.m:158-185; boxes are [c, diag(s/2)] as in
+SIM/worlds/obstacles/box_obstacle_zonotope.m:21-26).
+"""
+import numpy as np
+
+# RT/KinovaWithoutGripperInfo.h:76-79
+STATE_LB = np.array([-1000.0, -2.41, -1000.0, -2.66, -1000.0, -2.23, -1000.0])
+STATE_UB = -STATE_LB
+SPEED = np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
+
+
+def random_problem(seed, num_obstacles):
+    """One world: dict(q0, qd0, qdd0, q_des [7], obstacles [O,12])."""
+    rng = np.random.default_rng(seed)
+    cont = np.abs(STATE_LB) >= 1000.0
+    q0 = np.where(cont, rng.uniform(-np.pi, np.pi, 7), rng.uniform(STATE_LB + 0.3, STATE_UB - 0.3))
+    qd0 = rng.uniform(-0.5, 0.5, 7) * SPEED
+    qdd0 = rng.uniform(-1.0, 1.0, 7)
+    q_des = q0 + rng.uniform(-np.pi / 8, np.pi / 8, 7)
+    c = rng.uniform([-0.8, -0.8, 0.05], [0.8, 0.8, 1.2], (num_obstacles, 3))
+    s = rng.uniform(0.01, 0.5, (num_obstacles, 3))
+    obs = np.zeros((num_obstacles, 12))
+    obs[:, 0:3] = c
+    obs[:, 3] = s[:, 0] / 2
+    obs[:, 7] = s[:, 1] / 2
+    obs[:, 11] = s[:, 2] / 2
+    return dict(q0=q0, qd0=qd0, qdd0=qdd0, q_des=q_des, obstacles=obs)
+
+
+def random_batch(first_seed, batch, num_obstacles):
+    """`batch` worlds with seeds first_seed..first_seed+batch-1, stacked: q0 [B,7] ... obstacles [B,O,12]."""
+    ps = [random_problem(first_seed + b, num_obstacles) for b in range(batch)]
+    return {k: np.stack([p[k] for p in ps]) for k in ps[0]}
+
+
+def random_k(seed, count, n=7):
+    """Evaluation points k ~ U[-1,1]^n."""
+    return np.random.default_rng(10_000 + seed).uniform(-1.0, 1.0, (count, n))
+
+
+def load_scene_csv(path):
+    """Saved random scene of the reference (kinova_src/saved_worlds/random/*.csv, load_saved_world.m:4-13):
+    row 1 start, row 2 goal, row 3 NaN, rows 4.. = [cx cy cz sx sy sz NaN] boxes."""
+    rows = np.genfromtxt(path, delimiter=",")
+    q_start, q_goal = rows[0, :7], rows[1, :7]
+    boxes = rows[3:, :6]
+    obs = np.zeros((boxes.shape[0], 12))
+    obs[:, 0:3] = boxes[:, 0:3]
+    obs[:, 3] = boxes[:, 3] / 2
+    obs[:, 7] = boxes[:, 4] / 2
+    obs[:, 11] = boxes[:, 5] / 2
+    return q_start, q_goal, obs

@@ -1,0 +1,135 @@
+/*
+ * armour_hip.h -- C ABI of libarmour_hip.so, the MI355X (gfx950) implementation of ARMOUR's
+ * per-planning-iteration reachable-set + constraint pipeline.
+ *
+ * This is the drop-in boundary for the hot path of roahmlab/armour (RT/ =
+ * kinova_src/kinova_simulator_interfaces/kinova_planner_realtime/).  The reference has no FFI for
+ * this path: it spawns `armour_main` and exchanges text files (KSI/uarmtd_planner.m:158-219); its
+ * only in-process native precedent is the MEX gateway of the robust controller
+ * (MEXC/kinova_controller.cpp:19-84).  The entry points below are what a MEX / ctypes / cgo binding
+ * of the planner would bind; each cites the reference interface it replaces.  INTEGRATION.md shows
+ * the MEX stub and the file-protocol CLI built on them.
+ *
+ * Conventions: plain pointers and sizes; fp64; all host buffers caller-owned; the handle owns all
+ * device memory; every function returns 0 on success or a negative ARMOUR_E* code and never
+ * throws; armour_last_error() returns a thread-local message.  A handle is bound to one device and
+ * one HIP stream; calls on different handles may run concurrently from different host threads.
+ *
+ * Batch semantics: a handle holds B independent planning problems (B >= 1) that share the robot,
+ * the parameters and the obstacle count O.  B = 1 is the reference's use.  Arrays are
+ * problem-major: q0[B][n], obstacles[B][O][12], k[B][n], g[B][m], jac[B][m][n].
+ *
+ * Constraint rows (RT/NLPclass.cu:46-49,117-164,304-320), m = n*T + J*T*O + 4n:
+ *   [0, nT)                torque centre      g[t*n + j]
+ *   [nT, nT + J*T*O)       collision          g[nT + (l*T + t)*O + o] = -max_p(...)  (feasible <= 0)
+ *   then n rows min position, n rows max position, n rows min velocity, n rows max velocity.
+ * Jacobian: dense, row-major values[row*n + col] exactly as IPOPT's `values` (RT/NLPclass.cu:348-357).
+ */
+#ifndef ARMOUR_HIP_H
+#define ARMOUR_HIP_H
+
+#include <stdint.h>
+#include "armour_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARMOUR_OK 0
+#define ARMOUR_EINVAL (-1)    /* bad argument */
+#define ARMOUR_EDEVICE (-2)   /* HIP runtime error (message has the hipError string) */
+#define ARMOUR_ECAPACITY (-3) /* a polynomial zonotope outgrew its device table; raise the capacity in ArmourLimits */
+#define ARMOUR_ESTATE (-4)    /* call order violated (e.g. eval before set_problems) */
+
+typedef struct ArmourPlanner ArmourPlanner;
+
+/* Device-table capacities (monomials). Zero fields take the defaults in parentheses. */
+typedef struct ArmourLimits {
+    int32_t max_batch;          /* problems per handle (1) */
+    int32_t max_obstacles;      /* O upper bound (40, RT/Parameters.h:26 MAX_OBSTACLE_NUM; any value allowed) */
+    int32_t link_monomials;     /* k-only monomials kept per link PZ (32) */
+    int32_t torque_monomials;   /* k-only monomials kept per torque PZ (128) */
+    int32_t work_monomials;     /* monomials of an intermediate PZ during FK/RNEA (1024) */
+    int32_t raw_terms;          /* unsimplified terms of one PZ product (4096) */
+} ArmourLimits;
+
+/* ---- robot / parameter presets (RT/KinovaWithoutGripperInfo.h, RT/Parameters.h) ---- */
+void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot);
+void armour_params_default(ArmourParams* params, int32_t num_time_steps);
+
+/* ---- lifetime ---- */
+/* Replaces the process start-up of RT/armour_main.cu:11-86 (Obstacles ctor cudaMalloc x10, constant uploads).
+ * `device` is a HIP device ordinal.  limits may be NULL. */
+int armour_create(const ArmourRobot* robot, const ArmourParams* params, const ArmourLimits* limits,
+                  int32_t device, ArmourPlanner** out);
+void armour_destroy(ArmourPlanner* h);
+const char* armour_last_error(void);
+/* 1 if a HIP device is visible to this process, else 0 (never fails). */
+int armour_device_available(void);
+
+/* ---- P1: reach-set build, once per planning iteration ---- */
+/* Replaces RT/armour_main.cu:36-216 (parse armour.in, JRS, FK, RNEA x2, torque radius, half-space tables)
+ * for B problems at once.  obstacles: [B][O][12], each = column-major Z=[c g1 g2 g3]
+ * (KSI/uarmtd_planner.m:178; RT/CollisionChecking.cu:156-160).  Synchronous. */
+int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
+                        const double* qdd0, const double* q_des, const double* obstacles);
+
+/* sizes after set_problems: n = NUM_FACTORS, m = constraint_number (RT/NLPclass.cu:46-49, get_nlp_info :62-82) */
+int armour_get_sizes(const ArmourPlanner* h, int32_t* B, int32_t* n, int32_t* m);
+
+/* ---- NLP callback surface (RT/NLPclass.h armtd_NLP : Ipopt::TNLP) ---- */
+/* get_bounds_info, RT/NLPclass.cu:87-165.  x_l,x_u: [n] (shared by all problems); g_l,g_u: [B][m]. */
+int armour_get_bounds(ArmourPlanner* h, double* x_l, double* x_u, double* g_l, double* g_u);
+/* eval_f / eval_grad_f, RT/NLPclass.cu:207-267 (host arithmetic, 7 numbers).  k: [B][n]; f: [B]; grad_f: [B][n]. */
+int armour_eval_f(ArmourPlanner* h, const double* k, double* f);
+int armour_eval_grad_f(ArmourPlanner* h, const double* k, double* grad_f);
+/* eval_g + eval_jac_g fused, RT/NLPclass.cu:272-396.  Host pointers; g and/or jac may be NULL.
+ * Synchronous: H2D of k, one kernel launch, D2H of the requested outputs. */
+int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac);
+/* Same, device-resident: d_k [B][n], d_g [B][m], d_jac [B][m][n] are device pointers on the handle's device
+ * (d_g / d_jac may be NULL).  Enqueued on `stream` (a hipStream_t; NULL = the handle's own stream) and NOT
+ * synchronised -- this is the entry the throughput benchmark and a device-side solver use. */
+int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, double* d_jac, void* stream);
+/* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
+int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
+
+/* ---- diagnostics the reference writes to its 4 extra files (RT/armour_main.cu:329-372) ---- */
+/* torque_radius [B][n][T]   (armour_control_input_radius.out holds its transpose) */
+int armour_get_torque_radius(ArmourPlanner* h, double* torque_radius);
+/* link_independent_generators [B][T][J][3][6] row-major (armour_joint_position_radius.out) */
+int armour_get_link_generators(ArmourPlanner* h, double* gens);
+/* sliced link centres at k: [B][T][J][3] (armour_joint_position_center.out; RT/NLPclass.cu:311-314) */
+int armour_get_link_centers(ArmourPlanner* h, const double* k, double* centers);
+
+/* ---- table introspection (parity tests, roofline accounting: SURVEY 8d Sigma M_link / Sigma M_torque) ---- */
+/* which: 0 = links(l,t) 3x1, 1 = u_nom(j,t) 1x1.  Returns the monomial count (>= 0) or a negative error.
+ * center (may be NULL) receives [2][sz]: the centre, then the independent (interval) radius.
+ * keys/coeffs may be NULL; otherwise keys[count], coeffs[count][sz]. */
+int armour_get_pz(ArmourPlanner* h, int32_t b, int32_t which, int32_t i, int32_t t, double* center,
+                  uint64_t* keys, double* coeffs, int32_t capacity);
+/* sum over all problems of monomial counts: out4 = {sum_link, sum_torque, max_link, max_torque} */
+int armour_get_table_sizes(ArmourPlanner* h, int64_t* out4);
+/* half-space tables in the reference's layout (RT/CollisionChecking.cu:215-227):
+ * A [B][T][J][O][36][3], d and delta [B][T][J][O][36]; any pointer may be NULL. */
+int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, double* delta);
+/* ms spent in the last armour_set_problems (device time, hipEvent) */
+int armour_get_build_ms(ArmourPlanner* h, double* ms);
+/* name of the P2 kernel as it appears in rocprofv3 kernel traces */
+const char* armour_p2_kernel_name(void);
+
+/* ---- test hook: load externally built reach-set tables instead of running P1 ---- */
+/* Used only by tests to isolate P2 (tables built by the CPU oracle); never called by the product path.
+ * link_* : [B][J][T] counts, centers [..][2][3] (centre, independent radius), keys [..][cap_l], coeffs [..][cap_l][3]
+ * torque_*: [B][n][T] counts, centers [..][2], keys [..][cap_t], coeffs [..][cap_t]
+ * A,d,delta in the reference layout (see armour_get_hyperplanes); torque_radius [B][n][T]. */
+int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
+                             const double* qdd0, const double* q_des, const int32_t* link_count,
+                             const double* link_center, const uint64_t* link_keys, const double* link_coeffs,
+                             int32_t cap_l, const int32_t* torque_count, const double* torque_center,
+                             const uint64_t* torque_keys, const double* torque_coeffs, int32_t cap_t,
+                             const double* A, const double* d, const double* delta, const double* torque_radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,31 @@
+"""Ad-hoc GPU smoke used during development: P2 parity on oracle tables + rough timing."""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np
+from helpers import oracle_tables, PZ_TESTS_K
+from oracle.cpu_oracle import Oracle
+from armour_amd.planner import ArmourNLP
+from armour_amd.worlds import random_problem, random_k
+import torch
+T, O = 100, 20
+p = random_problem(0, O)
+o = Oracle(T=T).set_problem(p['q0'], p['qd0'], p['qdd0'], p['q_des'], p['obstacles'])
+print("oracle build ms", o.build_ms, o.table_sizes())
+nlp = ArmourNLP(T=T).debug_load_tables(p['q0'], p['qd0'], p['qdd0'], p['q_des'], oracle_tables([o]))
+g, jac = nlp.eval_g_jac(PZ_TESTS_K[None])
+gr, jr = o.eval_g_jac(PZ_TESTS_K)
+print("max |dg|", np.abs(g[0]-gr).max(), "max |djac|", np.abs(jac[0]-jr).max())
+# timing: device-resident
+dev = torch.device('cuda:0')
+ks = torch.tensor(random_k(0, 64), device=dev)
+dg = torch.empty(nlp.m, device=dev, dtype=torch.float64); dj = torch.empty(nlp.m*7, device=dev, dtype=torch.float64)
+s = torch.cuda.current_stream().cuda_stream
+for i in range(10): nlp.eval_g_jac_device(ks[i % 64].data_ptr(), dg.data_ptr(), dj.data_ptr(), s)
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+N = 2000
+t0 = time.time(); e0.record()
+for i in range(N): nlp.eval_g_jac_device(ks[i % 64].data_ptr(), dg.data_ptr(), dj.data_ptr(), s)
+e1.record(); torch.cuda.synchronize(); t1 = time.time()
+print("us/eval (events)", e0.elapsed_time(e1)*1e3/N, "wall", (t1-t0)*1e6/N, "B_alg", nlp.algorithmic_bytes())
+print("GB/s alg", nlp.algorithmic_bytes()/(e0.elapsed_time(e1)*1e-3/N)/1e9)

@@ -1,0 +1,44 @@
+"""Shared test helpers: build device-table inputs from the CPU oracle, PZ_tests slice point, etc."""
+import numpy as np
+
+# slice point of the reference's only numeric sanity program (RT/PZ_tests.cu:198)
+PZ_TESTS_K = np.array([0.5, 0.6, 0.7, 0.0, -0.5, -0.6, -0.7])
+# initial state of RT/debug_script.m:29-31
+DEBUG_STATE = dict(q0=np.array([-1.0, -1, -1, -1, 1, 1, 1]), qd0=np.array([1.0, 1, 1, -1, -1, -1, -1]), qdd0=np.full(7, 2.0))
+
+
+def oracle_tables(oracles, cap_l=32, cap_t=128):
+    """Pack the reach-set tables of a list of solved oracle problems in the layout armour_debug_load_tables takes."""
+    B = len(oracles)
+    o0 = oracles[0]
+    T, J, n, O = o0.T, o0.J, o0.n, o0.O
+    t = dict(
+        link_count=np.zeros((B, J, T), np.int32), link_center=np.zeros((B, J, T, 2, 3)),
+        link_keys=np.zeros((B, J, T, cap_l), np.uint64), link_coeffs=np.zeros((B, J, T, cap_l, 3)),
+        torque_count=np.zeros((B, n, T), np.int32), torque_center=np.zeros((B, n, T, 2)),
+        torque_keys=np.zeros((B, n, T, cap_t), np.uint64), torque_coeffs=np.zeros((B, n, T, cap_t)),
+        A=np.zeros((B, T, J, O, 36, 3)), d=np.zeros((B, T, J, O, 36)), delta=np.zeros((B, T, J, O, 36)),
+        torque_radius=np.zeros((B, n, T)))
+    for b, o in enumerate(oracles):
+        for l in range(J):
+            for tt in range(T):
+                c, ind, keys, co = o.pz("link", l, tt)
+                M = len(keys)
+                t["link_count"][b, l, tt] = M
+                t["link_center"][b, l, tt, 0] = c
+                t["link_center"][b, l, tt, 1] = ind
+                t["link_keys"][b, l, tt, :M] = keys
+                t["link_coeffs"][b, l, tt, :M] = co
+        for j in range(n):
+            for tt in range(T):
+                c, ind, keys, co = o.pz("torque", j, tt)
+                M = len(keys)
+                t["torque_count"][b, j, tt] = M
+                t["torque_center"][b, j, tt] = [c[0], ind[0]]
+                t["torque_keys"][b, j, tt, :M] = keys
+                t["torque_coeffs"][b, j, tt, :M] = co[:, 0]
+        if O > 0:
+            A, d, delta = o.hyperplanes()
+            t["A"][b], t["d"][b], t["delta"][b] = A, d, delta
+        t["torque_radius"][b] = o.torque_radius()
+    return t
