@@ -1,9 +1,852 @@
-// P1: reach-set build on the device (placeholder until the JRS / FK / RNEA kernels land).
+// P1: reach-set build on the device (gfx950), once per planning iteration and problem.
+//
+// Replaces RT/armour_main.cu:96-216 -- the OpenMP loop over time steps running
+// BezierCurve::makePolyZono (RT/Trajectory.cu:63-254), KinematicsDynamics::fk / rnea x2
+// (RT/Dynamics.cu:69-181), the disturbance / robust-input radius (RT/armour_main.cu:133-141,172-205) -- and
+// Obstacles::initializeHyperPlane (RT/CollisionChecking.cu:69-88,136-228).
+//
+// Mapping: one 64-lane wavefront per (problem, time interval) runs the whole dependent chain
+// JRS -> FK -> link reduce -> RNEA(nominal) -> RNEA(interval) -> disturbance -> torque radius on the
+// wave-level PZ arithmetic of pz_wave.h; the grid is persistent (a fixed number of waves, each with a
+// private global-memory arena of PZ slots, stride over the (b,t) work list).  A second, trivially parallel
+// kernel builds the half-space table one thread per (problem, link, time, obstacle) row.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 #include "common.h"
+#include "pz_wave.h"
+
+using namespace pzw;
+
+namespace {
+
+constexpr int kNV = 32, kNS = 24, kNM = 2;   // work slots per wave: 3x1, 1x1, 3x3
+constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
+constexpr int kMaxSlots = 192;
+
+struct P1Cfg {
+    int B, T, J, n, O;
+    int capW, capRaw, capL, capT;
+    size_t arena_bytes;
+    unsigned char* arena;
+    ArmourRobot rb;
+    ArmourParams pr;
+    ArmourUltimateBound ub;
+    const double* bez;  // [B][3][n]: q0, Tqd0, TTqdd0
+    // outputs
+    int* link_count; double* link_center; double* link_indep; uint32_t* link_keys; double* link_coeff;
+    int* tq_count; double* tq_center; double* tq_indep; uint32_t* tq_keys; double* tq_coeff;
+    double* link_gens;      // [B][T][J][18]
+    double* torque_radius;  // [B][n][T]
+    unsigned* status;
+};
+
+__host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+__host__ __device__ inline size_t slot_bytes(int cap, int sz) { return align64((size_t)cap * 8) + align64((size_t)cap * sz * 8) + align64((size_t)sz * 8) * 2; }
+
+// arena = work V | work S | work M | small M | small V | small S
+struct Layout {
+    int nJM, nJV, nJS;
+    size_t offV, offS, offM, offJM, offJV, offJS, total;
+    int idV, idS, idM, idJM, idJV, idJS;
+};
+__host__ __device__ inline Layout make_layout(int J, int n, int capW) {
+    Layout L;
+    L.nJM = (J + 1) + J + 3 + 2 * J;  // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia nominal/uncertain
+    L.nJV = (J + 1) + J;              // trans P_i, link boxes
+    L.nJS = 3 * n + 2 * J + 4;        // qd, qda, qdda; mass nominal/uncertain; raw temps
+    L.offV = 0;
+    L.offS = L.offV + (size_t)kNV * slot_bytes(capW, 3);
+    L.offM = L.offS + (size_t)kNS * slot_bytes(capW, 1);
+    L.offJM = L.offM + (size_t)kNM * slot_bytes(capW, 9);
+    L.offJV = L.offJM + (size_t)L.nJM * slot_bytes(kCapSmall, 9);
+    L.offJS = L.offJV + (size_t)L.nJV * slot_bytes(kCapSmall, 3);
+    L.total = align64(L.offJS + (size_t)L.nJS * slot_bytes(kCapSmall, 1));
+    L.idV = 0; L.idS = L.idV + kNV; L.idM = L.idS + kNS; L.idJM = L.idM + kNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
+    return L;
+}
+
+__device__ inline PZ mk_slot(unsigned char* base, size_t off, int index, int cap, int sz, int id0) {
+    unsigned char* p = base + off + (size_t)index * slot_bytes(cap, sz);
+    PZ z;
+    z.keys = (uint64_t*)p;
+    z.coef = (double*)(p + align64((size_t)cap * 8));
+    z.cen = (double*)(p + align64((size_t)cap * 8) + align64((size_t)cap * sz * 8));
+    z.ind = z.cen + align64((size_t)sz * 8) / 8;
+    z.sz = sz; z.cap = cap; z.id = id0 + index;
+    return z;
+}
+
+// ------------------------------------------------------------------ device interval helpers (RT/Headers.h:26-36)
+struct Itv { double lo, hi; };
+__device__ inline double dn(double x) { return nextafter(x, -INFINITY); }
+__device__ inline double up(double x) { return nextafter(x, INFINITY); }
+__device__ inline Itv iv(double l, double h) { return Itv{l, h}; }
+__device__ inline Itv iout(double l, double h) { return Itv{dn(l), up(h)}; }
+__device__ inline Itv ineg(Itv a) { return Itv{-a.hi, -a.lo}; }
+__device__ inline Itv iadd(Itv a, Itv b) { return iout(a.lo + b.lo, a.hi + b.hi); }
+__device__ inline Itv iadds(double a, Itv b) { return iout(a + b.lo, a + b.hi); }
+__device__ inline Itv isub(Itv a, Itv b) { return iout(a.lo - b.hi, a.hi - b.lo); }
+__device__ inline Itv isubs(Itv a, double b) { return iout(a.lo - b, a.hi - b); }
+__device__ inline Itv imul(Itv a, Itv b) {
+    const double p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    return iout(fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3)));
+}
+__device__ inline Itv imuls(double a, Itv b) { return imul(Itv{a, a}, b); }
+__device__ inline Itv isqr(Itv a) {
+    if (a.lo >= 0) return iout(a.lo * a.lo, a.hi * a.hi);
+    if (a.hi <= 0) return iout(a.hi * a.hi, a.lo * a.lo);
+    const double m = fmax(-a.lo, a.hi);
+    return Itv{0.0, up(m * m)};
+}
+__device__ inline Itv icos(Itv a) {
+    const double pi = 3.14159265358979323846;
+    if (a.hi - a.lo >= 2 * pi) return Itv{-1, 1};
+    double lo = fmin(cos(a.lo), cos(a.hi)), hi = fmax(cos(a.lo), cos(a.hi));
+    const double kmax = ceil((a.lo - 1e-15) / (2 * pi));
+    if (kmax * 2 * pi <= a.hi + 1e-15) hi = 1.0;
+    const double kmin = ceil((a.lo - pi - 1e-15) / (2 * pi));
+    if (pi + kmin * 2 * pi <= a.hi + 1e-15) lo = -1.0;
+    return Itv{fmax(-1.0, dn(lo)), fmin(1.0, up(hi))};
+}
+__device__ inline Itv isin(Itv a) {
+    const double pi = 3.14159265358979323846;
+    if (a.hi - a.lo >= 2 * pi) return Itv{-1, 1};
+    double lo = fmin(sin(a.lo), sin(a.hi)), hi = fmax(sin(a.lo), sin(a.hi));
+    const double kmax = ceil((a.lo - pi / 2 - 1e-15) / (2 * pi));
+    if (pi / 2 + kmax * 2 * pi <= a.hi + 1e-15) hi = 1.0;
+    const double kmin = ceil((a.lo + pi / 2 - 1e-15) / (2 * pi));
+    if (-pi / 2 + kmin * 2 * pi <= a.hi + 1e-15) lo = -1.0;
+    return Itv{fmax(-1.0, dn(lo)), fmin(1.0, up(hi))};
+}
+__device__ inline double icen(Itv a) { return (a.lo + a.hi) * 0.5; }
+__device__ inline double irad(Itv a) { return (a.hi - a.lo) * 0.5; }
+
+__device__ inline double p2(double x) { return x * x; }
+__device__ inline double p3(double x) { return x * x * x; }
+__device__ inline double p4(double x) { const double y = x * x; return y * y; }
+__device__ inline double p5(double x) { const double y = x * x; return y * y * x; }
+
+// k-independent parts of the Bezier curve (RT/Trajectory.cu:812-822)
+__device__ inline double q_indep(double q0, double a, double b, double s) {
+    return q0 + a * s - 6 * a * p3(s) + 8 * a * p4(s) - 3 * a * p5(s) + (b * p2(s)) * 0.5 - (3 * b * p3(s)) * 0.5 + (3 * b * p4(s)) * 0.5 - (b * p5(s)) * 0.5;
+}
+__device__ inline double qd_indep(double a, double b, double s, double D) {
+    return (p2(s - 1) * (2 * a + 4 * a * s + 2 * b * s - 30 * a * p2(s) - 5 * b * p2(s))) * 0.5 / D;
+}
+__device__ inline double qdd_indep(double a, double b, double s, double D) {
+    return -(s - 1.0) * (b - (36 * a + 8 * b) * s + (60 * a + 10 * b) * p2(s)) / (D * D);
+}
+__device__ inline void bound_ext(double& lb, double& ub_, double s_lb, double s_ub, double x1, double m1, double x2, double m2) {
+    if (lb > ub_) { const double t = lb; lb = ub_; ub_ = t; }
+    if (s_lb < x1 && x1 < s_ub) { lb = fmin(lb, m1); ub_ = fmax(ub_, m1); }
+    if (s_lb < x2 && x2 < s_ub) { lb = fmin(lb, m2); ub_ = fmax(ub_, m2); }
+}
+
+// scalars of one joint's JRS on [s/T, (s+1)/T] (RT/Trajectory.cu:63-243)
+struct JrsScalars {
+    double cos_c, cos_k, cos_e, sin_c, sin_k, sin_e;          // centre, k coefficient, error coefficient
+    double qd_c, qd_k, qd_e, qda_e, qdd_c, qdd_k, qdd_e;
+};
+
+__device__ inline JrsScalars jrs_scalars(const P1Cfg& cf, double q0, double a, double b, int i, int s_ind) {
+    JrsScalars o;
+    const double ds = 1.0 / cf.T, D = cf.pr.duration, kr = cf.pr.k_range[i];
+    const double s_lb = s_ind * ds, s_ub = (s_ind + 1) * ds;
+    // k-independent extrema (RT/Trajectory.cu:36-58)
+    const double dq = sqrt(64 * p2(a) + 14 * a * b + p2(b)), dv = sqrt(6 * (54 * p2(a) + 14 * a * b + p2(b))), da = sqrt(2 * (152 * p2(a) + 42 * a * b + 3 * p2(b)));
+    const double qx1 = (2 * a + b + dq) / (5 * (6 * a + b)), qx2 = (2 * a + b - dq) / (5 * (6 * a + b));
+    const double vx1 = (18 * a + 4 * b + dv) / (10 * (6 * a + b)), vx2 = (18 * a + 4 * b - dv) / (10 * (6 * a + b));
+    const double ax1 = (32 * a + 6 * b + da) / (10 * (6 * a + b)), ax2 = (32 * a + 6 * b - da) / (10 * (6 * a + b));
+    // Part 1: q_des
+    double kd_lb = p3(s_lb) * (6 * p2(s_lb) - 15 * s_lb + 10), kd_ub = p3(s_ub) * (6 * p2(s_ub) - 15 * s_ub + 10);
+    double kd_c = (kd_ub + kd_lb) * 0.5, kd_r = (kd_ub - kd_lb) * 0.5 * kr;
+    double ki_lb = q_indep(q0, a, b, s_lb), ki_ub = q_indep(q0, a, b, s_ub);
+    bound_ext(ki_lb, ki_ub, s_lb, s_ub, qx1, q_indep(q0, a, b, qx1), qx2, q_indep(q0, a, b, qx2));
+    double ki_r = (ki_ub - ki_lb) * 0.5;
+    const double q_c = (ki_lb + ki_ub) * 0.5;
+    const Itv q_rad = iv(-kd_r - ki_r - cf.ub.qe, kd_r + ki_r + cf.ub.qe);
+    const Itv kint = imuls(kd_c, iv(-kr, kr));
+    {
+        Itv rad = isub(imul(ineg(q_rad), iv(sin(q_c), sin(q_c))), imul(imuls(0.5, icos(iadd(iadds(q_c, kint), q_rad))), isqr(iadd(q_rad, kint))));
+        o.cos_c = cos(q_c) + icen(rad);
+        rad = isubs(rad, icen(rad));
+        o.cos_k = -kd_c * kr * sin(q_c);
+        o.cos_e = irad(rad);
+    }
+    {
+        Itv rad = isub(imul(q_rad, iv(cos(q_c), cos(q_c))), imul(imuls(0.5, isin(iadd(iadds(q_c, kint), q_rad))), isqr(iadd(q_rad, kint))));
+        o.sin_c = sin(q_c) + icen(rad);
+        rad = isubs(rad, icen(rad));
+        o.sin_k = kd_c * kr * cos(q_c);
+        o.sin_e = irad(rad);
+    }
+    // Part 2: qd_des
+    kd_lb = (30 * p2(s_lb) * p2(s_lb - 1)) / D;
+    kd_ub = (30 * p2(s_ub) * p2(s_ub - 1)) / D;
+    if (kd_ub < kd_lb) { const double t = kd_lb; kd_lb = kd_ub; kd_ub = t; }
+    kd_c = (kd_ub + kd_lb) * 0.5 * kr;
+    kd_r = (kd_ub - kd_lb) * 0.5 * kr;
+    ki_lb = qd_indep(a, b, s_lb, D); ki_ub = qd_indep(a, b, s_ub, D);
+    bound_ext(ki_lb, ki_ub, s_lb, s_ub, vx1, qd_indep(a, b, vx1, D), vx2, qd_indep(a, b, vx2, D));
+    ki_r = (ki_ub - ki_lb) * 0.5;
+    o.qd_c = (ki_lb + ki_ub) * 0.5;
+    o.qd_k = kd_c;
+    o.qd_e = kd_r + ki_r + cf.ub.qde;
+    o.qda_e = kd_r + ki_r + cf.ub.qdae;
+    // Part 3: qdd_des
+    const double MAXIMA = 0.5 - sqrt(3.0) / 6, MINIMA = 0.5 + sqrt(3.0) / 6;
+#define ACC(s) ((60 * (s) * (2 * p2(s) - 3 * (s) + 1)) / D / D)
+    const double t_lb = ACC(s_lb), t_ub = ACC(s_ub);
+    if (s_ub <= MAXIMA) { kd_lb = t_lb; kd_ub = t_ub; }
+    else if (s_lb <= MAXIMA) { kd_lb = fmin(t_lb, t_ub); kd_ub = ACC(MAXIMA); }
+    else if (s_ub <= MINIMA) { kd_lb = t_ub; kd_ub = t_lb; }
+    else if (s_lb <= MINIMA) { kd_lb = ACC(MINIMA); kd_ub = fmax(t_lb, t_ub); }
+    else { kd_lb = t_lb; kd_ub = t_ub; }
+#undef ACC
+    kd_c = (kd_ub + kd_lb) * 0.5 * kr;
+    kd_r = (kd_ub - kd_lb) * 0.5 * kr;
+    ki_lb = qdd_indep(a, b, s_lb, D); ki_ub = qdd_indep(a, b, s_ub, D);
+    bound_ext(ki_lb, ki_ub, s_lb, s_ub, ax1, qdd_indep(a, b, ax1, D), ax2, qdd_indep(a, b, ax2, D));
+    ki_r = (ki_ub - ki_lb) * 0.5;
+    o.qdd_c = (ki_lb + ki_ub) * 0.5;
+    o.qdd_k = kd_c;
+    o.qdd_e = kd_r + ki_r + cf.ub.qddae;
+    return o;
+}
+
+__device__ inline void make_rotation(double* R, double c, double s, int axis, bool from_zero) {  // RT/PZsparse.cu:211-250
+    for (int i = 0; i < 9; i++) R[i] = 0.0;
+    if (!from_zero) R[0] = R[4] = R[8] = 1.0;
+    const double ns = -1.0 * s;
+    if (axis == 1) { R[4] = c; R[5] = ns; R[7] = s; R[8] = c; }
+    else if (axis == 2) { R[0] = c; R[2] = s; R[6] = ns; R[8] = c; }
+    else if (axis == 3) { R[0] = c; R[1] = ns; R[3] = s; R[4] = c; }
+}
+__device__ inline void rpy_matrix(double roll, double pitch, double yaw, double* c) {  // RT/PZsparse.cu:160-176
+    c[0] = cos(pitch) * cos(yaw);
+    c[1] = -cos(pitch) * sin(yaw);
+    c[2] = sin(pitch);
+    c[3] = cos(roll) * sin(yaw) + cos(yaw) * sin(pitch) * sin(roll);
+    c[4] = cos(roll) * cos(yaw) - sin(pitch) * sin(roll) * sin(yaw);
+    c[5] = -cos(pitch) * sin(roll);
+    c[6] = sin(roll) * sin(yaw) - cos(roll) * cos(yaw) * sin(pitch);
+    c[7] = cos(yaw) * sin(roll) + cos(roll) * sin(pitch) * sin(yaw);
+    c[8] = cos(pitch) * cos(roll);
+}
+
+// ------------------------------------------------------------------ per-wave state and slot pools
+struct Chain {
+    Wave w;
+    const P1Cfg* cf;
+    unsigned char* arena;
+    Layout L;
+    unsigned freeV, freeS;
+    int n, J;
+
+    __device__ PZ V(int i) const { return mk_slot(arena, L.offV, i, cf->capW, 3, L.idV); }
+    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS); }
+    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM); }
+    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM); }
+    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV); }
+    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS); }
+    // named small slots
+    __device__ PZ R(int i) const { return JM(i); }                       // 0..J
+    __device__ PZ Rt(int i) const { return JM(J + 1 + i); }              // 0..J-1
+    __device__ PZ rotRaw() const { return JM(2 * J + 1); }
+    __device__ PZ rotS() const { return JM(2 * J + 2); }
+    __device__ PZ rpy() const { return JM(2 * J + 3); }
+    __device__ PZ Inom(int i) const { return JM(2 * J + 4 + i); }
+    __device__ PZ Iunc(int i) const { return JM(3 * J + 4 + i); }
+    __device__ PZ Ptr(int i) const { return JV(i); }                     // trans, 0..J
+    __device__ PZ linkbox(int i) const { return JV(J + 1 + i); }
+    __device__ PZ qd(int i) const { return JS(i); }
+    __device__ PZ qda(int i) const { return JS(n + i); }
+    __device__ PZ qdda(int i) const { return JS(2 * n + i); }
+    __device__ PZ mnom(int i) const { return JS(3 * n + i); }
+    __device__ PZ munc(int i) const { return JS(3 * n + J + i); }
+    __device__ PZ rawS(int i) const { return JS(3 * n + 2 * J + i); }    // 0..3
+
+    __device__ PZ allocV() {
+        const int i = __ffs(freeV) - 1;
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(0); }
+        freeV &= ~(1u << i);
+        return V(i);
+    }
+    __device__ void freeVs(const PZ& p) { freeV |= 1u << (p.id - L.idV); }
+    __device__ PZ allocS() {
+        const int i = __ffs(freeS) - 1;
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return S(0); }
+        freeS &= ~(1u << i);
+        return S(i);
+    }
+    __device__ void freeSs(const PZ& p) { freeS |= 1u << (p.id - L.idS); }
+
+    // ---- composite operators (names as in RT/PZsparse.cu) ----
+    __device__ PZ add(const PZ& a, const PZ& b, double sb = 1.0) {  // operator+ / operator- on 3x1
+        PZ o = allocV();
+        Seg s[2] = {{view(w, a), 1.0, -1}, {view(w, b), sb, -1}};
+        lincomb<3, 2>(w, o, s);
+        return o;
+    }
+    __device__ PZ addOneDim(const PZ& p, const PZ& a, int r) {  // RT/PZsparse.cu:1068-1085 (fresh slot)
+        PZ o = allocV();
+        Seg s[2] = {{view(w, p), 1.0, -1}, {view(w, a), 1.0, r}};
+        lincomb<3, 2>(w, o, s);
+        return o;
+    }
+    __device__ PZ stack(const PZ& r0, const PZ& r1, const PZ& r2) {  // RT/PZsparse.cu:1087-1116
+        PZ o = allocV();
+        Seg s[3] = {{view(w, r0), 1.0, 0}, {view(w, r1), 1.0, 1}, {view(w, r2), 1.0, 2}};
+        lincomb<3, 3>(w, o, s);
+        return o;
+    }
+    __device__ PZ comb2(const View& a, double sa, const View& b, double sb) {  // 1x1: sa*a + sb*b
+        PZ o = allocS();
+        Seg s[2] = {{a, sa, -1}, {b, sb, -1}};
+        lincomb<1, 2>(w, o, s);
+        return o;
+    }
+    __device__ PZ crossPzMat(const PZ& a, const double* b) {  // RT/PZsparse.cu:1153-1167
+        PZ r0 = comb2(elem(w, a, 1), b[2], elem(w, a, 2), -b[1]);
+        PZ r1 = comb2(elem(w, a, 2), b[0], elem(w, a, 0), -b[2]);
+        PZ r2 = comb2(elem(w, a, 0), b[1], elem(w, a, 1), -b[0]);
+        PZ o = stack(r0, r1, r2);
+        freeSs(r0); freeSs(r1); freeSs(r2);
+        return o;
+    }
+    __device__ PZ crossMatPz(const double* a, const PZ& b) {  // RT/PZsparse.cu:1118-1132
+        PZ r0 = comb2(elem(w, b, 2), a[1], elem(w, b, 1), -a[2]);
+        PZ r1 = comb2(elem(w, b, 0), a[2], elem(w, b, 2), -a[0]);
+        PZ r2 = comb2(elem(w, b, 1), a[0], elem(w, b, 0), -a[1]);
+        PZ o = stack(r0, r1, r2);
+        freeSs(r0); freeSs(r1); freeSs(r2);
+        return o;
+    }
+    __device__ PZ mulSS(const View& a, const View& b) {
+        PZ o = allocS();
+        mul<1, 1, 1, 1>(w, o, a, b);
+        return o;
+    }
+    __device__ PZ crossComp(const PZ& a, int a1, int a2, const PZ& b, int b1, int b2) {  // a[a1]*b[b1] - a[a2]*b[b2]
+        PZ t1 = mulSS(elem(w, a, a1), elem(w, b, b1));
+        PZ t2 = mulSS(elem(w, a, a2), elem(w, b, b2));
+        PZ r = comb2(view(w, t1), 1.0, view(w, t2), -1.0);
+        freeSs(t1); freeSs(t2);
+        return r;
+    }
+    __device__ PZ crossPzPz(const PZ& a, const PZ& b) {  // RT/PZsparse.cu:1134-1151
+        PZ r0 = crossComp(a, 1, 2, b, 2, 1);
+        PZ r1 = crossComp(a, 2, 0, b, 0, 2);
+        PZ r2 = crossComp(a, 0, 1, b, 1, 0);
+        PZ o = stack(r0, r1, r2);
+        freeSs(r0); freeSs(r1); freeSs(r2);
+        return o;
+    }
+    __device__ PZ mulMV(const PZ& A, const PZ& v) {
+        PZ o = allocV();
+        mul<3, 3, 3, 1>(w, o, view(w, A), view(w, v));
+        return o;
+    }
+    __device__ PZ mulSV(const PZ& s, const PZ& v) {
+        PZ o = allocV();
+        mul<1, 1, 3, 1>(w, o, view(w, s), view(w, v));
+        return o;
+    }
+};
+
+// write a raw (unsimplified) small PZ from lane 0 and simplify it into `out` (the constructors that end with
+// simplify(): RT/PZsparse.cu:120-136,179-205)
+template <int SZ>
+__device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
+    if (c.w.lane == 0) {
+        for (int e = 0; e < SZ; e++) { raw.cen[e] = cen[e]; raw.ind[e] = 0.0; }
+        for (int i = 0; i < m; i++) {
+            raw.keys[i] = keys[i];
+            for (int e = 0; e < SZ; e++) raw.coef[i * SZ + e] = coefs[i * SZ + e];
+        }
+        c.w.cnt[raw.id] = m;
+    }
+    __syncthreads();
+    Seg s[1] = {{view(c.w, raw), 1.0, -1}};
+    lincomb<SZ, 1>(c.w, out, s);
+}
+
+// JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67)
+__device__ void build_jrs(Chain& c, int b, int t) {
+    const P1Cfg& cf = *c.cf;
+    const int n = c.n, J = c.J;
+    const double* bz = cf.bez + (size_t)b * 3 * n;
+    for (int i = 0; i < J; i++) {
+        double rp[9];
+        rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
+        if (i < n && cf.rb.axes[i] != 0) {
+            const JrsScalars js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t);
+            const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
+            // rotation about the joint axis from cos / sin polynomials, then R = R_rpy * Rz (:129-134)
+            double cen[9], co[4 * 9];
+            make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
+            make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
+            make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
+            make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
+            make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
+            const uint64_t keys[4] = {kk, kc, kk, ks};
+            build_simplified<9>(c, c.rotRaw(), c.rotS(), cen, 4, keys, co);
+            set_const(c.w, c.rpy(), rp, nullptr);
+            mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy()), view(c.w, c.rotS()));
+            // qd_des, qda_des, qdda_des (:176-243)
+            {
+                const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
+                const double co2[2] = {js.qd_k, js.qd_e};
+                build_simplified<1>(c, c.rawS(0), c.qd(i), &js.qd_c, 2, k2, co2);
+            }
+            {
+                const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
+                const double co2[2] = {js.qd_k, js.qda_e};
+                build_simplified<1>(c, c.rawS(0), c.qda(i), &js.qd_c, 2, k2, co2);
+            }
+            {
+                const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
+                const double co2[2] = {js.qdd_k, js.qdd_e};
+                build_simplified<1>(c, c.rawS(0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+            }
+        } else {
+            set_const(c.w, c.R(i), rp, nullptr);
+        }
+        transpose33(c.w, c.Rt(i), c.R(i));
+    }
+    {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
+        set_const(c.w, c.R(J), id, nullptr);
+    }
+    for (int i = 0; i <= J; i++) set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+    for (int i = 0; i < J; i++) {
+        double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
+        set_const(c.w, c.mnom(i), &cf.rb.mass[i], nullptr);
+        set_const(c.w, c.munc(i), &cf.rb.mass[i], &mi);
+        double ii[9];
+        for (int e = 0; e < 9; e++) ii[e] = cf.rb.inertia_uncertainty * fabs(cf.rb.inertia[9 * i + e]);
+        set_const(c.w, c.Inom(i), &cf.rb.inertia[9 * i], nullptr);
+        set_const(c.w, c.Iunc(i), &cf.rb.inertia[9 * i], ii);
+        // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
+        for (int j = 0; j < 3; j++) {
+            const uint64_t key = 1ull << ((j + 2) * n);
+            build_simplified<1>(c, c.rawS(0), c.rawS(1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+        }
+        Seg s[3] = {{view(c.w, c.rawS(1)), 1.0, 0}, {view(c.w, c.rawS(2)), 1.0, 1}, {view(c.w, c.rawS(3)), 1.0, 2}};
+        lincomb<3, 3>(c.w, c.linkbox(i), s);
+    }
+}
+
+// RT/PZsparse.cu:370-402 reduce_link_PZ + write of the final link table entry
+__device__ void emit_link(Chain& c, const PZ& p, int b, int l, int t) {
+    const P1Cfg& cf = *c.cf;
+    Wave& w = c.w;
+    const int n = c.n, cnt = w.cnt[p.id];
+    const uint64_t kmax = 1ull << (2 * n), lmax = 1ull << (5 * n), kmask = kmax - 1;
+    const size_t idx = ((size_t)b * c.J + l) * cf.T + t;
+    double* gens = cf.link_gens + (((size_t)b * cf.T + t) * c.J + l) * 18;
+    if (w.lane < 18) gens[w.lane] = 0.0;
+    __syncthreads();
+    double ra[3] = {0, 0, 0};
+    int nk = 0, ng = 0;
+    for (int base = 0; base < cnt; base += WAVE) {
+        const int m = base + w.lane;
+        bool isk = false, isg = false;
+        if (m < cnt) {
+            const uint64_t key = p.keys[m];
+            isk = key < kmax;
+            isg = !isk && key < lmax && (key & kmask) == 0;
+            if (isk) {
+                if (m < cf.capL) {
+                    cf.link_keys[idx * cf.capL + m] = (uint32_t)key;
+                    for (int e = 0; e < 3; e++) cf.link_coeff[(idx * cf.capL + m) * 3 + e] = p.coef[(size_t)m * 3 + e];
+                }
+            } else if (!isg) {
+                for (int e = 0; e < 3; e++) ra[e] += fabs(p.coef[(size_t)m * 3 + e]);
+            }
+        }
+        const unsigned long long mg = __ballot(isg);
+        if (isg) {
+            const int j = ng + __popcll(mg & ((1ull << w.lane) - 1ull));
+            if (j < 3) for (int r = 0; r < 3; r++) gens[r * 6 + j] = p.coef[(size_t)m * 3 + r];
+        }
+        ng += __popcll(mg);
+        nk += __popcll(__ballot(isk));
+    }
+    if (ng > 3) flag(w, ERR_LINK_GENS);
+    if (nk > cf.capL) { flag(w, ERR_TABLE_OVERFLOW); nk = cf.capL; }
+    for (int e = 0; e < 3; e++) ra[e] = p.ind[e] + wave_sum(ra[e]);
+    if (w.lane == 0) {
+        cf.link_count[idx] = nk;
+        for (int e = 0; e < 3; e++) {
+            cf.link_center[idx * 3 + e] = p.cen[e];
+            cf.link_indep[idx * 3 + e] = ra[e];
+            gens[e * 6 + 3 + e] = ra[e];
+        }
+    }
+    __syncthreads();
+}
+
+// RT/Dynamics.cu:69-81 + RT/armour_main.cu:121-124
+__device__ void run_fk(Chain& c, int b, int t) {
+    Wave& w = c.w;
+    PZ FK_R = c.M(0), FK_Rn = c.M(1);
+    {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        set_const(w, FK_R, id, nullptr);
+    }
+    PZ FK_T = c.allocV();
+    set_const(w, FK_T, nullptr, nullptr);
+    for (int i = 0; i < c.J; i++) {
+        PZ tp = c.mulMV(FK_R, c.Ptr(i));
+        PZ nt = c.add(FK_T, tp);
+        c.freeVs(tp); c.freeVs(FK_T);
+        FK_T = nt;
+        mul<3, 3, 3, 3>(w, FK_Rn, view(w, FK_R), view(w, c.R(i)));
+        { PZ s = FK_R; FK_R = FK_Rn; FK_Rn = s; }
+        PZ l1 = c.mulMV(FK_R, c.linkbox(i));
+        PZ lk = c.add(l1, FK_T);
+        emit_link(c, lk, b, i, t);
+        c.freeVs(l1); c.freeVs(lk);
+    }
+    c.freeVs(FK_T);
+}
+
+// RT/Dynamics.cu:83-181; u[i] receives freshly allocated scalar slots
+__device__ void run_rnea(Chain& c, bool uncertain, PZ* u) {
+    const P1Cfg& cf = *c.cf;
+    Wave& w = c.w;
+    const int J = c.J;
+    PZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV(), lacc = c.allocV();
+    set_const(w, wv, nullptr, nullptr);
+    set_const(w, wdot, nullptr, nullptr);
+    set_const(w, waux, nullptr, nullptr);
+    {
+        double g[3] = {0.0, 0.0, cf.rb.gravity};
+        set_const(w, lacc, g, nullptr);
+    }
+    PZ F[ARMOUR_MAX_JOINTS], N[ARMOUR_MAX_JOINTS];
+    for (int i = 0; i < J; i++) {
+        const double* tr = &cf.rb.trans[3 * i];
+        const double* cm = &cf.rb.com[3 * i];
+        const PZ Rt = c.Rt(i);
+        const int ax = abs(cf.rb.axes[i]) - 1;
+        {   // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+            PZ c1 = c.crossPzMat(wdot, tr);
+            PZ s1 = c.add(lacc, c1); c.freeVs(c1);
+            PZ c2 = c.crossPzMat(waux, tr);
+            PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+            PZ s2 = c.add(s1, c3); c.freeVs(s1); c.freeVs(c3);
+            PZ nl = c.mulMV(Rt, s2); c.freeVs(s2); c.freeVs(lacc);
+            lacc = nl;
+        }
+        {   // lines 13-15: rotate w, w_aux, wdot into the joint frame
+            PZ nw = c.mulMV(Rt, wv); c.freeVs(wv); wv = nw;
+            if (cf.rb.axes[i] != 0) { PZ t2 = c.addOneDim(wv, c.qd(i), ax); c.freeVs(wv); wv = t2; }
+            PZ na = c.mulMV(Rt, waux); c.freeVs(waux); waux = na;
+            PZ nd = c.mulMV(Rt, wdot); c.freeVs(wdot); wdot = nd;
+        }
+        if (cf.rb.axes[i] != 0) {
+            PZ zero = c.allocV();
+            set_const(w, zero, nullptr, nullptr);
+            PZ temp = c.addOneDim(zero, c.qd(i), ax); c.freeVs(zero);
+            PZ c4 = c.crossPzPz(waux, temp); c.freeVs(temp);
+            PZ nd = c.add(wdot, c4); c.freeVs(c4); c.freeVs(wdot); wdot = nd;
+            PZ nd2 = c.addOneDim(wdot, c.qdda(i), ax); c.freeVs(wdot); wdot = nd2;
+            PZ na = c.addOneDim(waux, c.qda(i), ax); c.freeVs(waux); waux = na;
+        }
+        {   // lines 23 & 27: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
+            PZ c1 = c.crossPzMat(wdot, cm);
+            PZ s1 = c.add(lacc, c1); c.freeVs(c1);
+            PZ c2 = c.crossPzMat(waux, cm);
+            PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+            PZ s2 = c.add(s1, c3); c.freeVs(s1); c.freeVs(c3);
+            F[i] = c.mulSV(uncertain ? c.munc(i) : c.mnom(i), s2); c.freeVs(s2);
+        }
+        {   // line 29: N = I * wdot + cross(w_aux, I * w)
+            const PZ I = uncertain ? c.Iunc(i) : c.Inom(i);
+            PZ t1 = c.mulMV(I, wdot);
+            PZ t2 = c.mulMV(I, wv);
+            PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+            N[i] = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
+        }
+    }
+    c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); c.freeVs(lacc);
+    PZ f = c.allocV(), nn = c.allocV();
+    set_const(w, f, nullptr, nullptr);
+    set_const(w, nn, nullptr, nullptr);
+    for (int i = J - 1; i >= 0; i--) {
+        const PZ Rn = c.R(i + 1);
+        // n = N + R*n + cross(com, F) + cross(trans_next, R*f);  f = R*f + F
+        PZ a1 = c.mulMV(Rn, nn);
+        PZ s1 = c.add(N[i], a1); c.freeVs(a1); c.freeVs(N[i]);
+        PZ c1 = c.crossMatPz(&cf.rb.com[3 * i], F[i]);
+        PZ s2 = c.add(s1, c1); c.freeVs(s1); c.freeVs(c1);
+        PZ a2 = c.mulMV(Rn, f);
+        PZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
+        PZ n2 = c.add(s2, c2); c.freeVs(s2); c.freeVs(c2); c.freeVs(nn);
+        nn = n2;
+        PZ f2 = c.add(a2, F[i]); c.freeVs(a2); c.freeVs(F[i]); c.freeVs(f);
+        f = f2;
+        if (cf.rb.axes[i] != 0) {
+            const int ax = abs(cf.rb.axes[i]) - 1;
+            PZ u1 = c.comb2(elem(w, nn, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i]);
+            PZ u2 = c.comb2(view(w, u1), 1.0, view(w, c.qd(i)), cf.rb.damping[i]);
+            c.freeSs(u1);
+            u[i] = u2;
+        }
+    }
+    c.freeVs(f); c.freeVs(nn);
+}
+
+// disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
+__device__ void finish_torque(Chain& c, PZ* u_nom, PZ* u_int, int b, int t) {
+    const P1Cfg& cf = *c.cf;
+    Wave& w = c.w;
+    const int n = c.n, T = cf.T;
+    const uint64_t kmax = 1ull << (2 * n);
+    Itv rho = {0.0, 0.0};
+    double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
+    for (int j = 0; j < n; j++) {
+        // toInterval of the disturbance (RT/PZsparse.cu:557-576)
+        PZ dist = c.comb2(view(w, u_int[j]), 1.0, view(w, u_nom[j]), -1.0);
+        const int dc = w.cnt[dist.id];
+        double rs = 0.0;
+        for (int m = w.lane; m < dc; m += WAVE) rs += fabs(dist.coef[m]);
+        const double rad = dist.ind[0] + wave_sum(rs);
+        const double lo = dist.cen[0] - rad, hi = dist.cen[0] + rad;
+        c.freeSs(dist);
+        rho = iadd(rho, imul(iv(lo, hi), iv(lo, hi)));
+        tr[j] = cf.rb.alpha * (cf.rb.M_max - cf.rb.M_min) * cf.ub.eps + 0.5 * fmax(fabs(lo), fabs(hi));
+        // reduce(u_nom) (RT/PZsparse.cu:352-368) straight into the final torque table
+        const PZ& p = u_nom[j];
+        const int cnt = w.cnt[p.id];
+        const size_t idx = ((size_t)b * n + j) * T + t;
+        double ra = 0.0;
+        int nk = 0;
+        for (int base = 0; base < cnt; base += WAVE) {
+            const int m = base + w.lane;
+            bool isk = false;
+            if (m < cnt) {
+                const uint64_t key = p.keys[m];
+                isk = key < kmax;
+                if (isk) {
+                    if (m < cf.capT) { cf.tq_keys[idx * cf.capT + m] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + m] = p.coef[m]; }
+                } else {
+                    ra += fabs(p.coef[m]);
+                }
+            }
+            nk += __popcll(__ballot(isk));
+        }
+        if (nk > cf.capT) { flag(w, ERR_TABLE_OVERFLOW); nk = cf.capT; }
+        const double ind = p.ind[0] + wave_sum(ra);
+        if (w.lane == 0) { cf.tq_count[idx] = nk; cf.tq_center[idx] = p.cen[0]; cf.tq_indep[idx] = ind; }
+        un_ind[j] = ind;
+    }
+    __syncthreads();
+    // sqrt of the interval sum: Boost clamps a negative lower bound to 0; only .upper() is used (:185-188)
+    const double rho_hi = up(sqrt(rho.hi));
+    for (int j = 0; j < n; j++) {
+        double v = tr[j];
+        v += 0.5 * rho_hi;
+        v += un_ind[j];
+        v += cf.rb.friction[j];
+        if (w.lane == 0) cf.torque_radius[((size_t)b * n + j) * T + t] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Chain c;
+    c.cf = &cf;
+    c.n = cf.n; c.J = cf.J;
+    c.L = make_layout(cf.J, cf.n, cf.capW);
+    c.arena = cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
+    c.w.skey = (uint64_t*)smem;
+    c.w.sidx = (uint16_t*)(smem + (size_t)cf.capRaw * 8);
+    c.w.cnt = (int*)(smem + (size_t)cf.capRaw * 10);
+    c.w.lstat = c.w.cnt + kMaxSlots;
+    c.w.cap_raw = cf.capRaw;
+    c.w.thr = cf.pr.simplify_threshold;
+    c.w.lane = threadIdx.x;
+    if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
+    const int total = cf.B * cf.T;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int b = item / cf.T, t = item - b * cf.T;
+        c.freeV = 0xffffffffu;
+        c.freeS = (1u << kNS) - 1u;
+        for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
+        __syncthreads();
+        build_jrs(c, b, t);
+        run_fk(c, b, t);
+        PZ u_nom[ARMOUR_MAX_FACTORS], u_int[ARMOUR_MAX_FACTORS];
+        run_rnea(c, false, u_nom);
+        run_rnea(c, true, u_int);
+        finish_torque(c, u_nom, u_int, b, t);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c.w.lstat[ST_ERR]) atomicOr(&cf.status[ST_ERR], (unsigned)c.w.lstat[ST_ERR]);
+        atomicMax(&cf.status[ST_MAX_RAW], (unsigned)c.w.lstat[ST_MAX_RAW]);
+        atomicMax(&cf.status[ST_MAX_OUT], (unsigned)c.w.lstat[ST_MAX_OUT]);
+    }
+}
+
+// RT/CollisionChecking.cu:136-228: one thread per (b, q = (l*T+t)*O + o) builds the row's 36 half-spaces
+__global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
+                                        const double* __restrict__ obstacles, double* __restrict__ planes) {
+    const int Q = J * T * O;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (q >= Q) return;
+    const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
+    const double* ob = obstacles + ((size_t)b * O + o) * 12;
+    const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+    double G[9][3], c[3];
+    for (int ax = 0; ax < 3; ax++) {
+        c[ax] = ob[ax];
+        for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
+        for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
+    }
+    double* out = planes + (size_t)b * 5 * 36 * Q + q;
+    const size_t cs = (size_t)36 * Q;
+    int p = 0;
+    for (int a_id = 0; a_id < 8; a_id++)
+        for (int b_id = a_id + 1; b_id < 9; b_id++, p++) {  // pair order of RT/CollisionChecking.cu:26-39
+            const double* ga = G[a_id];
+            const double* gb = G[b_id];
+            const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
+            const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
+            double C0 = 0, C1 = 0, C2 = 0;
+            if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
+            double dl = 0.0;
+            for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
+            const size_t po = (size_t)p * Q;
+            out[po] = C0; out[cs + po] = C1; out[2 * cs + po] = C2;
+            out[3 * cs + po] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+            out[4 * cs + po] = dl;
+        }
+}
+
+struct P1Work {
+    unsigned char* arena = nullptr;
+    size_t arena_total = 0;
+    int waves = 0;
+    unsigned* d_status = nullptr;
+    double* d_link_gens = nullptr; size_t gens_cap = 0;
+    double* d_torque_radius = nullptr; size_t tr_cap = 0;
+    double* d_obstacles = nullptr; size_t obs_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+}  // namespace
+
+void armour_p1_free(ArmourPlanner* h) {
+    P1Work* wk = (P1Work*)h->p1;
+    if (!wk) return;
+    if (wk->arena) (void)hipFree(wk->arena);
+    if (wk->d_status) (void)hipFree(wk->d_status);
+    if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
+    if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
+    if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
+    if (wk->ev0) (void)hipEventDestroy(wk->ev0);
+    if (wk->ev1) (void)hipEventDestroy(wk->ev1);
+    delete wk;
+    h->p1 = nullptr;
+}
+
+template <class Tp>
+static int grow(Tp** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return ARMOUR_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    HIPCHK(hipMalloc((void**)p, (need ? need : 1) * sizeof(Tp)));
+    *cap = need;
+    return ARMOUR_OK;
+}
 
 int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
-    (void)h; (void)obstacles;
-    armour_set_error("armour_set_problems: device reach-set build not available in this build");
-    return ARMOUR_ESTATE;
+    if (!h->p1) {
+        P1Work* nw = new P1Work();
+        h->p1 = nw;
+        HIPCHK(hipMalloc((void**)&nw->d_status, ST_WORDS * sizeof(unsigned)));
+        HIPCHK(hipEventCreate(&nw->ev0));
+        HIPCHK(hipEventCreate(&nw->ev1));
+    }
+    P1Work* wk = (P1Work*)h->p1;
+    const int B = h->B, T = h->T, J = h->J, n = h->n, O = h->O;
+    int rc;
+    if ((rc = grow(&wk->d_link_gens, &wk->gens_cap, (size_t)B * T * J * 18)) != ARMOUR_OK) return rc;
+    if ((rc = grow(&wk->d_torque_radius, &wk->tr_cap, (size_t)B * n * T)) != ARMOUR_OK) return rc;
+    if ((rc = grow(&wk->d_obstacles, &wk->obs_cap, (size_t)B * O * 12)) != ARMOUR_OK) return rc;
+    if (O > 0) HIPCHK(hipMemcpyAsync(wk->d_obstacles, obstacles, (size_t)B * O * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    int cap_raw = 64;
+    while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
+    const int max_lds = (int)prop.sharedMemPerBlock;  // 64 KiB by default; up to 160 KiB on gfx950 with the attribute below
+    for (;;) {
+        const size_t smem = (size_t)cap_raw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int);
+        if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap_raw); return ARMOUR_EINVAL; }
+        (void)max_lds;
+        HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const Layout L = make_layout(J, n, h->lim.work_monomials);
+        if (L.idJS + L.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
+        const int per_cu = std::max(1, std::min(8, (int)((size_t)160 * 1024 / smem)));
+        const int waves = std::min(B * T, prop.multiProcessorCount * per_cu);
+        if ((size_t)waves * L.total > wk->arena_total) {
+            if (wk->arena) (void)hipFree(wk->arena);
+            wk->arena = nullptr;
+            HIPCHK(hipMalloc((void**)&wk->arena, (size_t)waves * L.total));
+            wk->arena_total = (size_t)waves * L.total;
+        }
+        P1Cfg cf;
+        memset(&cf, 0, sizeof(cf));
+        cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
+        cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+        cf.arena_bytes = L.total; cf.arena = wk->arena;
+        cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
+        cf.bez = h->d_bez;
+        cf.link_count = h->d_link_count; cf.link_center = h->d_link_center; cf.link_indep = h->d_link_indep;
+        cf.link_keys = h->d_link_keys; cf.link_coeff = h->d_link_coeff;
+        cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
+        cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
+        cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
+        HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
+        HIPCHK(hipEventRecord(wk->ev0, h->stream));
+        hipLaunchKernelGGL(armour_p1_chain_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
+        HIPCHK(hipGetLastError());
+        if (O > 0) {
+            const int Q = J * T * O;
+            hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(wk->ev1, h->stream));
+        unsigned st[ST_WORDS];
+        HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
+            if (cap_raw < 8192) { cap_raw <<= 1; continue; }  // retry with a larger LDS sort buffer
+            armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
+            return ARMOUR_ECAPACITY;
+        }
+        if (st[ST_ERR]) {
+            armour_set_error("reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
+                             st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            return ARMOUR_ECAPACITY;
+        }
+        break;
+    }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
+    h->build_ms = ms;
+    h->h_torque_radius.resize((size_t)B * n * T);
+    h->h_link_gens.resize((size_t)B * T * J * 18);
+    HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, h->h_torque_radius.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, h->h_link_gens.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return ARMOUR_OK;
 }
-void armour_p1_free(ArmourPlanner* h) { (void)h; }
