@@ -318,6 +318,20 @@ extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, dou
     return armour_p2_launch(tb, d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
 }
 
+extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
+                                              void* stream) {
+    NEED_READY(h);
+    if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+    const P2Tables tb = armour_make_tables(h);
+    const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t stride = (size_t)h->B * h->n;
+    for (int s = 0; s < steps; s++) {
+        int rc = armour_p2_launch(tb, d_k + (size_t)s * stride, d_g, d_jac, st);
+        if (rc != ARMOUR_OK) return rc;
+    }
+    return ARMOUR_OK;
+}
+
 extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac) {
     NEED_READY(h);
     if (!k) { armour_set_error("k is null"); return ARMOUR_EINVAL; }

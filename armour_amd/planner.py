@@ -154,6 +154,10 @@ class ArmourNLP:
         """Asynchronous, device pointers (ints), e.g. torch tensors' .data_ptr(); stream = hipStream_t as int."""
         check(self.L.armour_eval_g_jac_device(self.h, d_k, d_g, d_jac, stream))
 
+    def eval_g_jac_device_steps(self, d_k, steps, d_g, d_jac, stream=0):
+        """`steps` back-to-back fused evaluations (d_k holds [steps][B][n]); asynchronous."""
+        check(self.L.armour_eval_g_jac_device_steps(self.h, d_k, steps, d_g, d_jac, stream))
+
     def finalize_solution(self, g):
         """feasible[B] from g[B,m] with the reference's slack thresholds -- RT/NLPclass.cu:422-538."""
         g = np.ascontiguousarray(np.asarray(g, dtype=np.float64).reshape(self.B, self.m))

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of ARMOUR's constraint callback on MI355X: planning iters/s (fused eval_g + eval_jac_g).
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--obstacles O] [--time-steps T]
+
+One "step" = one pass of the hot path (RT/NLPclass.cu:272-396: eval_g + eval_jac_g at a fresh k) over this
+rank's batch of planning problems; one kernel launch per step, inputs (reach-set tables from
+armour_set_problems, the k points) resident in HBM before the timed region.  The default workload is
+BASELINE.json configs[1]: Kinova Gen3 7-DOF, 20 obstacles, 100 time steps, a single planning problem per
+GPU.  Ranks (one per GPU, launched by torch.distributed.run) hold independent random worlds: the path
+shards with no collective, so scaling is "weak" and `value` = problems*steps over all ranks / max-rank time.
+
+The JSON line also carries
+  roofline     HBM roofline of the P2 kernel: algorithmic bytes per launch / average launch
+               duration measured with HIP events on the launch stream over the timed region;
+  cpu_baseline the CPU oracle (oracle/, a port of the reference's host path) timed on this box's cores on a
+               bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "planning iters/s (eval_g+jac) Kinova 7-DOF, 100 timesteps × 20 obstacles"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(T, O, seed, budget_s=12.0):
+    """Oracle (kind 'port') on the host cores: P2 evals/s on the same world, bounded to ~budget_s seconds."""
+    from oracle.cpu_oracle import Oracle, max_threads
+    from armour_amd.worlds import random_k, random_problem
+    p = random_problem(seed, O)
+    o = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    ks = random_k(seed, 64)
+    o.time_eval(ks, 3)  # warm-up
+    t1 = o.time_eval(ks, 8) / 8
+    reps = int(max(20, min(20000, budget_s / max(t1, 1e-6))))
+    secs = o.time_eval(ks, reps)
+    return {
+        "value": reps / secs, "unit": "iters/s", "cores": max_threads(), "kind": "port",
+        "sample": f"{reps} fused eval_g+eval_jac_g of 1 world (seed {seed}, O={O}, T={T}) at 64 cycling k points, "
+                  f"OpenMP over time steps as RT/NLPclass.cu:304,376; reach-set build {o.build_ms:.0f} ms on the same cores",
+        "p1_build_ms": o.build_ms,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=1, help="planning problems per GPU (1 = BASELINE configs[1])")
+    ap.add_argument("--obstacles", type=int, default=20)
+    ap.add_argument("--time-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, O, T, K, W = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup
+    # independent worlds per rank: seeds rank*B .. rank*B + B - 1
+    probs = random_batch(rank * B, B, O)
+    nlp = ArmourNLP(T=T, device=local_rank)
+    t0 = time.time()
+    nlp.set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
+    p1_wall_ms = (time.time() - t0) * 1e3
+    p1_dev_ms = nlp.build_ms
+
+    n, m = nlp.n, nlp.m
+    ks = torch.tensor(random_k(rank, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
+    d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
+    d_jac = torch.empty((B, m, n), device=dev, dtype=torch.float64)
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed)
+    nlp.eval_g_jac_device_steps(ks.data_ptr(), W, d_g.data_ptr(), d_jac.data_ptr(), sh)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    e0.record(stream)
+    nlp.eval_g_jac_device_steps(ks[W:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr(), sh)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    barrier()
+    ev_ms = e0.elapsed_time(e1)
+
+    el = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed_max, ev_ms_max = float(el[0]), float(el[1])
+
+    # sanity: the last step's outputs are finite and the synchronous host entry agrees with the device entry
+    g_host, jac_host = nlp.eval_g_jac(ks[-1].cpu().numpy())
+    assert np.isfinite(g_host).all() and np.isfinite(jac_host).all()
+    assert np.array_equal(g_host, d_g.cpu().numpy()) and np.array_equal(jac_host, d_jac.cpu().numpy())
+
+    if rank == 0:
+        b_alg = nlp.algorithmic_bytes()          # bytes one launch must move (all B problems)
+        launch_us = ev_ms_max * 1e3 / K          # average launch duration over the timed region (HIP events)
+        achieved = b_alg / (launch_us * 1e-6) / 1e9
+        # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
+        k1 = ks[0].cpu().numpy()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            nlp.eval_g_jac(k1)
+        sync_us = (time.perf_counter() - t1) / 20 * 1e6
+        out = {
+            "metric": METRIC, "value": world * B * K / elapsed_max, "unit": "iters/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed_max * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Kinova Gen3 7-DOF, {O} obstacles, {T} time steps, {B} planning problem(s) per GPU "
+                                   f"(BASELINE configs[{1 if (B, O, T) == (1, 20, 100) else 2 if (B, O) == (128, 50) else 'custom'}]), "
+                                   "one fused eval_g+eval_jac_g launch per step at a fresh k",
+                       "robot": "kinova_gen3_7dof_no_gripper", "batch_per_gpu": B, "obstacles": O, "time_steps": T,
+                       "constraints_m": m, "parallelism": f"independent worlds x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": b_alg,
+                         "launch_us": launch_us},
+            "p1_set_problems_ms": {"device": p1_dev_ms, "wall": p1_wall_ms, "per_problem_device": p1_dev_ms / B},
+            "sync_host_call_us": sync_us,
+            "table_sizes": nlp.table_sizes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, O, seed=0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,11 @@ int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac)
  * (d_g / d_jac may be NULL).  Enqueued on `stream` (a hipStream_t; NULL = the handle's own stream) and NOT
  * synchronised -- this is the entry the throughput benchmark and a device-side solver use. */
 int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, double* d_jac, void* stream);
+/* `steps` consecutive fused evaluations enqueued back to back on `stream` without host synchronisation:
+ * step s reads d_k + s*B*n (d_k holds [steps][B][n]) and overwrites d_g / d_jac.  One kernel launch per step
+ * (the IPOPT iterate sequence of RT/armour_main.cu:273 with the solver's own arithmetic removed). */
+int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
+                                   void* stream);
 /* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
 int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 

@@ -664,6 +664,7 @@ void oracle_slice_links(void* h, const double* k, double* center /*[T][J][3]*/) 
     Ctx cx; cx.kl.n = P.n;
     for (int t = 0; t < P.T; t++) for (int l = 0; l < P.J; l++) slice_value(cx, P.links[l * P.T + t], k, &center[(t * P.J + l) * 3], nullptr);
 }
+double oracle_min_margin(void* h) { return ((Problem*)h)->st.min_margin; }
 int oracle_max_threads(void) { return omp_get_max_threads(); }
 
 }  // extern "C"

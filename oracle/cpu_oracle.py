@@ -80,6 +80,8 @@ def lib():
         L.oracle_slice_torque.argtypes = [C.c_void_p, dp, dp]
         L.oracle_slice_links.argtypes = [C.c_void_p, dp, dp]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_min_margin.argtypes = [C.c_void_p]
+        L.oracle_min_margin.restype = C.c_double
         _lib = L
     return _lib
 
@@ -201,6 +203,11 @@ class Oracle:
         lib().oracle_stats(self.h, out)
         keys = ["mul_calls", "mul_pairs", "simplify_calls", "simplify_terms", "max_raw_terms", "max_out_terms"]
         return dict(zip(keys, [int(x) for x in out]))
+
+    def min_margin(self):
+        """Smallest relative distance of any summed monomial norm to SIMPLIFY_THRESHOLD during the build: a value
+        below ~1e-9 means a last-bit difference could flip a monomial between 'kept' and 'pruned'."""
+        return lib().oracle_min_margin(self.h)
 
     def slice_torque(self, k):
         k = np.ascontiguousarray(k, dtype=np.float64)

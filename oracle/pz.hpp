@@ -54,7 +54,9 @@ struct Mono {
 struct Stats {
     uint64_t mul_calls = 0, mul_pairs = 0, simplify_calls = 0, simplify_terms = 0;
     uint64_t max_raw_terms = 0, max_out_terms = 0;
+    double min_margin = 1e300; /* min over all simplify() decisions of |norm - threshold| / threshold */
     void merge(const Stats& o) {
+        min_margin = std::min(min_margin, o.min_margin);
         mul_calls += o.mul_calls; mul_pairs += o.mul_pairs;
         simplify_calls += o.simplify_calls; simplify_terms += o.simplify_terms;
         max_raw_terms = std::max(max_raw_terms, o.max_raw_terms);
@@ -117,7 +119,9 @@ inline void simplify(Ctx& cx, PZ& p) {
             if (p.poly[j].key != key) break;
             for (int e = 0; e < n; e++) p.poly[i].c[e] += p.poly[j].c[e];
         }
-        if (frob(p.poly[i].c, n) <= cx.threshold) {
+        const double nrm = frob(p.poly[i].c, n);
+        if (nrm > 0) cx.st.min_margin = std::min(cx.st.min_margin, std::fabs(nrm - cx.threshold) / cx.threshold);
+        if (nrm <= cx.threshold) {
             for (int e = 0; e < n; e++) reduce_amount[e] += std::fabs(p.poly[i].c[e]);
         } else {
             out.push_back(p.poly[i]);

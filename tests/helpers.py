@@ -7,6 +7,22 @@ PZ_TESTS_K = np.array([0.5, 0.6, 0.7, 0.0, -0.5, -0.6, -0.7])
 DEBUG_STATE = dict(q0=np.array([-1.0, -1, -1, -1, 1, 1, 1]), qd0=np.array([1.0, 1, 1, -1, -1, -1, -1]), qdd0=np.full(7, 2.0))
 
 
+_FIVE = np.array([
+    [-0.28239, -0.33281, 0.88069, 0.069825, 0, 0, 0, 0.09508, 0, 0, 0, 0.016624],
+    [-0.19033, 0.035391, 1.3032, 0.11024, 0, 0, 0, 0.025188, 0, 0, 0, 0.014342],
+    [0.67593, -0.085841, 0.43572, 0.17408, 0, 0, 0, 0.07951, 0, 0, 0, 0.18012],
+    [0.75382, 0.51895, 0.4731, 0.030969, 0, 0, 0, 0.22312, 0, 0, 0, 0.22981],
+    [0.75382, 0.51895, 0.4731, 0.030969, 0, 0, 0, 0.22312, 0, 0, 0, 0.22981]])
+# the reference's commented sample input (RT/armour_main.cu:18-33): a known input without a known answer
+SAMPLE_PROBLEM = dict(q0=np.array([0.6543, -0.0876, -0.4837, -1.2278, -1.5735, -1.0720, 0]), qd0=np.zeros(7), qdd0=np.zeros(7),
+                      q_des=np.array([0.6831, 0.009488, -0.2471, -0.9777, -1.414, -0.9958, 0]), obstacles=np.vstack([_FIVE, _FIVE]))
+
+
+def load_golden(name):
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+
+
 def oracle_tables(oracles, cap_l=32, cap_t=128):
     """Pack the reach-set tables of a list of solved oracle problems in the layout armour_debug_load_tables takes."""
     B = len(oracles)

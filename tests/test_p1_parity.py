@@ -1,0 +1,152 @@
+"""GPU parity of the whole product path -- armour_set_problems (device JRS / FK / RNEA / torque radius /
+half-space tables) followed by the fused eval kernel -- against the committed golden fixtures and the live
+CPU oracle, all through the C ABI.
+
+Stated tolerances (BASELINE.md "parity tolerance"; north_star "within a stated fp tolerance"):
+    identical monomial key sets per (link|joint, t);
+    |d coeff|, |d centre|, |d independent radius| <= 1e-11;  link generators, half-space tables <= 1e-11
+    torque radius <= 1e-10;  |dg| <= 1e-9;  |djac| <= 1e-8     (all absolute; observed ~1e-14)
+valid when no monomial norm lies within 1e-9 (relative) of SIMPLIFY_THRESHOLD -- each fixture records that
+margin (min_margin, ~1e-7 here), so a prune flip would be detected rather than silent.  Sources of the
+residual: summation order of equal keys (the reference's std::sort leaves it unspecified), wave-parallel
+abs-sums, device cos/sin vs glibc."""
+import numpy as np
+import pytest
+
+from helpers import PZ_TESTS_K, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = [f"{n}_T{T}" for n in ("sample", "debug", "scene013") for T in (100, 128)]
+C_TOL, R_TOL, G_TOL, J_TOL = 1e-11, 1e-10, 1e-9, 1e-8
+
+
+def _nlp(gd):
+    from armour_amd.planner import ArmourNLP
+    return ArmourNLP(T=int(gd["T"])).set_parameters(gd["q0"], gd["qd0"], gd["qdd0"], gd["q_des"], gd["obstacles"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_against_golden_fixtures(case):
+    gd = load_golden(case)
+    assert float(gd["min_margin"]) > 1e-9
+    nlp = _nlp(gd)
+    T = int(gd["T"])
+    assert np.abs(nlp.torque_radius()[0] - gd["torque_radius"]).max() <= R_TOL
+    assert np.abs(nlp.link_generators()[0] - gd["link_gens"]).max() <= C_TOL
+    lc, lk, tc, tk = [], [], [], []
+    for i in range(7):
+        for t in range(T):
+            k1 = nlp.pz("link", i, t)[2]; lc.append(len(k1)); lk.append(k1)
+            k2 = nlp.pz("torque", i, t)[2]; tc.append(len(k2)); tk.append(k2)
+    assert np.array_equal(np.array(lc), gd["link_count"]) and np.array_equal(np.concatenate(lk), gd["link_keys"])
+    assert np.array_equal(np.array(tc), gd["torque_count"]) and np.array_equal(np.concatenate(tk), gd["torque_keys"])
+    _, _, gl, gu = nlp.get_bounds_info()
+    assert np.abs(gl[0] - gd["g_l"]).max() <= R_TOL and np.abs(gu[0] - gd["g_u"]).max() <= R_TOL
+    for tag, k in (("k0", np.zeros(7)), ("kt", PZ_TESTS_K)):
+        g, jac = nlp.eval_g_jac(k)
+        assert np.abs(g[0] - gd[f"g_{tag}"]).max() <= G_TOL
+        assert np.abs(jac[0][gd["jac_rows"]] - gd[f"jac_{tag}"]).max() <= J_TOL
+        assert abs(nlp.eval_f(k)[0] - float(gd[f"f_{tag}"])) <= 1e-12
+        assert np.abs(nlp.eval_grad_f(k)[0] - gd[f"gradf_{tag}"]).max() <= 1e-12
+
+
+def _compare_tables(nlp, oracles):
+    for b, o in enumerate(oracles):
+        assert o.min_margin() > 1e-9
+        for which, cnt in (("link", o.J), ("torque", o.n)):
+            for i in range(cnt):
+                for t in range(o.T):
+                    c, ind, keys, co = o.pz(which, i, t)
+                    c2, ind2, keys2, co2 = nlp.pz(which, i, t, b=b)
+                    assert np.array_equal(keys, keys2), (b, which, i, t)
+                    if len(keys):
+                        assert np.abs(co - co2).max() <= C_TOL
+                    assert np.abs(c - c2).max() <= C_TOL and np.abs(ind - ind2).max() <= C_TOL
+        assert np.abs(nlp.torque_radius()[b] - o.torque_radius()).max() <= R_TOL
+        assert np.abs(nlp.link_generators()[b] - o.link_generators()).max() <= C_TOL
+    if oracles[0].O:
+        A2, d2, dl2 = nlp.hyperplanes()
+        for b, o in enumerate(oracles):
+            A, d, dl = o.hyperplanes()
+            assert np.abs(A - A2[b]).max() <= C_TOL and np.abs(d - d2[b]).max() <= C_TOL and np.abs(dl - dl2[b]).max() <= C_TOL
+
+
+def test_random_batch_against_live_oracle():
+    """B = 4 independent worlds in one handle (the batched twin of the reference's single-problem process)."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    from oracle.cpu_oracle import Oracle
+    T, O, B = 100, 9, 4
+    bp = random_batch(20, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    oracles = [Oracle(T=T).set_problem(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b]) for b in range(B)]
+    _compare_tables(nlp, oracles)
+    ks = random_k(99, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b, o in enumerate(oracles):
+        gr, jr = o.eval_g_jac(ks[b])
+        assert np.abs(g[b] - gr).max() <= G_TOL and np.abs(jac[b] - jr).max() <= J_TOL
+    ts = nlp.table_sizes()
+    assert ts["sum_link"] == sum(o.table_sizes()["sum_link"] for o in oracles)
+    assert ts["sum_torque"] == sum(o.table_sizes()["sum_torque"] for o in oracles)
+
+
+def test_fast_initial_state_stress():
+    """speed-limit initial velocity and |qdd0| = 3: the largest intermediate PZs we know of (~2.6k raw terms)."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import SPEED, random_problem
+    from oracle.cpu_oracle import Oracle
+    T = 100
+    p = random_problem(0, 2)
+    p["qd0"] = SPEED.copy(); p["qdd0"] = np.full(7, 3.0)
+    nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    o = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    _compare_tables(nlp, [o])
+
+
+def test_handle_reuse_and_state_errors():
+    """set_problems can be called again on the same handle with a different (B, O); eval before set is an error;
+    too-small table capacities are reported, never silently truncated."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    nlp = ArmourNLP(T=20)
+    with pytest.raises(_lib.ArmourError) as ei:
+        nlp.L.armour_get_sizes(nlp.h, None, None, None) and None
+        _lib.check(nlp.L.armour_get_sizes(nlp.h, None, None, None))
+    assert ei.value.code == _lib.ESTATE
+    p = random_problem(1, 3)
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    g1 = nlp.eval_g(np.zeros(7))
+    p2 = random_problem(2, 12)
+    nlp.set_parameters(p2["q0"], p2["qd0"], p2["qdd0"], p2["q_des"], p2["obstacles"])
+    assert nlp.m == 7 * 20 + 7 * 20 * 12 + 28
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert np.array_equal(nlp.eval_g(np.zeros(7)), g1)
+    small = _lib.ArmourLimits(link_monomials=2)
+    with pytest.raises(_lib.ArmourError) as ei:
+        ArmourNLP(T=20, limits=small).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert ei.value.code == _lib.ECAPACITY
+
+
+def test_linearity_of_slices_in_duplicate_obstacles_and_permutation():
+    """Size-independent properties at the full BASELINE size (T=100, O=20): permuting the obstacle list permutes
+    the collision rows and nothing else; rows of a duplicated obstacle are identical."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    T, O = 100, 20
+    p = random_problem(42, O)
+    p["obstacles"][7] = p["obstacles"][3]
+    nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    g, jac = nlp.eval_g_jac(PZ_TESTS_K)
+    perm = np.random.default_rng(0).permutation(O)
+    nlp2 = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"][perm])
+    g2, jac2 = nlp2.eval_g_jac(PZ_TESTS_K)
+    n = 7
+    a = g[0][n * T:-28].reshape(7, T, O); b = g2[0][n * T:-28].reshape(7, T, O)
+    assert np.array_equal(a[:, :, perm], b)
+    ja = jac[0][n * T:-28].reshape(7, T, O, n); jb = jac2[0][n * T:-28].reshape(7, T, O, n)
+    assert np.array_equal(ja[:, :, perm], jb)
+    assert np.array_equal(g[0][:n * T], g2[0][:n * T]) and np.array_equal(g[0][-28:], g2[0][-28:])
+    assert np.array_equal(a[:, :, 7], a[:, :, 3]) and np.array_equal(ja[:, :, 7], ja[:, :, 3])
