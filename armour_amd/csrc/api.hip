@@ -168,12 +168,27 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     return ARMOUR_OK;
 }
 
+int armour_refresh_table_stats(ArmourPlanner* h) {
+    const size_t nl = (size_t)h->B * h->J * h->T, nt = (size_t)h->B * h->n * h->T;
+    std::vector<int> lc(nl), tc(nt);
+    HIPCHK(hipMemcpy(lc.data(), h->d_link_count, nl * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tc.data(), h->d_tq_count, nt * sizeof(int), hipMemcpyDeviceToHost));
+    long long sl = 0, st = 0;
+    int ml = 0, mt = 0;
+    for (int v : lc) { sl += v; if (v > ml) ml = v; }
+    for (int v : tc) { st += v; if (v > mt) mt = v; }
+    h->sum_link = sl; h->sum_torque = st; h->max_link = ml; h->max_torque = mt;
+    return ARMOUR_OK;
+}
+
 extern "C" int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
                                    const double* qdd0, const double* q_des, const double* obstacles) {
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
     if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
     rc = armour_p1_build(h, obstacles);
+    if (rc != ARMOUR_OK) return rc;
+    rc = armour_refresh_table_stats(h);
     if (rc != ARMOUR_OK) return rc;
     h->ready = true;
     return ARMOUR_OK;
@@ -228,6 +243,8 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
 #undef UP
     h->h_torque_radius.assign(torque_radius, torque_radius + (size_t)B * n * T);
     h->h_link_gens.assign((size_t)B * T * J * 18, 0.0);
+    rc = armour_refresh_table_stats(h);
+    if (rc != ARMOUR_OK) return rc;
     h->ready = true;
     return ARMOUR_OK;
 }
@@ -315,7 +332,7 @@ extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, dou
     NEED_READY(h);
     if (!d_k) { armour_set_error("d_k is null"); return ARMOUR_EINVAL; }
     const P2Tables tb = armour_make_tables(h);
-    return armour_p2_launch(tb, d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
+    return armour_p2_launch(tb, h->max_link, h->max_torque, d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
 }
 
 extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
@@ -326,7 +343,7 @@ extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const size_t stride = (size_t)h->B * h->n;
     for (int s = 0; s < steps; s++) {
-        int rc = armour_p2_launch(tb, d_k + (size_t)s * stride, d_g, d_jac, st);
+        int rc = armour_p2_launch(tb, h->max_link, h->max_torque, d_k + (size_t)s * stride, d_g, d_jac, st);
         if (rc != ARMOUR_OK) return rc;
     }
     return ARMOUR_OK;
@@ -339,7 +356,7 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     const size_t bn = (size_t)h->B * h->n, bm = (size_t)h->B * h->m;
     HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     const P2Tables tb = armour_make_tables(h);
-    int rc = armour_p2_launch(tb, h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
+    int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
     if (rc != ARMOUR_OK) return rc;
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -434,16 +451,7 @@ extern "C" int armour_get_pz(ArmourPlanner* h, int32_t b, int32_t which, int32_t
 
 extern "C" int armour_get_table_sizes(ArmourPlanner* h, int64_t* out4) {
     NEED_READY(h);
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const size_t nl = (size_t)h->B * h->J * h->T, nt = (size_t)h->B * h->n * h->T;
-    std::vector<int> lc(nl), tc(nt);
-    HIPCHK(hipMemcpy(lc.data(), h->d_link_count, nl * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(tc.data(), h->d_tq_count, nt * sizeof(int), hipMemcpyDeviceToHost));
-    int64_t sl = 0, st = 0, ml = 0, mt = 0;
-    for (int v : lc) { sl += v; if (v > ml) ml = v; }
-    for (int v : tc) { st += v; if (v > mt) mt = v; }
-    out4[0] = sl; out4[1] = st; out4[2] = ml; out4[3] = mt;
+    out4[0] = h->sum_link; out4[1] = h->sum_torque; out4[2] = h->max_link; out4[3] = h->max_torque;
     return ARMOUR_OK;
 }
 

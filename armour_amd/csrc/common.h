@@ -85,12 +85,15 @@ struct ArmourPlanner {
     double* d_g = nullptr;
     double* d_jac = nullptr;
     double build_ms = 0;
+    int max_link = 0, max_torque = 0;          // largest monomial counts in the current tables (LDS sizing of P2)
+    long long sum_link = 0, sum_torque = 0;
     // P1 workspace (p1_reach.hip)
     void* p1 = nullptr;
 };
 
 // p2_eval.hip
-int armour_p2_launch(const P2Tables& tb, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
+int armour_refresh_table_stats(ArmourPlanner* h);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);
 

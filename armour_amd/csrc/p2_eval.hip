@@ -5,26 +5,35 @@
 // RT/PZsparse.cu:404-555, RT/Trajectory.cu:256-540) by ONE launch over all B problems:
 //
 //   blockIdx.y = problem b;  blockIdx.x selects the role:
-//     [0, nbc)          collision blocks: 256 consecutive rows q = (l*T+t)*O + o each
-//     [nbc, nbc+nbt)    torque blocks: 32 (t,j) rows x 8 outputs (value + 7 partials) each
+//     [0, nbc)          collision blocks: 64 consecutive rows q = (l*T+t)*O + o each (lane = row), the block's
+//                       four waves splitting each row's 36 half-spaces 9 apiece
+//     [nbc, nbc+nbt)    torque blocks: 8 (t,j) rows x 32 monomial lanes each
 //     nbc+nbt           joint position / velocity limit rows (4n rows, closed form)
 //
-// Collision block: the (l,t) link PZs the block's rows touch are sliced first (value + gradient,
-// RT/PZsparse.cu:404-435,477-516) into LDS; then every lane streams its row's 36 half-spaces from the
-// plane table planes[b][c][p][q] (q fastest: each load is one 512-B coalesced request per wave), keeps the
-// running arg-max with the reference's scan order (pos_p before neg_p, strict >) and finally dots the
-// winning normal with the 7 centre derivatives.  Bound: HBM -- 1440 B of table per row against ~450 flop.
-// g rows are written coalesced; Jacobian rows are staged through LDS so the block writes 256*7 contiguous
-// doubles.
+// Collision block: every lane first issues its 9 planes x 5 components from planes[b][c][p][q] (q fastest:
+// each load is one 512-B coalesced request per wave; 45 loads in flight per lane) and only then, while those
+// are in flight, the block slices the (l,t) link PZs its rows touch (value + gradient,
+// RT/PZsparse.cu:404-435,477-516): one thread per (pair, monomial, output entry) writes the monomial term to
+// LDS, one thread per (pair, output entry) sums the terms in monomial order.  Each wave then scans its 9
+// planes in the reference's order (pos_p before neg_p, strict >); wave 0 merges the four partial arg-maxes in
+// plane order -- the same winner as the reference's serial scan -- and dots the winning normal with the 7
+// centre derivatives.  Bound: HBM -- 1440 B of table per row against ~450 flop.  g rows are written coalesced;
+// Jacobian rows are staged through LDS so the block writes 64*7 contiguous doubles.
 //
 // Arithmetic order follows the CPU statement of the reference exactly (products of k-powers in factor
 // order, sums in monomial order), so with identical tables the outputs agree with the oracle to the ulp of
 // pow() vs. repeated multiplication; FMA contraction is disabled for this file (see Makefile).
+#include <algorithm>
+
 #include "bezier.h"
 #include "common.h"
 
 #define P2_BLOCK 256
-#define P2_TQ_ROWS 32
+#define P2_ROWS 64        // collision rows per block (one per lane); the 4 waves split the 36 planes 9 each
+#define P2_PPW 9          // planes per wave
+#define P2_TASK_ROUNDS 2   // (monomial, axis) slicing tasks a thread preloads per LDS pass
+#define P2_TQ_ROWS 8      // torque rows per block (32 monomial lanes each)
+#define P2_TQ_ROUNDS 4    // monomials per lane of a torque row (strideT <= 128)
 
 namespace {
 
@@ -43,24 +52,54 @@ __device__ inline void fill_kpow(KPow& kp, const double* k, int n) {
     }
 }
 
-// value of coeff * prod_j k_j^{d_j}, multiplying in factor order (RT/PZsparse.cu:416-418)
+// value of coeff * prod_j k_j^{d_j}, multiplying in factor order (RT/PZsparse.cu:416-418).  The 7 table reads are
+// independent of the multiply chain (pw[j][0] = 1.0 makes the absent factors exact no-ops), so they issue together.
 __device__ inline double mono_value(const KPow& kp, uint32_t key, double c, int n) {
+    double f[ARMOUR_MAX_FACTORS];
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) f[j] = (j < n) ? kp.pw[j][(key >> (2 * j)) & 3u] : 1.0;
     double v = c;
-    for (int j = 0; j < n; j++) {
-        const uint32_t d = (key >> (2 * j)) & 3u;
-        if (d) v *= kp.pw[j][d];
-    }
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) v *= f[j];
     return v;
 }
-// d/dk_kk of the same monomial (RT/PZsparse.cu:454-468); caller guarantees degree(kk) > 0
+// d/dk_kk of the same monomial (RT/PZsparse.cu:454-468): the kk-th factor is d*k^(d-1) (0 when k_kk is absent)
 __device__ inline double mono_grad(const KPow& kp, uint32_t key, double c, int n, int kk) {
-    double v = c;
-    for (int j = 0; j < n; j++) {
+    double f[ARMOUR_MAX_FACTORS];
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) {
         const uint32_t d = (key >> (2 * j)) & 3u;
-        if (j == kk) v *= kp.df[j][d];
-        else if (d) v *= kp.pw[j][d];
+        f[j] = (j < n) ? (j == kk ? kp.df[j][d] : kp.pw[j][d]) : 1.0;
     }
+    double v = c;
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) v *= f[j];
     return v;
+}
+// value and all n partials of one monomial with ONE decode of the key and one set of table reads; each of the
+// 8 products still multiplies coeff * f_0 * ... * f_{n-1} in factor order as the reference does.
+template <bool WANT_J>
+__device__ inline void mono_all(const KPow& kp, uint32_t key, double c, int n, double* o) {
+    double pw[ARMOUR_MAX_FACTORS], df[ARMOUR_MAX_FACTORS];
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) {
+        const uint32_t d = (key >> (2 * j)) & 3u;
+        pw[j] = (j < n) ? kp.pw[j][d] : 1.0;
+        df[j] = (j < n) ? kp.df[j][d] : 0.0;
+    }
+    double v = c;
+#pragma unroll
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) v *= pw[j];
+    o[0] = v;
+    if (WANT_J) {
+#pragma unroll
+        for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) {
+            double g = c;
+#pragma unroll
+            for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) g *= (j == kk) ? df[j] : pw[j];
+            o[1 + kk] = g;
+        }
+    }
 }
 // centre of Interval(c - r, c + r) as getCenter computes it (RT/PZsparse.cu:10-12,427-432)
 __device__ inline double interval_center(double c, double r) {
@@ -68,140 +107,280 @@ __device__ inline double interval_center(double c, double r) {
     return (lo + hi) * 0.5;
 }
 
+struct P2Launch {
+    int nbc, nbt;       // collision / torque block counts
+    int max_pairs;      // (l,t) pairs a collision block can touch
+    int strideL;        // monomial stride of the LDS term buffer for link PZs (>= max link count)
+    int strideT;        // same for torque PZs
+    int pair_chunk;     // (l,t) pairs sliced per LDS pass
+};
+
 template <bool WANT_G, bool WANT_J>
 __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
-                                                                  int nbc, int nbt, int max_pairs) {
+                                                                  P2Launch lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     KPow& kp = *reinterpret_cast<KPow*>(smem_raw);
-    double* sx = reinterpret_cast<double*>(smem_raw + sizeof(KPow));  // [max_pairs][24]: x[3], dx[7][3]
-    double* sj = sx + (size_t)max_pairs * 24;                          // [256][7] Jacobian staging
+    double* lds = reinterpret_cast<double*>(smem_raw + sizeof(KPow));
 
     const int b = blockIdx.y;
     const int n = tb.n, T = tb.T, O = tb.O, Q = tb.Q, m = tb.m;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* k = k_all + (size_t)b * n;
     double* g = WANT_G ? g_all + (size_t)b * m : nullptr;
     double* jac = WANT_J ? jac_all + (size_t)b * m * n : nullptr;
-
-    fill_kpow(kp, k, n);
-    __syncthreads();
-
     const int role = blockIdx.x;
-    if (role < nbc) {
+#ifdef P2_ABLATE  // development only: skip roles to attribute kernel time
+    if ((P2_ABLATE & 1) && role < lp.nbc) return;
+    if ((P2_ABLATE & 2) && role >= lp.nbc && role < lp.nbc + lp.nbt) return;
+    if ((P2_ABLATE & 4) && role >= lp.nbc + lp.nbt) return;
+#endif
+
+    if (role < lp.nbc) {
         // ------------------------------------------------------------------ collision rows
-        const int q_begin = role * P2_BLOCK;
-        const int q_end = min(Q, q_begin + P2_BLOCK);
+        double* sx = lds;                                               // [max_pairs][24]: x[3], dx[7][3]
+        double* terms = sx + (size_t)lp.max_pairs * 24;                 // [pair_chunk][strideL][24]
+        double* part = terms + (size_t)lp.pair_chunk * lp.strideL * 24; // [4][64][4] + flags; reused as Jacobian staging
+        int* pneg = reinterpret_cast<int*>(part + 4 * 64 * 4);          // [4][64]
+
+        const int q_begin = role * P2_ROWS;
+        const int q_end = min(Q, q_begin + P2_ROWS);
+        const int q = min(q_begin + lane, q_end - 1);
+        // 1. issue this lane's 9 planes x 5 components first: nothing below depends on them until step 4
+        const double* pl = tb.planes + (size_t)b * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * Q + q;
+        const size_t cs = (size_t)ARMOUR_NPLANES * Q;
+        double a0[P2_PPW], a1[P2_PPW], a2[P2_PPW], dd[P2_PPW], dl[P2_PPW];
+#pragma unroll
+        for (int i = 0; i < P2_PPW; i++) {
+            const size_t o = (size_t)(wv * P2_PPW + i) * Q;
+            a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o]; dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
+#if defined(P2_ABLATE) && (P2_ABLATE & 8)
+            a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;
+#endif
+        }
+        // 2. slice the (l,t) link PZs this block's rows touch: one thread per (pair, monomial, output entry).
+        //    The table loads of a pass are issued before the k-power table is waited for, so the fresh k (an HBM
+        //    miss), the PZ tables (L2) and the planes are all in flight together.
         const int lt_first = q_begin / O;
         const int npairs = (q_end - 1) / O - lt_first + 1;
-        // slice link PZs: task = (pair, axis)
-        for (int task = tid; task < npairs * 3; task += P2_BLOCK) {
-            const int pair = task / 3, e = task - pair * 3;
-            const size_t idx = (size_t)b * tb.J * T + (lt_first + pair);
-            const int cnt = tb.link_count[idx];
-            const uint32_t* keys = tb.link_keys + idx * tb.capL;
-            const double* co = tb.link_coeff + idx * tb.capL * 3;
-            double cen = tb.link_center[idx * 3 + e];
-            double gr[ARMOUR_MAX_FACTORS];
-            for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) gr[kk] = 0.0;
-            for (int mo = 0; mo < cnt; mo++) {
-                const uint32_t key = keys[mo];
-                const double c = co[mo * 3 + e];
-                cen += mono_value(kp, key, c, n);
-                if (WANT_J) {
-                    for (int kk = 0; kk < n; kk++)
-                        if ((key >> (2 * kk)) & 3u) gr[kk] += mono_grad(kp, key, c, n, kk);
+        const int per_pair = lp.strideL * 24;
+        const int per_pair3 = lp.strideL * 3;  // tasks per pair: (monomial, axis), 8 outputs each
+        fill_kpow(kp, k, n);
+        for (int p0 = 0; p0 < npairs; p0 += lp.pair_chunk) {
+            const int pc = min(lp.pair_chunk, npairs - p0);
+            const int ntask = pc * per_pair3;
+            uint32_t tkey[P2_TASK_ROUNDS];
+            double tco[P2_TASK_ROUNDS];
+            int tcnt[P2_TASK_ROUNDS], tdst[P2_TASK_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < P2_TASK_ROUNDS; r++) {
+                const int task = tid + r * P2_BLOCK;
+                tcnt[r] = -1;
+                if (task < ntask) {
+                    const int pr = task / per_pair3, rem = task - pr * per_pair3, mo = rem / 3, e = rem - mo * 3;
+                    const size_t idx = (size_t)b * tb.J * T + (lt_first + p0 + pr);
+                    tcnt[r] = tb.link_count[idx] - mo;  // > 0: live monomial
+                    tdst[r] = pr * per_pair + mo * 24 + e;
+                    if (mo < tb.capL) {
+                        tkey[r] = tb.link_keys[idx * tb.capL + mo];
+                        tco[r] = tb.link_coeff[(idx * tb.capL + mo) * 3 + e];
+                    }
                 }
             }
-            sx[pair * 24 + e] = interval_center(cen, tb.link_indep[idx * 3 + e]);
-            if (WANT_J)
-                for (int kk = 0; kk < n; kk++) sx[pair * 24 + 3 + kk * 3 + e] = gr[kk];
-        }
-        __syncthreads();
-
-        const int q = q_begin + tid;
-        const bool valid = q < q_end;
-        const int qc = valid ? q : q_end - 1;
-        const double* xs = sx + (qc / O - lt_first) * 24;
-        const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
-        const double* pl = tb.planes + (size_t)b * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * Q + qc;
-        const size_t cs = (size_t)ARMOUR_NPLANES * Q;  // component stride
-
-        double max_elt = -100000000.0;
-        double mA0 = 0, mA1 = 0, mA2 = 0;
-        bool neg = false;
-        bool first = true;  // max_id == 0 initially: the winning normal defaults to plane 0
-#pragma unroll 6
-        for (int p = 0; p < ARMOUR_NPLANES; p++) {
-            const size_t o = (size_t)p * Q;
-            const double a0 = pl[o], a1 = pl[cs + o], a2 = pl[2 * cs + o];
-            const double dd = pl[3 * cs + o], dl = pl[4 * cs + o];
-            if (first) { mA0 = a0; mA1 = a1; mA2 = a2; first = false; }
-            double pos_res = -100000000.0, neg_res = -100000000.0;
-            if (a0 != 0.0 || a1 != 0.0 || a2 != 0.0) {  // A_elt.norm() > 0 (RT/CollisionChecking.cu:252)
-                const double dot = a0 * x0 + a1 * x1 + a2 * x2;
-                pos_res = dot - (dd + dl);
-                neg_res = -dot - (-dd + dl);
+            // reduce-phase inputs (centre, independent radius, count) for thread < pc*24
+            double rc_cen = 0.0, rc_ind = 0.0;
+            int rc_cnt = 0;
+            if (tid < pc * 24) {
+                const int pr = tid / 24, c = tid - pr * 24, e = c % 3;
+                const size_t idx = (size_t)b * tb.J * T + (lt_first + p0 + pr);
+                rc_cnt = min(tb.link_count[idx], lp.strideL);
+                if (c < 3) { rc_cen = tb.link_center[idx * 3 + e]; rc_ind = tb.link_indep[idx * 3 + e]; }
             }
-            if (pos_res > max_elt) { max_elt = pos_res; mA0 = a0; mA1 = a1; mA2 = a2; neg = false; }
-            if (neg_res > max_elt) { max_elt = neg_res; mA0 = a0; mA1 = a1; mA2 = a2; neg = true; }
-        }
-        const size_t row0 = (size_t)n * T + q_begin;
-        if (WANT_G && valid) g[row0 + tid] = -max_elt;
-        if (WANT_J) {
-            for (int kk = 0; kk < n; kk++) {
-                const double* dx = xs + 3 + kk * 3;
-                const double dot = mA0 * dx[0] + mA1 * dx[1] + mA2 * dx[2];
-                sj[tid * n + kk] = neg ? dot : -dot;
+            __syncthreads();  // k-power table ready (first pass) / previous pass done with `terms`
+#pragma unroll
+            for (int r = 0; r < P2_TASK_ROUNDS; r++) {
+                if (tcnt[r] > 0) {
+                    double o8[8];
+                    mono_all<WANT_J>(kp, tkey[r], tco[r], n, o8);
+                    double* dst = terms + tdst[r];
+                    dst[0] = o8[0];
+                    if (WANT_J) {
+#pragma unroll
+                        for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) dst[3 + kk * 3] = o8[1 + kk];
+                    }
+                }
             }
             __syncthreads();
-            const int total = (q_end - q_begin) * n;
-            double* jrow = jac + row0 * n;
-            for (int i = tid; i < total; i += P2_BLOCK) jrow[i] = sj[i];
+            // ordered sum over monomials (the reference's accumulation order, RT/PZsparse.cu:420,470-472)
+            if (tid < pc * 24) {
+                const int pr = tid / 24, c = tid - pr * 24, out = c / 3, e = c - out * 3;
+                double acc = rc_cen;
+                const double* tp = terms + (size_t)pr * per_pair + c;
+#pragma unroll 4
+                for (int mo = 0; mo < rc_cnt; mo++) acc += tp[mo * 24];
+                if (out == 0) acc = interval_center(acc, rc_ind);
+                sx[(p0 + pr) * 24 + (out == 0 ? e : 3 + (out - 1) * 3 + e)] = acc;
+            }
+            __syncthreads();
         }
-    } else if (role < nbc + nbt) {
-        // ------------------------------------------------------------------ torque rows (t*n + j)
-        const int row = (role - nbc) * P2_TQ_ROWS + tid / 8;
-        const int out = tid & 7;
-        if (row < n * T && out <= n) {
-            const int t = row / n, j = row - t * n;
-            const size_t idx = ((size_t)b * n + j) * T + t;
-            const int cnt = tb.tq_count[idx];
-            const uint32_t* keys = tb.tq_keys + idx * tb.capT;
-            const double* co = tb.tq_coeff + idx * tb.capT;
-            if (out == 0) {
+        // 3. this wave's 9 planes in the reference's scan order (pos_p before neg_p, strict >)
+        const double* xs = sx + (q / O - lt_first) * 24;
+        const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
+        double max_elt = -100000000.0;
+        double mA0 = a0[0], mA1 = a1[0], mA2 = a2[0];  // max_id defaults to the first plane scanned
+        bool neg = false;
+#pragma unroll
+        for (int i = 0; i < P2_PPW; i++) {
+            double pos_res = -100000000.0, neg_res = -100000000.0;
+            if (a0[i] != 0.0 || a1[i] != 0.0 || a2[i] != 0.0) {  // A_elt.norm() > 0 (RT/CollisionChecking.cu:252)
+                const double dot = a0[i] * x0 + a1[i] * x1 + a2[i] * x2;
+                pos_res = dot - (dd[i] + dl[i]);
+                neg_res = -dot - (-dd[i] + dl[i]);
+            }
+            if (pos_res > max_elt) { max_elt = pos_res; mA0 = a0[i]; mA1 = a1[i]; mA2 = a2[i]; neg = false; }
+            if (neg_res > max_elt) { max_elt = neg_res; mA0 = a0[i]; mA1 = a1[i]; mA2 = a2[i]; neg = true; }
+        }
+        double* my = part + ((size_t)wv * 64 + lane) * 4;
+        my[0] = max_elt; my[1] = mA0; my[2] = mA1; my[3] = mA2;
+        pneg[wv * 64 + lane] = neg ? 1 : 0;
+        __syncthreads();
+        // 4. wave 0 merges the four partial scans in plane order and finishes the row
+        double jrow_local[ARMOUR_MAX_FACTORS];
+        if (wv == 0) {
+#pragma unroll
+            for (int w2 = 1; w2 < 4; w2++) {
+                const double* o = part + ((size_t)w2 * 64 + lane) * 4;
+                if (o[0] > max_elt) { max_elt = o[0]; mA0 = o[1]; mA1 = o[2]; mA2 = o[3]; neg = pneg[w2 * 64 + lane] != 0; }
+            }
+#if defined(P2_ABLATE) && (P2_ABLATE & 32)
+            if (WANT_G && max_elt == 12345.678) g[(size_t)n * T + q_begin + lane] = -max_elt;
+#else
+            if (WANT_G && q_begin + lane < q_end) g[(size_t)n * T + q_begin + lane] = -max_elt;
+#endif
+            if (WANT_J) {
+                for (int kk = 0; kk < n; kk++) {
+                    const double* dx = xs + 3 + kk * 3;
+                    const double dot = mA0 * dx[0] + mA1 * dx[1] + mA2 * dx[2];
+                    jrow_local[kk] = neg ? dot : -dot;
+                }
+            }
+        }
+        if (WANT_J) {
+            __syncthreads();  // everyone is done reading `part`; reuse it as the [64][n] Jacobian staging tile
+            if (wv == 0)
+                for (int kk = 0; kk < n; kk++) part[lane * n + kk] = jrow_local[kk];
+            __syncthreads();
+            const int total = (q_end - q_begin) * n;
+            double* jrow = jac + ((size_t)n * T + q_begin) * n;
+#if defined(P2_ABLATE) && (P2_ABLATE & 32)
+            for (int i = tid; i < total; i += P2_BLOCK) if (part[i] == 12345.678) jrow[i] = part[i];
+#else
+            for (int i = tid; i < total; i += P2_BLOCK) jrow[i] = part[i];
+#endif
+        }
+    } else if (role < lp.nbc + lp.nbt) {
+        // ------------------------------------------------------------------ torque rows (row = t*n + j)
+        double* terms = lds;  // [P2_TQ_ROWS][strideT][8]
+        fill_kpow(kp, k, n);
+        const int r = tid >> 5, ml = tid & 31;
+        const int row = (role - lp.nbc) * P2_TQ_ROWS + r;
+        const bool live = row < n * T;
+        int t = 0, j = 0, cnt = 0;
+        size_t idx = 0;
+        uint32_t tkey[P2_TQ_ROUNDS];
+        double tco[P2_TQ_ROUNDS];
+        double cen0 = 0.0, ind0 = 0.0;
+        if (live) {
+            t = row / n; j = row - t * n;
+            idx = ((size_t)b * n + j) * T + t;
+            cnt = min(tb.tq_count[idx], lp.strideT);
+            if (ml == 0) { cen0 = tb.tq_center[idx]; ind0 = tb.tq_indep[idx]; }
+#pragma unroll
+            for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
+                const int mo = ml + rr * 32;
+                if (mo < lp.strideT && mo < tb.capT) { tkey[rr] = tb.tq_keys[idx * tb.capT + mo]; tco[rr] = tb.tq_coeff[idx * tb.capT + mo]; }
+            }
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
+                const int mo = ml + rr * 32;
+                if (mo < cnt) {
+                    double* tp = terms + ((size_t)r * lp.strideT + mo) * 8;
+                    double o8[8];
+                    mono_all<WANT_J>(kp, tkey[rr], tco[rr], n, o8);
+                    tp[0] = o8[0];
+                    if (WANT_J) {
+#pragma unroll
+                        for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) tp[1 + kk] = o8[1 + kk];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (live && ml <= n) {
+            const double* tp = terms + (size_t)r * lp.strideT * 8 + ml;
+            if (ml == 0) {
                 if (WANT_G) {
-                    double cen = tb.tq_center[idx];
-                    for (int mo = 0; mo < cnt; mo++) cen += mono_value(kp, keys[mo], co[mo], n);
-                    g[row] = interval_center(cen, tb.tq_indep[idx]);
+                    double cen = cen0;
+#pragma unroll 4
+                    for (int mo = 0; mo < cnt; mo++) cen += tp[mo * 8];
+                    g[row] = interval_center(cen, ind0);
                 }
             } else if (WANT_J) {
-                const int kk = out - 1;
                 double gr = 0.0;
-                for (int mo = 0; mo < cnt; mo++) {
-                    const uint32_t key = keys[mo];
-                    if ((key >> (2 * kk)) & 3u) gr += mono_grad(kp, key, co[mo], n, kk);
-                }
-                jac[(size_t)row * n + kk] = gr;
+#pragma unroll 4
+                for (int mo = 0; mo < cnt; mo++) gr += tp[mo * 8];
+                jac[(size_t)row * n + (ml - 1)] = gr;
             }
         }
     } else {
         // ------------------------------------------------------------------ joint limit rows
-        if (tid < n) {
-            const int i = tid;
-            const double* bz = tb.bez + (size_t)b * 3 * n;
-            const double q0 = bz[i], a = bz[n + i], bb = bz[2 * n + i];
+        // RT/Trajectory.cu:256-540.  One thread per (joint, position|velocity, piece): pieces 0-3 evaluate the curve
+        // at t = 0, the two stationary points and t = 1, pieces 4-5 the d/dk of the two interior extrema; a second
+        // step per (joint, position|velocity) selects min / max exactly as bez::joint_extremum does.
+        double* pv = lds;  // [2n][8]
+        const int jv = tid >> 3, piece = tid & 7;
+        const double* bz = tb.bez + (size_t)b * 3 * n;
+        if (jv < 2 * n && piece < 6) {
+            const int i = jv % n;
+            const bool vel = jv >= n;
+            const double q0 = bz[i], a = bz[n + i], bb = bz[2 * n + i], ka = tb.k_range[i] * k[i];
+            double e2, e3, v;
+            if (!vel) bez::q_stationary(a, bb, ka, &e2, &e3); else bez::qd_stationary(a, bb, ka, &e2, &e3);
+            if (piece < 4) {
+                const double tt = piece == 0 ? 0.0 : piece == 1 ? e2 : piece == 2 ? e3 : 1.0;
+                v = vel ? bez::qd_des(q0, a, bb, ka, tt) : bez::q_des(q0, a, bb, ka, tt);
+            } else {
+                const int sg = piece == 4 ? +1 : -1;
+                v = vel ? bez::qd_extremum_dk(q0, a, bb, ka, sg) : bez::q_extremum_dk(q0, a, bb, ka, sg);
+            }
+            pv[jv * 8 + piece] = v;
+            if (piece == 1) pv[jv * 8 + 6] = e2;
+            if (piece == 2) pv[jv * 8 + 7] = e3;
+        }
+        __syncthreads();
+        if (tid < 2 * n) {
+            const int i = tid % n;
+            const bool vel = tid >= n;
+            const double* v = pv + tid * 8;
+            const double v1 = v[0], v2 = v[1], v3 = v[2], v4 = v[3], e2 = v[6], e3 = v[7];
+            double mn, mx;
+            int mnId, mxId;
+            if (v1 < v4) { mn = v1; mnId = 1; mx = v4; mxId = 4; } else { mn = v4; mnId = 4; mx = v1; mxId = 1; }
+            if (0 <= e2 && e2 <= 1) { if (v2 < mn) { mn = v2; mnId = 2; } if (mx < v2) { mx = v2; mxId = 2; } }
+            if (0 <= e3 && e3 <= 1) { if (v3 < mn) { mn = v3; mnId = 3; } if (mx < v3) { mx = v3; mxId = 3; } }
+            const double sc = vel ? tb.k_range[i] / tb.duration : tb.k_range[i];
+            const double dmn = (mnId == 1 ? 0.0 : mnId == 2 ? v[4] : mnId == 3 ? v[5] : 1.0) * sc;
+            const double dmx = (mxId == 1 ? 0.0 : mxId == 2 ? v[4] : mxId == 3 ? v[5] : 1.0) * sc;
             const size_t off = (size_t)n * T + Q;
-            for (int vel = 0; vel < 2; vel++) {
-                double mn, mx, dmn, dmx;
-                bez::joint_extremum(q0, a, bb, k[i], tb.k_range[i], tb.duration, vel != 0, &mn, &mx, &dmn, &dmx);
-                const size_t r_mn = off + vel * 2 * n + i, r_mx = r_mn + n;
-                if (WANT_G) { g[r_mn] = mn; g[r_mx] = mx; }
-                if (WANT_J) {
-                    for (int c = 0; c < n; c++) {
-                        jac[r_mn * n + c] = (c == i) ? dmn : 0.0;
-                        jac[r_mx * n + c] = (c == i) ? dmx : 0.0;
-                    }
+            const size_t r_mn = off + (vel ? 2 * n : 0) + i, r_mx = r_mn + n;
+            if (WANT_G) { g[r_mn] = vel ? mn / tb.duration : mn; g[r_mx] = vel ? mx / tb.duration : mx; }
+            if (WANT_J) {
+                for (int c = 0; c < n; c++) {
+                    jac[r_mn * n + c] = (c == i) ? dmn : 0.0;
+                    jac[r_mx * n + c] = (c == i) ? dmx : 0.0;
                 }
             }
         }
@@ -231,19 +410,30 @@ __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restri
 
 const char* armour_p2_kernel_name(void) { return "armour_p2_eval_kernel"; }
 
-int armour_p2_launch(const P2Tables& tb, const double* d_k, double* d_g, double* d_jac, hipStream_t stream) {
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const double* d_k, double* d_g, double* d_jac,
+                     hipStream_t stream) {
     if (!d_g && !d_jac) return ARMOUR_OK;
-    const int nbc = (tb.Q + P2_BLOCK - 1) / P2_BLOCK;
-    const int nbt = (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;
-    const int max_pairs = tb.O > 0 ? (P2_BLOCK - 1) / tb.O + 2 : 1;
-    const size_t smem = sizeof(KPow) + (size_t)max_pairs * 24 * sizeof(double) + (size_t)P2_BLOCK * ARMOUR_MAX_FACTORS * sizeof(double);
-    dim3 grid(nbc + nbt + 1, tb.B), block(P2_BLOCK);
+    P2Launch lp;
+    lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
+    lp.nbt = (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;
+    lp.max_pairs = tb.O > 0 ? (P2_ROWS - 1) / tb.O + 2 : 1;
+    lp.strideL = max_link > 0 ? max_link : 1;
+    lp.strideT = max_torque > 0 ? max_torque : 1;
+    if (lp.strideL * 3 > P2_BLOCK * P2_TASK_ROUNDS) { armour_set_error("link PZ with %d monomials exceeds the P2 kernel's %d", lp.strideL, P2_BLOCK * P2_TASK_ROUNDS / 3); return ARMOUR_ECAPACITY; }
+    lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / 24), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
+    if (lp.strideT > 32 * P2_TQ_ROUNDS) { armour_set_error("torque PZ with %d monomials exceeds the P2 kernel's %d", lp.strideT, 32 * P2_TQ_ROUNDS); return ARMOUR_ECAPACITY; }
+    const size_t col = ((size_t)lp.max_pairs * 24 + (size_t)lp.pair_chunk * lp.strideL * 24 + 4 * 64 * 4) * sizeof(double) + 4 * 64 * sizeof(int);
+    const size_t tq = (size_t)P2_TQ_ROWS * lp.strideT * 8 * sizeof(double);
+    const size_t lim = (size_t)2 * ARMOUR_MAX_FACTORS * 8 * sizeof(double);
+    const size_t smem = sizeof(KPow) + std::max(std::max(col, tq), lim);
+    if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }
+    dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
     if (d_g && d_jac)
-        hipLaunchKernelGGL((armour_p2_eval_kernel<true, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, nbc, nbt, max_pairs);
+        hipLaunchKernelGGL((armour_p2_eval_kernel<true, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);
     else if (d_g)
-        hipLaunchKernelGGL((armour_p2_eval_kernel<true, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, nbc, nbt, max_pairs);
+        hipLaunchKernelGGL((armour_p2_eval_kernel<true, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);
     else
-        hipLaunchKernelGGL((armour_p2_eval_kernel<false, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, nbc, nbt, max_pairs);
+        hipLaunchKernelGGL((armour_p2_eval_kernel<false, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);
     HIPCHK(hipGetLastError());
     return ARMOUR_OK;
 }

@@ -95,8 +95,9 @@ def main():
     ks = torch.tensor(random_k(rank, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
     d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
     d_jac = torch.empty((B, m, n), device=dev, dtype=torch.float64)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: HIP events on the null stream do not bracket the launches
     sh = stream.cuda_stream
+    torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
