@@ -1,0 +1,110 @@
+"""The reference's process boundary: text files under `buffer/` (transport A).
+
+Input  `armour.in`  (KSI/uarmtd_planner.m:158-185, parsed by RT/armour_main.cu:53-76):
+    4 lines of n numbers "%.10f " (q0, qd0, qdd0, q_des), one line with nObs, then nObs lines of 12 numbers
+    = column-major Z = [c g1 g2 g3] of each obstacle zonotope.
+Outputs (RT/armour_main.cu:312-372, read back by KSI/uarmtd_planner.m:192-230):
+    armour.out                          n lines k_opt (setprecision(10)) or a single -1, then the time in ms
+    armour_joint_position_center.out    T*J rows x 3   sliced link centres
+    armour_joint_position_radius.out    T*J*3 rows x 6 link independent generators
+    armour_control_input_radius.out     T rows x n     torque radius
+    armour_constraints.out              m rows (setprecision(6))
+C++ streams with setprecision(p) print like "%.{p}g"; that is what the writers below use.
+"""
+import os
+
+import numpy as np
+
+IN_NAME = "armour.in"
+OUT_NAMES = ("armour.out", "armour_joint_position_center.out", "armour_joint_position_radius.out",
+             "armour_control_input_radius.out", "armour_constraints.out")
+
+
+def write_armour_in(path, q0, qd0, qdd0, q_des, obstacles):
+    """What uarmtd_planner.replan writes before spawning the planner process."""
+    obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 12)
+    with open(path, "w") as f:
+        for v in (q0, qd0, qdd0, q_des):
+            f.write("".join("%.10f " % x for x in np.asarray(v, dtype=np.float64)) + "\n")
+        f.write("%d\n" % obs.shape[0])
+        for row in obs:
+            f.write("".join("%.10f " % x for x in row) + "\n")
+
+
+def parse_armour_in(path, n=7, max_obstacles=None):
+    """Whitespace-separated token stream exactly as the `>>` loop of RT/armour_main.cu:53-76 reads it.
+    Raises ValueError where the reference writes -1 and throws (missing file, bad obstacle count)."""
+    if not os.path.exists(path):
+        raise ValueError("Error reading input files")
+    tok = open(path).read().split()
+    need = 4 * n + 1
+    if len(tok) < need:
+        raise ValueError("input file too short")
+    vals = [float(t) for t in tok[:4 * n]]
+    q0, qd0, qdd0, q_des = (np.array(vals[i * n:(i + 1) * n]) for i in range(4))
+    nobs = int(float(tok[4 * n]))
+    if nobs < 0 or (max_obstacles is not None and nobs > max_obstacles):
+        raise ValueError("Number of obstacles larger than MAX_OBSTACLE_NUM")
+    if len(tok) < need + 12 * nobs:
+        raise ValueError("input file too short for %d obstacles" % nobs)
+    obs = np.array([float(t) for t in tok[need:need + 12 * nobs]]).reshape(nobs, 12)
+    return dict(q0=q0, qd0=qd0, qdd0=qdd0, q_des=q_des, obstacles=obs)
+
+
+def _g(x, p):
+    return "%.*g" % (p, x)
+
+
+def write_outputs(dirname, k_opt, time_ms, link_centers, link_gens, torque_radius, constraints):
+    """k_opt: [n] or None (infeasible -> -1); link_centers [T,J,3]; link_gens [T,J,3,6]; torque_radius [n,T];
+    constraints [m]."""
+    with open(os.path.join(dirname, OUT_NAMES[0]), "w") as f:
+        if k_opt is None:
+            f.write("-1\n")
+        else:
+            for v in k_opt:
+                f.write(_g(v, 10) + "\n")
+        f.write(_g(time_ms, 10))
+    T, J = link_centers.shape[:2]
+    with open(os.path.join(dirname, OUT_NAMES[1]), "w") as f:
+        for t in range(T):
+            for j in range(J):
+                f.write("".join(_g(v, 10) + " " for v in link_centers[t, j]) + "\n")
+    with open(os.path.join(dirname, OUT_NAMES[2]), "w") as f:
+        for t in range(T):
+            for j in range(J):
+                for r in range(3):
+                    f.write("".join(_g(v, 10) + " " for v in link_gens[t, j, r]) + "\n")
+    with open(os.path.join(dirname, OUT_NAMES[3]), "w") as f:
+        for t in range(T):
+            f.write("".join(_g(v, 10) + " " for v in torque_radius[:, t]) + "\n")
+    with open(os.path.join(dirname, OUT_NAMES[4]), "w") as f:
+        for v in constraints:
+            f.write(_g(v, 6) + "\n")
+
+
+def read_armour_out(path, n=7):
+    """uarmtd_planner.m:192-208: a single leading -1 (or fewer than n+1 numbers) means 'no plan'.
+    Returns (k_opt or None, time_ms)."""
+    vals = np.loadtxt(path, ndmin=1)
+    if vals.size == n + 1:
+        return vals[:n], float(vals[n])
+    return None, float(vals[-1])
+
+
+def run_planning_iteration(nlp, dirname, k=None):
+    """One pass over the file protocol with the device library: read armour.in, build the reach sets, evaluate the
+    constraints at `k` (the starting point x = 0 when None) and write the five output files.  The NLP solve that
+    picks k is outside the hot path (IPOPT in the reference, RT/armour_main.cu:237-273); a caller that has a solver
+    passes its k_opt here."""
+    import time
+    t0 = time.perf_counter()
+    p = parse_armour_in(os.path.join(dirname, IN_NAME), n=nlp.n)
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    x = np.zeros(nlp.n) if k is None else np.asarray(k, dtype=np.float64)
+    g = nlp.eval_g(x)
+    feasible = bool(nlp.finalize_solution(g)[0])
+    cen = nlp.link_centers(x)[0]
+    ms = (time.perf_counter() - t0) * 1e3
+    write_outputs(dirname, x if feasible else None, ms, cen, nlp.link_generators()[0], nlp.torque_radius()[0], g[0])
+    return feasible

@@ -72,6 +72,7 @@ def main():
     import torch
     import torch.distributed as dist
     from armour_amd.planner import ArmourNLP
+    from armour_amd.sharding import shard_seeds
     from armour_amd.worlds import random_batch, random_k
 
     if not torch.cuda.is_available():
@@ -83,8 +84,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, O, T, K, W = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup
-    # independent worlds per rank: seeds rank*B .. rank*B + B - 1
-    probs = random_batch(rank * B, B, O)
+    # independent worlds per rank (block partition of world*B seeds, armour_amd/sharding.py); no data-path collective
+    seeds = shard_seeds(0, world * B, rank, world)
+    probs = random_batch(seeds[0], len(seeds), O)
     nlp = ArmourNLP(T=T, device=local_rank)
     t0 = time.time()
     nlp.set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])

@@ -1,0 +1,114 @@
+"""Host-side logic that needs no GPU: synthetic worlds, the reference's file protocol, sharding (incl. a
+world_size-2 gloo run of the multi-rank plumbing bench.py uses)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_random_worlds_are_deterministic_and_in_range():
+    from armour_amd.worlds import SPEED, STATE_LB, STATE_UB, random_batch, random_k, random_problem
+    a, b = random_problem(3, 20), random_problem(3, 20)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["obstacles"].shape == (20, 12)
+    lim = np.abs(STATE_LB) < 1000
+    assert np.all(a["q0"][lim] >= STATE_LB[lim] + 0.3) and np.all(a["q0"][lim] <= STATE_UB[lim] - 0.3)
+    assert np.all(np.abs(a["qd0"]) <= 0.5 * SPEED) and np.all(np.abs(a["qdd0"]) <= 1)
+    # boxes are [c, diag(s/2)] column-major (SIM/worlds/obstacles/box_obstacle_zonotope.m:21-26)
+    ob = a["obstacles"][0]
+    assert ob[4] == ob[5] == ob[6] == ob[8] == ob[9] == ob[10] == 0 and 0.005 <= ob[3] <= 0.25
+    bt = random_batch(10, 4, 5)
+    assert bt["q0"].shape == (4, 7) and bt["obstacles"].shape == (4, 5, 12)
+    assert np.array_equal(bt["q0"][2], random_problem(12, 5)["q0"])
+    k = random_k(0, 64)
+    assert k.shape == (64, 7) and np.all(np.abs(k) <= 1)
+
+
+def test_scene_csv_loader():
+    from armour_amd.worlds import load_scene_csv
+    qs, qg, obs = load_scene_csv(os.path.join(ROOT, "tests", "golden", "scene_013_001.csv"))
+    assert qs.shape == (7,) and qg.shape == (7,) and obs.shape == (6, 12)
+    assert abs(qs[2] - 2.859) < 1e-12 and abs(obs[0, 3] - 0.037916 / 2) < 1e-15 and abs(obs[5, 11] - 0.37495 / 2) < 1e-15
+
+
+def test_file_protocol_roundtrip(tmp_path):
+    from armour_amd import file_protocol as fp
+    from helpers import SAMPLE_PROBLEM as p
+    path = tmp_path / fp.IN_NAME
+    fp.write_armour_in(path, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    lines = open(path).read().splitlines()
+    assert len(lines) == 4 + 1 + 10 and lines[4].strip() == "10"
+    assert lines[0].split()[0] == "0.6543000000"          # "%.10f " as uarmtd_planner.m:160
+    back = fp.parse_armour_in(path)
+    for k in p:
+        assert np.allclose(back[k], p[k], rtol=0, atol=5e-11)
+    # error conventions of RT/armour_main.cu:47-71
+    with pytest.raises(ValueError):
+        fp.parse_armour_in(tmp_path / "missing.in")
+    with pytest.raises(ValueError):
+        fp.parse_armour_in(path, max_obstacles=5)
+    # outputs
+    T, J, n, m = 4, 7, 7, 11
+    rng = np.random.default_rng(0)
+    cen, gens, tr, g = rng.normal(size=(T, J, 3)), rng.normal(size=(T, J, 3, 6)), rng.uniform(1, 2, (n, T)), rng.normal(size=m)
+    fp.write_outputs(tmp_path, np.arange(7) / 10.0, 123.0, cen, gens, tr, g)
+    k_opt, ms = fp.read_armour_out(tmp_path / "armour.out")
+    assert np.allclose(k_opt, np.arange(7) / 10.0) and ms == 123.0
+    assert np.loadtxt(tmp_path / "armour_joint_position_center.out").shape == (T * J, 3)
+    assert np.loadtxt(tmp_path / "armour_joint_position_radius.out").shape == (T * J * 3, 6)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_control_input_radius.out"), tr.T, rtol=1e-9)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_constraints.out"), g, rtol=1e-5)
+    fp.write_outputs(tmp_path, None, 5.0, cen, gens, tr, g)   # infeasible: single -1 then the time
+    k_opt, ms = fp.read_armour_out(tmp_path / "armour.out")
+    assert k_opt is None and ms == 5.0 and open(tmp_path / "armour.out").read().split()[0] == "-1"
+
+
+def test_shard_ranges_cover_exactly_once():
+    from armour_amd.sharding import shard_range, shard_seeds
+    for total in (1, 7, 128, 1024, 1025):
+        for world in (1, 2, 4, 8):
+            rs = [shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in rs]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_seeds(100, 10, 1, 4) == [103, 104, 105]
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from armour_amd.sharding import shard_seeds, reduce_max_elapsed, gather_counts
+from armour_amd.worlds import random_problem
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+seeds = shard_seeds(0, 9, rank, world)
+# every rank builds only its own worlds; nothing is exchanged on the data path
+probs = [random_problem(s, 3) for s in seeds]
+counts = gather_counts(len(probs))
+mx = reduce_max_elapsed(0.5 + rank)
+all_seeds = [None] * world
+dist.all_gather_object(all_seeds, seeds)
+if rank == 0:
+    flat = sorted(s for part in all_seeds for s in part)
+    assert flat == list(range(9)), flat
+    assert sum(counts) == 9 and counts == [5, 4], counts
+    assert mx == 0.5 + (world - 1), mx
+    print("GLOO_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert "GLOO_OK" in out.stdout, out.stdout + out.stderr

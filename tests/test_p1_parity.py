@@ -150,3 +150,23 @@ def test_linearity_of_slices_in_duplicate_obstacles_and_permutation():
     assert np.array_equal(ja[:, :, perm], jb)
     assert np.array_equal(g[0][:n * T], g2[0][:n * T]) and np.array_equal(g[0][-28:], g2[0][-28:])
     assert np.array_equal(a[:, :, 7], a[:, :, 3]) and np.array_equal(ja[:, :, 7], ja[:, :, 3])
+
+
+def test_file_protocol_planning_iteration(tmp_path, sample_problem):
+    """armour.in -> device reach sets + constraints -> the five *.out files (RT/armour_main.cu:36-76,312-372)."""
+    from armour_amd import file_protocol as fp
+    from armour_amd.planner import ArmourNLP
+    from oracle.cpu_oracle import Oracle
+    p = sample_problem
+    fp.write_armour_in(tmp_path / fp.IN_NAME, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    nlp = ArmourNLP(T=128)
+    feasible = fp.run_planning_iteration(nlp, tmp_path, k=PZ_TESTS_K)
+    o = Oracle(T=128).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    g_ref, _ = o.eval_g_jac(PZ_TESTS_K)
+    g_file = np.loadtxt(tmp_path / "armour_constraints.out")
+    assert g_file.shape == (nlp.m,) and np.allclose(g_file, g_ref, rtol=2e-6, atol=1e-12)   # setprecision(6)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_control_input_radius.out"), o.torque_radius().T, rtol=1e-9)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_joint_position_center.out").reshape(128, 7, 3), o.slice_links(PZ_TESTS_K), rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_joint_position_radius.out").reshape(128, 7, 3, 6), o.link_generators(), rtol=1e-9, atol=1e-12)
+    k_opt, ms = fp.read_armour_out(tmp_path / "armour.out")
+    assert (k_opt is not None) == feasible and ms > 0
