@@ -58,6 +58,7 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_tq_keys, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_tq_coeff, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_planes, (size_t)nb * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * h->J * h->T * (size_t)no));
+    TRY(dev_alloc(&h->d_plane_skip, (size_t)nb));
     TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
     TRY(dev_alloc(&h->d_k, (size_t)nb * h->n));
@@ -78,7 +79,7 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.link_keys = h->d_link_keys; tb.link_coeff = h->d_link_coeff;
     tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
     tb.tq_keys = h->d_tq_keys; tb.tq_coeff = h->d_tq_coeff;
-    tb.planes = h->d_planes; tb.bez = h->d_bez;
+    tb.planes = h->d_planes; tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
     for (int i = 0; i < ARMOUR_MAX_FACTORS; i++) tb.k_range[i] = h->params.k_range[i];
     tb.duration = h->params.duration;
     return tb;
@@ -136,7 +137,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
     dev_free(&h->d_tq_count); dev_free(&h->d_tq_center); dev_free(&h->d_tq_indep);
     dev_free(&h->d_tq_keys); dev_free(&h->d_tq_coeff);
-    dev_free(&h->d_planes); dev_free(&h->d_bez);
+    dev_free(&h->d_planes); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
     dev_free(&h->d_k); dev_free(&h->d_g); dev_free(&h->d_jac);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -178,6 +179,8 @@ int armour_refresh_table_stats(ArmourPlanner* h) {
     for (int v : lc) { sl += v; if (v > ml) ml = v; }
     for (int v : tc) { st += v; if (v > mt) mt = v; }
     h->sum_link = sl; h->sum_torque = st; h->max_link = ml; h->max_torque = mt;
+    h->h_plane_skip.assign((size_t)h->B, 0ull);
+    if (h->O > 0) HIPCHK(hipMemcpy(h->h_plane_skip.data(), h->d_plane_skip, (size_t)h->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return ARMOUR_OK;
 }
 
@@ -240,6 +243,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
     UP(h->d_link_center, lc); UP(h->d_link_indep, li); UP(h->d_link_keys, lk); UP(h->d_link_coeff, lco);
     UP(h->d_tq_center, tc); UP(h->d_tq_indep, ti); UP(h->d_tq_keys, tk); UP(h->d_tq_coeff, tco);
     if (!pl.empty()) UP(h->d_planes, pl);
+    HIPCHK(hipMemset(h->d_plane_skip, 0, (size_t)B * sizeof(unsigned long long)));  // loaded tables: evaluate every plane
 #undef UP
     h->h_torque_radius.assign(torque_radius, torque_radius + (size_t)B * n * T);
     h->h_link_gens.assign((size_t)B * T * J * 18, 0.0);
@@ -332,7 +336,7 @@ extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, dou
     NEED_READY(h);
     if (!d_k) { armour_set_error("d_k is null"); return ARMOUR_EINVAL; }
     const P2Tables tb = armour_make_tables(h);
-    return armour_p2_launch(tb, h->max_link, h->max_torque, d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
+    return armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
 }
 
 extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
@@ -343,7 +347,7 @@ extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const size_t stride = (size_t)h->B * h->n;
     for (int s = 0; s < steps; s++) {
-        int rc = armour_p2_launch(tb, h->max_link, h->max_torque, d_k + (size_t)s * stride, d_g, d_jac, st);
+        int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k + (size_t)s * stride, d_g, d_jac, st);
         if (rc != ARMOUR_OK) return rc;
     }
     return ARMOUR_OK;
@@ -356,7 +360,7 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     const size_t bn = (size_t)h->B * h->n, bm = (size_t)h->B * h->m;
     HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     const P2Tables tb = armour_make_tables(h);
-    int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
+    int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
     if (rc != ARMOUR_OK) return rc;
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));

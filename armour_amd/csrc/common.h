@@ -47,6 +47,7 @@ struct P2Tables {
     const uint32_t* tq_keys;    // [..][capT]
     const double* tq_coeff;     // [..][capT]
     const double* planes;       // [B][5][36][Q]
+    const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem
     const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0
     double k_range[ARMOUR_MAX_FACTORS];
     double duration;
@@ -66,6 +67,7 @@ struct ArmourPlanner {
     std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
     std::vector<double> h_torque_radius;              // [B][n][T]
     std::vector<double> h_link_gens;                  // [B][T][J][18]
+    std::vector<unsigned long long> h_plane_skip;     // [B] host copy of d_plane_skip
     // device tables (sized for allocB x allocO)
     int allocB = 0, allocO = 0;
     int* d_link_count = nullptr;
@@ -79,6 +81,7 @@ struct ArmourPlanner {
     uint32_t* d_tq_keys = nullptr;
     double* d_tq_coeff = nullptr;
     double* d_planes = nullptr;
+    unsigned long long* d_plane_skip = nullptr;
     double* d_bez = nullptr;
     // staging for the host-pointer API
     double* d_k = nullptr;
@@ -92,7 +95,7 @@ struct ArmourPlanner {
 };
 
 // p2_eval.hip
-int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
 int armour_refresh_table_stats(ArmourPlanner* h);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);

@@ -695,39 +695,60 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     }
 }
 
-// RT/CollisionChecking.cu:136-228: one thread per (b, q = (l*T+t)*O + o) builds the row's 36 half-spaces
+// RT/CollisionChecking.cu:136-228: one thread per (b, q = (l*T+t)*O + o) builds the row's 36 half-spaces.
+// It also derives which planes can never win the row's arg-max: a plane whose normal is zero (the -1e8 sentinel
+// of :252-259) or bit-for-bit equal to +-the normal of an earlier plane of the same row reproduces values the
+// strict-> scan of :268-279 has already seen (d and delta follow the normal exactly), so skipping it changes
+// neither the maximum nor the winning normal.  The AND over all rows of a problem goes to plane_skip[b]; with
+// axis-aligned box obstacles that is 12 of the 36 planes (all obstacle x error-generator and error x error pairs).
 __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
-                                        const double* __restrict__ obstacles, double* __restrict__ planes) {
+                                        const double* __restrict__ obstacles, double* __restrict__ planes,
+                                        unsigned long long* __restrict__ plane_skip) {
     const int Q = J * T * O;
     const int q = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (q >= Q) return;
-    const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
-    const double* ob = obstacles + ((size_t)b * O + o) * 12;
-    const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
-    double G[9][3], c[3];
-    for (int ax = 0; ax < 3; ax++) {
-        c[ax] = ob[ax];
-        for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
-        for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
-    }
-    double* out = planes + (size_t)b * 5 * 36 * Q + q;
-    const size_t cs = (size_t)36 * Q;
-    int p = 0;
-    for (int a_id = 0; a_id < 8; a_id++)
-        for (int b_id = a_id + 1; b_id < 9; b_id++, p++) {  // pair order of RT/CollisionChecking.cu:26-39
-            const double* ga = G[a_id];
-            const double* gb = G[b_id];
-            const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
-            const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
-            double C0 = 0, C1 = 0, C2 = 0;
-            if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
-            double dl = 0.0;
-            for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
-            const size_t po = (size_t)p * Q;
-            out[po] = C0; out[cs + po] = C1; out[2 * cs + po] = C2;
-            out[3 * cs + po] = C0 * c[0] + C1 * c[1] + C2 * c[2];
-            out[4 * cs + po] = dl;
+    unsigned long long skip = ~0ull;
+    if (q < Q) {
+        const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
+        const double* ob = obstacles + ((size_t)b * O + o) * 12;
+        const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+        double G[9][3], c[3], Cs[36][3];
+        for (int ax = 0; ax < 3; ax++) {
+            c[ax] = ob[ax];
+            for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
+            for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
         }
+        double* out = planes + (size_t)b * 5 * 36 * Q + q;
+        const size_t cs = (size_t)36 * Q;
+        int p = 0;
+        skip = 0ull;
+        for (int a_id = 0; a_id < 8; a_id++)
+            for (int b_id = a_id + 1; b_id < 9; b_id++, p++) {  // pair order of RT/CollisionChecking.cu:26-39
+                const double* ga = G[a_id];
+                const double* gb = G[b_id];
+                const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
+                const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
+                double C0 = 0, C1 = 0, C2 = 0;
+                if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
+                double dl = 0.0;
+                for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
+                const size_t po = (size_t)p * Q;
+                out[po] = C0; out[cs + po] = C1; out[2 * cs + po] = C2;
+                out[3 * cs + po] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+                out[4 * cs + po] = dl;
+                Cs[p][0] = C0; Cs[p][1] = C1; Cs[p][2] = C2;
+                bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
+                for (int e = 0; e < p && !red; e++)
+                    red = (Cs[e][0] == C0 && Cs[e][1] == C1 && Cs[e][2] == C2) || (Cs[e][0] == -C0 && Cs[e][1] == -C1 && Cs[e][2] == -C2);
+                if (red) skip |= 1ull << p;
+            }
+    }
+    // AND over the wave, then one atomic per wave
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)skip, o2, 64), hi = __shfl_xor((unsigned)(skip >> 32), o2, 64);
+        skip &= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) atomicAnd(&plane_skip[b], skip);
 }
 
 struct P1Work {
@@ -821,8 +842,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipGetLastError());
         if (O > 0) {
             const int Q = J * T * O;
+            HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
             hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes);
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_plane_skip);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));

@@ -113,6 +113,8 @@ struct P2Launch {
     int strideL;        // monomial stride of the LDS term buffer for link PZs (>= max link count)
     int strideT;        // same for torque PZs
     int pair_chunk;     // (l,t) pairs sliced per LDS pass
+    int skip_by_value;  // 1: plane_skip of the (single) problem is in `skip0` (saves a dependent load at B = 1)
+    unsigned long long skip0;
 };
 
 template <bool WANT_G, bool WANT_J>
@@ -146,14 +148,25 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         const int q_begin = role * P2_ROWS;
         const int q_end = min(Q, q_begin + P2_ROWS);
         const int q = min(q_begin + lane, q_end - 1);
-        // 1. issue this lane's 9 planes x 5 components first: nothing below depends on them until step 4
+        // 1. issue this lane's share of the live planes x 5 components first: nothing below depends on them until
+        //    step 3.  Planes flagged in plane_skip[b] (degenerate or exact duplicates in every row, see
+        //    armour_p1_planes_kernel) are not fetched; the live ones are dealt to the 4 waves in ascending order.
         const double* pl = tb.planes + (size_t)b * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * Q + q;
         const size_t cs = (size_t)ARMOUR_NPLANES * Q;
+        unsigned long long live = ~(lp.skip_by_value ? lp.skip0 : tb.plane_skip[b]) & ((1ull << ARMOUR_NPLANES) - 1ull);
+        const bool plane0_live = (live & 1ull) != 0;
+        const int na = __popcll(live), base = na >> 2, rem = na & 3;
+        const int my_cnt = base + (wv < rem ? 1 : 0), my_start = wv * base + min(wv, rem);
+        for (int s = 0; s < my_start; s++) live &= live - 1ull;
         double a0[P2_PPW], a1[P2_PPW], a2[P2_PPW], dd[P2_PPW], dl[P2_PPW];
 #pragma unroll
         for (int i = 0; i < P2_PPW; i++) {
-            const size_t o = (size_t)(wv * P2_PPW + i) * Q;
-            a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o]; dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
+            a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
+            if (i < my_cnt) {
+                const size_t o = (size_t)__builtin_ctzll(live) * Q;
+                live &= live - 1ull;
+                a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o]; dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
+            }
 #if defined(P2_ABLATE) && (P2_ABLATE & 8)
             a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;
 #endif
@@ -227,7 +240,8 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         const double* xs = sx + (q / O - lt_first) * 24;
         const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
         double max_elt = -100000000.0;
-        double mA0 = a0[0], mA1 = a1[0], mA2 = a2[0];  // max_id defaults to the first plane scanned
+        // max_id defaults to plane 0 (RT/CollisionChecking.cu:262): its normal if it is live, zero if it was skipped
+        double mA0 = (wv == 0 && plane0_live) ? a0[0] : 0.0, mA1 = (wv == 0 && plane0_live) ? a1[0] : 0.0, mA2 = (wv == 0 && plane0_live) ? a2[0] : 0.0;
         bool neg = false;
 #pragma unroll
         for (int i = 0; i < P2_PPW; i++) {
@@ -410,7 +424,7 @@ __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restri
 
 const char* armour_p2_kernel_name(void) { return "armour_p2_eval_kernel"; }
 
-int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const double* d_k, double* d_g, double* d_jac,
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac,
                      hipStream_t stream) {
     if (!d_g && !d_jac) return ARMOUR_OK;
     P2Launch lp;
@@ -419,6 +433,8 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const dou
     lp.max_pairs = tb.O > 0 ? (P2_ROWS - 1) / tb.O + 2 : 1;
     lp.strideL = max_link > 0 ? max_link : 1;
     lp.strideT = max_torque > 0 ? max_torque : 1;
+    lp.skip_by_value = (tb.B == 1 && h_skip) ? 1 : 0;
+    lp.skip0 = lp.skip_by_value ? h_skip[0] : 0ull;
     if (lp.strideL * 3 > P2_BLOCK * P2_TASK_ROUNDS) { armour_set_error("link PZ with %d monomials exceeds the P2 kernel's %d", lp.strideL, P2_BLOCK * P2_TASK_ROUNDS / 3); return ARMOUR_ECAPACITY; }
     lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / 24), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
     if (lp.strideT > 32 * P2_TQ_ROUNDS) { armour_set_error("torque PZ with %d monomials exceeds the P2 kernel's %d", lp.strideT, 32 * P2_TQ_ROUNDS); return ARMOUR_ECAPACITY; }
