@@ -29,6 +29,13 @@ extern "C" int armour_device_available(void) {
     return n > 0 ? 1 : 0;
 }
 
+extern "C" int armour_alloc_pinned(uint64_t bytes, void** out) {
+    if (!out) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return ARMOUR_OK;
+}
+extern "C" void armour_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
 template <class Tp>
 static int dev_alloc(Tp** p, size_t count) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }

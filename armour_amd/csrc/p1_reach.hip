@@ -67,13 +67,15 @@ __host__ __device__ inline Layout make_layout(int J, int n, int capW) {
     return L;
 }
 
-__device__ inline PZ mk_slot(unsigned char* base, size_t off, int index, int cap, int sz, int id0) {
-    unsigned char* p = base + off + (size_t)index * slot_bytes(cap, sz);
+// keys / coefficients of a slot live in the wave's global arena; its centre and independent radius (sz doubles each)
+// live in LDS (`ci`), so the per-operator scalar traffic never leaves the CU.
+__device__ inline PZ mk_slot(GLB_AS unsigned char* base, size_t off, int index, int cap, int sz, int id0, LDS_AS double* ci) {
+    GLB_AS unsigned char* p = base + off + (size_t)index * slot_bytes(cap, sz);
     PZ z;
-    z.keys = (uint64_t*)p;
-    z.coef = (double*)(p + align64((size_t)cap * 8));
-    z.cen = (double*)(p + align64((size_t)cap * 8) + align64((size_t)cap * sz * 8));
-    z.ind = z.cen + align64((size_t)sz * 8) / 8;
+    z.keys = (GLB_AS uint64_t*)p;
+    z.coef = (GLB_AS double*)(p + align64((size_t)cap * 8));
+    z.cen = ci + (size_t)index * 2 * sz;
+    z.ind = z.cen + sz;
     z.sz = sz; z.cap = cap; z.id = id0 + index;
     return z;
 }
@@ -240,17 +242,18 @@ __device__ inline void rpy_matrix(double roll, double pitch, double yaw, double*
 struct Chain {
     Wave w;
     const P1Cfg* cf;
-    unsigned char* arena;
+    GLB_AS unsigned char* arena;
     Layout L;
     unsigned freeV, freeS;
     int n, J;
 
-    __device__ PZ V(int i) const { return mk_slot(arena, L.offV, i, cf->capW, 3, L.idV); }
-    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS); }
-    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM); }
-    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM); }
-    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV); }
-    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS); }
+    LDS_AS double* ci;  // LDS: centre / indep of every slot, classes laid out V | S | M | JM | JV | JS
+    __device__ PZ V(int i) const { return mk_slot(arena, L.offV, i, cf->capW, 3, L.idV, ci); }
+    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS, ci + kNV * 6); }
+    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM, ci + kNV * 6 + kNS * 2); }
+    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM, ci + kNV * 6 + kNS * 2 + kNM * 18); }
+    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV, ci + kNV * 6 + kNS * 2 + kNM * 18 + L.nJM * 18); }
+    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS, ci + kNV * 6 + kNS * 2 + kNM * 18 + L.nJM * 18 + L.nJV * 6); }
     // named small slots
     __device__ PZ R(int i) const { return JM(i); }                       // 0..J
     __device__ PZ Rt(int i) const { return JM(J + 1 + i); }              // 0..J-1
@@ -308,20 +311,18 @@ struct Chain {
         lincomb<1, 2>(w, o, s);
         return o;
     }
-    __device__ PZ crossPzMat(const PZ& a, const double* b) {  // RT/PZsparse.cu:1153-1167
-        PZ r0 = comb2(elem(w, a, 1), b[2], elem(w, a, 2), -b[1]);
-        PZ r1 = comb2(elem(w, a, 2), b[0], elem(w, a, 0), -b[2]);
-        PZ r2 = comb2(elem(w, a, 0), b[1], elem(w, a, 1), -b[0]);
-        PZ o = stack(r0, r1, r2);
-        freeSs(r0); freeSs(r1); freeSs(r2);
+    __device__ PZ crossPzMat(const PZ& a, const double* b) {  // RT/PZsparse.cu:1153-1167: a x b
+        PZ o = allocV();
+        const double sA[3] = {b[2], b[0], b[1]}, sB[3] = {-b[1], -b[2], -b[0]};
+        const int cA[3] = {1, 2, 0}, cB[3] = {2, 0, 1};
+        cross_const(w, o, view(w, a), sA, cA, sB, cB);
         return o;
     }
-    __device__ PZ crossMatPz(const double* a, const PZ& b) {  // RT/PZsparse.cu:1118-1132
-        PZ r0 = comb2(elem(w, b, 2), a[1], elem(w, b, 1), -a[2]);
-        PZ r1 = comb2(elem(w, b, 0), a[2], elem(w, b, 2), -a[0]);
-        PZ r2 = comb2(elem(w, b, 1), a[0], elem(w, b, 0), -a[1]);
-        PZ o = stack(r0, r1, r2);
-        freeSs(r0); freeSs(r1); freeSs(r2);
+    __device__ PZ crossMatPz(const double* a, const PZ& b) {  // RT/PZsparse.cu:1118-1132: a x b
+        PZ o = allocV();
+        const double sA[3] = {a[1], a[2], a[0]}, sB[3] = {-a[2], -a[0], -a[1]};
+        const int cA[3] = {2, 0, 1}, cB[3] = {1, 2, 0};
+        cross_const(w, o, view(w, b), sA, cA, sB, cB);
         return o;
     }
     __device__ PZ mulSS(const View& a, const View& b) {
@@ -664,11 +665,19 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     c.cf = &cf;
     c.n = cf.n; c.J = cf.J;
     c.L = make_layout(cf.J, cf.n, cf.capW);
-    c.arena = cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
-    c.w.skey = (uint64_t*)smem;
-    c.w.sidx = (uint16_t*)(smem + (size_t)cf.capRaw * 8);
-    c.w.cnt = (int*)(smem + (size_t)cf.capRaw * 10);
+    c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
+    LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
+    c.w.skey = (LDS_AS uint64_t*)lds;
+    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capRaw * 8);
+    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capRaw * 10);
     c.w.lstat = c.w.cnt + kMaxSlots;
+    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capRaw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
+#ifdef P1_PROFILE
+    __shared__ unsigned long long prof_lds[PR_WORDS];
+    c.w.prof = (LDS_AS unsigned long long*)prof_lds;
+    if (threadIdx.x < PR_WORDS) prof_lds[threadIdx.x] = 0;
+    const long long prof_start = clock64();
+#endif
     c.w.cap_raw = cf.capRaw;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.lane = threadIdx.x;
@@ -688,10 +697,18 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
         finish_torque(c, u_nom, u_int, b, t);
         __syncthreads();
     }
+#ifdef P1_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        prof_lds[PR_TOTAL] = (unsigned long long)(clock64() - prof_start);
+        unsigned long long* dst = (unsigned long long*)(cf.status + ST_WORDS);
+        for (int i = 0; i < PR_WORDS; i++) dst[i] = prof_lds[i];
+    }
+#endif
     if (threadIdx.x == 0) {
         if (c.w.lstat[ST_ERR]) atomicOr(&cf.status[ST_ERR], (unsigned)c.w.lstat[ST_ERR]);
         atomicMax(&cf.status[ST_MAX_RAW], (unsigned)c.w.lstat[ST_MAX_RAW]);
         atomicMax(&cf.status[ST_MAX_OUT], (unsigned)c.w.lstat[ST_MAX_OUT]);
+        atomicMax(&cf.status[3], (unsigned)c.w.lstat[3]);
     }
 }
 
@@ -792,7 +809,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (!h->p1) {
         P1Work* nw = new P1Work();
         h->p1 = nw;
-        HIPCHK(hipMalloc((void**)&nw->d_status, ST_WORDS * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&nw->d_status, (ST_WORDS + 32) * sizeof(unsigned)));
         HIPCHK(hipEventCreate(&nw->ev0));
         HIPCHK(hipEventCreate(&nw->ev1));
     }
@@ -810,7 +827,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
     const int max_lds = (int)prop.sharedMemPerBlock;  // 64 KiB by default; up to 160 KiB on gfx950 with the attribute below
     for (;;) {
-        const size_t smem = (size_t)cap_raw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int);
+        const Layout L0 = make_layout(J, n, h->lim.work_monomials);
+        const size_t ci_doubles = (size_t)kNV * 6 + kNS * 2 + kNM * 18 + (size_t)L0.nJM * 18 + (size_t)L0.nJV * 6 + (size_t)L0.nJS * 2;
+        const size_t smem = (((size_t)cap_raw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap_raw); return ARMOUR_EINVAL; }
         (void)max_lds;
         HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -851,14 +870,22 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         unsigned st[ST_WORDS];
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+#ifdef P1_PROFILE
+        {
+            unsigned long long pr[PR_WORDS];
+            HIPCHK(hipMemcpy(pr, wk->d_status + ST_WORDS, sizeof(pr), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[P1 profile, wave 0] cycles: fill %llu sort %llu emit %llu abs_sum %llu total %llu | simplify calls %llu (N<=64: %llu) raw terms %llu\n",
+                    pr[PR_FILL], pr[PR_SORT], pr[PR_EMIT], pr[PR_ABS], pr[PR_TOTAL], pr[PR_CALLS], pr[PR_SMALL], pr[PR_TERMS]);
+        }
+#endif
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
             if (cap_raw < 8192) { cap_raw <<= 1; continue; }  // retry with a larger LDS sort buffer
             armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
             return ARMOUR_ECAPACITY;
         }
         if (st[ST_ERR]) {
-            armour_set_error("reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
-                             st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            armour_set_error("[dbg word3=%u] reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
+                             st[3], st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             return ARMOUR_ECAPACITY;
         }
         break;

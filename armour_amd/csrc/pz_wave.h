@@ -25,35 +25,52 @@ namespace pzw {
 
 constexpr int WAVE = 64;
 
+// Explicit address spaces: the PZ slots are reached through structs of pointers, which the compiler would
+// otherwise treat as generic and lower to flat_load / flat_store (slow for LDS, and unordered against ds_ / global_
+// instructions).  LDS_AS -> ds_read / ds_write, GLB_AS -> global_load / global_store.
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
 // status words (global, one array per launch)
 enum { ST_ERR = 0, ST_MAX_RAW = 1, ST_MAX_OUT = 2, ST_WORDS = 4 };
+#ifdef P1_PROFILE  // development only: per-wave cycle attribution, dumped after the status words
+enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS = 5, PR_SMALL = 6, PR_TOTAL = 7, PR_WORDS = 8 };
+#define PROF_T0 const long long prof_t0__ = clock64();
+#define PROF_ADD(slot) if (w.lane == 0) w.prof[slot] += (unsigned long long)(clock64() - prof_t0__);
+#else
+#define PROF_T0
+#define PROF_ADD(slot)
+#endif
 enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8 };
 
 // A PZ slot (all fields wave-uniform).  id indexes the per-wave LDS count table.
 struct PZ {
-    uint64_t* keys;
-    double* coef;  // [cap][sz]
-    double* cen;   // [sz]
-    double* ind;   // [sz]
+    GLB_AS uint64_t* keys;
+    GLB_AS double* coef;  // [cap][sz]
+    LDS_AS double* cen;   // [sz]
+    LDS_AS double* ind;   // [sz]
     int sz, cap, id;
 };
 
 // Read view of a PZ or of one entry of it (RT/PZsparse.cu:678-697 operator()(r,c) without the copy).
 struct View {
-    const uint64_t* keys;
-    const double* coef;
-    const double* cen;
-    const double* ind;
+    const GLB_AS uint64_t* keys;
+    const GLB_AS double* coef;
+    const LDS_AS double* cen;
+    const LDS_AS double* ind;
     int cnt, stride, off, sz;
 };
 
 struct Wave {
-    uint64_t* skey;   // LDS [cap_raw]
-    uint16_t* sidx;   // LDS [cap_raw]
-    int* cnt;         // LDS per-slot monomial counts
+    LDS_AS uint64_t* skey;   // LDS [cap_raw]
+    LDS_AS uint16_t* sidx;   // LDS [cap_raw]
+    LDS_AS int* cnt;         // LDS per-slot monomial counts
     int cap_raw;
     double thr;       // SIMPLIFY_THRESHOLD
-    int* lstat;       // LDS [ST_WORDS]: error bits / max raw terms / max monomials of this wave (flushed once per launch)
+#ifdef P1_PROFILE
+    LDS_AS unsigned long long* prof;  // LDS [PR_WORDS]
+#endif
+    LDS_AS int* lstat;       // LDS [ST_WORDS]: error bits / max raw terms / max monomials of this wave (flushed once per launch)
     int lane;
 };
 
@@ -87,37 +104,92 @@ __device__ inline void bitonic_sort(const Wave& w, int P) {
     }
 }
 
+// number of a[0..n) strictly below t / not above t (a ascending, in LDS)
+__device__ inline int lower_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t t) {
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        if (a[lo + half] < t) { lo += half + 1; len -= half + 1; } else len = half;
+    }
+    return lo;
+}
+__device__ inline int upper_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t t) {
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        if (a[lo + half] <= t) { lo += half + 1; len -= half + 1; } else len = half;
+    }
+    return lo;
+}
+
 // Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
 // and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind = independent part before pruning.
 // Eval: uint64_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
 template <int SZ, class Eval>
 __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind) {
     int emitted = 0;
+    bool any_pruned = false, indirect = false;
     double ra[SZ];
 #pragma unroll
     for (int e = 0; e < SZ; e++) ra[e] = 0.0;
     if (N > w.cap_raw) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
     if (w.lane == 0 && N > w.lstat[ST_MAX_RAW]) w.lstat[ST_MAX_RAW] = N;
+#ifdef P1_PROFILE
+    if (w.lane == 0) { w.prof[PR_CALLS] += 1; w.prof[PR_TERMS] += N; if (N <= 64) w.prof[PR_SMALL] += 1; }
+#endif
     if (N > 0) {
+        if (N <= WAVE) {
+            // one term per lane: rank by counting (key, index) pairs that sort before this lane's, N broadcast steps
+            PROF_T0
+            const uint64_t key = w.lane < N ? ev.key(w.lane) : ~0ull;
+            const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+            int rank = 0;
+            for (int l = 0; l < N; l++) {
+                const uint64_t kl = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)khi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)klo, l);
+                rank += (kl < key || (kl == key && l < w.lane)) ? 1 : 0;
+            }
+            if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
+            __syncthreads();
+            PROF_ADD(PR_SORT)
+        } else if (ev.try_merge(w, N)) {
+            // the operands' sorted runs were merged by ranking: sidx holds the permutation, keys come from LDS staging
+            indirect = true;
+#ifdef DBG_CHECK_MERGE
+            {
+                int bad = 0;
+                for (int p = w.lane; p < N; p += WAVE) {
+                    if (p > 0 && ev.key_lds(w, w.sidx[p - 1]) > ev.key_lds(w, w.sidx[p])) bad = 1;
+                    if (ev.key_lds(w, w.sidx[p]) != ev.key(w.sidx[p])) bad |= 2;
+                }
+                if (__ballot(bad != 0) != 0ull && w.lane == 0) { w.lstat[ST_ERR] |= 64; w.lstat[3] = N; }
+            }
+#endif
+        } else {
         const int P = next_pow2(N);
+        { PROF_T0
         for (int p = w.lane; p < P; p += WAVE) {
             w.skey[p] = p < N ? ev.key(p) : ~0ull;
             w.sidx[p] = (uint16_t)p;
         }
         __syncthreads();
+        PROF_ADD(PR_FILL) }
+        { PROF_T0
         bitonic_sort(w, P);
+        PROF_ADD(PR_SORT) }
+        }
+        PROF_T0
         for (int base = 0; base < N; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false;
             uint64_t key = 0;
             double acc[SZ];
             if (p < N) {
-                key = w.skey[p];
-                head = (p == 0) || (w.skey[p - 1] != key);
+                key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
+                head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
             }
             if (head) {
                 ev.coef(w.sidx[p], acc);
-                for (int q = p + 1; q < N && w.skey[q] == key; q++) {
+                for (int q = p + 1; q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key; q++) {
                     double c[SZ];
                     ev.coef(w.sidx[q], c);
 #pragma unroll
@@ -133,6 +205,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
                 }
             }
             const unsigned long long m = __ballot(keep);
+            any_pruned = any_pruned || (__ballot(head && !keep) != 0ull);
             if (keep) {
                 const int pos = emitted + __popcll(m & ((1ull << w.lane) - 1ull));
                 if (pos < out.cap) {
@@ -143,10 +216,13 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             }
             emitted += __popcll(m);
         }
+        PROF_ADD(PR_EMIT)
     }
     if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (any_pruned) {
 #pragma unroll
-    for (int e = 0; e < SZ; e++) ra[e] = wave_sum(ra[e]);
+        for (int e = 0; e < SZ; e++) ra[e] = wave_sum(ra[e]);
+    }
     if (w.lane == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.ind[e] = base_ind[e] + ra[e];
@@ -180,10 +256,37 @@ struct LinEval {
         const int k = seg_of(idx);
         return s[k].v.keys[idx - off[k]];
     }
+    // every source is a simplified PZ (sorted, unique keys): merge the NS runs by ranking each term with binary
+    // searches in the other runs; ties across runs go to the earlier run (= generation order)
+    __device__ inline bool try_merge(Wave& w, int N) const {
+#ifdef DBG_NO_MERGE_LIN
+        return false;
+#endif
+        PROF_T0
+        for (int idx = w.lane; idx < N; idx += WAVE) w.skey[idx] = key(idx);
+        __syncthreads();
+        for (int idx = w.lane; idx < N; idx += WAVE) {
+            const int k = seg_of(idx);
+            const uint64_t ky = w.skey[idx];
+            int rank = idx - off[k];
+#pragma unroll
+            for (int k2 = 0; k2 < NS; k2++) {
+                if (k2 == k) continue;
+                const LDS_AS uint64_t* run = w.skey + off[k2];
+                const int len = off[k2 + 1] - off[k2];
+                rank += (k2 < k) ? upper_bound_lds(run, len, ky) : lower_bound_lds(run, len, ky);
+            }
+            w.sidx[rank] = (uint16_t)idx;
+        }
+        __syncthreads();
+        PROF_ADD(PR_SORT)
+        return true;
+    }
+    __device__ inline uint64_t key_lds(const Wave& w, int idx) const { return w.skey[idx]; }
     __device__ inline void coef(int idx, double* c) const {
         const int k = seg_of(idx);
         const Seg& g = s[k];
-        const double* src = g.v.coef + (size_t)(idx - off[k]) * g.v.stride + g.v.off;
+        const GLB_AS double* src = g.v.coef + (size_t)(idx - off[k]) * g.v.stride + g.v.off;
         if (g.comp < 0) {
 #pragma unroll
             for (int e = 0; e < SZ; e++) c[e] = g.scale * src[e];
@@ -272,16 +375,69 @@ struct MulEval {
         split(idx, i, j);
         return (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);  // plain u64 add (RT/PZsparse.cu:938-940)
     }
+    // When one operand has at most 7 monomials the raw terms are (its count + 1) sorted runs over the other operand's
+    // keys [0, k_1, k_2, ...]: rank each term by binary searches with the target shifted by the run's own key.
+    // LDS staging: skey[0 .. nl] = long operand's keys (0 for the centre), skey[nl+1 ..] = short operand's keys.
+    static constexpr int MAX_RUNS = 8;
+    __device__ inline bool try_merge(Wave& w, int N) const {
+        const bool a_short = a.cnt <= b.cnt;
+        const int ns = (a_short ? a.cnt : b.cnt) + 1, nl = (a_short ? b.cnt : a.cnt) + 1;
+        if (ns > MAX_RUNS || nl + ns > w.cap_raw) return false;
+#ifdef DBG_NO_MERGE_MUL
+        return false;
+#endif
+        PROF_T0
+        const GLB_AS uint64_t* lk = a_short ? b.keys : a.keys;
+        const GLB_AS uint64_t* sk = a_short ? a.keys : b.keys;
+        for (int t = w.lane; t < nl; t += WAVE) w.skey[t] = t ? lk[t - 1] : 0ull;
+        if (w.lane < ns) w.skey[nl + w.lane] = w.lane ? sk[w.lane - 1] : 0ull;
+        __syncthreads();
+        const LDS_AS uint64_t* L = w.skey;
+        const LDS_AS uint64_t* S = w.skey + nl;
+        for (int idx = w.lane; idx < N; idx += WAVE) {
+            int i, j;
+            split(idx, i, j);
+            const int r = a_short ? i : j, pos = a_short ? j : i;
+            const uint64_t ky = S[r] + L[pos];
+            int rank = pos - 1;  // the (centre, centre) term sorts first and is not a monomial
+            for (int r2 = 0; r2 < ns; r2++) {
+                if (r2 == r || ky < S[r2]) continue;
+                const uint64_t tgt = ky - S[r2];
+                rank += (r2 < r) ? upper_bound_lds(L, nl, tgt) : lower_bound_lds(L, nl, tgt);
+            }
+            w.sidx[rank] = (uint16_t)idx;
+        }
+        __syncthreads();
+        PROF_ADD(PR_SORT)
+        return true;
+    }
+    __device__ inline uint64_t key_lds(const Wave& w, int idx) const {
+        int i, j;
+        split(idx, i, j);
+        const bool a_short = a.cnt <= b.cnt;
+        const int nl = (a_short ? b.cnt : a.cnt) + 1;
+        return w.skey[nl + (a_short ? i : j)] + w.skey[a_short ? j : i];
+    }
     __device__ inline void coef(int idx, double* c) const {
         int i, j;
         split(idx, i, j);
         double ca[SH::ASZ], cb[SH::BSZ];
-        const double* pa = i ? a.coef + (size_t)(i - 1) * a.stride + a.off : a.cen + a.off;
-        const double* pb = j ? b.coef + (size_t)(j - 1) * b.stride + b.off : b.cen + b.off;
+        if (i) {
+            const GLB_AS double* pa = a.coef + (size_t)(i - 1) * a.stride + a.off;
 #pragma unroll
-        for (int e = 0; e < SH::ASZ; e++) ca[e] = pa[e];
+            for (int e = 0; e < SH::ASZ; e++) ca[e] = pa[e];
+        } else {
 #pragma unroll
-        for (int e = 0; e < SH::BSZ; e++) cb[e] = pb[e];
+            for (int e = 0; e < SH::ASZ; e++) ca[e] = a.cen[a.off + e];
+        }
+        if (j) {
+            const GLB_AS double* pb = b.coef + (size_t)(j - 1) * b.stride + b.off;
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) cb[e] = pb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) cb[e] = b.cen[b.off + e];
+        }
         SH::mul(ca, cb, c);
     }
 };
@@ -292,7 +448,7 @@ __device__ inline void abs_sum(const Wave& w, const View& v, double* r) {
 #pragma unroll
     for (int e = 0; e < SZ; e++) r[e] = 0.0;
     for (int m = w.lane; m < v.cnt; m += WAVE) {
-        const double* c = v.coef + (size_t)m * v.stride + v.off;
+        const GLB_AS double* c = v.coef + (size_t)m * v.stride + v.off;
 #pragma unroll
         for (int e = 0; e < SZ; e++) r[e] += fabs(c[e]);
     }
@@ -307,8 +463,10 @@ __device__ inline void mul(Wave& w, const PZ& out, const View& a, const View& b)
     ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
     const int N = (a.cnt + 1) * (b.cnt + 1) - 1;
     double r2[SH::ASZ], r3[SH::BSZ], ia[SH::ASZ], ib[SH::BSZ], ca[SH::ASZ], cb[SH::BSZ];
+    { PROF_T0
     abs_sum<SH::ASZ>(w, a, r2);
     abs_sum<SH::BSZ>(w, b, r3);
+    PROF_ADD(PR_ABS) }
 #pragma unroll
     for (int e = 0; e < SH::ASZ; e++) { ia[e] = a.ind[a.off + e]; ca[e] = a.cen[a.off + e]; }
 #pragma unroll
@@ -326,6 +484,67 @@ __device__ inline void mul(Wave& w, const PZ& out, const View& a, const View& b)
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
     sort_reduce_emit<SH::SZ>(w, N, ev, out, base);
+}
+
+// Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):
+//     out[c] = sA[c] * a[cA[c]] + sB[c] * a[cB[c]],  c = 0..2.
+// The reference builds each entry as (double * 1x1 PZ) - (double * 1x1 PZ) -- both operands carry a's key list, so
+// simplify() just adds the two coefficients per key and prunes |.| <= threshold -- and then stack()s the three
+// entries, whose simplify() merges equal keys with disjoint non-zero entries and prunes by the 3-vector norm.
+// Because the key list never changes, the whole thing is one ordered pass over a's monomials: no sort.
+__device__ inline void cross_const(Wave& w, const PZ& out, const View& a, const double* sA, const int* cA,
+                                   const double* sB, const int* cB) {
+    double cen[3], ind[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        cen[c] = sA[c] * a.cen[cA[c]] + sB[c] * a.cen[cB[c]];
+        ind[c] = a.ind[cA[c]] * fabs(sA[c]) + a.ind[cB[c]] * fabs(sB[c]);
+    }
+    int emitted = 0;
+    bool any1 = false, any2 = false;
+    for (int base = 0; base < a.cnt; base += WAVE) {
+        const int m = base + w.lane;
+        bool keep = false;
+        double r[3] = {0, 0, 0};
+        uint64_t key = 0;
+        if (m < a.cnt) {
+            key = a.keys[m];
+            const GLB_AS double* x = a.coef + (size_t)m * a.stride + a.off;
+            const double x3[3] = {x[0], x[1], x[2]};
+            bool anyc = false;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double v = sA[c] * x3[cA[c]];
+                v += sB[c] * x3[cB[c]];
+                if (sqrt(v * v) <= w.thr) { ra1[c] += fabs(v); any1 = true; v = 0.0; } else anyc = true;
+                r[c] = v;
+            }
+            if (anyc) {
+                keep = !(sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) <= w.thr);
+                if (!keep) { ra2[0] += fabs(r[0]); ra2[1] += fabs(r[1]); ra2[2] += fabs(r[2]); any2 = true; }
+            }
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (keep) {
+            const int pos = emitted + __popcll(mk & ((1ull << w.lane) - 1ull));
+            if (pos < out.cap) {
+                out.keys[pos] = key;
+                out.coef[(size_t)pos * 3 + 0] = r[0]; out.coef[(size_t)pos * 3 + 1] = r[1]; out.coef[(size_t)pos * 3 + 2] = r[2];
+            }
+        }
+        emitted += __popcll(mk);
+    }
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (__ballot(any1) != 0ull) { ra1[0] = wave_sum(ra1[0]); ra1[1] = wave_sum(ra1[1]); ra1[2] = wave_sum(ra1[2]); }
+    if (__ballot(any2) != 0ull) { ra2[0] = wave_sum(ra2[0]); ra2[1] = wave_sum(ra2[1]); ra2[2] = wave_sum(ra2[2]); }
+    __syncthreads();
+    if (w.lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { out.cen[c] = cen[c]; out.ind[c] = (ind[c] + ra1[c]) + ra2[c]; }
+        w.cnt[out.id] = emitted;
+        if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
+    }
+    __syncthreads();
 }
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066); keys unchanged, no simplify.

@@ -55,7 +55,25 @@ class ArmourNLP:
         self.O = 0
         self.m = 0
 
+    def _pinned(self, name, shape):
+        """numpy view of a page-locked buffer owned by this object (re-used across calls of the same shape)."""
+        cache = self.__dict__.setdefault("_pin", {})
+        ent = cache.get(name)
+        if ent is None or ent[1].shape != tuple(shape):
+            if ent is not None:
+                self.L.armour_free_pinned(ent[0])
+            nbytes = int(np.prod(shape)) * 8
+            ptr = C.c_void_p()
+            check(self.L.armour_alloc_pinned(nbytes, C.byref(ptr)))
+            arr = np.ctypeslib.as_array((C.c_double * (nbytes // 8)).from_address(ptr.value)).reshape(shape)
+            ent = (ptr, arr)
+            cache[name] = ent
+        return ent[1]
+
     def close(self):
+        for ptr, _ in self.__dict__.get("_pin", {}).values():
+            self.L.armour_free_pinned(ptr)
+        self.__dict__["_pin"] = {}
         if getattr(self, "h", None):
             self.L.armour_destroy(self.h)
             self.h = None
@@ -144,10 +162,14 @@ class ArmourNLP:
         check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), None, _dp(jac)))
         return jac
 
-    def eval_g_jac(self, x):
-        g = np.zeros((self.B, self.m))
-        jac = np.zeros((self.B, self.m, self.n))
-        check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), _dp(g), _dp(jac)))
+    def eval_g_jac(self, x, pinned=False):
+        """pinned=True returns views of page-locked buffers owned by this object (valid until the next call)."""
+        if pinned:
+            k = self._pinned("k", (self.B, self.n)); k[...] = np.asarray(x, dtype=np.float64).reshape(self.B, self.n)
+            g, jac = self._pinned("g", (self.B, self.m)), self._pinned("jac", (self.B, self.m, self.n))
+        else:
+            k, g, jac = self._k(x), np.zeros((self.B, self.m)), np.zeros((self.B, self.m, self.n))
+        check(self.L.armour_eval_g_jac(self.h, _dp(k), _dp(g), _dp(jac)))
         return g, jac
 
     def eval_g_jac_device(self, d_k, d_g, d_jac, stream=0):

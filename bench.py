@@ -139,6 +139,10 @@ def main():
         for _ in range(20):
             nlp.eval_g_jac(k1)
         sync_us = (time.perf_counter() - t1) / 20 * 1e6
+        t1 = time.perf_counter()
+        for _ in range(20):
+            nlp.eval_g_jac(k1, pinned=True)
+        sync_pinned_us = (time.perf_counter() - t1) / 20 * 1e6
         out = {
             "metric": METRIC, "value": world * B * K / elapsed_max, "unit": "iters/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed_max * 1e3 / K, "higher_is_better": True,
@@ -153,7 +157,7 @@ def main():
                          "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": b_alg,
                          "launch_us": launch_us},
             "p1_set_problems_ms": {"device": p1_dev_ms, "wall": p1_wall_ms, "per_problem_device": p1_dev_ms / B},
-            "sync_host_call_us": sync_us,
+            "sync_host_call_us": {"pageable": sync_us, "pinned": sync_pinned_us},
             "table_sizes": nlp.table_sizes(),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -67,6 +67,12 @@ const char* armour_last_error(void);
 /* 1 if a HIP device is visible to this process, else 0 (never fails). */
 int armour_device_available(void);
 
+/* Optional page-locked host buffers for k / g / jac: armour_eval_g_jac DMAs straight into them instead of
+ * staging through the runtime's bounce buffers (the reference pays 8-16 blocking cudaMemcpy per callback,
+ * RT/CollisionChecking.cu:98-132). */
+int armour_alloc_pinned(uint64_t bytes, void** out);
+void armour_free_pinned(void* p);
+
 /* ---- P1: reach-set build, once per planning iteration ---- */
 /* Replaces RT/armour_main.cu:36-216 (parse armour.in, JRS, FK, RNEA x2, torque radius, half-space tables)
  * for B problems at once.  obstacles: [B][O][12], each = column-major Z=[c g1 g2 g3]
