@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libarmour_hip.so")
 
-MAXJ = 7
+MAXJ = 9   # ARMOUR_MAX_JOINTS
+MAXF = 7   # ARMOUR_MAX_FACTORS
 
 OK, EINVAL, EDEVICE, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
 
@@ -17,14 +18,14 @@ OK, EINVAL, EDEVICE, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
 class ArmourRobot(C.Structure):
     _fields_ = [
         ("num_joints", C.c_int32), ("num_factors", C.c_int32),
-        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXJ),
+        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXF),
         ("trans", C.c_double * ((MAXJ + 1) * 3)), ("rots", C.c_double * (MAXJ * 3)),
         ("mass", C.c_double * MAXJ), ("mass_uncertainty", C.c_double),
         ("com", C.c_double * (MAXJ * 3)),
         ("inertia", C.c_double * (MAXJ * 9)), ("inertia_uncertainty", C.c_double),
         ("friction", C.c_double * MAXJ), ("damping", C.c_double * MAXJ), ("armature", C.c_double * MAXJ),
-        ("state_limits_lb", C.c_double * MAXJ), ("state_limits_ub", C.c_double * MAXJ),
-        ("speed_limits", C.c_double * MAXJ), ("torque_limits", C.c_double * MAXJ),
+        ("state_limits_lb", C.c_double * MAXF), ("state_limits_ub", C.c_double * MAXF),
+        ("speed_limits", C.c_double * MAXF), ("torque_limits", C.c_double * MAXF),
         ("gravity", C.c_double),
         ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
         ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
@@ -34,7 +35,7 @@ class ArmourRobot(C.Structure):
 class ArmourParams(C.Structure):
     _fields_ = [
         ("num_time_steps", C.c_int32), ("reserved", C.c_int32),
-        ("duration", C.c_double), ("k_range", C.c_double * MAXJ),
+        ("duration", C.c_double), ("k_range", C.c_double * MAXF),
         ("simplify_threshold", C.c_double), ("t_plan", C.c_double), ("cost_scale", C.c_double),
         ("collision_violation_threshold", C.c_double), ("torque_violation_threshold", C.c_double),
     ]
@@ -49,7 +50,7 @@ class ArmourLimits(C.Structure):
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "armour_robot_kinova_gen3_no_gripper", "armour_params_default", "armour_create", "armour_destroy",
+    "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
     "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_check_feasible", "armour_get_torque_radius",
@@ -74,6 +75,8 @@ def load():
     vp = C.c_void_p
     L.armour_robot_kinova_gen3_no_gripper.argtypes = [C.POINTER(ArmourRobot)]
     L.armour_robot_kinova_gen3_no_gripper.restype = None
+    L.armour_robot_kinova_gen3_gripper.argtypes = [C.POINTER(ArmourRobot)]
+    L.armour_robot_kinova_gen3_gripper.restype = None
     L.armour_params_default.argtypes = [C.POINTER(ArmourParams), C.c_int32]
     L.armour_params_default.restype = None
     L.armour_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams), C.POINTER(ArmourLimits), C.c_int32, C.POINTER(vp)]

@@ -21,6 +21,7 @@ void armour_set_error(const char* fmt, ...) {
 extern "C" const char* armour_last_error(void) { return g_err; }
 
 extern "C" void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_no_gripper(robot); }
+extern "C" void armour_robot_kinova_gen3_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_gripper(robot); }
 extern "C" void armour_params_default(ArmourParams* params, int32_t T) { armour_fill_default_params(params, T); }
 
 extern "C" int armour_device_available(void) {
@@ -96,11 +97,17 @@ extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* param
                              int32_t device, ArmourPlanner** out) {
     if (!robot || !params || !out) { armour_set_error("armour_create: null argument"); return ARMOUR_EINVAL; }
     if (robot->num_joints < 1 || robot->num_joints > ARMOUR_MAX_JOINTS || robot->num_factors < 1 ||
-        robot->num_factors > robot->num_joints) {
-        armour_set_error("armour_create: unsupported robot (joints=%d, factors=%d; max %d)", robot->num_joints,
-                         robot->num_factors, ARMOUR_MAX_JOINTS);
+        robot->num_factors > robot->num_joints || robot->num_factors > ARMOUR_MAX_FACTORS) {
+        armour_set_error("armour_create: unsupported robot (joints=%d, factors=%d; max %d joints, %d factors -- the monomial key "
+                         "packs 9 bits per factor into 64, RT/PZsparse.h:8-21)", robot->num_joints, robot->num_factors,
+                         ARMOUR_MAX_JOINTS, ARMOUR_MAX_FACTORS);
         return ARMOUR_EINVAL;
     }
+    for (int i = 0; i < robot->num_joints; i++)
+        if ((i < robot->num_factors) != (robot->axes[i] != 0)) {
+            armour_set_error("armour_create: the actuated joints must come first and the fixed ones last (RT/Dynamics.cu:103-105)");
+            return ARMOUR_EINVAL;
+        }
     if (params->num_time_steps < 2 || (params->num_time_steps & 1)) {
         armour_set_error("armour_create: num_time_steps must be even and >= 2 (RT/Parameters.h:16)");
         return ARMOUR_EINVAL;

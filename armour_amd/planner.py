@@ -31,6 +31,12 @@ def kinova_robot():
     return r
 
 
+def kinova_gripper_robot():
+    r = ArmourRobot()
+    _lib.load().armour_robot_kinova_gen3_gripper(C.byref(r))
+    return r
+
+
 def default_params(T=128):
     p = ArmourParams()
     _lib.load().armour_params_default(C.byref(p), T)

@@ -55,6 +55,7 @@ typedef struct ArmourLimits {
 
 /* ---- robot / parameter presets (RT/KinovaWithoutGripperInfo.h, RT/Parameters.h) ---- */
 void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot);
+void armour_robot_kinova_gen3_gripper(ArmourRobot* robot);   /* RT/KinovaInfo.h: 8 links, last joint fixed */
 void armour_params_default(ArmourParams* params, int32_t num_time_steps);
 
 /* ---- lifetime ---- */

@@ -76,6 +76,26 @@ static inline void armour_fill_kinova_gen3_no_gripper(ArmourRobot* r) {
     r->K = 5.0;
 }
 
+/* Kinova Gen3 with the 1.72 kg gripper as a fixed 8th joint: RT/KinovaInfo.h:10-119 (NUM_JOINTS 8, NUM_FACTORS 7).
+ * Differs from the no-gripper arm by the extra link (mass, com, inertia, bounding box 0.07 x 0.09 x 0.07) and by the
+ * controller constants alpha = 1, M_min = 8.29938, K = 10. */
+static inline void armour_fill_kinova_gen3_gripper(ArmourRobot* r) {
+    armour_fill_kinova_gen3_no_gripper(r);
+    r->num_joints = 8;
+    r->axes[7] = 0;
+    r->trans[7 * 3 + 0] = 0; r->trans[7 * 3 + 1] = 0; r->trans[7 * 3 + 2] = -0.061525 - 0.10155;
+    r->trans[8 * 3 + 0] = 0; r->trans[8 * 3 + 1] = 0; r->trans[8 * 3 + 2] = 0;
+    r->rots[7 * 3] = ARMOUR_PI * 0.5;
+    r->mass[7] = 1.72;
+    r->com[7 * 3 + 0] = 0.00000691; r->com[7 * 3 + 1] = 0.0000044117; r->com[7 * 3 + 2] = 0.031656;
+    { const double in7[9] = {0.0004596, 0, 0, 0, 0.0005181, 0, 0, 0, 0.00036051}; memcpy(&r->inertia[7 * 9], in7, sizeof(in7)); }
+    r->link_zonotope_center[7 * 3 + 0] = 0.0; r->link_zonotope_center[7 * 3 + 1] = -0.0; r->link_zonotope_center[7 * 3 + 2] = -0.0;
+    r->link_zonotope_generators[7 * 3 + 0] = 0.07; r->link_zonotope_generators[7 * 3 + 1] = 0.09; r->link_zonotope_generators[7 * 3 + 2] = 0.07;
+    r->alpha = 1.0;
+    r->M_min = 8.29938;
+    r->K = 10.0;
+}
+
 /* RT/Parameters.h defaults except num_time_steps, which the caller chooses
  * (128 in RT/Parameters.h:17; 100 in the BASELINE configs and CMP/Parameters.h:17). */
 static inline void armour_fill_default_params(ArmourParams* p, int num_time_steps) {

@@ -21,8 +21,8 @@
 extern "C" {
 #endif
 
-#define ARMOUR_MAX_JOINTS 7   /* 9 bits of monomial key per factor: 7 factors fill a u64 (RT/PZsparse.h:8-21) */
-#define ARMOUR_MAX_FACTORS 7
+#define ARMOUR_MAX_JOINTS 9   /* links incl. fixed joints at the end of the chain (RT/KinovaInfo.h: 8; CMP/FetchInfo.h: 9) */
+#define ARMOUR_MAX_FACTORS 7  /* 9 bits of monomial key per factor: 7 factors fill a u64 (RT/PZsparse.h:8-21) */
 #define ARMOUR_OBS_DOUBLES 12 /* one obstacle = column-major Z=[c g1 g2 g3] (KSI/uarmtd_planner.m:178) */
 #define ARMOUR_NUM_PLANES 36  /* C(9,2) generator pairs of a buffered obstacle (RT/CollisionChecking.h:6-7) */
 

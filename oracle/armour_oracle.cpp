@@ -538,6 +538,7 @@ using namespace oracle;
 extern "C" {
 
 void oracle_fill_kinova(ArmourRobot* rb) { armour_fill_kinova_gen3_no_gripper(rb); }
+void oracle_fill_kinova_gripper(ArmourRobot* rb) { armour_fill_kinova_gen3_gripper(rb); }
 void oracle_fill_default_params(ArmourParams* pr, int T) { armour_fill_default_params(pr, T); }
 
 void* oracle_create(const ArmourRobot* rb, const ArmourParams* pr) {

@@ -12,20 +12,21 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-MAXJ = 7
+MAXJ = 9   # ARMOUR_MAX_JOINTS
+MAXF = 7   # ARMOUR_MAX_FACTORS
 
 
 class ArmourRobot(C.Structure):
     _fields_ = [
         ("num_joints", C.c_int32), ("num_factors", C.c_int32),
-        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXJ),
+        ("axes", C.c_int32 * MAXJ), ("continuous", C.c_int32 * MAXF),
         ("trans", C.c_double * ((MAXJ + 1) * 3)), ("rots", C.c_double * (MAXJ * 3)),
         ("mass", C.c_double * MAXJ), ("mass_uncertainty", C.c_double),
         ("com", C.c_double * (MAXJ * 3)),
         ("inertia", C.c_double * (MAXJ * 9)), ("inertia_uncertainty", C.c_double),
         ("friction", C.c_double * MAXJ), ("damping", C.c_double * MAXJ), ("armature", C.c_double * MAXJ),
-        ("state_limits_lb", C.c_double * MAXJ), ("state_limits_ub", C.c_double * MAXJ),
-        ("speed_limits", C.c_double * MAXJ), ("torque_limits", C.c_double * MAXJ),
+        ("state_limits_lb", C.c_double * MAXF), ("state_limits_ub", C.c_double * MAXF),
+        ("speed_limits", C.c_double * MAXF), ("torque_limits", C.c_double * MAXF),
         ("gravity", C.c_double),
         ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
         ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
@@ -35,7 +36,7 @@ class ArmourRobot(C.Structure):
 class ArmourParams(C.Structure):
     _fields_ = [
         ("num_time_steps", C.c_int32), ("reserved", C.c_int32),
-        ("duration", C.c_double), ("k_range", C.c_double * MAXJ),
+        ("duration", C.c_double), ("k_range", C.c_double * MAXF),
         ("simplify_threshold", C.c_double), ("t_plan", C.c_double), ("cost_scale", C.c_double),
         ("collision_violation_threshold", C.c_double), ("torque_violation_threshold", C.c_double),
     ]
@@ -94,6 +95,13 @@ def kinova_robot():
     """RT/KinovaWithoutGripperInfo.h constants (same data as include/armour_robot_kinova.h)."""
     r = ArmourRobot()
     lib().oracle_fill_kinova(C.byref(r))
+    return r
+
+
+def kinova_gripper_robot():
+    """RT/KinovaInfo.h: the arm with the 1.72 kg gripper as a fixed 8th joint."""
+    r = ArmourRobot()
+    lib().oracle_fill_kinova_gripper(C.byref(r))
     return r
 
 

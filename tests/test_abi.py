@@ -28,8 +28,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from armour_amd import _lib
     # sizes as the C compiler lays them out: 2+7+7 int32, then doubles
-    n_doubles = 24 + 21 + 7 + 1 + 21 + 63 + 1 + 7 * 3 + 7 * 4 + 1 + 21 + 21 + 5
-    assert C.sizeof(_lib.ArmourRobot) == 16 * 4 + n_doubles * 8
+    J, F = 9, 7   # ARMOUR_MAX_JOINTS, ARMOUR_MAX_FACTORS
+    n_doubles = (J + 1) * 3 + J * 3 + J + 1 + J * 3 + J * 9 + 1 + J * 3 + F * 4 + 1 + J * 3 + J * 3 + 5
+    assert C.sizeof(_lib.ArmourRobot) == (2 + J + F) * 4 + n_doubles * 8
     assert C.sizeof(_lib.ArmourParams) == 8 + 8 * (1 + 7 + 5)
     assert C.sizeof(_lib.ArmourLimits) == 24
 
@@ -38,10 +39,13 @@ def test_presets_match_reference_constants():
     from armour_amd import planner
     r = planner.kinova_robot()
     assert (r.num_joints, r.num_factors) == (7, 7)
-    assert list(r.axes) == [3] * 7
+    assert list(r.axes)[:7] == [3] * 7
     assert abs(r.armature[1] - 11.9962024615303644) < 1e-15
     assert abs(r.trans[2] - 0.15643) < 1e-15 and abs(r.trans[3 * 6 + 1] + 0.10593) < 1e-15
     assert r.torque_limits[4] == 29.4 and r.state_limits_ub[3] == 2.66
+    rg = planner.kinova_gripper_robot()   # RT/KinovaInfo.h
+    assert (rg.num_joints, rg.num_factors, rg.axes[7]) == (8, 7, 0) and rg.mass[7] == 1.72 and rg.K == 10.0
+    assert abs(rg.trans[7 * 3 + 2] + 0.163075) < 1e-15 and rg.link_zonotope_generators[7 * 3 + 1] == 0.09
     p = planner.default_params(100)
     assert p.num_time_steps == 100 and p.simplify_threshold == 5e-4 and p.t_plan == 0.5
 

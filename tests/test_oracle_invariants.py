@@ -25,11 +25,11 @@ def rot_z(q):
 def robot_arrays():
     from oracle.cpu_oracle import kinova_robot
     r = kinova_robot()
-    tr = np.array(r.trans).reshape(8, 3)
-    rots = np.array(r.rots).reshape(7, 3)
-    return dict(trans=tr, rots=rots, mass=np.array(r.mass), com=np.array(r.com).reshape(7, 3),
-                inertia=np.array(r.inertia).reshape(7, 3, 3), armature=np.array(r.armature), gravity=r.gravity,
-                zc=np.array(r.link_zonotope_center).reshape(7, 3))
+    tr = np.array(r.trans)[:24].reshape(8, 3)
+    rots = np.array(r.rots)[:21].reshape(7, 3)
+    return dict(trans=tr, rots=rots, mass=np.array(r.mass)[:7], com=np.array(r.com)[:21].reshape(7, 3),
+                inertia=np.array(r.inertia)[:63].reshape(7, 3, 3), armature=np.array(r.armature)[:7], gravity=r.gravity,
+                zc=np.array(r.link_zonotope_center)[:21].reshape(7, 3))
 
 
 def bezier(q0, qd0, qdd0, k_actual, s):

@@ -170,3 +170,26 @@ def test_file_protocol_planning_iteration(tmp_path, sample_problem):
     assert np.allclose(np.loadtxt(tmp_path / "armour_joint_position_radius.out").reshape(128, 7, 3, 6), o.link_generators(), rtol=1e-9, atol=1e-12)
     k_opt, ms = fp.read_armour_out(tmp_path / "armour.out")
     assert (k_opt is not None) == feasible and ms > 0
+
+
+def test_kinova_with_gripper_payload():
+    """RT/KinovaInfo.h: 8 links (7 actuated + the 1.72 kg gripper on a fixed joint), 3 % mass / inertia uncertainty,
+    many obstacles -- the closest configuration the reference's RT path supports to BASELINE configs[4]
+    (its 7-factor u64 key cannot hold an 8-factor arm, and CMP/FetchInfo.h has no link zonotopes)."""
+    from armour_amd.planner import ArmourNLP, kinova_gripper_robot
+    from armour_amd.worlds import random_k, random_problem
+    from oracle.cpu_oracle import Oracle
+    from oracle.cpu_oracle import kinova_gripper_robot as oracle_robot
+    T, O = 100, 100
+    p = random_problem(8, O)
+    nlp = ArmourNLP(robot=kinova_gripper_robot(), T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    o = Oracle(robot=oracle_robot(), T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert nlp.J == 8 and nlp.m == 7 * T + 8 * T * O + 28 == o.m
+    _compare_tables(nlp, [o])
+    for k in (PZ_TESTS_K, random_k(5, 1)[0]):
+        g, jac = nlp.eval_g_jac(k)
+        gr, jr = o.eval_g_jac(k)
+        assert np.abs(g[0] - gr).max() <= G_TOL and np.abs(jac[0] - jr).max() <= J_TOL
+    # the gripper makes the robust-input radius larger than on the bare arm for the same motion
+    bare = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"][:1])
+    assert nlp.torque_radius()[0].mean() != bare.torque_radius()[0].mean()
