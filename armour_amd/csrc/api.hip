@@ -378,7 +378,13 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     if (rc != ARMOUR_OK) return rc;
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // spin on the stream instead of sleeping in hipStreamSynchronize: the whole call is tens of microseconds and an
+    // interrupt-driven wake-up would dominate it
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { armour_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+    }
     return ARMOUR_OK;
 }
 

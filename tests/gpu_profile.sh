@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $OLDPWD/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $OLDPWD/bench.py --no-cpu-baseline --steps 200 --warmup 20 "$@" > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $OLDPWD/bench.py --no-cpu-baseline --steps 200 --warmup 20 "$@" > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $OLDPWD/bench.py --no-cpu-baseline --headline-only "$@" > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $OLDPWD/bench.py --no-cpu-baseline --headline-only --steps 200 --warmup 20 "$@" > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $OLDPWD/bench.py --no-cpu-baseline --headline-only --steps 200 --warmup 20 "$@" > $OUT/bench_pmc_write.log 2>&1
 cd $OLDPWD
 find $OUT -name "*.csv" | head -20
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
