@@ -65,7 +65,7 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_tq_indep, nt));
     TRY(dev_alloc(&h->d_tq_keys, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_tq_coeff, nt * h->lim.torque_monomials));
-    TRY(dev_alloc(&h->d_planes, (size_t)nb * ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * h->J * h->T * (size_t)no));
+    TRY(dev_alloc(&h->d_planes, (size_t)nb * armour_planes_per_problem(h->J * h->T * no)));
     TRY(dev_alloc(&h->d_plane_skip, (size_t)nb));
     TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
@@ -237,19 +237,20 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
         tc[i] = torque_center[i * 2]; ti[i] = torque_center[i * 2 + 1];
         for (int mo = 0; mo < torque_count[i]; mo++) { tk[i * capT + mo] = (uint32_t)torque_keys[i * cap_t + mo]; tco[i * capT + mo] = torque_coeffs[i * cap_t + mo]; }
     }
-    // reference layout [b][t][l][o][p] -> planes[b][c][p][(l*T+t)*O+o]
-    const size_t Q = (size_t)h->Q;
-    std::vector<double> pl((size_t)B * 5 * 36 * Q);
+    // reference layout [b][t][l][o][p] -> tiled device layout (common.h: armour_plane_index)
+    const size_t ppp = armour_planes_per_problem(h->Q);
+    std::vector<double> pl((size_t)B * ppp, 0.0);
     for (int b = 0; b < B; b++)
         for (int t = 0; t < T; t++)
             for (int l = 0; l < J; l++)
                 for (int o = 0; o < O; o++)
                     for (int p = 0; p < 36; p++) {
                         const size_t src = ((((size_t)b * T + t) * J + l) * O + o) * 36 + p;
-                        const size_t q = ((size_t)l * T + t) * O + o;
-                        double* base = &pl[(size_t)b * 5 * 36 * Q + (size_t)p * Q + q];
-                        base[0 * 36 * Q] = A[src * 3 + 0]; base[1 * 36 * Q] = A[src * 3 + 1]; base[2 * 36 * Q] = A[src * 3 + 2];
-                        base[3 * 36 * Q] = d[src]; base[4 * 36 * Q] = delta[src];
+                        const int q = (l * T + t) * O + o;
+                        double* base = &pl[(size_t)b * ppp];
+                        base[armour_plane_index(h->Q, q, p, 0)] = A[src * 3 + 0]; base[armour_plane_index(h->Q, q, p, 1)] = A[src * 3 + 1];
+                        base[armour_plane_index(h->Q, q, p, 2)] = A[src * 3 + 2];
+                        base[armour_plane_index(h->Q, q, p, 3)] = d[src]; base[armour_plane_index(h->Q, q, p, 4)] = delta[src];
                     }
 #define UP(dst, vec) HIPCHK(hipMemcpy(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
     HIPCHK(hipMemcpy(h->d_link_count, link_count, nl * sizeof(int), hipMemcpyHostToDevice));
@@ -484,8 +485,8 @@ extern "C" int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, do
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int B = h->B, T = h->T, J = h->J, O = h->O;
-    const size_t Q = (size_t)h->Q;
-    std::vector<double> pl((size_t)B * 5 * 36 * Q);
+    const size_t ppp = armour_planes_per_problem(h->Q);
+    std::vector<double> pl(h->Q > 0 ? (size_t)B * ppp : 0);
     if (pl.empty()) return ARMOUR_OK;
     HIPCHK(hipMemcpy(pl.data(), h->d_planes, pl.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int b = 0; b < B; b++)
@@ -494,11 +495,11 @@ extern "C" int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, do
                 for (int o = 0; o < O; o++)
                     for (int p = 0; p < 36; p++) {
                         const size_t dst = ((((size_t)b * T + t) * J + l) * O + o) * 36 + p;
-                        const size_t q = ((size_t)l * T + t) * O + o;
-                        const double* base = &pl[(size_t)b * 5 * 36 * Q + (size_t)p * Q + q];
-                        if (A) { A[dst * 3 + 0] = base[0]; A[dst * 3 + 1] = base[1 * 36 * Q]; A[dst * 3 + 2] = base[2 * 36 * Q]; }
-                        if (d) d[dst] = base[3 * 36 * Q];
-                        if (delta) delta[dst] = base[4 * 36 * Q];
+                        const int q = (l * T + t) * O + o;
+                        const double* base = &pl[(size_t)b * ppp];
+                        if (A) { A[dst * 3 + 0] = base[armour_plane_index(h->Q, q, p, 0)]; A[dst * 3 + 1] = base[armour_plane_index(h->Q, q, p, 1)]; A[dst * 3 + 2] = base[armour_plane_index(h->Q, q, p, 2)]; }
+                        if (d) d[dst] = base[armour_plane_index(h->Q, q, p, 3)];
+                        if (delta) delta[dst] = base[armour_plane_index(h->Q, q, p, 4)];
                     }
     return ARMOUR_OK;
 }

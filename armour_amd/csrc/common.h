@@ -16,6 +16,14 @@
 
 void armour_set_error(const char* fmt, ...);
 
+// doubles per problem in the plane table and the offset (within one problem) of component c of plane p of row q.
+// planes[b][c][p][q]: the row index q = (l*T + t)*O + o is the fastest axis, so a wave reads 64 consecutive rows with
+// one coalesced 512-B request per (component, plane) and consecutive planes / components of a row are Q*8 / 36*Q*8
+// bytes apart -- a wave's 45 requests land on 45 different HBM pages/channels.  (A tiled variant that made each
+// block's 92 KB contiguous was measured 18 % slower at B=128, O=50: it concentrates a block on few channels.)
+__host__ __device__ inline size_t armour_planes_per_problem(int Q) { return (size_t)ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * (size_t)Q; }
+__host__ __device__ inline size_t armour_plane_index(int Q, int q, int p, int c) { return ((size_t)c * ARMOUR_NPLANES + p) * (size_t)Q + q; }
+
 #define HIPCHK(expr)                                                                                     \
     do {                                                                                                 \
         hipError_t e__ = (expr);                                                                         \
@@ -29,10 +37,9 @@ void armour_set_error(const char* fmt, ...);
 //
 // Final link / torque PZs hold only k-dependent monomials (key < 2^(2n)); keys are stored as u32.
 //   link  index: (b*J + l)*T + t     torque index: (b*n + j)*T + t
-// Half-space table: planes[b][c][p][q], c in {Ax,Ay,Az,d,delta}, p in [0,36), q = (l*T + t)*O + o --
-// the obstacle/time/link index is the fastest axis so that a wave reads 64 consecutive q with one
-// coalesced 512-B request per component and plane, and so that q is also the output row order of the
-// collision block (RT/NLPclass.cu:117-164: g[nT + (l*T+t)*O + o]).
+// Half-space table: planes[b][c][p][q], c in {Ax,Ay,Az,d,delta}, p in [0,36), q = (l*T + t)*O + o -- the row index is
+// the fastest axis and is also the output row order of the collision block (RT/NLPclass.cu:117-164:
+// g[nT + (l*T+t)*O + o]).  armour_plane_index() is the single definition of this layout.
 struct P2Tables {
     int B, T, J, n, O, Q, m;
     int capL, capT;

@@ -734,8 +734,7 @@ __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double
             for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
             for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
         }
-        double* out = planes + (size_t)b * 5 * 36 * Q + q;
-        const size_t cs = (size_t)36 * Q;
+        double* out = planes + (size_t)b * armour_planes_per_problem(Q);
         int p = 0;
         skip = 0ull;
         for (int a_id = 0; a_id < 8; a_id++)
@@ -748,10 +747,9 @@ __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double
                 if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
                 double dl = 0.0;
                 for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
-                const size_t po = (size_t)p * Q;
-                out[po] = C0; out[cs + po] = C1; out[2 * cs + po] = C2;
-                out[3 * cs + po] = C0 * c[0] + C1 * c[1] + C2 * c[2];
-                out[4 * cs + po] = dl;
+                out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
+                out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+                out[armour_plane_index(Q, q, p, 4)] = dl;
                 Cs[p][0] = C0; Cs[p][1] = C1; Cs[p][2] = C2;
                 bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
                 for (int e = 0; e < p && !red; e++)
