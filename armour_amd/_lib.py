@@ -48,6 +48,16 @@ class ArmourLimits(C.Structure):
     ]
 
 
+class ArmourSolveOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("max_line_search", C.c_int32), ("tolerance", C.c_double),
+                ("max_wall_time_s", C.c_double), ("reserved", C.c_double * 4)]
+
+
+class ArmourSolveResult(C.Structure):
+    _fields_ = [("k_opt", C.c_double * MAXF), ("cost", C.c_double), ("max_violation", C.c_double), ("feasible", C.c_int32),
+                ("iterations", C.c_int32), ("evaluations", C.c_int32), ("status", C.c_int32), ("time_ms", C.c_double)]
+
+
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
@@ -55,6 +65,7 @@ EXPORTS = [
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
+    "armour_solve_options_default", "armour_solve", "armour_debug_qp",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
 ]
 
@@ -95,6 +106,10 @@ def load():
     L.armour_eval_g_jac_device.argtypes = [vp, vp, vp, vp, vp]
     L.armour_eval_g_jac_device_steps.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     L.armour_check_feasible.argtypes = [vp, dp, ip]
+    L.armour_solve_options_default.argtypes = [C.POINTER(ArmourSolveOptions)]
+    L.armour_solve_options_default.restype = None
+    L.armour_solve.argtypes = [vp, C.POINTER(ArmourSolveOptions), C.POINTER(ArmourSolveResult)]
+    L.armour_debug_qp.argtypes = [C.c_int32, dp, dp, C.c_int32, dp, dp, dp, dp, ip]
     L.armour_get_torque_radius.argtypes = [vp, dp]
     L.armour_get_link_generators.argtypes = [vp, dp]
     L.armour_get_link_centers.argtypes = [vp, dp, dp]

@@ -1,0 +1,385 @@
+// armour_solve: the NLP solve of one planning iteration on top of the device callbacks.
+//
+// Replaces, for this library, what the reference delegates to IPOPT (RT/armour_main.cu:237-304: OptimizeTNLP with
+// tol 1e-4, a wall-time limit, L-BFGS Hessian, start x = 0) and armtd_NLP::finalize_solution
+// (RT/NLPclass.cu:422-538).  IPOPT / HSL are not available here, so this is a from-scratch solver sized for the
+// problem ARMOUR actually poses: n = 7 variables in [-1,1], an exactly quadratic cost (q(t_plan) is affine in k, so
+// the Hessian is the constant diagonal 2*scale*(dq/dk)^2) and m ~ 1e4 inequality rows whose values and dense Jacobian
+// come from ONE fused device launch per iterate for all B problems of the handle:
+//
+//   SQP:  d = argmin grad_f.d + 1/2 d'Hd   s.t.  g_l <= g + J d <= g_u,  -1 <= x + d <= 1      (dense QP, n = 7)
+//         L1-merit backtracking line search (trial points need eval_g only), start x = 0
+//   QP:   Goldfarb-Idnani dual active-set method; with n <= 7 the operators H = G^-1(I - N N*) and
+//         N* = (N'G^-1N)^-1 N'G^-1 are re-formed from the <= n active normals at every step instead of being
+//         updated by Givens rotations.
+//
+// Host code only: the arithmetic of the hot path (eval_g / eval_jac_g) stays in p2_eval.hip.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "bezier.h"
+#include "common.h"
+
+namespace {
+
+constexpr int NV = ARMOUR_MAX_FACTORS;
+constexpr double kInf = 1e300;
+
+// ---- tiny dense helpers (q <= NV) ----
+// solve M y = rhs for symmetric positive definite M (q x q, row-major NV stride) by Cholesky; false if not SPD
+bool spd_solve(const double* M, int q, const double* rhs, double* y) {
+    double L[NV][NV];
+    for (int i = 0; i < q; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = M[i * NV + j];
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (s <= 1e-14 * std::fabs(M[i * NV + i]) || s <= 0) return false;
+                L[i][i] = std::sqrt(s);
+            } else {
+                L[i][j] = s / L[j][j];
+            }
+        }
+    double t[NV];
+    for (int i = 0; i < q; i++) {
+        double s = rhs[i];
+        for (int k = 0; k < i; k++) s -= L[i][k] * t[k];
+        t[i] = s / L[i][i];
+    }
+    for (int i = q - 1; i >= 0; i--) {
+        double s = t[i];
+        for (int k = i + 1; k < q; k++) s -= L[k][i] * y[k];
+        y[i] = s / L[i][i];
+    }
+    return true;
+}
+
+// One inequality a'x >= b of the QP.  Rows come from three sources: upper sides (-J_i d >= g_i - hi_i), lower sides
+// (J_i d >= lo_i - g_i) and the variable bounds.
+struct QpRow {
+    double a[NV];
+    double b;
+};
+
+struct QpResult {
+    double x[NV];
+    double max_mult;  // largest multiplier (for the merit penalty)
+    int iterations;
+    bool feasible;
+};
+
+// Goldfarb-Idnani for  min 1/2 x'Gx + g0'x  s.t.  a_i'x >= b_i,  G = diag(Gd) > 0.
+QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = 400) {
+    QpResult res;
+    res.iterations = 0; res.feasible = true; res.max_mult = 0;
+    double x[NV];
+    for (int j = 0; j < n; j++) x[j] = -g0[j] / Gd[j];
+    int A[NV];       // active row ids
+    double u[NV + 1];  // multipliers of the active rows (+ the entering one)
+    int q = 0;
+    const int m = (int)rows.size();
+    std::vector<char> is_active(m, 0), excluded(m, 0);
+    for (;;) {
+        // most violated inactive row
+        int p = -1;
+        double worst = -1e-10;
+        for (int i = 0; i < m; i++) {
+            if (is_active[i] || excluded[i]) continue;
+            double s = -rows[i].b;
+            for (int j = 0; j < n; j++) s += rows[i].a[j] * x[j];
+            // scale-free test: violation relative to the row norm
+            if (s < worst) { worst = s; p = i; }
+        }
+        if (p < 0) break;
+        if (++res.iterations > max_iter) { res.feasible = false; break; }
+        const double* np = rows[p].a;
+        double up = 0.0;
+        bool added = false;
+        for (int guard = 0; guard < 4 * NV + 8 && !added; guard++) {
+            // r = N* np,  z = G^-1 (np - N r)
+            double r[NV] = {0}, z[NV];
+            if (q > 0) {
+                double M[NV * NV], rhs[NV];
+                for (int i = 0; i < q; i++) {
+                    for (int k = 0; k <= i; k++) {
+                        double s = 0;
+                        for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * rows[A[k]].a[j] / Gd[j];
+                        M[i * NV + k] = s; M[k * NV + i] = s;
+                    }
+                    double s = 0;
+                    for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * np[j] / Gd[j];
+                    rhs[i] = s;
+                }
+                if (!spd_solve(M, q, rhs, r)) { excluded[p] = 1; break; }  // dependent active set: skip this row
+            }
+            double zz = 0, znp = 0;
+            for (int j = 0; j < n; j++) {
+                double s = np[j];
+                for (int i = 0; i < q; i++) s -= rows[A[i]].a[j] * r[i];
+                z[j] = s / Gd[j];
+                zz += z[j] * z[j];
+                znp += z[j] * np[j];
+            }
+            // step lengths
+            double t1 = kInf;
+            int l = -1;
+            for (int i = 0; i < q; i++)
+                if (r[i] > 1e-14 && u[i] / r[i] < t1) { t1 = u[i] / r[i]; l = i; }
+            double sp = -rows[p].b;
+            for (int j = 0; j < n; j++) sp += np[j] * x[j];
+            double t2 = kInf;
+            if (zz > 1e-24 && znp > 1e-16) t2 = -sp / znp;
+            if (t2 < 0) t2 = 0;
+            const double t = t1 < t2 ? t1 : t2;
+            if (t >= kInf) { res.feasible = false; break; }
+            if (t2 >= kInf) {  // dual step only, drop the blocking row
+                for (int i = 0; i < q; i++) u[i] -= t * r[i];
+                up += t;
+                is_active[A[l]] = 0;
+                for (int i = l; i < q - 1; i++) { A[i] = A[i + 1]; u[i] = u[i + 1]; }
+                q--;
+                continue;
+            }
+            for (int j = 0; j < n; j++) x[j] += t * z[j];
+            for (int i = 0; i < q; i++) u[i] -= t * r[i];
+            up += t;
+            if (t == t2) {  // full step: the row becomes active
+                if (q >= n) { res.feasible = false; break; }
+                A[q] = p; u[q] = up; q++;
+                is_active[p] = 1;
+                added = true;
+            } else {        // partial step: drop the blocking row and try again
+                is_active[A[l]] = 0;
+                for (int i = l; i < q - 1; i++) { A[i] = A[i + 1]; u[i] = u[i + 1]; }
+                q--;
+            }
+        }
+        if (!res.feasible) break;
+        if (!added && !excluded[p]) { excluded[p] = 1; }  // could not make progress on this row
+    }
+    for (int j = 0; j < n; j++) res.x[j] = x[j];
+    for (int i = 0; i < q; i++) if (u[i] > res.max_mult) res.max_mult = u[i];
+    // excluded rows that remain violated mean the linearisation is inconsistent
+    for (int i = 0; i < m && res.feasible; i++) {
+        if (!excluded[i]) continue;
+        double s = -rows[i].b;
+        for (int j = 0; j < n; j++) s += rows[i].a[j] * x[j];
+        if (s < -1e-7) res.feasible = false;
+    }
+    return res;
+}
+
+struct ProblemState {
+    double x[NV], f, gradf[NV], viol, mu;
+    int iters = 0, evals = 0, status = 0;  // 0 running, 1 converged, 2 max iterations, 3 QP infeasible, 4 line search failed, 5 time limit
+    bool done = false;
+};
+
+double violation(const double* g, const double* lo, const double* hi, int m) {
+    double v = 0;
+    for (int i = 0; i < m; i++) {
+        if (g[i] > hi[i]) v += g[i] - hi[i];
+        else if (g[i] < lo[i]) v += lo[i] - g[i];
+    }
+    return v;
+}
+
+}  // namespace
+
+extern "C" void armour_solve_options_default(ArmourSolveOptions* o) {
+    memset(o, 0, sizeof(*o));
+    o->max_iterations = 60;
+    o->max_line_search = 12;
+    o->tolerance = 1e-4;       // IPOPT_OPTIMIZATION_TOLERANCE, RT/Parameters.h:50
+    o->max_wall_time_s = 0.0;  // 0 = no limit (the reference passes 0.5 s - t(P1) - 0.05 s, RT/armour_main.cu:227-229)
+}
+
+// test hook: the QP solver alone.  rows: lo <= A x <= hi (|bound| >= 1e18 = absent).  Returns 0 / ARMOUR_EINVAL; feasible flag in *feasible.
+extern "C" int armour_debug_qp(int32_t n, const double* Gd, const double* g0, int32_t m, const double* Amat, const double* lo,
+                               const double* hi, double* x, int32_t* feasible) {
+    if (n < 1 || n > NV || m < 0) { armour_set_error("armour_debug_qp: bad size"); return ARMOUR_EINVAL; }
+    std::vector<QpRow> rows;
+    for (int i = 0; i < m; i++) {
+        if (hi[i] < 1e18) { QpRow r; for (int j = 0; j < n; j++) r.a[j] = -Amat[i * n + j]; r.b = -hi[i]; rows.push_back(r); }
+        if (lo[i] > -1e18) { QpRow r; for (int j = 0; j < n; j++) r.a[j] = Amat[i * n + j]; r.b = lo[i]; rows.push_back(r); }
+    }
+    const QpResult q = solve_qp(n, Gd, g0, rows);
+    for (int j = 0; j < n; j++) x[j] = q.x[j];
+    *feasible = q.feasible ? 1 : 0;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, ArmourSolveResult* results) {
+    if (!h || !results) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    if (!h->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
+    ArmourSolveOptions opt;
+    if (opt_in) opt = *opt_in; else armour_solve_options_default(&opt);
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int B = h->B, n = h->n, m = h->m;
+    // pinned host mirrors of k, g, jac for all problems
+    double *hk = nullptr, *hg = nullptr, *hj = nullptr;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipHostMalloc((void**)&hk, (size_t)B * n * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&hg, (size_t)B * m * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&hj, (size_t)B * m * n * sizeof(double), hipHostMallocDefault));
+    struct Guard { double *a, *b, *c; ~Guard() { (void)hipHostFree(a); (void)hipHostFree(b); (void)hipHostFree(c); } } guard{hk, hg, hj};
+
+    std::vector<double> xl(n), xu(n), gl((size_t)B * m), gu((size_t)B * m);
+    int rc = armour_get_bounds(h, xl.data(), xu.data(), gl.data(), gu.data());
+    if (rc != ARMOUR_OK) return rc;
+    // constant diagonal Hessian of the cost: f = scale * sum (q_des - q0 - ... - c*kr*x)^2  (RT/NLPclass.cu:207-236)
+    const double tp = h->params.t_plan;
+    double Hd[NV];
+    for (int j = 0; j < n; j++) {
+        const double dk = (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[j];
+        Hd[j] = 2.0 * h->params.cost_scale * dk * dk;
+        if (Hd[j] < 1e-12) Hd[j] = 1e-12;
+    }
+    std::vector<ProblemState> st(B);
+    std::vector<double> fb(B), gfb((size_t)B * n);
+    for (int b = 0; b < B; b++) { for (int j = 0; j < n; j++) { st[b].x[j] = 0.0; hk[b * n + j] = 0.0; } st[b].mu = 1.0; }  // get_starting_point: x = 0
+
+    auto eval = [&](bool want_jac) -> int {
+        int r = armour_eval_g_jac(h, hk, hg, want_jac ? hj : nullptr);
+        return r;
+    };
+    auto time_left = [&]() {
+        if (opt.max_wall_time_s <= 0) return true;
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < opt.max_wall_time_s;
+    };
+
+    if ((rc = eval(true)) != ARMOUR_OK) return rc;
+    if ((rc = armour_eval_f(h, hk, fb.data())) != ARMOUR_OK) return rc;
+    if ((rc = armour_eval_grad_f(h, hk, gfb.data())) != ARMOUR_OK) return rc;
+    for (int b = 0; b < B; b++) {
+        st[b].f = fb[b];
+        for (int j = 0; j < n; j++) st[b].gradf[j] = gfb[(size_t)b * n + j];
+        st[b].viol = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+        st[b].evals = 1;
+    }
+    std::vector<double> dstep((size_t)B * n), alpha(B), dphi(B), phi0(B);
+    std::vector<char> searching(B);
+    const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)B));
+
+    for (int it = 0; it < opt.max_iterations; it++) {
+        bool any = false;
+        for (int b = 0; b < B; b++) any = any || !st[b].done;
+        if (!any) break;
+        if (!time_left()) { for (int b = 0; b < B; b++) if (!st[b].done) { st[b].done = true; st[b].status = 5; } break; }
+        // ---- QP subproblems (host threads over problems) ----
+        auto work = [&](int b0, int b1) {
+            std::vector<QpRow> rows;
+            for (int b = b0; b < b1; b++) {
+                ProblemState& s = st[b];
+                if (s.done) continue;
+                const double* g = hg + (size_t)b * m;
+                const double* J = hj + (size_t)b * m * n;
+                const double* lo = gl.data() + (size_t)b * m;
+                const double* hi = gu.data() + (size_t)b * m;
+                QpResult qp;
+                double sigma = 0.0;  // fraction of the current violation a row may keep (elastic retry)
+                for (int attempt = 0; attempt < 4; attempt++) {
+                    rows.clear();
+                    for (int i = 0; i < m; i++) {
+                        const double* Ji = J + (size_t)i * n;
+                        double l1 = 0;
+                        for (int j = 0; j < n; j++) l1 += std::fabs(Ji[j]);
+                        // a row that cannot become active for any |d|_inf <= 2 is left out
+                        if (hi[i] < 1e18 && g[i] + 2.0 * l1 > hi[i]) {
+                            QpRow r; for (int j = 0; j < n; j++) r.a[j] = -Ji[j];
+                            const double v = g[i] - hi[i];
+                            r.b = v - (v > 0 ? sigma * v : 0.0); rows.push_back(r);
+                        }
+                        if (lo[i] > -1e18 && g[i] - 2.0 * l1 < lo[i]) {
+                            QpRow r; for (int j = 0; j < n; j++) r.a[j] = Ji[j];
+                            const double v = lo[i] - g[i];
+                            r.b = v - (v > 0 ? sigma * v : 0.0); rows.push_back(r);
+                        }
+                    }
+                    for (int j = 0; j < n; j++) {
+                        QpRow r; memset(&r, 0, sizeof(r)); r.a[j] = 1.0; r.b = xl[j] - s.x[j]; rows.push_back(r);
+                        QpRow r2; memset(&r2, 0, sizeof(r2)); r2.a[j] = -1.0; r2.b = -(xu[j] - s.x[j]); rows.push_back(r2);
+                    }
+                    qp = solve_qp(n, Hd, s.gradf, rows);
+                    if (qp.feasible) break;
+                    sigma = attempt == 0 ? 0.5 : attempt == 1 ? 0.9 : 0.99;
+                }
+                if (!qp.feasible) { s.done = true; s.status = 3; continue; }
+                double dn = 0, gd = 0;
+                for (int j = 0; j < n; j++) { dstep[(size_t)b * n + j] = qp.x[j]; dn = std::fmax(dn, std::fabs(qp.x[j])); gd += s.gradf[j] * qp.x[j]; }
+                if (dn <= opt.tolerance * 1e-2 || (dn <= opt.tolerance && s.viol <= opt.tolerance)) { s.done = true; s.status = 1; continue; }
+                s.mu = std::fmax(s.mu, 1.5 * qp.max_mult + 1e-3);
+                phi0[b] = s.f + s.mu * s.viol;
+                dphi[b] = gd - s.mu * (1.0 - sigma) * s.viol;
+                if (dphi[b] > -1e-14) dphi[b] = -1e-14;
+                alpha[b] = 1.0;
+                searching[b] = 1;
+            }
+        };
+        for (int b = 0; b < B; b++) searching[b] = 0;
+        if (nthreads <= 1) work(0, B);
+        else {
+            std::vector<std::thread> th;
+            const int per = (B + (int)nthreads - 1) / (int)nthreads;
+            for (unsigned tI = 0; tI < nthreads; tI++) { const int b0 = (int)tI * per, b1 = std::min(B, b0 + per); if (b0 < b1) th.emplace_back(work, b0, b1); }
+            for (auto& t : th) t.join();
+        }
+        // ---- L1-merit backtracking line search, all problems in lock step (one eval_g launch per trial) ----
+        for (int ls = 0; ls <= opt.max_line_search; ls++) {
+            bool need = false;
+            for (int b = 0; b < B; b++) {
+                for (int j = 0; j < n; j++) hk[b * n + j] = st[b].x[j] + (searching[b] ? alpha[b] * dstep[(size_t)b * n + j] : 0.0);
+                need = need || searching[b];
+            }
+            if (!need) break;
+            if ((rc = eval(false)) != ARMOUR_OK) return rc;
+            if ((rc = armour_eval_f(h, hk, fb.data())) != ARMOUR_OK) return rc;
+            for (int b = 0; b < B; b++) {
+                if (!searching[b]) continue;
+                st[b].evals++;
+                const double v = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+                const double phi = fb[b] + st[b].mu * v;
+                if (phi <= phi0[b] + 1e-4 * alpha[b] * dphi[b] || ls == opt.max_line_search) {
+                    if (ls == opt.max_line_search && phi > phi0[b]) { st[b].done = true; st[b].status = 4; searching[b] = 0; continue; }
+                    for (int j = 0; j < n; j++) st[b].x[j] = hk[b * n + j];
+                    st[b].f = fb[b]; st[b].viol = v; searching[b] = 0; st[b].iters++;
+                } else {
+                    alpha[b] *= 0.5;
+                }
+            }
+        }
+        // ---- new linearisation at the accepted points ----
+        for (int b = 0; b < B; b++) for (int j = 0; j < n; j++) hk[b * n + j] = st[b].x[j];
+        if ((rc = eval(true)) != ARMOUR_OK) return rc;
+        if ((rc = armour_eval_grad_f(h, hk, gfb.data())) != ARMOUR_OK) return rc;
+        for (int b = 0; b < B; b++) {
+            if (st[b].done) continue;
+            st[b].evals++;
+            for (int j = 0; j < n; j++) st[b].gradf[j] = gfb[(size_t)b * n + j];
+            st[b].viol = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+        }
+    }
+    // ---- finalize_solution: feasibility re-check with the reference's slack thresholds ----
+    for (int b = 0; b < B; b++) for (int j = 0; j < n; j++) hk[b * n + j] = st[b].x[j];
+    if ((rc = eval(false)) != ARMOUR_OK) return rc;
+    if ((rc = armour_eval_f(h, hk, fb.data())) != ARMOUR_OK) return rc;
+    std::vector<int32_t> feas(B);
+    if ((rc = armour_check_feasible(h, hg, feas.data())) != ARMOUR_OK) return rc;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int b = 0; b < B; b++) {
+        ArmourSolveResult& r = results[b];
+        memset(&r, 0, sizeof(r));
+        for (int j = 0; j < n; j++) r.k_opt[j] = st[b].x[j];
+        r.cost = fb[b];
+        r.max_violation = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+        r.feasible = feas[b];
+        r.iterations = st[b].iters;
+        r.evaluations = st[b].evals + 1;
+        r.status = st[b].done ? st[b].status : 2;
+        r.time_ms = ms;
+    }
+    return ARMOUR_OK;
+}

@@ -93,17 +93,21 @@ def read_armour_out(path, n=7):
 
 
 def run_planning_iteration(nlp, dirname, k=None):
-    """One pass over the file protocol with the device library: read armour.in, build the reach sets, evaluate the
-    constraints at `k` (the starting point x = 0 when None) and write the five output files.  The NLP solve that
-    picks k is outside the hot path (IPOPT in the reference, RT/armour_main.cu:237-273); a caller that has a solver
-    passes its k_opt here."""
+    """One pass over the file protocol with the device library: read armour.in, build the reach sets, solve the NLP
+    (armour_solve; or evaluate at a caller-supplied `k`) and write the five output files -- what the `armour_main`
+    binary (armour_amd/csrc/armour_main.cpp) does natively."""
     import time
     t0 = time.perf_counter()
     p = parse_armour_in(os.path.join(dirname, IN_NAME), n=nlp.n)
     nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
-    x = np.zeros(nlp.n) if k is None else np.asarray(k, dtype=np.float64)
-    g = nlp.eval_g(x)
-    feasible = bool(nlp.finalize_solution(g)[0])
+    if k is None:
+        sol = nlp.solve()[0]          # OptimizeTNLP + finalize_solution on the device callbacks
+        x, feasible = sol["k_opt"], sol["feasible"]
+        g = nlp.eval_g(x)
+    else:
+        x = np.asarray(k, dtype=np.float64)
+        g = nlp.eval_g(x)
+        feasible = bool(nlp.finalize_solution(g)[0])
     cen = nlp.link_centers(x)[0]
     ms = (time.perf_counter() - t0) * 1e3
     write_outputs(dirname, x if feasible else None, ms, cen, nlp.link_generators()[0], nlp.torque_radius()[0], g[0])

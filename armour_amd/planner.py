@@ -193,6 +193,22 @@ class ArmourNLP:
         check(self.L.armour_check_feasible(self.h, _dp(g), feas.ctypes.data_as(C.POINTER(C.c_int32))))
         return feas.astype(bool)
 
+    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None):
+        """OptimizeTNLP + finalize_solution for all B problems (RT/armour_main.cu:237-304): returns a list of dicts
+        (k_opt, cost, feasible, iterations, evaluations, status, time_ms)."""
+        opt = _lib.ArmourSolveOptions()
+        self.L.armour_solve_options_default(C.byref(opt))
+        if max_iterations is not None:
+            opt.max_iterations = max_iterations
+        if tolerance is not None:
+            opt.tolerance = tolerance
+        if max_wall_time_s is not None:
+            opt.max_wall_time_s = max_wall_time_s
+        res = (_lib.ArmourSolveResult * self.B)()
+        check(self.L.armour_solve(self.h, C.byref(opt), res))
+        return [dict(k_opt=np.array(r.k_opt[:self.n]), cost=r.cost, max_violation=r.max_violation, feasible=bool(r.feasible),
+                     iterations=r.iterations, evaluations=r.evaluations, status=r.status, time_ms=r.time_ms) for r in res]
+
     # ------------------------------------------------------------------ MATLAB callback shape
     def eval_constraint(self, k, b=0):
         """[h, heq, grad_h, grad_heq] with h <= 0 feasible and grad_h sized n_k x n_constraints

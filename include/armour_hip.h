@@ -105,6 +105,34 @@ int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t 
 /* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
 int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 
+/* ---- NLP solve of the planning iteration ---- */
+/* Replaces IpoptApplication::OptimizeTNLP + armtd_NLP::finalize_solution (RT/armour_main.cu:237-304,
+ * RT/NLPclass.cu:422-538) for all B problems of the handle at once: SQP on the device callbacks, start x = 0,
+ * exact (constant, diagonal) cost Hessian, dense QP by a dual active-set method, L1-merit line search.
+ * IPOPT itself is not part of this library; this solver returns a local optimum of the same NLP. */
+typedef struct ArmourSolveOptions {
+    int32_t max_iterations;   /* SQP iterations (60) */
+    int32_t max_line_search;  /* halvings per iteration (12) */
+    double tolerance;         /* step / violation tolerance (1e-4 = IPOPT_OPTIMIZATION_TOLERANCE, RT/Parameters.h:50) */
+    double max_wall_time_s;   /* 0 = unlimited (reference: 0.5 s - t(P1) - 0.05 s, RT/armour_main.cu:227-229) */
+    double reserved[4];
+} ArmourSolveOptions;
+typedef struct ArmourSolveResult {
+    double k_opt[ARMOUR_MAX_FACTORS];
+    double cost;              /* eval_f at k_opt (includes COST_FUNCTION_OPTIMALITY_SCALE) */
+    double max_violation;     /* L1 violation of g_l <= g <= g_u at k_opt */
+    int32_t feasible;         /* finalize_solution verdict: what armour.out's "k_opt or -1" is decided on */
+    int32_t iterations, evaluations;
+    int32_t status;           /* 1 converged, 2 iteration limit, 3 inconsistent linearisation, 4 line search failed, 5 time limit */
+    double time_ms;
+} ArmourSolveResult;
+void armour_solve_options_default(ArmourSolveOptions* opt);
+int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt, ArmourSolveResult* results /* [B] */);
+/* test hook for the dense QP: min 1/2 x'diag(Gd)x + g0'x  s.t. lo <= A x <= hi (A row-major [m][n], n <= 7,
+ * |bound| >= 1e18 = absent).  Host-only: runs without a GPU. */
+int armour_debug_qp(int32_t n, const double* Gd, const double* g0, int32_t m, const double* A, const double* lo,
+                    const double* hi, double* x, int32_t* feasible);
+
 /* ---- diagnostics the reference writes to its 4 extra files (RT/armour_main.cu:329-372) ---- */
 /* torque_radius [B][n][T]   (armour_control_input_radius.out holds its transpose) */
 int armour_get_torque_radius(ArmourPlanner* h, double* torque_radius);

@@ -1,0 +1,106 @@
+"""armour_solve (SQP on the device callbacks) and the armour_main CLI on the GPU.
+
+IPOPT is absent, so the check is against an independent solver on the CPU oracle's callbacks (scipy SLSQP) and
+against the optimality / feasibility conditions themselves."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import SAMPLE_PROBLEM
+
+pytestmark = pytest.mark.gpu
+
+
+def _scipy_reference(o, m, gl, gu):
+    from scipy.optimize import minimize
+    two = gl > -1e18
+
+    def cons(k):
+        g, _ = o.eval_g_jac(k, want_jac=False)
+        return np.concatenate([gu - g, (g - gl)[two]])
+
+    def cons_jac(k):
+        _, j = o.eval_g_jac(k, want_g=False)
+        return np.concatenate([-j, j[two]])
+
+    r = minimize(o.eval_f, np.zeros(7), jac=o.eval_grad_f, bounds=[(-1, 1)] * 7, method="SLSQP",
+                 constraints=[dict(type="ineq", fun=cons, jac=cons_jac)], options=dict(maxiter=200, ftol=1e-12))
+    return r
+
+
+@pytest.mark.parametrize("seed,O", [(3, 3), (5, 6), (11, 0)])
+def test_solve_matches_independent_solver(seed, O):
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    from oracle.cpu_oracle import Oracle
+    T = 20
+    p = random_problem(seed, O)
+    nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    sol = nlp.solve(tolerance=1e-7, max_iterations=100)[0]
+    o = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    _, _, gl, gu = o.bounds()
+    ref = _scipy_reference(o, o.m, gl, gu)
+    g_ref, _ = o.eval_g_jac(ref.x, want_jac=False)
+    ref_feasible = bool(np.all(g_ref <= gu + 1e-6) and np.all(g_ref >= gl - 1e-6))
+    g, _ = o.eval_g_jac(sol["k_opt"], want_jac=False)
+    if ref_feasible:
+        # same NLP, same start: both SQP methods should land on the same local optimum
+        assert sol["max_violation"] <= 1e-6
+        assert np.all(np.abs(sol["k_opt"]) <= 1 + 1e-12)
+        assert sol["cost"] <= ref.fun + 1e-6 * (1 + abs(ref.fun)), (sol, ref.fun)
+        assert abs(sol["cost"] - o.eval_f(sol["k_opt"])) <= 1e-10
+        assert np.all(g <= gu + 1e-6) and np.all(g >= gl - 1e-6)
+        assert sol["feasible"]
+    else:
+        assert not sol["feasible"] or sol["max_violation"] <= 1e-2
+
+
+def test_batched_solve_equals_single_solves():
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    T, O, B = 20, 4, 3
+    bp = random_batch(30, B, O)
+    batch = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
+    for b in range(B):
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b]).solve()[0]
+        assert np.allclose(batch[b]["k_opt"], one["k_opt"], atol=1e-9) and batch[b]["feasible"] == one["feasible"]
+
+
+def test_wall_time_limit_is_honoured(sample_problem):
+    from armour_amd.planner import ArmourNLP
+    p = sample_problem
+    nlp = ArmourNLP(T=128).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    sol = nlp.solve(max_wall_time_s=1e-6)[0]
+    assert sol["status"] == 5 and sol["iterations"] == 0 and np.all(sol["k_opt"] == 0)   # stopped at the start point
+    full = nlp.solve()[0]
+    assert full["status"] in (1, 2) and full["cost"] <= sol["cost"] + 1e-12
+
+
+def test_cli_drop_in_for_armour_main(tmp_path, sample_problem):
+    """The armour_main binary over the reference's file protocol (KSI/uarmtd_planner.m:158-219)."""
+    from armour_amd import file_protocol as fp
+    from armour_amd.planner import ArmourNLP
+    exe = os.path.join(ROOT, "armour_amd", "bin", "armour_main")
+    assert os.path.exists(exe), "build with make -C armour_amd/csrc"
+    p = sample_problem
+    fp.write_armour_in(tmp_path / fp.IN_NAME, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    out = subprocess.run([exe, str(tmp_path), "128"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    k_opt, ms = fp.read_armour_out(tmp_path / "armour.out")
+    nlp = ArmourNLP(T=128).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    sol = nlp.solve()[0]
+    assert (k_opt is not None) == sol["feasible"] and ms > 0
+    if k_opt is not None:
+        assert np.allclose(k_opt, sol["k_opt"], atol=1e-8)
+    g_file = np.loadtxt(tmp_path / "armour_constraints.out")
+    assert g_file.shape == (nlp.m,) and np.allclose(g_file, nlp.eval_g(sol["k_opt"])[0], rtol=1e-5, atol=1e-12)
+    assert np.loadtxt(tmp_path / "armour_joint_position_center.out").shape == (128 * 7, 3)
+    assert np.loadtxt(tmp_path / "armour_joint_position_radius.out").shape == (128 * 7 * 3, 6)
+    assert np.allclose(np.loadtxt(tmp_path / "armour_control_input_radius.out"), nlp.torque_radius()[0].T, rtol=1e-9)
+    # missing input: -1 in armour.out and a non-zero exit code (RT/armour_main.cu:47-52)
+    os.remove(tmp_path / fp.IN_NAME)
+    bad = subprocess.run([exe, str(tmp_path), "128"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and open(tmp_path / "armour.out").read().split()[0] == "-1"
