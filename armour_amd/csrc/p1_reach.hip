@@ -27,7 +27,7 @@ constexpr int kMaxSlots = 192;
 
 struct P1Cfg {
     int B, T, J, n, O;
-    int capW, capRaw, capL, capT;
+    int capW, capRaw, capKey, capL, capT;
     size_t arena_bytes;
     unsigned char* arena;
     ArmourRobot rb;
@@ -152,7 +152,7 @@ struct JrsScalars {
     double qd_c, qd_k, qd_e, qda_e, qdd_c, qdd_k, qdd_e;
 };
 
-__device__ inline JrsScalars jrs_scalars(const P1Cfg& cf, double q0, double a, double b, int i, int s_ind) {
+__device__ PZW_NOINLINE JrsScalars jrs_scalars(const P1Cfg& cf, double q0, double a, double b, int i, int s_ind) {
     JrsScalars o;
     const double ds = 1.0 / cf.T, D = cf.pr.duration, kr = cf.pr.k_range[i];
     const double s_lb = s_ind * ds, s_ub = (s_ind + 1) * ds;
@@ -375,7 +375,7 @@ __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, 
 }
 
 // JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67)
-__device__ void build_jrs(Chain& c, int b, int t) {
+__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
@@ -441,7 +441,7 @@ __device__ void build_jrs(Chain& c, int b, int t) {
 }
 
 // RT/PZsparse.cu:370-402 reduce_link_PZ + write of the final link table entry
-__device__ void emit_link(Chain& c, const PZ& p, int b, int l, int t) {
+__device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int t) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, cnt = w.cnt[p.id];
@@ -491,7 +491,7 @@ __device__ void emit_link(Chain& c, const PZ& p, int b, int l, int t) {
 }
 
 // RT/Dynamics.cu:69-81 + RT/armour_main.cu:121-124
-__device__ void run_fk(Chain& c, int b, int t) {
+__device__ PZW_NOINLINE void run_fk(Chain& c, int b, int t) {
     Wave& w = c.w;
     PZ FK_R = c.M(0), FK_Rn = c.M(1);
     {
@@ -516,7 +516,7 @@ __device__ void run_fk(Chain& c, int b, int t) {
 }
 
 // RT/Dynamics.cu:83-181; u[i] receives freshly allocated scalar slots
-__device__ void run_rnea(Chain& c, bool uncertain, PZ* u) {
+__device__ PZW_NOINLINE void run_rnea(Chain& c, bool uncertain, PZ* u) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int J = c.J;
@@ -603,7 +603,7 @@ __device__ void run_rnea(Chain& c, bool uncertain, PZ* u) {
 }
 
 // disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
-__device__ void finish_torque(Chain& c, PZ* u_nom, PZ* u_int, int b, int t) {
+__device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, PZ* u_int, int b, int t) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, T = cf.T;
@@ -668,10 +668,10 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
     c.w.skey = (LDS_AS uint64_t*)lds;
-    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capRaw * 8);
-    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capRaw * 10);
+    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
+    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
     c.w.lstat = c.w.cnt + kMaxSlots;
-    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capRaw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
+    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
 #ifdef P1_PROFILE
     __shared__ unsigned long long prof_lds[PR_WORDS];
     c.w.prof = (LDS_AS unsigned long long*)prof_lds;
@@ -679,6 +679,7 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     const long long prof_start = clock64();
 #endif
     c.w.cap_raw = cf.capRaw;
+    c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.lane = threadIdx.x;
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
@@ -827,13 +828,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     for (;;) {
         const Layout L0 = make_layout(J, n, h->lim.work_monomials);
         const size_t ci_doubles = (size_t)kNV * 6 + kNS * 2 + kNM * 18 + (size_t)L0.nJM * 18 + (size_t)L0.nJV * 6 + (size_t)L0.nJS * 2;
-        const size_t smem = (((size_t)cap_raw * 10 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
+        const int cap_key = cap_raw;  // a smaller key buffer (more waves per CU) was tried: typical batches overflow it and the retry costs more than it gains
+        const size_t smem = (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap_raw); return ARMOUR_EINVAL; }
         (void)max_lds;
         HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const Layout L = make_layout(J, n, h->lim.work_monomials);
         if (L.idJS + L.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
-        const int per_cu = std::max(1, std::min(8, (int)((size_t)160 * 1024 / smem)));
+        const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / smem)));  // 4 = one wave per SIMD (the kernel needs > 256 registers)
         const int waves = std::min(B * T, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
@@ -844,7 +846,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         P1Cfg cf;
         memset(&cf, 0, sizeof(cf));
         cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
-        cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+        cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capKey = cap_key; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
         cf.arena_bytes = L.total; cf.arena = wk->arena;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
@@ -877,7 +879,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         }
 #endif
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
-            if (cap_raw < 8192) { cap_raw <<= 1; continue; }  // retry with a larger LDS sort buffer
+            if (cap_raw < 16384) { cap_raw <<= 1; continue; }  // retry with larger LDS sort buffers
             armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
             return ARMOUR_ECAPACITY;
         }

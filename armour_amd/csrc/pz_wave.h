@@ -28,6 +28,9 @@ constexpr int WAVE = 64;
 // Explicit address spaces: the PZ slots are reached through structs of pointers, which the compiler would
 // otherwise treat as generic and lower to flat_load / flat_store (slow for LDS, and unordered against ds_ / global_
 // instructions).  LDS_AS -> ds_read / ds_write, GLB_AS -> global_load / global_store.
+// The operators are real functions (one copy per shape), not inlined into every call site: the chain kernel issues
+// ~1000 of them per time step and fully inlined it is a 300 KB instruction stream that thrashes the 64 KB I-cache.
+#define PZW_NOINLINE __attribute__((noinline))
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
 
@@ -62,10 +65,10 @@ struct View {
 };
 
 struct Wave {
-    LDS_AS uint64_t* skey;   // LDS [cap_raw]
-    LDS_AS uint16_t* sidx;   // LDS [cap_raw]
+    LDS_AS uint64_t* skey;   // LDS [cap_key]: raw keys (bitonic / linear-combination merge) or the operands' key lists (product merge)
+    LDS_AS uint16_t* sidx;   // LDS [cap_raw]: sorted permutation of the raw terms
     LDS_AS int* cnt;         // LDS per-slot monomial counts
-    int cap_raw;
+    int cap_raw, cap_key;
     double thr;       // SIMPLIFY_THRESHOLD
 #ifdef P1_PROFILE
     LDS_AS unsigned long long* prof;  // LDS [PR_WORDS]
@@ -132,7 +135,9 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
     double ra[SZ];
 #pragma unroll
     for (int e = 0; e < SZ; e++) ra[e] = 0.0;
-    if (N > w.cap_raw) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
+    // LDS capacity: sidx holds every raw term; skey holds either the operands' key lists (merge paths) or, for the
+    // bitonic path, all raw keys padded to a power of two.  On overflow the host retries with larger buffers.
+    if (N > w.cap_raw || (N > WAVE && !ev.can_merge(w, N) && next_pow2(N) > w.cap_key)) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
     if (w.lane == 0 && N > w.lstat[ST_MAX_RAW]) w.lstat[ST_MAX_RAW] = N;
 #ifdef P1_PROFILE
     if (w.lane == 0) { w.prof[PR_CALLS] += 1; w.prof[PR_TERMS] += N; if (N <= 64) w.prof[PR_SMALL] += 1; }
@@ -258,7 +263,9 @@ struct LinEval {
     }
     // every source is a simplified PZ (sorted, unique keys): merge the NS runs by ranking each term with binary
     // searches in the other runs; ties across runs go to the earlier run (= generation order)
+    __device__ inline bool can_merge(const Wave& w, int N) const { return N <= w.cap_key; }
     __device__ inline bool try_merge(Wave& w, int N) const {
+        if (!can_merge(w, N)) return false;
 #ifdef DBG_NO_MERGE_LIN
         return false;
 #endif
@@ -299,7 +306,7 @@ struct LinEval {
 };
 
 template <int SZ, int NS>
-__device__ inline void lincomb(Wave& w, const PZ& out, const Seg* segs) {
+__device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
     LinEval<SZ, NS> ev;
     int N = 0;
     double cen[SZ], ind[SZ];
@@ -379,10 +386,15 @@ struct MulEval {
     // keys [0, k_1, k_2, ...]: rank each term by binary searches with the target shifted by the run's own key.
     // LDS staging: skey[0 .. nl] = long operand's keys (0 for the centre), skey[nl+1 ..] = short operand's keys.
     static constexpr int MAX_RUNS = 8;
+    __device__ inline bool can_merge(const Wave& w, int) const {
+        const bool a_short = a.cnt <= b.cnt;
+        const int ns = (a_short ? a.cnt : b.cnt) + 1, nl = (a_short ? b.cnt : a.cnt) + 1;
+        return ns <= MAX_RUNS && nl + ns <= w.cap_key;
+    }
     __device__ inline bool try_merge(Wave& w, int N) const {
         const bool a_short = a.cnt <= b.cnt;
         const int ns = (a_short ? a.cnt : b.cnt) + 1, nl = (a_short ? b.cnt : a.cnt) + 1;
-        if (ns > MAX_RUNS || nl + ns > w.cap_raw) return false;
+        if (!can_merge(w, N)) return false;
 #ifdef DBG_NO_MERGE_MUL
         return false;
 #endif
@@ -457,7 +469,7 @@ __device__ inline void abs_sum(const Wave& w, const View& v, double* r) {
 }
 
 template <int AR, int AC, int BR, int BC>
-__device__ inline void mul(Wave& w, const PZ& out, const View& a, const View& b) {
+__device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
     typedef MulShape<AR, AC, BR, BC> SH;
     MulEval<SH> ev;
     ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
@@ -492,7 +504,7 @@ __device__ inline void mul(Wave& w, const PZ& out, const View& a, const View& b)
 // simplify() just adds the two coefficients per key and prunes |.| <= threshold -- and then stack()s the three
 // entries, whose simplify() merges equal keys with disjoint non-zero entries and prunes by the 3-vector norm.
 // Because the key list never changes, the whole thing is one ordered pass over a's monomials: no sort.
-__device__ inline void cross_const(Wave& w, const PZ& out, const View& a, const double* sA, const int* cA,
+__device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, const double* sA, const int* cA,
                                    const double* sB, const int* cB) {
     double cen[3], ind[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
 #pragma unroll
@@ -548,7 +560,7 @@ __device__ inline void cross_const(Wave& w, const PZ& out, const View& a, const 
 }
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066); keys unchanged, no simplify.
-__device__ inline void transpose33(Wave& w, const PZ& out, const PZ& a) {
+__device__ PZW_NOINLINE void transpose33(Wave& w, const PZ& out, const PZ& a) {
     const int n = w.cnt[a.id];
     for (int t = w.lane; t < n * 9; t += WAVE) {
         const int m = t / 9, e = t - m * 9, r = e / 3, c = e - r * 3;
@@ -565,7 +577,7 @@ __device__ inline void transpose33(Wave& w, const PZ& out, const PZ& a) {
 }
 
 // constant PZ (centre + independent radius, no monomials): RT/PZsparse.cu:66-98
-__device__ inline void set_const(Wave& w, const PZ& out, const double* cen, const double* ind) {
+__device__ PZW_NOINLINE void set_const(Wave& w, const PZ& out, const double* cen, const double* ind) {
     if (w.lane < out.sz) {
         out.cen[w.lane] = cen ? cen[w.lane] : 0.0;
         out.ind[w.lane] = ind ? ind[w.lane] : 0.0;

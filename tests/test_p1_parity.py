@@ -193,3 +193,21 @@ def test_kinova_with_gripper_payload():
     # the gripper makes the robust-input radius larger than on the bare arm for the same motion
     bare = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"][:1])
     assert nlp.torque_radius()[0].mean() != bare.torque_radius()[0].mean()
+
+
+def test_more_work_items_than_resident_waves():
+    """B*T = 1000 (problem, time step) items exceed the persistent grid (<= 4 waves x 256 CUs would hold them, the
+    LDS-limited grid of 768 does not): waves loop over several items and must give the same tables as a
+    single-problem handle, bit for bit."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, O, B = 100, 2, 10
+    bp = random_batch(1000, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = random_k(3, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b in (0, 7, 9):
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        g1, j1 = one.eval_g_jac(ks[b])
+        assert np.array_equal(g[b], g1[0]) and np.array_equal(jac[b], j1[0])
+        assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
