@@ -1,0 +1,96 @@
+// MEX gateway of libarmour_hip.so for MATLAB (source only: neither MATLAB nor mex.h exists in the build image, so this
+// file is NOT part of `make`; build it on a MATLAB host with
+//     mex armour_hip_mex.cpp -I<repo>/include -L<repo>/armour_amd/lib -larmour_hip
+// ).  Conventions follow the reference's only MEX precedent, kinova_robust_controllers_mex/kinova_controller.cpp:19-84:
+// column vectors of doubles in, mxCreateNumericMatrix out, mexErrMsgTxt on error.  Unlike that gateway the handle is
+// persistent (mexLock / mexAtExit): the reach sets built by 'set_problem' stay on the device for the 'eval' calls of
+// the solver loop.
+//
+//   armour_hip_mex('create', T)                                    T = NUM_TIME_STEPS (RT/Parameters.h:17)
+//   armour_hip_mex('set_problem', q0, qd0, qdd0, q_des, Z)         Z = 12 x nObs, columns = obstacle zonotope Z(:)
+//   [g, jac]             = armour_hip_mex('eval', k)               g: m x 1, jac: n x m (gradient of row i in column i)
+//   [x_l, x_u, g_l, g_u] = armour_hip_mex('bounds')
+//   [f, grad_f]          = armour_hip_mex('cost', k)
+//   [k_opt, feasible, info] = armour_hip_mex('solve')              info = [cost; iterations; evaluations; status; ms]
+//   armour_hip_mex('destroy')
+#include <string.h>
+
+#include "armour_hip.h"
+#include "mex.h"
+
+static ArmourPlanner* g_h = nullptr;
+
+static void cleanup(void) {
+    if (g_h) { armour_destroy(g_h); g_h = nullptr; }
+}
+static void chk(int rc) {
+    if (rc < 0) mexErrMsgTxt(armour_last_error());
+}
+static void need(bool ok, const char* msg) {
+    if (!ok) mexErrMsgTxt(msg);
+}
+static mxArray* col(mwSize n) { return mxCreateNumericMatrix(n, 1, mxDOUBLE_CLASS, mxREAL); }
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    char cmd[32];
+    need(nrhs >= 1 && !mxGetString(prhs[0], cmd, sizeof(cmd)), "usage: armour_hip_mex(command, ...)");
+    if (!strcmp(cmd, "create")) {
+        need(nrhs >= 2, "create needs the number of time steps");
+        ArmourRobot rb;
+        ArmourParams pr;
+        armour_robot_kinova_gen3_no_gripper(&rb);
+        armour_params_default(&pr, (int)mxGetScalar(prhs[1]));
+        cleanup();
+        chk(armour_create(&rb, &pr, nullptr, 0, &g_h));
+        if (!mexIsLocked()) { mexAtExit(cleanup); mexLock(); }
+        return;
+    }
+    if (!strcmp(cmd, "destroy")) {
+        cleanup();
+        if (mexIsLocked()) mexUnlock();
+        return;
+    }
+    need(g_h != nullptr, "call armour_hip_mex('create', T) first");
+    if (!strcmp(cmd, "set_problem")) {
+        need(nrhs == 6, "set_problem needs q0, qd0, qdd0, q_des, Z");
+        for (int i = 1; i <= 4; i++) need(mxGetNumberOfElements(prhs[i]) == 7, "state vectors must have 7 entries");
+        need(mxGetNumberOfElements(prhs[5]) % 12 == 0, "Z must be 12 x nObs");
+        const int nObs = (int)(mxGetNumberOfElements(prhs[5]) / 12);
+        chk(armour_set_problems(g_h, 1, nObs, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5])));
+        return;
+    }
+    int B, n, m;
+    chk(armour_get_sizes(g_h, &B, &n, &m));
+    if (!strcmp(cmd, "eval")) {
+        need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n, "eval needs k (n x 1)");
+        plhs[0] = col(m);
+        mxArray* jac = mxCreateNumericMatrix(n, m, mxDOUBLE_CLASS, mxREAL);  // column-major n x m == row-major values[m][n]
+        chk(armour_eval_g_jac(g_h, mxGetPr(prhs[1]), mxGetPr(plhs[0]), mxGetPr(jac)));
+        if (nlhs > 1) plhs[1] = jac; else mxDestroyArray(jac);
+    } else if (!strcmp(cmd, "bounds")) {
+        mxArray* o[4] = {col(n), col(n), col(m), col(m)};
+        chk(armour_get_bounds(g_h, mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3])));
+        for (int i = 0; i < 4; i++) { if (i < nlhs || i == 0) plhs[i] = o[i]; else mxDestroyArray(o[i]); }
+    } else if (!strcmp(cmd, "cost")) {
+        need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n, "cost needs k (n x 1)");
+        plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL);
+        chk(armour_eval_f(g_h, mxGetPr(prhs[1]), mxGetPr(plhs[0])));
+        if (nlhs > 1) { plhs[1] = col(n); chk(armour_eval_grad_f(g_h, mxGetPr(prhs[1]), mxGetPr(plhs[1]))); }
+    } else if (!strcmp(cmd, "solve")) {
+        ArmourSolveOptions so;
+        armour_solve_options_default(&so);
+        if (nrhs > 1) so.max_wall_time_s = mxGetScalar(prhs[1]);
+        ArmourSolveResult r;
+        chk(armour_solve(g_h, &so, &r));
+        plhs[0] = col(n);
+        memcpy(mxGetPr(plhs[0]), r.k_opt, n * sizeof(double));
+        if (nlhs > 1) plhs[1] = mxCreateLogicalScalar(r.feasible != 0);
+        if (nlhs > 2) {
+            plhs[2] = col(5);
+            double* p = mxGetPr(plhs[2]);
+            p[0] = r.cost; p[1] = r.iterations; p[2] = r.evaluations; p[3] = r.status; p[4] = r.time_ms;
+        }
+    } else {
+        mexErrMsgTxt("unknown command");
+    }
+}
