@@ -5,6 +5,15 @@
 // (RT/Dynamics.cu:69-181), the disturbance / robust-input radius (RT/armour_main.cu:133-141,172-205) -- and
 // Obstacles::initializeHyperPlane (RT/CollisionChecking.cu:69-88,136-228).
 //
+// Fused nominal / interval RNEA.  The reference runs KinematicsDynamics::rnea twice per time step, with the nominal and
+// with the 3 %-uncertain mass / inertia PZs (RT/Dynamics.h:41-47, RT/armour_main.cu:126-129).  Those parameter PZs have
+// no monomials -- only a centre and an independent radius (RT/Dynamics.cu:27-40, RT/PZsparse.cu:93-98) -- and no
+// operator lets the independent radius flow back into a centre or a monomial coefficient (RT/PZsparse.cu:864-994:
+// it only feeds res.independent; simplify() prunes on coefficients alone).  Hence both passes produce bit-identical
+// centres, keys and coefficients and differ in the independent radii only.  Here every PZ carries both radii
+// (ind = nominal, ind2 = uncertain) and the recursion runs ONCE; u_nom_int - u_nom then has centre 0, all monomials
+// cancel exactly and its radius is ind2 + ind, which is what RT/armour_main.cu:133-136,179-191 computes the long way.
+//
 // Mapping: one 64-lane wavefront per (problem, time interval) runs the whole dependent chain
 // JRS -> FK -> link reduce -> RNEA(nominal) -> RNEA(interval) -> disturbance -> torque radius on the
 // wave-level PZ arithmetic of pz_wave.h; the grid is persistent (a fixed number of waves, each with a
@@ -53,9 +62,9 @@ struct Layout {
 };
 __host__ __device__ inline Layout make_layout(int J, int n, int capW) {
     Layout L;
-    L.nJM = (J + 1) + J + 3 + 2 * J;  // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia nominal/uncertain
+    L.nJM = (J + 1) + J + 3 + J;      // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia
     L.nJV = (J + 1) + J;              // trans P_i, link boxes
-    L.nJS = 3 * n + 2 * J + 4;        // qd, qda, qdda; mass nominal/uncertain; raw temps
+    L.nJS = 3 * n + J + 4;            // qd, qda, qdda; mass; raw temps
     L.offV = 0;
     L.offS = L.offV + (size_t)kNV * slot_bytes(capW, 3);
     L.offM = L.offS + (size_t)kNS * slot_bytes(capW, 1);
@@ -74,8 +83,9 @@ __device__ inline PZ mk_slot(GLB_AS unsigned char* base, size_t off, int index, 
     PZ z;
     z.keys = (GLB_AS uint64_t*)p;
     z.coef = (GLB_AS double*)(p + align64((size_t)cap * 8));
-    z.cen = ci + (size_t)index * 2 * sz;
+    z.cen = ci + (size_t)index * 3 * sz;
     z.ind = z.cen + sz;
+    z.ind2 = z.ind + sz;
     z.sz = sz; z.cap = cap; z.id = id0 + index;
     return z;
 }
@@ -249,27 +259,25 @@ struct Chain {
 
     LDS_AS double* ci;  // LDS: centre / indep of every slot, classes laid out V | S | M | JM | JV | JS
     __device__ PZ V(int i) const { return mk_slot(arena, L.offV, i, cf->capW, 3, L.idV, ci); }
-    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS, ci + kNV * 6); }
-    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM, ci + kNV * 6 + kNS * 2); }
-    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM, ci + kNV * 6 + kNS * 2 + kNM * 18); }
-    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV, ci + kNV * 6 + kNS * 2 + kNM * 18 + L.nJM * 18); }
-    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS, ci + kNV * 6 + kNS * 2 + kNM * 18 + L.nJM * 18 + L.nJV * 6); }
+    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS, ci + kNV * 9); }
+    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM, ci + kNV * 9 + kNS * 3); }
+    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM, ci + kNV * 9 + kNS * 3 + kNM * 27); }
+    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV, ci + kNV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27); }
+    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS, ci + kNV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27 + L.nJV * 9); }
     // named small slots
     __device__ PZ R(int i) const { return JM(i); }                       // 0..J
     __device__ PZ Rt(int i) const { return JM(J + 1 + i); }              // 0..J-1
     __device__ PZ rotRaw() const { return JM(2 * J + 1); }
     __device__ PZ rotS() const { return JM(2 * J + 2); }
     __device__ PZ rpy() const { return JM(2 * J + 3); }
-    __device__ PZ Inom(int i) const { return JM(2 * J + 4 + i); }
-    __device__ PZ Iunc(int i) const { return JM(3 * J + 4 + i); }
+    __device__ PZ inertia(int i) const { return JM(2 * J + 4 + i); }
     __device__ PZ Ptr(int i) const { return JV(i); }                     // trans, 0..J
     __device__ PZ linkbox(int i) const { return JV(J + 1 + i); }
     __device__ PZ qd(int i) const { return JS(i); }
     __device__ PZ qda(int i) const { return JS(n + i); }
     __device__ PZ qdda(int i) const { return JS(2 * n + i); }
-    __device__ PZ mnom(int i) const { return JS(3 * n + i); }
-    __device__ PZ munc(int i) const { return JS(3 * n + J + i); }
-    __device__ PZ rawS(int i) const { return JS(3 * n + 2 * J + i); }    // 0..3
+    __device__ PZ mass(int i) const { return JS(3 * n + i); }
+    __device__ PZ rawS(int i) const { return JS(3 * n + J + i); }        // 0..3
 
     __device__ PZ allocV() {
         const int i = __ffs(freeV) - 1;
@@ -362,7 +370,7 @@ struct Chain {
 template <int SZ>
 __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
     if (c.w.lane == 0) {
-        for (int e = 0; e < SZ; e++) { raw.cen[e] = cen[e]; raw.ind[e] = 0.0; }
+        for (int e = 0; e < SZ; e++) { raw.cen[e] = cen[e]; raw.ind[e] = 0.0; raw.ind2[e] = 0.0; }
         for (int i = 0; i < m; i++) {
             raw.keys[i] = keys[i];
             for (int e = 0; e < SZ; e++) raw.coef[i * SZ + e] = coefs[i * SZ + e];
@@ -423,13 +431,13 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
     }
     for (int i = 0; i <= J; i++) set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
     for (int i = 0; i < J; i++) {
+        // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
         double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
-        set_const(c.w, c.mnom(i), &cf.rb.mass[i], nullptr);
-        set_const(c.w, c.munc(i), &cf.rb.mass[i], &mi);
+        double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
         double ii[9];
         for (int e = 0; e < 9; e++) ii[e] = cf.rb.inertia_uncertainty * fabs(cf.rb.inertia[9 * i + e]);
-        set_const(c.w, c.Inom(i), &cf.rb.inertia[9 * i], nullptr);
-        set_const(c.w, c.Iunc(i), &cf.rb.inertia[9 * i], ii);
+        set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
         // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
         for (int j = 0; j < 3; j++) {
             const uint64_t key = 1ull << ((j + 2) * n);
@@ -516,7 +524,7 @@ __device__ PZW_NOINLINE void run_fk(Chain& c, int b, int t) {
 }
 
 // RT/Dynamics.cu:83-181; u[i] receives freshly allocated scalar slots
-__device__ PZW_NOINLINE void run_rnea(Chain& c, bool uncertain, PZ* u) {
+__device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int J = c.J;
@@ -564,10 +572,10 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, bool uncertain, PZ* u) {
             PZ c2 = c.crossPzMat(waux, cm);
             PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
             PZ s2 = c.add(s1, c3); c.freeVs(s1); c.freeVs(c3);
-            F[i] = c.mulSV(uncertain ? c.munc(i) : c.mnom(i), s2); c.freeVs(s2);
+            F[i] = c.mulSV(c.mass(i), s2); c.freeVs(s2);
         }
         {   // line 29: N = I * wdot + cross(w_aux, I * w)
-            const PZ I = uncertain ? c.Iunc(i) : c.Inom(i);
+            const PZ I = c.inertia(i);
             PZ t1 = c.mulMV(I, wdot);
             PZ t2 = c.mulMV(I, wv);
             PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
@@ -603,7 +611,7 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, bool uncertain, PZ* u) {
 }
 
 // disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
-__device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, PZ* u_int, int b, int t) {
+__device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, T = cf.T;
@@ -611,14 +619,12 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, PZ* u_int, int b
     Itv rho = {0.0, 0.0};
     double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
     for (int j = 0; j < n; j++) {
-        // toInterval of the disturbance (RT/PZsparse.cu:557-576)
-        PZ dist = c.comb2(view(w, u_int[j]), 1.0, view(w, u_nom[j]), -1.0);
-        const int dc = w.cnt[dist.id];
-        double rs = 0.0;
-        for (int m = w.lane; m < dc; m += WAVE) rs += fabs(dist.coef[m]);
-        const double rad = dist.ind[0] + wave_sum(rs);
-        const double lo = dist.cen[0] - rad, hi = dist.cen[0] + rad;
-        c.freeSs(dist);
+        // disturbance u_nom_int - u_nom (RT/armour_main.cu:133-136) and its toInterval (RT/PZsparse.cu:557-576): the two
+        // PZs share centre, keys and coefficients (see the header note), so the centre is 0, every monomial cancels to an
+        // exact 0 that simplify() drops, and the radius is independent(u_nom_int) + independent(u_nom) (RT/PZsparse.cu:829)
+        const double dcen = u_nom[j].cen[0] - u_nom[j].cen[0];
+        const double rad = u_nom[j].ind2[0] + u_nom[j].ind[0];
+        const double lo = dcen - rad, hi = dcen + rad;
         rho = iadd(rho, imul(iv(lo, hi), iv(lo, hi)));
         tr[j] = cf.rb.alpha * (cf.rb.M_max - cf.rb.M_min) * cf.ub.eps + 0.5 * fmax(fabs(lo), fabs(hi));
         // reduce(u_nom) (RT/PZsparse.cu:352-368) straight into the final torque table
@@ -692,10 +698,9 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
         __syncthreads();
         build_jrs(c, b, t);
         run_fk(c, b, t);
-        PZ u_nom[ARMOUR_MAX_FACTORS], u_int[ARMOUR_MAX_FACTORS];
-        run_rnea(c, false, u_nom);
-        run_rnea(c, true, u_int);
-        finish_torque(c, u_nom, u_int, b, t);
+        PZ u_nom[ARMOUR_MAX_FACTORS];
+        run_rnea(c, u_nom);
+        finish_torque(c, u_nom, b, t);
         __syncthreads();
     }
 #ifdef P1_PROFILE
@@ -827,7 +832,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     const int max_lds = (int)prop.sharedMemPerBlock;  // 64 KiB by default; up to 160 KiB on gfx950 with the attribute below
     for (;;) {
         const Layout L0 = make_layout(J, n, h->lim.work_monomials);
-        const size_t ci_doubles = (size_t)kNV * 6 + kNS * 2 + kNM * 18 + (size_t)L0.nJM * 18 + (size_t)L0.nJV * 6 + (size_t)L0.nJS * 2;
+        const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L0.nJM * 27 + (size_t)L0.nJV * 9 + (size_t)L0.nJS * 3;
         const int cap_key = cap_raw;  // a smaller key buffer (more waves per CU) was tried: typical batches overflow it and the retry costs more than it gains
         const size_t smem = (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap_raw); return ARMOUR_EINVAL; }

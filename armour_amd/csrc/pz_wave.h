@@ -51,7 +51,8 @@ struct PZ {
     GLB_AS uint64_t* keys;
     GLB_AS double* coef;  // [cap][sz]
     LDS_AS double* cen;   // [sz]
-    LDS_AS double* ind;   // [sz]
+    LDS_AS double* ind;   // [sz] independent (interval) radius, nominal inertial parameters
+    LDS_AS double* ind2;  // [sz] the same with the uncertain mass / inertia (see the note on the fused RNEA in p1_reach.hip)
     int sz, cap, id;
 };
 
@@ -61,6 +62,7 @@ struct View {
     const GLB_AS double* coef;
     const LDS_AS double* cen;
     const LDS_AS double* ind;
+    const LDS_AS double* ind2;
     int cnt, stride, off, sz;
 };
 
@@ -77,8 +79,8 @@ struct Wave {
     int lane;
 };
 
-__device__ inline View view(const Wave& w, const PZ& p) { return View{p.keys, p.coef, p.cen, p.ind, w.cnt[p.id], p.sz, 0, p.sz}; }
-__device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.keys, p.coef, p.cen, p.ind, w.cnt[p.id], p.sz, r, 1}; }
+__device__ inline View view(const Wave& w, const PZ& p) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, 0, p.sz}; }
+__device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, r, 1}; }
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -126,10 +128,10 @@ __device__ inline int upper_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t 
 }
 
 // Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
-// and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind = independent part before pruning.
+// and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind / base_ind2 = independent parts before pruning.
 // Eval: uint64_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
 template <int SZ, class Eval>
-__device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind) {
+__device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
     int emitted = 0;
     bool any_pruned = false, indirect = false;
     double ra[SZ];
@@ -230,7 +232,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
     }
     if (w.lane == 0) {
 #pragma unroll
-        for (int e = 0; e < SZ; e++) out.ind[e] = base_ind[e] + ra[e];
+        for (int e = 0; e < SZ; e++) { out.ind[e] = base_ind[e] + ra[e]; out.ind2[e] = base_ind2[e] + ra[e]; }
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
@@ -309,9 +311,9 @@ template <int SZ, int NS>
 __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
     LinEval<SZ, NS> ev;
     int N = 0;
-    double cen[SZ], ind[SZ];
+    double cen[SZ], ind[SZ], ind2[SZ];
 #pragma unroll
-    for (int e = 0; e < SZ; e++) { cen[e] = 0.0; ind[e] = 0.0; }
+    for (int e = 0; e < SZ; e++) { cen[e] = 0.0; ind[e] = 0.0; ind2[e] = 0.0; }
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         ev.s[k] = segs[k];
@@ -322,15 +324,16 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
         if (segs[k].comp < 0) {
 #pragma unroll
             for (int e = 0; e < SZ; e++) {
-                const double c = sc * v.cen[v.off + e], i = v.ind[v.off + e] * asc;
+                const double c = sc * v.cen[v.off + e], i = v.ind[v.off + e] * asc, i2 = v.ind2[v.off + e] * asc;
                 cen[e] = (k == 0) ? c : cen[e] + c;
                 ind[e] = (k == 0) ? i : ind[e] + i;
+                ind2[e] = (k == 0) ? i2 : ind2[e] + i2;
             }
         } else {
-            const double c = sc * v.cen[v.off], i = v.ind[v.off] * asc;
+            const double c = sc * v.cen[v.off], i = v.ind[v.off] * asc, i2 = v.ind2[v.off] * asc;
 #pragma unroll
             for (int e = 0; e < SZ; e++)
-                if (e == segs[k].comp) { cen[e] = cen[e] + c; ind[e] = ind[e] + i; }
+                if (e == segs[k].comp) { cen[e] = cen[e] + c; ind[e] = ind[e] + i; ind2[e] = ind2[e] + i2; }
         }
     }
     ev.off[NS] = N;
@@ -339,7 +342,7 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
     }
-    sort_reduce_emit<SZ>(w, N, ev, out, ind);
+    sort_reduce_emit<SZ>(w, N, ev, out, ind, ind2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -479,23 +482,29 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
     abs_sum<SH::ASZ>(w, a, r2);
     abs_sum<SH::BSZ>(w, b, r3);
     PROF_ADD(PR_ABS) }
+    double ia2[SH::ASZ], ib2[SH::BSZ];
 #pragma unroll
-    for (int e = 0; e < SH::ASZ; e++) { ia[e] = a.ind[a.off + e]; ca[e] = a.cen[a.off + e]; }
+    for (int e = 0; e < SH::ASZ; e++) { ia[e] = a.ind[a.off + e]; ia2[e] = a.ind2[a.off + e]; ca[e] = a.cen[a.off + e]; }
 #pragma unroll
-    for (int e = 0; e < SH::BSZ; e++) { ib[e] = b.ind[b.off + e]; cb[e] = b.cen[b.off + e]; }
-    double t2[SH::SZ], t3[SH::SZ], ii[SH::SZ], cen[SH::SZ], base[SH::SZ];
+    for (int e = 0; e < SH::BSZ; e++) { ib[e] = b.ind[b.off + e]; ib2[e] = b.ind2[b.off + e]; cb[e] = b.cen[b.off + e]; }
+    double t2[SH::SZ], t3[SH::SZ], ii[SH::SZ], cen[SH::SZ], base[SH::SZ], base2[SH::SZ];
     SH::mul(r2, ib, t2);   // (|c_a| + sum|coef_a|) * indep_b
     SH::mul(ia, r3, t3);   // indep_a * (|c_b| + sum|coef_b|)
     SH::mul(ia, ib, ii);
     SH::mul(ca, cb, cen);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) base[e] = ii[e] + (t2[e] + t3[e]);
+    SH::mul(r2, ib2, t2);  // the same with the second (uncertain-parameter) radii; r2, r3 are shared
+    SH::mul(ia2, r3, t3);
+    SH::mul(ia2, ib2, ii);
+#pragma unroll
+    for (int e = 0; e < SH::SZ; e++) base2[e] = ii[e] + (t2[e] + t3[e]);
     __syncthreads();
     if (w.lane == 0) {
 #pragma unroll
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
-    sort_reduce_emit<SH::SZ>(w, N, ev, out, base);
+    sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
 }
 
 // Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):
@@ -506,11 +515,12 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
 // Because the key list never changes, the whole thing is one ordered pass over a's monomials: no sort.
 __device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, const double* sA, const int* cA,
                                    const double* sB, const int* cB) {
-    double cen[3], ind[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
+    double cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         cen[c] = sA[c] * a.cen[cA[c]] + sB[c] * a.cen[cB[c]];
         ind[c] = a.ind[cA[c]] * fabs(sA[c]) + a.ind[cB[c]] * fabs(sB[c]);
+        ind2[c] = a.ind2[cA[c]] * fabs(sA[c]) + a.ind2[cB[c]] * fabs(sB[c]);
     }
     int emitted = 0;
     bool any1 = false, any2 = false;
@@ -552,7 +562,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, 
     __syncthreads();
     if (w.lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) { out.cen[c] = cen[c]; out.ind[c] = (ind[c] + ra1[c]) + ra2[c]; }
+        for (int c = 0; c < 3; c++) { out.cen[c] = cen[c]; out.ind[c] = (ind[c] + ra1[c]) + ra2[c]; out.ind2[c] = (ind2[c] + ra1[c]) + ra2[c]; }
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
@@ -571,16 +581,19 @@ __device__ PZW_NOINLINE void transpose33(Wave& w, const PZ& out, const PZ& a) {
         const int r = w.lane / 3, c = w.lane - r * 3;
         out.cen[c * 3 + r] = a.cen[w.lane];
         out.ind[c * 3 + r] = a.ind[w.lane];
+        out.ind2[c * 3 + r] = a.ind2[w.lane];
     }
     if (w.lane == 0) w.cnt[out.id] = n;
     __syncthreads();
 }
 
 // constant PZ (centre + independent radius, no monomials): RT/PZsparse.cu:66-98
-__device__ PZW_NOINLINE void set_const(Wave& w, const PZ& out, const double* cen, const double* ind) {
+// ind2 == nullptr: the second radius equals the first (everything except the mass / inertia PZs)
+__device__ PZW_NOINLINE void set_const(Wave& w, const PZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
     if (w.lane < out.sz) {
         out.cen[w.lane] = cen ? cen[w.lane] : 0.0;
         out.ind[w.lane] = ind ? ind[w.lane] : 0.0;
+        out.ind2[w.lane] = ind2 ? ind2[w.lane] : (ind ? ind[w.lane] : 0.0);
     }
     if (w.lane == 0) w.cnt[out.id] = 0;
     __syncthreads();
@@ -591,7 +604,7 @@ __device__ inline void copy(Wave& w, const PZ& out, const PZ& a) {
     const int n = w.cnt[a.id], sz = a.sz;
     for (int t = w.lane; t < n * sz; t += WAVE) out.coef[t] = a.coef[t];
     for (int m = w.lane; m < n; m += WAVE) out.keys[m] = a.keys[m];
-    if (w.lane < sz) { out.cen[w.lane] = a.cen[w.lane]; out.ind[w.lane] = a.ind[w.lane]; }
+    if (w.lane < sz) { out.cen[w.lane] = a.cen[w.lane]; out.ind[w.lane] = a.ind[w.lane]; out.ind2[w.lane] = a.ind2[w.lane]; }
     if (w.lane == 0) w.cnt[out.id] = n;
     __syncthreads();
 }
