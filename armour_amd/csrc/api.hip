@@ -504,6 +504,17 @@ extern "C" int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, do
     return ARMOUR_OK;
 }
 
+extern "C" int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, const int32_t* sz, const int32_t* cnt, const uint64_t* const* keys,
+                                  const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
+                                  int32_t r, int32_t out_cap, uint64_t* out_keys, double* out_coef, double* out_misc) {
+    if (!h || nops < 1 || nops > 3 || op < 0 || op > 11) { armour_set_error("armour_debug_pz_op: bad argument"); return ARMOUR_EINVAL; }
+    for (int o = 0; o < nops; o++)
+        if ((sz[o] != 1 && sz[o] != 3 && sz[o] != 9) || cnt[o] < 0 || cnt[o] > h->lim.work_monomials || (sz[o] == 9 && o == 1 && cnt[o] > 8)) {
+            armour_set_error("armour_debug_pz_op: bad operand"); return ARMOUR_EINVAL;
+        }
+    return armour_p1_debug_pz_op(h, op, nops, sz, cnt, keys, coef, cen, ind, ind2, consts, r, out_cap, out_keys, out_coef, out_misc);
+}
+
 extern "C" int armour_get_build_ms(ArmourPlanner* h, double* ms) {
     NEED_READY(h);
     *ms = h->build_ms;

@@ -110,3 +110,6 @@ P2Tables armour_make_tables(const ArmourPlanner* h);
 // p1_reach.hip
 int armour_p1_build(ArmourPlanner* h, const double* obstacles);
 void armour_p1_free(ArmourPlanner* h);
+int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, const int* cnt, const uint64_t* const* keys,
+                          const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
+                          int r, int out_cap, uint64_t* out_keys, double* out_coef, double* out_misc);

@@ -772,6 +772,79 @@ __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double
     if ((threadIdx.x & 63) == 0) atomicAnd(&plane_skip[b], skip);
 }
 
+
+// ------------------------------------------------------------------ test hook: one PZ operator on caller-supplied operands
+// Operand block layout (doubles / u64 in two flat buffers): see armour_debug_pz_op in api.  ops:
+//   0 mul 3x3*3x1   1 mul 3x3*3x3   2 mul 1x1*1x1   3 mul 1x1*3x1   4 a+b (3x1)   5 a-b (3x1)   6 addOneDimPZ(a 3x1, b 1x1, r)
+//   7 stack(a,b,c 1x1)   8 cross(a 3x1, const)   9 cross(const, a 3x1)   10 cross(a 3x1, b 3x1)   11 sa*a + sb*b (1x1)
+struct PzOpArgs {
+    int op, nops, r;
+    int sz[3], cnt[3];
+    const uint64_t* keys[3];
+    const double* coef[3];
+    double cen[3][9], ind[3][9], ind2[3][9];
+    double consts[4];
+    uint64_t* out_keys; double* out_coef; double* out_misc;  // misc: cnt, cen[9], ind[9], ind2[9]
+    int out_cap;
+};
+
+__global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOpArgs* ap) {
+    const PzOpArgs a = *ap;  // passed through memory: P1Cfg alone nearly fills the 4 KB kernel-argument segment
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Chain c;
+    c.cf = &cf;
+    c.n = cf.n; c.J = cf.J;
+    c.L = make_layout(cf.J, cf.n, cf.capW);
+    c.arena = (GLB_AS unsigned char*)cf.arena;
+    LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
+    c.w.skey = (LDS_AS uint64_t*)lds;
+    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
+    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    c.w.lstat = c.w.cnt + kMaxSlots;
+    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
+    c.w.cap_raw = cf.capRaw; c.w.cap_key = cf.capKey;
+    c.w.thr = cf.pr.simplify_threshold;
+    c.w.lane = threadIdx.x;
+    if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
+    c.freeV = 0xffffffffu; c.freeS = (1u << kNS) - 1u;
+    for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
+    __syncthreads();
+    PZ in[3];
+    for (int o = 0; o < a.nops; o++) {
+        // 3x3 operands: the first in a work slot, the second in a small (<= 8 monomials) slot like a joint rotation
+        in[o] = a.sz[o] == 9 ? (o == 0 ? c.M(0) : c.JM(0)) : a.sz[o] == 3 ? c.allocV() : c.allocS();
+        const int n = a.cnt[o], sz = a.sz[o];
+        for (int m = threadIdx.x; m < n; m += WAVE) in[o].keys[m] = a.keys[o][m];
+        for (int m = threadIdx.x; m < n * sz; m += WAVE) in[o].coef[m] = a.coef[o][m];
+        if (threadIdx.x < sz) { in[o].cen[threadIdx.x] = a.cen[o][threadIdx.x]; in[o].ind[threadIdx.x] = a.ind[o][threadIdx.x]; in[o].ind2[threadIdx.x] = a.ind2[o][threadIdx.x]; }
+        if (threadIdx.x == 0) c.w.cnt[in[o].id] = n;
+        __syncthreads();
+    }
+    Wave& w = c.w;
+    PZ out;
+    switch (a.op) {
+        case 0: out = c.mulMV(in[0], in[1]); break;
+        case 1: out = c.M(1); mul<3, 3, 3, 3>(w, out, view(w, in[0]), view(w, in[1])); break;
+        case 2: out = c.mulSS(view(w, in[0]), view(w, in[1])); break;
+        case 3: out = c.mulSV(in[0], in[1]); break;
+        case 4: out = c.add(in[0], in[1]); break;
+        case 5: out = c.add(in[0], in[1], -1.0); break;
+        case 6: out = c.addOneDim(in[0], in[1], a.r); break;
+        case 7: out = c.stack(in[0], in[1], in[2]); break;
+        case 8: out = c.crossPzMat(in[0], a.consts); break;
+        case 9: out = c.crossMatPz(a.consts, in[0]); break;
+        case 10: out = c.crossPzPz(in[0], in[1]); break;
+        default: out = c.comb2(view(w, in[0]), a.consts[0], view(w, in[1]), a.consts[1]); break;
+    }
+    const int n = w.cnt[out.id], sz = out.sz;
+    for (int m = threadIdx.x; m < n && m < a.out_cap; m += WAVE) a.out_keys[m] = out.keys[m];
+    for (int m = threadIdx.x; m < n * sz && m < a.out_cap * sz; m += WAVE) a.out_coef[m] = out.coef[m];
+    if (threadIdx.x == 0) {
+        a.out_misc[0] = n; a.out_misc[1] = sz; a.out_misc[2] = w.lstat[ST_ERR];
+        for (int e = 0; e < sz; e++) { a.out_misc[3 + e] = out.cen[e]; a.out_misc[12 + e] = out.ind[e]; a.out_misc[21 + e] = out.ind2[e]; }
+    }
+}
+
 struct P1Work {
     unsigned char* arena = nullptr;
     size_t arena_total = 0;
@@ -806,6 +879,63 @@ static int grow(Tp** p, size_t* cap, size_t need) {
     *p = nullptr;
     HIPCHK(hipMalloc((void**)p, (need ? need : 1) * sizeof(Tp)));
     *cap = need;
+    return ARMOUR_OK;
+}
+
+
+// test hook (include/armour_hip.h: armour_debug_pz_op)
+int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, const int* cnt, const uint64_t* const* keys,
+                          const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
+                          int r, int out_cap, uint64_t* out_keys, double* out_coef, double* out_misc) {
+    HIPCHK(hipSetDevice(h->device));
+    const int J = h->J, n = h->n;
+    int cap_raw = 64;
+    while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
+    const Layout L = make_layout(J, n, h->lim.work_monomials);
+    const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
+    const size_t smem = (((size_t)cap_raw * 8 + (size_t)cap_raw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void*)armour_p1_pzop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    unsigned char* arena = nullptr;
+    HIPCHK(hipMalloc((void**)&arena, L.total));
+    PzOpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.op = op; a.nops = nops; a.r = r; a.out_cap = out_cap;
+    std::vector<void*> dev;
+    auto up = [&](const void* src, size_t bytes) -> void* {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return nullptr;
+        dev.push_back(d);
+        if (bytes && src) (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+        return d;
+    };
+    for (int o = 0; o < nops; o++) {
+        a.sz[o] = sz[o]; a.cnt[o] = cnt[o];
+        a.keys[o] = (const uint64_t*)up(keys[o], (size_t)cnt[o] * 8);
+        a.coef[o] = (const double*)up(coef[o], (size_t)cnt[o] * sz[o] * 8);
+        for (int e = 0; e < sz[o]; e++) { a.cen[o][e] = cen[o * 9 + e]; a.ind[o][e] = ind[o * 9 + e]; a.ind2[o][e] = ind2[o * 9 + e]; }
+    }
+    for (int i = 0; i < 4; i++) a.consts[i] = consts ? consts[i] : 0.0;
+    a.out_keys = (uint64_t*)up(nullptr, (size_t)out_cap * 8);
+    a.out_coef = (double*)up(nullptr, (size_t)out_cap * 9 * 8);
+    a.out_misc = (double*)up(nullptr, 32 * 8);
+    P1Cfg cf;
+    memset(&cf, 0, sizeof(cf));
+    cf.B = 1; cf.T = h->T; cf.J = J; cf.n = n;
+    cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capKey = cap_raw; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+    cf.arena_bytes = L.total; cf.arena = arena;
+    cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
+    const PzOpArgs* d_args = (const PzOpArgs*)up(&a, sizeof(a));
+    hipLaunchKernelGGL(armour_p1_pzop_kernel, dim3(1), dim3(WAVE), smem, h->stream, cf, d_args);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) {
+        (void)hipMemcpy(out_keys, a.out_keys, (size_t)out_cap * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_coef, a.out_coef, (size_t)out_cap * 9 * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_misc, a.out_misc, 32 * 8, hipMemcpyDeviceToHost);
+    }
+    for (void* d : dev) (void)hipFree(d);
+    (void)hipFree(arena);
+    if (e != hipSuccess) { armour_set_error("armour_debug_pz_op: %s", hipGetErrorString(e)); return ARMOUR_EDEVICE; }
     return ARMOUR_OK;
 }
 

@@ -224,6 +224,28 @@ class ArmourNLP:
         grad_h = np.concatenate([jac, -jac[two_sided]], axis=0).T
         return h, np.zeros(0), grad_h, np.zeros((self.n, 0))
 
+    def debug_pz_op(self, op, operands, consts=None, r=0, out_cap=4096):
+        """Test hook: one device PZ operator (include/armour_hip.h: armour_debug_pz_op).  operands: list of dicts
+        {sz, keys[cnt], coef[cnt, sz], cen[sz], ind[sz], ind2[sz] (optional)}."""
+        n = len(operands)
+        i32 = C.c_int32 * n
+        sz = i32(*[o["sz"] for o in operands])
+        cnt = i32(*[len(o["keys"]) for o in operands])
+        ks = [np.ascontiguousarray(o["keys"], dtype=np.uint64) if len(o["keys"]) else np.zeros(1, np.uint64) for o in operands]
+        cs = [np.ascontiguousarray(o["coef"], dtype=np.float64).reshape(-1) if len(o["keys"]) else np.zeros(1) for o in operands]
+        kp = (C.POINTER(C.c_uint64) * n)(*[k.ctypes.data_as(C.POINTER(C.c_uint64)) for k in ks])
+        cp = (C.POINTER(C.c_double) * n)(*[_dp(c) for c in cs])
+        cen, ind, ind2 = np.zeros((n, 9)), np.zeros((n, 9)), np.zeros((n, 9))
+        for i, o in enumerate(operands):
+            cen[i, :o["sz"]] = o["cen"]; ind[i, :o["sz"]] = o["ind"]; ind2[i, :o["sz"]] = o.get("ind2", o["ind"])
+        cst = np.zeros(4) if consts is None else np.ascontiguousarray(np.concatenate([np.asarray(consts, dtype=np.float64), np.zeros(4)])[:4])
+        ok, oc, misc = np.zeros(out_cap, np.uint64), np.zeros(out_cap * 9), np.zeros(32)
+        check(self.L.armour_debug_pz_op(self.h, op, n, sz, cnt, kp, cp, _dp(cen), _dp(ind), _dp(ind2), _dp(cst), r, out_cap,
+                                        ok.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(oc), _dp(misc)))
+        m, osz = int(misc[0]), int(misc[1])
+        return dict(keys=ok[:m].copy(), coef=oc[:m * osz].reshape(m, osz).copy(), cen=misc[3:3 + osz].copy(), ind=misc[12:12 + osz].copy(),
+                    ind2=misc[21:21 + osz].copy(), flags=int(misc[2]))
+
     # ------------------------------------------------------------------ diagnostics / tables
     def torque_radius(self):
         out = np.zeros((self.B, self.n, self.T))

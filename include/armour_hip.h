@@ -157,6 +157,18 @@ int armour_get_build_ms(ArmourPlanner* h, double* ms);
 /* name of the P2 kernel as it appears in rocprofv3 kernel traces */
 const char* armour_p2_kernel_name(void);
 
+/* ---- test hook: one wave-level polynomial-zonotope operator on caller-supplied operands ---- */
+/* Runs the device implementation of one operator of RT/PZsparse.cu (the same functions the reach-set kernel uses):
+ *   op 0 mul 3x3*3x1, 1 mul 3x3*3x3, 2 mul 1x1*1x1, 3 mul 1x1*3x1 (:864-994); 4 a+b, 5 a-b on 3x1 (:743-834);
+ *   6 addOneDimPZ(a 3x1, b 1x1, r) (:1068-1085); 7 stack(a,b,c) (:1087-1116); 8 cross(a, const), 9 cross(const, a),
+ *   10 cross(a, b) (:1118-1167); 11 consts[0]*a + consts[1]*b on 1x1 (:996-1030 + :743-764).
+ * Operand o: sz[o] in {1,3,9} entries per coefficient (row-major), cnt[o] monomials with keys[o][cnt] sorted unique and
+ * coef[o][cnt][sz]; cen / ind / ind2 are [nops][9].  Result: out_keys[<=out_cap], out_coef[<=out_cap][sz],
+ * out_misc = {count, sz, error flags, cen[9], ind[9], ind2[9]}. */
+int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, const int32_t* sz, const int32_t* cnt, const uint64_t* const* keys,
+                       const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
+                       int32_t r, int32_t out_cap, uint64_t* out_keys, double* out_coef, double* out_misc);
+
 /* ---- test hook: load externally built reach-set tables instead of running P1 ---- */
 /* Used only by tests to isolate P2 (tables built by the CPU oracle); never called by the product path.
  * link_* : [B][J][T] counts, centers [..][2][3] (centre, independent radius), keys [..][cap_l], coeffs [..][cap_l][3]

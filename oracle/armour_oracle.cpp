@@ -665,6 +665,44 @@ void oracle_slice_links(void* h, const double* k, double* center /*[T][J][3]*/) 
     Ctx cx; cx.kl.n = P.n;
     for (int t = 0; t < P.T; t++) for (int l = 0; l < P.J; l++) slice_value(cx, P.links[l * P.T + t], k, &center[(t * P.J + l) * 3], nullptr);
 }
+/* one operator of pz.hpp on caller-supplied operands (mirror of armour_debug_pz_op, same op codes and layout) */
+int oracle_pz_op(int op, int nops, const int* sz, const int* cnt, const uint64_t* const* keys, const double* const* coef,
+                 const double* cen, const double* ind, const double* consts, int r, double threshold, int out_cap,
+                 uint64_t* out_keys, double* out_coef, double* out_misc) {
+    Ctx cx; cx.kl.n = 7; cx.threshold = threshold;
+    PZ in[3];
+    for (int o = 0; o < nops; o++) {
+        in[o] = sz[o] == 9 ? PZ(3, 3) : sz[o] == 3 ? PZ(3, 1) : PZ(1, 1);
+        for (int e = 0; e < sz[o]; e++) { in[o].center[e] = cen[o * 9 + e]; in[o].indep[e] = ind[o * 9 + e]; }
+        for (int m = 0; m < cnt[o]; m++) {
+            Mono mo{};
+            mo.key = keys[o][m];
+            for (int e = 0; e < sz[o]; e++) mo.c[e] = coef[o][(size_t)m * sz[o] + e];
+            in[o].poly.push_back(mo);
+        }
+    }
+    PZ out;
+    switch (op) {
+        case 0: case 1: case 2: case 3: out = mul(cx, in[0], in[1]); break;
+        case 4: out = add(cx, in[0], in[1]); break;
+        case 5: out = sub(cx, in[0], in[1]); break;
+        case 6: out = in[0]; add_one_dim(cx, out, in[1], r, 0); break;
+        case 7: out = stack3(cx, in[0], in[1], in[2]); break;
+        case 8: out = cross_pz_mat(cx, in[0], consts); break;
+        case 9: out = cross_mat_pz(cx, consts, in[0]); break;
+        case 10: out = cross_pz_pz(cx, in[0], in[1]); break;
+        default: out = add(cx, scale(in[0], consts[0]), scale(in[1], consts[1])); break;
+    }
+    const int n = (int)out.poly.size(), osz = out.sz();
+    if (n > out_cap) return -1;
+    for (int m = 0; m < n; m++) {
+        out_keys[m] = out.poly[m].key;
+        for (int e = 0; e < osz; e++) out_coef[(size_t)m * osz + e] = out.poly[m].c[e];
+    }
+    out_misc[0] = n; out_misc[1] = osz; out_misc[2] = cx.st.min_margin;
+    for (int e = 0; e < osz; e++) { out_misc[3 + e] = out.center[e]; out_misc[12 + e] = out.indep[e]; }
+    return 0;
+}
 double oracle_min_margin(void* h) { return ((Problem*)h)->st.min_margin; }
 int oracle_max_threads(void) { return omp_get_max_threads(); }
 

@@ -81,6 +81,8 @@ def lib():
         L.oracle_slice_torque.argtypes = [C.c_void_p, dp, dp]
         L.oracle_slice_links.argtypes = [C.c_void_p, dp, dp]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_pz_op.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(dp),
+                                   dp, dp, dp, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_uint64), dp, dp]
         L.oracle_min_margin.argtypes = [C.c_void_p]
         L.oracle_min_margin.restype = C.c_double
         _lib = L
@@ -232,3 +234,26 @@ class Oracle:
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+def pz_op(op, operands, consts=None, r=0, threshold=5e-4, out_cap=1 << 16):
+    """One PZ operator of the restatement (op codes of armour_debug_pz_op).  operands: list of dicts
+    {sz, keys[cnt] u64, coef[cnt, sz], cen[sz], ind[sz]}.  Returns dict(keys, coef, cen, ind, min_margin)."""
+    n = len(operands)
+    sz = (C.c_int * n)(*[o["sz"] for o in operands])
+    cnt = (C.c_int * n)(*[len(o["keys"]) for o in operands])
+    ks = [np.ascontiguousarray(o["keys"], dtype=np.uint64) if len(o["keys"]) else np.zeros(1, np.uint64) for o in operands]
+    cs = [np.ascontiguousarray(o["coef"], dtype=np.float64).reshape(-1) if len(o["keys"]) else np.zeros(1) for o in operands]
+    kp = (C.POINTER(C.c_uint64) * n)(*[k.ctypes.data_as(C.POINTER(C.c_uint64)) for k in ks])
+    cp = (C.POINTER(C.c_double) * n)(*[_dp(c) for c in cs])
+    cen, ind = np.zeros((n, 9)), np.zeros((n, 9))
+    for i, o in enumerate(operands):
+        cen[i, :o["sz"]] = o["cen"]; ind[i, :o["sz"]] = o["ind"]
+    cst = np.zeros(4) if consts is None else np.ascontiguousarray(np.concatenate([np.asarray(consts, dtype=np.float64), np.zeros(4)])[:4])
+    ok, oc, misc = np.zeros(out_cap, np.uint64), np.zeros(out_cap * 9), np.zeros(32)
+    rc = lib().oracle_pz_op(op, n, sz, cnt, kp, cp, _dp(cen), _dp(ind), _dp(cst), r, threshold, out_cap,
+                            ok.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(oc), _dp(misc))
+    if rc != 0:
+        raise RuntimeError("oracle_pz_op overflow")
+    m, osz = int(misc[0]), int(misc[1])
+    return dict(keys=ok[:m].copy(), coef=oc[:m * osz].reshape(m, osz).copy(), cen=misc[3:3 + osz].copy(), ind=misc[12:12 + osz].copy(), min_margin=misc[2])
