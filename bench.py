@@ -129,8 +129,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even a single rank goes through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, O, T, K, W = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup
@@ -153,7 +155,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +173,7 @@ def main():
     ev_ms = e0.elapsed_time(e1)
 
     el = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed_max, ev_ms_max = float(el[0]), float(el[1])
 
@@ -216,7 +218,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, O, seed=0)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -211,3 +211,34 @@ def test_more_work_items_than_resident_waves():
         g1, j1 = one.eval_g_jac(ks[b])
         assert np.array_equal(g[b], g1[0]) and np.array_equal(jac[b], j1[0])
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
+
+
+def test_two_handles_from_two_host_threads():
+    """One handle = one stream; handles are independent (include/armour_hip.h): two host threads building and evaluating
+    different worlds at the same time get the results of serial runs."""
+    import threading
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_k, random_problem
+    T = 50
+    probs = [random_problem(60 + i, 3 + i) for i in range(2)]
+    ks = random_k(8, 6)
+    serial = []
+    for p in probs:
+        nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        serial.append([nlp.eval_g_jac(k) for k in ks])
+    out = [None, None]
+
+    def work(i):
+        nlp = ArmourNLP(T=T)
+        res = []
+        for rep in range(3):
+            nlp.set_parameters(probs[i]["q0"], probs[i]["qd0"], probs[i]["qdd0"], probs[i]["q_des"], probs[i]["obstacles"])
+            res = [nlp.eval_g_jac(k) for k in ks]
+        out[i] = res
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        for (g, j), (g0, j0) in zip(out[i], serial[i]):
+            assert np.array_equal(g, g0) and np.array_equal(j, j0)

@@ -1,7 +1,7 @@
-"""Copies the rocprofv3 summaries of tests/gpu_profile.sh (gpurun_out/prof_<tag>/) into profiles/ (tracked):
+"""Copies the rocprofv3 summaries of tools/gpu_profile.sh (gpurun_out/prof_<tag>/) into profiles/ (tracked):
     profiles/<name>_kernel_stats.csv   the --kernel-trace --stats table
     profiles/<name>_pmc.json           per-kernel means of the PMC passes + the P2 HBM traffic per launch
-Usage: python tests/collect_profiles.py <tag> <name>"""
+Usage: python tools/collect_profiles.py <tag> <name>"""
 import collections
 import csv
 import glob

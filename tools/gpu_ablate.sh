@@ -4,5 +4,5 @@
 for ab in ${ABLATIONS:-6 14 22 38 62}; do
   make -C armour_amd/csrc -B EXTRA="-DP2_ABLATE=$ab" >/dev/null 2>&1
   echo -n "ablate=$ab: "
-  timeout 200 python tests/gpu_launch_probe.py 2>&1 | grep -E "graph replay" | tail -1
+  timeout 200 python tools/gpu_launch_probe.py 2>&1 | grep -E "graph replay" | tail -1
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py on the GPU box (writes under gpurun_out/prof_*).
-# Usage: bash tests/gpu_profile.sh <tag> [bench args...]
+# Usage: bash tools/gpu_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
