@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarmour_hip.so")
+LIB_PATH = os.environ.get("ARMOUR_HIP_LIB") or os.path.join(_HERE, "lib", "libarmour_hip.so")  # env override: A/B builds
 
 MAXJ = 9   # ARMOUR_MAX_JOINTS
 MAXF = 7   # ARMOUR_MAX_FACTORS
@@ -63,13 +63,38 @@ EXPORTS = [
     "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
     "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
-    "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_check_feasible", "armour_get_torque_radius",
+    "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_eval_g_jac_device_multi", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7,
+    the name libarmour_hip.so links against) but refers to it by file name, so if libarmour_hip.so pulled in
+    /opt/rocm's copy first a later `import torch` would load a second runtime next to it, and device discovery in
+    the second one fails ("no ROCm-capable device is detected").  When torch is installed, map its copy first (no
+    torch import needed): the dynamic linker then binds libarmour_hip.so to it by SONAME and torch finds it already
+    loaded.  Without torch nothing happens and /opt/rocm's runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -81,6 +106,7 @@ def load():
         raise OSError(
             f"{LIB_PATH} not found: build it with `make -C armour_amd/csrc` (hipcc, gfx950) or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU path.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     vp = C.c_void_p
@@ -105,6 +131,7 @@ def load():
     L.armour_eval_g_jac.argtypes = [vp, dp, dp, dp]
     L.armour_eval_g_jac_device.argtypes = [vp, vp, vp, vp, vp]
     L.armour_eval_g_jac_device_steps.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+    L.armour_eval_g_jac_device_multi.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     L.armour_check_feasible.argtypes = [vp, dp, ip]
     L.armour_solve_options_default.argtypes = [C.POINTER(ArmourSolveOptions)]
     L.armour_solve_options_default.restype = None

@@ -368,6 +368,17 @@ extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_
     return ARMOUR_OK;
 }
 
+extern "C" int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_k, int32_t points, double* d_g, double* d_jac,
+                                              void* stream) {
+    NEED_READY(h);
+    if (!d_k || points < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+    if (points == 0) return ARMOUR_OK;
+    const P2Tables tb = armour_make_tables(h);
+    const long long bn = (long long)h->B * h->n, bm = (long long)h->B * h->m;
+    return armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream,
+                            points, bn, bm, bm * h->n);
+}
+
 extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac) {
     NEED_READY(h);
     if (!k) { armour_set_error("k is null"); return ARMOUR_EINVAL; }

@@ -102,7 +102,8 @@ struct ArmourPlanner {
 };
 
 // p2_eval.hip
-int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream);
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,
+                     int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0);
 int armour_refresh_table_stats(ArmourPlanner* h);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);

@@ -37,16 +37,21 @@
 
 namespace {
 
+#ifdef P2_TIMELINE  // development only: 100 MHz wall-clock stamps of the collision phases of three blocks, left in the limit rows of g
+#define P2_STAMP(i) do { unsigned long long t__; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); stamp[i] = t__; } while (0)
+#else
+#define P2_STAMP(i)
+#endif
+
 // k-power tables in LDS: pw[j][d] = k_j^d (d = 0..3); df[j][d] = d * k_j^(d-1)
 struct KPow {
     double pw[ARMOUR_MAX_FACTORS][4];
     double df[ARMOUR_MAX_FACTORS][4];
 };
 
-__device__ inline void fill_kpow(KPow& kp, const double* k, int n) {
+__device__ inline void fill_kpow(KPow& kp, double x, int n) {
     const int j = threadIdx.x;
     if (j < n) {
-        const double x = k[j];
         kp.pw[j][0] = 1.0; kp.pw[j][1] = x; kp.pw[j][2] = x * x; kp.pw[j][3] = x * x * x;
         kp.df[j][0] = 0.0; kp.df[j][1] = 1.0; kp.df[j][2] = 2.0 * x; kp.df[j][3] = 3.0 * (x * x);
     }
@@ -115,23 +120,71 @@ struct P2Launch {
     int pair_chunk;     // (l,t) pairs sliced per LDS pass
     int skip_by_value;  // 1: plane_skip of the (single) problem is in `skip0` (saves a dependent load at B = 1)
     unsigned long long skip0;
+    // multi-point evaluation: the block keeps its share of the tables in registers and loops over `steps` points k;
+    // point s reads k_all + s*k_stride and writes g_all + s*g_stride, jac_all + s*j_stride (strides in doubles; 0 = overwrite)
+    int steps;
+    long long k_stride, g_stride, j_stride;
 };
 
-template <bool WANT_G, bool WANT_J>
+// registers of one slicing pass: the (monomial, axis) tasks of this thread and, for threads < pairs*24, the inputs of
+// the ordered reduction.  None of it depends on k, so a block that evaluates several points loads it once.
+struct PassRegs {
+    uint32_t tkey[P2_TASK_ROUNDS];
+    double tco[P2_TASK_ROUNDS];
+    int tcnt[P2_TASK_ROUNDS], tdst[P2_TASK_ROUNDS];
+    double rc_cen, rc_ind;
+    int rc_cnt;
+};
+
+// (Measured at B = 1 against these predicated groups: unconditional clamped loads issued as one batch behind the planes,
+// 3 % slower; the same plus a fixed 9 plane slots per wave, so that the slicing overlaps the planes in flight, 15 % slower.)
+__device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, int lt_first, int p0, int pc, PassRegs& pr) {
+    const int tid = threadIdx.x;
+    const int per_pair = lp.strideL * 24, per_pair3 = lp.strideL * 3;
+    const int ntask = pc * per_pair3;
+#pragma unroll
+    for (int r = 0; r < P2_TASK_ROUNDS; r++) {
+        const int task = tid + r * P2_BLOCK;
+        pr.tcnt[r] = -1; pr.tdst[r] = 0; pr.tkey[r] = 0; pr.tco[r] = 0.0;
+        if (task < ntask) {
+            const int pi = task / per_pair3, rem = task - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
+            const size_t idx = (size_t)b * tb.J * tb.T + (lt_first + p0 + pi);
+            pr.tcnt[r] = tb.link_count[idx] - mo;  // > 0: live monomial
+            pr.tdst[r] = pi * per_pair + mo * 24 + e;
+            if (mo < tb.capL) {
+                pr.tkey[r] = tb.link_keys[idx * tb.capL + mo];
+                pr.tco[r] = tb.link_coeff[(idx * tb.capL + mo) * 3 + e];
+            }
+        }
+    }
+    pr.rc_cen = 0.0; pr.rc_ind = 0.0; pr.rc_cnt = 0;
+    if (tid < pc * 24) {
+        const int pi = tid / 24, c = tid - pi * 24, e = c % 3;
+        const size_t idx = (size_t)b * tb.J * tb.T + (lt_first + p0 + pi);
+        pr.rc_cnt = min(tb.link_count[idx], lp.strideL);
+        if (c < 3) { pr.rc_cen = tb.link_center[idx * 3 + e]; pr.rc_ind = tb.link_indep[idx * 3 + e]; }
+    }
+}
+
+template <bool WANT_G, bool WANT_J, bool MULTI>
 __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    KPow& kp = *reinterpret_cast<KPow*>(smem_raw);
-    double* lds = reinterpret_cast<double*>(smem_raw + sizeof(KPow));
+    KPow* kp2 = reinterpret_cast<KPow*>(smem_raw);  // double-buffered over the points
+    double* lds = reinterpret_cast<double*>(smem_raw + 2 * sizeof(KPow));
 
     const int b = blockIdx.y;
     const int n = tb.n, T = tb.T, O = tb.O, Q = tb.Q, m = tb.m;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double* k = k_all + (size_t)b * n;
-    double* g = WANT_G ? g_all + (size_t)b * m : nullptr;
-    double* jac = WANT_J ? jac_all + (size_t)b * m * n : nullptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, known uniform: the plane dealing below runs on the scalar unit
+    const double* k0 = k_all + (size_t)b * n;
+    double* g0 = WANT_G ? g_all + (size_t)b * m : nullptr;
+    double* jac0 = WANT_J ? jac_all + (size_t)b * m * n : nullptr;
     const int role = blockIdx.x;
+    const int nsteps = MULTI ? lp.steps : 1;  // the one-point instantiation keeps the loop-free code of a single launch
+    // this thread's component of the NEXT point's k is fetched one point ahead: a fresh k is an HBM miss
+    double k_next = (tid < n) ? k0[tid] : 0.0;
 #ifdef P2_ABLATE  // development only: skip roles to attribute kernel time
     if ((P2_ABLATE & 1) && role < lp.nbc) return;
     if ((P2_ABLATE & 2) && role >= lp.nbc && role < lp.nbc + lp.nbt) return;
@@ -139,11 +192,19 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
 #endif
 
     if (role < lp.nbc) {
+#ifdef P2_TIMELINE
+        unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        P2_STAMP(0);
+#ifdef P2_TIMELINE
+        const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
+#endif
         // ------------------------------------------------------------------ collision rows
         double* sx = lds;                                               // [max_pairs][24]: x[3], dx[7][3]
         double* terms = sx + (size_t)lp.max_pairs * 24;                 // [pair_chunk][strideL][24]
-        double* part = terms + (size_t)lp.pair_chunk * lp.strideL * 24; // [4][64][4] + flags; reused as Jacobian staging
+        double* part = terms + (size_t)lp.pair_chunk * lp.strideL * 24; // [4][64][4] partial scans
         int* pneg = reinterpret_cast<int*>(part + 4 * 64 * 4);          // [4][64]
+        double* stage = part + 4 * 64 * 4 + 4 * 64 / 2;                 // [64][n] Jacobian staging tile
 
         const int q_begin = role * P2_ROWS;
         const int q_end = min(Q, q_begin + P2_ROWS);
@@ -159,6 +220,10 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         const int my_cnt = base + (wv < rem ? 1 : 0), my_start = wv * base + min(wv, rem);
         for (int s = 0; s < my_start; s++) live &= live - 1ull;
         double a0[P2_PPW], a1[P2_PPW], a2[P2_PPW], dd[P2_PPW], dl[P2_PPW];
+        const int lt_first = q_begin / O;
+        const int npairs = (q_end - 1) / O - lt_first + 1;
+        const bool single_pass = npairs <= lp.pair_chunk;
+        PassRegs pr;
 #pragma unroll
         for (int i = 0; i < P2_PPW; i++) {
             a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
@@ -172,131 +237,139 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
             a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;
 #endif
         }
-        // 2. slice the (l,t) link PZs this block's rows touch: one thread per (pair, monomial, output entry).
-        //    The table loads of a pass are issued before the k-power table is waited for, so the fresh k (an HBM
-        //    miss), the PZ tables (L2) and the planes are all in flight together.
-        const int lt_first = q_begin / O;
-        const int npairs = (q_end - 1) / O - lt_first + 1;
+        P2_STAMP(1);
+        // 2. per point: slice the (l,t) link PZs this block's rows touch (one thread per (pair, monomial, axis)), then
+        //    scan the planes.  The link-PZ table entries do not depend on k: when one pass covers all pairs they are
+        //    loaded once, before the k-power table of the first point is waited for, so the fresh k (an HBM miss), the
+        //    PZ tables (L2) and the planes are all in flight together.
         const int per_pair = lp.strideL * 24;
-        const int per_pair3 = lp.strideL * 3;  // tasks per pair: (monomial, axis), 8 outputs each
-        fill_kpow(kp, k, n);
-        for (int p0 = 0; p0 < npairs; p0 += lp.pair_chunk) {
-            const int pc = min(lp.pair_chunk, npairs - p0);
-            const int ntask = pc * per_pair3;
-            uint32_t tkey[P2_TASK_ROUNDS];
-            double tco[P2_TASK_ROUNDS];
-            int tcnt[P2_TASK_ROUNDS], tdst[P2_TASK_ROUNDS];
-#pragma unroll
-            for (int r = 0; r < P2_TASK_ROUNDS; r++) {
-                const int task = tid + r * P2_BLOCK;
-                tcnt[r] = -1;
-                if (task < ntask) {
-                    const int pr = task / per_pair3, rem = task - pr * per_pair3, mo = rem / 3, e = rem - mo * 3;
-                    const size_t idx = (size_t)b * tb.J * T + (lt_first + p0 + pr);
-                    tcnt[r] = tb.link_count[idx] - mo;  // > 0: live monomial
-                    tdst[r] = pr * per_pair + mo * 24 + e;
-                    if (mo < tb.capL) {
-                        tkey[r] = tb.link_keys[idx * tb.capL + mo];
-                        tco[r] = tb.link_coeff[(idx * tb.capL + mo) * 3 + e];
-                    }
-                }
-            }
-            // reduce-phase inputs (centre, independent radius, count) for thread < pc*24
-            double rc_cen = 0.0, rc_ind = 0.0;
-            int rc_cnt = 0;
-            if (tid < pc * 24) {
-                const int pr = tid / 24, c = tid - pr * 24, e = c % 3;
-                const size_t idx = (size_t)b * tb.J * T + (lt_first + p0 + pr);
-                rc_cnt = min(tb.link_count[idx], lp.strideL);
-                if (c < 3) { rc_cen = tb.link_center[idx * 3 + e]; rc_ind = tb.link_indep[idx * 3 + e]; }
-            }
-            __syncthreads();  // k-power table ready (first pass) / previous pass done with `terms`
-#pragma unroll
-            for (int r = 0; r < P2_TASK_ROUNDS; r++) {
-                if (tcnt[r] > 0) {
-                    double o8[8];
-                    mono_all<WANT_J>(kp, tkey[r], tco[r], n, o8);
-                    double* dst = terms + tdst[r];
-                    dst[0] = o8[0];
-                    if (WANT_J) {
-#pragma unroll
-                        for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) dst[3 + kk * 3] = o8[1 + kk];
-                    }
-                }
-            }
-            __syncthreads();
-            // ordered sum over monomials (the reference's accumulation order, RT/PZsparse.cu:420,470-472)
-            if (tid < pc * 24) {
-                const int pr = tid / 24, c = tid - pr * 24, out = c / 3, e = c - out * 3;
-                double acc = rc_cen;
-                const double* tp = terms + (size_t)pr * per_pair + c;
-#pragma unroll 4
-                for (int mo = 0; mo < rc_cnt; mo++) acc += tp[mo * 24];
-                if (out == 0) acc = interval_center(acc, rc_ind);
-                sx[(p0 + pr) * 24 + (out == 0 ? e : 3 + (out - 1) * 3 + e)] = acc;
-            }
-            __syncthreads();
-        }
-        // 3. this wave's 9 planes in the reference's scan order (pos_p before neg_p, strict >)
+        if (MULTI && single_pass) load_pass(tb, lp, b, lt_first, 0, npairs, pr);
         const double* xs = sx + (q / O - lt_first) * 24;
-        const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
-        double max_elt = -100000000.0;
-        // max_id defaults to plane 0 (RT/CollisionChecking.cu:262): its normal if it is live, zero if it was skipped
-        double mA0 = (wv == 0 && plane0_live) ? a0[0] : 0.0, mA1 = (wv == 0 && plane0_live) ? a1[0] : 0.0, mA2 = (wv == 0 && plane0_live) ? a2[0] : 0.0;
-        bool neg = false;
+        for (int s = 0; s < nsteps; s++) {
+            KPow& kp = kp2[s & 1];
+            const double k_cur = k_next;
+            if (tid < n && s + 1 < nsteps) k_next = k0[(size_t)(s + 1) * lp.k_stride + tid];
+            fill_kpow(kp, k_cur, n);
+            double* g = WANT_G ? g0 + (size_t)s * lp.g_stride : nullptr;
+            double* jac = WANT_J ? jac0 + (size_t)s * lp.j_stride : nullptr;
+            for (int p0 = 0; p0 < npairs; p0 += lp.pair_chunk) {
+                const int pc = min(lp.pair_chunk, npairs - p0);
+                if (!MULTI || !single_pass) load_pass(tb, lp, b, lt_first, p0, pc, pr);
+                __syncthreads();  // k-power table ready / previous pass or point done with `terms`
+                P2_STAMP(2);
 #pragma unroll
-        for (int i = 0; i < P2_PPW; i++) {
-            double pos_res = -100000000.0, neg_res = -100000000.0;
-            if (a0[i] != 0.0 || a1[i] != 0.0 || a2[i] != 0.0) {  // A_elt.norm() > 0 (RT/CollisionChecking.cu:252)
+                for (int r = 0; r < P2_TASK_ROUNDS; r++) {
+                    if (pr.tcnt[r] > 0) {
+                        double o8[8];
+                        mono_all<WANT_J>(kp, pr.tkey[r], pr.tco[r], n, o8);
+                        double* dst = terms + pr.tdst[r];
+                        dst[0] = o8[0];
+                        if (WANT_J) {
+#pragma unroll
+                            for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) dst[3 + kk * 3] = o8[1 + kk];
+                        }
+                    }
+                }
+                __syncthreads();
+                P2_STAMP(3);
+                // ordered sum over monomials (the reference's accumulation order, RT/PZsparse.cu:420,470-472)
+                if (tid < pc * 24) {
+                    const int pi = tid / 24, c = tid - pi * 24, out = c / 3, e2 = c - out * 3;
+                    double acc = pr.rc_cen;
+                    const double* tp = terms + (size_t)pi * per_pair + c;
+#pragma unroll 4
+                    for (int mo = 0; mo < pr.rc_cnt; mo++) acc += tp[mo * 24];
+                    if (out == 0) acc = interval_center(acc, pr.rc_ind);
+                    sx[(p0 + pi) * 24 + (out == 0 ? e2 : 3 + (out - 1) * 3 + e2)] = acc;
+                }
+                __syncthreads();
+            }
+            P2_STAMP(4);
+            // 3. this wave's planes in the reference's scan order (pos_p before neg_p, strict >), branch-free: `best` is
+            //    2*slot + (1 if the negative side won); the winner's normal is picked out of the registers afterwards.
+            //    max_id defaults to plane 0 (RT/CollisionChecking.cu:262): its normal if it is live (then it is slot 0 of
+            //    wave 0), zero if it was skipped (best = -2 matches no slot).
+            const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
+            double max_elt = -100000000.0;
+            int best = (wv == 0 && plane0_live) ? 0 : -2;
+#pragma unroll
+            for (int i = 0; i < P2_PPW; i++) {
+                const bool nz = (a0[i] != 0.0) | (a1[i] != 0.0) | (a2[i] != 0.0);  // A_elt.norm() > 0 (RT/CollisionChecking.cu:252)
                 const double dot = a0[i] * x0 + a1[i] * x1 + a2[i] * x2;
-                pos_res = dot - (dd[i] + dl[i]);
-                neg_res = -dot - (-dd[i] + dl[i]);
+                const double pos_res = nz ? dot - (dd[i] + dl[i]) : -100000000.0;
+                const double neg_res = nz ? -dot - (-dd[i] + dl[i]) : -100000000.0;
+                const bool c1 = pos_res > max_elt;
+                max_elt = c1 ? pos_res : max_elt; best = c1 ? 2 * i : best;
+                const bool c2 = neg_res > max_elt;
+                max_elt = c2 ? neg_res : max_elt; best = c2 ? 2 * i + 1 : best;
             }
-            if (pos_res > max_elt) { max_elt = pos_res; mA0 = a0[i]; mA1 = a1[i]; mA2 = a2[i]; neg = false; }
-            if (neg_res > max_elt) { max_elt = neg_res; mA0 = a0[i]; mA1 = a1[i]; mA2 = a2[i]; neg = true; }
-        }
-        double* my = part + ((size_t)wv * 64 + lane) * 4;
-        my[0] = max_elt; my[1] = mA0; my[2] = mA1; my[3] = mA2;
-        pneg[wv * 64 + lane] = neg ? 1 : 0;
-        __syncthreads();
-        // 4. wave 0 merges the four partial scans in plane order and finishes the row
-        double jrow_local[ARMOUR_MAX_FACTORS];
-        if (wv == 0) {
+            {
+                double mA0 = 0.0, mA1 = 0.0, mA2 = 0.0;
+                const int bs = best >> 1;
 #pragma unroll
-            for (int w2 = 1; w2 < 4; w2++) {
-                const double* o = part + ((size_t)w2 * 64 + lane) * 4;
-                if (o[0] > max_elt) { max_elt = o[0]; mA0 = o[1]; mA1 = o[2]; mA2 = o[3]; neg = pneg[w2 * 64 + lane] != 0; }
+                for (int i = 0; i < P2_PPW; i++) {
+                    const bool hit = bs == i;
+                    mA0 = hit ? a0[i] : mA0; mA1 = hit ? a1[i] : mA1; mA2 = hit ? a2[i] : mA2;
+                }
+                double* my = part + ((size_t)wv * 64 + lane) * 4;
+                my[0] = max_elt; my[1] = mA0; my[2] = mA1; my[3] = mA2;
+                pneg[wv * 64 + lane] = best & 1;  // (-2 & 1) = 0
             }
+            __syncthreads();
+            P2_STAMP(5);
+            // 4. every wave merges the four partial scans in plane order (the reference's serial winner), then takes its
+            //    share of the row's outputs: wave 0 the value, wave w the Jacobian columns w and w + 4
+            {
+                const double* c0 = part + (size_t)lane * 4;
+                double m_elt = c0[0], mA0 = c0[1], mA1 = c0[2], mA2 = c0[3];
+                int neg = pneg[lane];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; w2++) {
+                    const double* o = part + ((size_t)w2 * 64 + lane) * 4;
+                    const double oe = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+                    const int on = pneg[w2 * 64 + lane];
+                    const bool c = oe > m_elt;
+                    m_elt = c ? oe : m_elt; mA0 = c ? o1 : mA0; mA1 = c ? o2 : mA1; mA2 = c ? o3 : mA2; neg = c ? on : neg;
+                }
 #if defined(P2_ABLATE) && (P2_ABLATE & 32)
-            if (WANT_G && max_elt == 12345.678) g[(size_t)n * T + q_begin + lane] = -max_elt;
+                if (WANT_G && wv == 0 && m_elt == 12345.678) g[(size_t)n * T + q_begin + lane] = -m_elt;
 #else
-            if (WANT_G && q_begin + lane < q_end) g[(size_t)n * T + q_begin + lane] = -max_elt;
+                if (WANT_G && wv == 0 && q_begin + lane < q_end) g[(size_t)n * T + q_begin + lane] = -m_elt;
 #endif
-            if (WANT_J) {
-                for (int kk = 0; kk < n; kk++) {
-                    const double* dx = xs + 3 + kk * 3;
-                    const double dot = mA0 * dx[0] + mA1 * dx[1] + mA2 * dx[2];
-                    jrow_local[kk] = neg ? dot : -dot;
+                if (WANT_J) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int kk = wv + 4 * h;
+                        if (kk < n) {
+                            const double* dx = xs + 3 + kk * 3;
+                            const double dot = mA0 * dx[0] + mA1 * dx[1] + mA2 * dx[2];
+                            stage[lane * n + kk] = neg ? dot : -dot;
+                        }
+                    }
                 }
             }
-        }
-        if (WANT_J) {
-            __syncthreads();  // everyone is done reading `part`; reuse it as the [64][n] Jacobian staging tile
-            if (wv == 0)
-                for (int kk = 0; kk < n; kk++) part[lane * n + kk] = jrow_local[kk];
-            __syncthreads();
-            const int total = (q_end - q_begin) * n;
-            double* jrow = jac + ((size_t)n * T + q_begin) * n;
+            if (WANT_J) {
+                __syncthreads();
+                const int total = (q_end - q_begin) * n;
+                double* jrow = jac + ((size_t)n * T + q_begin) * n;
 #if defined(P2_ABLATE) && (P2_ABLATE & 32)
-            for (int i = tid; i < total; i += P2_BLOCK) if (part[i] == 12345.678) jrow[i] = part[i];
+                for (int i = tid; i < total; i += P2_BLOCK) if (stage[i] == 12345.678) jrow[i] = stage[i];
 #else
-            for (int i = tid; i < total; i += P2_BLOCK) jrow[i] = part[i];
+                for (int i = tid; i < total; i += P2_BLOCK) jrow[i] = stage[i];
 #endif
+            }
         }
+#ifdef P2_TIMELINE
+        P2_STAMP(6);
+        stamp[7] = __builtin_amdgcn_s_memtime() - cyc0;
+        if (tid == 0 && (role == 0 || role == lp.nbc / 2 || role == lp.nbc - 1)) {
+            const int slot = role == 0 ? 0 : role == lp.nbc - 1 ? 2 : 1;
+            for (int i2 = 0; i2 < 8; i2++) g_all[(size_t)b * m + (size_t)n * T + Q + slot * 8 + i2] = (double)(stamp[i2] & 0xffffffffffffull);
+        }
+#endif
     } else if (role < lp.nbc + lp.nbt) {
         // ------------------------------------------------------------------ torque rows (row = t*n + j)
         double* terms = lds;  // [P2_TQ_ROWS][strideT][8]
-        fill_kpow(kp, k, n);
         const int r = tid >> 5, ml = tid & 31;
         const int row = (role - lp.nbc) * P2_TQ_ROWS + r;
         const bool live = row < n * T;
@@ -313,41 +386,50 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
 #pragma unroll
             for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
                 const int mo = ml + rr * 32;
+                tkey[rr] = 0; tco[rr] = 0.0;
                 if (mo < lp.strideT && mo < tb.capT) { tkey[rr] = tb.tq_keys[idx * tb.capT + mo]; tco[rr] = tb.tq_coeff[idx * tb.capT + mo]; }
             }
         }
-        __syncthreads();
-        if (live) {
+        for (int s = 0; s < nsteps; s++) {
+            KPow& kp = kp2[s & 1];
+            const double k_cur = k_next;
+            if (tid < n && s + 1 < nsteps) k_next = k0[(size_t)(s + 1) * lp.k_stride + tid];
+            fill_kpow(kp, k_cur, n);
+            double* g = WANT_G ? g0 + (size_t)s * lp.g_stride : nullptr;
+            double* jac = WANT_J ? jac0 + (size_t)s * lp.j_stride : nullptr;
+            __syncthreads();  // k-power table ready; every thread is done with the previous point's `terms`
+            if (live) {
 #pragma unroll
-            for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
-                const int mo = ml + rr * 32;
-                if (mo < cnt) {
-                    double* tp = terms + ((size_t)r * lp.strideT + mo) * 8;
-                    double o8[8];
-                    mono_all<WANT_J>(kp, tkey[rr], tco[rr], n, o8);
-                    tp[0] = o8[0];
-                    if (WANT_J) {
+                for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
+                    const int mo = ml + rr * 32;
+                    if (mo < cnt) {
+                        double* tp = terms + ((size_t)r * lp.strideT + mo) * 8;
+                        double o8[8];
+                        mono_all<WANT_J>(kp, tkey[rr], tco[rr], n, o8);
+                        tp[0] = o8[0];
+                        if (WANT_J) {
 #pragma unroll
-                        for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) tp[1 + kk] = o8[1 + kk];
+                            for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) tp[1 + kk] = o8[1 + kk];
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
-        if (live && ml <= n) {
-            const double* tp = terms + (size_t)r * lp.strideT * 8 + ml;
-            if (ml == 0) {
-                if (WANT_G) {
-                    double cen = cen0;
+            __syncthreads();
+            if (live && ml <= n) {
+                const double* tp = terms + (size_t)r * lp.strideT * 8 + ml;
+                if (ml == 0) {
+                    if (WANT_G) {
+                        double cen = cen0;
 #pragma unroll 4
-                    for (int mo = 0; mo < cnt; mo++) cen += tp[mo * 8];
-                    g[row] = interval_center(cen, ind0);
+                        for (int mo = 0; mo < cnt; mo++) cen += tp[mo * 8];
+                        g[row] = interval_center(cen, ind0);
+                    }
+                } else if (WANT_J) {
+                    double gr = 0.0;
+#pragma unroll 4
+                    for (int mo = 0; mo < cnt; mo++) gr += tp[mo * 8];
+                    jac[(size_t)row * n + (ml - 1)] = gr;
                 }
-            } else if (WANT_J) {
-                double gr = 0.0;
-#pragma unroll 4
-                for (int mo = 0; mo < cnt; mo++) gr += tp[mo * 8];
-                jac[(size_t)row * n + (ml - 1)] = gr;
             }
         }
     } else {
@@ -358,46 +440,52 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         double* pv = lds;  // [2n][8]
         const int jv = tid >> 3, piece = tid & 7;
         const double* bz = tb.bez + (size_t)b * 3 * n;
-        if (jv < 2 * n && piece < 6) {
-            const int i = jv % n;
-            const bool vel = jv >= n;
-            const double q0 = bz[i], a = bz[n + i], bb = bz[2 * n + i], ka = tb.k_range[i] * k[i];
-            double e2, e3, v;
-            if (!vel) bez::q_stationary(a, bb, ka, &e2, &e3); else bez::qd_stationary(a, bb, ka, &e2, &e3);
-            if (piece < 4) {
-                const double tt = piece == 0 ? 0.0 : piece == 1 ? e2 : piece == 2 ? e3 : 1.0;
-                v = vel ? bez::qd_des(q0, a, bb, ka, tt) : bez::q_des(q0, a, bb, ka, tt);
-            } else {
-                const int sg = piece == 4 ? +1 : -1;
-                v = vel ? bez::qd_extremum_dk(q0, a, bb, ka, sg) : bez::q_extremum_dk(q0, a, bb, ka, sg);
+        for (int s = 0; s < nsteps; s++) {
+            const double* k = k0 + (size_t)s * lp.k_stride;
+            double* g = WANT_G ? g0 + (size_t)s * lp.g_stride : nullptr;
+            double* jac = WANT_J ? jac0 + (size_t)s * lp.j_stride : nullptr;
+            if (jv < 2 * n && piece < 6) {
+                const int i = jv % n;
+                const bool vel = jv >= n;
+                const double q0 = bz[i], a = bz[n + i], bb = bz[2 * n + i], ka = tb.k_range[i] * k[i];
+                double e2, e3, v;
+                if (!vel) bez::q_stationary(a, bb, ka, &e2, &e3); else bez::qd_stationary(a, bb, ka, &e2, &e3);
+                if (piece < 4) {
+                    const double tt = piece == 0 ? 0.0 : piece == 1 ? e2 : piece == 2 ? e3 : 1.0;
+                    v = vel ? bez::qd_des(q0, a, bb, ka, tt) : bez::q_des(q0, a, bb, ka, tt);
+                } else {
+                    const int sg = piece == 4 ? +1 : -1;
+                    v = vel ? bez::qd_extremum_dk(q0, a, bb, ka, sg) : bez::q_extremum_dk(q0, a, bb, ka, sg);
+                }
+                pv[jv * 8 + piece] = v;
+                if (piece == 1) pv[jv * 8 + 6] = e2;
+                if (piece == 2) pv[jv * 8 + 7] = e3;
             }
-            pv[jv * 8 + piece] = v;
-            if (piece == 1) pv[jv * 8 + 6] = e2;
-            if (piece == 2) pv[jv * 8 + 7] = e3;
-        }
-        __syncthreads();
-        if (tid < 2 * n) {
-            const int i = tid % n;
-            const bool vel = tid >= n;
-            const double* v = pv + tid * 8;
-            const double v1 = v[0], v2 = v[1], v3 = v[2], v4 = v[3], e2 = v[6], e3 = v[7];
-            double mn, mx;
-            int mnId, mxId;
-            if (v1 < v4) { mn = v1; mnId = 1; mx = v4; mxId = 4; } else { mn = v4; mnId = 4; mx = v1; mxId = 1; }
-            if (0 <= e2 && e2 <= 1) { if (v2 < mn) { mn = v2; mnId = 2; } if (mx < v2) { mx = v2; mxId = 2; } }
-            if (0 <= e3 && e3 <= 1) { if (v3 < mn) { mn = v3; mnId = 3; } if (mx < v3) { mx = v3; mxId = 3; } }
-            const double sc = vel ? tb.k_range[i] / tb.duration : tb.k_range[i];
-            const double dmn = (mnId == 1 ? 0.0 : mnId == 2 ? v[4] : mnId == 3 ? v[5] : 1.0) * sc;
-            const double dmx = (mxId == 1 ? 0.0 : mxId == 2 ? v[4] : mxId == 3 ? v[5] : 1.0) * sc;
-            const size_t off = (size_t)n * T + Q;
-            const size_t r_mn = off + (vel ? 2 * n : 0) + i, r_mx = r_mn + n;
-            if (WANT_G) { g[r_mn] = vel ? mn / tb.duration : mn; g[r_mx] = vel ? mx / tb.duration : mx; }
-            if (WANT_J) {
-                for (int c = 0; c < n; c++) {
-                    jac[r_mn * n + c] = (c == i) ? dmn : 0.0;
-                    jac[r_mx * n + c] = (c == i) ? dmx : 0.0;
+            __syncthreads();
+            if (tid < 2 * n) {
+                const int i = tid % n;
+                const bool vel = tid >= n;
+                const double* v = pv + tid * 8;
+                const double v1 = v[0], v2 = v[1], v3 = v[2], v4 = v[3], e2 = v[6], e3 = v[7];
+                double mn, mx;
+                int mnId, mxId;
+                if (v1 < v4) { mn = v1; mnId = 1; mx = v4; mxId = 4; } else { mn = v4; mnId = 4; mx = v1; mxId = 1; }
+                if (0 <= e2 && e2 <= 1) { if (v2 < mn) { mn = v2; mnId = 2; } if (mx < v2) { mx = v2; mxId = 2; } }
+                if (0 <= e3 && e3 <= 1) { if (v3 < mn) { mn = v3; mnId = 3; } if (mx < v3) { mx = v3; mxId = 3; } }
+                const double sc = vel ? tb.k_range[i] / tb.duration : tb.k_range[i];
+                const double dmn = (mnId == 1 ? 0.0 : mnId == 2 ? v[4] : mnId == 3 ? v[5] : 1.0) * sc;
+                const double dmx = (mxId == 1 ? 0.0 : mxId == 2 ? v[4] : mxId == 3 ? v[5] : 1.0) * sc;
+                const size_t off = (size_t)n * T + Q;
+                const size_t r_mn = off + (vel ? 2 * n : 0) + i, r_mx = r_mn + n;
+                if (WANT_G) { g[r_mn] = vel ? mn / tb.duration : mn; g[r_mx] = vel ? mx / tb.duration : mx; }
+                if (WANT_J) {
+                    for (int c = 0; c < n; c++) {
+                        jac[r_mn * n + c] = (c == i) ? dmn : 0.0;
+                        jac[r_mx * n + c] = (c == i) ? dmx : 0.0;
+                    }
                 }
             }
+            __syncthreads();  // `pv` is rewritten by the next point
         }
     }
 }
@@ -406,7 +494,7 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
 __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restrict__ k_all, double* __restrict__ centers) {
     __shared__ KPow kp;
     const int b = blockIdx.y;
-    fill_kpow(kp, k_all + (size_t)b * tb.n, tb.n);
+    fill_kpow(kp, threadIdx.x < (unsigned)tb.n ? k_all[(size_t)b * tb.n + threadIdx.x] : 0.0, tb.n);
     __syncthreads();
     const int task = blockIdx.x * blockDim.x + threadIdx.x;
     const int JT = tb.J * tb.T;
@@ -426,7 +514,7 @@ __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restri
 const char* armour_p2_kernel_name(void) { return "armour_p2_eval_kernel"; }
 
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac,
-                     hipStream_t stream) {
+                     hipStream_t stream, int steps, long long k_stride, long long g_stride, long long j_stride) {
     if (!d_g && !d_jac) return ARMOUR_OK;
     P2Launch lp;
     lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
@@ -436,16 +524,21 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     lp.strideT = max_torque > 0 ? max_torque : 1;
     lp.skip_by_value = (tb.B == 1 && h_skip) ? 1 : 0;
     lp.skip0 = lp.skip_by_value ? h_skip[0] : 0ull;
+    lp.steps = steps; lp.k_stride = k_stride; lp.g_stride = g_stride; lp.j_stride = j_stride;
     if (lp.strideL * 3 > P2_BLOCK * P2_TASK_ROUNDS) { armour_set_error("link PZ with %d monomials exceeds the P2 kernel's %d", lp.strideL, P2_BLOCK * P2_TASK_ROUNDS / 3); return ARMOUR_ECAPACITY; }
     lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / 24), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
     if (lp.strideT > 32 * P2_TQ_ROUNDS) { armour_set_error("torque PZ with %d monomials exceeds the P2 kernel's %d", lp.strideT, 32 * P2_TQ_ROUNDS); return ARMOUR_ECAPACITY; }
-    const size_t col = ((size_t)lp.max_pairs * 24 + (size_t)lp.pair_chunk * lp.strideL * 24 + 4 * 64 * 4) * sizeof(double) + 4 * 64 * sizeof(int);
+    const size_t col = ((size_t)lp.max_pairs * 24 + (size_t)lp.pair_chunk * lp.strideL * 24 + 4 * 64 * 4 + 64 * ARMOUR_MAX_FACTORS) * sizeof(double) + 4 * 64 * sizeof(int);
     const size_t tq = (size_t)P2_TQ_ROWS * lp.strideT * 8 * sizeof(double);
     const size_t lim = (size_t)2 * ARMOUR_MAX_FACTORS * 8 * sizeof(double);
-    const size_t smem = sizeof(KPow) + std::max(std::max(col, tq), lim);
+    const size_t smem = 2 * sizeof(KPow) + std::max(std::max(col, tq), lim);
     if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }
     dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
-#define P2_LAUNCH(G, J) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp)
+#define P2_LAUNCH(G, J)                                                                                                     \
+    do {                                                                                                                    \
+        if (steps > 1) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);  \
+        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);           \
+    } while (0)
     if (d_g && d_jac) P2_LAUNCH(true, true);
     else if (d_g) P2_LAUNCH(true, false);
     else P2_LAUNCH(false, true);

@@ -186,6 +186,11 @@ class ArmourNLP:
         """`steps` back-to-back fused evaluations (d_k holds [steps][B][n]); asynchronous."""
         check(self.L.armour_eval_g_jac_device_steps(self.h, d_k, steps, d_g, d_jac, stream))
 
+    def eval_g_jac_device_multi(self, d_k, points, d_g, d_jac, stream=0):
+        """`points` evaluations of the same problems in one launch: d_k [points][B][n] -> d_g [points][B][m],
+        d_jac [points][B][m][n]; asynchronous.  Bit-identical to `points` single launches."""
+        check(self.L.armour_eval_g_jac_device_multi(self.h, d_k, points, d_g, d_jac, stream))
+
     def finalize_solution(self, g):
         """feasible[B] from g[B,m] with the reference's slack thresholds -- RT/NLPclass.cu:422-538."""
         g = np.ascontiguousarray(np.asarray(g, dtype=np.float64).reshape(self.B, self.m))

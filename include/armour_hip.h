@@ -102,6 +102,15 @@ int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, d
  * (the IPOPT iterate sequence of RT/armour_main.cu:273 with the solver's own arithmetic removed). */
 int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
                                    void* stream);
+/* `points` evaluations of the SAME problems in ONE kernel launch: point s reads d_k + s*B*n and writes
+ * d_g + s*B*m, d_jac + s*B*m*n (d_k [points][B][n], d_g [points][B][m], d_jac [points][B][m][n]; d_g / d_jac may be
+ * NULL).  Every block keeps its share of the plane and PZ tables in registers across the points, so the tables are
+ * read once per launch instead of once per point.  Results are bit-identical to `points` separate
+ * armour_eval_g_jac_device calls.  For callers that know several trial points at once (line search, multi-start,
+ * finite-difference checks -- the derivative checker of RT/armour_main.cu:248-251); IPOPT's own iterate sequence is
+ * serial and uses the one-point entries above. */
+int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_k, int32_t points, double* d_g, double* d_jac,
+                                   void* stream);
 /* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
 int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 

@@ -120,3 +120,47 @@ def test_matlab_callback_shape(sample_problem):
     _, _, gl, gu = o.bounds()
     assert np.abs(h[:m] - (g_ref - gu)).max() <= G_TOL
     assert np.abs(grad_h[:, :m] - jac_ref.T).max() <= J_TOL
+
+
+@pytest.mark.parametrize("B,O,points", [(1, 10, 5), (3, 7, 4), (2, 0, 3), (1, 40, 2)])
+def test_multi_point_launch_is_bit_identical(B, O, points):
+    """armour_eval_g_jac_device_multi keeps the tables in registers over `points` k's: every point must equal the
+    one-point launch bit for bit (same arithmetic, same order), including with g-only / jac-only outputs, and the
+    back-to-back `_steps` entry must leave the last point's result."""
+    import torch
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_k, random_problem
+    T = 100
+    probs = [random_problem(20 + s, O) for s in range(B)]
+    oracles = [_oracle(T, p) for p in probs]
+    stack = lambda key: np.stack([p[key] for p in probs])
+    nlp = ArmourNLP(T=T).debug_load_tables(stack("q0"), stack("qd0"), stack("qdd0"), stack("q_des"), oracle_tables(oracles))
+    m, n = nlp.m, nlp.n
+    ks = np.stack([random_k(100 + s, B) for s in range(points)])            # [points, B, n]
+    ref = [nlp.eval_g_jac(ks[s]) for s in range(points)]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    d_k = torch.from_numpy(ks).to(dev)
+    d_g = torch.full((points, B, m), float("nan"), dtype=torch.float64, device=dev)
+    d_j = torch.full((points, B, m, n), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    nlp.eval_g_jac_device_multi(d_k.data_ptr(), points, d_g.data_ptr(), d_j.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    for s in range(points):
+        assert np.array_equal(d_g[s].cpu().numpy(), ref[s][0])
+        assert np.array_equal(d_j[s].cpu().numpy(), ref[s][1])
+    # g only / jac only
+    d_g2 = torch.zeros_like(d_g); d_j2 = torch.zeros_like(d_j)
+    nlp.eval_g_jac_device_multi(d_k.data_ptr(), points, d_g2.data_ptr(), 0, st.cuda_stream)
+    nlp.eval_g_jac_device_multi(d_k.data_ptr(), points, 0, d_j2.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(d_g2, d_g) and torch.equal(d_j2, d_j)
+    # `_steps`: one launch per point, outputs overwritten
+    d_g1 = torch.zeros((B, m), dtype=torch.float64, device=dev); d_j1 = torch.zeros((B, m, n), dtype=torch.float64, device=dev)
+    nlp.eval_g_jac_device_steps(d_k.data_ptr(), points, d_g1.data_ptr(), d_j1.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(d_g1, d_g[-1]) and torch.equal(d_j1, d_j[-1])
+    # and against the oracle at one of the points
+    g_ref, jac_ref = oracles[0].eval_g_jac(ks[-1, 0])
+    assert np.abs(d_g[-1, 0].cpu().numpy() - g_ref).max() <= G_TOL
+    assert np.abs(d_j[-1, 0].cpu().numpy() - jac_ref).max() <= J_TOL
