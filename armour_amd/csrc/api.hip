@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/armour_robot_kinova.h"
@@ -30,12 +31,38 @@ extern "C" int armour_device_available(void) {
     return n > 0 ? 1 : 0;
 }
 
+// page-locked host ranges handed out by armour_alloc_pinned: armour_eval_g_jac lets the kernel read k from and write
+// g / jac to them directly over PCIe (one launch, no staging copies) when every buffer of the call lies in one
+namespace {
+struct PinnedRange { const char* p; size_t bytes; };
+std::mutex g_pinned_mu;
+std::vector<PinnedRange> g_pinned;
+bool in_pinned(const void* q, size_t bytes) {
+    if (!q) return true;
+    const char* c = static_cast<const char*>(q);
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (const PinnedRange& r : g_pinned)
+        if (c >= r.p && c + bytes <= r.p + r.bytes) return true;
+    return false;
+}
+}  // namespace
+
 extern "C" int armour_alloc_pinned(uint64_t bytes, void** out) {
     if (!out) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned.push_back({static_cast<const char*>(*out), (size_t)(bytes ? bytes : 1)});
     return ARMOUR_OK;
 }
-extern "C" void armour_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" void armour_free_pinned(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned.size(); i++)
+            if (g_pinned[i].p == p) { g_pinned.erase(g_pinned.begin() + i); break; }
+    }
+    (void)hipHostFree(p);
+}
 
 template <class Tp>
 static int dev_alloc(Tp** p, size_t count) {
@@ -142,10 +169,20 @@ extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* param
     return ARMOUR_OK;
 }
 
+double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes) {
+    if (h->solve_pin[slot] && h->solve_pin_bytes[slot] >= bytes) return static_cast<double*>(h->solve_pin[slot]);
+    if (h->solve_pin[slot]) { armour_free_pinned(h->solve_pin[slot]); h->solve_pin[slot] = nullptr; h->solve_pin_bytes[slot] = 0; }
+    void* p = nullptr;
+    if (armour_alloc_pinned(bytes, &p) != ARMOUR_OK) return nullptr;
+    h->solve_pin[slot] = p; h->solve_pin_bytes[slot] = bytes;
+    return static_cast<double*>(p);
+}
+
 extern "C" void armour_destroy(ArmourPlanner* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 3; i++) armour_free_pinned(h->solve_pin[i]);
     armour_p1_free(h);
     dev_free(&h->d_link_count); dev_free(&h->d_link_center); dev_free(&h->d_link_indep);
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
@@ -379,25 +416,34 @@ extern "C" int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_
                             points, bn, bm, bm * h->n);
 }
 
+static int spin_on_stream(hipStream_t st) {
+    // spin on the stream instead of sleeping in hipStreamSynchronize: the whole call is tens of microseconds and an
+    // interrupt-driven wake-up would dominate it
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return ARMOUR_OK;
+        if (q != hipErrorNotReady) { armour_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+    }
+}
+
 extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac) {
     NEED_READY(h);
     if (!k) { armour_set_error("k is null"); return ARMOUR_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     const size_t bn = (size_t)h->B * h->n, bm = (size_t)h->B * h->m;
-    HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     const P2Tables tb = armour_make_tables(h);
+    if (in_pinned(k, bn * sizeof(double)) && in_pinned(g, bm * sizeof(double)) && in_pinned(jac, bm * h->n * sizeof(double))) {
+        // all buffers page-locked by armour_alloc_pinned: the kernel reads k and writes g / jac in host memory itself
+        int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), k, g, jac, h->stream);
+        if (rc != ARMOUR_OK) return rc;
+        return spin_on_stream(h->stream);
+    }
+    HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
     if (rc != ARMOUR_OK) return rc;
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    // spin on the stream instead of sleeping in hipStreamSynchronize: the whole call is tens of microseconds and an
-    // interrupt-driven wake-up would dominate it
-    for (;;) {
-        const hipError_t q = hipStreamQuery(h->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) { armour_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
-    }
-    return ARMOUR_OK;
+    return spin_on_stream(h->stream);
 }
 
 extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible) {

@@ -71,6 +71,9 @@ struct ArmourPlanner {
     // current problem set
     int B = 0, O = 0, Q = 0, m = 0;
     bool ready = false;
+    // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
+    void* solve_pin[3] = {nullptr, nullptr, nullptr};
+    size_t solve_pin_bytes[3] = {0, 0, 0};
     std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
     std::vector<double> h_torque_radius;              // [B][n][T]
     std::vector<double> h_link_gens;                  // [B][T][J][18]
@@ -105,6 +108,8 @@ struct ArmourPlanner {
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,
                      int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0);
 int armour_refresh_table_stats(ArmourPlanner* h);
+// page-locked scratch slot of the handle with at least `bytes` bytes (registered for the zero-copy eval path); nullptr on failure
+double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);
 

@@ -220,12 +220,12 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, n = h->n, m = h->m;
     // pinned host mirrors of k, g, jac for all problems
-    double *hk = nullptr, *hg = nullptr, *hj = nullptr;
+    // (owned by the handle and kept across solves; armour_eval_g_jac recognises them and lets the kernel write into them)
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipHostMalloc((void**)&hk, (size_t)B * n * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&hg, (size_t)B * m * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&hj, (size_t)B * m * n * sizeof(double), hipHostMallocDefault));
-    struct Guard { double *a, *b, *c; ~Guard() { (void)hipHostFree(a); (void)hipHostFree(b); (void)hipHostFree(c); } } guard{hk, hg, hj};
+    double* hk = armour_handle_pinned(h, 0, (size_t)B * n * sizeof(double));
+    double* hg = armour_handle_pinned(h, 1, (size_t)B * m * sizeof(double));
+    double* hj = armour_handle_pinned(h, 2, (size_t)B * m * n * sizeof(double));
+    if (!hk || !hg || !hj) return ARMOUR_EDEVICE;
 
     std::vector<double> xl(n), xu(n), gl((size_t)B * m), gu((size_t)B * m);
     int rc = armour_get_bounds(h, xl.data(), xu.data(), gl.data(), gu.data());

@@ -194,10 +194,11 @@ def main():
         for _ in range(20):
             nlp.eval_g_jac(k1)
         sync_us = (time.perf_counter() - t1) / 20 * 1e6
+        nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
         t1 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(50):
             nlp.eval_g_jac(k1, pinned=True)
-        sync_pinned_us = (time.perf_counter() - t1) / 20 * 1e6
+        sync_pinned_us = (time.perf_counter() - t1) / 50 * 1e6
         out = {
             "metric": METRIC, "value": world * B * K / elapsed_max, "unit": "iters/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed_max * 1e3 / K, "higher_is_better": True,

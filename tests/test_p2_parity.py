@@ -30,6 +30,9 @@ def _check(nlp, oracles, ks):
     # separate g-only / jac-only entry points give the same numbers as the fused one
     assert np.array_equal(nlp.eval_g(ks), g)
     assert np.array_equal(nlp.eval_jac_g(ks), jac)
+    # page-locked buffers: the kernel reads k / writes g, jac in host memory directly (no staging copies)
+    g_p, jac_p = nlp.eval_g_jac(ks, pinned=True)
+    assert np.array_equal(g_p, g) and np.array_equal(jac_p, jac)
     return g, jac
 
 
