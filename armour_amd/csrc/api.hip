@@ -384,6 +384,19 @@ extern "C" int armour_eval_grad_f(ArmourPlanner* h, const double* k, double* gra
     return ARMOUR_OK;
 }
 
+extern "C" int armour_desired_trajectory(int32_t n, const double* q0, const double* qd0, const double* qdd0, const double* k_range,
+                                         double duration, const double* k, double t, double* q, double* qd, double* qdd) {
+    if (n < 1 || !q0 || !qd0 || !qdd0 || !k_range || !k || !(duration > 0)) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+    const double D = duration, s = t / D;  // the curve is parameterised on s = t / DURATION in [0,1] with qd0, qdd0 scaled accordingly (RT/Trajectory.cu:22-23)
+    for (int i = 0; i < n; i++) {
+        const double a = qd0[i] * D, b = qdd0[i] * D * D, ka = k_range[i] * k[i];
+        if (q) q[i] = bez::q_des(q0[i], a, b, ka, s);
+        if (qd) qd[i] = bez::qd_des(q0[i], a, b, ka, s) / D;
+        if (qdd) qdd[i] = bez::qdd_des(q0[i], a, b, ka, s) / (D * D);
+    }
+    return ARMOUR_OK;
+}
+
 extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, double* d_jac, void* stream) {
     NEED_READY(h);
     if (!d_k) { armour_set_error("d_k is null"); return ARMOUR_EINVAL; }

@@ -696,12 +696,28 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
         c.freeS = (1u << kNS) - 1u;
         for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
         __syncthreads();
+#ifdef P1_PROFILE
+        const long long ph0 = clock64();
+#endif
         build_jrs(c, b, t);
+#ifdef P1_PROFILE
+        const long long ph1 = clock64();
+#endif
         run_fk(c, b, t);
+#ifdef P1_PROFILE
+        const long long ph2 = clock64();
+#endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
         run_rnea(c, u_nom);
+#ifdef P1_PROFILE
+        const long long ph3 = clock64();
+#endif
         finish_torque(c, u_nom, b, t);
         __syncthreads();
+#ifdef P1_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x == 0)
+            printf("[P1 phases, wave 0] jrs %lld fk %lld rnea %lld torque %lld cycles\n", ph1 - ph0, ph2 - ph1, ph3 - ph2, (long long)clock64() - ph3);
+#endif
     }
 #ifdef P1_PROFILE
     if (threadIdx.x == 0 && blockIdx.x == 0) {

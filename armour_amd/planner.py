@@ -43,6 +43,29 @@ def default_params(T=128):
     return p
 
 
+def desired_trajectory(q0, qd0, qdd0, k, t, k_range=None, duration=1.0, t_plan=0.5, previous=None):
+    """uarmtd_planner.desired_trajectory for traj_type 'bernstein' (KSI/uarmtd_planner.m:846-925).
+
+    k finite: (q, qd, qdd) at time t of the planned degree-5 Bezier curve (armour_desired_trajectory).
+    k is None / NaN (no plan found): braking -- if t <= t_plan and the arm is moving, evaluate `previous`, the
+    desired-trajectory callable of the previous plan, at t + t_plan (:909-911); otherwise hold q0 with zero
+    velocity and acceleration (:912-916).  Returns three [n] arrays."""
+    q0 = np.ascontiguousarray(q0, dtype=np.float64).ravel()
+    qd0 = np.ascontiguousarray(qd0, dtype=np.float64).ravel()
+    qdd0 = np.ascontiguousarray(qdd0, dtype=np.float64).ravel()
+    n = q0.size
+    if k is None or np.any(np.isnan(np.asarray(k, dtype=np.float64))):
+        if t <= t_plan and np.linalg.norm(qd0) > 1e-8 and previous is not None:
+            return previous(t + t_plan)
+        return q0.copy(), np.zeros(n), np.zeros(n)
+    L = _lib.load()
+    kr = np.full(n, np.pi / 48) if k_range is None else np.ascontiguousarray(k_range, dtype=np.float64).ravel()
+    kk = np.ascontiguousarray(k, dtype=np.float64).ravel()
+    q, qd, qdd = np.zeros(n), np.zeros(n), np.zeros(n)
+    check(L.armour_desired_trajectory(n, _dp(q0), _dp(qd0), _dp(qdd0), _dp(kr), float(duration), _dp(kk), float(t), _dp(q), _dp(qd), _dp(qdd)))
+    return q, qd, qdd
+
+
 class ArmourNLP:
     """B independent planning problems on one MI355X (B = 1 is the reference's use)."""
 

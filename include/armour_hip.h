@@ -114,6 +114,16 @@ int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_k, int32_t 
 /* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
 int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 
+/* ---- caller side of the path: the trajectory the planner hands to the controller ---- */
+/* uarmtd_planner.desired_trajectory, traj_type 'bernstein' (KSI/uarmtd_planner.m:846-925, with
+ * PZM/utility/match_deg5_bernstein_coefficients.m and bernstein_to_poly.m): position / velocity / acceleration at time
+ * t in [0, duration] of the degree-5 Bezier curve that starts at (q0, qd0, qdd0) and ends at rest at
+ * q0 + k_range .* k -- the same curve the NLP constrains (RT/Trajectory.cu:542-602).  Stateless host arithmetic;
+ * any of q / qd / qdd may be NULL.  The braking fallback (k = NaN: re-use the previous plan shifted by t_plan, or
+ * hold position) is caller logic, see armour_amd/planner.py desired_trajectory. */
+int armour_desired_trajectory(int32_t n, const double* q0, const double* qd0, const double* qdd0, const double* k_range,
+                              double duration, const double* k, double t, double* q, double* qd, double* qdd);
+
 /* ---- NLP solve of the planning iteration ---- */
 /* Replaces IpoptApplication::OptimizeTNLP + armtd_NLP::finalize_solution (RT/armour_main.cu:237-304,
  * RT/NLPclass.cu:422-538) for all B problems of the handle at once: SQP on the device callbacks, start x = 0,

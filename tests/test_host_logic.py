@@ -112,3 +112,52 @@ def test_two_rank_gloo_sharding(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29531", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
     assert "GLOO_OK" in out.stdout, out.stdout + out.stderr
+
+
+def _matlab_desired_trajectory(q0, qd0, qdd0, q1, t):
+    """KSI/uarmtd_planner.m:886-905 restated: match_deg5_bernstein_coefficients (final velocity and acceleration 0,
+    T = 1) -> bernstein_to_poly -> power-basis evaluation of position, velocity and acceleration."""
+    from math import comb
+    out = []
+    for j in range(len(q0)):
+        beta = [q0[j], q0[j] + qd0[j] / 5, qdd0[j] / 20 + 2 * qd0[j] / 5 + q0[j], q1[j], q1[j], q1[j]]
+        alpha = [sum((-1) ** (i - jj) * comb(5, i) * comb(i, jj) * beta[jj] for jj in range(i + 1)) for i in range(6)]
+        q = sum(alpha[c] * t ** c for c in range(6))
+        qd = sum(c * alpha[c] * t ** (c - 1) for c in range(1, 6))
+        qdd = sum(c * (c - 1) * alpha[c] * t ** (c - 2) for c in range(2, 6))
+        out.append((q, qd, qdd))
+    return tuple(np.array(x) for x in zip(*out))
+
+
+def test_desired_trajectory_matches_the_matlab_bernstein_formulation():
+    """armour_desired_trajectory (the C++ closed form of RT/Trajectory.cu:542-602) against the MATLAB caller's
+    Bernstein -> monomial evaluation of the same curve; end conditions; braking fallback."""
+    from armour_amd.planner import desired_trajectory
+    rng = np.random.default_rng(5)
+    q0, qd0, qdd0 = rng.uniform(-3, 3, 7), rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    k = rng.uniform(-1, 1, 7)
+    kr = np.full(7, np.pi / 48)
+    for t in (0.0, 0.13, 0.5, 0.77, 1.0):
+        q, qd, qdd = desired_trajectory(q0, qd0, qdd0, k, t)
+        rq, rqd, rqdd = _matlab_desired_trajectory(q0, qd0, qdd0, q0 + kr * k, t)
+        assert np.abs(q - rq).max() <= 1e-12 and np.abs(qd - rqd).max() <= 1e-11 and np.abs(qdd - rqdd).max() <= 1e-10
+    q, qd, qdd = desired_trajectory(q0, qd0, qdd0, k, 0.0)
+    assert np.abs(q - q0).max() <= 1e-15 and np.abs(qd - qd0).max() <= 1e-14 and np.abs(qdd - qdd0).max() <= 1e-13
+    q, qd, qdd = desired_trajectory(q0, qd0, qdd0, k, 1.0)
+    assert np.abs(q - (q0 + kr * k)).max() <= 1e-14 and np.abs(qd).max() <= 1e-13 and np.abs(qdd).max() <= 1e-12
+    # duration scaling: the curve over [0, D] with the same end conditions
+    q2, qd2, qdd2 = desired_trajectory(q0, qd0, qdd0, k, 1.0, duration=2.0)
+    h = 1e-6
+    qa, _, _ = desired_trajectory(q0, qd0, qdd0, k, 1.0 + h, duration=2.0)
+    qb, _, _ = desired_trajectory(q0, qd0, qdd0, k, 1.0 - h, duration=2.0)
+    assert np.abs((qa - qb) / (2 * h) - qd2).max() <= 1e-8
+    # no plan (k = NaN): follow the previous plan shifted by t_plan while moving, else hold
+    prev = lambda tt: desired_trajectory(q0, qd0, qdd0, k, tt)
+    nan = np.full(7, np.nan)
+    bq, bqd, _ = desired_trajectory(q0 + 0.1, qd0, qdd0, nan, 0.2, previous=prev)
+    pq, pqd, _ = prev(0.7)
+    assert np.array_equal(bq, pq) and np.array_equal(bqd, pqd)
+    hq, hqd, hqdd = desired_trajectory(q0, np.zeros(7), qdd0, nan, 0.2, previous=prev)
+    assert np.array_equal(hq, q0) and not hqd.any() and not hqdd.any()
+    hq, hqd, _ = desired_trajectory(q0, qd0, qdd0, None, 0.6, previous=prev)
+    assert np.array_equal(hq, q0) and not hqd.any()
