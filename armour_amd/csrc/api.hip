@@ -93,6 +93,7 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_tq_keys, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_tq_coeff, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_planes, (size_t)nb * armour_planes_per_problem(h->J * h->T * no)));
+    TRY(dev_alloc(&h->d_planes_ll, (size_t)nb * armour_planes_ll_per_problem(h->J * h->T)));
     TRY(dev_alloc(&h->d_plane_skip, (size_t)nb));
     TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
@@ -114,7 +115,7 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.link_keys = h->d_link_keys; tb.link_coeff = h->d_link_coeff;
     tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
     tb.tq_keys = h->d_tq_keys; tb.tq_coeff = h->d_tq_coeff;
-    tb.planes = h->d_planes; tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
+    tb.planes = h->d_planes; tb.planes_ll = h->d_planes_ll; tb.ll_shared = h->ll_shared; tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
     for (int i = 0; i < ARMOUR_MAX_FACTORS; i++) tb.k_range[i] = h->params.k_range[i];
     tb.duration = h->params.duration;
     return tb;
@@ -188,7 +189,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
     dev_free(&h->d_tq_count); dev_free(&h->d_tq_center); dev_free(&h->d_tq_indep);
     dev_free(&h->d_tq_keys); dev_free(&h->d_tq_coeff);
-    dev_free(&h->d_planes); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
+    dev_free(&h->d_planes); dev_free(&h->d_planes_ll); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
     dev_free(&h->d_k); dev_free(&h->d_g); dev_free(&h->d_jac);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -295,6 +296,25 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
     UP(h->d_link_center, lc); UP(h->d_link_indep, li); UP(h->d_link_keys, lk); UP(h->d_link_coeff, lco);
     UP(h->d_tq_center, tc); UP(h->d_tq_indep, ti); UP(h->d_tq_keys, tk); UP(h->d_tq_coeff, tco);
     if (!pl.empty()) UP(h->d_planes, pl);
+    {
+        // compact link x link normals (taken at obstacle 0); used only if the loaded normals really are obstacle-independent
+        const int JT = J * T;
+        std::vector<double> pll((size_t)B * armour_planes_ll_per_problem(JT), 0.0);
+        bool shared = O > 0;
+        for (int b = 0; b < B && O > 0; b++)
+            for (int t = 0; t < T; t++)
+                for (int l = 0; l < J; l++)
+                    for (int p = ARMOUR_FIRST_LL_PLANE; p < 36; p++)
+                        for (int o = 0; o < O; o++) {
+                            const size_t src = ((((size_t)b * T + t) * J + l) * O + o) * 36 + p, src0 = ((((size_t)b * T + t) * J + l) * O) * 36 + p;
+                            for (int cc = 0; cc < 3; cc++) {
+                                if (o == 0) pll[(size_t)b * armour_planes_ll_per_problem(JT) + armour_plane_ll_index(JT, l * T + t, p - ARMOUR_FIRST_LL_PLANE, cc)] = A[src * 3 + cc];
+                                else if (memcmp(&A[src * 3 + cc], &A[src0 * 3 + cc], sizeof(double)) != 0) shared = false;
+                            }
+                        }
+        UP(h->d_planes_ll, pll);
+        h->ll_shared = shared ? 1 : 0;
+    }
     HIPCHK(hipMemset(h->d_plane_skip, 0, (size_t)B * sizeof(unsigned long long)));  // loaded tables: evaluate every plane
 #undef UP
     h->h_torque_radius.assign(torque_radius, torque_radius + (size_t)B * n * T);

@@ -23,6 +23,13 @@ void armour_set_error(const char* fmt, ...);
 // block's 92 KB contiguous was measured 18 % slower at B=128, O=50: it concentrates a block on few channels.)
 __host__ __device__ inline size_t armour_planes_per_problem(int Q) { return (size_t)ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * (size_t)Q; }
 __host__ __device__ inline size_t armour_plane_index(int Q, int q, int p, int c) { return ((size_t)c * ARMOUR_NPLANES + p) * (size_t)Q + q; }
+// The pair order of RT/CollisionChecking.cu:26-39 puts the 3 obstacle generators first, so planes 21..35 pair two of the
+// 6 link generators: their NORMALS do not depend on the obstacle.  They are also kept once per (link, time step) in
+// planes_ll[b][c in {Ax,Ay,Az}][p - 21][lt] (lt = l*T + t), which P2 reads instead of O identical copies.
+#define ARMOUR_FIRST_LL_PLANE 21
+#define ARMOUR_N_LL_PLANES 15
+__host__ __device__ inline size_t armour_planes_ll_per_problem(int JT) { return (size_t)3 * ARMOUR_N_LL_PLANES * (size_t)JT; }
+__host__ __device__ inline size_t armour_plane_ll_index(int JT, int lt, int pll, int c) { return ((size_t)c * ARMOUR_N_LL_PLANES + pll) * (size_t)JT + lt; }
 
 #define HIPCHK(expr)                                                                                     \
     do {                                                                                                 \
@@ -54,6 +61,8 @@ struct P2Tables {
     const uint32_t* tq_keys;    // [..][capT]
     const double* tq_coeff;     // [..][capT]
     const double* planes;       // [B][5][36][Q]
+    const double* planes_ll;    // [B][3][15][J*T], see armour_plane_ll_index; used when ll_shared != 0
+    int ll_shared;
     const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem
     const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0
     double k_range[ARMOUR_MAX_FACTORS];
@@ -91,6 +100,8 @@ struct ArmourPlanner {
     uint32_t* d_tq_keys = nullptr;
     double* d_tq_coeff = nullptr;
     double* d_planes = nullptr;
+    double* d_planes_ll = nullptr;
+    int ll_shared = 0;  // the link x link normals of the loaded table are identical over the obstacles (always so for tables built by P1)
     unsigned long long* d_plane_skip = nullptr;
     double* d_bez = nullptr;
     // staging for the host-pointer API

@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
 // axis-aligned box obstacles that is 12 of the 36 planes (all obstacle x error-generator and error x error pairs).
 __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
                                         const double* __restrict__ obstacles, double* __restrict__ planes,
-                                        unsigned long long* __restrict__ plane_skip) {
+                                        double* __restrict__ planes_ll, unsigned long long* __restrict__ plane_skip) {
     const int Q = J * T * O;
     const int q = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     unsigned long long skip = ~0ull;
@@ -772,6 +772,12 @@ __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double
                 out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
                 out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
                 out[armour_plane_index(Q, q, p, 4)] = dl;
+                if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
+                    double* ll = planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T);
+                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
+                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
+                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
+                }
                 Cs[p][0] = C0; Cs[p][1] = C1; Cs[p][2] = C2;
                 bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
                 for (int e = 0; e < p && !red; e++)
@@ -1014,7 +1020,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int Q = J * T * O;
             HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
             hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_plane_skip);
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_plane_skip);
+            h->ll_shared = 1;
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         //    armour_p1_planes_kernel) are not fetched; the live ones are dealt to the 4 waves in ascending order.
         const double* pl = tb.planes + (size_t)b * armour_planes_per_problem(Q) + q;  // layout: common.h armour_plane_index
         const size_t cs = (size_t)ARMOUR_NPLANES * Q;
+        const int JT = tb.J * T;
+        const double* pll = tb.planes_ll + (size_t)b * armour_planes_ll_per_problem(JT) + q / O;
         unsigned long long live = ~(lp.skip_by_value ? lp.skip0 : tb.plane_skip[b]) & ((1ull << ARMOUR_NPLANES) - 1ull);
         const bool plane0_live = (live & 1ull) != 0;
         const int na = __popcll(live), base = na >> 2, rem = na & 3;
@@ -228,10 +230,19 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
         for (int i = 0; i < P2_PPW; i++) {
             a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
             if (i < my_cnt) {
-                const size_t o = (size_t)__builtin_ctzll(live) * Q;
+                const int pidx = __builtin_ctzll(live);
+                const size_t o = (size_t)pidx * Q;
                 live &= live - 1ull;
                 // (non-temporal loads were measured 7 % slower at B=128, O=50: default cache policy kept)
-                a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o]; dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
+                if (tb.ll_shared && pidx >= ARMOUR_FIRST_LL_PLANE) {
+                    // link x link plane: its normal is the same for the O obstacles of a (link, time step) and is read from
+                    // the compact copy -- a wave touches 64/O + 1 distinct addresses instead of 64
+                    const double* al = pll + (size_t)(pidx - ARMOUR_FIRST_LL_PLANE) * JT;
+                    a0[i] = al[0]; a1[i] = al[(size_t)ARMOUR_N_LL_PLANES * JT]; a2[i] = al[(size_t)2 * ARMOUR_N_LL_PLANES * JT];
+                } else {
+                    a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o];
+                }
+                dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
             }
 #if defined(P2_ABLATE) && (P2_ABLATE & 8)
             a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;

@@ -16,7 +16,8 @@ for rep in range(2):
     for s in range(K):
         nlp.eval_g_jac_device(ks[s].data_ptr(), dg[s].data_ptr(), dj[s].data_ptr(), st.cuda_stream)
     st.synchronize()
-g = dg.cpu().numpy()[:, 7 * T + 7 * T * O:]
+gfull = dg.cpu().numpy()
+g = gfull[:, 7 * T + 7 * T * O:]
 raw = g[:, :24].reshape(K, 3, 8)
 stamps = raw[:, :, :7]
 print('shader cycles per block / (end-start) ns -> GHz:', np.median(raw[8:, :, 7] / ((raw[8:, :, 6] - raw[8:, :, 0]) * 10.0), axis=0))
@@ -29,3 +30,10 @@ for i, nme in enumerate(names):
 prev_end = stamps[:-1, :, 6].max(axis=1)
 print("gap from previous launch's last end stamp to this launch's first start: median ns", np.median((base[1:] - prev_end)[8:]) * 10.0)
 print("launch-to-launch (start to start) median ns", np.median(np.diff(base)[8:]) * 10.0)
+
+sl = gfull[:, :24].reshape(K, 3, 8)[:, :, :7]
+if sl[8:].any():
+    rel2 = (sl - base[:, None, None]) * 10.0
+    print("slicing-wave view (split kernel):")
+    for i, nme in enumerate(names):
+        print(f"  {nme:18s}", np.median(rel2[8:, :, i], axis=0))
