@@ -94,6 +94,7 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_tq_coeff, nt * h->lim.torque_monomials));
     TRY(dev_alloc(&h->d_planes, (size_t)nb * armour_planes_per_problem(h->J * h->T * no)));
     TRY(dev_alloc(&h->d_planes_ll, (size_t)nb * armour_planes_ll_per_problem(h->J * h->T)));
+    TRY(dev_alloc(&h->d_obs_center, (size_t)nb * 3 * (no > 0 ? no : 1)));
     TRY(dev_alloc(&h->d_plane_skip, (size_t)nb));
     TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
@@ -115,7 +116,11 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.link_keys = h->d_link_keys; tb.link_coeff = h->d_link_coeff;
     tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
     tb.tq_keys = h->d_tq_keys; tb.tq_coeff = h->d_tq_coeff;
-    tb.planes = h->d_planes; tb.planes_ll = h->d_planes_ll; tb.ll_shared = h->ll_shared; tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
+    tb.planes = h->d_planes; tb.planes_ll = h->d_planes_ll; tb.ll_shared = h->ll_shared;
+    // recomputing d = A.c in the kernel trades 8 B per plane and row for 5 flops: pays once the launch is bandwidth-bound
+    // (measured: -25 % at B = 128, O = 50; +1 % at B = 1)
+    tb.obs_center = (h->d_from_center && h->B >= 8) ? h->d_obs_center : nullptr;
+    tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
     for (int i = 0; i < ARMOUR_MAX_FACTORS; i++) tb.k_range[i] = h->params.k_range[i];
     tb.duration = h->params.duration;
     return tb;
@@ -189,7 +194,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
     dev_free(&h->d_tq_count); dev_free(&h->d_tq_center); dev_free(&h->d_tq_indep);
     dev_free(&h->d_tq_keys); dev_free(&h->d_tq_coeff);
-    dev_free(&h->d_planes); dev_free(&h->d_planes_ll); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
+    dev_free(&h->d_planes); dev_free(&h->d_planes_ll); dev_free(&h->d_obs_center); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
     dev_free(&h->d_k); dev_free(&h->d_g); dev_free(&h->d_jac);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -314,6 +319,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
                         }
         UP(h->d_planes_ll, pll);
         h->ll_shared = shared ? 1 : 0;
+        h->d_from_center = 0;  // loaded tables: use the d column as given
     }
     HIPCHK(hipMemset(h->d_plane_skip, 0, (size_t)B * sizeof(unsigned long long)));  // loaded tables: evaluate every plane
 #undef UP

@@ -61,6 +61,7 @@ struct P2Tables {
     const uint32_t* tq_keys;    // [..][capT]
     const double* tq_coeff;     // [..][capT]
     const double* planes;       // [B][5][36][Q]
+    const double* obs_center;   // [B][3][O] obstacle centres; when non-null P2 computes d = A.c itself instead of reading it (tables built by P1)
     const double* planes_ll;    // [B][3][15][J*T], see armour_plane_ll_index; used when ll_shared != 0
     int ll_shared;
     const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem
@@ -100,6 +101,8 @@ struct ArmourPlanner {
     uint32_t* d_tq_keys = nullptr;
     double* d_tq_coeff = nullptr;
     double* d_planes = nullptr;
+    double* d_obs_center = nullptr;
+    int d_from_center = 0;  // the d column of the table is exactly A.c of the stored normals and obs_center (tables built by P1)
     double* d_planes_ll = nullptr;
     int ll_shared = 0;  // the link x link normals of the loaded table are identical over the obstacles (always so for tables built by P1)
     unsigned long long* d_plane_skip = nullptr;

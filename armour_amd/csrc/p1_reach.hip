@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
 // axis-aligned box obstacles that is 12 of the 36 planes (all obstacle x error-generator and error x error pairs).
 __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
                                         const double* __restrict__ obstacles, double* __restrict__ planes,
-                                        double* __restrict__ planes_ll, unsigned long long* __restrict__ plane_skip) {
+                                        double* __restrict__ planes_ll, double* __restrict__ obs_center, unsigned long long* __restrict__ plane_skip) {
     const int Q = J * T * O;
     const int q = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     unsigned long long skip = ~0ull;
@@ -757,6 +757,7 @@ __global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double
             for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
         }
         double* out = planes + (size_t)b * armour_planes_per_problem(Q);
+        if (lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
         int p = 0;
         skip = 0ull;
         for (int a_id = 0; a_id < 8; a_id++)
@@ -1020,8 +1021,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int Q = J * T * O;
             HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
             hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_plane_skip);
-            h->ll_shared = 1;
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, h->d_plane_skip);
+            h->ll_shared = 1; h->d_from_center = 1;
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));

@@ -166,7 +166,9 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
     }
 }
 
-template <bool WANT_G, bool WANT_J, bool MULTI>
+// DFC: d = A . c_obstacle is recomputed from tb.obs_center instead of read (batched launches of tables built by P1)
+// LL: the link x link normals come from the compact tb.planes_ll (tables whose normals are obstacle-independent)
+template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL>
 __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
                 const size_t o = (size_t)pidx * Q;
                 live &= live - 1ull;
                 // (non-temporal loads were measured 7 % slower at B=128, O=50: default cache policy kept)
-                if (tb.ll_shared && pidx >= ARMOUR_FIRST_LL_PLANE) {
+                if (LL && pidx >= ARMOUR_FIRST_LL_PLANE) {
                     // link x link plane: its normal is the same for the O obstacles of a (link, time step) and is read from
                     // the compact copy -- a wave touches 64/O + 1 distinct addresses instead of 64
                     const double* al = pll + (size_t)(pidx - ARMOUR_FIRST_LL_PLANE) * JT;
@@ -242,11 +244,19 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
                 } else {
                     a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o];
                 }
-                dd[i] = pl[3 * cs + o]; dl[i] = pl[4 * cs + o];
+                if (!DFC) dd[i] = pl[3 * cs + o];
+                dl[i] = pl[4 * cs + o];
             }
 #if defined(P2_ABLATE) && (P2_ABLATE & 8)
             a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;
 #endif
+        }
+        // d = A . c_obstacle (RT/CollisionChecking.cu:200-202): with the obstacle centres at hand it is recomputed, in the
+        // expression of armour_p1_planes_kernel, instead of read -- 8 B less per plane and row
+        double oc0 = 0.0, oc1 = 0.0, oc2 = 0.0;
+        if (DFC) {
+            const double* oc = tb.obs_center + (size_t)b * 3 * O + q % O;
+            oc0 = oc[0]; oc1 = oc[O]; oc2 = oc[2 * (size_t)O];
         }
         P2_STAMP(1);
         // 2. per point: slice the (l,t) link PZs this block's rows touch (one thread per (pair, monomial, axis)), then
@@ -301,6 +311,10 @@ __global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, c
             //    max_id defaults to plane 0 (RT/CollisionChecking.cu:262): its normal if it is live (then it is slot 0 of
             //    wave 0), zero if it was skipped (best = -2 matches no slot).
             const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
+            if (DFC) {
+#pragma unroll
+                for (int i = 0; i < P2_PPW; i++) dd[i] = a0[i] * oc0 + a1[i] * oc1 + a2[i] * oc2;
+            }
             double max_elt = -100000000.0;
             int best = (wv == 0 && plane0_live) ? 0 : -2;
 #pragma unroll
@@ -545,15 +559,22 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     const size_t smem = 2 * sizeof(KPow) + std::max(std::max(col, tq), lim);
     if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }
     dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
+    const bool dfc = tb.obs_center != nullptr && tb.ll_shared;
+#define P2_LAUNCH_M(G, J, M)                                                                                                                      \
+    do {                                                                                                                                          \
+        if (dfc) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);              \
+        else if (tb.ll_shared) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);                \
+    } while (0)
 #define P2_LAUNCH(G, J)                                                                                                     \
     do {                                                                                                                    \
-        if (steps > 1) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);  \
-        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);           \
+        if (steps > 1) P2_LAUNCH_M(G, J, true); else P2_LAUNCH_M(G, J, false);                                                                         \
     } while (0)
     if (d_g && d_jac) P2_LAUNCH(true, true);
     else if (d_g) P2_LAUNCH(true, false);
     else P2_LAUNCH(false, true);
 #undef P2_LAUNCH
+#undef P2_LAUNCH_M
     HIPCHK(hipGetLastError());
     return ARMOUR_OK;
 }
