@@ -35,6 +35,13 @@
 #define P2_TQ_ROWS 8      // torque rows per block (32 monomial lanes each)
 #define P2_TQ_ROUNDS 4    // monomials per lane of a torque row (strideT <= 128)
 
+#ifndef P2_DFC_WAVES
+#define P2_DFC_WAVES 3
+#endif
+// batched one-point launches (DFC) are occupancy-bound: hold the kernel to the 168 VGPRs of 3 waves per SIMD (4 was measured:
+// 128 VGPRs + 120 B/lane of scratch, twice as slow)
+#define P2_WPE(DFC, MULTI) ((DFC) && !(MULTI) ? P2_DFC_WAVES : 1)
+
 namespace {
 
 #ifdef P2_TIMELINE  // development only: 100 MHz wall-clock stamps of the collision phases of three blocks, left in the limit rows of g
@@ -169,7 +176,7 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
 // DFC: d = A . c_obstacle is recomputed from tb.obs_center instead of read (batched launches of tables built by P1)
 // LL: the link x link normals come from the compact tb.planes_ll (tables whose normals are obstacle-independent)
 template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL>
-__global__ __launch_bounds__(P2_BLOCK) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
+__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE(DFC, MULTI)))) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
