@@ -346,12 +346,18 @@ struct Chain {
         return r;
     }
     __device__ PZ crossPzPz(const PZ& a, const PZ& b) {  // RT/PZsparse.cu:1134-1151
+#ifdef P1_COMPOSED_CROSS  // the reference's composition out of 1x1 operators (10 passes); kept for A/B runs
         PZ r0 = crossComp(a, 1, 2, b, 2, 1);
         PZ r1 = crossComp(a, 2, 0, b, 0, 2);
         PZ r2 = crossComp(a, 0, 1, b, 1, 0);
         PZ o = stack(r0, r1, r2);
         freeSs(r0); freeSs(r1); freeSs(r2);
         return o;
+#else
+        PZ o = allocV();
+        cross_pzpz(w, o, view(w, a), view(w, b));  // the same three simplify() stages in one pass (pz_wave.h)
+        return o;
+#endif
     }
     __device__ PZ mulMV(const PZ& A, const PZ& v) {
         PZ o = allocV();

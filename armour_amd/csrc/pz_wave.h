@@ -127,16 +127,12 @@ __device__ inline int upper_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t 
     return lo;
 }
 
-// Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
-// and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind / base_ind2 = independent parts before pruning.
-// Eval: uint64_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
-template <int SZ, class Eval>
-__device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
-    int emitted = 0;
-    bool any_pruned = false, indirect = false;
-    double ra[SZ];
-#pragma unroll
-    for (int e = 0; e < SZ; e++) ra[e] = 0.0;
+// Sort step shared by every operator: checks the LDS capacity, then leaves the N raw terms of `ev` ordered by
+// (key, generation index) -- sidx[p] = index of the p-th term; the p-th key is skey[p], or ev.key_lds(w, sidx[p]) when
+// `indirect` is returned (merge paths that keep the operands' key lists in skey).  Returns the N to process (0 on overflow).
+template <class Eval>
+__device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect) {
+    indirect = false;
     // LDS capacity: sidx holds every raw term; skey holds either the operands' key lists (merge paths) or, for the
     // bitonic path, all raw keys padded to a power of two.  On overflow the host retries with larger buffers.
     if (N > w.cap_raw || (N > WAVE && !ev.can_merge(w, N) && next_pow2(N) > w.cap_key)) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
@@ -172,18 +168,34 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             }
 #endif
         } else {
-        const int P = next_pow2(N);
-        { PROF_T0
-        for (int p = w.lane; p < P; p += WAVE) {
-            w.skey[p] = p < N ? ev.key(p) : ~0ull;
-            w.sidx[p] = (uint16_t)p;
+            const int P = next_pow2(N);
+            { PROF_T0
+            for (int p = w.lane; p < P; p += WAVE) {
+                w.skey[p] = p < N ? ev.key(p) : ~0ull;
+                w.sidx[p] = (uint16_t)p;
+            }
+            __syncthreads();
+            PROF_ADD(PR_FILL) }
+            { PROF_T0
+            bitonic_sort(w, P);
+            PROF_ADD(PR_SORT) }
         }
-        __syncthreads();
-        PROF_ADD(PR_FILL) }
-        { PROF_T0
-        bitonic_sort(w, P);
-        PROF_ADD(PR_SORT) }
-        }
+    }
+    return N;
+}
+
+// Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
+// and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind / base_ind2 = independent parts before pruning.
+// Eval: uint64_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
+template <int SZ, class Eval>
+__device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
+    int emitted = 0;
+    bool any_pruned = false, indirect = false;
+    double ra[SZ];
+#pragma unroll
+    for (int e = 0; e < SZ; e++) ra[e] = 0.0;
+    N = sort_terms(w, N, ev, indirect);
+    if (N > 0) {
         PROF_T0
         for (int base = 0; base < N; base += WAVE) {
             const int p = base + w.lane;
@@ -505,6 +517,153 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
     sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cross(PZ a, PZ b) for 3x1 operands (RT/PZsparse.cu:1134-1151) in ONE pass.
+// The reference composes it from 1x1 operators, each ending in simplify():
+//     P(c,0) = a[c+1] * b[c+2],  P(c,1) = a[c+2] * b[c+1]      (6 scalar products, indices mod 3)
+//     r_c    = P(c,0) - P(c,1)                                  (3 differences)
+//     out    = stack(r_0, r_1, r_2)
+// All six products run over the same raw terms -- the pairs (monomial or centre of a) x (monomial or centre of b), with
+// the same key per pair -- so one sort of those pairs serves them all.  For every run of equal keys the head lane
+// sums the six coefficient products in generation order and then applies the three simplify() stages in sequence,
+// exactly as the composed operators would: |sum| <= threshold drops a product term into that product's radius; the
+// surviving terms of a component are combined as 1.0*P0 + (-1.0)*P1 and pruned again into the difference's radius;
+// the surviving components form the 3-vector that stack() prunes by its norm.  Radii are assembled in the order of the
+// composed operators (product radius + pruned, summed over the two products, + pruned, + pruned by stack).
+struct CrossEval : MulEval<MulShape<1, 1, 1, 1>> {
+    // p6[2*c + s] = coefficient product of P(c,s) for raw pair idx
+    __device__ inline void coef6(int idx, double* p6) const {
+        int i, j;
+        split(idx, i, j);
+        double ca[3], cb[3];
+        if (i) {
+            const GLB_AS double* pa = a.coef + (size_t)(i - 1) * 3;
+            ca[0] = pa[0]; ca[1] = pa[1]; ca[2] = pa[2];
+        } else { ca[0] = a.cen[0]; ca[1] = a.cen[1]; ca[2] = a.cen[2]; }
+        if (j) {
+            const GLB_AS double* pb = b.coef + (size_t)(j - 1) * 3;
+            cb[0] = pb[0]; cb[1] = pb[1]; cb[2] = pb[2];
+        } else { cb[0] = b.cen[0]; cb[1] = b.cen[1]; cb[2] = b.cen[2]; }
+        p6[0] = ca[1] * cb[2]; p6[1] = ca[2] * cb[1];
+        p6[2] = ca[2] * cb[0]; p6[3] = ca[0] * cb[2];
+        p6[4] = ca[0] * cb[1]; p6[5] = ca[1] * cb[0];
+    }
+};
+
+__device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, const View& b) {
+    CrossEval ev;
+    ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
+    int N = (a.cnt + 1) * (b.cnt + 1) - 1;
+    // centres and radii of the six products, as mul<1,1,1,1> forms them
+    double r2[3], r3[3];
+    { PROF_T0
+    abs_sum<3>(w, a, r2);
+    abs_sum<3>(w, b, r3);
+    PROF_ADD(PR_ABS) }
+    double cenP[6], baseP[6], base2P[6];
+    {
+        const int ia_[6] = {1, 2, 2, 0, 0, 1}, ib_[6] = {2, 1, 0, 2, 1, 0};
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            const int i = ia_[e], j = ib_[e];
+            const double ia = a.ind[i], ib = b.ind[j], ia2 = a.ind2[i], ib2 = b.ind2[j];
+            cenP[e] = a.cen[i] * b.cen[j];
+            baseP[e] = ia * ib + (r2[i] * ib + ia * r3[j]);
+            base2P[e] = ia2 * ib2 + (r2[i] * ib2 + ia2 * r3[j]);
+        }
+    }
+    __syncthreads();
+    int emitted = 0;
+    bool any_pruned = false, indirect = false;
+    double raP[6] = {0, 0, 0, 0, 0, 0}, raR[3] = {0, 0, 0}, raS[3] = {0, 0, 0};
+    N = sort_terms(w, N, ev, indirect);
+    if (N > 0) {
+        PROF_T0
+        for (int base = 0; base < N; base += WAVE) {
+            const int p = base + w.lane;
+            bool head = false, keep = false;
+            uint64_t key = 0;
+            double u[3] = {0.0, 0.0, 0.0};
+            if (p < N) {
+                key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
+                head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
+            }
+            if (head) {
+                double acc[6];
+                ev.coef6(w.sidx[p], acc);
+                for (int q = p + 1; q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key; q++) {
+                    double c6[6];
+                    ev.coef6(w.sidx[q], c6);
+#pragma unroll
+                    for (int e = 0; e < 6; e++) acc[e] += c6[e];
+                }
+                bool anyc = false, pruned = false;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    // simplify() of each product: 1x1 norm
+                    double v0 = acc[2 * c], v1 = acc[2 * c + 1];
+                    bool h0 = !(sqrt(0.0 + v0 * v0) <= w.thr), h1 = !(sqrt(0.0 + v1 * v1) <= w.thr);
+                    if (!h0) { raP[2 * c] += fabs(v0); pruned = true; }
+                    if (!h1) { raP[2 * c + 1] += fabs(v1); pruned = true; }
+                    // simplify() of the difference 1.0*P0 + (-1.0)*P1 over the surviving terms
+                    if (h0 || h1) {
+                        double wv = h0 ? 1.0 * v0 : -1.0 * v1;
+                        if (h0 && h1) wv += -1.0 * v1;
+                        if (sqrt(0.0 + wv * wv) <= w.thr) { raR[c] += fabs(wv); pruned = true; }
+                        else { u[c] = wv; anyc = true; }
+                    }
+                }
+                // simplify() of stack(): 3-vector norm over the surviving components
+                if (anyc) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s += u[c] * u[c];
+                    keep = !(sqrt(s) <= w.thr);
+                    if (!keep) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) raS[c] += fabs(u[c]);
+                        pruned = true;
+                    }
+                }
+                head = pruned;
+            }
+            const unsigned long long m = __ballot(keep);
+            any_pruned = any_pruned || (__ballot(head) != 0ull);
+            if (keep) {
+                const int pos = emitted + __popcll(m & ((1ull << w.lane) - 1ull));
+                if (pos < out.cap) {
+                    out.keys[pos] = key;
+                    out.coef[(size_t)pos * 3 + 0] = u[0]; out.coef[(size_t)pos * 3 + 1] = u[1]; out.coef[(size_t)pos * 3 + 2] = u[2];
+                }
+            }
+            emitted += __popcll(m);
+        }
+        PROF_ADD(PR_EMIT)
+    }
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (any_pruned) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) raP[e] = wave_sum(raP[e]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { raR[c] = wave_sum(raR[c]); raS[c] = wave_sum(raS[c]); }
+    }
+    if (w.lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            // product: base + pruned; difference: sum of the two (scales 1, |-1|) + pruned; stack: 0 + that, + pruned
+            const double i0 = baseP[2 * c] + raP[2 * c], i1 = baseP[2 * c + 1] + raP[2 * c + 1];
+            const double j0 = base2P[2 * c] + raP[2 * c], j1 = base2P[2 * c + 1] + raP[2 * c + 1];
+            const double ir = (i0 * 1.0 + i1 * 1.0) + raR[c], jr = (j0 * 1.0 + j1 * 1.0) + raR[c];
+            out.cen[c] = 0.0 + (1.0 * cenP[2 * c] + -1.0 * cenP[2 * c + 1]);
+            out.ind[c] = (0.0 + ir) + raS[c];
+            out.ind2[c] = (0.0 + jr) + raS[c];
+        }
+        w.cnt[out.id] = emitted;
+        if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
+    }
+    __syncthreads();
 }
 
 // Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):

@@ -102,7 +102,8 @@ CASES = [
     (4, [(3, 300), (3, 280)], "add merge"), (4, [(3, 20), (3, 30)], "add small"), (4, [(3, 0), (3, 77)], "add empty + x"),
     (5, [(3, 250), (3, 250)], "sub merge"), (6, [(3, 140), (1, 2)], "addOneDim"), (7, [(1, 90), (1, 70), (1, 110)], "stack 3-way merge"),
     (7, [(1, 10), (1, 0), (1, 12)], "stack with an empty entry"), (8, [(3, 333)], "cross(a, const)"), (9, [(3, 64)], "cross(const, a)"),
-    (10, [(3, 30), (3, 25)], "cross(a, b) bitonic"), (10, [(3, 6), (3, 90)], "cross(a, b) merge"), (11, [(1, 200), (1, 190)], "s1*a + s2*b"),
+    (10, [(3, 30), (3, 25)], "cross(a, b) bitonic"), (10, [(3, 6), (3, 90)], "cross(a, b) merge"),
+    (10, [(3, 6), (3, 7)], "cross(a, b) <= 64 raw"), (10, [(3, 0), (3, 40)], "cross(constant a, b)"), (10, [(3, 25), (3, 0)], "cross(a, constant b)"), (11, [(1, 200), (1, 190)], "s1*a + s2*b"),
 ]
 
 
