@@ -313,6 +313,25 @@ struct Chain {
         lincomb<3, 3>(w, o, s);
         return o;
     }
+    // (a + b) + c with simplify() after each sum, in one pass (pz_wave.h lincomb_chain); c may be a 1x1 PZ added to entry comp_c
+    __device__ PZ sum3(const PZ& a, const PZ& b, const PZ& c3, int comp_c = -1) {
+        PZ o = allocV();
+        Seg s[3] = {{view(w, a), 1.0, -1}, {view(w, b), 1.0, -1}, {view(w, c3), 1.0, comp_c}};
+        lincomb_chain<3, 3>(w, o, s);
+        return o;
+    }
+    __device__ PZ sum4(const PZ& a, const PZ& b, const PZ& c3, const PZ& d) {  // ((a + b) + c) + d
+        PZ o = allocV();
+        Seg s[4] = {{view(w, a), 1.0, -1}, {view(w, b), 1.0, -1}, {view(w, c3), 1.0, -1}, {view(w, d), 1.0, -1}};
+        lincomb_chain<3, 4>(w, o, s);
+        return o;
+    }
+    __device__ PZ comb3(const View& a, double sa, const View& b, double sb, const View& c3, double sc) {  // 1x1: (sa*a + sb*b) + sc*c
+        PZ o = allocS();
+        Seg s[3] = {{a, sa, -1}, {b, sb, -1}, {c3, sc, -1}};
+        lincomb_chain<1, 3>(w, o, s);
+        return o;
+    }
     __device__ PZ comb2(const View& a, double sa, const View& b, double sb) {  // 1x1: sa*a + sb*b
         PZ o = allocS();
         Seg s[2] = {{a, sa, -1}, {b, sb, -1}};
@@ -550,10 +569,9 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u) {
         const int ax = abs(cf.rb.axes[i]) - 1;
         {   // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
             PZ c1 = c.crossPzMat(wdot, tr);
-            PZ s1 = c.add(lacc, c1); c.freeVs(c1);
             PZ c2 = c.crossPzMat(waux, tr);
             PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            PZ s2 = c.add(s1, c3); c.freeVs(s1); c.freeVs(c3);
+            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);  // (linear_acc + c1) + c3
             PZ nl = c.mulMV(Rt, s2); c.freeVs(s2); c.freeVs(lacc);
             lacc = nl;
         }
@@ -568,16 +586,14 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u) {
             set_const(w, zero, nullptr, nullptr);
             PZ temp = c.addOneDim(zero, c.qd(i), ax); c.freeVs(zero);
             PZ c4 = c.crossPzPz(waux, temp); c.freeVs(temp);
-            PZ nd = c.add(wdot, c4); c.freeVs(c4); c.freeVs(wdot); wdot = nd;
-            PZ nd2 = c.addOneDim(wdot, c.qdda(i), ax); c.freeVs(wdot); wdot = nd2;
+            PZ nd2 = c.sum3(wdot, c4, c.qdda(i), ax); c.freeVs(c4); c.freeVs(wdot); wdot = nd2;  // (wdot + c4), then + qdda on the axis
             PZ na = c.addOneDim(waux, c.qda(i), ax); c.freeVs(waux); waux = na;
         }
         {   // lines 23 & 27: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
             PZ c1 = c.crossPzMat(wdot, cm);
-            PZ s1 = c.add(lacc, c1); c.freeVs(c1);
             PZ c2 = c.crossPzMat(waux, cm);
             PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            PZ s2 = c.add(s1, c3); c.freeVs(s1); c.freeVs(c3);
+            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
             F[i] = c.mulSV(c.mass(i), s2); c.freeVs(s2);
         }
         {   // line 29: N = I * wdot + cross(w_aux, I * w)
@@ -596,21 +612,16 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u) {
         const PZ Rn = c.R(i + 1);
         // n = N + R*n + cross(com, F) + cross(trans_next, R*f);  f = R*f + F
         PZ a1 = c.mulMV(Rn, nn);
-        PZ s1 = c.add(N[i], a1); c.freeVs(a1); c.freeVs(N[i]);
         PZ c1 = c.crossMatPz(&cf.rb.com[3 * i], F[i]);
-        PZ s2 = c.add(s1, c1); c.freeVs(s1); c.freeVs(c1);
         PZ a2 = c.mulMV(Rn, f);
         PZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
-        PZ n2 = c.add(s2, c2); c.freeVs(s2); c.freeVs(c2); c.freeVs(nn);
+        PZ n2 = c.sum4(N[i], a1, c1, c2); c.freeVs(a1); c.freeVs(N[i]); c.freeVs(c1); c.freeVs(c2); c.freeVs(nn);  // ((N + a1) + c1) + c2
         nn = n2;
         PZ f2 = c.add(a2, F[i]); c.freeVs(a2); c.freeVs(F[i]); c.freeVs(f);
         f = f2;
         if (cf.rb.axes[i] != 0) {
             const int ax = abs(cf.rb.axes[i]) - 1;
-            PZ u1 = c.comb2(elem(w, nn, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i]);
-            PZ u2 = c.comb2(view(w, u1), 1.0, view(w, c.qd(i)), cf.rb.damping[i]);
-            c.freeSs(u1);
-            u[i] = u2;
+            u[i] = c.comb3(elem(w, nn, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i], view(w, c.qd(i)), cf.rb.damping[i]);
         }
     }
     c.freeVs(f); c.freeVs(nn);
@@ -721,6 +732,10 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
         finish_torque(c, u_nom, b, t);
         __syncthreads();
 #ifdef P1_PROFILE
+        if (threadIdx.x == 0 && (t % 10 == 0 || t == cf.T - 1))
+            printf("[t=%d] total %lld: N<=64 %llu (%llu calls), mid %llu (%llu calls, %llu terms), big %llu (%llu calls, %llu terms) | fill %llu sort %llu (rank %llu bitonic %llu linmerge %llu mulmerge %llu) emit %llu abs %llu\n", t, (long long)clock64() - ph0,
+                   prof_lds[PR_CYC64], prof_lds[PR_SMALL], prof_lds[PR_CYC512], prof_lds[PR_N512], prof_lds[PR_TERMS512], prof_lds[PR_CYCBIG], prof_lds[PR_NBIG], prof_lds[PR_TERMSBIG],
+                   prof_lds[PR_FILL], prof_lds[PR_SORT], prof_lds[PR_S_RANK], prof_lds[PR_S_BITONIC], prof_lds[PR_S_LINMERGE], prof_lds[PR_S_MULMERGE], prof_lds[PR_EMIT], prof_lds[PR_ABS]);
         if (threadIdx.x == 0 && blockIdx.x == 0)
             printf("[P1 phases, wave 0] jrs %lld fk %lld rnea %lld torque %lld cycles\n", ph1 - ph0, ph2 - ph1, ph3 - ph2, (long long)clock64() - ph3);
 #endif
@@ -972,7 +987,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (!h->p1) {
         P1Work* nw = new P1Work();
         h->p1 = nw;
-        HIPCHK(hipMalloc((void**)&nw->d_status, (ST_WORDS + 32) * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&nw->d_status, (ST_WORDS + 64) * sizeof(unsigned)));
         HIPCHK(hipEventCreate(&nw->ev0));
         HIPCHK(hipEventCreate(&nw->ev1));
     }
@@ -1041,6 +1056,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipMemcpy(pr, wk->d_status + ST_WORDS, sizeof(pr), hipMemcpyDeviceToHost));
             fprintf(stderr, "[P1 profile, wave 0] cycles: fill %llu sort %llu emit %llu abs_sum %llu total %llu | simplify calls %llu (N<=64: %llu) raw terms %llu\n",
                     pr[PR_FILL], pr[PR_SORT], pr[PR_EMIT], pr[PR_ABS], pr[PR_TOTAL], pr[PR_CALLS], pr[PR_SMALL], pr[PR_TERMS]);
+            fprintf(stderr, "[P1 profile, wave 0] whole-call cycles: N<=64 %llu | 64<N<=512: %llu in %llu calls (%llu terms) | N>512: %llu in %llu calls (%llu terms)\n",
+                    pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {

@@ -37,12 +37,17 @@ constexpr int WAVE = 64;
 // status words (global, one array per launch)
 enum { ST_ERR = 0, ST_MAX_RAW = 1, ST_MAX_OUT = 2, ST_WORDS = 4 };
 #ifdef P1_PROFILE  // development only: per-wave cycle attribution, dumped after the status words
-enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS = 5, PR_SMALL = 6, PR_TOTAL = 7, PR_WORDS = 8 };
+enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS = 5, PR_SMALL = 6, PR_TOTAL = 7,
+       PR_CYC64 = 8, PR_CYC512 = 9, PR_CYCBIG = 10, PR_N512 = 11, PR_NBIG = 12, PR_TERMS512 = 13, PR_TERMSBIG = 14, PR_S_RANK = 15, PR_S_BITONIC = 16, PR_S_LINMERGE = 17, PR_S_MULMERGE = 18, PR_WORDS = 20 };
+#define PROF_CALL_T0 const long long prof_c0__ = clock64();
+#define PROF_CALL_END(N) if (w.lane == 0) { const unsigned long long d__ = (unsigned long long)(clock64() - prof_c0__); if ((N) <= 64) w.prof[PR_CYC64] += d__; else if ((N) <= 512) { w.prof[PR_CYC512] += d__; w.prof[PR_N512] += 1; w.prof[PR_TERMS512] += (N); } else { w.prof[PR_CYCBIG] += d__; w.prof[PR_NBIG] += 1; w.prof[PR_TERMSBIG] += (N); } }
 #define PROF_T0 const long long prof_t0__ = clock64();
 #define PROF_ADD(slot) if (w.lane == 0) w.prof[slot] += (unsigned long long)(clock64() - prof_t0__);
 #else
 #define PROF_T0
 #define PROF_ADD(slot)
+#define PROF_CALL_T0
+#define PROF_CALL_END(N)
 #endif
 enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8 };
 
@@ -93,16 +98,30 @@ __device__ inline void flag(const Wave& w, int bit) { if (w.lane == 0) w.lstat[S
 
 // 64-lane bitonic sort of (skey, sidx)[0, P) ascending by (key, idx); P is a power of two >= 64.
 __device__ inline void bitonic_sort(const Wave& w, int P) {
+    const int half = P >> 1;
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = w.lane; t < (P >> 1); t += WAVE) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const uint64_t ka = w.skey[i], kb = w.skey[l];
-                const uint16_t ia = w.sidx[i], ib = w.sidx[l];
-                const bool gt = (ka > kb) || (ka == kb && ia > ib);
-                const bool up = (i & k) == 0;
-                if (gt == up) { w.skey[i] = kb; w.skey[l] = ka; w.sidx[i] = ib; w.sidx[l] = ia; }
+            // four compare-exchanges per lane in flight: all LDS reads of a group are issued before the first compare
+            // (the pairs of one pass are disjoint); the loop is LDS-latency bound otherwise
+            for (int t0 = w.lane; t0 < half; t0 += 4 * WAVE) {
+                int ii[4], ll[4];
+                uint64_t ka[4], kb[4];
+                uint16_t ia[4], ib[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + u * WAVE;
+                    const int tc = t < half ? t : t0;  // clamp: the spare slots re-read the first pair and do not write
+                    ii[u] = ((tc & ~(j - 1)) << 1) | (tc & (j - 1));
+                    ll[u] = ii[u] | j;
+                    ka[u] = w.skey[ii[u]]; kb[u] = w.skey[ll[u]];
+                    ia[u] = w.sidx[ii[u]]; ib[u] = w.sidx[ll[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool gt = (ka[u] > kb[u]) || (ka[u] == kb[u] && ia[u] > ib[u]);
+                    const bool up = (ii[u] & k) == 0;
+                    if (t0 + u * WAVE < half && gt == up) { w.skey[ii[u]] = kb[u]; w.skey[ll[u]] = ka[u]; w.sidx[ii[u]] = ib[u]; w.sidx[ll[u]] = ia[u]; }
+                }
             }
             __syncthreads();
         }
@@ -153,7 +172,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             }
             if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
             __syncthreads();
-            PROF_ADD(PR_SORT)
+            PROF_ADD(PR_SORT) PROF_ADD(PR_S_RANK)
         } else if (ev.try_merge(w, N)) {
             // the operands' sorted runs were merged by ranking: sidx holds the permutation, keys come from LDS staging
             indirect = true;
@@ -178,7 +197,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             PROF_ADD(PR_FILL) }
             { PROF_T0
             bitonic_sort(w, P);
-            PROF_ADD(PR_SORT) }
+            PROF_ADD(PR_SORT) PROF_ADD(PR_S_BITONIC) }
         }
     }
     return N;
@@ -300,7 +319,7 @@ struct LinEval {
             w.sidx[rank] = (uint16_t)idx;
         }
         __syncthreads();
-        PROF_ADD(PR_SORT)
+        PROF_ADD(PR_SORT) PROF_ADD(PR_S_LINMERGE)
         return true;
     }
     __device__ inline uint64_t key_lds(const Wave& w, int idx) const { return w.skey[idx]; }
@@ -321,6 +340,7 @@ struct LinEval {
 
 template <int SZ, int NS>
 __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
+    PROF_CALL_T0
     LinEval<SZ, NS> ev;
     int N = 0;
     double cen[SZ], ind[SZ], ind2[SZ];
@@ -355,6 +375,136 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
     }
     sort_reduce_emit<SZ>(w, N, ev, out, ind, ind2);
+    PROF_CALL_END(N)
+}
+
+// Chain of sums ((s0*x0 + s1*x1) + s2*x2) + ... where the reference calls simplify() after every `+`
+// (e.g. linear_acc + cross(..) + cross(..), RT/Dynamics.cu:107-109): ONE sort over all sources, and the head lane of
+// each run of equal keys replays the stages -- after source k (k >= 1) has been added, the term accumulated so far is
+// pruned into that stage's radius if its norm is <= threshold and takes no part in the later stages, exactly as the
+// intermediate PZ would have lost it.  Centre and radii are accumulated in the composed order.  NS = 2 is lincomb.
+template <int SZ, int NS>
+__device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* segs) {
+    PROF_CALL_T0
+    LinEval<SZ, NS> ev;
+    int N = 0;
+    double cen[SZ], indk[NS][SZ], ind2k[NS][SZ];  // indk[k]: what source k adds to the radius at its stage
+#pragma unroll
+    for (int e = 0; e < SZ; e++) cen[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        ev.s[k] = segs[k];
+        ev.off[k] = N;
+        N += segs[k].v.cnt;
+        const View& v = segs[k].v;
+        const double sc = segs[k].scale, asc = fabs(sc);
+#pragma unroll
+        for (int e = 0; e < SZ; e++) { indk[k][e] = 0.0; ind2k[k][e] = 0.0; }
+        if (segs[k].comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) {
+                const double c = sc * v.cen[v.off + e];
+                cen[e] = (k == 0) ? c : cen[e] + c;
+                indk[k][e] = v.ind[v.off + e] * asc; ind2k[k][e] = v.ind2[v.off + e] * asc;
+            }
+        } else {
+            const double c = sc * v.cen[v.off];
+#pragma unroll
+            for (int e = 0; e < SZ; e++)
+                if (e == segs[k].comp) { cen[e] = cen[e] + c; indk[k][e] = v.ind[v.off] * asc; ind2k[k][e] = v.ind2[v.off] * asc; }
+        }
+    }
+    ev.off[NS] = N;
+    [[maybe_unused]] const int N_in = N;
+    __syncthreads();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
+    if (w.lane == 0) {
+#pragma unroll
+        for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
+    }
+    int emitted = 0;
+    bool any_pruned = false, indirect = false;
+    double ra[NS][SZ];  // ra[k]: pruned at stage k (k >= 1)
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < SZ; e++) ra[k][e] = 0.0;
+    N = sort_terms(w, N, ev, indirect);
+    if (N > 0) {
+        PROF_T0
+        for (int base = 0; base < N; base += WAVE) {
+            const int p = base + w.lane;
+            bool head = false, keep = false, pruned = false;
+            uint64_t key = 0;
+            double acc[SZ];
+#pragma unroll
+            for (int e = 0; e < SZ; e++) acc[e] = 0.0;
+            if (p < N) {
+                key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
+                head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
+            }
+            if (head) {
+                int q = p;
+                bool present = false;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    // the sources hold unique keys, so a run has at most one term per source, in source order
+                    if (q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key && ev.seg_of(w.sidx[q]) == k) {
+                        double c[SZ];
+                        ev.coef(w.sidx[q], c);
+#pragma unroll
+                        for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + c[e] : c[e];
+                        present = true;
+                        q++;
+                    }
+                    if (k >= 1 && present) {  // simplify() of stage k
+                        double s = 0.0;
+#pragma unroll
+                        for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+                        if (sqrt(s) <= w.thr) {
+#pragma unroll
+                            for (int e = 0; e < SZ; e++) ra[k][e] += fabs(acc[e]);
+                            present = false;
+                            pruned = true;
+                        }
+                    }
+                }
+                keep = present;
+            }
+            const unsigned long long m = __ballot(keep);
+            any_pruned = any_pruned || (__ballot(pruned) != 0ull);
+            if (keep) {
+                const int pos = emitted + __popcll(m & ((1ull << w.lane) - 1ull));
+                if (pos < out.cap) {
+                    out.keys[pos] = key;
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) out.coef[(size_t)pos * SZ + e] = acc[e];
+                }
+            }
+            emitted += __popcll(m);
+        }
+        PROF_ADD(PR_EMIT)
+    }
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (any_pruned) {
+#pragma unroll
+        for (int k = 1; k < NS; k++)
+#pragma unroll
+            for (int e = 0; e < SZ; e++) ra[k][e] = wave_sum(ra[k][e]);
+    }
+    if (w.lane == 0) {
+#pragma unroll
+        for (int e = 0; e < SZ; e++) {
+            // stage 1: (i0 + i1) + pruned; stage k: (previous * 1.0 + ik) + pruned  -- as lincomb over two sources each time
+            double r = indk[0][e], r2 = ind2k[0][e];
+#pragma unroll
+            for (int k = 1; k < NS; k++) { r = (r + indk[k][e]) + ra[k][e]; r2 = (r2 + ind2k[k][e]) + ra[k][e]; }
+            out.ind[e] = r; out.ind2[e] = r2;
+        }
+        w.cnt[out.id] = emitted;
+        if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
+    }
+    __syncthreads();
+    PROF_CALL_END(N_in)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -435,7 +585,7 @@ struct MulEval {
             w.sidx[rank] = (uint16_t)idx;
         }
         __syncthreads();
-        PROF_ADD(PR_SORT)
+        PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
         return true;
     }
     __device__ inline uint64_t key_lds(const Wave& w, int idx) const {
@@ -485,6 +635,7 @@ __device__ inline void abs_sum(const Wave& w, const View& v, double* r) {
 
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
+    PROF_CALL_T0
     typedef MulShape<AR, AC, BR, BC> SH;
     MulEval<SH> ev;
     ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
@@ -517,6 +668,7 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
     sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
+    PROF_CALL_END(N)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -553,9 +705,11 @@ struct CrossEval : MulEval<MulShape<1, 1, 1, 1>> {
 };
 
 __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, const View& b) {
+    PROF_CALL_T0
     CrossEval ev;
     ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
     int N = (a.cnt + 1) * (b.cnt + 1) - 1;
+    [[maybe_unused]] const int N_in = N;
     // centres and radii of the six products, as mul<1,1,1,1> forms them
     double r2[3], r3[3];
     { PROF_T0
@@ -664,6 +818,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
     __syncthreads();
+    PROF_CALL_END(N_in)
 }
 
 // Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):
