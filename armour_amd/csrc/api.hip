@@ -101,6 +101,7 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_k, (size_t)nb * h->n));
     TRY(dev_alloc(&h->d_g, (size_t)nb * mmax));
     TRY(dev_alloc(&h->d_jac, (size_t)nb * mmax * h->n));
+    TRY(dev_alloc(&h->d_bounds, (size_t)2 * nb * mmax));
 #undef TRY
     h->allocB = nb;
     h->allocO = no;
@@ -188,7 +189,8 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 3; i++) armour_free_pinned(h->solve_pin[i]);
+    for (int i = 0; i < 6; i++) armour_free_pinned(h->solve_pin[i]);
+    dev_free(&h->d_bounds);
     armour_p1_free(h);
     dev_free(&h->d_link_count); dev_free(&h->d_link_center); dev_free(&h->d_link_indep);
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
@@ -206,6 +208,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     if (B < 1 || O < 0) { armour_set_error("bad batch/obstacle count (B=%d, O=%d)", B, O); return ARMOUR_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
+    h->bounds_on_device = false;
     int rc = ensure_capacity(h, B, O);
     if (rc != ARMOUR_OK) return rc;
     h->B = B; h->O = O; h->Q = h->J * h->T * O;

@@ -82,8 +82,11 @@ struct ArmourPlanner {
     int B = 0, O = 0, Q = 0, m = 0;
     bool ready = false;
     // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
-    void* solve_pin[3] = {nullptr, nullptr, nullptr};
-    size_t solve_pin_bytes[3] = {0, 0, 0};
+    void* solve_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows
+    size_t solve_pin_bytes[6] = {0, 0, 0, 0, 0, 0};
+    double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
+    bool bounds_on_device = false;
+    std::vector<double> h_gl, h_gu;  // host copy of the same bounds (valid while bounds_on_device)
     std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
     std::vector<double> h_torque_radius;              // [B][n][T]
     std::vector<double> h_link_gens;                  // [B][T][J][18]

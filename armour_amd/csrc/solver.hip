@@ -16,6 +16,8 @@
 // Host code only: the arithmetic of the hot path (eval_g / eval_jac_g) stays in p2_eval.hip.
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -178,6 +180,97 @@ struct ProblemState {
     bool done = false;
 };
 
+// ---- device-side scan of one evaluation: what the host QP needs instead of the whole g / jac ----
+// One block per problem walks the rows in order and leaves (a) the L1 violation of g_l <= g <= g_u and, with ROWS,
+// (b) the rows the QP has to see -- those that can become active for some |d|_inf <= 2, the filter of the host loop
+// below -- compacted IN ROW ORDER (upper side before lower side of a row), each as {row, side, v = violation-signed
+// distance to the bound, a = -+J_i}.  A problem with 20 obstacles moves a few hundred such rows instead of 0.94 MB.
+constexpr int kScanRowsPerBlock = 2048;
+struct SolveRow {
+    int idx, side;
+    double v;
+    double a[NV];
+};
+
+// MODE 0: violation only (line-search trials); 1: violation + candidate rows (new linearisation); 2: violation + number of
+// rows outside [g_l - slack, g_u + slack] with the slacks of armtd_NLP::finalize_solution (RT/NLPclass.cu:422-538:
+// torque rows 1e-2, collision rows 1e-4, limit rows 0) -- the verdict armour_check_feasible gives on the host.
+template <int MODE>
+__global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, int n_torque_rows, int n_collision_rows, double torque_slack, double collision_slack, const double* __restrict__ g_all, const double* __restrict__ jac_all,
+                                                                const double* __restrict__ lo_all, const double* __restrict__ hi_all, int cap,
+                                                                double* __restrict__ viol_out, int* __restrict__ count_out, SolveRow* __restrict__ rows_out) {
+    // grid (segments, B): a block owns kScanRowsPerBlock consecutive rows and its own slice of the outputs; the host
+    // concatenates the slices in segment order
+    const int b = blockIdx.y, seg = blockIdx.x, nseg = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* g = g_all + (size_t)b * m;
+    constexpr bool ROWS = MODE == 1;
+    const double* jac = ROWS ? jac_all + (size_t)b * m * n : nullptr;
+    const double* lo = lo_all + (size_t)b * m;
+    const double* hi = hi_all + (size_t)b * m;
+    SolveRow* rows = ROWS ? rows_out + ((size_t)b * nseg + seg) * cap : nullptr;
+    const int row_end = min(m, (seg + 1) * kScanRowsPerBlock);
+    __shared__ int wave_tot[4];
+    __shared__ double red[256];
+    int base = 0, bad = 0;
+    double vsum = 0.0;
+    for (int i0 = seg * kScanRowsPerBlock; i0 < row_end; i0 += 256) {
+        const int i = i0 + tid;
+        const bool in = i < row_end;
+        const double gi = in ? g[i] : 0.0, li = in ? lo[i] : -1e300, ui = in ? hi[i] : 1e300;
+        if (gi > ui) vsum += gi - ui;
+        else if (gi < li) vsum += li - gi;
+        if (MODE == 2 && in) {
+            const double slack = i < n_torque_rows ? torque_slack : i < n_torque_rows + n_collision_rows ? collision_slack : 0.0;
+            if (gi < li - slack || gi > ui + slack) bad++;
+        }
+        if (ROWS) {
+            double J[NV], l1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; j++) { J[j] = (in && j < n) ? jac[(size_t)i * n + j] : 0.0; l1 += fabs(J[j]); }
+            const bool fh = in && ui < 1e18 && gi + 2.0 * l1 > ui;
+            const bool fl = in && li > -1e18 && gi - 2.0 * l1 < li;
+            const unsigned long long bh = __ballot(fh), bl = __ballot(fl);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (lane == 0) wave_tot[wv] = __popcll(bh) + __popcll(bl);
+            __syncthreads();
+            int pos = base + __popcll(bh & below) + __popcll(bl & below);
+            for (int w2 = 0; w2 < wv; w2++) pos += wave_tot[w2];
+            if (fh) {
+                if (pos < cap) {
+                    SolveRow r; r.idx = i; r.side = 0; r.v = gi - ui;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) r.a[j] = -J[j];
+                    rows[pos] = r;
+                }
+                pos++;
+            }
+            if (fl && pos < cap) {
+                SolveRow r; r.idx = i; r.side = 1; r.v = li - gi;
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.a[j] = J[j];
+                rows[pos] = r;
+            }
+            base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            __syncthreads();
+        }
+    }
+    red[tid] = vsum;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (MODE == 2) {
+        __shared__ int bad_tot;
+        if (tid == 0) bad_tot = 0;
+        __syncthreads();
+        if (bad) atomicAdd(&bad_tot, bad);
+        __syncthreads();
+        base = bad_tot;
+    }
+    if (tid == 0) { viol_out[(size_t)b * nseg + seg] = red[0]; if (MODE != 0) count_out[(size_t)b * nseg + seg] = base; }
+}
+
 double violation(const double* g, const double* lo, const double* hi, int m) {
     double v = 0;
     for (int i = 0; i < m; i++) {
@@ -223,13 +316,31 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     // (owned by the handle and kept across solves; armour_eval_g_jac recognises them and lets the kernel write into them)
     HIPCHK(hipSetDevice(h->device));
     double* hk = armour_handle_pinned(h, 0, (size_t)B * n * sizeof(double));
-    double* hg = armour_handle_pinned(h, 1, (size_t)B * m * sizeof(double));
-    double* hj = armour_handle_pinned(h, 2, (size_t)B * m * n * sizeof(double));
-    if (!hk || !hg || !hj) return ARMOUR_EDEVICE;
+    double *hg = nullptr, *hj = nullptr;  // whole-g / whole-jac mirrors: only the row-buffer overflow fallback allocates them
+    if (!hk) return ARMOUR_EDEVICE;
 
-    std::vector<double> xl(n), xu(n), gl((size_t)B * m), gu((size_t)B * m);
-    int rc = armour_get_bounds(h, xl.data(), xu.data(), gl.data(), gu.data());
-    if (rc != ARMOUR_OK) return rc;
+    std::vector<double> xl(n), xu(n);
+    int rc = ARMOUR_OK;
+    // g and jac stay on the device; a scan kernel hands back the L1 violation and the compacted candidate rows
+    const size_t bm = (size_t)B * m;
+    if (!h->bounds_on_device) {  // once per problem set
+        h->h_gl.resize(bm); h->h_gu.resize(bm);
+        if ((rc = armour_get_bounds(h, xl.data(), xu.data(), h->h_gl.data(), h->h_gu.data())) != ARMOUR_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->bounds_on_device = true;
+    } else if ((rc = armour_get_bounds(h, xl.data(), xu.data(), nullptr, nullptr)) != ARMOUR_OK) return rc;
+    const std::vector<double>&gl = h->h_gl, &gu = h->h_gu;
+    const int nseg = (m + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
+    // rows a segment may hand back (its slice of the page-locked buffer): everything if the batch is small
+    const int cap_rows = (int)std::max<size_t>(64, std::min<size_t>(2 * kScanRowsPerBlock, ((size_t)128 << 20) / ((size_t)B * nseg * sizeof(SolveRow))));
+    double* hviol_seg = armour_handle_pinned(h, 3, (size_t)B * nseg * sizeof(double));
+    int* hcount = reinterpret_cast<int*>(armour_handle_pinned(h, 4, (size_t)B * nseg * sizeof(int)));
+    SolveRow* hrows = reinterpret_cast<SolveRow*>(armour_handle_pinned(h, 5, (size_t)B * nseg * cap_rows * sizeof(SolveRow)));
+    if (!hviol_seg || !hcount || !hrows) return ARMOUR_EDEVICE;
+    std::vector<double> hviol(B);
+    bool full_on_host = false;  // g / jac of the current linearisation were copied to hg / hj (row-buffer overflow fallback)
     // constant diagonal Hessian of the cost: f = scale * sum (q_des - q0 - ... - c*kr*x)^2  (RT/NLPclass.cu:207-236)
     const double tp = h->params.t_plan;
     double Hd[NV];
@@ -242,9 +353,51 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     std::vector<double> fb(B), gfb((size_t)B * n);
     for (int b = 0; b < B; b++) { for (int j = 0; j < n; j++) { st[b].x[j] = 0.0; hk[b * n + j] = 0.0; } st[b].mu = 1.0; }  // get_starting_point: x = 0
 
-    auto eval = [&](bool want_jac) -> int {
-        int r = armour_eval_g_jac(h, hk, hg, want_jac ? hj : nullptr);
-        return r;
+    // one fused evaluation of all problems at hk (read by the kernel from page-locked memory) into the handle's device
+    // buffers, then the scan; the host waits once
+    auto wait = [&]() -> int {
+        for (;;) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) return ARMOUR_OK;
+            if (q != hipErrorNotReady) { armour_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+        }
+    };
+    double t_eval = 0, t_qp = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto eval = [&](bool want_jac, bool verdict = false) -> int {
+        const auto e0 = now();
+        struct Acc { double& t; decltype(e0) s; ~Acc() { t += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s).count(); } } acc{t_eval, e0};
+        int r = armour_eval_g_jac_device(h, hk, h->d_g, want_jac ? h->d_jac : nullptr, h->stream);
+        if (r != ARMOUR_OK) return r;
+        const int nTq = n * h->T, nCol = h->Q;
+        const double tsl = h->params.torque_violation_threshold, csl = h->params.collision_violation_threshold;
+#define SCAN(MODE, JAC, CNT, ROWSP) hipLaunchKernelGGL(armour_solve_scan_kernel<MODE>, dim3(nseg, B), dim3(256), 0, h->stream, m, n, nTq, nCol, tsl, csl, h->d_g, JAC, h->d_bounds, h->d_bounds + bm, cap_rows, hviol_seg, CNT, ROWSP)
+        if (want_jac) SCAN(1, h->d_jac, hcount, hrows);
+        else if (verdict) SCAN(2, (const double*)nullptr, hcount, (SolveRow*)nullptr);
+        else SCAN(0, (const double*)nullptr, (int*)nullptr, (SolveRow*)nullptr);
+#undef SCAN
+        HIPCHK(hipGetLastError());
+        if ((r = wait()) != ARMOUR_OK) return r;
+        for (int b = 0; b < B; b++) {
+            double v = 0.0;
+            for (int sg = 0; sg < nseg; sg++) v += hviol_seg[(size_t)b * nseg + sg];
+            hviol[b] = v;
+        }
+        full_on_host = false;
+        if (want_jac) {
+            bool overflow = false;
+            for (size_t i = 0; i < (size_t)B * nseg; i++) overflow = overflow || hcount[i] > cap_rows;
+            if (overflow) {  // more candidate rows than the buffer holds: bring the whole linearisation over, as before
+                hg = armour_handle_pinned(h, 1, bm * sizeof(double));
+                hj = armour_handle_pinned(h, 2, bm * n * sizeof(double));
+                if (!hg || !hj) return ARMOUR_EDEVICE;
+                HIPCHK(hipMemcpyAsync(hg, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(hj, h->d_jac, bm * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                if ((r = wait()) != ARMOUR_OK) return r;
+                full_on_host = true;
+            }
+        }
+        return ARMOUR_OK;
     };
     auto time_left = [&]() {
         if (opt.max_wall_time_s <= 0) return true;
@@ -257,12 +410,13 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     for (int b = 0; b < B; b++) {
         st[b].f = fb[b];
         for (int j = 0; j < n; j++) st[b].gradf[j] = gfb[(size_t)b * n + j];
-        st[b].viol = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+        st[b].viol = hviol[b];
         st[b].evals = 1;
     }
     std::vector<double> dstep((size_t)B * n), alpha(B), dphi(B), phi0(B);
     std::vector<char> searching(B);
-    const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)B));
+    // the QPs are small now (tens to hundreds of rows each): a host thread per 32 problems
+    const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)B / 32u));
 
     for (int it = 0; it < opt.max_iterations; it++) {
         bool any = false;
@@ -283,7 +437,17 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                 double sigma = 0.0;  // fraction of the current violation a row may keep (elastic retry)
                 for (int attempt = 0; attempt < 4; attempt++) {
                     rows.clear();
-                    for (int i = 0; i < m; i++) {
+                    if (!full_on_host) {
+                        for (int sg = 0; sg < nseg; sg++) {
+                            const SolveRow* cr = hrows + ((size_t)b * nseg + sg) * cap_rows;
+                            for (int r0 = 0; r0 < hcount[(size_t)b * nseg + sg]; r0++) {
+                                QpRow r; for (int j = 0; j < n; j++) r.a[j] = cr[r0].a[j];
+                                const double v = cr[r0].v;
+                                r.b = v - (v > 0 ? sigma * v : 0.0); rows.push_back(r);
+                            }
+                        }
+                    }
+                    for (int i = 0; full_on_host && i < m; i++) {
                         const double* Ji = J + (size_t)i * n;
                         double l1 = 0;
                         for (int j = 0; j < n; j++) l1 += std::fabs(Ji[j]);
@@ -320,6 +484,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
             }
         };
         for (int b = 0; b < B; b++) searching[b] = 0;
+        const auto q0 = now();
         if (nthreads <= 1) work(0, B);
         else {
             std::vector<std::thread> th;
@@ -327,6 +492,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
             for (unsigned tI = 0; tI < nthreads; tI++) { const int b0 = (int)tI * per, b1 = std::min(B, b0 + per); if (b0 < b1) th.emplace_back(work, b0, b1); }
             for (auto& t : th) t.join();
         }
+        t_qp += std::chrono::duration<double, std::milli>(now() - q0).count();
         // ---- L1-merit backtracking line search, all problems in lock step (one eval_g launch per trial) ----
         for (int ls = 0; ls <= opt.max_line_search; ls++) {
             bool need = false;
@@ -340,7 +506,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
             for (int b = 0; b < B; b++) {
                 if (!searching[b]) continue;
                 st[b].evals++;
-                const double v = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+                const double v = hviol[b];
                 const double phi = fb[b] + st[b].mu * v;
                 if (phi <= phi0[b] + 1e-4 * alpha[b] * dphi[b] || ls == opt.max_line_search) {
                     if (ls == opt.max_line_search && phi > phi0[b]) { st[b].done = true; st[b].status = 4; searching[b] = 0; continue; }
@@ -359,22 +525,27 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
             if (st[b].done) continue;
             st[b].evals++;
             for (int j = 0; j < n; j++) st[b].gradf[j] = gfb[(size_t)b * n + j];
-            st[b].viol = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+            st[b].viol = hviol[b];
         }
     }
     // ---- finalize_solution: feasibility re-check with the reference's slack thresholds ----
     for (int b = 0; b < B; b++) for (int j = 0; j < n; j++) hk[b * n + j] = st[b].x[j];
-    if ((rc = eval(false)) != ARMOUR_OK) return rc;
+    if ((rc = eval(false, true)) != ARMOUR_OK) return rc;  // with the per-row slack test of finalize_solution done on the device
     if ((rc = armour_eval_f(h, hk, fb.data())) != ARMOUR_OK) return rc;
     std::vector<int32_t> feas(B);
-    if ((rc = armour_check_feasible(h, hg, feas.data())) != ARMOUR_OK) return rc;
+    for (int b = 0; b < B; b++) {
+        int bad = 0;
+        for (int sg = 0; sg < nseg; sg++) bad += hcount[(size_t)b * nseg + sg];
+        feas[b] = bad == 0 ? 1 : 0;
+    }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (getenv("ARMOUR_SOLVE_TIMING")) fprintf(stderr, "[armour_solve] B=%d total %.3f ms: evaluations+scan %.3f ms, QP %.3f ms, rows of problem 0, segment 0: %d (cap %d, %d segments)\n", B, ms, t_eval, t_qp, hcount[0], cap_rows, nseg);
     for (int b = 0; b < B; b++) {
         ArmourSolveResult& r = results[b];
         memset(&r, 0, sizeof(r));
         for (int j = 0; j < n; j++) r.k_opt[j] = st[b].x[j];
         r.cost = fb[b];
-        r.max_violation = violation(hg + (size_t)b * m, gl.data() + (size_t)b * m, gu.data() + (size_t)b * m, m);
+        r.max_violation = hviol[b];
         r.feasible = feas[b];
         r.iterations = st[b].iters;
         r.evaluations = st[b].evals + 1;

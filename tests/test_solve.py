@@ -69,6 +69,27 @@ def test_batched_solve_equals_single_solves():
         assert np.allclose(batch[b]["k_opt"], one["k_opt"], atol=1e-9) and batch[b]["feasible"] == one["feasible"]
 
 
+@pytest.mark.parametrize("seed,O,T", [(3, 3, 20), (7, 12, 100), (8, 30, 100)])
+def test_device_verdict_and_violation_equal_the_host_ones(seed, O, T):
+    """armour_solve leaves g / jac on the device and reads back a scan (violation sum, candidate rows, verdict): the
+    verdict must be armtd_NLP::finalize_solution's (host armour_check_feasible on the full g) and the violation the L1
+    violation of the bounds, for feasible and infeasible outcomes alike; a batch spans several scan segments."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    B = 3
+    bp = random_batch(seed, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    sols = nlp.solve()
+    _, _, gl, gu = nlp.get_bounds_info()
+    k = np.stack([s["k_opt"] for s in sols])
+    g = nlp.eval_g(k)
+    host = nlp.finalize_solution(g)
+    for b in range(B):
+        assert bool(sols[b]["feasible"]) == bool(host[b])
+        v = np.maximum(g[b] - gu[b], 0).sum() + np.maximum(gl[b] - g[b], 0).sum()
+        assert abs(sols[b]["max_violation"] - v) <= 1e-9 * max(1.0, v)
+
+
 def test_wall_time_limit_is_honoured(sample_problem):
     from armour_amd.planner import ArmourNLP
     p = sample_problem

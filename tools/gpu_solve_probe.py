@@ -6,7 +6,7 @@ from armour_amd.planner import ArmourNLP
 from armour_amd.worlds import random_problem, random_batch
 sys.path.insert(0, 'tests')
 from helpers import SAMPLE_PROBLEM as SP
-for B, O in ((1, 10), (16, 10)):
+for B, O in ((1, 10), (16, 10), (128, 10)):
     pb = {k: np.stack([np.asarray(SP[k], dtype=float) + (0.01 * b if k == 'q_des' else 0.0) for b in range(B)]) for k in ('q0', 'qd0', 'qdd0', 'q_des', 'obstacles')}
     nlp = ArmourNLP(T=100).set_parameters(pb['q0'], pb['qd0'], pb['qdd0'], pb['q_des'], pb['obstacles'])
     for rep in range(3):
