@@ -20,6 +20,7 @@
 // private global-memory arena of PZ slots, stride over the (b,t) work list).  A second, trivially parallel
 // kernel builds the half-space table one thread per (problem, link, time, obstacle) row.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -49,6 +50,13 @@ struct P1Cfg {
     double* link_gens;      // [B][T][J][18]
     double* torque_radius;  // [B][n][T]
     unsigned* status;
+    // work list: items[0..n_items) are the (problem, time step) indices b*T + t to build (nullptr: all 0..n_items-1).
+    // retry_list != nullptr: an item whose sort buffers overflowed is appended there (its error bits are dropped) for a
+    // second launch with larger buffers, instead of failing the whole launch.
+    const int* items;
+    int n_items;
+    int* retry_list;
+    unsigned* retry_count;
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -706,9 +714,10 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     c.w.thr = cf.pr.simplify_threshold;
     c.w.lane = threadIdx.x;
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
-    const int total = cf.B * cf.T;
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    for (int it = blockIdx.x; it < cf.n_items; it += gridDim.x) {
+        const int item = cf.items ? cf.items[it] : it;
         const int b = item / cf.T, t = item - b * cf.T;
+        const int err_before = c.w.lstat[ST_ERR];
         c.freeV = 0xffffffffu;
         c.freeS = (1u << kNS) - 1u;
         for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
@@ -731,6 +740,11 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
 #endif
         finish_torque(c, u_nom, b, t);
         __syncthreads();
+        if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
+            // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
+            if (threadIdx.x == 0) { cf.retry_list[atomicAdd(cf.retry_count, 1u)] = item; c.w.lstat[ST_ERR] = err_before; }
+            __syncthreads();
+        }
 #ifdef P1_PROFILE
         if (threadIdx.x == 0 && (t % 10 == 0 || t == cf.T - 1))
             printf("[t=%d] total %lld: N<=64 %llu (%llu calls), mid %llu (%llu calls, %llu terms), big %llu (%llu calls, %llu terms) | fill %llu sort %llu (rank %llu bitonic %llu linmerge %llu mulmerge %llu) emit %llu abs %llu\n", t, (long long)clock64() - ph0,
@@ -897,6 +911,7 @@ struct P1Work {
     double* d_link_gens = nullptr; size_t gens_cap = 0;
     double* d_torque_radius = nullptr; size_t tr_cap = 0;
     double* d_obstacles = nullptr; size_t obs_cap = 0;
+    int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -910,6 +925,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
+    if (wk->d_retry) (void)hipFree(wk->d_retry);
     if (wk->ev0) (void)hipEventDestroy(wk->ev0);
     if (wk->ev1) (void)hipEventDestroy(wk->ev1);
     delete wk;
@@ -1003,19 +1019,22 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
-    const int max_lds = (int)prop.sharedMemPerBlock;  // 64 KiB by default; up to 160 KiB on gfx950 with the attribute below
-    for (;;) {
-        const Layout L0 = make_layout(J, n, h->lim.work_monomials);
-        const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L0.nJM * 27 + (size_t)L0.nJV * 9 + (size_t)L0.nJS * 3;
-        const int cap_key = cap_raw;  // a smaller key buffer (more waves per CU) was tried: typical batches overflow it and the retry costs more than it gains
-        const size_t smem = (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
-        if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap_raw); return ARMOUR_EINVAL; }
-        (void)max_lds;
+    if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
+    const Layout L = make_layout(J, n, h->lim.work_monomials);
+    if (L.idJS + L.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
+    const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
+    auto lds_bytes = [&](int cap) { return (((size_t)cap * 8 + (size_t)cap * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double); };
+    auto waves_per_cu = [&](int cap) { return std::max(1, std::min(4, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };  // 4 = one wave per SIMD (the kernel needs > 256 registers)
+    float total_ms = 0;
+    unsigned st[ST_WORDS];
+    // one launch of the chain kernel over `n_items` work items (d_items == nullptr: all of them) with sort buffers of `cap`
+    // entries; with `collect` the items that overflow them are listed in wk->d_retry instead of failing the launch
+    auto launch = [&](int cap, const int* d_items, int n_items, bool collect) -> int {
+        const size_t smem = lds_bytes(cap);
+        if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
         HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const Layout L = make_layout(J, n, h->lim.work_monomials);
-        if (L.idJS + L.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
-        const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / smem)));  // 4 = one wave per SIMD (the kernel needs > 256 registers)
-        const int waves = std::min(B * T, prop.multiProcessorCount * per_cu);
+        const int per_cu = waves_per_cu(cap);
+        const int waves = std::min(n_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
             wk->arena = nullptr;
@@ -1025,7 +1044,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         P1Cfg cf;
         memset(&cf, 0, sizeof(cf));
         cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
-        cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capKey = cap_key; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+        cf.capW = h->lim.work_monomials; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
         cf.arena_bytes = L.total; cf.arena = wk->arena;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
@@ -1034,22 +1053,19 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
         cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
         cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
+        cf.items = d_items; cf.n_items = n_items;
+        cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
+        if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
         hipLaunchKernelGGL(armour_p1_chain_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
         HIPCHK(hipGetLastError());
-        if (O > 0) {
-            const int Q = J * T * O;
-            HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
-            hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, h->d_plane_skip);
-            h->ll_shared = 1; h->d_from_center = 1;
-            HIPCHK(hipGetLastError());
-        }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
-        unsigned st[ST_WORDS];
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
+        total_ms += ms;
 #ifdef P1_PROFILE
         {
             unsigned long long pr[PR_WORDS];
@@ -1060,21 +1076,58 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
+        if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1] %d items, cap_raw %d: %d waves (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+        return ARMOUR_OK;
+    };
+    auto other_errors = [&]() -> int {
+        if (st[ST_ERR] & ~(unsigned)ERR_RAW_OVERFLOW) {
+            armour_set_error("[dbg word3=%u] reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
+                             st[3], st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            return ARMOUR_ECAPACITY;
+        }
+        return ARMOUR_OK;
+    };
+    // Batches with more items than three waves per CU hold run a first pass with 2048-entry sort buffers -- 32 KB of LDS
+    // per wave, so FOUR waves per CU -- and list the few items that overflow them; those alone are rebuilt with the full
+    // buffers.  Small batches gain nothing from the fourth wave and go straight to the full buffers.
+    const int kFirstPassCap = 2048;
+    const int* d_items = nullptr;
+    int n_items = B * T;
+    // (the second pass costs at least one item's latency, ~4 ms: worth it from about 16 items per CU)
+    if (cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
+        if ((rc = launch(kFirstPassCap, nullptr, B * T, true)) != ARMOUR_OK) return rc;
+        if ((rc = other_errors()) != ARMOUR_OK) return rc;
+        int nretry = 0;
+        HIPCHK(hipMemcpy(&nretry, wk->d_retry, sizeof(int), hipMemcpyDeviceToHost));
+        d_items = wk->d_retry + 1;
+        n_items = nretry;
+    }
+    while (n_items > 0) {
+        if ((rc = launch(cap_raw, d_items, n_items, false)) != ARMOUR_OK) return rc;
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
             if (cap_raw < 16384) { cap_raw <<= 1; continue; }  // retry with larger LDS sort buffers
             armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
             return ARMOUR_ECAPACITY;
         }
-        if (st[ST_ERR]) {
-            armour_set_error("[dbg word3=%u] reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
-                             st[3], st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
-            return ARMOUR_ECAPACITY;
-        }
+        if ((rc = other_errors()) != ARMOUR_OK) return rc;
         break;
     }
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
-    h->build_ms = ms;
+    if (O > 0) {
+        const int Q = J * T * O;
+        HIPCHK(hipEventRecord(wk->ev0, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
+                           wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, h->d_plane_skip);
+        h->ll_shared = 1; h->d_from_center = 1;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(wk->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
+        total_ms += ms;
+    }
+    h->build_ms = total_ms;  // device time of every launch of this build, retries included
+
     h->h_torque_radius.resize((size_t)B * n * T);
     h->h_link_gens.resize((size_t)B * T * J * 18);
     HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, h->h_torque_radius.size() * sizeof(double), hipMemcpyDeviceToHost));

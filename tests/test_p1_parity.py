@@ -213,6 +213,27 @@ def test_more_work_items_than_resident_waves():
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
 
 
+def test_two_pass_build_of_large_batches():
+    """From 16 items per CU on, the build first runs every (problem, time step) item with 2048-entry sort buffers (four
+    waves per CU) and rebuilds only the items that overflowed them with the full buffers: the tables must equal those of
+    single-problem handles (one pass, full buffers) bit for bit, including for a fast initial state whose products are
+    the ones that overflow."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, O, B = 100, 1, 42
+    bp = random_batch(500, B, O)
+    bp["qd0"][5] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])   # fast start: the largest PZs
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = random_k(9, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b in (0, 5, 23, 41):
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        g1, j1 = one.eval_g_jac(ks[b])
+        assert np.array_equal(g[b], g1[0]) and np.array_equal(jac[b], j1[0])
+        assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
+        assert np.array_equal(nlp.link_generators()[b], one.link_generators()[0])
+
+
 def test_two_handles_from_two_host_threads():
     """One handle = one stream; handles are independent (include/armour_hip.h): two host threads building and evaluating
     different worlds at the same time get the results of serial runs."""
