@@ -30,7 +30,7 @@
 
 #define P2_BLOCK 256
 #define P2_ROWS 64        // collision rows per block (one per lane); the 4 waves split the 36 planes 9 each
-#define P2_PPW 9          // planes per wave
+#define P2_PPW 9          // planes per wave (36 / 4); the PPW template parameter is 9, or 6 when no problem has more than 24 live planes
 #define P2_TASK_ROUNDS 2   // (monomial, axis) slicing tasks a thread preloads per LDS pass
 #define P2_TQ_ROWS 8      // torque rows per block (32 monomial lanes each)
 #define P2_TQ_ROUNDS 4    // monomials per lane of a torque row (strideT <= 128)
@@ -175,7 +175,9 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
 
 // DFC: d = A . c_obstacle is recomputed from tb.obs_center instead of read (batched launches of tables built by P1)
 // LL: the link x link normals come from the compact tb.planes_ll (tables whose normals are obstacle-independent)
-template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL>
+// PPW: plane slots per wave.  With axis-aligned box obstacles 12 of the 36 planes are skipped (armour_p1_planes_kernel), so a
+// wave holds at most 6: the 6-slot instantiation drops a third of the slot loops (loads, d recomputation, scan, pick).
+template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW>
 __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE(DFC, MULTI)))) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         const int na = __popcll(live), base = na >> 2, rem = na & 3;
         const int my_cnt = base + (wv < rem ? 1 : 0), my_start = wv * base + min(wv, rem);
         for (int s = 0; s < my_start; s++) live &= live - 1ull;
-        double a0[P2_PPW], a1[P2_PPW], a2[P2_PPW], dd[P2_PPW], dl[P2_PPW];
+        double a0[PPW], a1[PPW], a2[PPW], dd[PPW], dl[PPW];
         const int lt_first = q_begin / O;
         const int npairs = (q_end - 1) / O - lt_first + 1;
         const bool single_pass = npairs <= lp.pair_chunk;
         PassRegs pr;
 #pragma unroll
-        for (int i = 0; i < P2_PPW; i++) {
+        for (int i = 0; i < PPW; i++) {
             a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
             if (i < my_cnt) {
                 const int pidx = __builtin_ctzll(live);
@@ -320,12 +322,12 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
             const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
             if (DFC) {
 #pragma unroll
-                for (int i = 0; i < P2_PPW; i++) dd[i] = a0[i] * oc0 + a1[i] * oc1 + a2[i] * oc2;
+                for (int i = 0; i < PPW; i++) dd[i] = a0[i] * oc0 + a1[i] * oc1 + a2[i] * oc2;
             }
             double max_elt = -100000000.0;
             int best = (wv == 0 && plane0_live) ? 0 : -2;
 #pragma unroll
-            for (int i = 0; i < P2_PPW; i++) {
+            for (int i = 0; i < PPW; i++) {
                 const bool nz = (a0[i] != 0.0) | (a1[i] != 0.0) | (a2[i] != 0.0);  // A_elt.norm() > 0 (RT/CollisionChecking.cu:252)
                 const double dot = a0[i] * x0 + a1[i] * x1 + a2[i] * x2;
                 const double pos_res = nz ? dot - (dd[i] + dl[i]) : -100000000.0;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                 double mA0 = 0.0, mA1 = 0.0, mA2 = 0.0;
                 const int bs = best >> 1;
 #pragma unroll
-                for (int i = 0; i < P2_PPW; i++) {
+                for (int i = 0; i < PPW; i++) {
                     const bool hit = bs == i;
                     mA0 = hit ? a0[i] : mA0; mA1 = hit ? a1[i] : mA1; mA2 = hit ? a2[i] : mA2;
                 }
@@ -567,11 +569,16 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }
     dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
     const bool dfc = tb.obs_center != nullptr && tb.ll_shared;
+    // every problem of the launch has at most 24 live planes (6 per wave): use the 6-slot kernels
+    bool six = h_skip != nullptr;
+    for (int b = 0; six && b < tb.B; b++) six = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) <= 24;
 #define P2_LAUNCH_M(G, J, M)                                                                                                                      \
     do {                                                                                                                                          \
-        if (dfc) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);              \
-        else if (tb.ll_shared) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
-        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);                \
+        if (dfc && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 6>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);                \
+        else if (dfc) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);              \
+        else if (tb.ll_shared && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 6>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else if (tb.ll_shared) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, false, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);             \
     } while (0)
 #define P2_LAUNCH(G, J)                                                                                                     \
     do {                                                                                                                    \
