@@ -125,6 +125,35 @@ def test_matlab_callback_shape(sample_problem):
     assert np.abs(grad_h[:, :m] - jac_ref.T).max() <= J_TOL
 
 
+def test_batched_kernel_variants_on_p1_tables():
+    """Tables built by P1 (compact link x link normals, plane-skip masks -> 6-slot kernels) at B = 9: from B = 8 the
+    fused kernel recomputes d = A.c from the obstacle centres.  Every problem must equal its single-problem handle
+    (which reads d from the table) bit for bit -- in one-point, g-only, jac-only and multi-point launches."""
+    import torch
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, O, B, P = 100, 6, 9, 3
+    bp = random_batch(70, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = np.stack([random_k(40 + s, B) for s in range(P)])
+    g, jac = nlp.eval_g_jac(ks[0])
+    assert np.array_equal(nlp.eval_g(ks[0]), g) and np.array_equal(nlp.eval_jac_g(ks[0]), jac)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    d_k = torch.from_numpy(ks).to(dev)
+    d_g = torch.zeros((P, B, nlp.m), dtype=torch.float64, device=dev)
+    d_j = torch.zeros((P, B, nlp.m, nlp.n), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    nlp.eval_g_jac_device_multi(d_k.data_ptr(), P, d_g.data_ptr(), d_j.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(d_g[0].cpu().numpy(), g) and np.array_equal(d_j[0].cpu().numpy(), jac)
+    for b in (0, 4, 8):
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        for s in range(P):
+            g1, j1 = one.eval_g_jac(ks[s, b])
+            assert np.array_equal(d_g[s, b].cpu().numpy(), g1[0]) and np.array_equal(d_j[s, b].cpu().numpy(), j1[0])
+
+
 @pytest.mark.parametrize("B,O,points", [(1, 10, 5), (3, 7, 4), (2, 0, 3), (1, 40, 2)])
 def test_multi_point_launch_is_bit_identical(B, O, points):
     """armour_eval_g_jac_device_multi keeps the tables in registers over `points` k's: every point must equal the
