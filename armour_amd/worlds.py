@@ -13,6 +13,19 @@ STATE_UB = -STATE_LB
 SPEED = np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
 
 
+def reference_sample_problem():
+    """The sample input the reference keeps as a comment in its main program (RT/armour_main.cu:18-33): the one
+    concrete planning problem it ships (10 box obstacles; a known input without a recorded answer)."""
+    five = np.array([
+        [-0.28239, -0.33281, 0.88069, 0.069825, 0, 0, 0, 0.09508, 0, 0, 0, 0.016624],
+        [-0.19033, 0.035391, 1.3032, 0.11024, 0, 0, 0, 0.025188, 0, 0, 0, 0.014342],
+        [0.67593, -0.085841, 0.43572, 0.17408, 0, 0, 0, 0.07951, 0, 0, 0, 0.18012],
+        [0.75382, 0.51895, 0.4731, 0.030969, 0, 0, 0, 0.22312, 0, 0, 0, 0.22981],
+        [0.75382, 0.51895, 0.4731, 0.030969, 0, 0, 0, 0.22312, 0, 0, 0, 0.22981]])
+    return dict(q0=np.array([0.6543, -0.0876, -0.4837, -1.2278, -1.5735, -1.0720, 0]), qd0=np.zeros(7), qdd0=np.zeros(7),
+                q_des=np.array([0.6831, 0.009488, -0.2471, -0.9777, -1.414, -0.9958, 0]), obstacles=np.vstack([five, five]))
+
+
 def random_problem(seed, num_obstacles):
     """One world: dict(q0, qd0, qdd0, q_des [7], obstacles [O,12])."""
     rng = np.random.default_rng(seed)

@@ -237,6 +237,24 @@ def main():
                                          "note": "armour_eval_g_jac_device_multi: one launch evaluates P trial points of the same "
                                                  "problems, tables read once; bit-identical to P single launches"}
             del d_gm, d_jm
+        if world == 1 and not args.headline_only:
+            # extra (never `value`): one whole planning iteration -- reach-set build + NLP solve -- of the reference's own
+            # sample problem (RT/armour_main.cu:18-33), and the same for 128 copies with perturbed goals in lock step
+            from armour_amd.worlds import reference_sample_problem
+            sp = reference_sample_problem()
+            plan = {}
+            for pb in (1, 128):
+                st = {k: np.stack([np.asarray(sp[k], dtype=float) + (0.002 * i if k == "q_des" else 0.0) for i in range(pb)]) for k in sp}
+                pn = ArmourNLP(T=T, device=local_rank)
+                for _ in range(2):
+                    pn.set_parameters(st["q0"], st["qd0"], st["qdd0"], st["q_des"], st["obstacles"])
+                    t1 = time.perf_counter()
+                    sols = pn.solve()
+                    solve_ms = (time.perf_counter() - t1) * 1e3
+                plan[f"{pb} problem(s)"] = {"reach_sets_ms": pn.build_ms, "solve_ms": solve_ms,
+                                             "evaluations": int(sols[0]["evaluations"]), "feasible": int(sum(int(s["feasible"]) for s in sols))}
+                pn.close()
+            out["planning_iteration_sample_problem"] = plan
         if world == 1 and (B, O, T) == (1, 20, 100) and not args.headline_only:
             out["other_configs"] = other_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
