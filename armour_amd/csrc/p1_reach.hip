@@ -31,7 +31,12 @@ using namespace pzw;
 
 namespace {
 
-constexpr int kNV = 32, kNS = 24, kNM = 2;   // work slots per wave: 3x1, 1x1, 3x3
+constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work slots: Layout::nV (32 for one wave, 48 for three)
+// The 3x1 pool is split between the roles of a block (see run_rnea): each role allocates and frees only in its own part,
+// so three waves can run different operators at the same time without sharing allocator state.
+constexpr int kRoles = 3;
+constexpr int kPartFirst[kRoles] = {0, 20, 40}, kPartCount[kRoles] = {20, 20, 8};  // of the 48 slots of a 3-wave block
+constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
 constexpr int kMaxSlots = 192;
 
@@ -65,22 +70,25 @@ __host__ __device__ inline size_t slot_bytes(int cap, int sz) { return align64((
 // arena = work V | work S | work M | small M | small V | small S
 struct Layout {
     int nJM, nJV, nJS;
+    int nV, nroles;  // 3x1 work slots; sets of per-role scratch slots (1 or kRoles)
     size_t offV, offS, offM, offJM, offJV, offJS, total;
     int idV, idS, idM, idJM, idJV, idJS;
 };
-__host__ __device__ inline Layout make_layout(int J, int n, int capW) {
+__host__ __device__ inline Layout make_layout(int J, int n, int capW, int nroles) {
     Layout L;
-    L.nJM = (J + 1) + J + 3 + J;      // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia
+    L.nroles = nroles;
+    L.nV = nroles == 1 ? kNVOneWave : kPartFirst[kRoles - 1] + kPartCount[kRoles - 1];
+    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
     L.nJV = (J + 1) + J;              // trans P_i, link boxes
-    L.nJS = 3 * n + J + 4;            // qd, qda, qdda; mass; raw temps
+    L.nJS = 3 * n + J + 4 * nroles;   // qd, qda, qdda; mass; per role: 4 raw temps
     L.offV = 0;
-    L.offS = L.offV + (size_t)kNV * slot_bytes(capW, 3);
+    L.offS = L.offV + (size_t)L.nV * slot_bytes(capW, 3);
     L.offM = L.offS + (size_t)kNS * slot_bytes(capW, 1);
     L.offJM = L.offM + (size_t)kNM * slot_bytes(capW, 9);
     L.offJV = L.offJM + (size_t)L.nJM * slot_bytes(kCapSmall, 9);
     L.offJS = L.offJV + (size_t)L.nJV * slot_bytes(kCapSmall, 3);
     L.total = align64(L.offJS + (size_t)L.nJS * slot_bytes(kCapSmall, 1));
-    L.idV = 0; L.idS = L.idV + kNV; L.idM = L.idS + kNS; L.idJM = L.idM + kNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
+    L.idV = 0; L.idS = L.idV + L.nV; L.idM = L.idS + kNS; L.idJM = L.idM + kNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
     return L;
 }
 
@@ -262,38 +270,49 @@ struct Chain {
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
     Layout L;
-    unsigned freeV, freeS;
+    unsigned long long freeV;  // bit i: 3x1 work slot i is free (a wave only touches the bits of its own roles' parts)
+    unsigned freeS;
     int n, J;
+    int wid, nw;               // this wave's index in the block and the number of waves (1 or kRoles)
+    LDS_AS int* mb;            // LDS mailbox: slot indices handed from one role to another across a block barrier
+    // role r runs on wave r of a 3-wave block, every role on the one wave of a 1-wave block
+    __device__ bool is(int role) const { return nw == 1 || wid == role; }
+    __device__ void bar() const { __syncthreads(); }  // all waves of the block: the only cross-wave synchronisation
+    __device__ void post(int slot, const PZ& p) const { if (w.lane == 0) mb[slot] = p.id - L.idV; }
+    __device__ PZ take(int slot) const { return V(mb[slot]); }
 
     LDS_AS double* ci;  // LDS: centre / indep of every slot, classes laid out V | S | M | JM | JV | JS
     __device__ PZ V(int i) const { return mk_slot(arena, L.offV, i, cf->capW, 3, L.idV, ci); }
-    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS, ci + kNV * 9); }
-    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM, ci + kNV * 9 + kNS * 3); }
-    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM, ci + kNV * 9 + kNS * 3 + kNM * 27); }
-    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV, ci + kNV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27); }
-    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS, ci + kNV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27 + L.nJV * 9); }
+    __device__ PZ S(int i) const { return mk_slot(arena, L.offS, i, cf->capW, 1, L.idS, ci + L.nV * 9); }
+    __device__ PZ M(int i) const { return mk_slot(arena, L.offM, i, cf->capW, 9, L.idM, ci + L.nV * 9 + kNS * 3); }
+    __device__ PZ JM(int i) const { return mk_slot(arena, L.offJM, i, kCapSmall, 9, L.idJM, ci + L.nV * 9 + kNS * 3 + kNM * 27); }
+    __device__ PZ JV(int i) const { return mk_slot(arena, L.offJV, i, kCapSmall, 3, L.idJV, ci + L.nV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27); }
+    __device__ PZ JS(int i) const { return mk_slot(arena, L.offJS, i, kCapSmall, 1, L.idJS, ci + L.nV * 9 + kNS * 3 + kNM * 27 + L.nJM * 27 + L.nJV * 9); }
     // named small slots
     __device__ PZ R(int i) const { return JM(i); }                       // 0..J
     __device__ PZ Rt(int i) const { return JM(J + 1 + i); }              // 0..J-1
-    __device__ PZ rotRaw() const { return JM(2 * J + 1); }
-    __device__ PZ rotS() const { return JM(2 * J + 2); }
-    __device__ PZ rpy() const { return JM(2 * J + 3); }
-    __device__ PZ inertia(int i) const { return JM(2 * J + 4 + i); }
+    __device__ int scratch(int role) const { return L.nroles == 1 ? 0 : role; }
+    __device__ PZ rotRaw(int role) const { return JM(2 * J + 1 + 3 * scratch(role)); }
+    __device__ PZ rotS(int role) const { return JM(2 * J + 2 + 3 * scratch(role)); }
+    __device__ PZ rpy(int role) const { return JM(2 * J + 3 + 3 * scratch(role)); }
+    __device__ PZ inertia(int i) const { return JM(2 * J + 1 + 3 * L.nroles + i); }
     __device__ PZ Ptr(int i) const { return JV(i); }                     // trans, 0..J
     __device__ PZ linkbox(int i) const { return JV(J + 1 + i); }
     __device__ PZ qd(int i) const { return JS(i); }
     __device__ PZ qda(int i) const { return JS(n + i); }
     __device__ PZ qdda(int i) const { return JS(2 * n + i); }
     __device__ PZ mass(int i) const { return JS(3 * n + i); }
-    __device__ PZ rawS(int i) const { return JS(3 * n + J + i); }        // 0..3
+    __device__ PZ rawS(int role, int i) const { return JS(3 * n + J + 4 * scratch(role) + i); }  // i = 0..3
 
+    int role = 0;  // the role the code being executed belongs to: selects the part of the 3x1 pool allocV() draws from
     __device__ PZ allocV() {
-        const int i = __ffs(freeV) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(0); }
-        freeV &= ~(1u << i);
+        const unsigned long long part = L.nroles == 1 ? ~0ull : ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role];
+        const int i = __ffsll((long long)(freeV & part)) - 1;
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : kPartFirst[role]); }
+        freeV &= ~(1ull << i);
         return V(i);
     }
-    __device__ void freeVs(const PZ& p) { freeV |= 1u << (p.id - L.idV); }
+    __device__ void freeVs(const PZ& p) { freeV |= 1ull << (p.id - L.idV); }
     __device__ PZ allocS() {
         const int i = __ffs(freeS) - 1;
         if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return S(0); }
@@ -410,17 +429,21 @@ __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, 
         }
         c.w.cnt[raw.id] = m;
     }
-    __syncthreads();
+    WSYNC();
     Seg s[1] = {{view(c.w, raw), 1.0, -1}};
     lincomb<SZ, 1>(c.w, out, s);
 }
 
-// JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67)
+// JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67).
+// The joints are independent of each other: joint i is built by role i % 3 (with that role's scratch slots), so a 3-wave
+// block builds three joints at a time.  The caller follows with a block barrier.
 __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
     for (int i = 0; i < J; i++) {
+        const int role = i % kRoles;
+        if (!c.is(role)) continue;
         double rp[9];
         rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
         if (i < n && cf.rb.axes[i] != 0) {
@@ -434,36 +457,30 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
             make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
             make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
             const uint64_t keys[4] = {kk, kc, kk, ks};
-            build_simplified<9>(c, c.rotRaw(), c.rotS(), cen, 4, keys, co);
-            set_const(c.w, c.rpy(), rp, nullptr);
-            mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy()), view(c.w, c.rotS()));
+            build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
+            set_const(c.w, c.rpy(role), rp, nullptr);
+            mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
             // qd_des, qda_des, qdda_des (:176-243)
             {
                 const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
                 const double co2[2] = {js.qd_k, js.qd_e};
-                build_simplified<1>(c, c.rawS(0), c.qd(i), &js.qd_c, 2, k2, co2);
+                build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
             }
             {
                 const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
                 const double co2[2] = {js.qd_k, js.qda_e};
-                build_simplified<1>(c, c.rawS(0), c.qda(i), &js.qd_c, 2, k2, co2);
+                build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
             }
             {
                 const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
                 const double co2[2] = {js.qdd_k, js.qdd_e};
-                build_simplified<1>(c, c.rawS(0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+                build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
             }
         } else {
             set_const(c.w, c.R(i), rp, nullptr);
         }
         transpose33(c.w, c.Rt(i), c.R(i));
-    }
-    {
-        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
-        set_const(c.w, c.R(J), id, nullptr);
-    }
-    for (int i = 0; i <= J; i++) set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
-    for (int i = 0; i < J; i++) {
+        set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
         // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
         double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
         double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -474,10 +491,15 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
         // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
         for (int j = 0; j < 3; j++) {
             const uint64_t key = 1ull << ((j + 2) * n);
-            build_simplified<1>(c, c.rawS(0), c.rawS(1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+            build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
         }
-        Seg s[3] = {{view(c.w, c.rawS(1)), 1.0, 0}, {view(c.w, c.rawS(2)), 1.0, 1}, {view(c.w, c.rawS(3)), 1.0, 2}};
+        Seg s[3] = {{view(c.w, c.rawS(role, 1)), 1.0, 0}, {view(c.w, c.rawS(role, 2)), 1.0, 1}, {view(c.w, c.rawS(role, 3)), 1.0, 2}};
         lincomb<3, 3>(c.w, c.linkbox(i), s);
+    }
+    if (c.is(0)) {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
+        set_const(c.w, c.R(J), id, nullptr);
+        set_const(c.w, c.Ptr(J), &cf.rb.trans[3 * J], nullptr);
     }
 }
 
@@ -490,7 +512,7 @@ __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int 
     const size_t idx = ((size_t)b * c.J + l) * cf.T + t;
     double* gens = cf.link_gens + (((size_t)b * cf.T + t) * c.J + l) * 18;
     if (w.lane < 18) gens[w.lane] = 0.0;
-    __syncthreads();
+    WSYNC();
     double ra[3] = {0, 0, 0};
     int nk = 0, ng = 0;
     for (int base = 0; base < cnt; base += WAVE) {
@@ -528,111 +550,180 @@ __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int 
             gens[e * 6 + 3 + e] = ra[e];
         }
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // RT/Dynamics.cu:69-81 + RT/armour_main.cu:121-124
-__device__ PZW_NOINLINE void run_fk(Chain& c, int b, int t) {
+// Forward kinematics / forward occupancy (RT/Dynamics.cu:69-81), one joint per call so that role 2 can run it alongside
+// the RNEA phases of roles 0 and 1 (it shares nothing with them but the read-only JRS).
+struct FkState { PZ R, Rn, T; };
+__device__ PZW_NOINLINE void fk_begin(Chain& c, FkState& f) {
+    f.R = c.M(0); f.Rn = c.M(1);
+    double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    set_const(c.w, f.R, id, nullptr);
+    f.T = c.allocV();
+    set_const(c.w, f.T, nullptr, nullptr);
+}
+__device__ PZW_NOINLINE void fk_step(Chain& c, FkState& f, int i, int b, int t) {
     Wave& w = c.w;
-    PZ FK_R = c.M(0), FK_Rn = c.M(1);
-    {
-        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        set_const(w, FK_R, id, nullptr);
-    }
-    PZ FK_T = c.allocV();
-    set_const(w, FK_T, nullptr, nullptr);
-    for (int i = 0; i < c.J; i++) {
-        PZ tp = c.mulMV(FK_R, c.Ptr(i));
-        PZ nt = c.add(FK_T, tp);
-        c.freeVs(tp); c.freeVs(FK_T);
-        FK_T = nt;
-        mul<3, 3, 3, 3>(w, FK_Rn, view(w, FK_R), view(w, c.R(i)));
-        { PZ s = FK_R; FK_R = FK_Rn; FK_Rn = s; }
-        PZ l1 = c.mulMV(FK_R, c.linkbox(i));
-        PZ lk = c.add(l1, FK_T);
-        emit_link(c, lk, b, i, t);
-        c.freeVs(l1); c.freeVs(lk);
-    }
-    c.freeVs(FK_T);
+    PZ tp = c.mulMV(f.R, c.Ptr(i));
+    PZ nt = c.add(f.T, tp);
+    c.freeVs(tp); c.freeVs(f.T);
+    f.T = nt;
+    mul<3, 3, 3, 3>(w, f.Rn, view(w, f.R), view(w, c.R(i)));
+    { PZ s = f.R; f.R = f.Rn; f.Rn = s; }
+    PZ l1 = c.mulMV(f.R, c.linkbox(i));
+    PZ lk = c.add(l1, f.T);
+    emit_link(c, lk, b, i, t);
+    c.freeVs(l1); c.freeVs(lk);
 }
 
 // RT/Dynamics.cu:83-181; u[i] receives freshly allocated scalar slots
-__device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u) {
+// Passivity RNEA with nominal and interval parameters in one pass (RT/Dynamics.cu:83-181), and the FK steps.
+//
+// Work of one time step is dealt to three ROLES.  In a 3-wave block role r is wave r and the roles run concurrently; in a
+// 1-wave block the one wave plays all three in turn.  Every operator is executed by exactly one wave with the same
+// operands either way, so the results do not depend on the block shape.
+//   forward, joint i   phase 1:  role 0  linear_acc_i            role 1  w_i, w_aux_i, wdot_i        role 2  FK of joint i
+//                      phase 2:  role 0  F_i                     role 1  N_i
+//   backward, joint i  phase 1:  role 0  R n, com x F_i          role 1  R f, p x (R f)
+//                      phase 2:  role 0  n_i, u_i                role 1  f_i
+// A role allocates and frees only in its own part of the slot pool; what another role still reads is freed by its owner
+// after the next block barrier.  Results cross roles as slot indices in the LDS mailbox.
+enum { MB_WV = 0, MB_WDOT, MB_WAUX, MB_LACC, MB_F, MB_N = MB_F + ARMOUR_MAX_JOINTS, MB_A2 = MB_N + ARMOUR_MAX_JOINTS, MB_C2, MB_FF, MB_NN, MB_WORDS };
+__device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int J = c.J;
-    PZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV(), lacc = c.allocV();
-    set_const(w, wv, nullptr, nullptr);
-    set_const(w, wdot, nullptr, nullptr);
-    set_const(w, waux, nullptr, nullptr);
-    {
+    FkState fk;
+    if (c.is(2)) { c.role = 2; fk_begin(c, fk); }
+    if (c.is(1)) {
+        c.role = 1;
+        PZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV();
+        set_const(w, wv, nullptr, nullptr);
+        set_const(w, wdot, nullptr, nullptr);
+        set_const(w, waux, nullptr, nullptr);
+        c.post(MB_WV, wv); c.post(MB_WDOT, wdot); c.post(MB_WAUX, waux);
+    }
+    if (c.is(0)) {
+        c.role = 0;
+        PZ lacc = c.allocV();
         double g[3] = {0.0, 0.0, cf.rb.gravity};
         set_const(w, lacc, g, nullptr);
+        c.post(MB_LACC, lacc);
     }
-    PZ F[ARMOUR_MAX_JOINTS], N[ARMOUR_MAX_JOINTS];
+    c.bar();
     for (int i = 0; i < J; i++) {
         const double* tr = &cf.rb.trans[3 * i];
         const double* cm = &cf.rb.com[3 * i];
         const PZ Rt = c.Rt(i);
         const int ax = abs(cf.rb.axes[i]) - 1;
-        {   // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+        // state of the previous joint (read-only in phase 1)
+        const PZ wv = c.take(MB_WV), wdot = c.take(MB_WDOT), waux = c.take(MB_WAUX), lacc = c.take(MB_LACC);
+        c.bar();  // everyone has taken the handles before phase 1 posts the new ones
+        if (c.is(0)) {  // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+            c.role = 0;
             PZ c1 = c.crossPzMat(wdot, tr);
             PZ c2 = c.crossPzMat(waux, tr);
             PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);  // (linear_acc + c1) + c3
-            PZ nl = c.mulMV(Rt, s2); c.freeVs(s2); c.freeVs(lacc);
-            lacc = nl;
+            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3); c.freeVs(lacc);  // (linear_acc + c1) + c3
+            PZ nl = c.mulMV(Rt, s2); c.freeVs(s2);
+            c.post(MB_LACC, nl);
         }
-        {   // lines 13-15: rotate w, w_aux, wdot into the joint frame
-            PZ nw = c.mulMV(Rt, wv); c.freeVs(wv); wv = nw;
-            if (cf.rb.axes[i] != 0) { PZ t2 = c.addOneDim(wv, c.qd(i), ax); c.freeVs(wv); wv = t2; }
-            PZ na = c.mulMV(Rt, waux); c.freeVs(waux); waux = na;
-            PZ nd = c.mulMV(Rt, wdot); c.freeVs(wdot); wdot = nd;
+        if (c.is(1)) {  // lines 13-15: rotate w, w_aux, wdot into the joint frame, add the joint's own motion
+            c.role = 1;
+            PZ nw = c.mulMV(Rt, wv);
+            if (cf.rb.axes[i] != 0) { PZ t2 = c.addOneDim(nw, c.qd(i), ax); c.freeVs(nw); nw = t2; }
+            PZ na = c.mulMV(Rt, waux);
+            PZ nd = c.mulMV(Rt, wdot);
+            if (cf.rb.axes[i] != 0) {
+                PZ zero = c.allocV();
+                set_const(w, zero, nullptr, nullptr);
+                PZ temp = c.addOneDim(zero, c.qd(i), ax); c.freeVs(zero);
+                PZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
+                PZ nd2 = c.sum3(nd, c4, c.qdda(i), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;  // (wdot + c4), then + qdda on the axis
+                PZ na2 = c.addOneDim(na, c.qda(i), ax); c.freeVs(na); na = na2;
+            }
+            c.post(MB_WV, nw); c.post(MB_WDOT, nd); c.post(MB_WAUX, na);
         }
-        if (cf.rb.axes[i] != 0) {
-            PZ zero = c.allocV();
-            set_const(w, zero, nullptr, nullptr);
-            PZ temp = c.addOneDim(zero, c.qd(i), ax); c.freeVs(zero);
-            PZ c4 = c.crossPzPz(waux, temp); c.freeVs(temp);
-            PZ nd2 = c.sum3(wdot, c4, c.qdda(i), ax); c.freeVs(c4); c.freeVs(wdot); wdot = nd2;  // (wdot + c4), then + qdda on the axis
-            PZ na = c.addOneDim(waux, c.qda(i), ax); c.freeVs(waux); waux = na;
+        if (c.is(2)) { c.role = 2; fk_step(c, fk, i, b, t); }
+        c.bar();
+        if (c.is(1)) { c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }  // the previous joint's state: role 0 has finished reading it
+        {
+            const PZ wv2 = c.take(MB_WV), wdot2 = c.take(MB_WDOT), waux2 = c.take(MB_WAUX), lacc2 = c.take(MB_LACC);
+            if (c.is(0)) {  // lines 23 & 27: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
+                c.role = 0;
+                PZ c1 = c.crossPzMat(wdot2, cm);
+                PZ c2 = c.crossPzMat(waux2, cm);
+                PZ c3 = c.crossPzPz(wv2, c2); c.freeVs(c2);
+                PZ s2 = c.sum3(lacc2, c1, c3); c.freeVs(c1); c.freeVs(c3);
+                PZ F = c.mulSV(c.mass(i), s2); c.freeVs(s2);
+                c.post(MB_F + i, F);
+            }
+            if (c.is(1)) {  // line 29: N = I * wdot + cross(w_aux, I * w)
+                c.role = 1;
+                const PZ I = c.inertia(i);
+                PZ t1 = c.mulMV(I, wdot2);
+                PZ t2 = c.mulMV(I, wv2);
+                PZ cr = c.crossPzPz(waux2, t2); c.freeVs(t2);
+                PZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
+                c.post(MB_N + i, N);
+            }
         }
-        {   // lines 23 & 27: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
-            PZ c1 = c.crossPzMat(wdot, cm);
-            PZ c2 = c.crossPzMat(waux, cm);
-            PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
-            F[i] = c.mulSV(c.mass(i), s2); c.freeVs(s2);
-        }
-        {   // line 29: N = I * wdot + cross(w_aux, I * w)
-            const PZ I = c.inertia(i);
-            PZ t1 = c.mulMV(I, wdot);
-            PZ t2 = c.mulMV(I, wv);
-            PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
-            N[i] = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
-        }
+        c.bar();
     }
-    c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); c.freeVs(lacc);
-    PZ f = c.allocV(), nn = c.allocV();
-    set_const(w, f, nullptr, nullptr);
-    set_const(w, nn, nullptr, nullptr);
+    {
+        const PZ wv = c.take(MB_WV), wdot = c.take(MB_WDOT), waux = c.take(MB_WAUX), lacc = c.take(MB_LACC);
+        if (c.is(1)) { c.role = 1; c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }
+        if (c.is(0)) { c.role = 0; c.freeVs(lacc); }
+    }
+    if (c.is(2)) { c.role = 2; c.freeVs(fk.T); }
+    if (c.is(0)) { c.role = 0; PZ nn = c.allocV(); set_const(w, nn, nullptr, nullptr); c.post(MB_NN, nn); }
+    if (c.is(1)) { c.role = 1; PZ f = c.allocV(); set_const(w, f, nullptr, nullptr); c.post(MB_FF, f); }
+    c.bar();
     for (int i = J - 1; i >= 0; i--) {
         const PZ Rn = c.R(i + 1);
         // n = N + R*n + cross(com, F) + cross(trans_next, R*f);  f = R*f + F
-        PZ a1 = c.mulMV(Rn, nn);
-        PZ c1 = c.crossMatPz(&cf.rb.com[3 * i], F[i]);
-        PZ a2 = c.mulMV(Rn, f);
-        PZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
-        PZ n2 = c.sum4(N[i], a1, c1, c2); c.freeVs(a1); c.freeVs(N[i]); c.freeVs(c1); c.freeVs(c2); c.freeVs(nn);  // ((N + a1) + c1) + c2
-        nn = n2;
-        PZ f2 = c.add(a2, F[i]); c.freeVs(a2); c.freeVs(F[i]); c.freeVs(f);
-        f = f2;
-        if (cf.rb.axes[i] != 0) {
-            const int ax = abs(cf.rb.axes[i]) - 1;
-            u[i] = c.comb3(elem(w, nn, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i], view(w, c.qd(i)), cf.rb.damping[i]);
+        const PZ nn = c.take(MB_NN), f = c.take(MB_FF), Fi = c.take(MB_F + i), Ni = c.take(MB_N + i);
+        PZ a1 = nn, c1 = nn;  // role 0's temporaries of phase 1 (kept in its registers across the barrier)
+        if (c.is(0)) {
+            c.role = 0;
+            a1 = c.mulMV(Rn, nn);
+            c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
         }
+        if (c.is(1)) {
+            c.role = 1;
+            PZ a2 = c.mulMV(Rn, f);
+            PZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
+            c.post(MB_A2, a2); c.post(MB_C2, c2);
+        }
+        c.bar();
+        const PZ a2 = c.take(MB_A2), c2 = c.take(MB_C2);
+        if (c.is(0)) {
+            c.role = 0;
+            PZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
+            c.post(MB_NN, n2);
+            if (cf.rb.axes[i] != 0) {
+                const int ax = abs(cf.rb.axes[i]) - 1;
+                u[i] = c.comb3(elem(w, n2, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i], view(w, c.qd(i)), cf.rb.damping[i]);
+            }
+        }
+        if (c.is(1)) {
+            c.role = 1;
+            PZ f2 = c.add(a2, Fi); c.freeVs(f);
+            c.post(MB_FF, f2);
+        }
+        c.bar();
+        // what the other role was still reading in phase 2
+        if (c.is(1)) { c.freeVs(a2); c.freeVs(c2); c.freeVs(Ni); }
+        if (c.is(0)) { c.freeVs(Fi); }
     }
-    c.freeVs(f); c.freeVs(nn);
+    {
+        const PZ nn = c.take(MB_NN), f = c.take(MB_FF);
+        if (c.is(0)) c.freeVs(nn);
+        if (c.is(1)) c.freeVs(f);
+    }
+    c.bar();
 }
 
 // disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
@@ -677,7 +768,7 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
         if (w.lane == 0) { cf.tq_count[idx] = nk; cf.tq_center[idx] = p.cen[0]; cf.tq_indep[idx] = ind; }
         un_ind[j] = ind;
     }
-    __syncthreads();
+    WSYNC();
     // sqrt of the interval sum: Boost clamps a negative lower bound to 0; only .upper() is used (:185-188)
     const double rho_hi = up(sqrt(rho.hi));
     for (int j = 0; j < n; j++) {
@@ -687,22 +778,34 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
         v += cf.rb.friction[j];
         if (w.lane == 0) cf.torque_radius[((size_t)b * n + j) * T + t] = v;
     }
-    __syncthreads();
+    WSYNC();
 }
 
-__global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
+// One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
+// NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
+// LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
+__host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chain c;
     c.cf = &cf;
     c.n = cf.n; c.J = cf.J;
-    c.L = make_layout(cf.J, cf.n, cf.capW);
+    c.L = make_layout(cf.J, cf.n, cf.capW, NW);
     c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
+    c.nw = NW;
+    c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
-    c.w.skey = (LDS_AS uint64_t*)lds;
-    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
-    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
-    c.w.lstat = c.w.cnt + kMaxSlots;
-    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
+    LDS_AS unsigned char* mine = lds + (size_t)c.wid * p1_wave_lds(cf.capKey, cf.capRaw);
+    c.w.skey = (LDS_AS uint64_t*)mine;
+    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
+    c.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    LDS_AS unsigned char* shared = lds + (size_t)NW * p1_wave_lds(cf.capKey, cf.capRaw);
+    c.w.cnt = (LDS_AS int*)shared;
+    c.mb = c.w.cnt + kMaxSlots;
+    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
 #ifdef P1_PROFILE
     __shared__ unsigned long long prof_lds[PR_WORDS];
     c.w.prof = (LDS_AS unsigned long long*)prof_lds;
@@ -712,33 +815,31 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
     c.w.cap_raw = cf.capRaw;
     c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
-    c.w.lane = threadIdx.x;
-    if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
+    c.w.lane = threadIdx.x & 63;
+    if (c.w.lane < ST_WORDS) c.w.lstat[c.w.lane] = 0;
     for (int it = blockIdx.x; it < cf.n_items; it += gridDim.x) {
         const int item = cf.items ? cf.items[it] : it;
         const int b = item / cf.T, t = item - b * cf.T;
-        const int err_before = c.w.lstat[ST_ERR];
-        c.freeV = 0xffffffffu;
+        const int err_before = c.w.lstat[ST_ERR];  // (the retry list is only used with NW = 1)
+        c.freeV = (1ull << c.L.nV) - 1ull;
         c.freeS = (1u << kNS) - 1u;
-        for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
+        c.role = 0;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         __syncthreads();
 #ifdef P1_PROFILE
         const long long ph0 = clock64();
 #endif
         build_jrs(c, b, t);
+        __syncthreads();
 #ifdef P1_PROFILE
         const long long ph1 = clock64();
 #endif
-        run_fk(c, b, t);
-#ifdef P1_PROFILE
-        const long long ph2 = clock64();
-#endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
-        run_rnea(c, u_nom);
+        run_rnea(c, u_nom, b, t);
 #ifdef P1_PROFILE
         const long long ph3 = clock64();
 #endif
-        finish_torque(c, u_nom, b, t);
+        if (c.is(0)) finish_torque(c, u_nom, b, t);
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
             // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
@@ -751,7 +852,7 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
                    prof_lds[PR_CYC64], prof_lds[PR_SMALL], prof_lds[PR_CYC512], prof_lds[PR_N512], prof_lds[PR_TERMS512], prof_lds[PR_CYCBIG], prof_lds[PR_NBIG], prof_lds[PR_TERMSBIG],
                    prof_lds[PR_FILL], prof_lds[PR_SORT], prof_lds[PR_S_RANK], prof_lds[PR_S_BITONIC], prof_lds[PR_S_LINMERGE], prof_lds[PR_S_MULMERGE], prof_lds[PR_EMIT], prof_lds[PR_ABS]);
         if (threadIdx.x == 0 && blockIdx.x == 0)
-            printf("[P1 phases, wave 0] jrs %lld fk %lld rnea %lld torque %lld cycles\n", ph1 - ph0, ph2 - ph1, ph3 - ph2, (long long)clock64() - ph3);
+            printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
 #endif
     }
 #ifdef P1_PROFILE
@@ -761,7 +862,7 @@ __global__ __launch_bounds__(64) void armour_p1_chain_kernel(P1Cfg cf) {
         for (int i = 0; i < PR_WORDS; i++) dst[i] = prof_lds[i];
     }
 #endif
-    if (threadIdx.x == 0) {
+    if (c.w.lane == 0) {  // every wave reports its own flags and maxima
         if (c.w.lstat[ST_ERR]) atomicOr(&cf.status[ST_ERR], (unsigned)c.w.lstat[ST_ERR]);
         atomicMax(&cf.status[ST_MAX_RAW], (unsigned)c.w.lstat[ST_MAX_RAW]);
         atomicMax(&cf.status[ST_MAX_OUT], (unsigned)c.w.lstat[ST_MAX_OUT]);
@@ -852,19 +953,22 @@ __global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOp
     Chain c;
     c.cf = &cf;
     c.n = cf.n; c.J = cf.J;
-    c.L = make_layout(cf.J, cf.n, cf.capW);
+    c.L = make_layout(cf.J, cf.n, cf.capW, 1);
     c.arena = (GLB_AS unsigned char*)cf.arena;
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
+    c.nw = 1; c.wid = 0; c.role = 0;
     c.w.skey = (LDS_AS uint64_t*)lds;
     c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
-    c.w.cnt = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
-    c.w.lstat = c.w.cnt + kMaxSlots;
-    c.ci = (LDS_AS double*)(lds + (((size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15));
+    c.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    LDS_AS unsigned char* shared = lds + p1_wave_lds(cf.capKey, cf.capRaw);
+    c.w.cnt = (LDS_AS int*)shared;
+    c.mb = c.w.cnt + kMaxSlots;
+    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
     c.w.cap_raw = cf.capRaw; c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.lane = threadIdx.x;
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
-    c.freeV = 0xffffffffu; c.freeS = (1u << kNS) - 1u;
+    c.freeV = (1ull << c.L.nV) - 1ull; c.freeS = (1u << kNS) - 1u;
     for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
     __syncthreads();
     PZ in[3];
@@ -951,9 +1055,9 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     const int J = h->J, n = h->n;
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
-    const Layout L = make_layout(J, n, h->lim.work_monomials);
-    const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
-    const size_t smem = (((size_t)cap_raw * 8 + (size_t)cap_raw * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double);
+    const Layout L = make_layout(J, n, h->lim.work_monomials, 1);
+    const size_t ci_doubles = (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
+    const size_t smem = p1_wave_lds(cap_raw, cap_raw) + p1_shared_lds(ci_doubles);
     HIPCHK(hipFuncSetAttribute((const void*)armour_p1_pzop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     unsigned char* arena = nullptr;
     HIPCHK(hipMalloc((void**)&arena, L.total));
@@ -1020,20 +1124,27 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
     if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
-    const Layout L = make_layout(J, n, h->lim.work_monomials);
-    if (L.idJS + L.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
-    const size_t ci_doubles = (size_t)kNV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
-    auto lds_bytes = [&](int cap) { return (((size_t)cap * 8 + (size_t)cap * 2 + (kMaxSlots + ST_WORDS) * sizeof(int) + 15) & ~(size_t)15) + ci_doubles * sizeof(double); };
+    const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles);
+    if (L3.idJS + L3.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
+    auto ci_doubles = [&](const Layout& L) { return (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3; };
+    auto lds_bytes = [&](int cap, int nw = 1) { return (size_t)nw * p1_wave_lds(cap, cap) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : L3)); };
     auto waves_per_cu = [&](int cap) { return std::max(1, std::min(4, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };  // 4 = one wave per SIMD (the kernel needs > 256 registers)
     float total_ms = 0;
     unsigned st[ST_WORDS];
     // one launch of the chain kernel over `n_items` work items (d_items == nullptr: all of them) with sort buffers of `cap`
     // entries; with `collect` the items that overflow them are listed in wk->d_retry instead of failing the launch
     auto launch = [&](int cap, const int* d_items, int n_items, bool collect) -> int {
-        const size_t smem = lds_bytes(cap);
+        // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
+        // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
+        static const int nw_env = [] { const char* e = getenv("ARMOUR_P1_WAVES"); return e ? atoi(e) : 0; }();  // development override
+        const bool three = nw_env ? nw_env == 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
+        const int nw = three ? kRoles : 1;
+        const Layout& L = three ? L3 : L1;
+        const size_t smem = lds_bytes(cap, nw);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
-        HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const int per_cu = waves_per_cu(cap);
+        if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int per_cu = three ? 1 : waves_per_cu(cap);
         const int waves = std::min(n_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
@@ -1058,7 +1169,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
-        hipLaunchKernelGGL(armour_p1_chain_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
+        if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
+        else hipLaunchKernelGGL(armour_p1_chain_kernel<1>, dim3(waves), dim3(WAVE), smem, h->stream, cf);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -1076,7 +1188,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
-        if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1] %d items, cap_raw %d: %d waves (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+        if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
         return ARMOUR_OK;
     };
     auto other_errors = [&]() -> int {

@@ -21,6 +21,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Synchronisation INSIDE an operator is wave-local: every operator runs on one 64-lane wave, whose LDS and memory
+// operations execute in order, so draining the wave's outstanding loads / stores / LDS traffic is all that the lanes
+// need to see each other's data.  (With one wave per block this is what __syncthreads() amounted to; written this way
+// the operators can also run in blocks whose waves work on different operators at the same time.)
+#define WSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+
 namespace pzw {
 
 constexpr int WAVE = 64;
@@ -123,7 +129,7 @@ __device__ inline void bitonic_sort(const Wave& w, int P) {
                     if (t0 + u * WAVE < half && gt == up) { w.skey[ii[u]] = kb[u]; w.skey[ll[u]] = ka[u]; w.sidx[ii[u]] = ib[u]; w.sidx[ll[u]] = ia[u]; }
                 }
             }
-            __syncthreads();
+            WSYNC();
         }
     }
 }
@@ -171,7 +177,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
                 rank += (kl < key || (kl == key && l < w.lane)) ? 1 : 0;
             }
             if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
-            __syncthreads();
+            WSYNC();
             PROF_ADD(PR_SORT) PROF_ADD(PR_S_RANK)
         } else if (ev.try_merge(w, N)) {
             // the operands' sorted runs were merged by ranking: sidx holds the permutation, keys come from LDS staging
@@ -193,7 +199,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
                 w.skey[p] = p < N ? ev.key(p) : ~0ull;
                 w.sidx[p] = (uint16_t)p;
             }
-            __syncthreads();
+            WSYNC();
             PROF_ADD(PR_FILL) }
             { PROF_T0
             bitonic_sort(w, P);
@@ -267,7 +273,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -304,7 +310,7 @@ struct LinEval {
 #endif
         PROF_T0
         for (int idx = w.lane; idx < N; idx += WAVE) w.skey[idx] = key(idx);
-        __syncthreads();
+        WSYNC();
         for (int idx = w.lane; idx < N; idx += WAVE) {
             const int k = seg_of(idx);
             const uint64_t ky = w.skey[idx];
@@ -318,7 +324,7 @@ struct LinEval {
             }
             w.sidx[rank] = (uint16_t)idx;
         }
-        __syncthreads();
+        WSYNC();
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_LINMERGE)
         return true;
     }
@@ -369,7 +375,7 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
         }
     }
     ev.off[NS] = N;
-    __syncthreads();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
+    WSYNC();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
     if (w.lane == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
@@ -416,7 +422,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
     }
     ev.off[NS] = N;
     [[maybe_unused]] const int N_in = N;
-    __syncthreads();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
+    WSYNC();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
     if (w.lane == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
@@ -503,7 +509,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    __syncthreads();
+    WSYNC();
     PROF_CALL_END(N_in)
 }
 
@@ -568,7 +574,7 @@ struct MulEval {
         const GLB_AS uint64_t* sk = a_short ? a.keys : b.keys;
         for (int t = w.lane; t < nl; t += WAVE) w.skey[t] = t ? lk[t - 1] : 0ull;
         if (w.lane < ns) w.skey[nl + w.lane] = w.lane ? sk[w.lane - 1] : 0ull;
-        __syncthreads();
+        WSYNC();
         const LDS_AS uint64_t* L = w.skey;
         const LDS_AS uint64_t* S = w.skey + nl;
         for (int idx = w.lane; idx < N; idx += WAVE) {
@@ -584,7 +590,7 @@ struct MulEval {
             }
             w.sidx[rank] = (uint16_t)idx;
         }
-        __syncthreads();
+        WSYNC();
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
         return true;
     }
@@ -662,7 +668,7 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
     SH::mul(ia2, ib2, ii);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) base2[e] = ii[e] + (t2[e] + t3[e]);
-    __syncthreads();
+    WSYNC();
     if (w.lane == 0) {
 #pragma unroll
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
@@ -728,7 +734,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
             base2P[e] = ia2 * ib2 + (r2[i] * ib2 + ia2 * r3[j]);
         }
     }
-    __syncthreads();
+    WSYNC();
     int emitted = 0;
     bool any_pruned = false, indirect = false;
     double raP[6] = {0, 0, 0, 0, 0, 0}, raR[3] = {0, 0, 0}, raS[3] = {0, 0, 0};
@@ -817,7 +823,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    __syncthreads();
+    WSYNC();
     PROF_CALL_END(N_in)
 }
 
@@ -873,14 +879,14 @@ __device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, 
     if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
     if (__ballot(any1) != 0ull) { ra1[0] = wave_sum(ra1[0]); ra1[1] = wave_sum(ra1[1]); ra1[2] = wave_sum(ra1[2]); }
     if (__ballot(any2) != 0ull) { ra2[0] = wave_sum(ra2[0]); ra2[1] = wave_sum(ra2[1]); ra2[2] = wave_sum(ra2[2]); }
-    __syncthreads();
+    WSYNC();
     if (w.lane == 0) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { out.cen[c] = cen[c]; out.ind[c] = (ind[c] + ra1[c]) + ra2[c]; out.ind2[c] = (ind2[c] + ra1[c]) + ra2[c]; }
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066); keys unchanged, no simplify.
@@ -898,7 +904,7 @@ __device__ PZW_NOINLINE void transpose33(Wave& w, const PZ& out, const PZ& a) {
         out.ind2[c * 3 + r] = a.ind2[w.lane];
     }
     if (w.lane == 0) w.cnt[out.id] = n;
-    __syncthreads();
+    WSYNC();
 }
 
 // constant PZ (centre + independent radius, no monomials): RT/PZsparse.cu:66-98
@@ -910,7 +916,7 @@ __device__ PZW_NOINLINE void set_const(Wave& w, const PZ& out, const double* cen
         out.ind2[w.lane] = ind2 ? ind2[w.lane] : (ind ? ind[w.lane] : 0.0);
     }
     if (w.lane == 0) w.cnt[out.id] = 0;
-    __syncthreads();
+    WSYNC();
 }
 
 // plain copy (operator=)
@@ -920,7 +926,7 @@ __device__ inline void copy(Wave& w, const PZ& out, const PZ& a) {
     for (int m = w.lane; m < n; m += WAVE) out.keys[m] = a.keys[m];
     if (w.lane < sz) { out.cen[w.lane] = a.cen[w.lane]; out.ind[w.lane] = a.ind[w.lane]; out.ind2[w.lane] = a.ind2[w.lane]; }
     if (w.lane == 0) w.cnt[out.id] = n;
-    __syncthreads();
+    WSYNC();
 }
 
 }  // namespace pzw
