@@ -35,7 +35,7 @@ constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work
 // The 3x1 pool is split between the roles of a block (see run_rnea): each role allocates and frees only in its own part,
 // so three waves can run different operators at the same time without sharing allocator state.
 constexpr int kRoles = 3;
-constexpr int kPartFirst[kRoles] = {0, 20, 40}, kPartCount[kRoles] = {20, 20, 8};  // of the 48 slots of a 3-wave block
+constexpr int kPartFirst[kRoles] = {0, 10, 24}, kPartCount[kRoles] = {10, 14, 24};  // of the 48 slots of a 3-wave block
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
 constexpr int kMaxSlots = 192;
@@ -277,7 +277,12 @@ struct Chain {
     LDS_AS int* mb;            // LDS mailbox: slot indices handed from one role to another across a block barrier
     // role r runs on wave r of a 3-wave block, every role on the one wave of a 1-wave block
     __device__ bool is(int role) const { return nw == 1 || wid == role; }
+#ifdef P1_PROFILE
+    mutable long long bar_wait = 0;
+    __device__ void bar() const { const long long t0 = clock64(); __syncthreads(); bar_wait += clock64() - t0; }
+#else
     __device__ void bar() const { __syncthreads(); }  // all waves of the block: the only cross-wave synchronisation
+#endif
     __device__ void post(int slot, const PZ& p) const { if (w.lane == 0) mb[slot] = p.id - L.idV; }
     __device__ PZ take(int slot) const { return V(mb[slot]); }
 
@@ -584,8 +589,8 @@ __device__ PZW_NOINLINE void fk_step(Chain& c, FkState& f, int i, int b, int t) 
 // Work of one time step is dealt to three ROLES.  In a 3-wave block role r is wave r and the roles run concurrently; in a
 // 1-wave block the one wave plays all three in turn.  Every operator is executed by exactly one wave with the same
 // operands either way, so the results do not depend on the block shape.
-//   forward, joint i   phase 1:  role 0  linear_acc_i            role 1  w_i, w_aux_i, wdot_i        role 2  FK of joint i
-//                      phase 2:  role 0  F_i                     role 1  N_i
+//   forward, step s = 0..J:   role 0  linear_acc_s     role 1  w_s, w_aux_s, wdot_s     role 2  F_{s-1}, N_{s-1}, FK of joint s
+//   (F and N of a joint only feed the backward pass, so they trail the state recursion by one step: one barrier per joint)
 //   backward, joint i  phase 1:  role 0  R n, com x F_i          role 1  R f, p x (R f)
 //                      phase 2:  role 0  n_i, u_i                role 1  f_i
 // A role allocates and frees only in its own part of the slot pool; what another role still reads is freed by its owner
@@ -613,68 +618,63 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
         c.post(MB_LACC, lacc);
     }
     c.bar();
-    for (int i = 0; i < J; i++) {
-        const double* tr = &cf.rb.trans[3 * i];
-        const double* cm = &cf.rb.com[3 * i];
-        const PZ Rt = c.Rt(i);
-        const int ax = abs(cf.rb.axes[i]) - 1;
-        // state of the previous joint (read-only in phase 1)
+    for (int s = 0; s <= J; s++) {
+        // state and linear acceleration of joint s-1 (read-only during this step)
         const PZ wv = c.take(MB_WV), wdot = c.take(MB_WDOT), waux = c.take(MB_WAUX), lacc = c.take(MB_LACC);
-        c.bar();  // everyone has taken the handles before phase 1 posts the new ones
-        if (c.is(0)) {  // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+        c.bar();  // everyone has taken the handles before this step posts the new ones
+        if (c.is(0)) {
             c.role = 0;
-            PZ c1 = c.crossPzMat(wdot, tr);
-            PZ c2 = c.crossPzMat(waux, tr);
-            PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3); c.freeVs(lacc);  // (linear_acc + c1) + c3
-            PZ nl = c.mulMV(Rt, s2); c.freeVs(s2);
-            c.post(MB_LACC, nl);
+            if (s < J) {  // line 16: linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+                const double* tr = &cf.rb.trans[3 * s];
+                PZ c1 = c.crossPzMat(wdot, tr);
+                PZ c2 = c.crossPzMat(waux, tr);
+                PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);  // (linear_acc + c1) + c3
+                PZ nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
+                c.post(MB_LACC, nl);
+            }
         }
-        if (c.is(1)) {  // lines 13-15: rotate w, w_aux, wdot into the joint frame, add the joint's own motion
+        if (c.is(1) && s < J) {  // lines 13-15: rotate w, w_aux, wdot into the joint frame, add the joint's own motion
             c.role = 1;
+            const PZ Rt = c.Rt(s);
+            const int ax = abs(cf.rb.axes[s]) - 1;
             PZ nw = c.mulMV(Rt, wv);
-            if (cf.rb.axes[i] != 0) { PZ t2 = c.addOneDim(nw, c.qd(i), ax); c.freeVs(nw); nw = t2; }
+            if (cf.rb.axes[s] != 0) { PZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
             PZ na = c.mulMV(Rt, waux);
             PZ nd = c.mulMV(Rt, wdot);
-            if (cf.rb.axes[i] != 0) {
+            if (cf.rb.axes[s] != 0) {
                 PZ zero = c.allocV();
                 set_const(w, zero, nullptr, nullptr);
-                PZ temp = c.addOneDim(zero, c.qd(i), ax); c.freeVs(zero);
+                PZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
                 PZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
-                PZ nd2 = c.sum3(nd, c4, c.qdda(i), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;  // (wdot + c4), then + qdda on the axis
-                PZ na2 = c.addOneDim(na, c.qda(i), ax); c.freeVs(na); na = na2;
+                PZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;  // (wdot + c4), then + qdda on the axis
+                PZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
             }
             c.post(MB_WV, nw); c.post(MB_WDOT, nd); c.post(MB_WAUX, na);
         }
-        if (c.is(2)) { c.role = 2; fk_step(c, fk, i, b, t); }
-        c.bar();
-        if (c.is(1)) { c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }  // the previous joint's state: role 0 has finished reading it
-        {
-            const PZ wv2 = c.take(MB_WV), wdot2 = c.take(MB_WDOT), waux2 = c.take(MB_WAUX), lacc2 = c.take(MB_LACC);
-            if (c.is(0)) {  // lines 23 & 27: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
-                c.role = 0;
-                PZ c1 = c.crossPzMat(wdot2, cm);
-                PZ c2 = c.crossPzMat(waux2, cm);
-                PZ c3 = c.crossPzPz(wv2, c2); c.freeVs(c2);
-                PZ s2 = c.sum3(lacc2, c1, c3); c.freeVs(c1); c.freeVs(c3);
-                PZ F = c.mulSV(c.mass(i), s2); c.freeVs(s2);
-                c.post(MB_F + i, F);
+        if (c.is(2)) {
+            c.role = 2;
+            if (s >= 1) {  // lines 23 & 27 for joint s-1: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
+                const double* cm = &cf.rb.com[3 * (s - 1)];
+                PZ c1 = c.crossPzMat(wdot, cm);
+                PZ c2 = c.crossPzMat(waux, cm);
+                PZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                PZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
+                PZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
+                c.post(MB_F + s - 1, F);
             }
-            if (c.is(1)) {  // line 29: N = I * wdot + cross(w_aux, I * w)
-                c.role = 1;
-                const PZ I = c.inertia(i);
-                PZ t1 = c.mulMV(I, wdot2);
-                PZ t2 = c.mulMV(I, wv2);
-                PZ cr = c.crossPzPz(waux2, t2); c.freeVs(t2);
+            if (s >= 1) {  // line 29 for joint s-1: N = I * wdot + cross(w_aux, I * w)
+                const PZ I = c.inertia(s - 1);
+                PZ t1 = c.mulMV(I, wdot);
+                PZ t2 = c.mulMV(I, wv);
+                PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
                 PZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
-                c.post(MB_N + i, N);
+                c.post(MB_N + s - 1, N);
             }
+            if (s < J) fk_step(c, fk, s, b, t);
         }
         c.bar();
-    }
-    {
-        const PZ wv = c.take(MB_WV), wdot = c.take(MB_WDOT), waux = c.take(MB_WAUX), lacc = c.take(MB_LACC);
-        if (c.is(1)) { c.role = 1; c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }
+        if (c.is(1)) { c.role = 1; c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }  // joint s-1's state: every reader is done
         if (c.is(0)) { c.role = 0; c.freeVs(lacc); }
     }
     if (c.is(2)) { c.role = 2; c.freeVs(fk.T); }
@@ -715,8 +715,8 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
         }
         c.bar();
         // what the other role was still reading in phase 2
-        if (c.is(1)) { c.freeVs(a2); c.freeVs(c2); c.freeVs(Ni); }
-        if (c.is(0)) { c.freeVs(Fi); }
+        if (c.is(1)) { c.freeVs(a2); c.freeVs(c2); }
+        if (c.is(2)) { c.freeVs(Ni); c.freeVs(Fi); }
     }
     {
         const PZ nn = c.take(MB_NN), f = c.take(MB_FF);
@@ -851,6 +851,8 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
             printf("[t=%d] total %lld: N<=64 %llu (%llu calls), mid %llu (%llu calls, %llu terms), big %llu (%llu calls, %llu terms) | fill %llu sort %llu (rank %llu bitonic %llu linmerge %llu mulmerge %llu) emit %llu abs %llu\n", t, (long long)clock64() - ph0,
                    prof_lds[PR_CYC64], prof_lds[PR_SMALL], prof_lds[PR_CYC512], prof_lds[PR_N512], prof_lds[PR_TERMS512], prof_lds[PR_CYCBIG], prof_lds[PR_NBIG], prof_lds[PR_TERMSBIG],
                    prof_lds[PR_FILL], prof_lds[PR_SORT], prof_lds[PR_S_RANK], prof_lds[PR_S_BITONIC], prof_lds[PR_S_LINMERGE], prof_lds[PR_S_MULMERGE], prof_lds[PR_EMIT], prof_lds[PR_ABS]);
+        if (c.w.lane == 0 && (t == 60 || t == 0)) printf("[t=%d wave %d] waited %lld cycles at role barriers of %lld\n", t, c.wid, c.bar_wait, (long long)clock64() - ph0);
+        c.bar_wait = 0;
         if (threadIdx.x == 0 && blockIdx.x == 0)
             printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
 #endif
