@@ -878,59 +878,80 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
 // strict-> scan of :268-279 has already seen (d and delta follow the normal exactly), so skipping it changes
 // neither the maximum nor the winning normal.  The AND over all rows of a problem goes to plane_skip[b]; with
 // axis-aligned box obstacles that is 12 of the 36 planes (all obstacle x error-generator and error x error pairs).
-__global__ void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
-                                        const double* __restrict__ obstacles, double* __restrict__ planes,
-                                        double* __restrict__ planes_ll, double* __restrict__ obs_center, unsigned long long* __restrict__ plane_skip) {
+// Four threads per row (wave w of the 256-thread block builds planes 9w .. 9w+8 of the block's 64 rows); the normals
+// go through LDS so that each thread can test its planes against all earlier planes of its row.
+__global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
+                                                               const double* __restrict__ obstacles, double* __restrict__ planes,
+                                                               double* __restrict__ planes_ll, double* __restrict__ obs_center,
+                                                               unsigned long long* __restrict__ plane_skip) {
+    __shared__ double Cs[ARMOUR_NPLANES][3][64];  // [plane][axis][row of the block]: conflict-free across a wave
     const int Q = J * T * O;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    unsigned long long skip = ~0ull;
-    if (q < Q) {
-        const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
-        const double* ob = obstacles + ((size_t)b * O + o) * 12;
-        const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
-        double G[9][3], c[3], Cs[36][3];
-        for (int ax = 0; ax < 3; ax++) {
-            c[ax] = ob[ax];
-            for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
-            for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
-        }
-        double* out = planes + (size_t)b * armour_planes_per_problem(Q);
-        if (lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
-        int p = 0;
-        skip = 0ull;
-        for (int a_id = 0; a_id < 8; a_id++)
-            for (int b_id = a_id + 1; b_id < 9; b_id++, p++) {  // pair order of RT/CollisionChecking.cu:26-39
-                const double* ga = G[a_id];
-                const double* gb = G[b_id];
-                const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
-                const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
-                double C0 = 0, C1 = 0, C2 = 0;
-                if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
-                double dl = 0.0;
-                for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
-                out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
-                out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
-                out[armour_plane_index(Q, q, p, 4)] = dl;
-                if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
-                    double* ll = planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T);
-                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
-                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
-                    ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
-                }
-                Cs[p][0] = C0; Cs[p][1] = C1; Cs[p][2] = C2;
-                bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
-                for (int e = 0; e < p && !red; e++)
-                    red = (Cs[e][0] == C0 && Cs[e][1] == C1 && Cs[e][2] == C2) || (Cs[e][0] == -C0 && Cs[e][1] == -C1 && Cs[e][2] == -C2);
-                if (red) skip |= 1ull << p;
-            }
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const bool in = q < Q;
+    const int qc = in ? q : Q - 1;
+    const int o = qc % O, lt = qc / O, l = lt / T, t = lt - l * T;
+    const double* ob = obstacles + ((size_t)b * O + o) * 12;
+    const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+    double G[9][3], c[3];
+    for (int ax = 0; ax < 3; ax++) {
+        c[ax] = ob[ax];
+        for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
+        for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
     }
-    // AND over the wave, then one atomic per wave
+    double* out = planes + (size_t)b * armour_planes_per_problem(Q);
+    if (in && grp == 0 && lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
+    // pair order of RT/CollisionChecking.cu:26-39: p enumerates (a_id < b_id) row by row; this thread's first pair
+    int a_id = 0, b_id = 1;
+    for (int s = 0; s < grp * 9; s++) { if (++b_id == 9) { a_id++; b_id = a_id + 1; } }
+    for (int k = 0; k < 9; k++) {
+        const int p = grp * 9 + k;
+        const double* ga = G[a_id];
+        const double* gb = G[b_id];
+        const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
+        const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
+        double C0 = 0, C1 = 0, C2 = 0;
+        if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
+        double dl = 0.0;
+        for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
+        if (in) {
+            out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
+            out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+            out[armour_plane_index(Q, q, p, 4)] = dl;
+            if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
+                double* ll = planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T);
+                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
+                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
+                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
+            }
+        }
+        Cs[p][0][lane] = C0; Cs[p][1][lane] = C1; Cs[p][2][lane] = C2;
+        if (++b_id == 9) { a_id++; b_id = a_id + 1; }
+    }
+    __syncthreads();
+    // redundancy of this thread's planes: zero normal, or bit-for-bit +- the normal of an earlier plane of the row
+    unsigned long long skip = in ? 0ull : ~0ull;
+    if (in) {
+        for (int k = 0; k < 9; k++) {
+            const int p = grp * 9 + k;
+            const double C0 = Cs[p][0][lane], C1 = Cs[p][1][lane], C2 = Cs[p][2][lane];
+            bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
+            for (int e2 = 0; e2 < p && !red; e2++) {
+                const double E0 = Cs[e2][0][lane], E1 = Cs[e2][1][lane], E2 = Cs[e2][2][lane];
+                red = (E0 == C0 && E1 == C1 && E2 == C2) || (E0 == -C0 && E1 == -C1 && E2 == -C2);
+            }
+            if (red) skip |= 1ull << p;
+        }
+        // planes of the other three groups: not this thread's to clear
+        skip |= ~(((1ull << 9) - 1ull) << (grp * 9));
+    }
+    // AND over the wave, then one atomic per wave (each wave owns 9 of the 36 bits; the other bits are all ones)
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         const unsigned lo = __shfl_xor((unsigned)skip, o2, 64), hi = __shfl_xor((unsigned)(skip >> 32), o2, 64);
         skip &= ((unsigned long long)hi << 32) | lo;
     }
-    if ((threadIdx.x & 63) == 0) atomicAnd(&plane_skip[b], skip);
+    if (lane == 0) atomicAnd(&plane_skip[b], skip);
 }
 
 
@@ -1230,7 +1251,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int Q = J * T * O;
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
         HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 255) / 256, B), dim3(256), 0, h->stream, B, T, J, O,
+        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 63) / 64, B), dim3(256), 0, h->stream, B, T, J, O,
                            wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, h->d_plane_skip);
         h->ll_shared = 1; h->d_from_center = 1;
         HIPCHK(hipGetLastError());
