@@ -13,7 +13,8 @@
 //         N* = (N'G^-1N)^-1 N'G^-1 are re-formed from the <= n active normals at every step instead of being
 //         updated by Givens rotations.
 //
-// Host code only: the arithmetic of the hot path (eval_g / eval_jac_g) stays in p2_eval.hip.
+// g and jac stay on the device: after each evaluation armour_solve_scan_kernel (below) hands the host the L1 violation,
+// the rows the QP can see and, at the end, finalize_solution's verdict.  The 7-variable QPs run on the host.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -269,15 +270,6 @@ __global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, in
         base = bad_tot;
     }
     if (tid == 0) { viol_out[(size_t)b * nseg + seg] = red[0]; if (MODE != 0) count_out[(size_t)b * nseg + seg] = base; }
-}
-
-double violation(const double* g, const double* lo, const double* hi, int m) {
-    double v = 0;
-    for (int i = 0; i < m; i++) {
-        if (g[i] > hi[i]) v += g[i] - hi[i];
-        else if (g[i] < lo[i]) v += lo[i] - g[i];
-    }
-    return v;
 }
 
 }  // namespace
