@@ -24,6 +24,7 @@
 // order, sums in monomial order), so with identical tables the outputs agree with the oracle to the ulp of
 // pow() vs. repeated multiplication; FMA contraction is disabled for this file (see Makefile).
 #include <algorithm>
+#include <cstdlib>
 
 #include "bezier.h"
 #include "common.h"
@@ -62,6 +63,14 @@ __device__ inline void fill_kpow(KPow& kp, double x, int n) {
         kp.pw[j][0] = 1.0; kp.pw[j][1] = x; kp.pw[j][2] = x * x; kp.pw[j][3] = x * x * x;
         kp.df[j][0] = 0.0; kp.df[j][1] = 1.0; kp.df[j][2] = 2.0 * x; kp.df[j][3] = 3.0 * (x * x);
     }
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
+// for the plane loads a wave has in flight; the EX kernels keep those in flight across the slicing barriers.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // value of coeff * prod_j k_j^{d_j}, multiplying in factor order (RT/PZsparse.cu:416-418).  The 7 table reads are
@@ -177,7 +186,40 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
 // LL: the link x link normals come from the compact tb.planes_ll (tables whose normals are obstacle-independent)
 // PPW: plane slots per wave.  With axis-aligned box obstacles 12 of the 36 planes are skipped (armour_p1_planes_kernel), so a
 // wave holds at most 6: the 6-slot instantiation drops a third of the slot loops (loads, d recomputation, scan, pick).
-template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW>
+// The same registers through UNCONDITIONAL loads with clamped indices (threads without a task re-read task 0's entry) and no
+// select on a loaded value (the compiler would sink the load into the branch): a fixed number of loads, so that loads issued
+// after them can stay in flight while these are waited for (vmcnt counts in order and takes an immediate).
+__device__ inline void load_pass_uncond(const P2Tables& tb, const P2Launch& lp, int b, int lt_first, int pc, PassRegs& pr) {
+    const int tid = threadIdx.x;
+    const int per_pair = lp.strideL * 24, per_pair3 = lp.strideL * 3;
+    const int ntask = pc * per_pair3;
+    const size_t idx0 = (size_t)b * tb.J * tb.T + lt_first;
+#pragma unroll
+    for (int r = 0; r < P2_TASK_ROUNDS; r++) {
+        const int task = tid + r * P2_BLOCK;
+        const bool valid = task < ntask;
+        const int tk = valid ? task : 0;
+        const int pi = tk / per_pair3, rem = tk - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
+        const size_t idx = idx0 + pi;
+        const int moc = min(mo, tb.capL - 1);
+        const int cnt = tb.link_count[idx];
+        pr.tkey[r] = tb.link_keys[idx * tb.capL + moc];
+        pr.tco[r] = tb.link_coeff[(idx * tb.capL + moc) * 3 + e];
+        pr.tcnt[r] = cnt - (valid ? mo : (1 << 20));  // > 0: live monomial (cnt <= capL, so a clamped mo is never live)
+        pr.tdst[r] = pi * per_pair + mo * 24 + e;
+    }
+    const int tc = tid < pc * 24 ? tid : 0;
+    const int pi = tc / 24, c = tc - pi * 24, e = c % 3;
+    const size_t idx = idx0 + pi;
+    pr.rc_cnt = min(tb.link_count[idx], lp.strideL);  // used by threads < pc*24 only
+    pr.rc_cen = tb.link_center[idx * 3 + e];            // used for the value column (c < 3) only
+    pr.rc_ind = tb.link_indep[idx * 3 + e];
+}
+
+// EX: every wave holds exactly PPW live planes and the block slices in one pass: the PZ-table loads are issued first and
+// the plane loads, a fixed number, after them, so the slicing (waiting for the tables with vmcnt(#plane loads)) runs while
+// the planes are still in flight; the barriers before the scan wait for LDS traffic only.
+template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW, bool EX>
 __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE(DFC, MULTI)))) void armour_p2_eval_kernel(P2Tables tb, const double* __restrict__ k_all,
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
@@ -237,10 +279,11 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         const int npairs = (q_end - 1) / O - lt_first + 1;
         const bool single_pass = npairs <= lp.pair_chunk;
         PassRegs pr;
+        if (EX) load_pass_uncond(tb, lp, b, lt_first, npairs, pr);
 #pragma unroll
         for (int i = 0; i < PPW; i++) {
             a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
-            if (i < my_cnt) {
+            if (EX || i < my_cnt) {
                 const int pidx = __builtin_ctzll(live);
                 const size_t o = (size_t)pidx * Q;
                 live &= live - 1ull;
@@ -284,8 +327,8 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
             double* jac = WANT_J ? jac0 + (size_t)s * lp.j_stride : nullptr;
             for (int p0 = 0; p0 < npairs; p0 += lp.pair_chunk) {
                 const int pc = min(lp.pair_chunk, npairs - p0);
-                if (!MULTI || !single_pass) load_pass(tb, lp, b, lt_first, p0, pc, pr);
-                __syncthreads();  // k-power table ready / previous pass or point done with `terms`
+                if (!EX && (!MULTI || !single_pass)) load_pass(tb, lp, b, lt_first, p0, pc, pr);
+                if (EX) lds_barrier(); else __syncthreads();  // k-power table ready / previous pass or point done with `terms`
                 P2_STAMP(2);
 #pragma unroll
                 for (int r = 0; r < P2_TASK_ROUNDS; r++) {
@@ -300,19 +343,19 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                         }
                     }
                 }
-                __syncthreads();
+                if (EX) lds_barrier(); else __syncthreads();
                 P2_STAMP(3);
                 // ordered sum over monomials (the reference's accumulation order, RT/PZsparse.cu:420,470-472)
                 if (tid < pc * 24) {
                     const int pi = tid / 24, c = tid - pi * 24, out = c / 3, e2 = c - out * 3;
-                    double acc = pr.rc_cen;
+                    double acc = (!EX || out == 0) ? pr.rc_cen : 0.0;  // (the unconditional loader fills rc_cen for every column)
                     const double* tp = terms + (size_t)pi * per_pair + c;
 #pragma unroll 4
                     for (int mo = 0; mo < pr.rc_cnt; mo++) acc += tp[mo * 24];
                     if (out == 0) acc = interval_center(acc, pr.rc_ind);
                     sx[(p0 + pi) * 24 + (out == 0 ? e2 : 3 + (out - 1) * 3 + e2)] = acc;
                 }
-                __syncthreads();
+                if (EX) lds_barrier(); else __syncthreads();
             }
             P2_STAMP(4);
             // 3. this wave's planes in the reference's scan order (pos_p before neg_p, strict >), branch-free: `best` is
@@ -572,13 +615,19 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     // every problem of the launch has at most 24 live planes (6 per wave): use the 6-slot kernels
     bool six = h_skip != nullptr;
     for (int b = 0; six && b < tb.B; b++) six = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) <= 24;
+    // ... exactly 24 (6 per wave) and the blocks slice in one pass: the EX kernels (development switch ARMOUR_P2_EX=0 turns them off)
+    static const bool ex_on = [] { const char* e = getenv("ARMOUR_P2_EX"); return !e || atoi(e) != 0; }();
+    bool exact = six && ex_on && lp.max_pairs <= lp.pair_chunk;
+    for (int b = 0; exact && b < tb.B; b++) exact = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) == 24;
 #define P2_LAUNCH_M(G, J, M)                                                                                                                      \
     do {                                                                                                                                          \
-        if (dfc && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 6>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);                \
-        else if (dfc) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);              \
-        else if (tb.ll_shared && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 6>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
-        else if (tb.ll_shared) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
-        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, false, 9>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);             \
+        if (dfc && exact && !(M)) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false, true, true, 6, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);      \
+        else if (dfc && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 6, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);                \
+        else if (dfc) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, true, true, 9, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);              \
+        else if (tb.ll_shared && exact && !(M)) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false, false, true, 6, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else if (tb.ll_shared && six) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 6, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else if (tb.ll_shared) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, true, 9, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp); \
+        else hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, M, false, false, 9, false>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);             \
     } while (0)
 #define P2_LAUNCH(G, J)                                                                                                     \
     do {                                                                                                                    \
