@@ -639,6 +639,66 @@ __device__ inline void abs_sum(const Wave& w, const View& v, double* r) {
     for (int e = 0; e < SZ; e++) r[e] = fabs(v.cen[v.off + e]) + wave_sum(r[e]);
 }
 
+// The N raw terms of `ev` already come in key order with unique keys (a product whose left operand has no monomials:
+// mass, inertia and the fixed rpy rotation times a PZ -- term m is `centre_a * coef_b[m]` under b's m-th key): the pass of
+// sort_reduce_emit without the sort and without runs.  Same lane-to-term assignment, so the results are identical.
+template <int SZ, class Eval>
+__device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
+    int emitted = 0;
+    bool any_pruned = false;
+    double ra[SZ];
+#pragma unroll
+    for (int e = 0; e < SZ; e++) ra[e] = 0.0;
+    if (w.lane == 0 && N > w.lstat[ST_MAX_RAW]) w.lstat[ST_MAX_RAW] = N;
+#ifdef P1_PROFILE
+    if (w.lane == 0) { w.prof[PR_CALLS] += 1; w.prof[PR_TERMS] += N; if (N <= 64) w.prof[PR_SMALL] += 1; }
+#endif
+    PROF_T0
+    for (int base = 0; base < N; base += WAVE) {
+        const int p = base + w.lane;
+        bool keep = false, pruned = false;
+        uint64_t key = 0;
+        double acc[SZ];
+        if (p < N) {
+            key = ev.key(p);
+            ev.coef(p, acc);
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+            keep = !(sqrt(s) <= w.thr);
+            if (!keep) {
+#pragma unroll
+                for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
+                pruned = true;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        any_pruned = any_pruned || (__ballot(pruned) != 0ull);
+        if (keep) {
+            const int pos = emitted + __popcll(m & ((1ull << w.lane) - 1ull));
+            if (pos < out.cap) {
+                out.keys[pos] = key;
+#pragma unroll
+                for (int e = 0; e < SZ; e++) out.coef[(size_t)pos * SZ + e] = acc[e];
+            }
+        }
+        emitted += __popcll(m);
+    }
+    PROF_ADD(PR_EMIT)
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (any_pruned) {
+#pragma unroll
+        for (int e = 0; e < SZ; e++) ra[e] = wave_sum(ra[e]);
+    }
+    if (w.lane == 0) {
+#pragma unroll
+        for (int e = 0; e < SZ; e++) { out.ind[e] = base_ind[e] + ra[e]; out.ind2[e] = base_ind2[e] + ra[e]; }
+        w.cnt[out.id] = emitted;
+        if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
+    }
+    WSYNC();
+}
+
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
     PROF_CALL_T0
@@ -673,7 +733,8 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
 #pragma unroll
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
-    sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
+    if (a.cnt == 0) emit_presorted<SH::SZ>(w, N, ev, out, base, base2);  // constant left operand: b's keys, in b's order
+    else sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
     PROF_CALL_END(N)
 }
 
