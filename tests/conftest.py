@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The CPU oracle parallelises over time steps with OpenMP.  On a shared many-core host, "all cores" threads spinning at
+# barriers next to other tenants made single tests take minutes: the tests cap it (bench.py's cpu_baseline does not).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
