@@ -326,7 +326,8 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const std::vector<double>&gl = h->h_gl, &gu = h->h_gu;
     const int nseg = (m + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
     // rows a segment may hand back (its slice of the page-locked buffer): everything if the batch is small
-    const int cap_rows = (int)std::max<size_t>(64, std::min<size_t>(2 * kScanRowsPerBlock, ((size_t)128 << 20) / ((size_t)B * nseg * sizeof(SolveRow))));
+    int cap_rows = (int)std::max<size_t>(64, std::min<size_t>(2 * kScanRowsPerBlock, ((size_t)128 << 20) / ((size_t)B * nseg * sizeof(SolveRow))));
+    if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) cap_rows = std::max(1, atoi(e));  // development / tests: force the overflow fallback
     double* hviol_seg = armour_handle_pinned(h, 3, (size_t)B * nseg * sizeof(double));
     int* hcount = reinterpret_cast<int*>(armour_handle_pinned(h, 4, (size_t)B * nseg * sizeof(int)));
     SolveRow* hrows = reinterpret_cast<SolveRow*>(armour_handle_pinned(h, 5, (size_t)B * nseg * cap_rows * sizeof(SolveRow)));

@@ -90,6 +90,21 @@ def test_device_verdict_and_violation_equal_the_host_ones(seed, O, T):
         assert abs(sols[b]["max_violation"] - v) <= 1e-9 * max(1.0, v)
 
 
+def test_row_buffer_overflow_falls_back_to_whole_linearisation(monkeypatch):
+    """If a scan segment has more candidate rows than its slice of the row buffer holds, armour_solve copies that
+    linearisation over whole and selects the rows on the host as it used to: same iterates, same answer."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    T, O, B = 20, 4, 3
+    bp = random_batch(30, B, O)
+    ref = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
+    monkeypatch.setenv("ARMOUR_SOLVE_ROW_CAP", "2")
+    small = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
+    for a, c in zip(ref, small):
+        assert np.array_equal(a["k_opt"], c["k_opt"]) and a["feasible"] == c["feasible"] and a["iterations"] == c["iterations"]
+        assert abs(a["max_violation"] - c["max_violation"]) <= 1e-12 * max(1.0, a["max_violation"])
+
+
 def test_wall_time_limit_is_honoured(sample_problem):
     from armour_amd.planner import ArmourNLP
     p = sample_problem
