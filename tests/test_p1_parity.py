@@ -92,6 +92,41 @@ def test_random_batch_against_live_oracle():
     assert ts["sum_torque"] == sum(o.table_sizes()["sum_torque"] for o in oracles)
 
 
+def _rotate_obstacles(obs, seed):
+    """Turn the axis-aligned boxes into generally oriented ones: generators g_i -> R g_i with a random rotation R."""
+    rng = np.random.default_rng(seed)
+    out = obs.copy()
+    for o in out.reshape(-1, 12):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        G = o[3:].reshape(3, 3)          # rows = generators
+        o[3:] = (G @ q.T).ravel()
+    return out
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_rotated_obstacles_keep_every_plane(B):
+    """With generally oriented obstacles no half-space is a duplicate of another (the reference's worlds only hold
+    axis-aligned boxes, where 12 of 36 are): more than 24 planes stay live, so the fused kernel runs its 9-slot variants
+    -- with the compact link x link normals (B = 1) and with d recomputed from the obstacle centres (B = 8)."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    from oracle.cpu_oracle import Oracle
+    T, O = 100, 5
+    bp = random_batch(60, B, O)
+    bp["obstacles"] = _rotate_obstacles(bp["obstacles"], 61)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = random_k(5, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b in sorted({0, B - 1}):
+        o = Oracle(T=T).set_problem(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        gr, jr = o.eval_g_jac(ks[b])
+        assert np.abs(g[b] - gr).max() <= G_TOL and np.abs(jac[b] - jr).max() <= J_TOL
+    if B > 1:   # batched (d recomputed) against a single-problem handle (d read): bit for bit
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][B - 1], bp["qd0"][B - 1], bp["qdd0"][B - 1], bp["q_des"][B - 1], bp["obstacles"][B - 1])
+        g1, j1 = one.eval_g_jac(ks[B - 1])
+        assert np.array_equal(g[B - 1], g1[0]) and np.array_equal(jac[B - 1], j1[0])
+
+
 def test_fast_initial_state_stress():
     """speed-limit initial velocity and |qdd0| = 3: the largest intermediate PZs we know of (~2.6k raw terms)."""
     from armour_amd.planner import ArmourNLP
