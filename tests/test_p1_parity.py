@@ -45,6 +45,7 @@ def test_against_golden_fixtures(case):
     assert np.abs(gl[0] - gd["g_l"]).max() <= R_TOL and np.abs(gu[0] - gd["g_u"]).max() <= R_TOL
     for tag, k in (("k0", np.zeros(7)), ("kt", PZ_TESTS_K)):
         g, jac = nlp.eval_g_jac(k)
+        assert np.array_equal(nlp.eval_g(k), g) and np.array_equal(nlp.eval_jac_g(k), jac)   # the g-only / jac-only kernels
         assert np.abs(g[0] - gd[f"g_{tag}"]).max() <= G_TOL
         assert np.abs(jac[0][gd["jac_rows"]] - gd[f"jac_{tag}"]).max() <= J_TOL
         assert abs(nlp.eval_f(k)[0] - float(gd[f"f_{tag}"])) <= 1e-12
