@@ -196,3 +196,42 @@ def test_multi_point_launch_is_bit_identical(B, O, points):
     g_ref, jac_ref = oracles[0].eval_g_jac(ks[-1, 0])
     assert np.abs(d_g[-1, 0].cpu().numpy() - g_ref).max() <= G_TOL
     assert np.abs(d_j[-1, 0].cpu().numpy() - jac_ref).max() <= J_TOL
+
+
+def test_first_order_derivative_check_through_one_multi_point_launch(sample_problem):
+    """The reference's (commented) IPOPT derivative checker, RT/armour_main.cu:255-259 (first-order, relative
+    tolerance 1e-6), run on the device path: g at k and at the 14 points k +- h e_j in ONE multi-point launch, the
+    central difference against the Jacobian of the same launch.  Rows whose arg-max plane (or limit branch) changes
+    inside the stencil are kinks of g -- recognised by their Jacobian row differing across the stencil -- and skipped."""
+    import torch
+    from armour_amd.planner import ArmourNLP
+    p = sample_problem
+    nlp = ArmourNLP(T=100).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    n, m, h = nlp.n, nlp.m, 1e-6
+    k = PZ_TESTS_K * 0.8
+    pts = np.concatenate([k[None, :]] + [np.stack([k + s * h * np.eye(n)[j] for s in (+1, -1)]) for j in range(n)])[:, None, :]   # [15, 1, n]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    d_k = torch.from_numpy(np.ascontiguousarray(pts)).to(dev)
+    d_g = torch.zeros((15, 1, m), dtype=torch.float64, device=dev)
+    d_j = torch.zeros((15, 1, m, n), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    nlp.eval_g_jac_device_multi(d_k.data_ptr(), 15, d_g.data_ptr(), d_j.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    g, J = d_g[:, 0].cpu().numpy(), d_j[:, 0].cpu().numpy()
+    # One quirk of the reference is reproduced on purpose and excluded here: when a joint's velocity extremum sits at
+    # t = 1, where the velocity is 0 for every k, RT/Trajectory.cu:503-505,520-522 still returns the POSITION rule's
+    # gradient 1.0 * k_range / DURATION (the true derivative is 0).
+    vel_rows = np.arange(m - 2 * n, m)
+    quirk = np.zeros(m, dtype=bool)
+    quirk[vel_rows] = (np.abs(g[0][vel_rows]) <= 1e-12) & (np.abs(J[0][vel_rows].sum(axis=1) - np.pi / 48) <= 1e-15)
+    assert quirk.sum() >= 1          # the sample problem starts at rest: some joint's velocity extremum is the end point
+    checked = 0
+    for j in range(n):
+        gp, gm, Jp, Jm = g[1 + 2 * j], g[2 + 2 * j], J[1 + 2 * j], J[2 + 2 * j]
+        smooth = (np.abs(Jp - J[0]).max(axis=1) <= 1e-4) & (np.abs(Jm - J[0]).max(axis=1) <= 1e-4) & ~quirk
+        fd = (gp - gm) / (2 * h)
+        err = np.abs(fd - J[0][:, j]) / np.maximum(1.0, np.abs(J[0][:, j]))
+        assert err[smooth].max() <= 1e-6, (j, err[smooth].max())
+        checked += int(smooth.sum())
+    assert checked >= 0.97 * n * m       # almost every row is smooth at a generic point
