@@ -128,6 +128,11 @@ __device__ inline double interval_center(double c, double r) {
     return (lo + hi) * 0.5;
 }
 
+// x / d for 0 <= x < 2^20 and 1 <= d < 2^20 with the host-computed m = ceil(2^40 / d): exact, one 64-bit multiply
+// (the compiler's runtime-divisor sequence is ~30 instructions; the fused kernel divides by O and by 3*strideL per thread)
+__host__ __device__ inline unsigned long long div_magic(int d) { return ((1ull << 40) + (unsigned long long)d - 1ull) / (unsigned long long)d; }
+__device__ inline int fast_div(int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); }
+
 struct P2Launch {
     int nbc, nbt;       // collision / torque block counts
     int max_pairs;      // (l,t) pairs a collision block can touch
@@ -140,6 +145,7 @@ struct P2Launch {
     // point s reads k_all + s*k_stride and writes g_all + s*g_stride, jac_all + s*j_stride (strides in doubles; 0 = overwrite)
     int steps;
     long long k_stride, g_stride, j_stride;
+    unsigned long long magic_O, magic_pp3;  // div_magic(O), div_magic(3 * strideL)
 };
 
 // registers of one slicing pass: the (monomial, axis) tasks of this thread and, for threads < pairs*24, the inputs of
@@ -163,7 +169,7 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
         const int task = tid + r * P2_BLOCK;
         pr.tcnt[r] = -1; pr.tdst[r] = 0; pr.tkey[r] = 0; pr.tco[r] = 0.0;
         if (task < ntask) {
-            const int pi = task / per_pair3, rem = task - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
+            const int pi = fast_div(task, lp.magic_pp3), rem = task - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
             const size_t idx = (size_t)b * tb.J * tb.T + (lt_first + p0 + pi);
             pr.tcnt[r] = tb.link_count[idx] - mo;  // > 0: live monomial
             pr.tdst[r] = pi * per_pair + mo * 24 + e;
@@ -199,7 +205,7 @@ __device__ inline void load_pass_uncond(const P2Tables& tb, const P2Launch& lp, 
         const int task = tid + r * P2_BLOCK;
         const bool valid = task < ntask;
         const int tk = valid ? task : 0;
-        const int pi = tk / per_pair3, rem = tk - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
+        const int pi = fast_div(tk, lp.magic_pp3), rem = tk - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
         const size_t idx = idx0 + pi;
         const int moc = min(mo, tb.capL - 1);
         const int cnt = tb.link_count[idx];
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         const double* pl = tb.planes + (size_t)b * armour_planes_per_problem(Q) + q;  // layout: common.h armour_plane_index
         const size_t cs = (size_t)ARMOUR_NPLANES * Q;
         const int JT = tb.J * T;
-        const double* pll = tb.planes_ll + (size_t)b * armour_planes_ll_per_problem(JT) + q / O;
+        const int q_lt = fast_div(q, lp.magic_O), q_o = q - q_lt * O;  // q = (l*T + t)*O + o
+        const double* pll = tb.planes_ll + (size_t)b * armour_planes_ll_per_problem(JT) + q_lt;
         unsigned long long live = ~(lp.skip_by_value ? lp.skip0 : tb.plane_skip[b]) & ((1ull << ARMOUR_NPLANES) - 1ull);
         const bool plane0_live = (live & 1ull) != 0;
         const int na = __popcll(live), base = na >> 2, rem = na & 3;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         // expression of armour_p1_planes_kernel, instead of read -- 8 B less per plane and row
         double oc0 = 0.0, oc1 = 0.0, oc2 = 0.0;
         if (DFC) {
-            const double* oc = tb.obs_center + (size_t)b * 3 * O + q % O;
+            const double* oc = tb.obs_center + (size_t)b * 3 * O + q_o;
             oc0 = oc[0]; oc1 = oc[O]; oc2 = oc[2 * (size_t)O];
         }
         P2_STAMP(1);
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         //    PZ tables (L2) and the planes are all in flight together.
         const int per_pair = lp.strideL * 24;
         if (MULTI && single_pass) load_pass(tb, lp, b, lt_first, 0, npairs, pr);
-        const double* xs = sx + (q / O - lt_first) * 24;
+        const double* xs = sx + (q_lt - lt_first) * 24;
         for (int s = 0; s < nsteps; s++) {
             KPow& kp = kp2[s & 1];
             const double k_cur = k_next;
@@ -602,6 +609,8 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     lp.skip_by_value = (tb.B == 1 && h_skip) ? 1 : 0;
     lp.skip0 = lp.skip_by_value ? h_skip[0] : 0ull;
     lp.steps = steps; lp.k_stride = k_stride; lp.g_stride = g_stride; lp.j_stride = j_stride;
+    lp.magic_O = div_magic(tb.O > 0 ? tb.O : 1); lp.magic_pp3 = div_magic(3 * lp.strideL);
+    if (tb.Q >= (1 << 20)) { armour_set_error("more than 2^20 collision rows per problem"); return ARMOUR_ECAPACITY; }
     if (lp.strideL * 3 > P2_BLOCK * P2_TASK_ROUNDS) { armour_set_error("link PZ with %d monomials exceeds the P2 kernel's %d", lp.strideL, P2_BLOCK * P2_TASK_ROUNDS / 3); return ARMOUR_ECAPACITY; }
     lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / 24), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
     if (lp.strideT > 32 * P2_TQ_ROUNDS) { armour_set_error("torque PZ with %d monomials exceeds the P2 kernel's %d", lp.strideT, 32 * P2_TQ_ROUNDS); return ARMOUR_ECAPACITY; }
