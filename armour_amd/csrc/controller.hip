@@ -1,0 +1,165 @@
+// armour_robust_controller: the reference's tracking controller for a BATCH of states -- nominal and interval passivity
+// RNEA and the ARMOUR robust input.
+//
+// Replaces kinova_controller.cpp:19-84 (the MEX gateway: builds the model and a RobustController, calls update once)
+// for B states at a time: one thread per state, everything in registers / thread-local memory.  The model preparation
+// (model file -> CoM frames -> interval model, robot_models.cpp:124-255) is host arithmetic done once per call from
+// the ArmourRobot constants; the per-state arithmetic is controller_core.h.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "controller_core.h"
+
+namespace {
+
+using namespace ctl;
+
+void rpy(double roll, double pitch, double yaw, double* c) {  // RT/PZsparse.cu:160-176 (the same convention as the planner)
+    c[0] = cos(pitch) * cos(yaw);
+    c[1] = -cos(pitch) * sin(yaw);
+    c[2] = sin(pitch);
+    c[3] = cos(roll) * sin(yaw) + cos(yaw) * sin(pitch) * sin(roll);
+    c[4] = cos(roll) * cos(yaw) - sin(pitch) * sin(roll) * sin(yaw);
+    c[5] = -cos(pitch) * sin(roll);
+    c[6] = sin(roll) * sin(yaw) - cos(roll) * cos(yaw) * sin(pitch);
+    c[7] = cos(yaw) * sin(roll) + cos(roll) * sin(pitch) * sin(yaw);
+    c[8] = cos(pitch) * cos(roll);
+}
+
+// The model file of the reference (kinova_without_gripper.txt) holds, per joint: the joint twist (rotation about the
+// joint's own axis), the spatial inertia at the joint frame, the parent-to-joint transform and the CoM offset.  The
+// same quantities follow from ArmourRobot; Model::Model then re-expresses everything in CoM frames.
+int build_models(const ArmourRobot& rb, double eps, Model<double>& md, Model<Itv>& imd) {
+    const int n = rb.num_factors;
+    if (n < 1 || n > ARMOUR_MAX_FACTORS) return -1;
+    Tw<double> S[ARMOUR_MAX_FACTORS];
+    Ri<double> I[ARMOUR_MAX_FACTORS];
+    Xf<double> XT[ARMOUR_MAX_FACTORS], CoM[ARMOUR_MAX_FACTORS];
+    for (int i = 0; i < n; i++) {
+        const int ax = std::abs(rb.axes[i]);
+        if (ax < 1 || ax > 3) return -1;
+        S[i].w = vzero<double>(); S[i].v = vzero<double>();
+        S[i].w.x[ax - 1] = rb.axes[i] > 0 ? 1.0 : -1.0;
+        // RigidInertia(m, c, Ic), spatial.cpp:123-131
+        V3<double> c{{rb.com[3 * i], rb.com[3 * i + 1], rb.com[3 * i + 2]}};
+        M3<double> Ic;
+        for (int e = 0; e < 9; e++) Ic.a[e] = rb.inertia[9 * i + e];
+        const M3<double> ch = hat(c);
+        I[i].m = rb.mass[i];
+        I[i].m_c_hat = lscale(rb.mass[i], ch);
+        I[i].I_bar = Ic - I[i].m_c_hat * ch;
+        // parent-to-joint transform: E = R_rpy^T, r = trans (Featherstone's X = (E, r))
+        double R[9];
+        rpy(rb.rots[3 * i], rb.rots[3 * i + 1], rb.rots[3 * i + 2], R);
+        M3<double> Rm;
+        for (int e = 0; e < 9; e++) Rm.a[e] = R[e];
+        XT[i].R = tr(Rm);
+        XT[i].p = V3<double>{{rb.trans[3 * i], rb.trans[3 * i + 1], rb.trans[3 * i + 2]}};
+        CoM[i].R = mident<double>();
+        CoM[i].p = c;
+    }
+    md.n = n;
+    for (int i = 0; i < n; i++) {  // robot_models.cpp:133-155
+        Xf<double> Xwj = XT[i];
+        for (int pind = i - 1; pind > -1; pind--) Xwj = apply(Xwj, XT[pind]);
+        md.S_[i] = invapply(Xwj, S[i]);
+        md.I[i] = apply(CoM[i], I[i]);
+        const Xf<double> prev = i > 0 ? CoM[i - 1] : xf_identity<double>();
+        md.XTree[i] = apply(prev, apply(inverse(XT[i]), inverse(CoM[i])));
+        md.transI[i] = rb.armature[i];
+        md.damping[i] = rb.damping[i];
+        md.friction[i] = rb.friction[i];
+    }
+    md.gravity.w = vzero<double>();
+    md.gravity.v = V3<double>{{0.0, 0.0, -rb.gravity}};
+    // IntModel(model, eps), robot_models.cpp:176-255: point intervals, then mass and I_bar widened by 1 -+ eps
+    imd.n = n;
+    const double lowP = 1 - eps, highP = 1 + eps;
+    for (int i = 0; i < n; i++) {
+        for (int e = 0; e < 3; e++) { imd.S_[i].w.x[e] = Itv{md.S_[i].w.x[e], md.S_[i].w.x[e]}; imd.S_[i].v.x[e] = Itv{md.S_[i].v.x[e], md.S_[i].v.x[e]}; imd.XTree[i].p.x[e] = Itv{md.XTree[i].p.x[e], md.XTree[i].p.x[e]}; }
+        for (int e = 0; e < 9; e++) {
+            imd.XTree[i].R.a[e] = Itv{md.XTree[i].R.a[e], md.XTree[i].R.a[e]};
+            imd.I[i].m_c_hat.a[e] = Itv{md.I[i].m_c_hat.a[e], md.I[i].m_c_hat.a[e]};
+            const double val = md.I[i].I_bar.a[e];
+            imd.I[i].I_bar.a[e] = val >= 0 ? Itv{val * lowP, val * highP} : Itv{val * highP, val * lowP};
+        }
+        imd.I[i].m = Itv{md.I[i].m * lowP, md.I[i].m * highP};
+        imd.transI[i] = Itv{md.transI[i], md.transI[i]};
+        imd.damping[i] = md.damping[i];
+        imd.friction[i] = md.friction[i];
+    }
+    for (int e = 0; e < 3; e++) { imd.gravity.w.x[e] = Itv{0.0, 0.0}; imd.gravity.v.x[e] = Itv{md.gravity.v.x[e], md.gravity.v.x[e]}; }
+    return 0;
+}
+
+struct CtlArgs {
+    Model<double> md;
+    Model<Itv> imd;
+    double Kr[ARMOUR_MAX_FACTORS];
+    double alpha, V_max, r_norm_threshold;
+};
+
+__global__ __launch_bounds__(64) void armour_controller_kernel(const CtlArgs* __restrict__ ap, int B, const double* __restrict__ q, const double* __restrict__ qd,
+                                                               const double* __restrict__ q_des, const double* __restrict__ qd_des,
+                                                               const double* __restrict__ qdd_des, double* __restrict__ u, double* __restrict__ tau,
+                                                               double* __restrict__ v, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const CtlArgs& a = *ap;
+    const int n = a.md.n;
+    double lq[ARMOUR_MAX_FACTORS], lqd[ARMOUR_MAX_FACTORS], lqdes[ARMOUR_MAX_FACTORS], lqddes[ARMOUR_MAX_FACTORS], lqdddes[ARMOUR_MAX_FACTORS];
+    double lu[ARMOUR_MAX_FACTORS], lt[ARMOUR_MAX_FACTORS], lv[ARMOUR_MAX_FACTORS];
+    for (int i = 0; i < n; i++) {
+        lq[i] = q[(size_t)b * n + i]; lqd[i] = qd[(size_t)b * n + i];
+        lqdes[i] = q_des[(size_t)b * n + i]; lqddes[i] = qd_des[(size_t)b * n + i]; lqdddes[i] = qdd_des[(size_t)b * n + i];
+    }
+    const bool ok = robust_update(a.md, a.imd, a.Kr, a.alpha, a.V_max, a.r_norm_threshold, lq, lqd, lqdes, lqddes, lqdddes, lu, lt, lv);
+    for (int i = 0; i < n; i++) { u[(size_t)b * n + i] = lu[i]; tau[(size_t)b * n + i] = lt[i]; v[(size_t)b * n + i] = lv[i]; }
+    if (!ok) atomicOr(status, 1);
+}
+
+}  // namespace
+
+// C ABI: see include/armour_hip.h.  Host pointers; B states of n = robot->num_factors joints each, row-major [B][n].
+extern "C" int armour_robust_controller(const ArmourRobot* robot, double model_uncertainty, const double* Kr, double alpha, double V_max,
+                                        double r_norm_threshold, int32_t B, const double* q, const double* qd, const double* q_des,
+                                        const double* qd_des, const double* qdd_des, double* u, double* tau, double* v) {
+    if (!robot || !Kr || !q || !qd || !q_des || !qd_des || !qdd_des || !u || !tau || !v || B < 1) { armour_set_error("null or empty argument"); return ARMOUR_EINVAL; }
+    CtlArgs args;
+    memset(&args, 0, sizeof(args));
+    if (build_models(*robot, model_uncertainty, args.md, args.imd) != 0) { armour_set_error("unsupported robot model (joint axes / count)"); return ARMOUR_EINVAL; }
+    const int n = args.md.n;
+    for (int i = 0; i < n; i++) args.Kr[i] = Kr[i];
+    args.alpha = alpha; args.V_max = V_max; args.r_norm_threshold = r_norm_threshold;
+    const size_t bn = (size_t)B * n * sizeof(double);
+    CtlArgs* d_args = nullptr;
+    double* d_buf = nullptr;  // 5 inputs + 3 outputs
+    int* d_status = nullptr;
+    hipError_t e = hipMalloc((void**)&d_args, sizeof(CtlArgs));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_buf, 8 * bn);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_status, sizeof(int));
+    int rc = ARMOUR_OK, st = 0;
+    if (e == hipSuccess) {
+        const double* in[5] = {q, qd, q_des, qd_des, qdd_des};
+        e = hipMemcpy(d_args, &args, sizeof(args), hipMemcpyHostToDevice);
+        for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipMemcpy(d_buf + (size_t)k * B * n, in[k], bn, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_status, 0, sizeof(int));
+        if (e == hipSuccess) {
+            double* o = d_buf + (size_t)5 * B * n;
+            hipLaunchKernelGGL(armour_controller_kernel, dim3((B + 63) / 64), dim3(64), 0, 0, d_args, B, d_buf, d_buf + (size_t)B * n, d_buf + (size_t)2 * B * n,
+                               d_buf + (size_t)3 * B * n, d_buf + (size_t)4 * B * n, o, o + (size_t)B * n, o + (size_t)2 * B * n, d_status);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpy(u, o, bn, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(tau, o + (size_t)B * n, bn, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(v, o + (size_t)2 * B * n, bn, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(&st, d_status, sizeof(int), hipMemcpyDeviceToHost);
+        }
+    }
+    if (e != hipSuccess) { armour_set_error("armour_robust_controller: %s", hipGetErrorString(e)); rc = ARMOUR_EDEVICE; }
+    else if (st) { armour_set_error("nominal model output falls outside interval output (robust_controller.cpp:88-94)"); rc = ARMOUR_ESTATE; }
+    if (d_args) (void)hipFree(d_args);
+    if (d_buf) (void)hipFree(d_buf);
+    if (d_status) (void)hipFree(d_status);
+    return rc;
+}

@@ -124,6 +124,18 @@ int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 int armour_desired_trajectory(int32_t n, const double* q0, const double* qd0, const double* qdd0, const double* k_range,
                               double duration, const double* k, double t, double* q, double* qd, double* qdd);
 
+/* ---- the tracking controller the planner's trajectories are executed with ---- */
+/* kinova_controller(Kr, alpha, V_max, r_norm_threshold, q, qd, q_des, qd_des, qdd_des[, eps]) ->  [u, tau, v]
+ * (kinova_robust_controllers_mex/kinova_controller.cpp:19-84; RobustController::update, ARMOUR method,
+ * robust_controller.cpp:63-168) for B states at once: tau = nominal passivity-RNEA torque, the interval RNEA over
+ * masses and inertias within +-model_uncertainty bounds the model error, v = robust input from the control barrier
+ * condition on V = 1/2 r'M r <= V_max, u = tau - v.  One device thread per state.  All pointers are host pointers,
+ * [B][n] row-major with n = robot->num_factors; Kr: [n] (diagonal gain).  ARMOUR_ESTATE if a nominal torque leaves its
+ * interval (the reference throws). */
+int armour_robust_controller(const ArmourRobot* robot, double model_uncertainty, const double* Kr, double alpha, double V_max,
+                             double r_norm_threshold, int32_t B, const double* q, const double* qd, const double* q_des,
+                             const double* qd_des, const double* qdd_des, double* u, double* tau, double* v);
+
 /* ---- NLP solve of the planning iteration ---- */
 /* Replaces IpoptApplication::OptimizeTNLP + armtd_NLP::finalize_solution (RT/armour_main.cu:237-304,
  * RT/NLPclass.cu:422-538) for all B problems of the handle at once: SQP on the device callbacks, start x = 0,

@@ -257,3 +257,30 @@ def pz_op(op, operands, consts=None, r=0, threshold=5e-4, out_cap=1 << 16):
         raise RuntimeError("oracle_pz_op overflow")
     m, osz = int(misc[0]), int(misc[1])
     return dict(keys=ok[:m].copy(), coef=oc[:m * osz].reshape(m, osz).copy(), cen=misc[3:3 + osz].copy(), ind=misc[12:12 + osz].copy(), min_margin=misc[2])
+
+
+def robust_controller(Kr, alpha, V_max, r_thr, q, qd, q_des, qd_des, qdd_des, eps=0.03, robot=None):
+    """CPU restatement of the reference's kinova_controller MEX for ONE state (controller_oracle.cpp).
+    Returns dict(u, tau, v, tau_interval [n,2], inside)."""
+    L = lib()
+    rb = robot if robot is not None else kinova_robot()
+    n = rb.num_factors
+    a = [np.ascontiguousarray(x, dtype=np.float64).ravel() for x in (q, qd, q_des, qd_des, qdd_des)]
+    kr = np.ascontiguousarray(np.broadcast_to(np.asarray(Kr, dtype=np.float64).ravel(), (n,)))
+    u, tau, v, ti = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros((n, 2))
+    L.oracle_robust_controller.restype = C.c_int
+    ok = L.oracle_robust_controller(C.byref(rb), C.c_double(eps), _dp(kr), C.c_double(alpha), C.c_double(V_max), C.c_double(r_thr),
+                                    *[_dp(x) for x in a], _dp(u), _dp(tau), _dp(v), _dp(ti))
+    return dict(u=u, tau=tau, v=v, tau_interval=ti, inside=bool(ok))
+
+
+def pass_rnea_scaled(s_m, s_I, q, qd, qda, qdd, gravity=True, robot=None):
+    """Nominal passivity RNEA of the controller with masses / CoM-frame inertias scaled by (1 + s_m[i]) / (1 + s_I[i])."""
+    L = lib()
+    rb = robot if robot is not None else kinova_robot()
+    n = rb.num_factors
+    a = [np.ascontiguousarray(x, dtype=np.float64).ravel() for x in (s_m, s_I, q, qd, qda, qdd)]
+    tau = np.zeros(n)
+    L.oracle_pass_rnea_scaled.restype = None
+    L.oracle_pass_rnea_scaled(C.byref(rb), *[_dp(x) for x in a], C.c_int(1 if gravity else 0), _dp(tau))
+    return tau
