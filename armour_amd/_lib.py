@@ -61,7 +61,7 @@ class ArmourSolveResult(C.Structure):
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
-    "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_get_sizes",
+    "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_set_problems_armtd", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
@@ -124,6 +124,7 @@ def load():
     L.armour_free_pinned.argtypes = [vp]
     L.armour_free_pinned.restype = None
     L.armour_set_problems.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, dp]
+    L.armour_set_problems_armtd.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp]
     L.armour_get_sizes.argtypes = [vp, ip, ip, ip]
     L.armour_get_bounds.argtypes = [vp, dp, dp, dp, dp]
     L.armour_eval_f.argtypes = [vp, dp, dp]

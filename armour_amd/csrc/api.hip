@@ -8,6 +8,7 @@
 
 #include "../../include/armour_robot_kinova.h"
 #include "bezier.h"
+#include "cacc.h"
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -113,6 +114,7 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     memset(&tb, 0, sizeof(tb));
     tb.B = h->B; tb.T = h->T; tb.J = h->J; tb.n = h->n; tb.O = h->O; tb.Q = h->Q; tb.m = h->m;
     tb.capL = h->lim.link_monomials; tb.capT = h->lim.torque_monomials;
+    tb.row0 = h->row0; tb.mode = h->mode;
     tb.link_count = h->d_link_count; tb.link_center = h->d_link_center; tb.link_indep = h->d_link_indep;
     tb.link_keys = h->d_link_keys; tb.link_coeff = h->d_link_coeff;
     tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
@@ -191,6 +193,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 6; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds);
+    dev_free(&h->d_jrs);
     armour_p1_free(h);
     dev_free(&h->d_link_count); dev_free(&h->d_link_center); dev_free(&h->d_link_indep);
     dev_free(&h->d_link_keys); dev_free(&h->d_link_coeff);
@@ -202,8 +205,9 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     delete h;
 }
 
+// mode ARMTD: `qdd0` carries k_range [B][n] (the curve has no initial acceleration) and the third row of d_bez holds it
 static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, const double* qd0, const double* qdd0,
-                             const double* q_des) {
+                             const double* q_des, int mode = ARMOUR_MODE_ARMOUR) {
     if (!h || !q0 || !qd0 || !qdd0 || !q_des) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     if (B < 1 || O < 0) { armour_set_error("bad batch/obstacle count (B=%d, O=%d)", B, O); return ARMOUR_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
@@ -212,13 +216,17 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     int rc = ensure_capacity(h, B, O);
     if (rc != ARMOUR_OK) return rc;
     h->B = B; h->O = O; h->Q = h->J * h->T * O;
-    h->m = h->n * h->T + h->Q + 4 * h->n;
+    h->mode = mode;
+    h->row0 = mode == ARMOUR_MODE_ARMTD ? 0 : h->n * h->T;  // CMP/NLPclass.cu:42-43: no torque rows
+    h->m = h->row0 + h->Q + 4 * h->n;
     const size_t bn = (size_t)B * h->n;
     h->h_q0.assign(q0, q0 + bn); h->h_qd0.assign(qd0, qd0 + bn);
-    h->h_qdd0.assign(qdd0, qdd0 + bn); h->h_qdes.assign(q_des, q_des + bn);
-    // Bezier scalars: q0, Tqd0 = qd0*DURATION, TTqdd0 = qdd0*DURATION^2 (RT/Trajectory.cu:22-26)
+    h->h_qdes.assign(q_des, q_des + bn);
+    if (mode == ARMOUR_MODE_ARMTD) { h->h_qdd0.assign(bn, 0.0); h->h_krange.assign(qdd0, qdd0 + bn); }
+    else { h->h_qdd0.assign(qdd0, qdd0 + bn); h->h_krange.clear(); }
+    // Bezier scalars: q0, Tqd0 = qd0*DURATION, TTqdd0 = qdd0*DURATION^2 (RT/Trajectory.cu:22-26); ARMTD: q0, qd0, k_range
     std::vector<double> bz((size_t)B * 3 * h->n);
-    const double D = h->params.duration;
+    const double D = mode == ARMOUR_MODE_ARMTD ? 1.0 : h->params.duration;
     for (int b = 0; b < B; b++)
         for (int i = 0; i < h->n; i++) {
             bz[((size_t)b * 3 + 0) * h->n + i] = q0[b * h->n + i];
@@ -249,6 +257,26 @@ extern "C" int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
     if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
+    rc = armour_p1_build(h, obstacles);
+    if (rc != ARMOUR_OK) return rc;
+    rc = armour_refresh_table_stats(h);
+    if (rc != ARMOUR_OK) return rc;
+    h->ready = true;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_set_problems_armtd(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0, const double* q_des,
+                                         const double* jrs, const double* k_range, const double* obstacles) {
+    if (!jrs || !k_range) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    int rc = begin_problem_set(h, B, O, q0, qd0, k_range, q_des, ARMOUR_MODE_ARMTD);
+    if (rc != ARMOUR_OK) return rc;
+    if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
+    const size_t cnt = (size_t)B * h->n * 6 * h->T;
+    if (cnt > h->jrs_cap) {
+        if ((rc = dev_alloc(&h->d_jrs, cnt)) != ARMOUR_OK) return rc;
+        h->jrs_cap = cnt;
+    }
+    HIPCHK(hipMemcpy(h->d_jrs, jrs, cnt * sizeof(double), hipMemcpyHostToDevice));
     rc = armour_p1_build(h, obstacles);
     if (rc != ARMOUR_OK) return rc;
     rc = armour_refresh_table_stats(h);
@@ -355,13 +383,15 @@ extern "C" int armour_get_bounds(ArmourPlanner* h, double* x_l, double* x_u, dou
     for (int b = 0; b < h->B; b++) {
         double* gl = g_l + (size_t)b * h->m;
         double* gu = g_u + (size_t)b * h->m;
-        const double* tr = &h->h_torque_radius[(size_t)b * n * T];
-        for (int t = 0; t < T; t++)
-            for (int j = 0; j < n; j++) {
-                gl[t * n + j] = -h->robot.torque_limits[j] + tr[j * T + t];
-                gu[t * n + j] = h->robot.torque_limits[j] - tr[j * T + t];
-            }
-        size_t off = (size_t)n * T;
+        if (h->mode == ARMOUR_MODE_ARMOUR) {
+            const double* tr = &h->h_torque_radius[(size_t)b * n * T];
+            for (int t = 0; t < T; t++)
+                for (int j = 0; j < n; j++) {
+                    gl[t * n + j] = -h->robot.torque_limits[j] + tr[j * T + t];
+                    gu[t * n + j] = h->robot.torque_limits[j] - tr[j * T + t];
+                }
+        }
+        size_t off = (size_t)h->row0;  // ARMTD mode (CMP/NLPclass.cu:73-140): the same collision and limit bounds, no torque rows
         for (size_t i = off; i < off + (size_t)h->Q; i++) { gl[i] = -1e19; gu[i] = 0; }
         off += h->Q;
         for (int rep = 0; rep < 2; rep++, off += n)
@@ -370,6 +400,10 @@ extern "C" int armour_get_bounds(ArmourPlanner* h, double* x_l, double* x_u, dou
             for (int i = 0; i < n; i++) { gl[off + i] = -h->robot.speed_limits[i] + h->ub.qde; gu[off + i] = h->robot.speed_limits[i] - h->ub.qde; }
     }
     return ARMOUR_OK;
+}
+
+int armour_checked_collision_rows(const ArmourPlanner* h) {
+    return h->mode == ARMOUR_MODE_ARMTD ? (h->n - 1 < h->J ? h->n - 1 : h->J) * h->T * h->O : h->Q;
 }
 
 static double wrap_to_pi(double a) {
@@ -389,7 +423,9 @@ extern "C" int armour_eval_f(ArmourPlanner* h, const double* k, double* f) {
             for (int i = 0; i < n; i++) {
                 if ((h->robot.continuous[i] != 0) != (pass == 0)) continue;
                 const size_t ix = (size_t)b * n + i;
-                const double qp = bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], h->params.t_plan);
+                const double qp = h->mode == ARMOUR_MODE_ARMTD  // CMP/NLPclass.cu:183-212
+                                      ? cacc::q_plan(h->h_q0[ix], h->h_qd0[ix], h->h_krange[ix], k[ix])
+                                      : bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], h->params.t_plan);
                 const double e = h->robot.continuous[i] ? wrap_to_pi(h->h_qdes[ix] - qp) : (h->h_qdes[ix] - qp);
                 obj += e * e;
             }
@@ -405,8 +441,10 @@ extern "C" int armour_eval_grad_f(ArmourPlanner* h, const double* k, double* gra
     for (int b = 0; b < h->B; b++)
         for (int i = 0; i < n; i++) {
             const size_t ix = (size_t)b * n + i;
-            const double qp = bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], tp);
-            const double dk = (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[i];
+            const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // CMP/NLPclass.cu:217-243
+            const double qp = armtd ? cacc::q_plan(h->h_q0[ix], h->h_qd0[ix], h->h_krange[ix], k[ix])
+                                    : bez::q_des(h->h_q0[ix], h->h_qd0[ix] * D, h->h_qdd0[ix] * D * D, h->params.k_range[i] * k[ix], tp);
+            const double dk = armtd ? cacc::q_plan_dk(h->h_krange[ix]) : (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[i];
             const double e = h->robot.continuous[i] ? wrap_to_pi(qp - h->h_qdes[ix]) : (qp - h->h_qdes[ix]);
             grad_f[ix] = 2 * e * dk * h->params.cost_scale;
         }
@@ -494,15 +532,19 @@ extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t*
     const double tt = h->params.torque_violation_threshold, ct = h->params.collision_violation_threshold;
     for (int b = 0; b < h->B; b++) {
         const double* gb = g + (size_t)b * h->m;
-        const double* tr = &h->h_torque_radius[(size_t)b * n * T];
         bool ok = true;
-        for (int t = 0; t < T && ok; t++)
-            for (int j = 0; j < n; j++) {
-                const double v = gb[t * n + j];
-                if (v < -h->robot.torque_limits[j] + tr[j * T + t] - tt || v > h->robot.torque_limits[j] - tr[j * T + t] + tt) { ok = false; break; }
-            }
-        size_t off = (size_t)n * T;
-        for (size_t i = 0; i < (size_t)h->Q && ok; i++)
+        if (h->mode == ARMOUR_MODE_ARMOUR) {
+            const double* tr = &h->h_torque_radius[(size_t)b * n * T];
+            for (int t = 0; t < T && ok; t++)
+                for (int j = 0; j < n; j++) {
+                    const double v = gb[t * n + j];
+                    if (v < -h->robot.torque_limits[j] + tr[j * T + t] - tt || v > h->robot.torque_limits[j] - tr[j * T + t] + tt) { ok = false; break; }
+                }
+        }
+        size_t off = (size_t)h->row0;
+        // CMP/NLPclass.cu:391-402 re-checks the collision rows of links 0 .. NUM_FACTORS-2 only (RT checks every link)
+        const size_t n_checked = (size_t)armour_checked_collision_rows(h);
+        for (size_t i = 0; i < n_checked && ok; i++)
             if (gb[off + i] > ct) ok = false;
         off += h->Q;
         for (int rep = 0; rep < 2 && ok; rep++, off += n)

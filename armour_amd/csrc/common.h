@@ -50,6 +50,7 @@ __host__ __device__ inline size_t armour_plane_ll_index(int JT, int lt, int pll,
 struct P2Tables {
     int B, T, J, n, O, Q, m;
     int capL, capT;
+    int row0;  // first collision row: n*T (after the torque rows), or 0 in ARMTD comparison mode (no torque rows)
     const int* link_count;
     const double* link_center;  // [..][3]
     const double* link_indep;   // [..][3]
@@ -64,11 +65,18 @@ struct P2Tables {
     const double* obs_center;   // [B][3][O] obstacle centres; when non-null P2 computes d = A.c itself instead of reading it (tables built by P1)
     const double* planes_ll;    // [B][3][15][J*T], see armour_plane_ll_index; used when ll_shared != 0
     int ll_shared;
+    int mode;  // ARMOUR_MODE_*: which trajectory the joint-limit rows belong to
     const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem
-    const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0
+    const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0  (ARMTD mode: q0, qd0, k_range)
     double k_range[ARMOUR_MAX_FACTORS];
     double duration;
 };
+
+// Which planner the current problem set belongs to.  ARMOUR: degree-5 Bezier trajectory, online JRS, torque rows (RT/).
+// ARMTD: the comparison planner (CMP/ = kinova_planner_realtime_armtd_comparison): constant-acceleration trajectory,
+// cos/sin JRS from the caller's offline tables, no torque rows.
+#define ARMOUR_MODE_ARMOUR 0
+#define ARMOUR_MODE_ARMTD 1
 
 struct ArmourPlanner {
     ArmourRobot robot;
@@ -81,6 +89,11 @@ struct ArmourPlanner {
     // current problem set
     int B = 0, O = 0, Q = 0, m = 0;
     bool ready = false;
+    int mode = ARMOUR_MODE_ARMOUR;
+    int row0 = 0;                   // rows before the collision block (n*T torque rows, or 0 in ARMTD mode)
+    std::vector<double> h_krange;   // ARMTD mode: [B][n] acceleration range of each problem's JRS tables
+    double* d_jrs = nullptr;        // ARMTD mode: [B][n][6][T] c/g/r of cos, then of sin (the order of armtd.in)
+    size_t jrs_cap = 0;
     // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
     void* solve_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows
     size_t solve_pin_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -125,13 +138,15 @@ struct ArmourPlanner {
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,
                      int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0);
 int armour_refresh_table_stats(ArmourPlanner* h);
+// collision rows the feasibility re-check looks at (all Q in ARMOUR mode; the first (n-1)*T*O in ARMTD mode, CMP/NLPclass.cu:391-402)
+int armour_checked_collision_rows(const ArmourPlanner* h);
 // page-locked scratch slot of the handle with at least `bytes` bytes (registered for the zero-copy eval path); nullptr on failure
 double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);
 
 // p1_reach.hip
-int armour_p1_build(ArmourPlanner* h, const double* obstacles);
+int armour_p1_build(ArmourPlanner* h, const double* obstacles);  // h->mode selects the ARMOUR or the ARMTD chain
 void armour_p1_free(ArmourPlanner* h);
 int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, const int* cnt, const uint64_t* const* keys,
                           const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,

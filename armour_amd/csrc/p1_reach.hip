@@ -49,6 +49,8 @@ struct P1Cfg {
     ArmourParams pr;
     ArmourUltimateBound ub;
     const double* bez;  // [B][3][n]: q0, Tqd0, TTqdd0
+    int mode;           // ARMOUR_MODE_*; ARMTD: cos/sin JRS from `jrs`, forward kinematics only (no RNEA, no torque tables)
+    const double* jrs;  // ARMTD mode: [B][n][6][T] centre / k-generator / radius of cos(q - q0), then of sin(q - q0)
     // outputs
     int* link_count; double* link_center; double* link_indep; uint32_t* link_keys; double* link_coeff;
     int* tq_count; double* tq_center; double* tq_indep; uint32_t* tq_keys; double* tq_coeff;
@@ -422,6 +424,24 @@ struct Chain {
     }
 };
 
+// ARMTD comparison mode, CMP/Trajectory.cu:29-61: cos / sin of the offline JRS (tabulated for q0 = 0) rotated by the
+// joint's initial angle; the radius term is scaled by 4 as the reference does.
+__device__ PZW_NOINLINE JrsScalars armtd_jrs_scalars(const P1Cfg& cf, double q0, int b, int i, int t) {
+    const int T = cf.T;
+    const double* tb = cf.jrs + ((size_t)b * cf.n + i) * 6 * T + t;
+    const double cc = tb[0], gc = tb[T], rc = tb[2 * T], cs = tb[3 * T], gs = tb[4 * T], rs = tb[5 * T];
+    const double c0 = cos(q0), s0 = sin(q0);
+    JrsScalars js;
+    js.cos_c = c0 * cc - s0 * cs;
+    js.cos_k = c0 * gc - s0 * gs;
+    js.cos_e = (fabs(c0) * rc + fabs(s0) * rs) * 4.0;
+    js.sin_c = c0 * cs + s0 * cc;
+    js.sin_k = c0 * gs + s0 * gc;
+    js.sin_e = (fabs(c0) * rs + fabs(s0) * rc) * 4.0;
+    js.qd_c = js.qd_k = js.qd_e = js.qda_e = js.qdd_c = js.qdd_k = js.qdd_e = 0.0;
+    return js;
+}
+
 // write a raw (unsimplified) small PZ from lane 0 and simplify it into `out` (the constructors that end with
 // simplify(): RT/PZsparse.cu:120-136,179-205)
 template <int SZ>
@@ -452,7 +472,9 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
         double rp[9];
         rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
         if (i < n && cf.rb.axes[i] != 0) {
-            const JrsScalars js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t);
+            JrsScalars js;
+            if (cf.mode == ARMOUR_MODE_ARMTD) js = armtd_jrs_scalars(cf, bz[i], b, i, t);
+            else js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t);
             const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
             // rotation about the joint axis from cos / sin polynomials, then R = R_rpy * Rz (:129-134)
             double cen[9], co[4 * 9];
@@ -465,7 +487,8 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
             build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
             set_const(c.w, c.rpy(role), rp, nullptr);
             mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
-            // qd_des, qda_des, qdda_des (:176-243)
+            // qd_des, qda_des, qdda_des (:176-243); the ARMTD chain stops at the forward kinematics and has none
+            if (cf.mode != ARMOUR_MODE_ARMTD) {
             {
                 const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
                 const double co2[2] = {js.qd_k, js.qd_e};
@@ -480,6 +503,7 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
                 const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
                 const double co2[2] = {js.qdd_k, js.qdd_e};
                 build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+            }
             }
         } else {
             set_const(c.w, c.R(i), rp, nullptr);
@@ -835,11 +859,20 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
         const long long ph1 = clock64();
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
-        run_rnea(c, u_nom, b, t);
+        if (cf.mode == ARMOUR_MODE_ARMTD) {
+            // CMP/armtd_main.cu:141-156: forward kinematics and the link tables, nothing else (launched with one wave)
+            FkState fk;
+            c.role = 2;
+            fk_begin(c, fk);
+            for (int i = 0; i < c.J; i++) fk_step(c, fk, i, b, t);
+            c.freeVs(fk.T);
+        } else {
+            run_rnea(c, u_nom, b, t);
+        }
 #ifdef P1_PROFILE
         const long long ph3 = clock64();
 #endif
-        if (c.is(0)) finish_torque(c, u_nom, b, t);
+        if (cf.mode != ARMOUR_MODE_ARMTD && c.is(0)) finish_torque(c, u_nom, b, t);
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
             // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
@@ -1160,7 +1193,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
         static const int nw_env = [] { const char* e = getenv("ARMOUR_P1_WAVES"); return e ? atoi(e) : 0; }();  // development override
-        const bool three = nw_env ? nw_env == 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
+        const bool three = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
+                           : nw_env ? nw_env == 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
         const int nw = three ? kRoles : 1;
         const Layout& L = three ? L3 : L1;
         const size_t smem = lds_bytes(cap, nw);
@@ -1182,6 +1216,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.arena_bytes = L.total; cf.arena = wk->arena;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
+        cf.mode = h->mode; cf.jrs = h->d_jrs;
         cf.link_count = h->d_link_count; cf.link_center = h->d_link_center; cf.link_indep = h->d_link_indep;
         cf.link_keys = h->d_link_keys; cf.link_coeff = h->d_link_coeff;
         cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
@@ -1225,6 +1260,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // Batches with more items than three waves per CU hold run a first pass with 2048-entry sort buffers -- 32 KB of LDS
     // per wave, so FOUR waves per CU -- and list the few items that overflow them; those alone are rebuilt with the full
     // buffers.  Small batches gain nothing from the fourth wave and go straight to the full buffers.
+    if (h->mode == ARMOUR_MODE_ARMTD) {  // no torque tables in this mode: empty PZs, zero radius
+        HIPCHK(hipMemsetAsync(h->d_tq_count, 0, (size_t)B * n * T * sizeof(int), h->stream));
+        HIPCHK(hipMemsetAsync(wk->d_torque_radius, 0, (size_t)B * n * T * sizeof(double), h->stream));
+    }
     const int kFirstPassCap = 2048;
     const int* d_items = nullptr;
     int n_items = B * T;

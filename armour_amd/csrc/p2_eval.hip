@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "bezier.h"
+#include "cacc.h"
 #include "common.h"
 
 #define P2_BLOCK 256
@@ -416,9 +417,9 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                     m_elt = c ? oe : m_elt; mA0 = c ? o1 : mA0; mA1 = c ? o2 : mA1; mA2 = c ? o3 : mA2; neg = c ? on : neg;
                 }
 #if defined(P2_ABLATE) && (P2_ABLATE & 32)
-                if (WANT_G && wv == 0 && m_elt == 12345.678) g[(size_t)n * T + q_begin + lane] = -m_elt;
+                if (WANT_G && wv == 0 && m_elt == 12345.678) g[(size_t)tb.row0 + q_begin + lane] = -m_elt;
 #else
-                if (WANT_G && wv == 0 && q_begin + lane < q_end) g[(size_t)n * T + q_begin + lane] = -m_elt;
+                if (WANT_G && wv == 0 && q_begin + lane < q_end) g[(size_t)tb.row0 + q_begin + lane] = -m_elt;
 #endif
                 if (WANT_J) {
 #pragma unroll
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
             if (WANT_J) {
                 __syncthreads();
                 const int total = (q_end - q_begin) * n;
-                double* jrow = jac + ((size_t)n * T + q_begin) * n;
+                double* jrow = jac + ((size_t)tb.row0 + q_begin) * n;
 #if defined(P2_ABLATE) && (P2_ABLATE & 32)
                 for (int i = tid; i < total; i += P2_BLOCK) if (stage[i] == 12345.678) jrow[i] = stage[i];
 #else
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         stamp[7] = __builtin_amdgcn_s_memtime() - cyc0;
         if (tid == 0 && (role == 0 || role == lp.nbc / 2 || role == lp.nbc - 1)) {
             const int slot = role == 0 ? 0 : role == lp.nbc - 1 ? 2 : 1;
-            for (int i2 = 0; i2 < 8; i2++) g_all[(size_t)b * m + (size_t)n * T + Q + slot * 8 + i2] = (double)(stamp[i2] & 0xffffffffffffull);
+            for (int i2 = 0; i2 < 8; i2++) g_all[(size_t)b * m + (size_t)tb.row0 + Q + slot * 8 + i2] = (double)(stamp[i2] & 0xffffffffffffull);
         }
 #endif
     } else if (role < lp.nbc + lp.nbt) {
@@ -524,6 +525,27 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
         double* pv = lds;  // [2n][8]
         const int jv = tid >> 3, piece = tid & 7;
         const double* bz = tb.bez + (size_t)b * 3 * n;
+        if (tb.mode == ARMOUR_MODE_ARMTD) {
+            // ARMTD comparison mode: constant-acceleration curve, CMP/Trajectory.cu:83-383 (cacc.h); bez = q0, qd0, k_range.
+            // One thread per joint; rows q_min, q_max, qd_min, qd_max (n each), Jacobian diagonal = d/d(k_range*k) as the
+            // reference stores it, every other entry of the rows 0.
+            for (int s = 0; s < nsteps; s++) {
+                const double* k = k0 + (size_t)s * lp.k_stride;
+                double* g = WANT_G ? g0 + (size_t)s * lp.g_stride : nullptr;
+                double* jac = WANT_J ? jac0 + (size_t)s * lp.j_stride : nullptr;
+                if (tid < n) {
+                    const cacc::Extrema e = cacc::joint_extrema(bz[tid], bz[n + tid], bz[2 * n + tid] * k[tid]);
+                    const cacc::Cand c4[4] = {e.q_min, e.q_max, e.qd_min, e.qd_max};
+                    const size_t off = (size_t)tb.row0 + Q;
+                    for (int r = 0; r < 4; r++) {
+                        const size_t row = off + (size_t)r * n + tid;
+                        if (WANT_G) g[row] = c4[r].v;
+                        if (WANT_J) for (int c = 0; c < n; c++) jac[row * n + c] = (c == tid) ? c4[r].d : 0.0;
+                    }
+                }
+            }
+            return;
+        }
         for (int s = 0; s < nsteps; s++) {
             const double* k = k0 + (size_t)s * lp.k_stride;
             double* g = WANT_G ? g0 + (size_t)s * lp.g_stride : nullptr;
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                 const double sc = vel ? tb.k_range[i] / tb.duration : tb.k_range[i];
                 const double dmn = (mnId == 1 ? 0.0 : mnId == 2 ? v[4] : mnId == 3 ? v[5] : 1.0) * sc;
                 const double dmx = (mxId == 1 ? 0.0 : mxId == 2 ? v[4] : mxId == 3 ? v[5] : 1.0) * sc;
-                const size_t off = (size_t)n * T + Q;
+                const size_t off = (size_t)tb.row0 + Q;
                 const size_t r_mn = off + (vel ? 2 * n : 0) + i, r_mx = r_mn + n;
                 if (WANT_G) { g[r_mn] = vel ? mn / tb.duration : mn; g[r_mx] = vel ? mx / tb.duration : mx; }
                 if (WANT_J) {
@@ -602,7 +624,7 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     if (!d_g && !d_jac) return ARMOUR_OK;
     P2Launch lp;
     lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
-    lp.nbt = (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;
+    lp.nbt = tb.mode == ARMOUR_MODE_ARMTD ? 0 : (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;  // ARMTD mode has no torque rows
     lp.max_pairs = tb.O > 0 ? (P2_ROWS - 1) / tb.O + 2 : 1;
     lp.strideL = max_link > 0 ? max_link : 1;
     lp.strideT = max_torque > 0 ? max_torque : 1;

@@ -197,7 +197,7 @@ struct SolveRow {
 // rows outside [g_l - slack, g_u + slack] with the slacks of armtd_NLP::finalize_solution (RT/NLPclass.cu:422-538:
 // torque rows 1e-2, collision rows 1e-4, limit rows 0) -- the verdict armour_check_feasible gives on the host.
 template <int MODE>
-__global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, int n_torque_rows, int n_collision_rows, double torque_slack, double collision_slack, const double* __restrict__ g_all, const double* __restrict__ jac_all,
+__global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, int n_torque_rows, int n_collision_rows, int n_unchecked_rows, double torque_slack, double collision_slack, const double* __restrict__ g_all, const double* __restrict__ jac_all,
                                                                 const double* __restrict__ lo_all, const double* __restrict__ hi_all, int cap,
                                                                 double* __restrict__ viol_out, int* __restrict__ count_out, SolveRow* __restrict__ rows_out) {
     // grid (segments, B): a block owns kScanRowsPerBlock consecutive rows and its own slice of the outputs; the host
@@ -221,8 +221,10 @@ __global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, in
         if (gi > ui) vsum += gi - ui;
         else if (gi < li) vsum += li - gi;
         if (MODE == 2 && in) {
-            const double slack = i < n_torque_rows ? torque_slack : i < n_torque_rows + n_collision_rows ? collision_slack : 0.0;
-            if (gi < li - slack || gi > ui + slack) bad++;
+            // (ARMTD mode: the re-check of CMP/NLPclass.cu:391-402 skips the collision rows of the last links)
+            const int ic = i - n_torque_rows - n_collision_rows;
+            const double slack = i < n_torque_rows ? torque_slack : ic < 0 ? collision_slack : 0.0;
+            if ((ic < 0 || ic >= n_unchecked_rows) && (gi < li - slack || gi > ui + slack)) bad++;
         }
         if (ROWS) {
             double J[NV], l1 = 0.0;
@@ -335,13 +337,16 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     std::vector<double> hviol(B);
     bool full_on_host = false;  // g / jac of the current linearisation were copied to hg / hj (row-buffer overflow fallback)
     // constant diagonal Hessian of the cost: f = scale * sum (q_des - q0 - ... - c*kr*x)^2  (RT/NLPclass.cu:207-236)
+    // (ARMTD mode, CMP/NLPclass.cu:183-243: the plan point is q0 + qd0/2 + k_range k/8 with the problem's own k_range)
     const double tp = h->params.t_plan;
-    double Hd[NV];
-    for (int j = 0; j < n; j++) {
-        const double dk = (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[j];
-        Hd[j] = 2.0 * h->params.cost_scale * dk * dk;
-        if (Hd[j] < 1e-12) Hd[j] = 1e-12;
-    }
+    std::vector<double> Hd_all((size_t)B * NV, 1e-12);
+    for (int b = 0; b < B; b++)
+        for (int j = 0; j < n; j++) {
+            const double dk = h->mode == ARMOUR_MODE_ARMTD ? 0.125 * h->h_krange[(size_t)b * n + j] : (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * h->params.k_range[j];
+            double& Hd = Hd_all[(size_t)b * NV + j];
+            Hd = 2.0 * h->params.cost_scale * dk * dk;
+            if (Hd < 1e-12) Hd = 1e-12;
+        }
     std::vector<ProblemState> st(B);
     std::vector<double> fb(B), gfb((size_t)B * n);
     for (int b = 0; b < B; b++) { for (int j = 0; j < n; j++) { st[b].x[j] = 0.0; hk[b * n + j] = 0.0; } st[b].mu = 1.0; }  // get_starting_point: x = 0
@@ -362,9 +367,9 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
         struct Acc { double& t; decltype(e0) s; ~Acc() { t += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s).count(); } } acc{t_eval, e0};
         int r = armour_eval_g_jac_device(h, hk, h->d_g, want_jac ? h->d_jac : nullptr, h->stream);
         if (r != ARMOUR_OK) return r;
-        const int nTq = n * h->T, nCol = h->Q;
+        const int nTq = h->row0, nCol = armour_checked_collision_rows(h), nSkip = h->Q - nCol;
         const double tsl = h->params.torque_violation_threshold, csl = h->params.collision_violation_threshold;
-#define SCAN(MODE, JAC, CNT, ROWSP) hipLaunchKernelGGL(armour_solve_scan_kernel<MODE>, dim3(nseg, B), dim3(256), 0, h->stream, m, n, nTq, nCol, tsl, csl, h->d_g, JAC, h->d_bounds, h->d_bounds + bm, cap_rows, hviol_seg, CNT, ROWSP)
+#define SCAN(MODE, JAC, CNT, ROWSP) hipLaunchKernelGGL(armour_solve_scan_kernel<MODE>, dim3(nseg, B), dim3(256), 0, h->stream, m, n, nTq, nCol, nSkip, tsl, csl, h->d_g, JAC, h->d_bounds, h->d_bounds + bm, cap_rows, hviol_seg, CNT, ROWSP)
         if (want_jac) SCAN(1, h->d_jac, hcount, hrows);
         else if (verdict) SCAN(2, (const double*)nullptr, hcount, (SolveRow*)nullptr);
         else SCAN(0, (const double*)nullptr, (int*)nullptr, (SolveRow*)nullptr);
@@ -460,7 +465,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                         QpRow r; memset(&r, 0, sizeof(r)); r.a[j] = 1.0; r.b = xl[j] - s.x[j]; rows.push_back(r);
                         QpRow r2; memset(&r2, 0, sizeof(r2)); r2.a[j] = -1.0; r2.b = -(xu[j] - s.x[j]); rows.push_back(r2);
                     }
-                    qp = solve_qp(n, Hd, s.gradf, rows);
+                    qp = solve_qp(n, &Hd_all[(size_t)b * NV], s.gradf, rows);
                     if (qp.feasible) break;
                     sigma = attempt == 0 ? 0.5 : attempt == 1 ? 0.9 : 0.99;
                 }

@@ -130,6 +130,25 @@ class ArmourNLP:
         self._after_set(B, O)
         return self
 
+    def set_parameters_armtd(self, q0, qd0, q_des, jrs, k_range, obstacles):
+        """ARMTD comparison mode (CMP/armtd_main.cu:36-216, the reference's second planner): constant-acceleration
+        trajectory, cos/sin JRS from offline tables, no torque rows (m = J*T*O + 4n).  jrs: [n,6,T] (or [B,n,6,T]) --
+        per joint the rows c_cos, g_cos, r_cos, c_sin, g_sin, r_sin of armtd.in; k_range: [n] (or [B,n]).  Every other
+        method of this class then follows CMP/NLPclass.cu."""
+        q0, qd0, q_des, k_range = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in (q0, qd0, q_des, k_range)]
+        B = q0.shape[0]
+        jrs = np.ascontiguousarray(np.asarray(jrs, dtype=np.float64).reshape(B, self.n, 6, self.T))
+        obs = np.asarray(obstacles, dtype=np.float64)
+        obs = np.ascontiguousarray(obs.reshape(B, -1, 12)) if obs.size else np.zeros((B, 0, 12))
+        O = obs.shape[1]
+        for a in (q0, qd0, q_des, k_range):
+            if a.shape != (B, self.n):
+                raise ValueError(f"expected shape ({B},{self.n}), got {a.shape}")
+        self._obs = obs
+        check(self.L.armour_set_problems_armtd(self.h, B, O, _dp(q0), _dp(qd0), _dp(q_des), _dp(jrs), _dp(k_range), _dp(obs) if O else None))
+        self._after_set(B, O)
+        return self
+
     def _after_set(self, B, O):
         b, n, m = C.c_int32(), C.c_int32(), C.c_int32()
         check(self.L.armour_get_sizes(self.h, C.byref(b), C.byref(n), C.byref(m)))

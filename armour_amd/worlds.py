@@ -67,3 +67,46 @@ def load_scene_csv(path):
     obs[:, 7] = boxes[:, 4] / 2
     obs[:, 11] = boxes[:, 5] / 2
     return q_start, q_goal, obs
+
+
+def synthetic_offline_jrs(qd0, T=100, t_plan=0.5, t_total=1.0):
+    """Stand-in for the offline joint-reachable-set tables of the ARMTD comparison planner.
+
+    The reference loads, per joint, the file JRS_<v>.mat of the initial-velocity bin nearest to qd0 (401 bins on
+    [-pi, pi], KSI/uarmtd_planner.m:249-255) -- zonotopes CORA computed offline (CMP/offline_jrs/
+    create_orig_offline_jrs.m) -- and writes six rows per joint into armtd.in (:277-312).  Those .mat files are
+    not part of the reference checkout, so tests and probes use this closed-form enclosure with the same meaning and
+    shapes: for time interval j, cos/sin of theta(t) = v t + ka t^2/2 (then the constant-deceleration stop), v in the
+    bin, ka = k_range*k, as  centre + generator*k + [-radius, radius]  (first-order Taylor, Lagrange remainder).
+    Returns (jrs [n,6,T], k_range [n]); real tables go through armour_set_problems_armtd unchanged.
+    """
+    qd0 = np.asarray(qd0, dtype=np.float64).ravel()
+    n = qd0.size
+    c_kvi = np.linspace(-np.pi, np.pi, 401)
+    delta_kvi = (c_kvi[1] - c_kvi[0]) / 2
+    dt = t_total / T
+    jrs = np.zeros((n, 6, T))
+    k_range = np.zeros(n)
+    ts = t_total - t_plan
+    for i in range(n):
+        v = c_kvi[np.argmin(np.abs(qd0[i] - c_kvi))]
+        ka = max(np.pi / 24, abs(v) / 3)          # delta_kai of create_orig_offline_jrs.m:56
+        k_range[i] = ka
+        for j in range(T):
+            tm, half = (j + 0.5) * dt, 0.5 * dt
+            if tm < t_plan:                          # theta = v t + ka t^2/2
+                th, dth_dv, dth_da, rate = v * tm, tm, 0.5 * tm * tm, abs(v) + ka * tm
+                da_dt = tm
+            else:                                    # stop from (theta_p, w_p) with constant deceleration w_p/ts
+                s = tm - t_plan
+                f = s - 0.5 * s * s / ts             # theta = theta_p + w_p f(s)
+                th, dth_dv = v * t_plan + v * f, t_plan + f
+                dth_da = 0.5 * t_plan * t_plan + t_plan * f
+                rate = (abs(v) + ka * t_plan) * (1 - s / ts + half / ts)
+                da_dt = t_plan * (1 - s / ts + half / ts)
+            a = dth_da * ka                          # k-dependent part of theta - theta_c
+            e = dth_dv * delta_kvi + rate * half + da_dt * half * ka   # everything else
+            rem = 0.5 * (abs(a) + e) ** 2
+            jrs[i, 0, j], jrs[i, 1, j], jrs[i, 2, j] = np.cos(th), -np.sin(th) * a, abs(np.sin(th)) * e + rem
+            jrs[i, 3, j], jrs[i, 4, j], jrs[i, 5, j] = np.sin(th), np.cos(th) * a, abs(np.cos(th)) * e + rem
+    return jrs, k_range

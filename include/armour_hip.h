@@ -81,6 +81,20 @@ void armour_free_pinned(void* p);
 int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
                         const double* qdd0, const double* q_des, const double* obstacles);
 
+/* ARMTD comparison mode: the same handle and the same callback surface for the reference's second
+ * planner, kinova_planner_realtime_armtd_comparison ("CMP").  Replaces CMP/armtd_main.cu:36-216: constant-acceleration
+ * trajectory q(t) = q0 + qd0 t + k t^2/2 (CMP/Trajectory.h:6-15), cos/sin JRS taken from the caller's offline tables and
+ * rotated by q0 (CMP/Trajectory.cu:29-81), forward kinematics, half-space tables; no torque rows:
+ * m = J*T*O + 4n (CMP/NLPclass.cu:42-43), collision rows first, then the joint-limit rows of the constant-acceleration
+ * curve (CMP/Trajectory.cu:83-383).  After this call armour_get_sizes / get_bounds / eval_f / eval_grad_f / eval_g_jac* /
+ * check_feasible / armour_solve and the table getters follow CMP/NLPclass.cu instead of RT/NLPclass.cu.
+ *   jrs: [B][n][6][T], per joint the six rows armtd.in holds for it (KSI/uarmtd_planner.m:277-312): centre, k-generator
+ *        and radius of cos(q - q0), then of sin(q - q0);  k_range: [B][n] (the number after each joint's rows, :314-315).
+ * The ArmourParams of the handle supply T, the simplify threshold, the violation thresholds and the cost scale; its
+ * k_range, duration and t_plan are not used in this mode. */
+int armour_set_problems_armtd(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0, const double* q_des,
+                              const double* jrs, const double* k_range, const double* obstacles);
+
 /* sizes after set_problems: n = NUM_FACTORS, m = constraint_number (RT/NLPclass.cu:46-49, get_nlp_info :62-82) */
 int armour_get_sizes(const ArmourPlanner* h, int32_t* B, int32_t* n, int32_t* m);
 

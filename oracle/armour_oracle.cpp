@@ -127,6 +127,10 @@ struct Problem {
     std::vector<double> A, d, delta;   /* [((t*J+l)*O+o)*36+p] (x3 for A) */
     Stats st;
     double build_ms = 0;
+    /* ARMTD comparison mode (CMP/ = kinova_planner_realtime_armtd_comparison): constant-acceleration curve, offline JRS tables */
+    bool armtd = false;
+    std::vector<double> jrs; /* [n][6][T]: c,g,r of cos then of sin (CMP/armtd_main.cu:76-96) */
+    double k_range_a[7];     /* per-joint k_range read with the tables (:97) */
 };
 
 /* RT/Trajectory.cu:15-61 */
@@ -245,6 +249,93 @@ static void make_poly_zono(Problem& P, Ctx& cx, int s_ind) {
         P.R_t[i * T + s_ind] = transpose(P.R[i * T + s_ind]);
     }
     P.R[J * T + s_ind] = pz_rpy(0, 0, 0);
+}
+
+/* CMP/Trajectory.cu:29-81 (ConstantAccelerationCurve::makePolyZono) */
+static void make_poly_zono_armtd(Problem& P, Ctx& cx, int t_ind) {
+    const int T = P.T, n = P.n, J = P.J;
+    const KeyLayout& kl = cx.kl;
+    for (int i = 0; i < n; i++) {
+        const double* tab = &P.jrs[(size_t)i * 6 * T];
+        const double *c_cos = tab, *g_cos = tab + T, *r_cos = tab + 2 * T, *c_sin = tab + 3 * T, *g_sin = tab + 4 * T, *r_sin = tab + 5 * T;
+        const double cos_q0 = std::cos(P.q0[i]), sin_q0 = std::sin(P.q0[i]);
+        const double cos_c = cos_q0 * c_cos[t_ind] - sin_q0 * c_sin[t_ind];
+        double cos_coeff[2];
+        cos_coeff[0] = cos_q0 * g_cos[t_ind] - sin_q0 * g_sin[t_ind];
+        cos_coeff[1] = std::fabs(cos_q0) * r_cos[t_ind] + std::fabs(sin_q0) * r_sin[t_ind];
+        cos_coeff[1] *= 4.0;
+        const uint64_t cos_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_cosqe(i)};
+        const double sin_c = cos_q0 * c_sin[t_ind] + sin_q0 * c_cos[t_ind];
+        double sin_coeff[2];
+        sin_coeff[0] = cos_q0 * g_sin[t_ind] + sin_q0 * g_cos[t_ind];
+        sin_coeff[1] = std::fabs(cos_q0) * r_sin[t_ind] + std::fabs(sin_q0) * r_cos[t_ind];
+        sin_coeff[1] *= 4.0;
+        const uint64_t sin_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_sinqe(i)};
+        PZ Ri = pz_rpy(P.rb.rots[3 * i], P.rb.rots[3 * i + 1], P.rb.rots[3 * i + 2]);
+        if (P.rb.axes[i] != 0)
+            Ri = mul(cx, Ri, pz_rotation(cx, cos_c, cos_coeff, cos_keys, 2, sin_c, sin_coeff, sin_keys, 2, P.rb.axes[i]));
+        P.R_t[i * T + t_ind] = transpose(Ri);
+        P.R[i * T + t_ind] = std::move(Ri);
+    }
+    for (int i = n; i < J; i++) { /* fixed joints at the end of the chain (:73-78) */
+        P.R[i * T + t_ind] = pz_rpy(P.rb.rots[3 * i], P.rb.rots[3 * i + 1], P.rb.rots[3 * i + 2]);
+        P.R_t[i * T + t_ind] = transpose(P.R[i * T + t_ind]);
+    }
+    P.R[J * T + t_ind] = pz_rpy(0, 0, 0);
+}
+
+/* CMP/Trajectory.cu:83-205 (values) and :207-383 (gradient): extremum[0..n) q_min, [n..2n) q_max, [2n..3n) qd_min,
+ * [3n..4n) qd_max; the gradient is what the reference writes on the Jacobian diagonal (d/d(k_range k), no k_range factor). */
+static void armtd_state_extremum(const Problem& P, const double* k, double* extremum, double* grad_diag) {
+    const int n = P.n;
+    const double t_move = 0.5, t_total = 1.0, t_to_stop = t_total - t_move;
+    for (int i = 0; i < n; i++) {
+        const double q0 = P.q0[i], qd0 = P.qd0[i];
+        const double k_actual = P.k_range_a[i] * k[i];
+        const double q_peak = q0 + qd0 * t_move + k_actual * t_move * t_move * 0.5;
+        const double q_dot_peak = qd0 + k_actual * t_move;
+        const double q_ddot_to_stop = -q_dot_peak / t_to_stop;
+        const double q_stop = q_peak + q_dot_peak * t_to_stop + 0.5 * q_ddot_to_stop * t_to_stop * t_to_stop;
+        const double t_max_min_to_peak = -qd0 / k_actual;
+        double q_lo, q_hi, g_lo, g_hi; /* q_endpoints_ordered / grad_q_endpoints_ordered */
+        if (q_peak >= q0) { q_lo = q0; q_hi = q_peak; g_lo = 0; g_hi = 0.5 * t_move * t_move; }
+        else { q_lo = q_peak; q_hi = q0; g_lo = 0.5 * t_move * t_move; g_hi = 0; }
+        double q_min_to_peak = q_lo, q_max_to_peak = q_hi, gq_min_to_peak = g_lo, gq_max_to_peak = g_hi;
+        if (t_max_min_to_peak > 0 && t_max_min_to_peak < t_move) {
+            const double turn = q0 + qd0 * t_max_min_to_peak + 0.5 * k_actual * t_max_min_to_peak * t_max_min_to_peak;
+            const double gturn = (0.5 * qd0 * qd0) / (k_actual * k_actual);
+            if (k_actual >= 0) { q_min_to_peak = turn; gq_min_to_peak = gturn; }
+            else { q_max_to_peak = turn; gq_max_to_peak = gturn; }
+        }
+        double qd_min_to_peak, qd_max_to_peak, gqd_min_to_peak, gqd_max_to_peak;
+        if (q_dot_peak >= qd0) { qd_min_to_peak = qd0; qd_max_to_peak = q_dot_peak; gqd_min_to_peak = 0; gqd_max_to_peak = t_move; }
+        else { qd_min_to_peak = q_dot_peak; qd_max_to_peak = qd0; gqd_min_to_peak = t_move; gqd_max_to_peak = 0; }
+        double q_min_to_stop, q_max_to_stop, gq_min_to_stop, gq_max_to_stop;
+        if (q_stop >= q_peak) {
+            q_min_to_stop = q_peak; q_max_to_stop = q_stop;
+            gq_min_to_stop = 0.5 * t_move * t_move; gq_max_to_stop = 0.5 * t_move * t_move + 0.5 * t_move * t_to_stop;
+        } else {
+            q_min_to_stop = q_stop; q_max_to_stop = q_peak;
+            gq_min_to_stop = 0.5 * t_move * t_move + 0.5 * t_move * t_to_stop; gq_max_to_stop = 0.5 * t_move * t_move;
+        }
+        double qd_min_to_stop, qd_max_to_stop, gqd_min_to_stop, gqd_max_to_stop;
+        if (q_dot_peak >= 0) { qd_min_to_stop = 0; qd_max_to_stop = q_dot_peak; gqd_min_to_stop = 0; gqd_max_to_stop = t_move; }
+        else { qd_min_to_stop = q_dot_peak; qd_max_to_stop = 0; gqd_min_to_stop = t_move; gqd_max_to_stop = 0; }
+        const bool a = q_min_to_peak <= q_min_to_stop, b = q_max_to_peak >= q_max_to_stop;
+        const bool c = qd_min_to_peak <= qd_min_to_stop, d = qd_max_to_peak >= qd_max_to_stop;
+        if (extremum) {
+            extremum[i] = a ? q_min_to_peak : q_min_to_stop;
+            extremum[i + n] = b ? q_max_to_peak : q_max_to_stop;
+            extremum[i + 2 * n] = c ? qd_min_to_peak : qd_min_to_stop;
+            extremum[i + 3 * n] = d ? qd_max_to_peak : qd_max_to_stop;
+        }
+        if (grad_diag) {
+            grad_diag[i] = a ? gq_min_to_peak : gq_min_to_stop;
+            grad_diag[i + n] = b ? gq_max_to_peak : gq_max_to_stop;
+            grad_diag[i + 2 * n] = c ? gqd_min_to_peak : gqd_min_to_stop;
+            grad_diag[i + 3 * n] = d ? gqd_max_to_peak : gqd_max_to_stop;
+        }
+    }
 }
 
 /* RT/Dynamics.cu:49-66 : link bounding-box PZ with pseudo-variables at key fields n, 2n, 3n */
@@ -368,7 +459,7 @@ static void build(Problem& P, int num_threads) {
     auto t0 = std::chrono::steady_clock::now();
     const int T = P.T, J = P.J, n = P.n;
     P.ub = armour_ultimate_bound(&P.rb);
-    bezier_init(P);
+    if (!P.armtd) bezier_init(P);
     P.R.assign((size_t)(J + 1) * T, PZ()); P.R_t.assign((size_t)J * T, PZ());
     P.qd_des.assign((size_t)n * T, PZ()); P.qda_des.assign((size_t)n * T, PZ()); P.qdda_des.assign((size_t)n * T, PZ());
     P.links.assign((size_t)J * T, PZ()); P.u_nom.assign((size_t)n * T, PZ()); P.u_nom_int.assign((size_t)n * T, PZ());
@@ -391,12 +482,13 @@ static void build(Problem& P, int num_threads) {
     {
         Ctx cx; cx.kl.n = n; cx.threshold = P.pr.simplify_threshold;
 #pragma omp for schedule(dynamic, 1)
-        for (int t = 0; t < T; t++) make_poly_zono(P, cx, t);
+        for (int t = 0; t < T; t++) { if (P.armtd) make_poly_zono_armtd(P, cx, t); else make_poly_zono(P, cx, t); }
 #pragma omp for schedule(dynamic)
         for (int t = 0; t < T; t++) {
             for (int i = 0; i < J; i++) P.links[i * T + t] = link_box[i];
             fk(P, cx, t);
             for (int i = 0; i < J; i++) reduce_link_PZ(cx, P.links[i * T + t], &P.link_gens[(size_t)(t * J + i) * 18]);
+            if (P.armtd) continue; /* CMP/armtd_main.cu:141-156: forward kinematics only */
             rnea(P, cx, t, mass_nom, I_nom, P.u_nom);
             rnea(P, cx, t, mass_unc, I_unc, P.u_nom_int);
             for (int i = 0; i < n; i++) P.u_nom_int[i * T + t] = sub(cx, P.u_nom_int[i * T + t], P.u_nom[i * T + t]);
@@ -406,7 +498,7 @@ static void build(Problem& P, int num_threads) {
         P.st.merge(cx.st);
     }
     /* robust input bound, RT/armour_main.cu:172-205 */
-    for (int t = 0; t < T; t++) {
+    for (int t = 0; t < T && !P.armtd; t++) {
         Interval rho(0.0);
         for (int i = 0; i < n; i++) {
             double lo, hi;
@@ -504,11 +596,12 @@ static void eval_g_jac(Problem& P, const double* x, double* g, double* jac, int 
     const int T = P.T, J = P.J, n = P.n, O = P.O;
     if (num_threads > 0) omp_set_num_threads(num_threads);
     Ctx cx; cx.kl.n = n;
-    const size_t off_col = (size_t)T * n, off_lim = off_col + (size_t)T * J * O;
+    /* ARMTD mode, CMP/NLPclass.cu:245-330: collision rows first, then the state-limit rows; no torque rows */
+    const size_t off_col = P.armtd ? 0 : (size_t)T * n, off_lim = off_col + (size_t)T * J * O;
 #pragma omp parallel for schedule(dynamic)
     for (int t = 0; t < T; t++) {
         double cen[3], dcen[ARMOUR_MAX_FACTORS * 3];
-        for (int j = 0; j < n; j++) {
+        for (int j = 0; j < n && !P.armtd; j++) {
             if (g) { double c; slice_value(cx, P.u_nom[j * T + t], x, &c, nullptr); g[t * n + j] = c; }
             if (jac) slice_gradient(cx, P.u_nom[j * T + t], x, &jac[(size_t)(t * n + j) * n]);
         }
@@ -520,6 +613,18 @@ static void eval_g_jac(Problem& P, const double* x, double* g, double* jac, int 
                 check_collision(P, t, l, o, cen, jac ? dcen : nullptr, g ? &g[row] : nullptr, jac ? &jac[row * n] : nullptr);
             }
         }
+    }
+    if (P.armtd) {
+        if (g) armtd_state_extremum(P, x, g + off_lim, nullptr);
+        if (jac) {
+            /* the reference clears only 4*n*n BYTES of these rows (CMP/Trajectory.cu:208) and leaves the rest as IPOPT
+             * handed them over; the intended value, zero off the diagonal, is what is written here */
+            double diag[4 * ARMOUR_MAX_FACTORS];
+            armtd_state_extremum(P, x, nullptr, diag);
+            for (int r = 0; r < 4 * n; r++)
+                for (int c = 0; c < n; c++) jac[(off_lim + r) * n + c] = (c == r % n) ? diag[r] : 0.0;
+        }
+        return;
     }
     if (g) { joint_extremum(P, x, false, g + off_lim, nullptr); joint_extremum(P, x, true, g + off_lim + 2 * n, nullptr); }
     if (jac) { joint_extremum(P, x, false, nullptr, jac + off_lim * n); joint_extremum(P, x, true, nullptr, jac + (off_lim + 2 * n) * n); }
@@ -559,7 +664,20 @@ int oracle_set_problem(void* h, const double* q0, const double* qd0, const doubl
     build(P, num_threads);
     return 0;
 }
-int oracle_num_constraints(void* h) { Problem& P = *(Problem*)h; return P.n * P.T + P.J * P.T * P.O + 4 * P.n; }
+/* ARMTD comparison mode: CMP/armtd_main.cu:36-156.  jrs [n][6][T], k_range [n] */
+int oracle_set_problem_armtd(void* h, const double* q0, const double* qd0, const double* q_des, const double* jrs, const double* k_range,
+                             int O, const double* obstacles, int num_threads) {
+    Problem& P = *(Problem*)h;
+    if (P.n > ARMOUR_MAX_FACTORS) return -1;
+    for (int i = 0; i < P.n; i++) { P.q0[i] = q0[i]; P.qd0[i] = qd0[i]; P.qdd0[i] = 0; P.q_des[i] = q_des[i]; P.k_range_a[i] = k_range[i]; }
+    P.armtd = true;
+    P.jrs.assign(jrs, jrs + (size_t)P.n * 6 * P.T);
+    P.O = O;
+    P.obstacles.assign(obstacles, obstacles + (size_t)O * 12);
+    build(P, num_threads);
+    return 0;
+}
+int oracle_num_constraints(void* h) { Problem& P = *(Problem*)h; return (P.armtd ? 0 : P.n * P.T) + P.J * P.T * P.O + 4 * P.n; }
 double oracle_build_ms(void* h) { return ((Problem*)h)->build_ms; }
 
 void oracle_eval_g_jac(void* h, const double* k, double* g, double* jac, int num_threads) { eval_g_jac(*(Problem*)h, k, g, jac, num_threads); }
@@ -577,12 +695,12 @@ void oracle_get_bounds(void* h, double* x_l, double* x_u, double* g_l, double* g
     Problem& P = *(Problem*)h;
     const int T = P.T, J = P.J, n = P.n, O = P.O;
     for (int i = 0; i < n; i++) { x_l[i] = -1.0; x_u[i] = 1.0; }
-    for (int i = 0; i < T; i++)
+    for (int i = 0; i < T && !P.armtd; i++)
         for (int j = 0; j < n; j++) {
             g_l[i * n + j] = -P.rb.torque_limits[j] + P.torque_radius[j * T + i];
             g_u[i * n + j] = P.rb.torque_limits[j] - P.torque_radius[j * T + i];
         }
-    size_t off = (size_t)n * T;
+    size_t off = P.armtd ? 0 : (size_t)n * T; /* CMP/NLPclass.cu:73-140: the same rows without the torque block */
     for (size_t i = off; i < off + (size_t)T * J * O; i++) { g_l[i] = -1e19; g_u[i] = 0; }
     off += (size_t)T * J * O;
     for (int rep = 0; rep < 2; rep++, off += n)
@@ -599,7 +717,8 @@ double oracle_eval_f(void* h, const double* x) {
     for (int pass = 0; pass < 2; pass++)
         for (int i = 0; i < P.n; i++) {
             if ((P.rb.continuous[i] != 0) != (pass == 0)) continue;
-            const double qp = q_des_func(P.q0[i], P.Tqd0[i], P.TTqdd0[i], P.pr.k_range[i] * x[i], P.pr.t_plan);
+            const double qp = P.armtd ? P.q0[i] + P.qd0[i] * 0.5 + P.k_range_a[i] * x[i] * 0.125 /* CMP/NLPclass.cu:197 */
+                                      : q_des_func(P.q0[i], P.Tqd0[i], P.TTqdd0[i], P.pr.k_range[i] * x[i], P.pr.t_plan);
             const double e = P.rb.continuous[i] ? wrap_to_pi(P.q_des[i] - qp) : (P.q_des[i] - qp);
             obj += pow(e, 2);
         }
@@ -610,8 +729,9 @@ void oracle_eval_grad_f(void* h, const double* x, double* grad) {
     Problem& P = *(Problem*)h;
     const double tp = P.pr.t_plan;
     for (int i = 0; i < P.n; i++) {
-        const double qp = q_des_func(P.q0[i], P.Tqd0[i], P.TTqdd0[i], P.pr.k_range[i] * x[i], tp);
-        const double dk = pow(tp, 3) * (6 * pow(tp, 2) - 15 * tp + 10) * P.pr.k_range[i];
+        const double qp = P.armtd ? P.q0[i] + P.qd0[i] * 0.5 + P.k_range_a[i] * x[i] * 0.125 /* CMP/NLPclass.cu:229-230 */
+                                  : q_des_func(P.q0[i], P.Tqd0[i], P.TTqdd0[i], P.pr.k_range[i] * x[i], tp);
+        const double dk = P.armtd ? P.k_range_a[i] * 0.125 : pow(tp, 3) * (6 * pow(tp, 2) - 15 * tp + 10) * P.pr.k_range[i];
         grad[i] = P.rb.continuous[i] ? (2 * wrap_to_pi(qp - P.q_des[i]) * dk) : (2 * (qp - P.q_des[i]) * dk);
         grad[i] *= P.pr.cost_scale;
     }

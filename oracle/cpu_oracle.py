@@ -61,6 +61,7 @@ def lib():
         L.oracle_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams)]
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_set_problem.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_int, dp, C.c_int]
+        L.oracle_set_problem_armtd.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, C.c_int, dp, C.c_int]
         L.oracle_num_constraints.argtypes = [C.c_void_p]
         L.oracle_build_ms.argtypes = [C.c_void_p]
         L.oracle_build_ms.restype = C.c_double
@@ -139,6 +140,19 @@ class Oracle:
         rc = lib().oracle_set_problem(self.h, _dp(q0), _dp(qd0), _dp(qdd0), _dp(q_des), self.O, _dp(obs), threads)
         if rc != 0:
             raise RuntimeError("oracle_set_problem failed")
+        self.m = lib().oracle_num_constraints(self.h)
+        return self
+
+    def set_problem_armtd(self, q0, qd0, q_des, jrs, k_range, obstacles, threads=0):
+        """ARMTD comparison mode (CMP/armtd_main.cu:36-156): jrs [n,6,T], k_range [n]."""
+        q0, qd0, q_des, k_range = [np.ascontiguousarray(a, dtype=np.float64) for a in (q0, qd0, q_des, k_range)]
+        jrs = np.ascontiguousarray(np.asarray(jrs, dtype=np.float64).reshape(self.n, 6, self.T))
+        obs = np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 12)
+        self.O = obs.shape[0]
+        if self.O == 0:
+            obs = np.zeros((1, 12))
+        if lib().oracle_set_problem_armtd(self.h, _dp(q0), _dp(qd0), _dp(q_des), _dp(jrs), _dp(k_range), self.O, _dp(obs), threads) != 0:
+            raise RuntimeError("oracle_set_problem_armtd failed")
         self.m = lib().oracle_num_constraints(self.h)
         return self
 
