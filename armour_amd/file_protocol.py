@@ -31,6 +31,27 @@ def write_armour_in(path, q0, qd0, qdd0, q_des, obstacles):
             f.write("".join("%.10f " % x for x in row) + "\n")
 
 
+ARMTD_IN_NAME = "armtd.in"
+
+
+def write_armtd_in(path, q0, qd0, q_des, jrs, k_range, obstacles):
+    """Input of the ARMTD comparison planner as uarmtd_planner.replan writes it (KSI/uarmtd_planner.m:257-327, parsed
+    by CMP/armtd_main.cu:57-110): q0, qd0, q_des; per joint six lines of T numbers (centre, k-generator, radius of cos,
+    then of sin) and a line with its k_range; nObs; nObs lines of 12 numbers."""
+    obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 12)
+    jrs = np.asarray(jrs, dtype=np.float64)
+    with open(path, "w") as f:
+        for v in (q0, qd0, q_des):
+            f.write("".join("%.10f " % x for x in np.asarray(v, dtype=np.float64)) + "\n")
+        for i in range(jrs.shape[0]):
+            for row in jrs[i]:
+                f.write("".join("%.10f " % x for x in row) + "\n")
+            f.write("%.10f\n " % k_range[i])
+        f.write("%d\n" % obs.shape[0])
+        for row in obs:
+            f.write("".join("%.10f " % x for x in row) + "\n")
+
+
 def parse_armour_in(path, n=7, max_obstacles=None):
     """Whitespace-separated token stream exactly as the `>>` loop of RT/armour_main.cu:53-76 reads it.
     Raises ValueError where the reference writes -1 and throws (missing file, bad obstacle count)."""

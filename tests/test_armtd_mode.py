@@ -6,6 +6,9 @@ armour_set_problems_armtd + the fused eval kernel with the oracle through the C 
 test_p1_parity.py.  PARITY UNPINNED: the reference ships neither golden vectors nor its offline JRS tables (the .mat
 files of CMP/offline_jrs are not in the checkout) and cannot be built here, so the tables are the closed-form enclosure
 of armour_amd.worlds.synthetic_offline_jrs."""
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -238,3 +241,37 @@ def test_solve_in_comparison_mode():
         if feasible[b] and start_ok[b]:
             assert f1[b] <= f0[b] + 1e-9
     assert feasible.any()
+
+
+@pytest.mark.gpu
+def test_cli_drop_in_for_armtd_main(tmp_path):
+    """The armtd_main binary over the comparison planner's file protocol (KSI/uarmtd_planner.m:257-345).  The tables
+    pass through "%.10f" text, so the in-process reference below is built from the parsed-back values."""
+    from armour_amd import file_protocol as fp
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "armour_amd", "bin", "armtd_main")
+    assert os.path.exists(exe), "build with make -C armour_amd/csrc"
+    p = _problem(33, 7)
+    fp.write_armtd_in(tmp_path / fp.ARMTD_IN_NAME, p["q0"], p["qd0"], p["q_des"], p["jrs"], p["k_range"], p["obstacles"])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tok = np.array(open(tmp_path / fp.ARMTD_IN_NAME).read().split(), dtype=np.float64)
+    q = dict(q0=tok[0:7], qd0=tok[7:14], q_des=tok[14:21])
+    body = tok[21:21 + 7 * (6 * T + 1)].reshape(7, 6 * T + 1)
+    q["jrs"], q["k_range"] = body[:, :6 * T].reshape(7, 6, T), body[:, -1]
+    nobs = int(tok[21 + 7 * (6 * T + 1)])
+    q["obstacles"] = tok[22 + 7 * (6 * T + 1):].reshape(nobs, 12)
+    assert nobs == 7
+    nlp = _nlp([q])
+    lines = open(tmp_path / "armtd.out").read().split()
+    sol = nlp.solve(tolerance=1e-7, max_wall_time_s=0.4)[0]
+    assert (len(lines) == 8) == sol["feasible"] and float(lines[-1]) > 0
+    k_used = sol["k_opt"]
+    if len(lines) == 8:
+        assert np.allclose(np.array(lines[:7], dtype=np.float64), sol["k_opt"], atol=1e-8)
+    g_file = np.loadtxt(tmp_path / "armtd_constraints.out")
+    assert g_file.shape == (nlp.m,) and np.allclose(g_file, nlp.eval_g(k_used)[0], rtol=1e-5, atol=1e-12)
+    assert np.allclose(np.loadtxt(tmp_path / "armtd_joint_position_center.out").reshape(T, 7, 3), nlp.link_centers(k_used)[0], rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.loadtxt(tmp_path / "armtd_joint_position_radius.out").reshape(T, 7, 3, 6), nlp.link_generators()[0], rtol=1e-9, atol=1e-12)
+    os.remove(tmp_path / fp.ARMTD_IN_NAME)   # missing input: -1 and a non-zero exit code (CMP/armtd_main.cu:57-62)
+    bad = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and open(tmp_path / "armtd.out").read().split()[0] == "-1"
