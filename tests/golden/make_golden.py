@@ -74,5 +74,40 @@ def main():
             print(path, os.path.getsize(path) // 1024, "KiB", "m =", o.m, "min_margin =", out["min_margin"])
 
 
+def main_armtd():
+    """ARMTD comparison mode (CMP/): the sample problem of CMP/armtd_main.cu:17-33 (the same numbers as RT's) with the
+    stand-in offline tables of armour_amd.worlds.synthetic_offline_jrs (the reference's .mat tables are not in its
+    checkout); the tables are stored in the fixture, so it does not depend on that generator staying as it is."""
+    from armour_amd.worlds import synthetic_offline_jrs
+    T = 100
+    p = SAMPLE_PROBLEM
+    jrs, k_range = synthetic_offline_jrs(p["qd0"], T)
+    o = Oracle(T=T).set_problem_armtd(p["q0"], p["qd0"], p["q_des"], jrs, k_range, p["obstacles"])
+    rng = np.random.default_rng(4321)
+    Q = o.m - 28
+    rows = np.concatenate([np.sort(rng.choice(Q, size=400, replace=False)), np.arange(Q, o.m)]).astype(np.int64)
+    out = dict(T=T, q0=p["q0"], qd0=p["qd0"], q_des=p["q_des"], obstacles=p["obstacles"], jrs=jrs, k_range=k_range,
+               link_gens=o.link_generators(), jac_rows=rows, min_margin=o.min_margin())
+    xl, xu, gl, gu = o.bounds()
+    out.update(g_l=gl, g_u=gu)
+    lc, lk = [], []
+    for l in range(7):
+        for t in range(T):
+            keys = o.pz("link", l, t)[2]
+            lc.append(len(keys)); lk.append(keys)
+    out.update(link_count=np.array(lc, np.int32), link_keys=np.concatenate(lk).astype(np.uint32))
+    for tag, k in (("k0", np.zeros(7)), ("kt", PZ_TESTS_K)):
+        g, jac = o.eval_g_jac(k)
+        out[f"g_{tag}"] = g
+        out[f"jac_{tag}"] = jac[rows]
+        out[f"f_{tag}"] = o.eval_f(k)
+        out[f"gradf_{tag}"] = o.eval_grad_f(k)
+    path = os.path.join(HERE, f"armtd_sample_T{T}.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB", "m =", o.m, "min_margin =", out["min_margin"])
+
+
 if __name__ == "__main__":
-    main()
+    if "--armtd-only" not in sys.argv:
+        main()
+    main_armtd()

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import SAMPLE_PROBLEM
+from helpers import PZ_TESTS_K, SAMPLE_PROBLEM, load_golden
 
 C_TOL, G_TOL, J_TOL = 1e-11, 1e-9, 1e-8
 T = 100
@@ -122,6 +122,53 @@ def test_oracle_cost_and_bounds():
     assert np.array_equal(gl, agl[7 * T:]) and np.array_equal(gu, agu[7 * T:])   # ARMOUR's rows minus the torque block
 
 
+def _check_against_fixture(gd, obj, tab_tol, g_tol, j_tol):
+    """obj: the oracle or the device planner, both built from the fixture's inputs."""
+    is_dev = hasattr(obj, "get_bounds_info")
+    first = (lambda a: a[0]) if is_dev else (lambda a: a)
+    assert np.abs(first(obj.link_generators()) - gd["link_gens"]).max() <= tab_tol
+    lc, lk = [], []
+    for i in range(7):
+        for t in range(T):
+            keys = obj.pz("link", i, t)[2]
+            lc.append(len(keys)); lk.append(keys)
+    assert np.array_equal(np.array(lc), gd["link_count"]) and np.array_equal(np.concatenate(lk), gd["link_keys"])
+    b = obj.get_bounds_info() if is_dev else obj.bounds()
+    assert np.array_equal(first(b[2]), gd["g_l"]) and np.array_equal(first(b[3]), gd["g_u"])
+    for tag, k in (("k0", np.zeros(7)), ("kt", PZ_TESTS_K)):
+        g, jac = obj.eval_g_jac(k)
+        assert np.abs(first(g) - gd[f"g_{tag}"]).max() <= g_tol
+        assert np.abs(first(jac)[gd["jac_rows"]] - gd[f"jac_{tag}"]).max() <= j_tol
+        assert abs(first(np.atleast_1d(obj.eval_f(k))) - float(gd[f"f_{tag}"])) <= 1e-12
+        assert np.abs(first(np.atleast_2d(obj.eval_grad_f(k))) - gd[f"gradf_{tag}"]).max() <= 1e-12
+
+
+def test_oracle_reproduces_armtd_fixture():
+    """tests/golden/armtd_sample_T100.npz (make_golden.py): the sample problem of CMP/armtd_main.cu:17-33."""
+    gd = load_golden("armtd_sample_T100")
+    o = _oracle(gd)
+    assert o.m == 7 * T * 10 + 28
+    assert abs(o.min_margin() - float(gd["min_margin"])) <= 1e-6 * float(gd["min_margin"])
+    _check_against_fixture(gd, o, 1e-13, 1e-12, 1e-12)
+
+
+def test_oracle_armtd_without_obstacles_and_with_the_gripper_link():
+    """Edge cases of the row layout: O = 0 leaves the 4n state-limit rows; the 8-link arm (fixed gripper joint last,
+    CMP/KinovaInfo.h) has J = 8 link blocks and still n = 7 factors."""
+    from oracle.cpu_oracle import Oracle, kinova_gripper_robot
+    p = _problem(3, 0)
+    o = _oracle(p)
+    assert o.m == 28
+    g0 = o.eval_g_jac(np.zeros(7))[0]
+    p5 = _problem(3, 5)
+    o5 = _oracle(p5)
+    assert np.array_equal(o5.eval_g_jac(np.zeros(7))[0][-28:], g0)
+    og = Oracle(robot=kinova_gripper_robot(), T=T).set_problem_armtd(p5["q0"], p5["qd0"], p5["q_des"], p5["jrs"], p5["k_range"], p5["obstacles"])
+    assert og.m == 8 * T * 5 + 28
+    gg = og.eval_g_jac(np.zeros(7))[0]
+    assert np.array_equal(gg[-28:], g0) and np.array_equal(gg[:6 * T * 5], o5.eval_g_jac(np.zeros(7))[0][:6 * T * 5])   # links before the gripper are unchanged
+
+
 # ---------------------------------------------------------------------------------------------- GPU: the HIP path
 def _nlp(ps):
     from armour_amd.planner import ArmourNLP
@@ -168,6 +215,44 @@ def test_tables_and_eval_against_oracle():
             assert abs(f[b] - o.eval_f(ks[b])) <= 1e-12 and np.abs(gf[b] - o.eval_grad_f(ks[b])).max() <= 1e-12
             ob = o.bounds()
             assert np.array_equal(gl[b], ob[2]) and np.array_equal(gu[b], ob[3])
+
+
+@pytest.mark.gpu
+def test_device_against_armtd_fixture():
+    gd = load_golden("armtd_sample_T100")
+    assert float(gd["min_margin"]) > 1e-9
+    _check_against_fixture(gd, _nlp([gd]), C_TOL, G_TOL, J_TOL)
+
+
+@pytest.mark.gpu
+def test_device_without_obstacles_and_with_the_gripper_link():
+    from armour_amd.planner import ArmourNLP, kinova_gripper_robot
+    from oracle.cpu_oracle import Oracle
+    from oracle.cpu_oracle import kinova_gripper_robot as oracle_gripper
+    p = _problem(3, 0)
+    nlp = _nlp([p])
+    assert nlp.m == 28
+    g, jac = nlp.eval_g_jac(np.full(7, 0.3))
+    gr, jr = _oracle(p).eval_g_jac(np.full(7, 0.3))
+    assert np.array_equal(g[0], gr) and np.array_equal(jac[0], jr)
+    sol = nlp.solve()[0]
+    assert sol["feasible"] == bool(nlp.finalize_solution(nlp.eval_g(sol["k_opt"]))[0])
+    p5 = _problem(3, 5)
+    dev = ArmourNLP(robot=kinova_gripper_robot(), T=T).set_parameters_armtd(p5["q0"], p5["qd0"], p5["q_des"], p5["jrs"], p5["k_range"], p5["obstacles"])
+    og = Oracle(robot=oracle_gripper(), T=T).set_problem_armtd(p5["q0"], p5["qd0"], p5["q_des"], p5["jrs"], p5["k_range"], p5["obstacles"])
+    assert dev.m == og.m == 8 * T * 5 + 28
+    k = np.linspace(-0.6, 0.6, 7)
+    g, jac = dev.eval_g_jac(k)
+    gr, jr = og.eval_g_jac(k)
+    assert np.abs(g[0] - gr).max() <= G_TOL and np.abs(jac[0] - jr).max() <= J_TOL
+    # the re-check looks at links 0..n-2 = 0..5 of the 8 (CMP/NLPclass.cu:391)
+    ok = g.copy()
+    ok[0, :8 * T * 5] = -1.0
+    bad = ok.copy()
+    bad[0, 6 * T * 5] = 1.0
+    assert dev.finalize_solution(ok)[0] and dev.finalize_solution(bad)[0]
+    bad[0, 6 * T * 5 - 1] = 1.0
+    assert not dev.finalize_solution(bad)[0]
 
 
 @pytest.mark.gpu
