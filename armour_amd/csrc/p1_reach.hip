@@ -36,6 +36,7 @@ constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work
 // so three waves can run different operators at the same time without sharing allocator state.
 constexpr int kRoles = 3;
 constexpr int kPartFirst[kRoles] = {0, 10, 24}, kPartCount[kRoles] = {10, 14, 24};  // of the 48 slots of a 3-wave block
+constexpr int kRoleN = 2;  // the role that computes (and later frees) the moments N_i (measured with it in role 0 / 1 / 2 and the forward kinematics split off: 2.06 / 2.01 / 1.95 ms)
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
 constexpr int kMaxSlots = 192;
@@ -62,6 +63,10 @@ struct P1Cfg {
     // second launch with larger buffers, instead of failing the whole launch.
     const int* items;
     int n_items;
+    // fk_items > 0 (small launches with idle CUs): work items [n_items, n_items + fk_items) redo the JRS rotations of item
+    // (it - n_items) and run ONLY its forward kinematics, on a CU of their own; the first n_items then skip it.  The
+    // forward kinematics shares nothing with the RNEA but the read-only JRS, and role 2 is the busiest of the three.
+    int fk_items;
     int* retry_list;
     unsigned* retry_count;
 };
@@ -462,7 +467,7 @@ __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, 
 // JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67).
 // The joints are independent of each other: joint i is built by role i % 3 (with that role's scratch slots), so a 3-wave
 // block builds three joints at a time.  The caller follows with a block barrier.
-__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
+__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
@@ -487,8 +492,8 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
             build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
             set_const(c.w, c.rpy(role), rp, nullptr);
             mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
-            // qd_des, qda_des, qdda_des (:176-243); the ARMTD chain stops at the forward kinematics and has none
-            if (cf.mode != ARMOUR_MODE_ARMTD) {
+            // qd_des, qda_des, qdda_des (:176-243); a chain that stops at the forward kinematics has none
+            if (!kin_only) {
             {
                 const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
                 const double co2[2] = {js.qd_k, js.qd_e};
@@ -510,13 +515,15 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t) {
         }
         transpose33(c.w, c.Rt(i), c.R(i));
         set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
-        // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
-        double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
-        double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
-        double ii[9];
-        for (int e = 0; e < 9; e++) ii[e] = cf.rb.inertia_uncertainty * fabs(cf.rb.inertia[9 * i + e]);
-        set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+        if (!kin_only) {
+            // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
+            double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
+            double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
+            double ii[9];
+            for (int e = 0; e < 9; e++) ii[e] = cf.rb.inertia_uncertainty * fabs(cf.rb.inertia[9 * i + e]);
+            set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+        }
         // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
         for (int j = 0; j < 3; j++) {
             const uint64_t key = 1ull << ((j + 2) * n);
@@ -613,7 +620,7 @@ __device__ PZW_NOINLINE void fk_step(Chain& c, FkState& f, int i, int b, int t) 
 // Work of one time step is dealt to three ROLES.  In a 3-wave block role r is wave r and the roles run concurrently; in a
 // 1-wave block the one wave plays all three in turn.  Every operator is executed by exactly one wave with the same
 // operands either way, so the results do not depend on the block shape.
-//   forward, step s = 0..J:   role 0  linear_acc_s     role 1  w_s, w_aux_s, wdot_s     role 2  F_{s-1}, N_{s-1}, FK of joint s
+//   forward, step s = 0..J:   role 0  linear_acc_s     role 1  w_s, w_aux_s, wdot_s     role 2  F_{s-1}, N_{s-1}, FK of joint s (unless split off)
 //   (F and N of a joint only feed the backward pass, so they trail the state recursion by one step: one barrier per joint)
 //   backward, joint i  phase 1:  role 0  R n, com x F_i          role 1  R f, p x (R f)
 //                      phase 2:  role 0  n_i, u_i                role 1  f_i
@@ -625,7 +632,8 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
     Wave& w = c.w;
     const int J = c.J;
     FkState fk;
-    if (c.is(2)) { c.role = 2; fk_begin(c, fk); }
+    const bool with_fk = cf.fk_items == 0;  // otherwise another block runs this item's forward kinematics
+    if (c.is(2) && with_fk) { c.role = 2; fk_begin(c, fk); }
     if (c.is(1)) {
         c.role = 1;
         PZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV();
@@ -676,6 +684,15 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
             }
             c.post(MB_WV, nw); c.post(MB_WDOT, nd); c.post(MB_WAUX, na);
         }
+        if (c.is(kRoleN) && s >= 1) {  // line 29 for joint s-1: N = I * wdot + cross(w_aux, I * w)
+            c.role = kRoleN;
+            const PZ I = c.inertia(s - 1);
+            PZ t1 = c.mulMV(I, wdot);
+            PZ t2 = c.mulMV(I, wv);
+            PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+            PZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
+            c.post(MB_N + s - 1, N);
+        }
         if (c.is(2)) {
             c.role = 2;
             if (s >= 1) {  // lines 23 & 27 for joint s-1: F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
@@ -687,21 +704,13 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
                 PZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
                 c.post(MB_F + s - 1, F);
             }
-            if (s >= 1) {  // line 29 for joint s-1: N = I * wdot + cross(w_aux, I * w)
-                const PZ I = c.inertia(s - 1);
-                PZ t1 = c.mulMV(I, wdot);
-                PZ t2 = c.mulMV(I, wv);
-                PZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
-                PZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
-                c.post(MB_N + s - 1, N);
-            }
-            if (s < J) fk_step(c, fk, s, b, t);
+            if (s < J && with_fk) fk_step(c, fk, s, b, t);
         }
         c.bar();
         if (c.is(1)) { c.role = 1; c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); }  // joint s-1's state: every reader is done
         if (c.is(0)) { c.role = 0; c.freeVs(lacc); }
     }
-    if (c.is(2)) { c.role = 2; c.freeVs(fk.T); }
+    if (c.is(2) && with_fk) { c.role = 2; c.freeVs(fk.T); }
     if (c.is(0)) { c.role = 0; PZ nn = c.allocV(); set_const(w, nn, nullptr, nullptr); c.post(MB_NN, nn); }
     if (c.is(1)) { c.role = 1; PZ f = c.allocV(); set_const(w, f, nullptr, nullptr); c.post(MB_FF, f); }
     c.bar();
@@ -740,7 +749,8 @@ __device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
         c.bar();
         // what the other role was still reading in phase 2
         if (c.is(1)) { c.freeVs(a2); c.freeVs(c2); }
-        if (c.is(2)) { c.freeVs(Ni); c.freeVs(Fi); }
+        if (c.is(kRoleN)) c.freeVs(Ni);
+        if (c.is(2)) c.freeVs(Fi);
     }
     {
         const PZ nn = c.take(MB_NN), f = c.take(MB_FF);
@@ -841,7 +851,9 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
     c.w.thr = cf.pr.simplify_threshold;
     c.w.lane = threadIdx.x & 63;
     if (c.w.lane < ST_WORDS) c.w.lstat[c.w.lane] = 0;
-    for (int it = blockIdx.x; it < cf.n_items; it += gridDim.x) {
+    for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
+        const bool fk_only = it0 >= cf.n_items || cf.mode == ARMOUR_MODE_ARMTD;
+        const int it = it0 >= cf.n_items ? it0 - cf.n_items : it0;
         const int item = cf.items ? cf.items[it] : it;
         const int b = item / cf.T, t = item - b * cf.T;
         const int err_before = c.w.lstat[ST_ERR];  // (the retry list is only used with NW = 1)
@@ -853,26 +865,29 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
 #ifdef P1_PROFILE
         const long long ph0 = clock64();
 #endif
-        build_jrs(c, b, t);
+        build_jrs(c, b, t, fk_only);
         __syncthreads();
 #ifdef P1_PROFILE
         const long long ph1 = clock64();
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
-        if (cf.mode == ARMOUR_MODE_ARMTD) {
-            // CMP/armtd_main.cu:141-156: forward kinematics and the link tables, nothing else (launched with one wave)
-            FkState fk;
-            c.role = 2;
-            fk_begin(c, fk);
-            for (int i = 0; i < c.J; i++) fk_step(c, fk, i, b, t);
-            c.freeVs(fk.T);
+        if (fk_only) {
+            // forward kinematics and the link tables, nothing else: the whole ARMTD chain (CMP/armtd_main.cu:141-156), or
+            // the forward-kinematics half of a split ARMOUR item.  A single role: one wave works.
+            if (c.is(2)) {
+                FkState fk;
+                c.role = 2;
+                fk_begin(c, fk);
+                for (int i = 0; i < c.J; i++) fk_step(c, fk, i, b, t);
+                c.freeVs(fk.T);
+            }
         } else {
             run_rnea(c, u_nom, b, t);
         }
 #ifdef P1_PROFILE
         const long long ph3 = clock64();
 #endif
-        if (cf.mode != ARMOUR_MODE_ARMTD && c.is(0)) finish_torque(c, u_nom, b, t);
+        if (!fk_only && c.is(0)) finish_torque(c, u_nom, b, t);
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
             // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
@@ -1202,7 +1217,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const int per_cu = three ? 1 : waves_per_cu(cap);
-        const int waves = std::min(n_items, prop.multiProcessorCount * per_cu);
+        // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
+        static const int split_env = [] { const char* e = getenv("ARMOUR_P1_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
+        const bool split = split_env >= 0 ? (split_env != 0 && three) : (three && 2 * n_items <= prop.multiProcessorCount);
+        const int fk_items = split ? n_items : 0;
+        const int waves = std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
             wk->arena = nullptr;
@@ -1222,7 +1241,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
         cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
         cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-        cf.items = d_items; cf.n_items = n_items;
+        cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
