@@ -8,6 +8,9 @@
 //
 //   armour_hip_mex('create', T)                                    T = NUM_TIME_STEPS (RT/Parameters.h:17)
 //   armour_hip_mex('set_problem', q0, qd0, qdd0, q_des, Z)         Z = 12 x nObs, columns = obstacle zonotope Z(:)
+//   armour_hip_mex('set_problem_armtd', q0, qd0, q_des, JRS, k_range, Z)   ARMTD comparison mode: JRS = T x 6 x 7
+//                    (per joint the columns c_cos g_cos r_cos c_sin g_sin r_sin that KSI/uarmtd_planner.m:277-312 writes
+//                    into armtd.in), k_range = 7 x 1; the commands below then follow CMP/NLPclass.cu
 //   [g, jac]             = armour_hip_mex('eval', k)               g: m x 1, jac: n x m (gradient of row i in column i)
 //   [x_l, x_u, g_l, g_u] = armour_hip_mex('bounds')
 //   [f, grad_f]          = armour_hip_mex('cost', k)
@@ -57,6 +60,16 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need(mxGetNumberOfElements(prhs[5]) % 12 == 0, "Z must be 12 x nObs");
         const int nObs = (int)(mxGetNumberOfElements(prhs[5]) / 12);
         chk(armour_set_problems(g_h, 1, nObs, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5])));
+        return;
+    }
+    if (!strcmp(cmd, "set_problem_armtd")) {
+        need(nrhs == 7, "set_problem_armtd needs q0, qd0, q_des, JRS, k_range, Z");
+        for (int i = 1; i <= 3; i++) need(mxGetNumberOfElements(prhs[i]) == 7, "state vectors must have 7 entries");
+        need(mxGetNumberOfElements(prhs[4]) % 42 == 0 && mxGetNumberOfElements(prhs[5]) == 7, "JRS must be T x 6 x 7 and k_range 7 x 1");
+        need(mxGetNumberOfElements(prhs[6]) % 12 == 0, "Z must be 12 x nObs");
+        const int nObs = (int)(mxGetNumberOfElements(prhs[6]) / 12);
+        // column-major T x 6 x 7 is the [joint][row][t] order of the C ABI; its T must be the T of 'create' (the library checks sizes only through it)
+        chk(armour_set_problems_armtd(g_h, 1, nObs, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), mxGetPr(prhs[6])));
         return;
     }
     int B, n, m;
