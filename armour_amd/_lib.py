@@ -63,7 +63,7 @@ EXPORTS = [
     "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
     "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_set_problems_armtd", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
-    "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
+    "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_prepare_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
@@ -132,6 +132,7 @@ def load():
     L.armour_eval_g_jac.argtypes = [vp, dp, dp, dp]
     L.armour_eval_g_jac_device.argtypes = [vp, vp, vp, vp, vp]
     L.armour_eval_g_jac_device_steps.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+    L.armour_prepare_steps.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.armour_eval_g_jac_device_multi.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     L.armour_desired_trajectory.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_double, dp, C.c_double, dp, dp, dp]
     L.armour_robust_controller.argtypes = [C.POINTER(ArmourRobot), C.c_double, dp, C.c_double, C.c_double, C.c_double, C.c_int32, dp, dp, dp, dp, dp, dp, dp, dp]

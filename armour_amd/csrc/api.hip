@@ -187,10 +187,16 @@ double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes) {
     return static_cast<double*>(p);
 }
 
+static void drop_step_graphs(ArmourPlanner* h) {
+    for (auto& g : h->step_graphs) (void)hipGraphExecDestroy(g.exec);
+    h->step_graphs.clear();
+}
+
 extern "C" void armour_destroy(ArmourPlanner* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_step_graphs(h);
     for (int i = 0; i < 6; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds);
     dev_free(&h->d_jrs);
@@ -213,6 +219,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
     h->bounds_on_device = false;
+    drop_step_graphs(h);  // they bake in the tables of the previous problem set
     int rc = ensure_capacity(h, B, O);
     if (rc != ARMOUR_OK) return rc;
     h->B = B; h->O = O; h->Q = h->J * h->T * O;
@@ -471,17 +478,72 @@ extern "C" int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, dou
     return armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, d_g, d_jac, stream ? (hipStream_t)stream : h->stream);
 }
 
-extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
-                                              void* stream) {
-    NEED_READY(h);
-    if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+static int enqueue_steps(ArmourPlanner* h, const double* d_k, int steps, double* d_g, double* d_jac, hipStream_t st) {
     const P2Tables tb = armour_make_tables(h);
-    const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const size_t stride = (size_t)h->B * h->n;
     for (int s = 0; s < steps; s++) {
         int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k + (size_t)s * stride, d_g, d_jac, st);
         if (rc != ARMOUR_OK) return rc;
     }
+    return ARMOUR_OK;
+}
+
+// The `steps` launches as ONE instantiated hipGraph (a chain: each launch still waits for the one before).  Submitting a
+// kernel costs the host 2.4-3.3 us per hipLaunchKernel on this platform -- as long as a small launch runs -- while the
+// nodes of a graph are pre-built AQL packets the command processor takes back to back (1.55 us per empty node measured,
+// tools/micro/launch_floor.hip).  The graph bakes in the pointers and the tables: it is keyed on (d_k, steps, d_g, d_jac)
+// and dropped with the problem set.
+static int steps_graph(ArmourPlanner* h, const double* d_k, int steps, double* d_g, double* d_jac, hipGraphExec_t* out) {
+    h->graph_clock++;
+    for (auto& g : h->step_graphs)
+        if (g.d_k == d_k && g.steps == steps && g.d_g == d_g && g.d_jac == d_jac) { g.last_use = h->graph_clock; *out = g.exec; return ARMOUR_OK; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_steps(h, d_k, steps, d_g, d_jac, h->stream);
+    const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc != ARMOUR_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { armour_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return ARMOUR_EDEVICE; }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { armour_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return ARMOUR_EDEVICE; }
+    if (h->step_graphs.size() >= 4) {  // keep the four most recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < h->step_graphs.size(); i++) if (h->step_graphs[i].last_use < h->step_graphs[lru].last_use) lru = i;
+        (void)hipGraphExecDestroy(h->step_graphs[lru].exec);
+        h->step_graphs.erase(h->step_graphs.begin() + lru);
+    }
+    h->step_graphs.push_back({d_k, steps, d_g, d_jac, exec, h->graph_clock});
+    *out = exec;
+    return ARMOUR_OK;
+}
+
+static bool steps_use_graph(int steps) {
+    static const int min_steps = [] { const char* e = getenv("ARMOUR_STEPS_GRAPH"); return e ? atoi(e) : 2; }();  // development switch: 0 = never
+    return min_steps > 0 && steps >= min_steps;
+}
+
+extern "C" int armour_prepare_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac) {
+    NEED_READY(h);
+    if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+    if (!steps_use_graph(steps)) return ARMOUR_OK;
+    hipGraphExec_t exec;
+    return steps_graph(h, d_k, steps, d_g, d_jac, &exec);
+}
+
+extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
+                                              void* stream) {
+    NEED_READY(h);
+    if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
+    if (steps == 0 || (!d_g && !d_jac)) return ARMOUR_OK;
+    const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (!steps_use_graph(steps)) return enqueue_steps(h, d_k, steps, d_g, d_jac, st);
+    hipGraphExec_t exec;
+    const int rc = steps_graph(h, d_k, steps, d_g, d_jac, &exec);
+    if (rc != ARMOUR_OK) return rc;
+    HIPCHK(hipGraphLaunch(exec, st));
     return ARMOUR_OK;
 }
 

@@ -132,6 +132,10 @@ struct ArmourPlanner {
     long long sum_link = 0, sum_torque = 0;
     // P1 workspace (p1_reach.hip)
     void* p1 = nullptr;
+    // instantiated graphs of armour_eval_g_jac_device_steps, valid for one problem set (api.hip)
+    struct StepsGraph { const double* d_k; int steps; double* d_g; double* d_jac; hipGraphExec_t exec; unsigned long long last_use; };
+    std::vector<StepsGraph> step_graphs;
+    unsigned long long graph_clock = 0;
 };
 
 // p2_eval.hip

@@ -228,6 +228,10 @@ class ArmourNLP:
         """`steps` back-to-back fused evaluations (d_k holds [steps][B][n]); asynchronous."""
         check(self.L.armour_eval_g_jac_device_steps(self.h, d_k, steps, d_g, d_jac, stream))
 
+    def prepare_steps(self, d_k, steps, d_g, d_jac):
+        """Build (without launching) the graph eval_g_jac_device_steps uses for these arguments."""
+        check(self.L.armour_prepare_steps(self.h, d_k, steps, d_g, d_jac))
+
     def eval_g_jac_device_multi(self, d_k, points, d_g, d_jac, stream=0):
         """`points` evaluations of the same problems in one launch: d_k [points][B][n] -> d_g [points][B][m],
         d_jac [points][B][m][n]; asynchronous.  Bit-identical to `points` single launches."""

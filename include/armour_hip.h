@@ -113,9 +113,14 @@ int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, double* jac)
 int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, double* d_jac, void* stream);
 /* `steps` consecutive fused evaluations enqueued back to back on `stream` without host synchronisation:
  * step s reads d_k + s*B*n (d_k holds [steps][B][n]) and overwrites d_g / d_jac.  One kernel launch per step
- * (the IPOPT iterate sequence of RT/armour_main.cu:273 with the solver's own arithmetic removed). */
+ * (the IPOPT iterate sequence of RT/armour_main.cu:273 with the solver's own arithmetic removed), executed in
+ * order.  For steps >= 2 the launches are submitted as one instantiated hipGraph -- a chain of `steps` kernel
+ * nodes -- built on the first call with these (d_k, steps, d_g, d_jac) and reused until the next
+ * armour_set_problems*; the CONTENT of d_k may change between calls, the pointers are part of the graph.
+ * armour_prepare_steps builds that graph without launching it, so that a timed region holds launches only. */
 int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
                                    void* stream);
+int armour_prepare_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac);
 /* `points` evaluations of the SAME problems in ONE kernel launch: point s reads d_k + s*B*n and writes
  * d_g + s*B*m, d_jac + s*B*m*n (d_k [points][B][n], d_g [points][B][m], d_jac [points][B][m][n]; d_g / d_jac may be
  * NULL).  Every block keeps its share of the plane and PZ tables in registers across the points, so the tables are

@@ -192,6 +192,21 @@ def test_multi_point_launch_is_bit_identical(B, O, points):
     nlp.eval_g_jac_device_steps(d_k.data_ptr(), points, d_g1.data_ptr(), d_j1.data_ptr(), st.cuda_stream)
     st.synchronize()
     assert torch.equal(d_g1, d_g[-1]) and torch.equal(d_j1, d_j[-1])
+    # the steps go out as one instantiated graph keyed on the pointers: new CONTENT in the same buffers is picked up ...
+    d_k.copy_(torch.flip(d_k, dims=[0]))
+    nlp.prepare_steps(d_k.data_ptr(), points, d_g1.data_ptr(), d_j1.data_ptr())
+    nlp.eval_g_jac_device_steps(d_k.data_ptr(), points, d_g1.data_ptr(), d_j1.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(d_g1, d_g[0]) and torch.equal(d_j1, d_j[0])
+    d_k.copy_(torch.flip(d_k, dims=[0]))
+    # ... and a new problem set drops the graph (it bakes the tables in)
+    nlp.debug_load_tables(stack("q0")[::-1].copy(), stack("qd0")[::-1].copy(), stack("qdd0")[::-1].copy(), stack("q_des")[::-1].copy(), oracle_tables(oracles[::-1]))
+    nlp.eval_g_jac_device_steps(d_k.data_ptr(), points, d_g1.data_ptr(), d_j1.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    g_new, j_new = nlp.eval_g_jac(ks[-1])
+    assert np.array_equal(d_g1.cpu().numpy(), g_new) and np.array_equal(d_j1.cpu().numpy(), j_new)
+    if B > 1 and O > 0:
+        assert not torch.equal(d_g1, d_g[-1])
     # and against the oracle at one of the points
     g_ref, jac_ref = oracles[0].eval_g_jac(ks[-1, 0])
     assert np.abs(d_g[-1, 0].cpu().numpy() - g_ref).max() <= G_TOL
