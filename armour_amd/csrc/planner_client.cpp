@@ -1,0 +1,69 @@
+// armour_main / armtd_main -- drop-ins for the two planner executables of the reference (RT/armour_main.cu,
+// CMP/armtd_main.cu) over its file protocol (KSI/uarmtd_planner.m:158-219 and :257-345).  This source builds both; the
+// name it is started under selects the protocol.
+//
+//   armour_main [buffer_dir] [num_time_steps=128]      one planning iteration: armour.in -> armour.out + 4 files
+//   armtd_main  [buffer_dir] [num_time_steps=100]      one planning iteration: armtd.in  -> armtd.out  + 3 files
+//   armour_main --serve [buffer_dir] [T_armour] [T_armtd] [--idle-seconds S]     stay resident for both of the above
+//   armour_main --quit  [buffer_dir]                                             stop the resident planner
+//
+// The reference compiles the buffer path in (BufferPath.h, kinova_src/initialize.m:32-36); here it is the first
+// argument (default "buffer/").  Exit code 0 = ran (even if no feasible plan), non-zero = error with "-1" in the .out
+// file -- what uarmtd_planner.m:196-208 tests.
+//
+// This process never touches the GPU: it forwards the iteration to the resident planner listening on
+// <buffer_dir>/armour.sock if there is one, and otherwise starts armour_worker (next to this executable) as a child and
+// returns its exit code.  File formats and conventions live in cli_common.h, which only the worker includes.
+#include <libgen.h>
+#include <spawn.h>
+#include <sys/wait.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "cli_socket.h"
+
+extern char** environ;
+
+// replace == true (only for --serve): become the worker, so that whoever started this process holds the resident
+// planner's pid; this process has not touched the GPU.  Falls through to spawn-and-wait if the exec is refused.
+static int run_worker(const std::string& self, const char* kind, int argc, char** argv, bool replace) {
+    std::string path = self;
+    const size_t slash = path.find_last_of('/');
+    path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "armour_worker";
+    std::vector<char*> av;
+    av.push_back(const_cast<char*>(path.c_str()));
+    av.push_back(const_cast<char*>(kind));
+    for (int i = 1; i < argc; i++) av.push_back(argv[i]);
+    av.push_back(nullptr);
+    if (replace) execv(path.c_str(), av.data());
+    pid_t pid;
+    if (posix_spawn(&pid, path.c_str(), nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "        HIP & C++: cannot start %s\n", path.c_str()); return 1; }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0) {}
+    return WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+}
+
+int main(int argc, char** argv) {
+    std::string self = argv[0];
+    std::string base = self.substr(self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/') + 1);
+    const char* kind = base.rfind("armtd", 0) == 0 ? "armtd" : "armour";
+    bool serve = false, quit = false;
+    std::vector<const char*> pos;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--serve") serve = true;
+        else if (a == "--quit") quit = true;
+        else if (a == "--idle-seconds") i++;
+        else pos.push_back(argv[i]);
+    }
+    const std::string dir = cli::buffer_dir(pos.size() > 0 ? pos[0] : nullptr);
+    int rc = 1;
+    if (quit) return cli::try_resident(dir, "quit", 0, &rc) ? rc : 1;
+    if (!serve) {
+        const int T = pos.size() > 1 ? atoi(pos[1]) : (kind[3] == 'o' ? 128 : 100);  // RT/Parameters.h:17, CMP/Parameters.h:17
+        if (cli::try_resident(dir, kind, T, &rc)) return rc;
+    }
+    return run_worker(self, kind, argc, argv, serve);
+}

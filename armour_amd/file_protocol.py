@@ -116,7 +116,7 @@ def read_armour_out(path, n=7):
 def run_planning_iteration(nlp, dirname, k=None):
     """One pass over the file protocol with the device library: read armour.in, build the reach sets, solve the NLP
     (armour_solve; or evaluate at a caller-supplied `k`) and write the five output files -- what the `armour_main`
-    binary (armour_amd/csrc/armour_main.cpp) does natively."""
+    binary (armour_amd/csrc/cli_common.h) does natively."""
     import time
     t0 = time.perf_counter()
     p = parse_armour_in(os.path.join(dirname, IN_NAME), n=nlp.n)
@@ -133,3 +133,45 @@ def run_planning_iteration(nlp, dirname, k=None):
     ms = (time.perf_counter() - t0) * 1e3
     write_outputs(dirname, x if feasible else None, ms, cen, nlp.link_generators()[0], nlp.torque_radius()[0], g[0])
     return feasible
+
+
+class ResidentPlanner:
+    """`armour_main --serve <dir>` as a child process: the planner stays resident (GPU context, code objects, handles) and
+    the per-iteration executables `armour_main <dir>` / `armtd_main <dir>` only forward to it over <dir>/armour.sock
+    (armour_amd/csrc/cli_common.h).  Use as a context manager around a simulation that spawns the executables."""
+
+    def __init__(self, dirname, T_armour=128, T_armtd=100, exe=None, start_timeout_s=300.0):
+        import subprocess
+        import time
+        here = os.path.dirname(os.path.abspath(__file__))
+        self.exe = exe or os.path.join(here, "bin", "armour_main")
+        self.dir = str(dirname)
+        self.sock = os.path.join(self.dir, "armour.sock")
+        if os.path.exists(self.sock):
+            os.remove(self.sock)
+        self.proc = subprocess.Popen([self.exe, "--serve", self.dir, str(T_armour), str(T_armtd)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        t0 = time.time()
+        while not os.path.exists(self.sock):
+            if self.proc.poll() is not None:
+                raise RuntimeError("resident planner exited: " + (self.proc.stdout.read() or ""))
+            if time.time() - t0 > start_timeout_s:
+                self.proc.kill()
+                raise RuntimeError("resident planner did not come up")
+            time.sleep(0.02)
+
+    def stop(self):
+        import subprocess
+        if self.proc.poll() is None:
+            subprocess.run([self.exe, "--quit", self.dir], timeout=60)
+            try:
+                self.proc.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()   # this exact child only
+                self.proc.wait()
+        return self.proc.returncode
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()

@@ -161,3 +161,39 @@ def test_desired_trajectory_matches_the_matlab_bernstein_formulation():
     assert np.array_equal(hq, q0) and not hqd.any() and not hqdd.any()
     hq, hqd, _ = desired_trajectory(q0, qd0, qdd0, None, 0.6, previous=prev)
     assert np.array_equal(hq, q0) and not hqd.any()
+
+
+def test_resident_planner_protocol_without_a_gpu(tmp_path):
+    """The socket protocol of `armour_main --serve` (armour_amd/csrc/cli_common.h), with no handles created up front so
+    that it runs on a CPU-only host: requests reach the resident process, failures come back as the reference's
+    conventions (-1 in the .out file, non-zero exit code), `--quit` ends it and removes the socket."""
+    import os
+    import subprocess
+    import time
+    from conftest import ROOT
+    bindir = os.path.join(ROOT, "armour_amd", "bin")
+    exe, exe2 = os.path.join(bindir, "armour_main"), os.path.join(bindir, "armtd_main")
+    if not (os.path.exists(exe) and os.path.exists(exe2)):
+        pytest.skip("executables not built (make -C armour_amd/csrc)")
+    daemon = subprocess.Popen([exe, "--serve", str(tmp_path), "0", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        t0 = time.time()
+        while not os.path.exists(tmp_path / "armour.sock"):
+            assert daemon.poll() is None and time.time() - t0 < 30
+            time.sleep(0.01)
+        for binary, out in ((exe, "armour.out"), (exe2, "armtd.out")):
+            r = subprocess.run([binary, str(tmp_path)], capture_output=True, text=True, timeout=60)
+            assert r.returncode == 1 and open(tmp_path / out).read().split() == ["-1"]
+            assert r.stdout == "" and r.stderr == ""          # the iteration ran in the resident process, not here
+        assert subprocess.run([exe, "--quit", str(tmp_path)], timeout=60).returncode == 0
+        assert daemon.wait(timeout=30) == 0 and not os.path.exists(tmp_path / "armour.sock")
+        log = daemon.stdout.read()
+        assert log.count("Error reading input files") == 2 and "listening" in log
+        # nobody listening any more: the executable runs the iteration itself (and reports the missing input)
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "Error reading input files" in r.stderr
+        assert subprocess.run([exe, "--quit", str(tmp_path)], timeout=60).returncode == 1
+    finally:
+        if daemon.poll() is None:
+            daemon.kill()
+            daemon.wait()

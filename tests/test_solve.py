@@ -140,3 +140,47 @@ def test_cli_drop_in_for_armour_main(tmp_path, sample_problem):
     os.remove(tmp_path / fp.IN_NAME)
     bad = subprocess.run([exe, str(tmp_path), "128"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and open(tmp_path / "armour.out").read().split()[0] == "-1"
+
+
+def test_resident_planner_serves_both_file_protocols(tmp_path, sample_problem):
+    """`armour_main --serve`: the per-iteration executables forward to the resident process and produce the same files
+    as their stand-alone runs, without the GPU start-up in every iteration; `--quit` ends it and they fall back."""
+    import time
+    from armour_amd import file_protocol as fp
+    from armour_amd.worlds import synthetic_offline_jrs
+    bindir = os.path.join(ROOT, "armour_amd", "bin")
+    exe, exe2 = os.path.join(bindir, "armour_main"), os.path.join(bindir, "armtd_main")
+    p = sample_problem
+    fp.write_armour_in(tmp_path / fp.IN_NAME, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    jrs, kr = synthetic_offline_jrs(p["qd0"], 100)
+    fp.write_armtd_in(tmp_path / fp.ARMTD_IN_NAME, p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
+    # stand-alone runs first
+    assert subprocess.run([exe, str(tmp_path), "128"], capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([exe2, str(tmp_path)], capture_output=True, timeout=300).returncode == 0
+    names = ["armour.out", "armour_constraints.out", "armour_joint_position_center.out", "armour_joint_position_radius.out", "armour_control_input_radius.out",
+             "armtd.out", "armtd_constraints.out", "armtd_joint_position_center.out", "armtd_joint_position_radius.out"]
+    alone = {nm: open(tmp_path / nm).read().split() for nm in names}
+    with fp.ResidentPlanner(tmp_path, 128, 100) as rp:
+        for rep in range(3):
+            for nm in names:
+                os.remove(tmp_path / nm)
+            t0 = time.perf_counter()
+            assert subprocess.run([exe, str(tmp_path), "128"], capture_output=True, timeout=120).returncode == 0
+            wall = time.perf_counter() - t0
+            assert subprocess.run([exe2, str(tmp_path)], capture_output=True, timeout=120).returncode == 0
+            for nm in names:
+                got = open(tmp_path / nm).read().split()
+                if nm in ("armour.out", "armtd.out"):     # last entry is the time in ms
+                    assert got[:-1] == alone[nm][:-1] and 0 < float(got[-1]) < 100.0, (nm, got[-1])
+                else:
+                    assert got == alone[nm], nm
+        assert wall < 1.0   # process start + forward + a ~3 ms iteration; the stand-alone run needs the GPU start-up
+        # error conventions through the resident planner: missing input -> -1 and a non-zero exit code
+        os.remove(tmp_path / fp.IN_NAME)
+        bad = subprocess.run([exe, str(tmp_path), "128"], capture_output=True, timeout=60)
+        assert bad.returncode != 0 and open(tmp_path / "armour.out").read().split()[0] == "-1"
+        assert rp.proc.poll() is None
+    assert rp.proc.returncode == 0 and not os.path.exists(tmp_path / "armour.sock")
+    fp.write_armour_in(tmp_path / fp.IN_NAME, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert subprocess.run([exe, str(tmp_path), "128"], capture_output=True, timeout=300).returncode == 0   # no resident planner: runs itself
+    assert open(tmp_path / "armour.out").read().split()[:-1] == alone["armour.out"][:-1]
