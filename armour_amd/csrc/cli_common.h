@@ -217,8 +217,11 @@ inline int serve(const std::string& dir, int T_armour, int T_armtd, double idle_
     if (T_armour > 0 && get_handle(&s.armour, &s.armour_T, T_armour, &rb, &pr) != ARMOUR_OK) { fprintf(stderr, "armour_create: %s\n", armour_last_error()); return 1; }
     if (T_armtd > 0 && get_handle(&s.armtd, &s.armtd_T, T_armtd, &rb, &pr) != ARMOUR_OK) { fprintf(stderr, "armour_create: %s\n", armour_last_error()); return 1; }
     if (s.armour) {  // load the code objects and size the work buffers before the first real request
-        std::vector<double> z(rb.num_factors, 0.0), box = {2, 2, 2, 0.05, 0, 0, 0, 0.05, 0, 0, 0, 0.05};
-        (void)armour_set_problems(s.armour, 1, 1, z.data(), z.data(), z.data(), z.data(), box.data());
+        // (MAX_OBSTACLE_NUM = 40 boxes far away, RT/Parameters.h:22, so that no later request has to grow a device buffer)
+        const int O = 40;
+        std::vector<double> z(rb.num_factors, 0.0), boxes((size_t)O * 12, 0.0);
+        for (int o = 0; o < O; o++) { double* b = &boxes[(size_t)o * 12]; b[0] = b[1] = b[2] = 5.0 + o; b[3] = b[7] = b[11] = 0.05; }
+        (void)armour_set_problems(s.armour, 1, O, z.data(), z.data(), z.data(), z.data(), boxes.data());
         ArmourSolveOptions so;
         armour_solve_options_default(&so);
         so.max_iterations = 1;
