@@ -15,6 +15,9 @@
 //   [x_l, x_u, g_l, g_u] = armour_hip_mex('bounds')
 //   [f, grad_f]          = armour_hip_mex('cost', k)
 //   [k_opt, feasible, info] = armour_hip_mex('solve')              info = [cost; iterations; evaluations; status; ms]
+//   [c, G, Grest, expMat, id] = armour_hip_mex('pz', which, i, t)  reach-set PZ as CORA polyZonotope fields: which =
+//                    'link' | 'torque', i and t 1-based; polyZonotope_ROAHM(c, G, Grest, expMat, id) rebuilds it with the
+//                    ids 1..7 of jrs_info.k_id (PZM/create_jrs_online.m:225); same mapping as armour_amd/cora.py
 //   armour_hip_mex('destroy')
 #include <string.h>
 
@@ -103,6 +106,25 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             double* p = mxGetPr(plhs[2]);
             p[0] = r.cost; p[1] = r.iterations; p[2] = r.evaluations; p[3] = r.status; p[4] = r.time_ms;
         }
+    } else if (!strcmp(cmd, "pz")) {
+        char which[16];
+        need(nrhs == 4 && !mxGetString(prhs[1], which, sizeof(which)), "pz needs which ('link'|'torque'), i, t");
+        const int w = !strcmp(which, "torque") ? 1 : 0, sz = w ? 1 : 3;
+        const int i = (int)mxGetScalar(prhs[2]) - 1, t = (int)mxGetScalar(prhs[3]) - 1;
+        double cen[6];
+        const int cnt = armour_get_pz(g_h, 0, w, i, t, cen, nullptr, nullptr, 0);
+        chk(cnt);
+        uint64_t* keys = (uint64_t*)mxMalloc(sizeof(uint64_t) * (cnt > 0 ? cnt : 1));
+        mxArray* G = mxCreateDoubleMatrix(sz, cnt, mxREAL);  // column-major sz x cnt == the ABI's coeffs[cnt][sz]
+        chk(armour_get_pz(g_h, 0, w, i, t, cen, keys, mxGetPr(G), cnt));
+        plhs[0] = col(sz);
+        memcpy(mxGetPr(plhs[0]), cen, sz * sizeof(double));
+        mxArray* o[4] = {G, mxCreateDoubleMatrix(sz, sz, mxREAL), mxCreateDoubleMatrix(n, cnt, mxREAL), col(n)};
+        for (int e = 0; e < sz; e++) mxGetPr(o[1])[e * sz + e] = cen[sz + e];                         // Grest = diag(independent radius)
+        for (int mo = 0; mo < cnt; mo++) for (int f = 0; f < n; f++) mxGetPr(o[2])[mo * n + f] = (double)((keys[mo] >> (2 * f)) & 3);  // RT/PZsparse.h:8-21
+        for (int f = 0; f < n; f++) mxGetPr(o[3])[f] = f + 1;
+        mxFree(keys);
+        for (int k2 = 0; k2 < 4; k2++) { if (k2 + 1 < nlhs) plhs[k2 + 1] = o[k2]; else mxDestroyArray(o[k2]); }
     } else {
         mexErrMsgTxt("unknown command");
     }

@@ -324,6 +324,12 @@ class ArmourNLP:
         cnt = check(self.L.armour_get_pz(self.h, b, w, i, t, _dp(cen), keys.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(co), cap))
         return cen[:sz], cen[sz:], keys[:cnt], co[:cnt]
 
+    def polyzonotope(self, which, i, t, b=0):
+        """The same PZ as CORA polyZonotope fields (armour_amd/cora.py): dict(c, G, Grest, expMat, id)."""
+        from . import cora
+        c, ind, keys, co = self.pz(which, i, t, b=b)
+        return cora.to_polyzonotope(c, ind, keys, co, self.n)
+
     def table_sizes(self):
         out = (C.c_int64 * 4)()
         check(self.L.armour_get_table_sizes(self.h, out))
