@@ -539,12 +539,16 @@ extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_
     if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
     if (steps == 0 || (!d_g && !d_jac)) return ARMOUR_OK;
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    if (!steps_use_graph(steps)) return enqueue_steps(h, d_k, steps, d_g, d_jac, st);
-    hipGraphExec_t exec;
-    const int rc = steps_graph(h, d_k, steps, d_g, d_jac, &exec);
-    if (rc != ARMOUR_OK) return rc;
-    HIPCHK(hipGraphLaunch(exec, st));
-    return ARMOUR_OK;
+    // a graph only if armour_prepare_steps built one for exactly these arguments: a caller that slides its pointers
+    // from call to call would otherwise pay a capture + instantiate every time
+    if (steps_use_graph(steps))
+        for (auto& g : h->step_graphs)
+            if (g.d_k == d_k && g.steps == steps && g.d_g == d_g && g.d_jac == d_jac) {
+                g.last_use = ++h->graph_clock;
+                HIPCHK(hipGraphLaunch(g.exec, st));
+                return ARMOUR_OK;
+            }
+    return enqueue_steps(h, d_k, steps, d_g, d_jac, st);
 }
 
 extern "C" int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_k, int32_t points, double* d_g, double* d_jac,

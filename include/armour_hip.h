@@ -114,10 +114,11 @@ int armour_eval_g_jac_device(ArmourPlanner* h, const double* d_k, double* d_g, d
 /* `steps` consecutive fused evaluations enqueued back to back on `stream` without host synchronisation:
  * step s reads d_k + s*B*n (d_k holds [steps][B][n]) and overwrites d_g / d_jac.  One kernel launch per step
  * (the IPOPT iterate sequence of RT/armour_main.cu:273 with the solver's own arithmetic removed), executed in
- * order.  For steps >= 2 the launches are submitted as one instantiated hipGraph -- a chain of `steps` kernel
- * nodes -- built on the first call with these (d_k, steps, d_g, d_jac) and reused until the next
- * armour_set_problems*; the CONTENT of d_k may change between calls, the pointers are part of the graph.
- * armour_prepare_steps builds that graph without launching it, so that a timed region holds launches only. */
+ * order.
+ * armour_prepare_steps(h, d_k, steps, d_g, d_jac) builds an instantiated hipGraph of those launches -- a chain of
+ * `steps` kernel nodes -- without running it; later armour_eval_g_jac_device_steps calls with exactly these arguments
+ * submit that graph (no host work per step) until the next armour_set_problems*.  The CONTENT of d_k may change
+ * between calls, the pointers are part of the graph.  The four most recently used graphs are kept. */
 int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac,
                                    void* stream);
 int armour_prepare_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac);
