@@ -104,9 +104,16 @@ __global__ __launch_bounds__(64) void armour_controller_kernel(const CtlArgs* __
                                                                const double* __restrict__ q_des, const double* __restrict__ qd_des,
                                                                const double* __restrict__ qdd_des, double* __restrict__ u, double* __restrict__ tau,
                                                                double* __restrict__ v, int* __restrict__ status) {
+    // the models go to LDS first: a lone state is one lane working through ~10^4 dependent operations, and every model
+    // entry read from global memory would be a full-latency miss on that chain
+    __shared__ CtlArgs sa;
+    static_assert(sizeof(CtlArgs) % sizeof(double) == 0, "CtlArgs is copied as doubles");
+    for (unsigned i2 = threadIdx.x; i2 < sizeof(CtlArgs) / sizeof(double); i2 += blockDim.x)
+        reinterpret_cast<double*>(&sa)[i2] = reinterpret_cast<const double*>(ap)[i2];
+    __syncthreads();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const CtlArgs& a = *ap;
+    const CtlArgs& a = sa;
     const int n = a.md.n;
     double lq[ARMOUR_MAX_FACTORS], lqd[ARMOUR_MAX_FACTORS], lqdes[ARMOUR_MAX_FACTORS], lqddes[ARMOUR_MAX_FACTORS], lqdddes[ARMOUR_MAX_FACTORS];
     double lu[ARMOUR_MAX_FACTORS], lt[ARMOUR_MAX_FACTORS], lv[ARMOUR_MAX_FACTORS];
@@ -119,6 +126,42 @@ __global__ __launch_bounds__(64) void armour_controller_kernel(const CtlArgs* __
     if (!ok) atomicOr(status, 1);
 }
 
+// Per-thread cache across calls: the MEX gateway this replaces is called once per ODE step with ONE state, so the fixed
+// cost of a call matters more than the kernel.  Kept: the prepared models on the device (rebuilt only when the robot or the
+// controller parameters change), the device buffer, and a page-locked staging buffer so that a small call is one H2D
+// copy, one launch and one D2H copy on a private stream (first version: three hipMalloc / hipFree and ten blocking
+// copies per call, 1.7 ms; now tens of microseconds).
+struct CtlCache {
+    bool have_model = false;
+    ArmourRobot rb;
+    double eps = 0, Kr[ARMOUR_MAX_FACTORS] = {0}, alpha = 0, V_max = 0, r_thr = 0;
+    int n = 0, device = -1;
+    CtlArgs* d_args = nullptr;
+    double* d_buf = nullptr; size_t d_cap = 0;   // doubles
+    double* h_pin = nullptr; size_t h_cap = 0;   // doubles
+    hipStream_t stream = nullptr;
+    ~CtlCache() {
+        // (process exit: the runtime may already be gone; errors are ignored)
+        if (d_args) (void)hipFree(d_args);
+        if (d_buf) (void)hipFree(d_buf);
+        if (h_pin) (void)hipHostFree(h_pin);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+thread_local CtlCache g_ctl;
+
+// spin on the stream instead of sleeping in hipStreamSynchronize: a small call is tens of microseconds and an
+// interrupt-driven wake-up would dominate it (same reasoning as armour_eval_g_jac)
+int ctl_wait(hipStream_t st) {
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return ARMOUR_OK;
+        if (q != hipErrorNotReady) { armour_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+    }
+}
+
+constexpr size_t kStagedDoubles = (size_t)1 << 20;  // calls up to this many input doubles go through the page-locked buffer
+
 }  // namespace
 
 // C ABI: see include/armour_hip.h.  Host pointers; B states of n = robot->num_factors joints each, row-major [B][n].
@@ -126,40 +169,72 @@ extern "C" int armour_robust_controller(const ArmourRobot* robot, double model_u
                                         double r_norm_threshold, int32_t B, const double* q, const double* qd, const double* q_des,
                                         const double* qd_des, const double* qdd_des, double* u, double* tau, double* v) {
     if (!robot || !Kr || !q || !qd || !q_des || !qd_des || !qdd_des || !u || !tau || !v || B < 1) { armour_set_error("null or empty argument"); return ARMOUR_EINVAL; }
-    CtlArgs args;
-    memset(&args, 0, sizeof(args));
-    if (build_models(*robot, model_uncertainty, args.md, args.imd) != 0) { armour_set_error("unsupported robot model (joint axes / count)"); return ARMOUR_EINVAL; }
-    const int n = args.md.n;
-    for (int i = 0; i < n; i++) args.Kr[i] = Kr[i];
-    args.alpha = alpha; args.V_max = V_max; args.r_norm_threshold = r_norm_threshold;
-    const size_t bn = (size_t)B * n * sizeof(double);
-    CtlArgs* d_args = nullptr;
-    double* d_buf = nullptr;  // 5 inputs + 3 outputs
-    int* d_status = nullptr;
-    hipError_t e = hipMalloc((void**)&d_args, sizeof(CtlArgs));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_buf, 8 * bn);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_status, sizeof(int));
-    int rc = ARMOUR_OK, st = 0;
-    if (e == hipSuccess) {
-        const double* in[5] = {q, qd, q_des, qd_des, qdd_des};
-        e = hipMemcpy(d_args, &args, sizeof(args), hipMemcpyHostToDevice);
-        for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipMemcpy(d_buf + (size_t)k * B * n, in[k], bn, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(d_status, 0, sizeof(int));
-        if (e == hipSuccess) {
-            double* o = d_buf + (size_t)5 * B * n;
-            hipLaunchKernelGGL(armour_controller_kernel, dim3((B + 63) / 64), dim3(64), 0, 0, d_args, B, d_buf, d_buf + (size_t)B * n, d_buf + (size_t)2 * B * n,
-                               d_buf + (size_t)3 * B * n, d_buf + (size_t)4 * B * n, o, o + (size_t)B * n, o + (size_t)2 * B * n, d_status);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpy(u, o, bn, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(tau, o + (size_t)B * n, bn, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(v, o + (size_t)2 * B * n, bn, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(&st, d_status, sizeof(int), hipMemcpyDeviceToHost);
-        }
+    CtlCache& c = g_ctl;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (c.device != dev) {  // first call of this thread, or the caller switched devices: start over
+        if (c.d_args) { (void)hipFree(c.d_args); c.d_args = nullptr; }
+        if (c.d_buf) { (void)hipFree(c.d_buf); c.d_buf = nullptr; c.d_cap = 0; }
+        if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+        c.have_model = false;
+        c.device = dev;
     }
-    if (e != hipSuccess) { armour_set_error("armour_robust_controller: %s", hipGetErrorString(e)); rc = ARMOUR_EDEVICE; }
-    else if (st) { armour_set_error("nominal model output falls outside interval output (robust_controller.cpp:88-94)"); rc = ARMOUR_ESTATE; }
-    if (d_args) (void)hipFree(d_args);
-    if (d_buf) (void)hipFree(d_buf);
-    if (d_status) (void)hipFree(d_status);
-    return rc;
+    if (!c.stream) HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.d_args) HIPCHK(hipMalloc((void**)&c.d_args, sizeof(CtlArgs)));
+    const int nf = robot->num_factors;
+    bool same = c.have_model && memcmp(&c.rb, robot, sizeof(ArmourRobot)) == 0 && c.eps == model_uncertainty && c.alpha == alpha && c.V_max == V_max &&
+                c.r_thr == r_norm_threshold;
+    for (int i = 0; same && i < nf; i++) same = c.Kr[i] == Kr[i];
+    if (!same) {
+        CtlArgs args;
+        memset(&args, 0, sizeof(args));
+        if (build_models(*robot, model_uncertainty, args.md, args.imd) != 0) { armour_set_error("unsupported robot model (joint axes / count)"); return ARMOUR_EINVAL; }
+        for (int i = 0; i < args.md.n; i++) args.Kr[i] = Kr[i];
+        args.alpha = alpha; args.V_max = V_max; args.r_norm_threshold = r_norm_threshold;
+        HIPCHK(hipMemcpy(c.d_args, &args, sizeof(args), hipMemcpyHostToDevice));
+        c.rb = *robot; c.eps = model_uncertainty; c.alpha = alpha; c.V_max = V_max; c.r_thr = r_norm_threshold; c.n = args.md.n;
+        for (int i = 0; i < c.n; i++) c.Kr[i] = Kr[i];
+        c.have_model = true;
+    }
+    const int n = c.n;
+    const size_t bn = (size_t)B * n, total = 8 * bn + 1;  // 5 inputs | 3 outputs | status word
+    if (total > c.d_cap) {
+        if (c.d_buf) { (void)hipFree(c.d_buf); c.d_buf = nullptr; c.d_cap = 0; }
+        HIPCHK(hipMalloc((void**)&c.d_buf, total * sizeof(double)));
+        c.d_cap = total;
+    }
+    double* d_in = c.d_buf;
+    double* d_out = c.d_buf + 5 * bn;
+    int* d_status = reinterpret_cast<int*>(c.d_buf + 8 * bn);
+    const double* in[5] = {q, qd, q_des, qd_des, qdd_des};
+    double* out[3] = {u, tau, v};
+    const bool staged = 5 * bn <= kStagedDoubles;
+    if (staged && total > c.h_cap) {
+        if (c.h_pin) { (void)hipHostFree(c.h_pin); c.h_pin = nullptr; c.h_cap = 0; }
+        HIPCHK(hipHostMalloc((void**)&c.h_pin, total * sizeof(double), hipHostMallocDefault));
+        c.h_cap = total;
+    }
+    if (staged) {
+        for (int k = 0; k < 5; k++) memcpy(c.h_pin + (size_t)k * bn, in[k], bn * sizeof(double));
+        HIPCHK(hipMemcpyAsync(d_in, c.h_pin, 5 * bn * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    } else {
+        for (int k = 0; k < 5; k++) HIPCHK(hipMemcpyAsync(d_in + (size_t)k * bn, in[k], bn * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    }
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(double), c.stream));
+    hipLaunchKernelGGL(armour_controller_kernel, dim3((B + 63) / 64), dim3(64), 0, c.stream, c.d_args, B, d_in, d_in + bn, d_in + 2 * bn, d_in + 3 * bn, d_in + 4 * bn,
+                       d_out, d_out + bn, d_out + 2 * bn, d_status);
+    HIPCHK(hipGetLastError());
+    int st = 0;
+    if (staged) {
+        HIPCHK(hipMemcpyAsync(c.h_pin + 5 * bn, d_out, (3 * bn + 1) * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        if (ctl_wait(c.stream) != ARMOUR_OK) return ARMOUR_EDEVICE;
+        for (int k = 0; k < 3; k++) memcpy(out[k], c.h_pin + (5 + (size_t)k) * bn, bn * sizeof(double));
+        memcpy(&st, c.h_pin + 8 * bn, sizeof(int));
+    } else {
+        for (int k = 0; k < 3; k++) HIPCHK(hipMemcpyAsync(out[k], d_out + (size_t)k * bn, bn * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipMemcpyAsync(&st, d_status, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
+    if (st) { armour_set_error("nominal model output falls outside interval output (robust_controller.cpp:88-94)"); return ARMOUR_ESTATE; }
+    return ARMOUR_OK;
 }
