@@ -657,6 +657,10 @@ extern "C" int armour_get_pz(ArmourPlanner* h, int32_t b, int32_t which, int32_t
         armour_set_error("armour_get_pz: index out of range");
         return ARMOUR_EINVAL;
     }
+    if (which == 1 && h->mode == ARMOUR_MODE_ARMTD) {  // the comparison planner has no torque PZs: empty, centred at 0
+        if (center) center[0] = center[1] = 0.0;
+        return 0;
+    }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int sz = which == 0 ? 3 : 1;
