@@ -841,9 +841,8 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
     c.mb = c.w.cnt + kMaxSlots;
     c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
 #ifdef P1_PROFILE
-    __shared__ unsigned long long prof_lds[PR_WORDS];
-    c.w.prof = (LDS_AS unsigned long long*)prof_lds;
-    if (threadIdx.x < PR_WORDS) prof_lds[threadIdx.x] = 0;
+    unsigned long long* prof_lds = c.w.prof;  // (name kept from the LDS version: these are this wave's own counters now)
+    for (int i = 0; i < PR_WORDS; i++) prof_lds[i] = 0;
     const long long prof_start = clock64();
 #endif
     c.w.cap_raw = cf.capRaw;
@@ -1055,6 +1054,10 @@ __global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOp
     }
     Wave& w = c.w;
     PZ out;
+#ifdef P1_PROFILE
+    for (int i = 0; i < PR_WORDS; i++) c.w.prof[i] = 0;
+#endif
+    const long long cyc0 = clock64();  // shader-clock cycles of the operator alone, reported in out_misc[30] (tools/gpu_pzop_cost.py)
     switch (a.op) {
         case 0: out = c.mulMV(in[0], in[1]); break;
         case 1: out = c.M(1); mul<3, 3, 3, 3>(w, out, view(w, in[0]), view(w, in[1])); break;
@@ -1069,7 +1072,14 @@ __global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOp
         case 10: out = c.crossPzPz(in[0], in[1]); break;
         default: out = c.comb2(view(w, in[0]), a.consts[0], view(w, in[1]), a.consts[1]); break;
     }
+    const long long cyc1 = clock64();
     const int n = w.cnt[out.id], sz = out.sz;
+    if (threadIdx.x == 0) {
+        a.out_misc[30] = (double)(cyc1 - cyc0); a.out_misc[31] = (double)w.lstat[ST_MAX_RAW];
+#ifdef P1_PROFILE  // phase attribution of the one operator (slots PR_* of pz_wave.h)
+        for (int i = 0; i < PR_WORDS && 32 + i < 64; i++) a.out_misc[32 + i] = (double)w.prof[i];
+#endif
+    }
     for (int m = threadIdx.x; m < n && m < a.out_cap; m += WAVE) a.out_keys[m] = out.keys[m];
     for (int m = threadIdx.x; m < n * sz && m < a.out_cap * sz; m += WAVE) a.out_coef[m] = out.coef[m];
     if (threadIdx.x == 0) {
@@ -1152,7 +1162,7 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     for (int i = 0; i < 4; i++) a.consts[i] = consts ? consts[i] : 0.0;
     a.out_keys = (uint64_t*)up(nullptr, (size_t)out_cap * 8);
     a.out_coef = (double*)up(nullptr, (size_t)out_cap * 9 * 8);
-    a.out_misc = (double*)up(nullptr, 32 * 8);
+    a.out_misc = (double*)up(nullptr, 64 * 8);
     P1Cfg cf;
     memset(&cf, 0, sizeof(cf));
     cf.B = 1; cf.T = h->T; cf.J = J; cf.n = n;
@@ -1166,7 +1176,7 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     if (e == hipSuccess) {
         (void)hipMemcpy(out_keys, a.out_keys, (size_t)out_cap * 8, hipMemcpyDeviceToHost);
         (void)hipMemcpy(out_coef, a.out_coef, (size_t)out_cap * 9 * 8, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(out_misc, a.out_misc, 32 * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_misc, a.out_misc, 64 * 8, hipMemcpyDeviceToHost);
     }
     for (void* d : dev) (void)hipFree(d);
     (void)hipFree(arena);

@@ -179,15 +179,17 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
             WSYNC();
             PROF_ADD(PR_SORT) PROF_ADD(PR_S_RANK)
-        } else if (ev.try_merge(w, N)) {
-            // the operands' sorted runs were merged by ranking: sidx holds the permutation, keys come from LDS staging
-            indirect = true;
+        } else if (ev.try_merge(w, N, indirect)) {
+            // the operands' sorted runs were merged: either skey / sidx hold the sorted keys and the permutation like the
+            // bitonic path leaves them, or (`indirect`) sidx holds the permutation and the keys come from the LDS staging
 #ifdef DBG_CHECK_MERGE
             {
                 int bad = 0;
                 for (int p = w.lane; p < N; p += WAVE) {
-                    if (p > 0 && ev.key_lds(w, w.sidx[p - 1]) > ev.key_lds(w, w.sidx[p])) bad = 1;
-                    if (ev.key_lds(w, w.sidx[p]) != ev.key(w.sidx[p])) bad |= 2;
+                    const uint64_t kp = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
+                    if (p > 0 && (indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) > kp) bad = 1;
+                    if (p > 0 && (indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) == kp && w.sidx[p - 1] > w.sidx[p]) bad |= 4;
+                    if (kp != ev.key(w.sidx[p])) bad |= 2;
                 }
                 if (__ballot(bad != 0) != 0ull && w.lane == 0) { w.lstat[ST_ERR] |= 64; w.lstat[3] = N; }
             }
@@ -303,8 +305,9 @@ struct LinEval {
     // every source is a simplified PZ (sorted, unique keys): merge the NS runs by ranking each term with binary
     // searches in the other runs; ties across runs go to the earlier run (= generation order)
     __device__ inline bool can_merge(const Wave& w, int N) const { return N <= w.cap_key; }
-    __device__ inline bool try_merge(Wave& w, int N) const {
+    __device__ inline bool try_merge(Wave& w, int N, bool& indirect) const {
         if (!can_merge(w, N)) return false;
+        indirect = true;
 #ifdef DBG_NO_MERGE_LIN
         return false;
 #endif
@@ -557,15 +560,94 @@ struct MulEval {
     // keys [0, k_1, k_2, ...]: rank each term by binary searches with the target shifted by the run's own key.
     // LDS staging: skey[0 .. nl] = long operand's keys (0 for the centre), skey[nl+1 ..] = short operand's keys.
     static constexpr int MAX_RUNS = 8;
-    __device__ inline bool can_merge(const Wave& w, int) const {
+    __device__ inline bool can_rank(const Wave& w) const {
         const bool a_short = a.cnt <= b.cnt;
         const int ns = (a_short ? a.cnt : b.cnt) + 1, nl = (a_short ? b.cnt : a.cnt) + 1;
         return ns <= MAX_RUNS && nl + ns <= w.cap_key;
     }
-    __device__ inline bool try_merge(Wave& w, int N) const {
+    __device__ inline bool can_tree(const Wave& w, int N) const { return 2 * N <= w.cap_key && 2 * N <= w.cap_raw; }
+    __device__ inline bool can_merge(const Wave& w, int N) const { return can_tree(w, N) || can_rank(w); }
+    __device__ inline bool try_merge(Wave& w, int N, bool& indirect) const {
+#ifdef DBG_NO_MERGE_MUL
+        return false;
+#endif
+        if (can_tree(w, N)) { indirect = false; tree_merge(w, N); return true; }
+        if (!can_rank(w)) return false;  // too long for the tree's two buffers and too many runs to rank: the bitonic network
+        indirect = true;
+        return rank_merge(w, N);
+    }
+    // The raw terms in generation order ARE a concatenation of sorted runs: for a fixed term i of a (centre first), the
+    // keys KA[i] + KB[j] rise with j.  Merge those runs pairwise, level by level, between the two halves of the sort
+    // buffers: an element's place in the merged pair is its offset in its own run plus the number of the sibling run's
+    // elements that go before it -- ONE binary search per element and level (ties: the earlier run first, which is
+    // generation order), log2(#runs) levels.  Against the bitonic network this replaces (72 % of a 40 x 40 cross product,
+    // tools/gpu_pzop_cost.py) that is ~50 search steps per element instead of 66 compare-exchange stages, and against the
+    // one-search-per-run ranking below it is log2 instead of linear in the number of runs.  Four elements per lane are
+    // searched together, branch-free with a wave-uniform step count, so that their LDS reads overlap.
+    __device__ inline void tree_merge(Wave& w, int N) const {
+        PROF_T0
+        const int na1 = a.cnt + 1;
+        int levels = 0;
+        while ((1 << levels) < na1) levels++;
+        int cur = levels & 1;  // the last level writes buffer 0 = (skey, sidx) as the reduce pass expects them
+        LDS_AS uint64_t* kb[2] = {w.skey, w.skey + N};
+        LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
+        for (int idx = w.lane; idx < N; idx += WAVE) { kb[cur][idx] = key(idx); vb[cur][idx] = (uint16_t)idx; }
+        WSYNC();
+        // t / mb1 by multiplication: exact while t * mb1 < 2^32 (both are below 2^13 here)
+        const unsigned long long magic = 0x100000000ull / (unsigned long long)mb1 + 1ull;
+        constexpr int U = 4;
+        for (int lv = 0; lv < levels; lv++) {
+            const int rl = mb1 << lv;  // run r of this level holds the terms t = idx + 1 in [r*rl, (r+1)*rl)
+            int top = 1;
+            while (top * 2 <= rl) top *= 2;
+            const LDS_AS uint64_t* K = kb[cur];
+            const LDS_AS uint16_t* V = vb[cur];
+            LDS_AS uint64_t* Ko = kb[cur ^ 1];
+            LDS_AS uint16_t* Vo = vb[cur ^ 1];
+            for (int p0 = w.lane; p0 < N; p0 += WAVE * U) {
+                int ss[U], len[U], cnt[U], dst[U];
+                uint64_t tg[U], ky[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int p = p0 + WAVE * u;
+                    ok[u] = p < N;
+                    const int pc = ok[u] ? p : 0;
+                    const int r = (int)(((unsigned long long)(pc + 1) * magic) >> 32) >> lv;
+                    const int s0 = max(r * rl - 1, 0);
+                    const int rs = r ^ 1;
+                    const int sb = max(rs * rl - 1, 0), se = min((rs + 1) * rl - 1, N);
+                    len[u] = max(se - sb, 0);  // 0: the last run of an odd count has no sibling
+                    ss[u] = len[u] > 0 ? sb : 0;
+                    ky[u] = K[pc];
+                    tg[u] = ky[u] + (uint64_t)(r & 1);  // the later run of a pair also counts the sibling's equal key
+                    cnt[u] = 0;
+                    dst[u] = min(s0, sb) + (pc - s0);
+                }
+                for (int step = top; step > 0; step >>= 1) {
+                    uint64_t v[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) v[u] = K[ss[u] + max(min(cnt[u] + step, len[u]), 1) - 1];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int take = (int)(cnt[u] + step <= len[u]) & (int)(v[u] < tg[u]);  // (no short circuit: a branch would serialise the reads)
+                        cnt[u] += take ? step : 0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (ok[u]) { Ko[dst[u] + cnt[u]] = ky[u]; Vo[dst[u] + cnt[u]] = V[p0 + WAVE * u]; }
+            }
+            WSYNC();
+            cur ^= 1;
+        }
+        PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
+    }
+    __device__ inline bool rank_merge(Wave& w, int N) const {
         const bool a_short = a.cnt <= b.cnt;
         const int ns = (a_short ? a.cnt : b.cnt) + 1, nl = (a_short ? b.cnt : a.cnt) + 1;
-        if (!can_merge(w, N)) return false;
+        if (!can_rank(w)) return false;
 #ifdef DBG_NO_MERGE_MUL
         return false;
 #endif

@@ -290,12 +290,12 @@ class ArmourNLP:
         for i, o in enumerate(operands):
             cen[i, :o["sz"]] = o["cen"]; ind[i, :o["sz"]] = o["ind"]; ind2[i, :o["sz"]] = o.get("ind2", o["ind"])
         cst = np.zeros(4) if consts is None else np.ascontiguousarray(np.concatenate([np.asarray(consts, dtype=np.float64), np.zeros(4)])[:4])
-        ok, oc, misc = np.zeros(out_cap, np.uint64), np.zeros(out_cap * 9), np.zeros(32)
+        ok, oc, misc = np.zeros(out_cap, np.uint64), np.zeros(out_cap * 9), np.zeros(64)
         check(self.L.armour_debug_pz_op(self.h, op, n, sz, cnt, kp, cp, _dp(cen), _dp(ind), _dp(ind2), _dp(cst), r, out_cap,
                                         ok.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(oc), _dp(misc)))
         m, osz = int(misc[0]), int(misc[1])
         return dict(keys=ok[:m].copy(), coef=oc[:m * osz].reshape(m, osz).copy(), cen=misc[3:3 + osz].copy(), ind=misc[12:12 + osz].copy(),
-                    ind2=misc[21:21 + osz].copy(), flags=int(misc[2]))
+                    ind2=misc[21:21 + osz].copy(), flags=int(misc[2]), cycles=float(misc[30]), raw_terms=int(misc[31]), prof=misc[32:].copy())
 
     # ------------------------------------------------------------------ diagnostics / tables
     def torque_radius(self):

@@ -215,7 +215,8 @@ const char* armour_p2_kernel_name(void);
  *   10 cross(a, b) (:1118-1167); 11 consts[0]*a + consts[1]*b on 1x1 (:996-1030 + :743-764).
  * Operand o: sz[o] in {1,3,9} entries per coefficient (row-major), cnt[o] monomials with keys[o][cnt] sorted unique and
  * coef[o][cnt][sz]; cen / ind / ind2 are [nops][9].  Result: out_keys[<=out_cap], out_coef[<=out_cap][sz],
- * out_misc = {count, sz, error flags, cen[9], ind[9], ind2[9]}. */
+ * out_misc[64] = {count, sz, error flags, cen[9], ind[9], ind2[9], [30] the operator's shader-clock cycles, [31] raw terms,
+ * [32..] phase counters in -DP1_PROFILE builds}. */
 int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, const int32_t* sz, const int32_t* cnt, const uint64_t* const* keys,
                        const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
                        int32_t r, int32_t out_cap, uint64_t* out_keys, double* out_coef, double* out_misc);
