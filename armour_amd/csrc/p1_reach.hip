@@ -1163,6 +1163,7 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     a.out_keys = (uint64_t*)up(nullptr, (size_t)out_cap * 8);
     a.out_coef = (double*)up(nullptr, (size_t)out_cap * 9 * 8);
     a.out_misc = (double*)up(nullptr, 64 * 8);
+    if (a.out_misc) (void)hipMemset(a.out_misc, 0, 64 * 8);
     P1Cfg cf;
     memset(&cf, 0, sizeof(cf));
     cf.B = 1; cf.T = h->T; cf.J = J; cf.n = n;

@@ -84,7 +84,7 @@ struct Wave {
     int cap_raw, cap_key;
     double thr;       // SIMPLIFY_THRESHOLD
 #ifdef P1_PROFILE
-    LDS_AS unsigned long long* prof;  // LDS [PR_WORDS]
+    unsigned long long prof[PR_WORDS];  // per-wave counters (lane 0's copy is the one that counts)
 #endif
     LDS_AS int* lstat;       // LDS [ST_WORDS]: error bits / max raw terms / max monomials of this wave (flushed once per launch)
     int lane;
@@ -582,7 +582,7 @@ struct MulEval {
     // elements that go before it -- ONE binary search per element and level (ties: the earlier run first, which is
     // generation order), log2(#runs) levels.  Against the bitonic network this replaces (72 % of a 40 x 40 cross product,
     // tools/gpu_pzop_cost.py) that is ~50 search steps per element instead of 66 compare-exchange stages, and against the
-    // one-search-per-run ranking below it is log2 instead of linear in the number of runs.  Four elements per lane are
+    // one-search-per-run ranking below it is log2 instead of linear in the number of runs.  Eight elements per lane are
     // searched together, branch-free with a wave-uniform step count, so that their LDS reads overlap.
     __device__ inline void tree_merge(Wave& w, int N) const {
         PROF_T0
@@ -596,7 +596,7 @@ struct MulEval {
         WSYNC();
         // t / mb1 by multiplication: exact while t * mb1 < 2^32 (both are below 2^13 here)
         const unsigned long long magic = 0x100000000ull / (unsigned long long)mb1 + 1ull;
-        constexpr int U = 4;
+        constexpr int U = 8;
         for (int lv = 0; lv < levels; lv++) {
             const int rl = mb1 << lv;  // run r of this level holds the terms t = idx + 1 in [r*rl, (r+1)*rl)
             int top = 1;

@@ -52,7 +52,9 @@ def run(name, op, operands, consts=None, reps=5):
     if pr.any():   # -DP1_PROFILE build: where the cycles went (slots of pz_wave.h)
         names = {0: "fill", 1: "sort", 2: "emit", 3: "abs_sum", 15: "rank", 16: "bitonic", 17: "lin-merge", 18: "mul-merge"}
         acc = sum(pr[i] for i in (0, 1, 2, 3))
-        print("      " + ", ".join(f"{nm} {pr[i]:.0f}" for i, nm in names.items() if pr[i]) + f" | unattributed {best['cycles'] - acc:.0f}", flush=True)
+        inside = pr[8] + pr[9] + pr[10]   # whole-call cycles measured inside the operator function(s)
+        print("      " + ", ".join(f"{nm} {pr[i]:.0f}" for i, nm in names.items() if pr[i]) + f" | inside the operator functions {inside:.0f} "
+              f"(unattributed there {inside - acc:.0f}), outside (call, slot allocation, views) {best['cycles'] - inside:.0f}", flush=True)
 
 
 for M in (4, 15, 40, 100, 200, 400):
