@@ -93,10 +93,24 @@ struct Wave {
 __device__ inline View view(const Wave& w, const PZ& p) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, 0, p.sz}; }
 __device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, r, 1}; }
 
+// Sum over the 64 lanes, returned in every lane.  Data-parallel-primitive moves inside the VALU (quad permutes, row
+// mirrors, row broadcasts) instead of six rounds of cross-lane shuffles through the LDS crossbar, which cost ~3 k cycles
+// per product operator in abs_sum alone (tools/gpu_pzop_cost.py).  Fixed summation tree: the same result in every launch shape.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_take(double v) {  // the value of the lane selected by CTRL; 0.0 where no lane is selected / the row is masked
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_take<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_take<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v += dpp_take<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 __device__ inline int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 
