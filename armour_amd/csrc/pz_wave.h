@@ -112,6 +112,19 @@ __device__ inline double wave_sum(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+// |v| <= thr for a 1x1 entry.  The reference tests the Euclidean norm sqrt(v*v); in binary floating point with a correctly
+// rounded square root, sqrt(fl(v*v)) == |v| exactly unless v*v under- or overflows (and an underflowing v is far below
+// any threshold either way), so this is the same decision bit for bit without the square root.
+__device__ inline bool norm1_le(double v, double thr) { return fabs(v) <= thr; }
+// ||acc|| <= thr as simplify() tests it (RT/PZsparse.cu:327-335): entries squared and summed in order, then the root
+template <int SZ>
+__device__ inline bool norm_le(const double* acc, double thr) {
+    if constexpr (SZ == 1) return norm1_le(acc[0], thr);
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+    return sqrt(s) <= thr;
+}
 __device__ inline int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 
 __device__ inline void flag(const Wave& w, int bit) { if (w.lane == 0) w.lstat[ST_ERR] |= bit; }
@@ -255,10 +268,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
 #pragma unroll
                     for (int e = 0; e < SZ; e++) acc[e] += c[e];
                 }
-                double s = 0.0;
-#pragma unroll
-                for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
-                keep = !(sqrt(s) <= w.thr);
+                keep = !norm_le<SZ>(acc, w.thr);
                 if (!keep) {
 #pragma unroll
                     for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
@@ -480,10 +490,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
                         q++;
                     }
                     if (k >= 1 && present) {  // simplify() of stage k
-                        double s = 0.0;
-#pragma unroll
-                        for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
-                        if (sqrt(s) <= w.thr) {
+                        if (norm_le<SZ>(acc, w.thr)) {
 #pragma unroll
                             for (int e = 0; e < SZ; e++) ra[k][e] += fabs(acc[e]);
                             present = false;
@@ -758,10 +765,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
         if (p < N) {
             key = ev.key(p);
             ev.coef(p, acc);
-            double s = 0.0;
-#pragma unroll
-            for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
-            keep = !(sqrt(s) <= w.thr);
+            keep = !norm_le<SZ>(acc, w.thr);
             if (!keep) {
 #pragma unroll
                 for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
@@ -921,14 +925,14 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
                 for (int c = 0; c < 3; c++) {
                     // simplify() of each product: 1x1 norm
                     double v0 = acc[2 * c], v1 = acc[2 * c + 1];
-                    bool h0 = !(sqrt(0.0 + v0 * v0) <= w.thr), h1 = !(sqrt(0.0 + v1 * v1) <= w.thr);
+                    bool h0 = !norm1_le(v0, w.thr), h1 = !norm1_le(v1, w.thr);
                     if (!h0) { raP[2 * c] += fabs(v0); pruned = true; }
                     if (!h1) { raP[2 * c + 1] += fabs(v1); pruned = true; }
                     // simplify() of the difference 1.0*P0 + (-1.0)*P1 over the surviving terms
                     if (h0 || h1) {
                         double wv = h0 ? 1.0 * v0 : -1.0 * v1;
                         if (h0 && h1) wv += -1.0 * v1;
-                        if (sqrt(0.0 + wv * wv) <= w.thr) { raR[c] += fabs(wv); pruned = true; }
+                        if (norm1_le(wv, w.thr)) { raR[c] += fabs(wv); pruned = true; }
                         else { u[c] = wv; anyc = true; }
                     }
                 }
@@ -1015,7 +1019,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, 
             for (int c = 0; c < 3; c++) {
                 double v = sA[c] * x3[cA[c]];
                 v += sB[c] * x3[cB[c]];
-                if (sqrt(v * v) <= w.thr) { ra1[c] += fabs(v); any1 = true; v = 0.0; } else anyc = true;
+                if (norm1_le(v, w.thr)) { ra1[c] += fabs(v); any1 = true; v = 0.0; } else anyc = true;
                 r[c] = v;
             }
             if (anyc) {
