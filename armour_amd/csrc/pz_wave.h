@@ -187,14 +187,16 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
     indirect = false;
     // LDS capacity: sidx holds every raw term; skey holds either the operands' key lists (merge paths) or, for the
     // bitonic path, all raw keys padded to a power of two.  On overflow the host retries with larger buffers.
-    if (N > w.cap_raw || (N > WAVE && !ev.can_merge(w, N) && next_pow2(N) > w.cap_key)) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
+    if (N > w.cap_raw || (N > Eval::kCountMax && !ev.can_merge(w, N) && next_pow2(N) > w.cap_key)) { flag(w, ERR_RAW_OVERFLOW); N = 0; }
     if (w.lane == 0 && N > w.lstat[ST_MAX_RAW]) w.lstat[ST_MAX_RAW] = N;
 #ifdef P1_PROFILE
     if (w.lane == 0) { w.prof[PR_CALLS] += 1; w.prof[PR_TERMS] += N; if (N <= 64) w.prof[PR_SMALL] += 1; }
 #endif
     if (N > 0) {
-        if (N <= WAVE) {
+        if (N <= Eval::kCountMax) {
             // one term per lane: rank by counting (key, index) pairs that sort before this lane's, N broadcast steps
+            // (Eval::kCountMax: up to a full wave for products, whose merge has per-level fixed costs; a handful of terms
+            // for sums, whose one-search merge is cheaper than ~200 cycles per broadcast step from there on)
             PROF_T0
             const uint64_t key = w.lane < N ? ev.key(w.lane) : ~0ull;
             const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
@@ -314,6 +316,7 @@ struct Seg {
 
 template <int SZ, int NS>
 struct LinEval {
+    static constexpr int kCountMax = 8;
     Seg s[NS];
     int off[NS + 1];
     __device__ inline int seg_of(int idx) const {
@@ -565,6 +568,7 @@ struct MulShape {
 
 template <class SH>
 struct MulEval {
+    static constexpr int kCountMax = WAVE;
     View a, b;
     int mb1;
     __device__ inline void split(int idx, int& i, int& j) const {
