@@ -609,21 +609,36 @@ struct MulEval {
     // tools/gpu_pzop_cost.py) that is ~50 search steps per element instead of 66 compare-exchange stages, and against the
     // one-search-per-run ranking below it is log2 instead of linear in the number of runs.  Eight elements per lane are
     // searched together, branch-free with a wave-uniform step count, so that their LDS reads overlap.
+    // The runs are taken along the SHORTER operand (fewer runs = fewer levels): a's terms when a is the shorter one -- the
+    // generation order itself -- and otherwise b's terms, with the raw terms laid out b-major for the merge and their
+    // generation index carried as the payload.  Equal keys must come out in generation order (a-major): between two runs
+    // of a's terms that is the earlier run first; between two runs of b's terms it is the LATER run first (equal sums,
+    // so the larger b-term pairs with the smaller a-term).
     __device__ inline void tree_merge(Wave& w, int N) const {
         PROF_T0
         const int na1 = a.cnt + 1;
+        const bool by_a = na1 <= mb1;
+        const int nr = by_a ? na1 : mb1, d1 = by_a ? mb1 : na1;  // number of runs, terms per run (run 0 lacks the centre x centre term)
         int levels = 0;
-        while ((1 << levels) < na1) levels++;
+        while ((1 << levels) < nr) levels++;
         int cur = levels & 1;  // the last level writes buffer 0 = (skey, sidx) as the reduce pass expects them
         LDS_AS uint64_t* kb[2] = {w.skey, w.skey + N};
         LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
-        for (int idx = w.lane; idx < N; idx += WAVE) { kb[cur][idx] = key(idx); vb[cur][idx] = (uint16_t)idx; }
+        // t / d1 by multiplication: exact while t * d1 < 2^32 (both are below 2^13 here)
+        const unsigned long long magic = 0x100000000ull / (unsigned long long)d1 + 1ull;
+        if (by_a) {
+            for (int idx = w.lane; idx < N; idx += WAVE) { kb[cur][idx] = key(idx); vb[cur][idx] = (uint16_t)idx; }
+        } else {
+            for (int q = w.lane; q < N; q += WAVE) {  // position q of the b-major layout holds the pair (i, j): q + 1 = j * na1 + i
+                const int j = (int)(((unsigned long long)(q + 1) * magic) >> 32), i = q + 1 - j * na1;
+                kb[cur][q] = (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);
+                vb[cur][q] = (uint16_t)(i * mb1 + j - 1);
+            }
+        }
         WSYNC();
-        // t / mb1 by multiplication: exact while t * mb1 < 2^32 (both are below 2^13 here)
-        const unsigned long long magic = 0x100000000ull / (unsigned long long)mb1 + 1ull;
         constexpr int U = 8;
         for (int lv = 0; lv < levels; lv++) {
-            const int rl = mb1 << lv;  // run r of this level holds the terms t = idx + 1 in [r*rl, (r+1)*rl)
+            const int rl = d1 << lv;  // run r of this level holds the positions q with q + 1 in [r*rl, (r+1)*rl)
             int top = 1;
             while (top * 2 <= rl) top *= 2;
             const LDS_AS uint64_t* K = kb[cur];
@@ -646,7 +661,8 @@ struct MulEval {
                     len[u] = max(se - sb, 0);  // 0: the last run of an odd count has no sibling
                     ss[u] = len[u] > 0 ? sb : 0;
                     ky[u] = K[pc];
-                    tg[u] = ky[u] + (uint64_t)(r & 1);  // the later run of a pair also counts the sibling's equal key
+                    // count the sibling's keys below ky -- and its equal key too if the sibling's term goes first on a tie
+                    tg[u] = ky[u] + (uint64_t)(((r & 1) != 0) == by_a);
                     cnt[u] = 0;
                     dst[u] = min(s0, sb) + (pc - s0);
                 }

@@ -63,7 +63,7 @@ for M in (4, 15, 40, 100, 200, 400):
     run(f"add    v({M}) + v({M})", 4, [vec(M), vec(M)])
 for M in (15, 100, 400):
     run(f"crossPzMat v({M}) x const", 8, [vec(M)], consts=[0.1, -0.2, 0.3])
-for Ma, Mb in ((3, 3), (7, 7), (7, 60), (15, 15), (30, 30), (40, 40), (20, 80)):
+for Ma, Mb in ((3, 3), (7, 7), (7, 60), (15, 15), (30, 30), (40, 40), (20, 80), (80, 20), (300, 2), (2, 300)):
     run(f"crossPzPz v({Ma}) x v({Mb})", 10, [vec(Ma), vec(Mb)])
 for M in (15, 100, 400):
     run(f"mulSV  s(0) x v({M})  (presorted)", 3, [dict(sz=1, keys=np.zeros(0, np.uint64), coef=np.zeros((0, 1)), cen=[2.0], ind=[0.0]), vec(M)])
