@@ -262,14 +262,35 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
                 key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
                 head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
             }
-            if (head) {
-                ev.coef(w.sidx[p], acc);
-                for (int q = p + 1; q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key; q++) {
-                    double c[SZ];
-                    ev.coef(w.sidx[q], c);
+            // Every lane evaluates its own term (one batch of loads in flight for the whole wave); the head lane of a run of
+            // equal keys then adds the members in generation order.  Member j of every run sits j lanes up: the terms are
+            // shifted down the wave one lane per round (a DPP move, no memory traffic), and only the tail of a run that
+            // crosses the end of this 64-term chunk is loaded directly.  (Before: each head walked its run with one dependent
+            // round trip to memory per member -- 37 % of the chain's operator time was this pass.)  Same sums, same order.
 #pragma unroll
-                    for (int e = 0; e < SZ; e++) acc[e] += c[e];
+            for (int e = 0; e < SZ; e++) acc[e] = 0.0;
+            if (p < N) ev.coef(w.sidx[p], acc);
+            {
+                double sh[SZ];
+#pragma unroll
+                for (int e = 0; e < SZ; e++) sh[e] = acc[e];
+                for (int j = 1;; j++) {
+                    const int q = p + j;
+                    const bool more = head && q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key;
+                    if (__ballot(more) == 0ull) break;
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) sh[e] = dpp_take<0x130, 0xf>(sh[e]);  // wave_shl:1 -- lane l now holds the term of lane l + j
+                    if (more) {
+                        double c[SZ];
+#pragma unroll
+                        for (int e = 0; e < SZ; e++) c[e] = sh[e];
+                        if (w.lane + j >= WAVE) ev.coef(w.sidx[q], c);
+#pragma unroll
+                        for (int e = 0; e < SZ; e++) acc[e] += c[e];
+                    }
                 }
+            }
+            if (head) {
                 keep = !norm_le<SZ>(acc, w.thr);
                 if (!keep) {
 #pragma unroll
@@ -931,15 +952,30 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
                 key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
                 head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
             }
-            if (head) {
-                double acc[6];
-                ev.coef6(w.sidx[p], acc);
-                for (int q = p + 1; q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key; q++) {
-                    double c6[6];
-                    ev.coef6(w.sidx[q], c6);
+            // (own term in every lane, run members shifted down the wave: see sort_reduce_emit)
+            double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (p < N) ev.coef6(w.sidx[p], acc);
+            {
+                double sh[6];
 #pragma unroll
-                    for (int e = 0; e < 6; e++) acc[e] += c6[e];
+                for (int e = 0; e < 6; e++) sh[e] = acc[e];
+                for (int j = 1;; j++) {
+                    const int q = p + j;
+                    const bool more = head && q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key;
+                    if (__ballot(more) == 0ull) break;
+#pragma unroll
+                    for (int e = 0; e < 6; e++) sh[e] = dpp_take<0x130, 0xf>(sh[e]);
+                    if (more) {
+                        double c6[6];
+#pragma unroll
+                        for (int e = 0; e < 6; e++) c6[e] = sh[e];
+                        if (w.lane + j >= WAVE) ev.coef6(w.sidx[q], c6);
+#pragma unroll
+                        for (int e = 0; e < 6; e++) acc[e] += c6[e];
+                    }
                 }
+            }
+            if (head) {
                 bool anyc = false, pruned = false;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {

@@ -32,6 +32,22 @@ def vec(M, sz=3):
     return dict(sz=sz, keys=rand_keys(M), coef=rng.normal(size=(M, sz)) * 0.1, cen=rng.normal(size=sz), ind=np.abs(rng.normal(size=sz)) * 1e-3)
 
 
+def vec_low(M, sz=3, nvar=4):
+    """M distinct keys over few variables with degree <= 1 each plus one error variable: products of two such operands
+    collide often (runs of equal keys in the sorted raw terms, as in the RNEA chain)."""
+    ks = set()
+    while len(ks) < M:
+        key = 0
+        for i in range(nvar):
+            if rng.random() < 0.5:
+                key += 1 << (2 * i)
+        if rng.random() < 0.7:
+            key += 1 << (2 * n + int(rng.integers(0, 8)))
+        if key:
+            ks.add(key)
+    return dict(sz=sz, keys=np.array(sorted(ks), dtype=np.uint64), coef=rng.normal(size=(M, sz)) * 0.1, cen=rng.normal(size=sz), ind=np.abs(rng.normal(size=sz)) * 1e-3)
+
+
 def rot(i=2):
     keys = np.array(sorted([1 << (2 * i), 1 << (5 * n + 2 * i), 1 << (7 * n + 2 * i)]), dtype=np.uint64)
     return dict(sz=9, keys=keys, coef=rng.normal(size=(3, 9)) * 0.05, cen=rng.normal(size=9), ind=np.zeros(9))
@@ -65,5 +81,9 @@ for M in (15, 100, 400):
     run(f"crossPzMat v({M}) x const", 8, [vec(M)], consts=[0.1, -0.2, 0.3])
 for Ma, Mb in ((3, 3), (7, 7), (7, 60), (15, 15), (30, 30), (40, 40), (20, 80), (80, 20), (300, 2), (2, 300)):
     run(f"crossPzPz v({Ma}) x v({Mb})", 10, [vec(Ma), vec(Mb)])
+for Ma, Mb in ((30, 30), (40, 40)):
+    run(f"crossPzPz colliding v({Ma}) x v({Mb})", 10, [vec_low(Ma), vec_low(Mb)])
+for M in (40, 100):
+    run(f"add colliding v({M}) + v({M})", 4, [vec_low(M, nvar=5), vec_low(M, nvar=5)])
 for M in (15, 100, 400):
     run(f"mulSV  s(0) x v({M})  (presorted)", 3, [dict(sz=1, keys=np.zeros(0, np.uint64), coef=np.zeros((0, 1)), cen=[2.0], ind=[0.0]), vec(M)])
