@@ -44,7 +44,7 @@ constexpr int WAVE = 64;
 enum { ST_ERR = 0, ST_MAX_RAW = 1, ST_MAX_OUT = 2, ST_WORDS = 4 };
 #ifdef P1_PROFILE  // development only: per-wave cycle attribution, dumped after the status words
 enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS = 5, PR_SMALL = 6, PR_TOTAL = 7,
-       PR_CYC64 = 8, PR_CYC512 = 9, PR_CYCBIG = 10, PR_N512 = 11, PR_NBIG = 12, PR_TERMS512 = 13, PR_TERMSBIG = 14, PR_S_RANK = 15, PR_S_BITONIC = 16, PR_S_LINMERGE = 17, PR_S_MULMERGE = 18, PR_WORDS = 20 };
+       PR_CYC64 = 8, PR_CYC512 = 9, PR_CYCBIG = 10, PR_N512 = 11, PR_NBIG = 12, PR_TERMS512 = 13, PR_TERMSBIG = 14, PR_S_RANK = 15, PR_S_BITONIC = 16, PR_S_LINMERGE = 17, PR_S_MULMERGE = 18, PR_E_HEAD = 19, PR_E_COEF = 20, PR_E_RUN = 21, PR_E_PRUNE = 22, PR_E_STORE = 23, PR_WORDS = 24 };
 #define PROF_CALL_T0 const long long prof_c0__ = clock64();
 #define PROF_CALL_END(N) if (w.lane == 0) { const unsigned long long d__ = (unsigned long long)(clock64() - prof_c0__); if ((N) <= 64) w.prof[PR_CYC64] += d__; else if ((N) <= 512) { w.prof[PR_CYC512] += d__; w.prof[PR_N512] += 1; w.prof[PR_TERMS512] += (N); } else { w.prof[PR_CYCBIG] += d__; w.prof[PR_NBIG] += 1; w.prof[PR_TERMSBIG] += (N); } }
 #define PROF_T0 const long long prof_t0__ = clock64();
@@ -258,10 +258,17 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             bool head = false, keep = false;
             uint64_t key = 0;
             double acc[SZ];
+#ifdef P1_PROFILE
+            long long e_t = clock64();
+#define E_LAP(slot) { const long long n__ = clock64(); if (w.lane == 0) w.prof[slot] += (unsigned long long)(n__ - e_t); e_t = n__; }
+#else
+#define E_LAP(slot)
+#endif
             if (p < N) {
                 key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
                 head = (p == 0) || ((indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) != key);
             }
+            E_LAP(PR_E_HEAD)
             // Every lane evaluates its own term (one batch of loads in flight for the whole wave); the head lane of a run of
             // equal keys then adds the members in generation order.  Member j of every run sits j lanes up: the terms are
             // shifted down the wave one lane per round (a DPP move, no memory traffic), and only the tail of a run that
@@ -270,6 +277,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
 #pragma unroll
             for (int e = 0; e < SZ; e++) acc[e] = 0.0;
             if (p < N) ev.coef(w.sidx[p], acc);
+            E_LAP(PR_E_COEF)
             {
                 double sh[SZ];
 #pragma unroll
@@ -290,6 +298,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
                     }
                 }
             }
+            E_LAP(PR_E_RUN)
             if (head) {
                 keep = !norm_le<SZ>(acc, w.thr);
                 if (!keep) {
@@ -297,6 +306,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
                     for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
                 }
             }
+            E_LAP(PR_E_PRUNE)
             const unsigned long long m = __ballot(keep);
             any_pruned = any_pruned || (__ballot(head && !keep) != 0ull);
             if (keep) {
@@ -308,6 +318,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
                 }
             }
             emitted += __popcll(m);
+            E_LAP(PR_E_STORE)
         }
         PROF_ADD(PR_EMIT)
     }
@@ -324,6 +335,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
     }
     WSYNC();
 }
+#undef E_LAP
 
 // ---------------------------------------------------------------------------------------------------
 // linear combination: out = sum_s scale_s * embed(src_s).  Covers operator+, operator-, operator+=,

@@ -66,7 +66,8 @@ def run(name, op, operands, consts=None, reps=5):
           f"{best['cycles'] / ((raw + 63) // 64):8.0f} per 64-term pass", flush=True)
     pr = best["prof"]
     if pr.any():   # -DP1_PROFILE build: where the cycles went (slots of pz_wave.h)
-        names = {0: "fill", 1: "sort", 2: "emit", 3: "abs_sum", 15: "rank", 16: "bitonic", 17: "lin-merge", 18: "mul-merge"}
+        names = {0: "fill", 1: "sort", 2: "emit", 3: "abs_sum", 15: "rank", 16: "bitonic", 17: "lin-merge", 18: "mul-merge",
+                 19: "emit:head", 20: "emit:coef", 21: "emit:run", 22: "emit:prune", 23: "emit:store"}
         acc = sum(pr[i] for i in (0, 1, 2, 3))
         inside = pr[8] + pr[9] + pr[10]   # whole-call cycles measured inside the operator function(s)
         print("      " + ", ".join(f"{nm} {pr[i]:.0f}" for i, nm in names.items() if pr[i]) + f" | inside the operator functions {inside:.0f} "
