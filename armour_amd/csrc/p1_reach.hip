@@ -848,6 +848,7 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
     c.w.cap_raw = cf.capRaw;
     c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
+    c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x & 63;
     if (c.w.lane < ST_WORDS) c.w.lstat[c.w.lane] = 0;
     for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
@@ -1036,6 +1037,7 @@ __global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOp
     c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
     c.w.cap_raw = cf.capRaw; c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
+    c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x;
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
     c.freeV = (1ull << c.L.nV) - 1ull; c.freeS = (1u << kNS) - 1u;

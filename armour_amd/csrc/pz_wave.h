@@ -83,6 +83,7 @@ struct Wave {
     LDS_AS int* cnt;         // LDS per-slot monomial counts
     int cap_raw, cap_key;
     double thr;       // SIMPLIFY_THRESHOLD
+    double thr_sq;    // the largest double s with sqrt(s) <= thr (sq_threshold()): `s <= thr_sq` IS `sqrt(s) <= thr`, without the root
 #ifdef P1_PROFILE
     unsigned long long prof[PR_WORDS];  // per-wave counters (lane 0's copy is the one that counts)
 #endif
@@ -116,14 +117,22 @@ __device__ inline double wave_sum(double v) {
 // rounded square root, sqrt(fl(v*v)) == |v| exactly unless v*v under- or overflows (and an underflowing v is far below
 // any threshold either way), so this is the same decision bit for bit without the square root.
 __device__ inline bool norm1_le(double v, double thr) { return fabs(v) <= thr; }
+// The correctly rounded square root is monotone, so { s : sqrt(s) <= thr } is an interval [0, S] of doubles: with S found
+// once per launch, the norm test of simplify() needs no root and decides exactly as before.
+__device__ inline double sq_threshold(double thr) {
+    double S = thr * thr;
+    while (sqrt(nextafter(S, INFINITY)) <= thr) S = nextafter(S, INFINITY);
+    while (S > 0.0 && sqrt(S) > thr) S = nextafter(S, -INFINITY);
+    return S;
+}
 // ||acc|| <= thr as simplify() tests it (RT/PZsparse.cu:327-335): entries squared and summed in order, then the root
 template <int SZ>
-__device__ inline bool norm_le(const double* acc, double thr) {
-    if constexpr (SZ == 1) return norm1_le(acc[0], thr);
+__device__ inline bool norm_le(const double* acc, const Wave& w) {
+    if constexpr (SZ == 1) return norm1_le(acc[0], w.thr);
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
-    return sqrt(s) <= thr;
+    return s <= w.thr_sq;
 }
 __device__ inline int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 
@@ -300,7 +309,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             }
             E_LAP(PR_E_RUN)
             if (head) {
-                keep = !norm_le<SZ>(acc, w.thr);
+                keep = !norm_le<SZ>(acc, w);
                 if (!keep) {
 #pragma unroll
                     for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
@@ -526,7 +535,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
                         q++;
                     }
                     if (k >= 1 && present) {  // simplify() of stage k
-                        if (norm_le<SZ>(acc, w.thr)) {
+                        if (norm_le<SZ>(acc, w)) {
 #pragma unroll
                             for (int e = 0; e < SZ; e++) ra[k][e] += fabs(acc[e]);
                             present = false;
@@ -818,7 +827,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
         if (p < N) {
             key = ev.key(p);
             ev.coef(p, acc);
-            keep = !norm_le<SZ>(acc, w.thr);
+            keep = !norm_le<SZ>(acc, w);
             if (!keep) {
 #pragma unroll
                 for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
@@ -1009,7 +1018,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
                     double s = 0.0;
 #pragma unroll
                     for (int c = 0; c < 3; c++) s += u[c] * u[c];
-                    keep = !(sqrt(s) <= w.thr);
+                    keep = !(s <= w.thr_sq);
                     if (!keep) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) raS[c] += fabs(u[c]);
@@ -1091,7 +1100,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, 
                 r[c] = v;
             }
             if (anyc) {
-                keep = !(sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) <= w.thr);
+                keep = !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= w.thr_sq);
                 if (!keep) { ra2[0] += fabs(r[0]); ra2[1] += fabs(r[1]); ra2[2] += fabs(r[2]); any2 = true; }
             }
         }
