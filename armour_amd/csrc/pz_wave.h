@@ -608,14 +608,20 @@ struct MulShape {
     }
 };
 
+// floor(2^32 / d) + 1 for 1 <= d < 2^16, through one double division (a 64-bit integer division is ~100 instructions): the
+// quotient is either an integer (d a power of two) or at least 2^-16 away from one, far more than the rounding error
+__device__ inline unsigned long long magic_u32(int d) { return (unsigned long long)(4294967296.0 / (double)d) + 1ull; }
+
 template <class SH>
 struct MulEval {
     static constexpr int kCountMax = WAVE;
     View a, b;
     int mb1;
+    unsigned long long mb1_magic;  // floor(2^32 / mb1) + 1: t / mb1 == (t * magic) >> 32 while t * mb1 < 2^32 (set_b())
+    __device__ inline void set_b(const View& bv) { b = bv; mb1 = bv.cnt + 1; mb1_magic = magic_u32(mb1); }
     __device__ inline void split(int idx, int& i, int& j) const {
         const int t = idx + 1;  // (0,0) = centre*centre is not a monomial
-        i = t / mb1;
+        i = (int)(((unsigned long long)t * mb1_magic) >> 32);  // a division by a run-time value is ~30 instructions, per term
         j = t - i * mb1;
     }
     __device__ inline uint64_t key(int idx) const {
@@ -667,7 +673,7 @@ struct MulEval {
         LDS_AS uint64_t* kb[2] = {w.skey, w.skey + N};
         LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
         // t / d1 by multiplication: exact while t * d1 < 2^32 (both are below 2^13 here)
-        const unsigned long long magic = 0x100000000ull / (unsigned long long)d1 + 1ull;
+        const unsigned long long magic = magic_u32(d1);
         if (by_a) {
             for (int idx = w.lane; idx < N; idx += WAVE) { kb[cur][idx] = key(idx); vb[cur][idx] = (uint16_t)idx; }
         } else {
@@ -866,7 +872,7 @@ __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const Vi
     PROF_CALL_T0
     typedef MulShape<AR, AC, BR, BC> SH;
     MulEval<SH> ev;
-    ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
+    ev.a = a; ev.set_b(b);
     const int N = (a.cnt + 1) * (b.cnt + 1) - 1;
     double r2[SH::ASZ], r3[SH::BSZ], ia[SH::ASZ], ib[SH::BSZ], ca[SH::ASZ], cb[SH::BSZ];
     { PROF_T0
@@ -936,7 +942,7 @@ struct CrossEval : MulEval<MulShape<1, 1, 1, 1>> {
 __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, const View& b) {
     PROF_CALL_T0
     CrossEval ev;
-    ev.a = a; ev.b = b; ev.mb1 = b.cnt + 1;
+    ev.a = a; ev.set_b(b);
     int N = (a.cnt + 1) * (b.cnt + 1) - 1;
     [[maybe_unused]] const int N_in = N;
     // centres and radii of the six products, as mul<1,1,1,1> forms them
