@@ -16,11 +16,12 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "BASELINE configs[1]: Kinova 7-
 extra = (" " + sys.argv[4]) if len(sys.argv) > 4 else ""
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+newest = lambda pattern: max(glob.glob(pattern, recursive=True), key=os.path.getmtime)  # gpurun_out/ accumulates earlier runs
+stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"))
 out = {}
 for sub in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in [newest(os.path.join(src, sub, "**", "*counter_collection.csv"))]:
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
             k = (row["Kernel_Name"], row["Counter_Name"])
