@@ -18,11 +18,16 @@ from oracle.cpu_oracle import Oracle  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-T = 100
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+GRIPPER = len(sys.argv) > 4 and sys.argv[4] == "gripper"   # the 8-link arm (fixed gripper joint, RT/KinovaInfo.h)
 worst = dict(coef=0.0, cen=0.0, gens=0.0, radius=0.0, planes=0.0, g=0.0, jac=0.0)
 min_margin, key_mismatch, low_margin_cases = 1.0, 0, 0
 t_start = time.time()
-nlp = ArmourNLP(T=T)
+if GRIPPER:
+    from armour_amd.planner import kinova_gripper_robot
+    from oracle.cpu_oracle import kinova_gripper_robot as oracle_gripper
+nlp = ArmourNLP(robot=kinova_gripper_robot(), T=T) if GRIPPER else ArmourNLP(T=T)
+mk_oracle = (lambda: Oracle(robot=oracle_gripper(), T=T)) if GRIPPER else (lambda: Oracle(T=T))
 for s in range(N):
     rng = np.random.default_rng(S0 + s)
     O = int(rng.choice([0, 1, 3, 10, 20, 40]))
@@ -34,10 +39,10 @@ for s in range(N):
     if armtd:
         jrs, kr = synthetic_offline_jrs(p["qd0"], T)
         nlp.set_parameters_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
-        o = Oracle(T=T).set_problem_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
+        o = mk_oracle().set_problem_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
     else:
         nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
-        o = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        o = mk_oracle().set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
     m = o.min_margin()
     min_margin = min(min_margin, m)
     bad_keys = 0
@@ -69,6 +74,6 @@ for s in range(N):
         gr, jr = o.eval_g_jac(k)
         worst["g"] = max(worst["g"], np.abs(g[0] - gr).max())
         worst["jac"] = max(worst["jac"], np.abs(jac[0] - jr).max())
-print(f"{N} problems (seeds {S0}..{S0 + N - 1}, every third in ARMTD mode, O in {{0,1,3,10,20,40}}, T={T}) in {time.time() - t_start:.0f} s")
+print(f"{N} problems (seeds {S0}..{S0 + N - 1}, every third in ARMTD mode, O in {{0,1,3,10,20,40}}, T={T}{', 8-link arm with gripper' if GRIPPER else ''}) in {time.time() - t_start:.0f} s")
 print("worst absolute deviations device vs oracle:", {k: float(f"{v:.3g}") for k, v in worst.items()})
 print(f"smallest prune margin seen by the oracle: {min_margin:.3g}; problems with a key-set difference: {key_mismatch} (of which margin < 1e-9: {low_margin_cases})")
