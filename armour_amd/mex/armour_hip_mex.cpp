@@ -18,6 +18,8 @@
 //   [c, G, Grest, expMat, id] = armour_hip_mex('pz', which, i, t)  reach-set PZ as CORA polyZonotope fields: which =
 //                    'link' | 'torque', i and t 1-based; polyZonotope_ROAHM(c, G, Grest, expMat, id) rebuilds it with the
 //                    ids 1..7 of jrs_info.k_id (PZM/create_jrs_online.m:225); same mapping as armour_amd/cora.py
+//   [q, qd, qdd] = armour_hip_mex('traj', q0, qd0, qdd0, k, t)     desired trajectory of a plan at time t (the Bernstein form of
+//                    KSI/uarmtd_planner.m:846-905 in the NLP's own closed form; k_range and duration of the handle's parameters)
 //   armour_hip_mex('destroy')
 #include <string.h>
 
@@ -25,6 +27,7 @@
 #include "mex.h"
 
 static ArmourPlanner* g_h = nullptr;
+static ArmourParams g_pr;
 
 static void cleanup(void) {
     if (g_h) { armour_destroy(g_h); g_h = nullptr; }
@@ -43,7 +46,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (!strcmp(cmd, "create")) {
         need(nrhs >= 2, "create needs the number of time steps");
         ArmourRobot rb;
-        ArmourParams pr;
+        ArmourParams& pr = g_pr;
         armour_robot_kinova_gen3_no_gripper(&rb);
         armour_params_default(&pr, (int)mxGetScalar(prhs[1]));
         cleanup();
@@ -73,6 +76,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int nObs = (int)(mxGetNumberOfElements(prhs[6]) / 12);
         // column-major T x 6 x 7 is the [joint][row][t] order of the C ABI; its T must be the T of 'create' (the library checks sizes only through it)
         chk(armour_set_problems_armtd(g_h, 1, nObs, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), mxGetPr(prhs[6])));
+        return;
+    }
+    if (!strcmp(cmd, "traj")) {  // stateless: needs no problem set
+        need(nrhs == 6, "traj needs q0, qd0, qdd0, k, t");
+        for (int i = 1; i <= 4; i++) need(mxGetNumberOfElements(prhs[i]) == 7, "q0, qd0, qdd0, k must have 7 entries");
+        mxArray* o[3] = {col(7), col(7), col(7)};
+        chk(armour_desired_trajectory(7, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), g_pr.k_range, g_pr.duration, mxGetPr(prhs[4]),
+                                      mxGetScalar(prhs[5]), mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2])));
+        for (int i = 0; i < 3; i++) { if (i < nlhs || i == 0) plhs[i] = o[i]; else mxDestroyArray(o[i]); }
         return;
     }
     int B, n, m;
