@@ -216,6 +216,14 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
                              const double* q_des, int mode = ARMOUR_MODE_ARMOUR) {
     if (!h || !q0 || !qd0 || !qdd0 || !q_des) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     if (B < 1 || O < 0) { armour_set_error("bad batch/obstacle count (B=%d, O=%d)", B, O); return ARMOUR_EINVAL; }
+    // the reference parses whatever the file holds ("There is no check and warning, so be careful!", RT/armour_main.cu:14);
+    // a NaN / inf state would only surface as NaN constraint rows, so it is refused here
+    {
+        const double* arrs[4] = {q0, qd0, qdd0, q_des};
+        for (int a = 0; a < 4; a++)
+            for (size_t i = 0; i < (size_t)B * h->n; i++)
+                if (!std::isfinite(arrs[a][i])) { armour_set_error("non-finite entry in the initial state / goal arrays (array %d, entry %zu)", a, i); return ARMOUR_EINVAL; }
+    }
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
     h->bounds_on_device = false;
@@ -264,6 +272,8 @@ extern "C" int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
     if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
+    for (size_t i = 0; i < (size_t)B * O * 12; i++)
+        if (!std::isfinite(obstacles[i])) { armour_set_error("non-finite obstacle entry %zu", i); return ARMOUR_EINVAL; }
     rc = armour_p1_build(h, obstacles);
     if (rc != ARMOUR_OK) return rc;
     rc = armour_refresh_table_stats(h);
@@ -278,6 +288,10 @@ extern "C" int armour_set_problems_armtd(ArmourPlanner* h, int32_t B, int32_t O,
     int rc = begin_problem_set(h, B, O, q0, qd0, k_range, q_des, ARMOUR_MODE_ARMTD);
     if (rc != ARMOUR_OK) return rc;
     if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
+    for (size_t i = 0; i < (size_t)B * O * 12; i++)
+        if (!std::isfinite(obstacles[i])) { armour_set_error("non-finite obstacle entry %zu", i); return ARMOUR_EINVAL; }
+    for (size_t i = 0; i < (size_t)B * h->n * 6 * h->T; i++)
+        if (!std::isfinite(jrs[i])) { armour_set_error("non-finite entry %zu in the offline JRS tables", i); return ARMOUR_EINVAL; }
     const size_t cnt = (size_t)B * h->n * 6 * h->T;
     if (cnt > h->jrs_cap) {
         if ((rc = dev_alloc(&h->d_jrs, cnt)) != ARMOUR_OK) return rc;

@@ -299,3 +299,18 @@ def test_two_handles_from_two_host_threads():
     for i in range(2):
         for (g, j), (g0, j0) in zip(out[i], serial[i]):
             assert np.array_equal(g, g0) and np.array_equal(j, j0)
+
+
+def test_non_finite_inputs_are_refused(sample_problem):
+    """The reference parses whatever armour.in holds; here a NaN / inf state, goal or obstacle is an EINVAL, not NaN rows."""
+    from armour_amd._lib import ArmourError
+    from armour_amd.planner import ArmourNLP
+    p = sample_problem
+    nlp = ArmourNLP(T=100)
+    for key, val in (("q0", np.nan), ("qd0", np.inf), ("q_des", -np.inf), ("obstacles", np.nan)):
+        bad = {k: np.array(v, dtype=np.float64, copy=True) for k, v in p.items()}
+        bad[key].reshape(-1)[3] = val
+        with pytest.raises(ArmourError):
+            nlp.set_parameters(bad["q0"], bad["qd0"], bad["qdd0"], bad["q_des"], bad["obstacles"])
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])   # the handle is still usable
+    assert np.isfinite(nlp.eval_g(np.zeros(7))).all()
