@@ -1300,7 +1300,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     const int* d_items = nullptr;
     int n_items = B * T;
     // (the second pass costs at least one item's latency, ~4 ms: worth it from about 16 items per CU)
-    if (cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
+    static const int two_pass_env = [] { const char* e = getenv("ARMOUR_P1_TWO_PASS"); return e ? atoi(e) : 1; }();  // development switch
+    if (two_pass_env && cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
         if ((rc = launch(kFirstPassCap, nullptr, B * T, true)) != ARMOUR_OK) return rc;
         if ((rc = other_errors()) != ARMOUR_OK) return rc;
         int nretry = 0;
