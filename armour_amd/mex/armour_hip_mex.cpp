@@ -1,7 +1,9 @@
-// MEX gateway of libarmour_hip.so for MATLAB (source only: neither MATLAB nor mex.h exists in the build image, so this
-// file is NOT part of `make`; build it on a MATLAB host with
+// MEX gateway of libarmour_hip.so for MATLAB.  Neither MATLAB nor mex.h exists in the build image, so this file is NOT
+// part of `make`; build it on a MATLAB host with
 //     mex armour_hip_mex.cpp -I<repo>/include -L<repo>/armour_amd/lib -larmour_hip
-// ).  Conventions follow the reference's only MEX precedent, kinova_robust_controllers_mex/kinova_controller.cpp:19-84:
+// In this repository it is compiled against tests/stubs/mex.h (a functional test double of the MEX C API) and driven
+// command by command by tests/test_mex_gateway.py -- on the CPU for the build, the argument checks and 'traj', on the
+// MI355X for everything that needs a handle.  Conventions follow the reference's only MEX precedent, kinova_robust_controllers_mex/kinova_controller.cpp:19-84:
 // column vectors of doubles in, mxCreateNumericMatrix out, mexErrMsgTxt on error.  Unlike that gateway the handle is
 // persistent (mexLock / mexAtExit): the reach sets built by 'set_problem' stay on the device for the 'eval' calls of
 // the solver loop.
@@ -12,6 +14,8 @@
 //                    (per joint the columns c_cos g_cos r_cos c_sin g_sin r_sin that KSI/uarmtd_planner.m:277-312 writes
 //                    into armtd.in), k_range = 7 x 1; the commands below then follow CMP/NLPclass.cu
 //   [g, jac]             = armour_hip_mex('eval', k)               g: m x 1, jac: n x m (gradient of row i in column i)
+//   [h, heq, grad_h, grad_heq] = armour_hip_mex('constraints', k)  the fmincon `nonlcon` shape of KSI/uarmtd_planner.m:776-796:
+//                    h <= 0 feasible, grad_h n x numel(h); rows g - g_u first, then g_l - g of the two-sided rows
 //   [x_l, x_u, g_l, g_u] = armour_hip_mex('bounds')
 //   [f, grad_f]          = armour_hip_mex('cost', k)
 //   [k_opt, feasible, info] = armour_hip_mex('solve')              info = [cost; iterations; evaluations; status; ms]
@@ -95,6 +99,35 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         mxArray* jac = mxCreateNumericMatrix(n, m, mxDOUBLE_CLASS, mxREAL);  // column-major n x m == row-major values[m][n]
         chk(armour_eval_g_jac(g_h, mxGetPr(prhs[1]), mxGetPr(plhs[0]), mxGetPr(jac)));
         if (nlhs > 1) plhs[1] = jac; else mxDestroyArray(jac);
+    } else if (!strcmp(cmd, "constraints")) {
+        need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n, "constraints needs k (n x 1)");
+        mxArray* g = col(m);
+        mxArray* jac = mxCreateNumericMatrix(n, m, mxDOUBLE_CLASS, mxREAL);
+        mxArray* b[4] = {col(n), col(n), col(m), col(m)};
+        chk(armour_eval_g_jac(g_h, mxGetPr(prhs[1]), mxGetPr(g), mxGetPr(jac)));
+        chk(armour_get_bounds(g_h, mxGetPr(b[0]), mxGetPr(b[1]), mxGetPr(b[2]), mxGetPr(b[3])));
+        const double *gv = mxGetPr(g), *jv = mxGetPr(jac), *gl = mxGetPr(b[2]), *gu = mxGetPr(b[3]);
+        int two = 0;
+        for (int i = 0; i < m; i++) two += gl[i] > -1e18;  // collision rows are one-sided (g_l = -1e19, RT/NLPclass.cu:131-140)
+        mxArray* h = col(m + two);
+        mxArray* gh = mxCreateNumericMatrix(n, m + two, mxDOUBLE_CLASS, mxREAL);
+        double *hv = mxGetPr(h), *ghv = mxGetPr(gh);
+        int r = m;
+        for (int i = 0; i < m; i++) {
+            hv[i] = gv[i] - gu[i];
+            for (int j = 0; j < n; j++) ghv[(size_t)i * n + j] = jv[(size_t)i * n + j];
+            if (gl[i] > -1e18) {
+                hv[r] = gl[i] - gv[i];
+                for (int j = 0; j < n; j++) ghv[(size_t)r * n + j] = -jv[(size_t)i * n + j];
+                r++;
+            }
+        }
+        mxDestroyArray(g); mxDestroyArray(jac);
+        for (int i = 0; i < 4; i++) mxDestroyArray(b[i]);
+        plhs[0] = h;
+        if (nlhs > 1) plhs[1] = mxCreateDoubleMatrix(0, 0, mxREAL);   // heq = []
+        if (nlhs > 2) plhs[2] = gh; else mxDestroyArray(gh);
+        if (nlhs > 3) plhs[3] = mxCreateDoubleMatrix(n, 0, mxREAL);   // grad_heq: n x 0
     } else if (!strcmp(cmd, "bounds")) {
         mxArray* o[4] = {col(n), col(n), col(m), col(m)};
         chk(armour_get_bounds(g_h, mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3])));

@@ -1,14 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of ARMOUR's constraint callback on MI355X: planning iters/s (fused eval_g + eval_jac_g).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--obstacles O] [--time-steps T]
+    python bench.py --gpus N --steps K --warmup W [--repeats R] [--batch B] [--obstacles O] [--time-steps T]
 
 One "step" = one pass of the hot path (RT/NLPclass.cu:272-396: eval_g + eval_jac_g at a fresh k) over this
 rank's batch of planning problems; one kernel launch per step, inputs (reach-set tables from
 armour_set_problems, the k points) resident in HBM before the timed region.  The default workload is
 BASELINE.json configs[1]: Kinova Gen3 7-DOF, 20 obstacles, 100 time steps, a single planning problem per
-GPU.  Ranks (one per GPU, launched by torch.distributed.run) hold independent random worlds: the path
-shards with no collective, so scaling is "weak" and `value` = problems*steps over all ranks / max-rank time.
+GPU.  Ranks (one per GPU) hold independent random worlds: the path shards with no collective, so scaling is
+"weak" and `value` = problems*steps over all ranks / max-rank time.
+
+Launching: `python bench.py --gpus N` starts its own N rank processes (one per device, rendezvous on
+127.0.0.1) when it is not already running under torch.distributed.run; the parent process touches neither
+torch nor HIP.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are
+the launcher's.
+
+Timing: the K timed steps (one instantiated graph of K kernel nodes) are bracketed by barrier + device
+synchronize on both sides and the interval is MAX-reduced over the ranks; this is repeated R times
+(default 9) and the MEDIAN interval is what `value` and `ms_per_step` are computed from -- a single 20-step
+interval is 0.1 ms and one scheduling hiccup moved the round-1 headline by 30 %.
 
 The JSON line also carries
   roofline     HBM roofline of the P2 kernel: algorithmic bytes per launch / average launch
@@ -17,12 +27,14 @@ The JSON line also carries
                bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,6 +43,44 @@ METRIC = "planning iters/s (eval_g+jac) Kinova 7-DOF, 100 timesteps × 20 obstac
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def launch_ranks(n_ranks, argv):
+    """Start `n_ranks` fresh copies of this script, one per device, and return the largest exit code.  Runs in the
+    parent BEFORE anything imports torch or touches HIP (a process that has initialised the GPU must not spawn-and-
+    replace itself on this pool; plain child processes are fine).  Rank 0 inherits stdout, so its one JSON line is
+    the parent's output."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                rc = max(rc, abs(code))
+                if code != 0:           # one rank failed: the others would wait at the next barrier forever
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- measurement pieces
 def cpu_baseline(T, O, seed, budget_s=12.0):
     """Oracle (kind 'port') on the host cores: P2 evals/s on the same world, bounded to ~budget_s seconds."""
     from oracle.cpu_oracle import Oracle, max_threads
@@ -57,88 +107,200 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
 
 
 def measured_traffic(B, O, T):
-    """HBM bytes per P2 launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json:
-    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile of this config exists."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_headline_pmc.json")
-    if (B, O, T) != (1, 20, 100) or not os.path.exists(path):
+    """HBM bytes per P2 launch from the newest committed rocprofv3 PMC passes of this same command
+    (profiles/r*_bench_headline_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).
+    None when no profile of this config exists."""
+    if (B, O, T) != (1, 20, 100):
         return None
-    try:
-        return float(json.load(open(path))["p2_hbm_traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_headline_pmc.json")), reverse=True):
+        try:
+            return float(json.load(open(path))["p2_hbm_traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
-def other_configs(device):
-    """BASELINE configs[2] (O=50, 128 random worlds on one GPU: the HBM-bound regime) measured the same way, reported
-    next to the headline line (not as `value`)."""
-    import torch
-    from armour_amd.planner import ArmourNLP
-    from armour_amd.worlds import random_batch, random_k
-    out = {}
-    for name, B, O, T, K in (("configs[2]: O=50, batch 128, T=100", 128, 50, 100, 40),):
-        dev = torch.device("cuda", device)
-        probs = random_batch(1000, B, O)
-        nlp = ArmourNLP(T=T, device=device).set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
-        ks = torch.tensor(random_k(77, (K + 4) * B).reshape(K + 4, B, nlp.n), device=dev)
-        d_g = torch.empty((B, nlp.m), device=dev, dtype=torch.float64)
-        d_jac = torch.empty((B, nlp.m, nlp.n), device=dev, dtype=torch.float64)
-        st = torch.cuda.Stream(device=dev)
-        nlp.prepare_steps(ks[4:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr())
-        nlp.eval_g_jac_device_steps(ks.data_ptr(), 4, d_g.data_ptr(), d_jac.data_ptr(), st.cuda_stream)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        nlp.eval_g_jac_device_steps(ks[4:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr(), st.cuda_stream)
-        e1.record(st)
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / K
-        b_alg = nlp.algorithmic_bytes()
-        out[name] = {"problem_evals_per_s": B / (us * 1e-6), "launch_us": us, "algorithmic_bytes_per_launch": b_alg,
-                     "achieved_GBps": b_alg / (us * 1e-6) / 1e9, "frac_of_hbm_peak": b_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "p1_set_problems_ms_per_problem": nlp.build_ms / B}
-        nlp.close()
-        del d_g, d_jac, ks
+class Timed:
+    """K fused evaluations of one handle's problems as one graph, timed R times.  Every interval is bracketed by
+    barrier + synchronize on both sides and MAX-reduced over the ranks (armour_amd.sharding.reduce_max_elapsed)."""
+
+    def __init__(self, nlp, dev, seed, K, W, use_dist):
+        import torch
+        from armour_amd.worlds import random_k
+        self.torch, self.nlp, self.dev, self.K, self.W, self.use_dist = torch, nlp, dev, K, W, use_dist
+        B, n, m = nlp.B, nlp.n, nlp.m
+        self.ks = torch.tensor(random_k(seed, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
+        self.d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
+        self.d_jac = torch.empty((B, m, n), device=dev, dtype=torch.float64)
+        self.stream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: HIP events on the null stream do not bracket the launches
+        # the K timed launches go out as one instantiated graph (a chain of K kernel nodes), built before the timed region
+        nlp.prepare_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr())
+
+    def barrier(self):
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, repeats):
+        from armour_amd.sharding import reduce_max_elapsed
+        torch, nlp, K, W = self.torch, self.nlp, self.K, self.W
+        sh = self.stream.cuda_stream
+        if W > 0:
+            nlp.eval_g_jac_device_steps(self.ks.data_ptr(), W, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
+        wall, ev = [], []
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.barrier()
+            t0 = time.perf_counter()
+            e0.record(self.stream)
+            nlp.eval_g_jac_device_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
+            e1.record(self.stream)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            self.barrier()
+            wall.append(reduce_max_elapsed(elapsed, device=self.dev if self.use_dist else None))
+            ev.append(reduce_max_elapsed(e0.elapsed_time(e1) * 1e-3, device=self.dev if self.use_dist else None))
+        return wall, ev
+
+    def check(self, oracle_problems=None, tol_g=1e-9, tol_j=1e-8):
+        """The last timed step's device outputs are finite and bit-equal to the synchronous host entry at the same k;
+        with `oracle_problems` = [(b, world dict)], those problems' g / jac also agree with the CPU oracle."""
+        import numpy as np
+        k_last = self.ks[-1].cpu().numpy()
+        g_host, jac_host = self.nlp.eval_g_jac(k_last)
+        g_dev, jac_dev = self.d_g.cpu().numpy(), self.d_jac.cpu().numpy()
+        assert np.isfinite(g_host).all() and np.isfinite(jac_host).all(), "non-finite constraint values"
+        assert np.array_equal(g_host, g_dev) and np.array_equal(jac_host, jac_dev), "device entry != host entry"
+        worst = None
+        if oracle_problems:
+            from oracle.cpu_oracle import Oracle
+            dg = dj = 0.0
+            for b, p in oracle_problems:
+                o = Oracle(T=self.nlp.T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+                g_ref, jac_ref = o.eval_g_jac(k_last[b])
+                dg = max(dg, float(np.abs(g_dev[b] - g_ref).max()))
+                dj = max(dj, float(np.abs(jac_dev[b] - jac_ref).max()))
+            assert dg <= tol_g and dj <= tol_j, (dg, dj)
+            worst = {"problems": [b for b, _ in oracle_problems], "max_abs_dg": dg, "max_abs_djac": dj}
+        return worst
+
+
+def summarise(nlp, wall, ev, K, world, extra=None):
+    b_alg = nlp.algorithmic_bytes()
+    med_wall, med_ev = statistics.median(wall), statistics.median(ev)
+    launch_us = med_ev * 1e6 / K
+    achieved = b_alg / (launch_us * 1e-6) / 1e9
+    out = {"problem_evals_per_s": world * nlp.B * K / med_wall, "ms_per_step": med_wall * 1e3 / K, "launch_us": launch_us,
+           "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+           "repeats": len(wall), "wall_ms_min_med_max": [min(wall) * 1e3, med_wall * 1e3, max(wall) * 1e3],
+           "p1_set_problems_ms_per_problem": nlp.build_ms / nlp.B}
+    if extra:
+        out.update(extra)
     return out
 
 
+def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle):
+    """One more BASELINE config measured exactly like the headline (never `value`): B worlds per GPU at O obstacles."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.sharding import shard_seeds
+    from armour_amd.worlds import random_batch, random_problem
+    seeds = shard_seeds(1000, world * B, rank, world)
+    probs = random_batch(seeds[0], len(seeds), O)
+    nlp = ArmourNLP(T=T, device=device).set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
+    tm = Timed(nlp, dev, 77 + rank, K, 4, use_dist)
+    wall, ev = tm.run(R)
+    # output check: finite, device entry == host entry, two problems against the CPU oracle (rank 0; the oracle is the checker)
+    spot = None
+    if check_oracle is not None:
+        picks = [(b, random_problem(seeds[b], O)) for b in ((0, B - 1) if check_oracle and rank == 0 else ())]
+        spot = tm.check(picks)
+    out = summarise(nlp, wall, ev, K, world, {"checked": "finite + device entry == host entry" + (" + oracle on problems 0 and B-1" if spot else ""),
+                                               "oracle_spot_check": spot} if check_oracle is not None else {"checked": None})
+    nlp.close()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- dry run (CPU, gloo)
+def dry_run(args, rank, world):
+    """Development / test mode: the launcher, the rendezvous (gloo) and the timing reduction of the real run with the GPU
+    work replaced by a sleep.  Used by tests/test_host_logic.py on a CPU-only host; prints the same JSON shape."""
+    import torch.distributed as dist
+    from armour_amd.sharding import gather_counts, reduce_max_elapsed, shard_seeds
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seeds = shard_seeds(0, world * args.batch, rank, world)
+    wall = []
+    for _ in range(args.repeats):
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(1e-4 * args.steps * (1 + rank))   # the slowest rank sets the interval
+        el = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        wall.append(reduce_max_elapsed(el))
+    counts = gather_counts(len(seeds))
+    if rank == 0:
+        med = statistics.median(wall)
+        print(json.dumps({"metric": METRIC, "value": sum(counts) * args.steps / med, "unit": "iters/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": med * 1e3 / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "dry-run (no GPU work)",
+                          "config": {"workload": "dry run", "batch_per_gpu": args.batch, "problems_per_rank": counts},
+                          "repeats": args.repeats}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=9, help="timed intervals of --steps steps each; the median is reported")
     ap.add_argument("--batch", type=int, default=1, help="planning problems per GPU (1 = BASELINE configs[1])")
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--time-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="development (ablated kernel builds): skip the output sanity check")
-    ap.add_argument("--headline-only", action="store_true", help="skip the extra configs[2] measurement (used under rocprofv3)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra measurements (other configs, multi-point, planning iteration)")
+    ap.add_argument("--no-sync-probe", action="store_true",
+                    help="for runs under rocprofv3: no synchronous host-pointer calls at all (they add PCIe-bound launches of the same "
+                         "kernel to the trace), i.e. skip the host-entry check and the sync-latency probe")
+    ap.add_argument("--dry-run", action="store_true", help="development / tests: launcher + rendezvous + reduction on CPU (gloo), no GPU work")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # the parent: no torch, no HIP
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from armour_amd.planner import ArmourNLP
     from armour_amd.sharding import shard_seeds
-    from armour_amd.worlds import random_batch, random_k
+    from armour_amd.worlds import random_batch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even a single rank goes through RCCL
+    use_dist = world > 1 or "RANK" in os.environ   # under a launcher even a single rank goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B, O, T, K, W = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup
+    B, O, T, K, W, R = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup, max(1, args.repeats)
     # independent worlds per rank (block partition of world*B seeds, armour_amd/sharding.py); no data-path collective
     seeds = shard_seeds(0, world * B, rank, world)
     probs = random_batch(seeds[0], len(seeds), O)
@@ -150,90 +312,59 @@ def main():
     p1_dev_ms = nlp.build_ms
 
     n, m = nlp.n, nlp.m
-    ks = torch.tensor(random_k(rank, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
-    d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
-    d_jac = torch.empty((B, m, n), device=dev, dtype=torch.float64)
-    stream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: HIP events on the null stream do not bracket the launches
-    sh = stream.cuda_stream
-    torch.cuda.synchronize()
+    tm = Timed(nlp, dev, rank, K, W, use_dist)
+    wall, ev = tm.run(R)
+    if not args.no_check and not args.no_sync_probe:
+        tm.check()   # finite, and the synchronous host entry reproduces the device entry bit for bit
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # the K timed launches go out as one instantiated graph (a chain of K kernel nodes): build it before the timed region
-    nlp.prepare_steps(ks[W:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr())
-    # warm-up (untimed)
-    nlp.eval_g_jac_device_steps(ks.data_ptr(), W, d_g.data_ptr(), d_jac.data_ptr(), sh)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    e0.record(stream)
-    nlp.eval_g_jac_device_steps(ks[W:].data_ptr(), K, d_g.data_ptr(), d_jac.data_ptr(), sh)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    barrier()
-    ev_ms = e0.elapsed_time(e1)
-
-    el = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed_max, ev_ms_max = float(el[0]), float(el[1])
-
-    # sanity: the last step's outputs are finite and the synchronous host entry agrees with the device entry
-    g_host, jac_host = nlp.eval_g_jac(ks[-1].cpu().numpy())
-    if not args.no_check:
-        assert np.isfinite(g_host).all() and np.isfinite(jac_host).all()
-        assert np.array_equal(g_host, d_g.cpu().numpy()) and np.array_equal(jac_host, d_jac.cpu().numpy())
-
+    out = None
     if rank == 0:
-        b_alg = nlp.algorithmic_bytes()          # bytes one launch must move (all B problems)
-        launch_us = ev_ms_max * 1e3 / K          # average launch duration over the timed region (HIP events)
-        achieved = b_alg / (launch_us * 1e-6) / 1e9
-        # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
-        k1 = ks[0].cpu().numpy()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            nlp.eval_g_jac(k1)
-        sync_us = (time.perf_counter() - t1) / 20 * 1e6
-        nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
-        t1 = time.perf_counter()
-        for _ in range(50):
-            nlp.eval_g_jac(k1, pinned=True)
-        sync_pinned_us = (time.perf_counter() - t1) / 50 * 1e6
+        s = summarise(nlp, wall, ev, K, world)
+        cfg_id = 1 if (B, O, T) == (1, 20, 100) else 2 if (B, O, T) == (128, 50, 100) else 3 if (B, O, T) == (128, 20, 100) else "custom"
         out = {
-            "metric": METRIC, "value": world * B * K / elapsed_max, "unit": "iters/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": elapsed_max * 1e3 / K, "higher_is_better": True,
+            "metric": METRIC, "value": s["problem_evals_per_s"], "unit": "iters/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": s["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Kinova Gen3 7-DOF, {O} obstacles, {T} time steps, {B} planning problem(s) per GPU "
-                                   f"(BASELINE configs[{1 if (B, O, T) == (1, 20, 100) else 2 if (B, O) == (128, 50) else 'custom'}]), "
-                                   "one fused eval_g+eval_jac_g launch per step at a fresh k",
+                                   f"(BASELINE configs[{cfg_id}]), one fused eval_g+eval_jac_g launch per step at a fresh k",
                        "robot": "kinova_gen3_7dof_no_gripper", "batch_per_gpu": B, "obstacles": O, "time_steps": T,
                        "constraints_m": m, "parallelism": f"independent worlds x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, O, T),
-                         "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": b_alg,
-                         "launch_us": launch_us},
+            "timing": {"repeats": R, "statistic": "median of the max-over-ranks wall time of K steps (barrier + synchronize on both sides)",
+                       "wall_ms_min_med_max": s["wall_ms_min_med_max"]},
+            "roofline": {"bound": "hbm", "achieved": s["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": s["frac_of_hbm_peak"], "traffic": measured_traffic(B, O, T),
+                         "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],
+                         "launch_us": s["launch_us"]},
             "p1_set_problems_ms": {"device": p1_dev_ms, "wall": p1_wall_ms, "per_problem_device": p1_dev_ms / B},
-            "sync_host_call_us": {"pageable": sync_us, "pinned": sync_pinned_us},
             "table_sizes": nlp.table_sizes(),
         }
+        if not args.no_sync_probe:
+            # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
+            k1 = tm.ks[0].cpu().numpy()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                nlp.eval_g_jac(k1)
+            sync_us = (time.perf_counter() - t1) / 20 * 1e6
+            nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
+            t1 = time.perf_counter()
+            for _ in range(50):
+                nlp.eval_g_jac(k1, pinned=True)
+            out["sync_host_call_us"] = {"pageable": sync_us, "pinned": (time.perf_counter() - t1) / 50 * 1e6}
         if not args.headline_only:
             # extra (never `value`): P points of the same problems per launch, tables held in registers across points
             P = 16
             L = max(1, min(K // P, 64))
             d_gm = torch.empty((P, B, m), device=dev, dtype=torch.float64)
             d_jm = torch.empty((P, B, m, n), device=dev, dtype=torch.float64)
-            kp = ks[:P].contiguous()
+            kp = tm.ks[:P].contiguous()
+            sh = tm.stream.cuda_stream
             nlp.eval_g_jac_device_multi(kp.data_ptr(), P, d_gm.data_ptr(), d_jm.data_ptr(), sh)
             torch.cuda.synchronize()
             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            m0.record(stream)
+            m0.record(tm.stream)
             for _ in range(L):
                 nlp.eval_g_jac_device_multi(kp.data_ptr(), P, d_gm.data_ptr(), d_jm.data_ptr(), sh)
-            m1.record(stream)
+            m1.record(tm.stream)
             torch.cuda.synchronize()
             mus = m0.elapsed_time(m1) * 1e3 / L
             out["multi_point_launch"] = {"points_per_launch": P, "launch_us": mus, "point_evals_per_s": P * B / (mus * 1e-6),
@@ -256,14 +387,27 @@ def main():
                     sols = pn.solve()
                     solve_ms = (time.perf_counter() - t1) * 1e3
                 plan[f"{pb} problem(s)"] = {"reach_sets_ms": pn.build_ms, "solve_ms": solve_ms,
-                                             "evaluations": int(sols[0]["evaluations"]), "feasible": int(sum(int(s["feasible"]) for s in sols))}
+                                             "evaluations": int(sols[0]["evaluations"]), "feasible": int(sum(int(s2["feasible"]) for s2 in sols))}
                 pn.close()
             out["planning_iteration_sample_problem"] = plan
-        if world == 1 and (B, O, T) == (1, 20, 100) and not args.headline_only:
-            out["other_configs"] = other_configs(local_rank)
+    nlp_done = (B, O, T) == (1, 20, 100) and not args.headline_only
+    if nlp_done:
+        # the other BASELINE configs, measured the same way by every rank (extras, never `value`):
+        #   N = 1: configs[2] = 128 random worlds at O = 50 on one GPU, outputs checked (incl. two problems against the oracle)
+        #   N > 1: configs[3] = 128 worlds per GPU at O = 20 (1024 over 8 GPUs), outputs checked
+        KX = max(4, min(K, 40))
+        chk = None if args.no_check or args.no_sync_probe else True
+        if world == 1:
+            oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk)}
+        else:
+            oc = {f"configs[3]: O=20, batch 128 per GPU ({128 * world} worlds over {world} GPUs), T=100":
+                  extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False)}
+        if rank == 0:
+            out["other_configs"] = oc
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, O, seed=0)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

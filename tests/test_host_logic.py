@@ -114,6 +114,27 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert "GLOO_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver invokes it (no torch.distributed.run around it): the parent starts one
+    process per rank, they meet on 127.0.0.1 and rank 0 prints ONE JSON line.  --dry-run swaps the GPU work for a sleep and
+    RCCL for gloo; launcher, rendezvous and the timing reduction (armour_amd.sharding) are the code of the real run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "1", "--repeats", "3",
+                          "--batch", "3", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]   # (gloo prints a connection banner on stdout)
+    assert len(lines) == 1, out.stdout
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["steps"] == 20 and js["scaling"] == "weak" and js["config"]["problems_per_rank"] == [3, 3]
+    # the slowest rank (rank 1 sleeps twice as long) sets the interval: value = 6 problems * 20 steps / max-rank time
+    assert js["ms_per_step"] >= 2 * 0.1 * 0.9 and abs(js["value"] - 6 * 20 / (js["ms_per_step"] * 20e-3)) <= 1e-6 * js["value"]
+    # a mismatch between --gpus and an existing WORLD_SIZE is refused, not silently re-interpreted
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode != 0 and "does not match" in bad.stderr
+
+
 def _matlab_desired_trajectory(q0, qd0, qdd0, q1, t):
     """KSI/uarmtd_planner.m:886-905 restated: match_deg5_bernstein_coefficients (final velocity and acceleration 0,
     T = 1) -> bernstein_to_poly -> power-basis evaluation of position, velocity and acceleration."""
