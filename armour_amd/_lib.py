@@ -29,6 +29,7 @@ class ArmourRobot(C.Structure):
         ("gravity", C.c_double),
         ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
         ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
+        ("mass_uncertainty_link", C.c_double * MAXJ), ("inertia_uncertainty_link", C.c_double * MAXJ),
     ]
 
 
@@ -60,7 +61,7 @@ class ArmourSolveResult(C.Structure):
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_params_default", "armour_create", "armour_destroy",
+    "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_robot_fetch", "armour_params_default", "armour_create", "armour_destroy",
     "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_set_problems_armtd", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_prepare_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
@@ -113,6 +114,8 @@ def load():
     L.armour_robot_kinova_gen3_no_gripper.argtypes = [C.POINTER(ArmourRobot)]
     L.armour_robot_kinova_gen3_no_gripper.restype = None
     L.armour_robot_kinova_gen3_gripper.argtypes = [C.POINTER(ArmourRobot)]
+    L.armour_robot_fetch.argtypes = [C.POINTER(ArmourRobot)]
+    L.armour_robot_fetch.restype = None
     L.armour_robot_kinova_gen3_gripper.restype = None
     L.armour_params_default.argtypes = [C.POINTER(ArmourParams), C.c_int32]
     L.armour_params_default.restype = None

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <new>
 
+#include "../../include/armour_robot_fetch.h"
 #include "../../include/armour_robot_kinova.h"
 #include "bezier.h"
 #include "cacc.h"
@@ -24,6 +25,7 @@ extern "C" const char* armour_last_error(void) { return g_err; }
 
 extern "C" void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_no_gripper(robot); }
 extern "C" void armour_robot_kinova_gen3_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_gripper(robot); }
+extern "C" void armour_robot_fetch(ArmourRobot* robot) { armour_fill_fetch(robot); }
 extern "C" void armour_params_default(ArmourParams* params, int32_t T) { armour_fill_default_params(params, T); }
 
 extern "C" int armour_device_available(void) {

@@ -517,11 +517,11 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
         set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
         if (!kin_only) {
             // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
-            double mi = cf.rb.mass_uncertainty * fabs(cf.rb.mass[i]);
+            double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
             double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
             double ii[9];
-            for (int e = 0; e < 9; e++) ii[e] = cf.rb.inertia_uncertainty * fabs(cf.rb.inertia[9 * i + e]);
+            for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
             set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
         }
         // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)

@@ -37,6 +37,18 @@ def kinova_gripper_robot():
     return r
 
 
+def fetch_robot(payload_mass_uncertainty=0.0):
+    """CMP/FetchInfo.h (9 links, 7 factors, mixed joint axes; link boxes / M_max are stand-ins, include/armour_robot_fetch.h).
+    payload_mass_uncertainty > 0 widens the mass (and inertia) interval of the last link to +-that fraction: BASELINE
+    configs[4], "payload-mass uncertainty"."""
+    r = ArmourRobot()
+    _lib.load().armour_robot_fetch(C.byref(r))
+    if payload_mass_uncertainty:
+        r.mass_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+        r.inertia_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+    return r
+
+
 def default_params(T=128):
     p = ArmourParams()
     _lib.load().armour_params_default(C.byref(p), T)

@@ -156,6 +156,8 @@ class Timed:
             e0.record(self.stream)
             nlp.eval_g_jac_device_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
             e1.record(self.stream)
+            while not self.stream.query():   # poll the stream: a sleeping synchronize adds its wake-up latency to a 0.1 ms interval
+                pass
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
             self.barrier()

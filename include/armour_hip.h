@@ -56,6 +56,9 @@ typedef struct ArmourLimits {
 /* ---- robot / parameter presets (RT/KinovaWithoutGripperInfo.h, RT/Parameters.h) ---- */
 void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot);
 void armour_robot_kinova_gen3_gripper(ArmourRobot* robot);   /* RT/KinovaInfo.h: 8 links, last joint fixed */
+/* CMP/FetchInfo.h: 9 links (two fixed), 7 factors, joint axes {z,y,x,y,x,y,x}; link boxes and M_max are stand-ins
+ * (include/armour_robot_fetch.h).  For payload-mass uncertainty set robot->mass_uncertainty_link[i] afterwards. */
+void armour_robot_fetch(ArmourRobot* robot);
 void armour_params_default(ArmourParams* params, int32_t num_time_steps);
 
 /* ---- lifetime ---- */

@@ -50,7 +50,22 @@ typedef struct ArmourRobot {
     double link_zonotope_generators[ARMOUR_MAX_JOINTS * 3];
     /* ultimate bound (RT/KinovaWithoutGripperInfo.h:103-112); eps, qe, qde, qdae, qddae are derived */
     double alpha, V_m, M_max, M_min, K;
+    /* per-link overrides of mass_uncertainty / inertia_uncertainty: entry i != 0 replaces the scalar for link i (the reference has one
+     * scalar for every link, RT/Dynamics.cu:33,40; a payload of uncertain mass on the last link is e.g. mass_uncertainty_link[J-1] = 0.5,
+     * BASELINE configs[4]).  Zero-initialised structs behave as before. */
+    double mass_uncertainty_link[ARMOUR_MAX_JOINTS];
+    double inertia_uncertainty_link[ARMOUR_MAX_JOINTS];
 } ArmourRobot;
+
+/* relative uncertainty of link i's mass / inertia (the per-link entry if set, else the robot-wide scalar); usable from
+ * plain C / C++ hosts and, when this header is compiled by hipcc, from device code */
+#if defined(__HIPCC__)
+#define ARMOUR_HD __host__ __device__
+#else
+#define ARMOUR_HD
+#endif
+ARMOUR_HD static inline double armour_mass_uncertainty(const ArmourRobot* r, int i) { return r->mass_uncertainty_link[i] != 0.0 ? r->mass_uncertainty_link[i] : r->mass_uncertainty; }
+ARMOUR_HD static inline double armour_inertia_uncertainty(const ArmourRobot* r, int i) { return r->inertia_uncertainty_link[i] != 0.0 ? r->inertia_uncertainty_link[i] : r->inertia_uncertainty; }
 
 typedef struct ArmourParams {
     int32_t num_time_steps;                 /* NUM_TIME_STEPS, must be even (RT/Parameters.h:16) */

@@ -22,10 +22,10 @@
 #include <cstdlib>
 #include <string>
 
-#include "../include/armour_robot_kinova.h"
 #include "../include/armour_types.h"
 #include "interval.hpp"
 #include "pz.hpp"
+#include "robot_tables.hpp" /* the oracle's own constants, generated from the reference headers (gen_robot_tables.py) */
 
 namespace oracle {
 
@@ -107,6 +107,17 @@ static double qd_des_extrema_k_derivative(double q0, double a, double b, double 
     const double dts = (dnum * 10 * den - num * 10 * (-12)) / (100 * den * den);
     const double dqddk = 30 * ts * ts * (ts - 1) * (ts - 1);
     return dqddk + qdd_des_func(q0, a, b, k, ts) * dts;
+}
+
+/* ultimate bound of the tracking error, RT/KinovaWithoutGripperInfo.h:103-112 */
+static ArmourUltimateBound ultimate_bound(const ArmourRobot& r) {
+    ArmourUltimateBound u;
+    u.eps = sqrt(2 * r.V_m / r.M_min);
+    u.qe = u.eps / r.K;
+    u.qde = 2 * u.eps;
+    u.qdae = u.eps;
+    u.qddae = 2 * r.K * u.eps;
+    return u;
 }
 
 /* ------------------------------------------------------------------ problem state */
@@ -458,7 +469,7 @@ static void build_hyperplanes(Problem& P) {
 static void build(Problem& P, int num_threads) {
     auto t0 = std::chrono::steady_clock::now();
     const int T = P.T, J = P.J, n = P.n;
-    P.ub = armour_ultimate_bound(&P.rb);
+    P.ub = ultimate_bound(P.rb);
     if (!P.armtd) bezier_init(P);
     P.R.assign((size_t)(J + 1) * T, PZ()); P.R_t.assign((size_t)J * T, PZ());
     P.qd_des.assign((size_t)n * T, PZ()); P.qda_des.assign((size_t)n * T, PZ()); P.qdda_des.assign((size_t)n * T, PZ());
@@ -473,9 +484,9 @@ static void build(Problem& P, int num_threads) {
     std::vector<PZ> mass_nom(J), mass_unc(J), I_nom(J), I_unc(J), link_box(J);
     for (int i = 0; i < J; i++) {
         mass_nom[i] = pz_matrix(1, 1, &P.rb.mass[i]);
-        mass_unc[i] = pz_matrix_uncertain(1, 1, &P.rb.mass[i], P.rb.mass_uncertainty);
+        mass_unc[i] = pz_matrix_uncertain(1, 1, &P.rb.mass[i], armour_mass_uncertainty(&P.rb, i));
         I_nom[i] = pz_matrix(3, 3, &P.rb.inertia[9 * i]);   /* symmetric: Eigen's column-major fill == row-major */
-        I_unc[i] = pz_matrix_uncertain(3, 3, &P.rb.inertia[9 * i], P.rb.inertia_uncertainty);
+        I_unc[i] = pz_matrix_uncertain(3, 3, &P.rb.inertia[9 * i], armour_inertia_uncertainty(&P.rb, i));
         link_box[i] = make_link_box(P, cx0, i);
     }
 #pragma omp parallel
@@ -642,9 +653,29 @@ static double wrap_to_pi(double a) { /* RT/NLPclass.cu:6-15 */
 using namespace oracle;
 extern "C" {
 
-void oracle_fill_kinova(ArmourRobot* rb) { armour_fill_kinova_gen3_no_gripper(rb); }
-void oracle_fill_kinova_gripper(ArmourRobot* rb) { armour_fill_kinova_gen3_gripper(rb); }
-void oracle_fill_default_params(ArmourParams* pr, int T) { armour_fill_default_params(pr, T); }
+void oracle_fill_kinova(ArmourRobot* rb) { oracle_tables::fill_kinova_gen3_no_gripper(rb); }
+void oracle_fill_kinova_gripper(ArmourRobot* rb) { oracle_tables::fill_kinova_gen3_gripper(rb); }
+void oracle_fill_fetch(ArmourRobot* rb) { oracle_tables::fill_fetch(rb); }
+void oracle_fill_default_params(ArmourParams* pr, int T) { oracle_tables::fill_default_params(pr, T); }
+
+/* The scalar Bezier helpers on their own (tests/test_ref_bezier.py checks them against the REFERENCE's functions compiled
+ * from RT/Trajectory.cu:542-822, oracle/_ref/libref_bezier.so, and against vectors recorded from that library).
+ * which: 0 q_des_func  1 qd_des_func  2 qdd_des_func (x = t)   3/4 q_des_extrema{2,3}_k_derivative   5/6 qd_des_extrema{2,3}_k_derivative
+ *        7 q_des_k_indep  8 qd_des_k_indep  9 qdd_des_k_indep (x = s; k unused) */
+double oracle_bezier_scalar(int which, double q0, double a, double b, double k, double x, double DUR) {
+    switch (which) {
+        case 0: return q_des_func(q0, a, b, k, x);
+        case 1: return qd_des_func(q0, a, b, k, x);
+        case 2: return qdd_des_func(q0, a, b, k, x);
+        case 3: return q_des_extrema_k_derivative(q0, a, b, k, +1);
+        case 4: return q_des_extrema_k_derivative(q0, a, b, k, -1);
+        case 5: return qd_des_extrema_k_derivative(q0, a, b, k, +1);
+        case 6: return qd_des_extrema_k_derivative(q0, a, b, k, -1);
+        case 7: return q_des_k_indep(q0, a, b, x);
+        case 8: return qd_des_k_indep(q0, a, b, x, DUR);
+        default: return qdd_des_k_indep(q0, a, b, x, DUR);
+    }
+}
 
 void* oracle_create(const ArmourRobot* rb, const ArmourParams* pr) {
     Problem* P = new Problem();

@@ -30,6 +30,7 @@ class ArmourRobot(C.Structure):
         ("gravity", C.c_double),
         ("link_zonotope_center", C.c_double * (MAXJ * 3)), ("link_zonotope_generators", C.c_double * (MAXJ * 3)),
         ("alpha", C.c_double), ("V_m", C.c_double), ("M_max", C.c_double), ("M_min", C.c_double), ("K", C.c_double),
+        ("mass_uncertainty_link", C.c_double * MAXJ), ("inertia_uncertainty_link", C.c_double * MAXJ),
     ]
 
 
@@ -95,7 +96,7 @@ def _dp(a):
 
 
 def kinova_robot():
-    """RT/KinovaWithoutGripperInfo.h constants (same data as include/armour_robot_kinova.h)."""
+    """RT/KinovaWithoutGripperInfo.h constants from the oracle's own generated table (oracle/robot_tables.hpp)."""
     r = ArmourRobot()
     lib().oracle_fill_kinova(C.byref(r))
     return r
@@ -105,6 +106,16 @@ def kinova_gripper_robot():
     """RT/KinovaInfo.h: the arm with the 1.72 kg gripper as a fixed 8th joint."""
     r = ArmourRobot()
     lib().oracle_fill_kinova_gripper(C.byref(r))
+    return r
+
+
+def fetch_robot(payload_mass_uncertainty=0.0):
+    """CMP/FetchInfo.h (oracle/robot_tables.hpp); payload_mass_uncertainty widens the last link's mass / inertia interval."""
+    r = ArmourRobot()
+    lib().oracle_fill_fetch(C.byref(r))
+    if payload_mass_uncertainty:
+        r.mass_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+        r.inertia_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
     return r
 
 

@@ -29,7 +29,7 @@ def test_struct_layout_matches_header():
     from armour_amd import _lib
     # sizes as the C compiler lays them out: 2+7+7 int32, then doubles
     J, F = 9, 7   # ARMOUR_MAX_JOINTS, ARMOUR_MAX_FACTORS
-    n_doubles = (J + 1) * 3 + J * 3 + J + 1 + J * 3 + J * 9 + 1 + J * 3 + F * 4 + 1 + J * 3 + J * 3 + 5
+    n_doubles = (J + 1) * 3 + J * 3 + J + 1 + J * 3 + J * 9 + 1 + J * 3 + F * 4 + 1 + J * 3 + J * 3 + 5 + 2 * J   # ... + the two per-link uncertainty arrays
     assert C.sizeof(_lib.ArmourRobot) == (2 + J + F) * 4 + n_doubles * 8
     assert C.sizeof(_lib.ArmourParams) == 8 + 8 * (1 + 7 + 5)
     assert C.sizeof(_lib.ArmourLimits) == 24

@@ -177,3 +177,83 @@ def test_cost_gradient():
     q_plan = p["q0"] + 0.5 * k * np.pi / 48
     e = p["q_des"] - q_plan
     assert abs(o.eval_f(k) - 10.0 * np.sum(e**2)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's only mixed-axis chain: Fetch (CMP/FetchInfo.h:16, axes {z,y,x,y,x,y,x,fixed,fixed}).  Same containment
+# check as RT/debug_script.m:96-123 with rotations about x / y / z: pins the oracle's handling of axes 1 and 2 (JRS
+# rotation matrices RT/PZsparse.cu:211-250, the joint-axis entries of RNEA RT/Dynamics.cu:111-131,166) to rigid-body
+# physics before the device is compared with it.
+def _rot_axis(axis, q):
+    c, s = np.cos(q), np.sin(q)
+    if axis == 1:
+        return np.array([[1.0, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == 2:
+        return np.array([[c, 0, s], [0, 1.0, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def _general_rnea_and_fk(r, q, qd, qda, qdda):
+    J, n = r.num_joints, r.num_factors
+    axes = list(r.axes)[:J]
+    tr = np.array(r.trans)[:3 * (J + 1)].reshape(J + 1, 3)
+    rots = np.array(r.rots)[:3 * J].reshape(J, 3)
+    com = np.array(r.com)[:3 * J].reshape(J, 3)
+    inertia = np.array(r.inertia)[:9 * J].reshape(J, 3, 3)
+    mass, arm, damp = np.array(r.mass)[:J], np.array(r.armature)[:J], np.array(r.damping)[:J]
+    zc = np.array(r.link_zonotope_center)[:3 * J].reshape(J, 3)
+    R = [rot_rpy(*rots[i]) @ (_rot_axis(axes[i], q[i]) if axes[i] else np.eye(3)) for i in range(J)] + [np.eye(3)]
+    w = np.zeros(3); wdot = np.zeros(3); waux = np.zeros(3); lacc = np.array([0, 0, r.gravity])
+    F, N = [], []
+    for i in range(J):
+        Rt = R[i].T
+        z = np.zeros(3)
+        if axes[i]:
+            z[abs(axes[i]) - 1] = 1.0
+        v, va, a = (qd[i], qda[i], qdda[i]) if axes[i] else (0.0, 0.0, 0.0)
+        lacc = Rt @ (lacc + np.cross(wdot, tr[i]) + np.cross(w, np.cross(waux, tr[i])))
+        w = Rt @ w + v * z
+        waux = Rt @ waux
+        wdot = Rt @ wdot + np.cross(waux, v * z) + a * z
+        waux = waux + va * z
+        F.append(mass[i] * (lacc + np.cross(wdot, com[i]) + np.cross(w, np.cross(waux, com[i]))))
+        N.append(inertia[i] @ wdot + np.cross(waux, inertia[i] @ w))
+    f = np.zeros(3); nn = np.zeros(3); u = np.zeros(n)
+    for i in range(J - 1, -1, -1):
+        nn = N[i] + R[i + 1] @ nn + np.cross(com[i], F[i]) + np.cross(tr[i + 1], R[i + 1] @ f)
+        f = R[i + 1] @ f + F[i]
+        if axes[i]:
+            u[i] = nn[abs(axes[i]) - 1] + arm[i] * qdda[i] + damp[i] * qd[i]
+    Rw = np.eye(3); pw = np.zeros(3); links = []
+    for i in range(J):
+        pw = pw + Rw @ tr[i]
+        Rw = Rw @ R[i]
+        links.append(Rw @ zc[i] + pw)
+    return u, np.array(links)
+
+
+def test_fetch_mixed_axes_inside_reach_sets():
+    from oracle.cpu_oracle import Oracle, default_params, fetch_robot
+    r = fetch_robot()
+    T = 32
+    q0 = np.array([0.4, -0.5, 0.8, 1.1, -0.7, 0.9, 0.3]); qd0 = np.array([0.5, -0.4, 0.6, -0.5, 0.7, -0.6, 0.4]); qdd0 = np.array([1.0, -1, 0.5, 1, -0.5, 1, -1])
+    o = Oracle(robot=r, params=default_params(T)).set_problem(q0, qd0, qdd0, q0, np.zeros((0, 12)))
+    assert (o.J, o.n) == (9, 7)
+    rng = np.random.default_rng(3)
+    for k in (np.zeros(7), PZ_TESTS_K, rng.uniform(-1, 1, 7)):
+        ka = k * np.pi / 48
+        tq_c, ln_c, gens = o.slice_torque(k), o.slice_links(k), o.link_generators()
+        for t in range(T):
+            tt = (t + rng.uniform(0.02, 0.98)) / T
+            q, qd, qdd = bezier(q0, qd0, qdd0, ka, tt)
+            u, links = _general_rnea_and_fk(r, q, qd, qd, qdd)
+            rad = np.array([o.pz("torque", j, t)[1][0] for j in range(7)])
+            assert np.all(np.abs(u - tq_c[t]) <= rad + 1e-9), (t, u - tq_c[t], rad)
+            hull = np.abs(gens[t]).sum(axis=2)
+            assert np.all(np.abs(links - ln_c[t]) <= hull + 1e-9), t
+    # and the joint axes matter: with all-z axes the same state gives different link positions
+    rz = fetch_robot()
+    for i in range(7):
+        rz.axes[i] = 3
+    oz = Oracle(robot=rz, params=default_params(T)).set_problem(q0, qd0, qdd0, q0, np.zeros((0, 12)))
+    assert np.abs(oz.slice_links(np.zeros(7)) - o.slice_links(np.zeros(7))).max() > 1e-2

@@ -231,6 +231,67 @@ def test_kinova_with_gripper_payload():
     assert nlp.torque_radius()[0].mean() != bare.torque_radius()[0].mean()
 
 
+def _fetch_problem(seed, O):
+    """a random state inside Fetch's joint limits (CMP/FetchInfo.h:86-89) and O random boxes"""
+    from armour_amd.worlds import random_problem
+    rng = np.random.default_rng(seed)
+    lb = np.array([-1.6056, -1.221, -np.pi, -2.251, -np.pi, -2.16, -np.pi]) + 0.3
+    ub = np.array([1.6056, 1.518, np.pi, 2.251, np.pi, 2.16, np.pi]) - 0.3
+    speed = np.array([1.256, 1.454, 1.571, 1.521, 1.571, 2.268, 2.268])
+    q0 = rng.uniform(lb, ub)
+    return dict(q0=q0, qd0=rng.uniform(-0.5, 0.5, 7) * speed, qdd0=rng.uniform(-1, 1, 7), q_des=q0 + rng.uniform(-0.3, 0.3, 7),
+                obstacles=random_problem(seed, O)["obstacles"])
+
+
+@pytest.mark.parametrize("mode", ["armour", "armtd"])
+def test_fetch_mixed_axes_payload_uncertainty(mode):
+    """BASELINE configs[4]: Fetch (CMP/FetchInfo.h: 9 links, 7 factors, joint axes {z,y,x,y,x,y,x}, two fixed links),
+    +-50 % mass / inertia uncertainty on the last link (the payload), 100 obstacles, T = 100 -- device against the oracle.
+    The first exercise of rotations about x and y (p1_reach.hip make_rotation, the joint-axis entries of the RNEA).
+    Link boxes / M_max are stated stand-ins (include/armour_robot_fetch.h); the "8-DOF" arm of BASELINE.json would need
+    an 8th factor, which the reference's own 64-bit monomial key cannot hold (RT/PZsparse.h:8-21).  `armtd` runs the same
+    robot through the comparison planner's chain -- the code path FetchInfo.h belongs to in the reference."""
+    from armour_amd.planner import ArmourNLP, default_params, fetch_robot
+    from armour_amd.worlds import random_k, synthetic_offline_jrs
+    from oracle.cpu_oracle import Oracle
+    from oracle.cpu_oracle import default_params as oracle_params
+    from oracle.cpu_oracle import fetch_robot as oracle_fetch
+    T, O = 100, 100
+    p = _fetch_problem(11, O)
+    nlp = ArmourNLP(robot=fetch_robot(0.5), params=default_params(T))
+    o = Oracle(robot=oracle_fetch(0.5), params=oracle_params(T))
+    if mode == "armour":
+        nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        o.set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        assert nlp.J == 9 and nlp.m == 7 * T + 9 * T * O + 28 == o.m
+    else:
+        jrs, kr = synthetic_offline_jrs(p["qd0"], T=T)
+        nlp.set_parameters_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
+        o.set_problem_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
+        assert nlp.m == 9 * T * O + 28 == o.m
+    _compare_tables(nlp, [o])
+    for k in (PZ_TESTS_K, random_k(6, 1)[0]):
+        g, jac = nlp.eval_g_jac(k)
+        gr, jr = o.eval_g_jac(k)
+        assert np.abs(g[0] - gr).max() <= G_TOL and np.abs(jac[0] - jr).max() <= J_TOL
+    _, _, gl, gu = nlp.get_bounds_info()
+    _, _, ogl, ogu = o.bounds()
+    assert np.abs(gl[0] - ogl).max() <= R_TOL and np.abs(gu[0] - ogu).max() <= R_TOL
+    if mode == "armour":
+        # the payload interval only widens the robust-input radius: same polynomials as the 3 % robot, larger radii
+        base = ArmourNLP(robot=fetch_robot(), params=default_params(T)).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"][:1])
+        tr, tb = nlp.torque_radius()[0], base.torque_radius()[0]
+        assert (tr >= tb).all() and (tr > tb + 1e-6).any()
+        assert np.array_equal(nlp.pz("torque", 3, 50)[2], base.pz("torque", 3, 50)[2])
+        # and a batch of two such problems equals the single-problem handles bit for bit (1-wave blocks vs 3-wave blocks)
+        p2 = _fetch_problem(12, O)
+        st = lambda key: np.stack([p[key], p2[key]])
+        two = ArmourNLP(robot=fetch_robot(0.5), params=default_params(T)).set_parameters(st("q0"), st("qd0"), st("qdd0"), st("q_des"), st("obstacles"))
+        g2, j2 = two.eval_g_jac(np.stack([PZ_TESTS_K, PZ_TESTS_K]))
+        g1, j1 = nlp.eval_g_jac(PZ_TESTS_K)
+        assert np.array_equal(g2[0], g1[0]) and np.array_equal(j2[0], j1[0])
+
+
 def test_more_work_items_than_resident_waves():
     """B*T = 1000 (problem, time step) items exceed the persistent grid (<= 4 waves x 256 CUs would hold them, the
     LDS-limited grid of 768 does not): waves loop over several items and must give the same tables as a

@@ -1,0 +1,132 @@
+"""Row a13 of SURVEY.md section 8 pinned to the REFERENCE ITSELF.
+
+RT/Trajectory.cu:542-822 -- q_des_func, qd_des_func, qdd_des_func, the MATLAB-generated q*_des_extrema{2,3}_k_derivative
+helpers (~40 temporaries each) and the *_k_indep polynomials -- are free functions that need nothing but <cmath>, so
+`make -C oracle ref` compiles them straight from the reference's file into oracle/_ref/libref_bezier.so (the rest of the
+reference needs CUDA / Eigen / Boost / IPOPT and cannot be built here).  tests/golden/make_ref_bezier_vectors.py recorded
+that library's outputs as fixtures; they travel, the reference does not.
+
+Both the oracle and the device write the k-derivative of an interior extremum as the chain rule
+df/dk + df/dt * dt*/dk instead of the reference's symbolic expansion (round-1 verdict: "a self-comparison").  Here the
+chain-rule form meets the reference's expansion: 1e-9 relative on the scalar functions, 1e-9 absolute on assembled rows.
+
+CPU: oracle vs recorded vectors; the live library (when present) reproduces the recorded vectors bit for bit; oracle
+eval_g / eval_jac_g limit rows vs rows assembled from the reference's functions.  GPU: the fused kernel's limit rows and
+the Jacobian's limit block vs the same recorded rows."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import load_golden
+
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref_bezier.so")
+REF_SRC = "/root/reference/kinova_src/kinova_simulator_interfaces/kinova_planner_realtime/Trajectory.cu"
+RTOL = 1e-9
+
+
+def _close(a, b, rtol=RTOL, atol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(both_nan | (np.abs(a - b) <= atol + rtol * np.abs(b))))
+
+
+def _oracle_scalar():
+    from oracle.cpu_oracle import lib
+    L = lib()
+    L.oracle_bezier_scalar.restype = C.c_double
+    L.oracle_bezier_scalar.argtypes = [C.c_int] + [C.c_double] * 6
+    return L.oracle_bezier_scalar
+
+
+def test_oracle_scalars_against_recorded_reference_outputs():
+    gd = load_golden("ref_bezier_vectors")
+    x, y = gd["x"], gd["y"]
+    f = _oracle_scalar()
+    got = np.array([[f(c, *row, 1.0) for c in range(10)] for row in x])
+    finite = np.isfinite(y).all(axis=1)
+    assert finite.sum() >= 550
+    for c, name in enumerate(gd["columns"]):
+        # NaN (0/0 at a start at rest) must be NaN on both sides: the selection logic relies on NaN comparing false
+        assert np.array_equal(np.isnan(got[:, c]), np.isnan(y[:, c])), name
+        # the symbolic expansion and the chain rule lose digits differently where the discriminant is tiny; bound the
+        # error relative to the magnitude of the value OR of the inputs' conditioning (|y| can pass through zero)
+        scale = np.maximum(np.abs(y[finite, c]), 1.0)
+        err = np.abs(got[finite, c] - y[finite, c]) / scale
+        assert err.max() <= RTOL, (name, err.max(), x[finite][err.argmax()])
+
+
+def test_live_reference_library_reproduces_the_recorded_vectors():
+    """Regenerating the fixture gives the same numbers: the recorded vectors ARE the reference's outputs."""
+    if not os.path.exists(REF_LIB):
+        if not os.path.exists(REF_SRC):
+            pytest.skip("no reference checkout and no prebuilt oracle/_ref (the recorded vectors stand in)")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_ref_bezier_vectors import NAMES4, NAMES5, load_ref, ref_limit_rows
+    fns = load_ref(REF_LIB)
+    gd = load_golden("ref_bezier_vectors")
+    for row, want in zip(gd["x"][::7], gd["y"][::7]):
+        q0, a, b, k, t = row
+        got = [fns[nm](q0, a, b, k, t) for nm in NAMES5] + [fns[nm](q0, a, b, k) for nm in NAMES4[:4]] + [fns[nm](q0, a, b, t) for nm in NAMES4[4:]]
+        assert np.array_equal(np.array(got), want, equal_nan=True)
+    lr = load_golden("ref_limit_rows")
+    kr = np.full(7, np.pi / 48)
+    for name in lr["cases"]:
+        q0, qd0, qdd0 = lr[f"{name}_state"]
+        rows, diag = ref_limit_rows(fns, q0, qd0, qdd0, lr[f"{name}_k"][3], kr, 1.0)
+        assert np.array_equal(rows, lr[f"{name}_rows"][3]) and np.array_equal(diag, lr[f"{name}_diag"][3])
+
+
+def _limit_block(g, jac, n=7):
+    """last 4n rows of g and the diagonal of their Jacobian block; also checks that the off-diagonal entries are 0"""
+    rows, blk = g[-4 * n:], jac[-4 * n:]
+    diag = np.array([blk[r, r % n] for r in range(4 * n)])
+    off = blk.copy()
+    off[np.arange(4 * n), np.arange(4 * n) % n] = 0.0
+    assert not off.any()
+    return rows, diag
+
+
+def test_oracle_limit_rows_against_reference_rows():
+    from oracle.cpu_oracle import Oracle
+    lr = load_golden("ref_limit_rows")
+    for name in lr["cases"]:
+        q0, qd0, qdd0 = lr[f"{name}_state"]
+        o = Oracle(T=10).set_problem(q0, qd0, qdd0, q0, np.zeros((0, 12)))
+        for k, rows_ref, diag_ref in zip(lr[f"{name}_k"], lr[f"{name}_rows"], lr[f"{name}_diag"]):
+            g, jac = o.eval_g_jac(k)
+            rows, diag = _limit_block(g, jac)
+            assert np.abs(rows - rows_ref).max() <= 1e-12, name
+            assert np.abs(diag - diag_ref).max() <= 1e-9, (name, np.abs(diag - diag_ref).max())
+
+
+@pytest.mark.gpu
+def test_device_limit_rows_against_reference_rows():
+    """armour_p2_eval_kernel's joint-limit block (bezier.h on the device) against the rows the reference's own functions
+    give: one-point launches and one multi-point launch over the 12 recorded points."""
+    import torch
+    from armour_amd.planner import ArmourNLP
+    lr = load_golden("ref_limit_rows")
+    for name in lr["cases"]:
+        q0, qd0, qdd0 = lr[f"{name}_state"]
+        ks = lr[f"{name}_k"]
+        nlp = ArmourNLP(T=10).set_parameters(q0, qd0, qdd0, q0, np.zeros((0, 12)))
+        P, m, n = len(ks), nlp.m, nlp.n
+        d_k = torch.from_numpy(ks.reshape(P, 1, n)).to("cuda:0")
+        d_g = torch.zeros((P, 1, m), dtype=torch.float64, device="cuda:0")
+        d_j = torch.zeros((P, 1, m, n), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        nlp.eval_g_jac_device_multi(d_k.data_ptr(), P, d_g.data_ptr(), d_j.data_ptr())
+        for s, (k, rows_ref, diag_ref) in enumerate(zip(ks, lr[f"{name}_rows"], lr[f"{name}_diag"])):
+            g, jac = nlp.eval_g_jac(k)
+            rows, diag = _limit_block(g[0], jac[0])
+            assert np.abs(rows - rows_ref).max() <= 1e-12, name
+            assert np.abs(diag - diag_ref).max() <= 1e-9, (name, np.abs(diag - diag_ref).max())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_g[s, 0].cpu().numpy(), g[0]) and np.array_equal(d_j[s, 0].cpu().numpy(), jac[0])
+        nlp.close()
