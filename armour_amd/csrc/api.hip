@@ -1,5 +1,6 @@
 // C ABI of libarmour_hip.so (see include/armour_hip.h): handle lifetime, device-table ownership, the
 // NLP-callback entry points and the host-side closed forms (bounds, cost, feasibility re-check).
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -82,6 +83,9 @@ static void dev_free(Tp** p) {
 static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     if (B <= h->allocB && O <= h->allocO) return ARMOUR_OK;
     const int nb = B > h->allocB ? B : h->allocB, no = O > h->allocO ? O : h->allocO;
+    // the buffers are replaced one by one below: until all of them exist at the new size the handle has NO capacity, so
+    // that a hipMalloc failing half-way cannot leave small (or null) buffers behind capacity fields a later call trusts
+    h->allocB = 0; h->allocO = 0;
     const size_t nl = (size_t)nb * h->J * h->T, nt = (size_t)nb * h->n * h->T;
     int rc;
 #define TRY(x) if ((rc = (x)) != ARMOUR_OK) return rc
@@ -103,7 +107,9 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
     TRY(dev_alloc(&h->d_k, (size_t)nb * h->n));
     TRY(dev_alloc(&h->d_g, (size_t)nb * mmax));
-    TRY(dev_alloc(&h->d_jac, (size_t)nb * mmax * h->n));
+    // d_jac doubles as the scratch of armour_get_link_centers (B*T*J*3 doubles): m*n >= T*J*3 does not hold for every
+    // robot armour_create accepts (n*n < 3J with O = 0), so size it for both uses
+    TRY(dev_alloc(&h->d_jac, std::max((size_t)nb * mmax * h->n, (size_t)nb * h->T * h->J * 3)));
     TRY(dev_alloc(&h->d_bounds, (size_t)2 * nb * mmax));
 #undef TRY
     h->allocB = nb;
@@ -658,7 +664,7 @@ extern "C" int armour_get_link_centers(ArmourPlanner* h, const double* k, double
     const size_t bn = (size_t)h->B * h->n, cnt = (size_t)h->B * h->T * h->J * 3;
     HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     const P2Tables tb = armour_make_tables(h);
-    // d_jac is at least B*m*n >= B*T*J*3 doubles; reuse it as scratch
+    // d_jac holds max(B*m*n, B*T*J*3) doubles (ensure_capacity): reuse it as scratch
     int rc = armour_p2_slice_links_launch(tb, h->d_k, h->d_jac, h->stream);
     if (rc != ARMOUR_OK) return rc;
     HIPCHK(hipMemcpyAsync(centers, h->d_jac, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <chrono>
 #include <csignal>
+#include <sys/prctl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -285,6 +286,9 @@ inline int serve(const std::string& dir, int T_armour, int T_armtd, double idle_
 // main() of the worker: `armour_worker armour|armtd [--serve] [--idle-seconds S] [buffer_dir] [T] [T_armtd]`
 inline int worker_main(int argc, char** argv) {
     if (argc < 2 || (strcmp(argv[1], "armour") && strcmp(argv[1], "armtd"))) { fprintf(stderr, "usage: armour_worker armour|armtd [--serve] [buffer_dir] [T]\n"); return 2; }
+    // started by armour_main / armtd_main (planner_client.cpp): if that front end dies -- e.g. killed by its caller --
+    // this process, which holds the GPU and the socket, gets SIGTERM instead of living on as an orphan
+    prctl(PR_SET_PDEATHSIG, SIGTERM);
     const char* kind = argv[1];
     const bool is_armour = !strcmp(kind, "armour");
     bool want_serve = false;

@@ -12,9 +12,15 @@
 // file -- what uarmtd_planner.m:196-208 tests.
 //
 // This process never touches the GPU: it forwards the iteration to the resident planner listening on
-// <buffer_dir>/armour.sock if there is one, and otherwise starts armour_worker (next to this executable) as a child and
-// returns its exit code.  File formats and conventions live in cli_common.h, which only the worker includes.
+// <buffer_dir>/armour.sock if there is one, and otherwise starts armour_worker (next to this executable) as a CHILD process,
+// relays SIGTERM / SIGINT to it and returns its exit code.  It never replaces itself with the worker (exec): under a
+// profiler (`rocprofv3 -- armour_main ...`) a preloaded library has initialised the GPU before main() runs, and an exec
+// from a GPU-initialised process takes the machine down on this pool -- profile `armour_worker armour|armtd ...` directly
+// instead.  The worker asks the kernel for SIGTERM should this process die (cli_common.h), so killing
+// the `--serve` front end never leaves an orphan holding the GPU and the socket.
+// File formats and conventions live in cli_common.h, which only the worker includes.
 #include <libgen.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/wait.h>
 
@@ -26,9 +32,10 @@
 
 extern char** environ;
 
-// replace == true (only for --serve): become the worker, so that whoever started this process holds the resident
-// planner's pid; this process has not touched the GPU.  Falls through to spawn-and-wait if the exec is refused.
-static int run_worker(const std::string& self, const char* kind, int argc, char** argv, bool replace) {
+static volatile pid_t g_child = 0;
+static void relay_signal(int sig) { if (g_child > 0) kill(g_child, sig); }
+
+static int run_worker(const std::string& self, const char* kind, int argc, char** argv) {
     std::string path = self;
     const size_t slash = path.find_last_of('/');
     path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "armour_worker";
@@ -37,11 +44,16 @@ static int run_worker(const std::string& self, const char* kind, int argc, char*
     av.push_back(const_cast<char*>(kind));
     for (int i = 1; i < argc; i++) av.push_back(argv[i]);
     av.push_back(nullptr);
-    if (replace) execv(path.c_str(), av.data());
     pid_t pid;
     if (posix_spawn(&pid, path.c_str(), nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "        HIP & C++: cannot start %s\n", path.c_str()); return 1; }
+    g_child = pid;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = relay_signal;
+    sigaction(SIGTERM, &sa, nullptr);
+    sigaction(SIGINT, &sa, nullptr);
     int status = 0;
-    while (waitpid(pid, &status, 0) < 0) {}
+    while (waitpid(pid, &status, 0) < 0) {}  // (EINTR after a relayed signal: keep waiting for the worker's own exit)
     return WIFEXITED(status) ? WEXITSTATUS(status) : 1;
 }
 
@@ -65,5 +77,5 @@ int main(int argc, char** argv) {
         const int T = pos.size() > 1 ? atoi(pos[1]) : (kind[3] == 'o' ? 128 : 100);  // RT/Parameters.h:17, CMP/Parameters.h:17
         if (cli::try_resident(dir, kind, T, &rc)) return rc;
     }
-    return run_worker(self, kind, argc, argv, serve);
+    return run_worker(self, kind, argc, argv);
 }

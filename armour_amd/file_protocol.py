@@ -140,7 +140,7 @@ class ResidentPlanner:
     the per-iteration executables `armour_main <dir>` / `armtd_main <dir>` only forward to it over <dir>/armour.sock
     (armour_amd/csrc/cli_common.h).  Use as a context manager around a simulation that spawns the executables."""
 
-    def __init__(self, dirname, T_armour=128, T_armtd=100, exe=None, start_timeout_s=300.0):
+    def __init__(self, dirname, T_armour=128, T_armtd=100, exe=None, start_timeout_s=300.0, log_path=None):
         import subprocess
         import time
         here = os.path.dirname(os.path.abspath(__file__))
@@ -149,15 +149,30 @@ class ResidentPlanner:
         self.sock = os.path.join(self.dir, "armour.sock")
         if os.path.exists(self.sock):
             os.remove(self.sock)
-        self.proc = subprocess.Popen([self.exe, "--serve", self.dir, str(T_armour), str(T_armtd)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        # The planner prints two or three "HIP & C++: ..." lines per served iteration, as the reference's program does.
+        # They go to a FILE, never to a pipe nobody reads: a pipe fills after a few hundred iterations (64 KB), the
+        # planner then blocks in fflush(stdout) and every forwarding armour_main waits on the socket forever.
+        self.log_path = log_path or os.path.join(self.dir, "armour_resident.log")
+        self._log = open(self.log_path, "w")
+        self.proc = subprocess.Popen([self.exe, "--serve", self.dir, str(T_armour), str(T_armtd)], stdout=self._log, stderr=subprocess.STDOUT)
         t0 = time.time()
         while not os.path.exists(self.sock):
             if self.proc.poll() is not None:
-                raise RuntimeError("resident planner exited: " + (self.proc.stdout.read() or ""))
+                raise RuntimeError("resident planner exited: " + self.log())
             if time.time() - t0 > start_timeout_s:
-                self.proc.kill()
-                raise RuntimeError("resident planner did not come up")
+                self.proc.kill()       # the front end; its worker child gets SIGTERM from the kernel (PR_SET_PDEATHSIG)
+                self.proc.wait()
+                raise RuntimeError("resident planner did not come up: " + self.log())
             time.sleep(0.02)
+
+    def log(self):
+        """what the planner has printed so far"""
+        try:
+            self._log.flush()
+            with open(self.log_path) as f:
+                return f.read()
+        except OSError:
+            return ""
 
     def stop(self):
         import subprocess
@@ -166,8 +181,10 @@ class ResidentPlanner:
             try:
                 self.proc.wait(timeout=60)
             except subprocess.TimeoutExpired:
-                self.proc.kill()   # this exact child only
+                self.proc.kill()   # this exact child only; the worker behind it is told by the kernel (PR_SET_PDEATHSIG)
                 self.proc.wait()
+        if not self._log.closed:
+            self._log.close()
         return self.proc.returncode
 
     def __enter__(self):

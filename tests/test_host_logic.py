@@ -218,3 +218,44 @@ def test_resident_planner_protocol_without_a_gpu(tmp_path):
         if daemon.poll() is None:
             daemon.kill()
             daemon.wait()
+
+
+def test_resident_planner_survives_thousands_of_iterations_and_dies_with_its_front_end(tmp_path):
+    """Two findings of the round-1 review, on a CPU-only host (no handles: every iteration fails fast with the reference's
+    "-1" convention, which is all this needs).  (1) file_protocol.ResidentPlanner used to hand the planner a pipe nobody
+    read: after ~64 KB of per-iteration "HIP & C++: ..." lines it blocked in fflush and every forwarding armour_main hung.
+    The output now goes to a log file: 1500 iterations (> 64 KB of output) complete.  (2) `armour_main --serve` no longer
+    exec()s the worker (an exec from a GPU-initialised process, e.g. under rocprofv3, takes the machine down on this pool);
+    it spawns it, relays SIGTERM, and the worker asks for SIGTERM on its parent's death: killing the front end with
+    SIGKILL does not leave a worker behind holding the socket."""
+    import signal
+    import time
+    from armour_amd import file_protocol as fp
+    bindir = os.path.join(ROOT, "armour_amd", "bin")
+    exe = os.path.join(bindir, "armour_main")
+    if not os.path.exists(exe):
+        pytest.skip("executables not built (make -C armour_amd/csrc)")
+    with fp.ResidentPlanner(tmp_path, 0, 0) as rp:
+        for i in range(1500):
+            r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=30)
+            assert r.returncode == 1 and r.stdout == "" and r.stderr == "", (i, r.stderr)
+        log = rp.log()
+        assert log.count("Error reading input files") == 1500 and len(log) > 65536
+    assert not os.path.exists(tmp_path / "armour.sock")
+    # (2) SIGKILL the front end: the worker must go away by itself
+    rp = fp.ResidentPlanner(tmp_path, 0, 0)
+    assert subprocess.run([exe, str(tmp_path)], capture_output=True, timeout=30).returncode == 1      # served
+    rp.proc.send_signal(signal.SIGKILL)
+    rp.proc.wait()
+    t0 = time.time()
+    while True:
+        # once the worker is gone nobody answers on the socket and the executable runs the iteration itself (stderr non-empty)
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=30)
+        if r.stderr:
+            break
+        assert time.time() - t0 < 20, "the worker outlived its front end"
+        time.sleep(0.05)
+    # SIGTERM to the front end is relayed: clean shutdown, socket removed, exit code 0
+    rp = fp.ResidentPlanner(tmp_path, 0, 0)
+    rp.proc.send_signal(signal.SIGTERM)
+    assert rp.proc.wait(timeout=30) == 0 and not os.path.exists(tmp_path / "armour.sock")

@@ -115,7 +115,7 @@ def test_device_limit_rows_against_reference_rows():
     for name in lr["cases"]:
         q0, qd0, qdd0 = lr[f"{name}_state"]
         ks = lr[f"{name}_k"]
-        nlp = ArmourNLP(T=10).set_parameters(q0, qd0, qdd0, q0, np.zeros((0, 12)))
+        nlp = ArmourNLP(T=100).set_parameters(q0, qd0, qdd0, q0, np.zeros((0, 12)))   # (the limit rows do not depend on T)
         P, m, n = len(ks), nlp.m, nlp.n
         d_k = torch.from_numpy(ks.reshape(P, 1, n)).to("cuda:0")
         d_g = torch.zeros((P, 1, m), dtype=torch.float64, device="cuda:0")
