@@ -51,7 +51,7 @@ class ArmourLimits(C.Structure):
 
 class ArmourSolveOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("max_line_search", C.c_int32), ("tolerance", C.c_double),
-                ("max_wall_time_s", C.c_double), ("reserved", C.c_double * 4)]
+                ("max_wall_time_s", C.c_double), ("force_host_qp", C.c_double), ("reserved", C.c_double * 3)]
 
 
 class ArmourSolveResult(C.Structure):

@@ -78,6 +78,16 @@ struct P2Tables {
 #define ARMOUR_MODE_ARMOUR 0
 #define ARMOUR_MODE_ARMTD 1
 
+// device buffers of the device-resident armour_solve (solver_device.hip), grown on demand and kept across solves
+struct SolveDeviceWork {
+    unsigned char* ctl = nullptr; size_t ctl_cap = 0;
+    unsigned char* blk_word = nullptr; size_t word_cap = 0;
+    unsigned char* blk_rows = nullptr; size_t blk_rows_cap = 0;
+    unsigned char* qp_rows = nullptr; size_t qp_rows_cap = 0;
+    unsigned char* flags = nullptr; size_t flags_cap = 0;
+    double* q_des = nullptr; size_t q_des_cap = 0;
+};
+
 struct ArmourPlanner {
     ArmourRobot robot;
     ArmourParams params;
@@ -97,6 +107,7 @@ struct ArmourPlanner {
     // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
     void* solve_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows
     size_t solve_pin_bytes[6] = {0, 0, 0, 0, 0, 0};
+    SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
     bool bounds_on_device = false;
     std::vector<double> h_gl, h_gu;  // host copy of the same bounds (valid while bounds_on_device)

@@ -74,9 +74,8 @@ __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restri
 
 const char* armour_p2_kernel_name(void) { return "armour_p2_eval_kernel"; }
 
-int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac,
-                     hipStream_t stream, int steps, long long k_stride, long long g_stride, long long j_stride) {
-    if (!d_g && !d_jac) return ARMOUR_OK;
+int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
+                   long long g_stride, long long j_stride, P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out) {
     P2Launch lp;
     lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
     lp.nbt = tb.mode == ARMOUR_MODE_ARMTD ? 0 : (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;  // ARMTD mode has no torque rows
@@ -96,7 +95,6 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     const size_t lim = (size_t)2 * ARMOUR_MAX_FACTORS * 8 * sizeof(double);
     const size_t smem = 2 * sizeof(KPow) + std::max(std::max(col, tq), lim);
     if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }
-    dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
     const bool dfc = tb.obs_center != nullptr && tb.ll_shared;
     // every problem of the launch has at most 24 live planes (6 per wave): use the 6-slot kernels
     bool six = h_skip != nullptr;
@@ -105,6 +103,19 @@ int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const uns
     static const bool ex_on = [] { const char* e = getenv("ARMOUR_P2_EX"); return !e || atoi(e) != 0; }();
     bool exact = six && ex_on && lp.max_pairs <= lp.pair_chunk;
     for (int b = 0; exact && b < tb.B; b++) exact = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) == 24;
+    *lp_out = lp; *smem_out = smem; *dfc_out = dfc; *six_out = six; *exact_out = exact;
+    return ARMOUR_OK;
+}
+
+int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac,
+                     hipStream_t stream, int steps, long long k_stride, long long g_stride, long long j_stride) {
+    if (!d_g && !d_jac) return ARMOUR_OK;
+    P2Launch lp;
+    size_t smem = 0;
+    bool dfc, six, exact;
+    const int rc = armour_p2_plan(tb, max_link, max_torque, h_skip, steps, k_stride, g_stride, j_stride, &lp, &smem, &dfc, &six, &exact);
+    if (rc != ARMOUR_OK) return rc;
+    dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
 #define P2_LAUNCH_M(G, J, M)                                                                                                                      \
     do {                                                                                                                                          \
         if (dfc && exact && !(M)) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false, true, true, 6, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);      \

@@ -25,10 +25,14 @@
 
 #include "bezier.h"
 #include "common.h"
+#include "solver_common.h"
+#include "solver_device.h"
+
+using slv::NV;
+using slv::SolveRow;
 
 namespace {
 
-constexpr int NV = ARMOUR_MAX_FACTORS;
 constexpr double kInf = 1e300;
 
 // ---- tiny dense helpers (q <= NV) ----
@@ -187,11 +191,6 @@ struct ProblemState {
 // below -- compacted IN ROW ORDER (upper side before lower side of a row), each as {row, side, v = violation-signed
 // distance to the bound, a = -+J_i}.  A problem with 20 obstacles moves a few hundred such rows instead of 0.94 MB.
 constexpr int kScanRowsPerBlock = 2048;
-struct SolveRow {
-    int idx, side;
-    double v;
-    double a[NV];
-};
 
 // MODE 0: violation only (line-search trials); 1: violation + candidate rows (new linearisation); 2: violation + number of
 // rows outside [g_l - slack, g_u + slack] with the slacks of armtd_NLP::finalize_solution (RT/NLPclass.cu:422-538:
@@ -199,7 +198,7 @@ struct SolveRow {
 template <int MODE>
 __global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, int n_torque_rows, int n_collision_rows, int n_unchecked_rows, double torque_slack, double collision_slack, const double* __restrict__ g_all, const double* __restrict__ jac_all,
                                                                 const double* __restrict__ lo_all, const double* __restrict__ hi_all, int cap,
-                                                                double* __restrict__ viol_out, int* __restrict__ count_out, SolveRow* __restrict__ rows_out) {
+                                                                long long* __restrict__ viol_out, int* __restrict__ count_out, SolveRow* __restrict__ rows_out) {
     // grid (segments, B): a block owns kScanRowsPerBlock consecutive rows and its own slice of the outputs; the host
     // concatenates the slices in segment order
     const int b = blockIdx.y, seg = blockIdx.x, nseg = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -211,15 +210,14 @@ __global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, in
     SolveRow* rows = ROWS ? rows_out + ((size_t)b * nseg + seg) * cap : nullptr;
     const int row_end = min(m, (seg + 1) * kScanRowsPerBlock);
     __shared__ int wave_tot[4];
-    __shared__ double red[256];
+    __shared__ long long red[256];
     int base = 0, bad = 0;
-    double vsum = 0.0;
+    long long vsum = 0;   // L1 violation in 2^-32 fixed point: the sum does not depend on the reduction order (solver_common.h)
     for (int i0 = seg * kScanRowsPerBlock; i0 < row_end; i0 += 256) {
         const int i = i0 + tid;
         const bool in = i < row_end;
         const double gi = in ? g[i] : 0.0, li = in ? lo[i] : -1e300, ui = in ? hi[i] : 1e300;
-        if (gi > ui) vsum += gi - ui;
-        else if (gi < li) vsum += li - gi;
+        vsum += slv::row_violation(gi, li, ui);
         if (MODE == 2 && in) {
             // (ARMTD mode: the re-check of CMP/NLPclass.cu:391-402 skips the collision rows of the last links)
             const int ic = i - n_torque_rows - n_collision_rows;
@@ -230,8 +228,8 @@ __global__ __launch_bounds__(256) void armour_solve_scan_kernel(int m, int n, in
             double J[NV], l1 = 0.0;
 #pragma unroll
             for (int j = 0; j < NV; j++) { J[j] = (in && j < n) ? jac[(size_t)i * n + j] : 0.0; l1 += fabs(J[j]); }
-            const bool fh = in && ui < 1e18 && gi + 2.0 * l1 > ui;
-            const bool fl = in && li > -1e18 && gi - 2.0 * l1 < li;
+            const bool fh = in && slv::row_upper_candidate(gi, ui, l1);
+            const bool fl = in && slv::row_lower_candidate(gi, li, l1);
             const unsigned long long bh = __ballot(fh), bl = __ballot(fl);
             const unsigned long long below = (1ull << lane) - 1ull;
             if (lane == 0) wave_tot[wv] = __popcll(bh) + __popcll(bl);
@@ -299,6 +297,110 @@ extern "C" int armour_debug_qp(int32_t n, const double* Gd, const double* g0, in
     return ARMOUR_OK;
 }
 
+// ---- the device-resident form (solver_device.hip): one persistent launch runs every problem's SQP to the end ----
+// Returns 1 when it produced the results, 0 when the caller must use the host form (no cooperative launch, batch larger than
+// the co-resident grid, or a problem's candidate rows outgrew the device buffers), < 0 on error.
+template <class Tp>
+static int grow_dev(Tp** p, size_t* cap, size_t need) {
+    if (*p && need <= *cap) return ARMOUR_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIPCHK(hipMalloc((void**)p, (need ? need : 1) * sizeof(Tp)));
+    *cap = need;
+    return ARMOUR_OK;
+}
+
+static int upload_bounds(ArmourPlanner* h) {
+    if (h->bounds_on_device) return ARMOUR_OK;
+    const size_t bm = (size_t)h->B * h->m;
+    h->h_gl.resize(bm); h->h_gu.resize(bm);
+    int rc = armour_get_bounds(h, nullptr, nullptr, h->h_gl.data(), h->h_gu.data());
+    if (rc != ARMOUR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->bounds_on_device = true;
+    return ARMOUR_OK;
+}
+
+static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, ArmourSolveResult* results, std::chrono::steady_clock::time_point t_begin) {
+    const int B = h->B, n = h->n, m = h->m;
+    const P2Tables tb = armour_make_tables(h);
+    SolvePlan plan;
+    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, &plan);
+    if (rc != ARMOUR_OK) return rc;
+    if (plan.capacity < B) return 0;
+    int nb = std::min(std::min(plan.n_tiles, plan.capacity / B), 1024);
+    // A block walks its tiles one after the other (~4 us each).  With many problems AND many obstacles the blocks per problem are
+    // few and the tiles many: there the host-driven form, whose evaluations are single full-occupancy launches, is the faster
+    // one (measured at B = 128: O = 20, 77 tiles per block: 11 ms against 15 ms; O = 50, 181 tiles per block: 50 ms against 30 ms).
+    static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
+    if (force_dev < 2 && (plan.n_tiles + nb - 1) / nb > 100) return 0;
+    if (const char* e = getenv("ARMOUR_SOLVE_BLOCKS")) nb = std::max(1, std::min(nb, atoi(e)));  // development / tests
+    if ((rc = upload_bounds(h)) != ARMOUR_OK) return rc;
+    // rows a block owns: at most ceil(n_tiles / nb) tiles of <= 64 rows, two candidates per row
+    const int tiles_per_block = (plan.n_tiles + nb - 1) / nb;
+    int cap_blk = std::min(2 * tiles_per_block * 64, 1024);
+    int cap_rows = std::min(2 * m, 8192);
+    if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) { cap_blk = std::max(1, std::min(cap_blk, atoi(e))); }  // tests: force the overflow fallback
+    SolveDeviceWork& w = h->solve_dev;
+    if ((rc = grow_dev(&w.ctl, &w.ctl_cap, (size_t)B * sizeof(SolveCtl))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.blk_word, &w.word_cap, (size_t)B * nb * sizeof(BlockWord))) != ARMOUR_OK) return rc;
+    HIPCHK(hipMemsetAsync(w.blk_word, 0, (size_t)B * nb * sizeof(BlockWord), h->stream));
+    if ((rc = grow_dev(&w.blk_rows, &w.blk_rows_cap, (size_t)B * nb * cap_blk * sizeof(SolveRow))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.qp_rows, &w.qp_rows_cap, (size_t)B * cap_rows * sizeof(SolveRow))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)B * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.q_des, &w.q_des_cap, (size_t)B * n)) != ARMOUR_OK) return rc;
+    ArmourSolveResult* hres = reinterpret_cast<ArmourSolveResult*>(armour_handle_pinned(h, 1, (size_t)B * sizeof(ArmourSolveResult)));
+    SolveCtl* hctl = reinterpret_cast<SolveCtl*>(armour_handle_pinned(h, 2, (size_t)B * sizeof(SolveCtl)));
+    if (!hres || !hctl) return ARMOUR_EDEVICE;
+    memset(hres, 0, (size_t)B * sizeof(ArmourSolveResult));
+    memset(hctl, 0, (size_t)B * sizeof(SolveCtl));
+    for (int b = 0; b < B; b++) { hctl[b].go = 1; /* phase 0: CMD_EVAL_GJ at x = 0 */ hres[b].status = -2; }
+    HIPCHK(hipMemcpyAsync(w.ctl, hctl, (size_t)B * sizeof(SolveCtl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(w.q_des, h->h_qdes.data(), (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tb = tb; a.lp = plan.lp; a.nb = nb; a.n_tiles = plan.n_tiles; a.cap_blk = cap_blk; a.cap_rows = cap_rows;
+    a.lo = h->d_bounds; a.hi = h->d_bounds + (size_t)B * m; a.g = h->d_g; a.jac = h->d_jac;
+    a.ctl = reinterpret_cast<SolveCtl*>(w.ctl); a.blk_word = reinterpret_cast<BlockWord*>(w.blk_word);
+    a.blk_rows = reinterpret_cast<SolveRow*>(w.blk_rows); a.qp_rows = reinterpret_cast<SolveRow*>(w.qp_rows); a.flags = w.flags;
+    a.q_des = w.q_des; a.out = hres;   // the kernel writes the results straight into page-locked host memory
+    for (int i = 0; i < n; i++) if (h->robot.continuous[i]) a.continuous_mask |= 1 << i;
+    a.max_iter = opt.max_iterations; a.max_ls = opt.max_line_search; a.tol = opt.tolerance;
+    a.n_checked_collision = armour_checked_collision_rows(h);
+    a.t_plan = h->params.t_plan; a.cost_scale = h->params.cost_scale;
+    a.torque_slack = h->params.torque_violation_threshold; a.collision_slack = h->params.collision_violation_threshold;
+    a.budget_ticks = -1;
+    if (opt.max_wall_time_s > 0) {
+        const double left_ms = (opt.max_wall_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3;
+        a.budget_ticks = left_ms > 0 ? (long long)(left_ms * plan.ticks_per_ms) : 0;
+    }
+    const bool timing = getenv("ARMOUR_SOLVE_TIMING") != nullptr;
+    long long* hstamps = timing ? reinterpret_cast<long long*>(armour_handle_pinned(h, 0, (size_t)B * 64 * sizeof(long long) + (size_t)B * n * sizeof(double))) : nullptr;
+    if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
+    a.stamps = hstamps;
+    const auto t_launch = std::chrono::steady_clock::now();
+    if ((rc = armour_solve_device_launch(a, plan, B, h->stream)) != ARMOUR_OK) return rc;
+    for (;;) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { armour_set_error("armour_solve (device form): %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+    }
+    for (int b = 0; b < B; b++)
+        if (hres[b].status < 0) return 0;   // candidate buffers too small for some problem: the host form redoes the solve
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (timing) {
+        fprintf(stderr, "[armour_solve, device form] B=%d: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, nb, plan.n_tiles, ms,
+                std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
+        for (int i = 0; i < 32 && (i < 2 || hstamps[i]); i++) fprintf(stderr, " %.1f", hstamps[i] / plan.ticks_per_ms * 1e3);
+        fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)\n", hstamps[32] / plan.ticks_per_ms * 1e3,
+                hstamps[33] / plan.ticks_per_ms * 1e3, hstamps[34] / plan.ticks_per_ms * 1e3, hstamps[40], hstamps[41]);
+    }
+    for (int b = 0; b < B; b++) { results[b] = hres[b]; results[b].time_ms = ms; }
+    return 1;
+}
+
 extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, ArmourSolveResult* results) {
     if (!h || !results) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     if (!h->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
@@ -306,6 +408,16 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     if (opt_in) opt = *opt_in; else armour_solve_options_default(&opt);
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, n = h->n, m = h->m;
+    {
+        // default: the device-resident form; `force_host_qp` (or ARMOUR_SOLVE_DEVICE=0) keeps the host-driven form below,
+        // which is also the fallback -- both produce the same iterates
+        static const int dev_env = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
+        if (dev_env && opt.force_host_qp == 0.0) {
+            HIPCHK(hipSetDevice(h->device));
+            const int r = solve_on_device(h, opt, results, t_begin);
+            if (r != 0) return r < 0 ? r : ARMOUR_OK;
+        }
+    }
     // pinned host mirrors of k, g, jac for all problems
     // (owned by the handle and kept across solves; armour_eval_g_jac recognises them and lets the kernel write into them)
     HIPCHK(hipSetDevice(h->device));
@@ -330,7 +442,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     // rows a segment may hand back (its slice of the page-locked buffer): everything if the batch is small
     int cap_rows = (int)std::max<size_t>(64, std::min<size_t>(2 * kScanRowsPerBlock, ((size_t)128 << 20) / ((size_t)B * nseg * sizeof(SolveRow))));
     if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) cap_rows = std::max(1, atoi(e));  // development / tests: force the overflow fallback
-    double* hviol_seg = armour_handle_pinned(h, 3, (size_t)B * nseg * sizeof(double));
+    long long* hviol_seg = reinterpret_cast<long long*>(armour_handle_pinned(h, 3, (size_t)B * nseg * sizeof(long long)));
     int* hcount = reinterpret_cast<int*>(armour_handle_pinned(h, 4, (size_t)B * nseg * sizeof(int)));
     SolveRow* hrows = reinterpret_cast<SolveRow*>(armour_handle_pinned(h, 5, (size_t)B * nseg * cap_rows * sizeof(SolveRow)));
     if (!hviol_seg || !hcount || !hrows) return ARMOUR_EDEVICE;
@@ -377,9 +489,9 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
         HIPCHK(hipGetLastError());
         if ((r = wait()) != ARMOUR_OK) return r;
         for (int b = 0; b < B; b++) {
-            double v = 0.0;
+            long long v = 0;
             for (int sg = 0; sg < nseg; sg++) v += hviol_seg[(size_t)b * nseg + sg];
-            hviol[b] = v;
+            hviol[b] = slv::viol_from_fixed(v);
         }
         full_on_host = false;
         if (want_jac) {

@@ -1,0 +1,799 @@
+// armour_solve, device-resident form: the whole SQP iterate of RT/armour_main.cu:237-304 (OptimizeTNLP) and
+// armtd_NLP::finalize_solution (RT/NLPclass.cu:422-538) in ONE persistent kernel launch -- SURVEY.md 8f rank 1.
+//
+// The host-driven form (solver.hip) pays a launch, a scan launch and a host wake-up per evaluation (4 evaluations of the
+// reference's sample problem: ~0.3 ms, of which the GPU works ~20 us) and solves the 7-variable QPs on the host.  Here:
+//
+//   grid   = B groups of `nb` blocks (all co-resident: cooperative launch); group b owns problem b, block j of a group owns a
+//            fixed, contiguous range of the problem's row tiles -- torque tiles, collision tiles, limit rows, in ROW ORDER -- for
+//            the whole solve.  The same tile always runs on the same CU, so after the first evaluation its share of the plane
+//            / PZ tables (12.6 MB at configs[1], 1.6 MB per XCD) is served by that XCD's L2 instead of HBM.
+//   phase  = one evaluation.  Every block evaluates its tiles at the point x the leader published (the tile code of
+//            p2_tiles.h, i.e. bit-identical rows to armour_eval_g_jac), scans its own rows -- L1 violation in fixed point
+//            (order-independent, solver_common.h), candidate rows of the QP compacted in row order into the block's slot, or the
+//            finalize_solution verdict -- and arrives at the group's barrier (one atomic per block).
+//   leader = block 0 of the group.  After the barrier it gathers the candidate rows in block (= row) order, runs the
+//            Goldfarb-Idnani QP (<= 7 active rows; the search for the most violated row uses the whole block, the 7 x 7
+//            algebra runs on one lane with the active normals in LDS), advances the SQP / line-search state machine and
+//            publishes the next point.  The other blocks of the group poll one word meanwhile.
+//
+// The arithmetic of the QP, of the merit function and of the cost is the host form's, operation for operation, on the same
+// candidate rows in the same order: both forms produce the same iterates (tests/test_solve.py compares k_opt bit for bit).
+// Problems of a batch no longer run in lock step: each group proceeds, converges and leaves on its own.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bezier.h"
+#include "cacc.h"
+#include "common.h"
+#include "p2_tiles.h"
+#include "solver_common.h"
+#include "solver_device.h"
+
+using namespace p2;
+using namespace slv;
+
+namespace {
+
+enum { CMD_EVAL = 1, CMD_DONE = 4 };
+enum { ST_AFTER_FIRST = 0, ST_AFTER_TRIAL = 1, ST_AFTER_RELIN = 2, ST_AFTER_VERDICT = 3 };
+constexpr double kInf = 1e300;
+// lanes of ONE wave exchanging data through LDS: its LDS instructions execute in order, so only the compiler has to be held
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// Communication between the blocks of a group.  MI355X has eight XCDs with an L2 each; L2s are not coherent with one another for
+// ordinary accesses, so an agent-scope release / acquire FENCE writes back / invalidates a whole L2 -- tens of microseconds per
+// phase when first tried here, and it throws away the very tables this kernel wants to keep cached.  Instead every word that
+// crosses blocks (the point x, the command, the candidate rows and their counts) is written and read with RELAXED agent-scope
+// atomic accesses -- the compiler emits them as coherent (sc1) loads / stores that go to the memory side and touch no other cache
+// line -- and ordering is by completion: a block waits for its own stores (s_waitcnt vmcnt(0)) before it signals.
+__device__ inline unsigned ld_coh(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int ld_coh(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline long long ld_coh(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_coh(const double* p) { return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ inline void st_coh(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coh(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coh(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coh(double* p, double v) { __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void wait_my_memory_ops() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+// a candidate row, word by word (9 x 8 bytes)
+__device__ inline void st_coh_row(SolveRow* dst, const SolveRow& r) {
+    long long* d = reinterpret_cast<long long*>(dst);
+    st_coh(d, ((long long)(unsigned)r.side << 32) | (unsigned)r.idx);
+    st_coh(reinterpret_cast<double*>(d + 1), r.v);
+#pragma unroll
+    for (int j = 0; j < NV; j++) st_coh(reinterpret_cast<double*>(d + 2 + j), r.a[j]);
+}
+__device__ inline SolveRow ld_coh_row(const SolveRow* src) {
+    const long long* d = reinterpret_cast<const long long*>(src);
+    SolveRow r;
+    const long long w0 = ld_coh(d);
+    r.idx = (int)(unsigned)(w0 & 0xffffffffll); r.side = (int)(w0 >> 32);
+    r.v = ld_coh(reinterpret_cast<const double*>(d + 1));
+#pragma unroll
+    for (int j = 0; j < NV; j++) r.a[j] = ld_coh(reinterpret_cast<const double*>(d + 2 + j));
+    return r;
+}
+
+// tile t of a problem in row order -> the role index the tile functions use (collision tiles first) and its rows [r0, r1)
+__device__ inline void tile_info(const SolveArgs& a, int t, int& role, int& r0, int& r1) {
+    const int nbt = a.lp.nbt, nbc = a.lp.nbc, row0 = a.tb.row0;
+    if (t < nbt) { role = nbc + t; r0 = t * P2_TQ_ROWS; r1 = min(row0, r0 + P2_TQ_ROWS); }
+    else if (t < nbt + nbc) { role = t - nbt; r0 = row0 + (t - nbt) * P2_ROWS; r1 = min(row0 + a.tb.Q, r0 + P2_ROWS); }
+    else { role = nbc + nbt; r0 = row0 + a.tb.Q; r1 = a.tb.m; }
+}
+
+__device__ inline double wrap_to_pi_dev(double x) {  // RT/NLPclass.cu:6-15
+    const double pi = 3.14159265358979323846;
+    while (x < -pi) x += 2 * pi;
+    while (x > pi) x -= 2 * pi;
+    return x;
+}
+// eval_f / eval_grad_f (RT/NLPclass.cu:207-267, CMP/NLPclass.cu:183-243): the expressions of api.hip armour_eval_f / _grad_f
+__device__ inline double plan_point(const SolveArgs& a, const double* bz, int i, double k) {
+    const int n = a.tb.n;
+    return a.tb.mode == ARMOUR_MODE_ARMTD ? cacc::q_plan(bz[i], bz[n + i], bz[2 * n + i], k)
+                                          : bez::q_des(bz[i], bz[n + i], bz[2 * n + i], a.tb.k_range[i] * k, a.t_plan);
+}
+// eval_f from the joints' squared errors, added in armour_eval_f's order (continuous joints first)
+__device__ inline double cost_sum(const SolveArgs& a, const double* sq) {
+    double obj = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < a.tb.n; i++)
+            if ((((a.continuous_mask >> i) & 1) != 0) == (pass == 0)) obj += sq[i];
+    return obj * a.cost_scale;
+}
+__device__ inline double plan_dk(const SolveArgs& a, const double* bz, int i) {
+    const double tp = a.t_plan;
+    return a.tb.mode == ARMOUR_MODE_ARMTD ? cacc::q_plan_dk(bz[2 * a.tb.n + i]) : (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * a.tb.k_range[i];
+}
+// ------------------------------------------------------------------------------------------------ per-block scan
+// The block's rows after an evaluation: their L1 violation (fixed point), the candidate rows of the QP compacted in row order
+// into `rows`, and the number of rows outside [g_l - slack, g_u + slack] (finalize_solution).  The row tests are the host
+// form's (solver_common.h; MODE is kept for the two tests' placement only: every phase runs 3 = all of it).
+struct ScanShared {
+    int wave_tot[4];
+    long long red[256];
+    int redi[256];
+};
+template <int MODE>
+__device__ inline void scan_rows(const SolveArgs& a, int b, int r0, int r1, SolveRow* __restrict__ rows, int cap, ScanShared& sh,
+                                 long long& viol_out, int& count_out, int& bad_out) {
+    const int n = a.tb.n, m = a.tb.m, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* g = a.g + (size_t)b * m;
+    const double* jac = a.jac + (size_t)b * m * n;
+    const double* lo = a.lo + (size_t)b * m;
+    const double* hi = a.hi + (size_t)b * m;
+    const int n_unchecked = a.tb.Q - a.n_checked_collision;
+    int base = 0, bad = 0;
+    long long vsum = 0;
+    for (int i0 = r0; i0 < r1; i0 += 256) {
+        const int i = i0 + tid;
+        const bool in = i < r1;
+        const double gi = in ? g[i] : 0.0, li = in ? lo[i] : -1e300, ui = in ? hi[i] : 1e300;
+        vsum += row_violation(gi, li, ui);
+        if ((MODE & 2) && in) {
+            const int ic = i - a.tb.row0 - a.n_checked_collision;  // >= 0: behind the re-checked collision rows
+            const double slack = i < a.tb.row0 ? a.torque_slack : ic < 0 ? a.collision_slack : 0.0;
+            if ((ic < 0 || ic >= n_unchecked) && (gi < li - slack || gi > ui + slack)) bad++;
+        }
+        if (MODE & 1) {
+            double J[NV], l1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; j++) { J[j] = (in && j < n) ? jac[(size_t)i * n + j] : 0.0; l1 += fabs(J[j]); }
+            const bool fh = in && row_upper_candidate(gi, ui, l1);
+            const bool fl = in && row_lower_candidate(gi, li, l1);
+            const unsigned long long bh = __ballot(fh), bl = __ballot(fl);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (lane == 0) sh.wave_tot[wv] = __popcll(bh) + __popcll(bl);
+            __syncthreads();
+            int pos = base + __popcll(bh & below) + __popcll(bl & below);
+            for (int w2 = 0; w2 < wv; w2++) pos += sh.wave_tot[w2];
+            if (fh) {
+                if (pos < cap) {
+                    SolveRow r; r.idx = i; r.side = 0; r.v = gi - ui;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) r.a[j] = -J[j];
+                    st_coh_row(rows + pos, r);
+                }
+                pos++;
+            }
+            if (fl && pos < cap) {
+                SolveRow r; r.idx = i; r.side = 1; r.v = li - gi;
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.a[j] = J[j];
+                st_coh_row(rows + pos, r);
+            }
+            base += sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+            __syncthreads();
+        }
+    }
+    sh.red[tid] = vsum;
+    sh.redi[tid] = bad;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) { sh.red[tid] += sh.red[tid + s2]; sh.redi[tid] += sh.redi[tid + s2]; }
+        __syncthreads();
+    }
+    viol_out = sh.red[0];
+    bad_out = sh.redi[0];
+    count_out = base;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ the leader
+constexpr int kFlagsInLds = 1024;   // QP rows whose active / excluded flags fit in LDS (more: the global byte arrays)
+struct Leader {
+    // SQP state (ProblemState + the line-search variables of solver.hip)
+    double x[NV], d[NV], xt[NV], gradf[NV], Hd[NV];
+    double f, viol, mu, alpha, phi0, dphi;
+    int it, ls, iters, evals, status, stage, ncand, bad;
+    long long t_start;
+    // the problem's constants, staged once (global loads from a single lane cost ~1 us each)
+    double bz[3 * NV], qdes[NV];
+    // QP state and temporaries (thread 0 works on them with run-time indices: LDS, not scratch)
+    double qx[NV], u[NV + 1], An[NV][NV], np[NV];
+    double M[NV * NV], Lc[NV][NV], rhs[NV], r[NV], z[NV];
+    double bp, up, max_mult, sigma;
+    int A[NV], q, p, qp_iter, feasible, stop, added, chol_rows;
+    unsigned char act[kFlagsInLds], exc[kFlagsInLds];
+    // scratch of the block-wide reductions
+    double rs[256];
+    int ri[256];
+    int scan[1024];
+};
+
+// QP rows: [0, ncand) the gathered candidates (b = v - sigma * max(v, 0)), then 2n bound rows  x_l <= x + d <= x_u
+__device__ inline void qp_row(const SolveArgs& a, const Leader& L, const SolveRow* cand, int i, double* arow, double& brow) {
+    if (i < L.ncand) {
+        const SolveRow& r = cand[i];
+#pragma unroll
+        for (int j = 0; j < NV; j++) arow[j] = r.a[j];
+        const double v = r.v;
+        brow = v - (v > 0 ? L.sigma * v : 0.0);
+    } else {
+        const int e = i - L.ncand, j = e >> 1;
+        const double sg = (e & 1) == 0 ? 1.0 : -1.0;
+#pragma unroll
+        for (int jj = 0; jj < NV; jj++) arow[jj] = jj == j ? sg : 0.0;    // (no run-time register index: that would be scratch)
+        brow = (e & 1) == 0 ? -1.0 - L.x[j] : -(1.0 - L.x[j]);            // r.b = xl[j] - s.x[j];  r2.b = -(xu[j] - s.x[j])
+    }
+}
+
+// Goldfarb-Idnani for  min 1/2 d'Gd + g0'd  s.t.  a_i'd >= b_i,  G = diag(Hd) > 0: solve_qp of solver.hip, same arithmetic, arranged
+// for a GPU block.  All 256 threads call it; results in L.qx / L.max_mult / L.feasible.
+//   * the search for the most violated row uses the whole block; with at most 256 rows every thread keeps its row in registers
+//     across the steps, and the active / excluded flags live in LDS while they fit;
+//   * the step runs on wave 0, all 64 lanes in lockstep on the same LDS state (redundant, hence free).  The loops with a division
+//     per term -- M = N'G^-1 N, N'G^-1 np and z -- are dealt one entry per lane, each entry summed in the host form's order;
+//   * the Cholesky factor of M and the two triangular solves run in registers (fully unrolled, guarded by the active count) and
+//     the factor is extended row by row as rows enter the active set: row i of the factor depends on rows <= i of M only, so the
+//     numbers are those of the from-scratch factorisation the host form does at every step.
+__device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const SolveRow* cand, unsigned char* is_active_g, unsigned char* excluded_g,
+                                       int max_iter = 400) {
+    const int n = a.tb.n, tid = threadIdx.x;
+    const int mrows = L.ncand + 2 * n;
+    unsigned char* is_active = mrows <= kFlagsInLds ? L.act : is_active_g;
+    unsigned char* excluded = mrows <= kFlagsInLds ? L.exc : excluded_g;
+    if (tid == 0) {
+        for (int j = 0; j < n; j++) L.qx[j] = -L.gradf[j] / L.Hd[j];
+        L.q = 0; L.qp_iter = 0; L.feasible = 1; L.max_mult = 0; L.stop = 0; L.chol_rows = 0;
+    }
+    for (int i = tid; i < mrows; i += 256) { is_active[i] = 0; excluded[i] = 0; }
+    const bool one_row = mrows <= 256;
+    double my_a[NV], my_b = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) my_a[j] = 0.0;
+    if (one_row && tid < mrows) qp_row(a, L, cand, tid, my_a, my_b);
+    __syncthreads();
+    for (;;) {
+        // most violated inactive row: smallest s = a_i'x - b_i below -1e-10, the first such row on ties
+        double best = -1e-10;
+        int bi = -1;
+        if (one_row) {
+            if (tid < mrows && !is_active[tid] && !excluded[tid]) {
+                double s = -my_b;
+#pragma unroll
+                for (int j = 0; j < NV; j++) if (j < n) s += my_a[j] * L.qx[j];
+                if (s < best) { best = s; bi = tid; }
+            }
+        } else {
+            for (int i = tid; i < mrows; i += 256) {
+                if (is_active[i] || excluded[i]) continue;
+                double ar[NV], br;
+                qp_row(a, L, cand, i, ar, br);
+                double s = -br;
+#pragma unroll
+                for (int j = 0; j < NV; j++) if (j < n) s += ar[j] * L.qx[j];   // (unrolled: `ar` stays in registers)
+                if (s < best) { best = s; bi = i; }
+            }
+        }
+        // lexicographic (value, index) minimum: the sequential scan keeps the FIRST row attaining the minimum.
+        // Inside each wave by shuffles, then the four waves' results through LDS: two barriers instead of nine.
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
+        }
+        if ((tid & 63) == 0) { L.rs[tid >> 6] = best; L.ri[tid >> 6] = bi; }
+        __syncthreads();
+        {
+            best = L.rs[0]; bi = L.ri[0];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; w2++) {
+                const double o = L.rs[w2];
+                const int oi = L.ri[w2];
+                if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
+            }
+        }
+        const int p = bi;
+        __syncthreads();
+        if (p < 0) break;
+        if (one_row && tid == p) {   // the entering row's normal and right-hand side: from the thread that holds them
+#pragma unroll
+            for (int j = 0; j < NV; j++) L.np[j] = my_a[j];
+            L.bp = my_b;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            L.p = p;
+            if (++L.qp_iter > max_iter) { L.feasible = 0; L.stop = 1; }
+            else {
+                if (!one_row) {
+                    double npr[NV], bpr;
+                    qp_row(a, L, cand, p, npr, bpr);
+#pragma unroll
+                    for (int j = 0; j < NV; j++) L.np[j] = npr[j];
+                    L.bp = bpr;
+                }
+                double up = 0.0;
+                bool added = false;
+                int q = L.q, cv = L.chol_rows;
+                for (int guard = 0; guard < 4 * NV + 8 && !added; guard++) {
+                    // r = N* np,  z = G^-1 (np - N r)
+                    double rr[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; i++) rr[i] = 0.0;
+                    WAVE_LDS_SYNC();
+                    if (q > 0) {
+                        if (tid < NV * NV) {
+                            const int i = tid / NV, k = tid - i * NV;
+                            if (i < q && k <= i) {
+                                double s = 0;
+#pragma unroll
+                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * L.An[k][j] / L.Hd[j];   // (unrolled: the 7 divisions overlap)
+                                L.M[i * NV + k] = s; L.M[k * NV + i] = s;
+                            }
+                        } else if (tid < NV * NV + NV) {
+                            const int i = tid - NV * NV;
+                            if (i < q) {
+                                double s = 0;
+#pragma unroll
+                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * L.np[j] / L.Hd[j];
+                                L.rhs[i] = s;
+                            }
+                        }
+                        WAVE_LDS_SYNC();
+                        // Cholesky M = Lc Lc' (spd_solve of solver.hip), rows [cv, q) new, in registers
+                        double Lr[NV][NV];
+#pragma unroll
+                        for (int i = 0; i < NV; i++)
+#pragma unroll
+                            for (int k = 0; k <= i; k++) Lr[i][k] = i < cv ? L.Lc[i][k] : 0.0;
+                        bool spd = true;
+#pragma unroll
+                        for (int i = 0; i < NV; i++) {
+                            if (i >= cv && i < q && spd) {
+#pragma unroll
+                                for (int jj = 0; jj <= i; jj++) {
+                                    if (spd) {
+                                        double s = L.M[i * NV + jj];
+#pragma unroll
+                                        for (int k = 0; k < jj; k++) s -= Lr[i][k] * Lr[jj][k];
+                                        if (jj == i) {
+                                            if (s <= 1e-14 * fabs(L.M[i * NV + i]) || s <= 0) spd = false;
+                                            else Lr[i][i] = sqrt(s);
+                                        } else {
+                                            Lr[i][jj] = s / Lr[jj][jj];
+                                        }
+                                    }
+                                }
+                                if (spd) {
+#pragma unroll
+                                    for (int k = 0; k <= i; k++) L.Lc[i][k] = Lr[i][k];
+                                    cv = i + 1;
+                                }
+                            }
+                        }
+                        if (!spd) { excluded[p] = 1; break; }  // dependent active set: skip this row
+                        double tt[NV];
+#pragma unroll
+                        for (int i = 0; i < NV; i++) {
+                            tt[i] = 0.0;
+                            if (i < q) {
+                                double s = L.rhs[i];
+#pragma unroll
+                                for (int k = 0; k < i; k++) s -= Lr[i][k] * tt[k];
+                                tt[i] = s / Lr[i][i];
+                            }
+                        }
+#pragma unroll
+                        for (int i = NV - 1; i >= 0; i--) {
+                            if (i < q) {
+                                double s = tt[i];
+#pragma unroll
+                                for (int k = i + 1; k < NV; k++) if (k < q) s -= Lr[k][i] * rr[k];
+                                rr[i] = s / Lr[i][i];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NV; i++) L.r[i] = rr[i];
+                    WAVE_LDS_SYNC();
+                    if (tid < n) {
+                        const int j = tid;
+                        double s = L.np[j];
+                        for (int i = 0; i < q; i++) s -= L.An[i][j] * L.r[i];
+                        L.z[j] = s / L.Hd[j];
+                    }
+                    WAVE_LDS_SYNC();
+                    double zz = 0, znp = 0;
+                    for (int j = 0; j < n; j++) {
+                        const double zj = L.z[j];
+                        zz += zj * zj;
+                        znp += zj * L.np[j];
+                    }
+                    // step lengths
+                    double t1 = kInf;
+                    int l = -1;
+#pragma unroll
+                    for (int i = 0; i < NV; i++)
+                        if (i < q && rr[i] > 1e-14) { const double ur = L.u[i] / rr[i]; if (ur < t1) { t1 = ur; l = i; } }
+                    double sp = -L.bp;
+                    for (int j = 0; j < n; j++) sp += L.np[j] * L.qx[j];
+                    double t2 = kInf;
+                    if (zz > 1e-24 && znp > 1e-16) t2 = -sp / znp;
+                    if (t2 < 0) t2 = 0;
+                    const double t = t1 < t2 ? t1 : t2;
+                    if (t >= kInf) { L.feasible = 0; break; }
+                    WAVE_LDS_SYNC();
+                    if (t2 >= kInf) {  // dual step only, drop the blocking row
+                        for (int i = 0; i < q; i++) L.u[i] -= t * L.r[i];
+                        up += t;
+                        is_active[L.A[l]] = 0;
+                        for (int i = l; i < q - 1; i++) { L.A[i] = L.A[i + 1]; L.u[i] = L.u[i + 1]; for (int j = 0; j < NV; j++) L.An[i][j] = L.An[i + 1][j]; }
+                        q--;
+                        if (cv > l) cv = l;
+                        continue;
+                    }
+                    for (int j = 0; j < n; j++) L.qx[j] += t * L.z[j];
+                    for (int i = 0; i < q; i++) L.u[i] -= t * L.r[i];
+                    up += t;
+                    if (t == t2) {  // full step: the row becomes active
+                        if (q >= n) { L.feasible = 0; break; }
+                        L.A[q] = p; L.u[q] = up;
+                        for (int j = 0; j < NV; j++) L.An[q][j] = L.np[j];
+                        q++;
+                        is_active[p] = 1;
+                        added = true;
+                    } else {        // partial step: drop the blocking row and try again
+                        is_active[L.A[l]] = 0;
+                        for (int i = l; i < q - 1; i++) { L.A[i] = L.A[i + 1]; L.u[i] = L.u[i + 1]; for (int j = 0; j < NV; j++) L.An[i][j] = L.An[i + 1][j]; }
+                        q--;
+                        if (cv > l) cv = l;
+                    }
+                }
+                L.added = added ? 1 : 0;
+                L.q = q;
+                L.chol_rows = cv;
+                if (!L.feasible) L.stop = 1;
+                else if (!L.added && !excluded[p]) excluded[p] = 1;  // could not make progress on this row
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (L.stop) break;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int i = 0; i < L.q; i++) if (L.u[i] > L.max_mult) L.max_mult = L.u[i];
+    // excluded rows that remain violated mean the linearisation is inconsistent
+    int viol = 0;
+    if (L.feasible)
+        for (int i = tid; i < mrows; i += 256) {
+            if (!excluded[i]) continue;
+            double ar[NV], br;
+            qp_row(a, L, cand, i, ar, br);
+            double s = -br;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (j < n) s += ar[j] * L.qx[j];   // (unrolled: `ar` stays in registers)
+            if (s < -1e-7) viol = 1;
+        }
+    L.ri[tid] = viol;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) L.ri[tid] |= L.ri[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0 && L.ri[0]) L.feasible = 0;
+    __syncthreads();
+}
+
+// gather the candidate rows of all blocks of the group, in block (= row) order, into the problem's contiguous buffer
+__device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, SolveRow* cand) {
+    const int tid = threadIdx.x, nb = a.nb;
+    const BlockWord* bw = a.blk_word + (size_t)b * nb;
+    // exclusive prefix sum of the block counts (nb <= 1024)
+    int mine[4], tot = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const int jb = tid * 4 + e; mine[e] = jb < nb ? ld_coh(&bw[jb].count) : 0; tot += mine[e]; }
+    L.ri[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? L.ri[tid - off] : 0;
+        __syncthreads();
+        L.ri[tid] += v;
+        __syncthreads();
+    }
+    int run = L.ri[tid] - tot;
+    const int total = L.ri[255];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { L.scan[tid * 4 + e] = run; run += mine[e]; }
+    __syncthreads();
+    bool ok = total <= a.cap_rows;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (tid * 4 + e < nb && mine[e] > a.cap_blk) ok = false;
+    L.ri[tid] = ok ? 0 : 1;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) L.ri[tid] |= L.ri[tid + s2];
+        __syncthreads();
+    }
+    const bool overflow = L.ri[0] != 0;
+    __syncthreads();
+    if (overflow) return false;
+    // candidate c of the problem lives in the slot of the block whose prefix range holds c
+    for (int c = tid; c < total; c += 256) {
+        int lo = 0, hi = nb - 1;
+        while (lo < hi) {  // last block with scan[jb] <= c
+            const int mid = (lo + hi + 1) >> 1;
+            if (L.scan[mid] <= c) lo = mid; else hi = mid - 1;
+        }
+        cand[c] = ld_coh_row(a.blk_rows + ((size_t)b * nb + lo) * a.cap_blk + (c - L.scan[lo]));
+    }
+    if (tid == 0) L.ncand = total;
+    __threadfence_block();
+    __syncthreads();
+    return true;
+}
+
+// One step of the SQP state machine after a phase.  Returns the next command (written to the control block by the caller).
+//
+// Every phase evaluates g AND jac at its point and scans violation, candidate rows and the finalize_solution count together
+// (a phase costs ~12 us of latency whatever it computes).  So a line-search trial that is accepted already IS the new
+// linearisation -- the host form evaluates the accepted point a second time, with identical results -- and the verdict of the
+// current point is always at hand: a solve that takes the full step needs one phase per SQP iteration, and none at the end.
+// `evals` counts what the host form would have evaluated, so both forms report the same numbers.
+__device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long long viol_fx, int bad, SolveRow* cand,
+                                  unsigned char* is_active, unsigned char* excluded, double* x_pub) {
+    const int n = a.tb.n, tid = threadIdx.x;
+    const double viol = viol_from_fixed(viol_fx);
+#define LSTAMP(k) do { if (a.stamps && tid == 0 && first) a.stamps[(size_t)b * 64 + 32 + (k)] = wall_clock64() - L.t_start; } while (0)
+    // ---- the point just evaluated: x itself (first phase) or the trial point xt
+    const bool first = L.stage == ST_AFTER_FIRST;
+    const double* pt = first ? L.x : L.xt;
+    if (tid < n) {   // the squared error of each joint (eval_f) and eval_grad_f at that point
+        const bool cont = (a.continuous_mask >> tid) & 1;
+        const double qp = plan_point(a, L.bz, tid, pt[tid]);
+        const double eg = cont ? wrap_to_pi_dev(qp - L.qdes[tid]) : (qp - L.qdes[tid]);
+        L.np[tid] = 2 * eg * plan_dk(a, L.bz, tid) * a.cost_scale;   // (np / z double as scratch between QPs)
+        const double e = cont ? wrap_to_pi_dev(L.qdes[tid] - qp) : (L.qdes[tid] - qp);
+        L.z[tid] = e * e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double fpt = cost_sum(a, L.z);
+        L.stop = 0;   // 0: new SQP iteration at x (linearisation at hand); 1: finished; 3: another trial
+        if (first) {
+            L.f = fpt; L.evals = 1; L.viol = viol; L.bad = bad; L.status = 0;
+            for (int j = 0; j < n; j++) L.gradf[j] = L.np[j];
+        } else {
+            // one trial of the L1-merit backtracking line search
+            L.evals++;
+            const double phi = fpt + L.mu * viol;
+            if (phi <= L.phi0 + 1e-4 * L.alpha * L.dphi || L.ls == a.max_ls) {
+                if (L.ls == a.max_ls && phi > L.phi0) { L.status = 4; L.stop = 1; }
+                else {   // accepted: this phase is the linearisation at the new x
+                    for (int j = 0; j < n; j++) { L.x[j] = L.xt[j]; L.gradf[j] = L.np[j]; }
+                    L.f = fpt; L.viol = viol; L.bad = bad; L.iters++; L.it++;
+                    L.evals++;   // (the host form's second evaluation of the accepted point)
+                }
+            } else {
+                L.alpha *= 0.5;
+                L.ls++;
+                for (int j = 0; j < n; j++) L.xt[j] = L.x[j] + L.alpha * L.d[j];
+                L.stop = 3;
+            }
+        }
+        L.stage = ST_AFTER_TRIAL;
+        if (L.stop == 0) {   // top of an SQP iteration (solver.hip: `for (it ...)`)
+            if (L.it >= a.max_iter) { L.status = 2; L.stop = 1; }
+            else if (a.budget_ticks >= 0 && wall_clock64() - L.t_start >= a.budget_ticks) { L.status = 5; L.stop = 1; }
+        }
+    }
+    __syncthreads();
+    LSTAMP(0);
+    if (L.stop == 0) {
+        bool finish = false;
+        if (!gather_candidates(a, L, b, cand)) {
+            if (tid == 0) L.status = -1;   // candidate buffers too small for this problem: the host form takes over
+            finish = true;
+        }
+        if (!finish) {
+            LSTAMP(1);
+            // QP with the elastic retries of solver.hip (sigma = fraction of the violation a row may keep)
+            for (int attempt = 0; attempt < 4; attempt++) {
+                if (tid == 0) L.sigma = attempt == 0 ? 0.0 : attempt == 1 ? 0.5 : attempt == 2 ? 0.9 : 0.99;
+                __syncthreads();
+                solve_qp_device(a, L, cand, is_active, excluded);
+                if (L.feasible) break;
+                __syncthreads();
+            }
+            __syncthreads();
+            LSTAMP(2);
+            if (tid == 0 && a.stamps && L.it == 0) { a.stamps[(size_t)b * 64 + 40] = L.qp_iter; a.stamps[(size_t)b * 64 + 41] = L.ncand; }
+            if (tid == 0) {
+                if (!L.feasible) { L.status = 3; L.stop = 1; }
+                else {
+                    double dn = 0, gd = 0;
+                    for (int j = 0; j < n; j++) { L.d[j] = L.qx[j]; dn = fmax(dn, fabs(L.qx[j])); gd += L.gradf[j] * L.qx[j]; }
+                    if (dn <= a.tol * 1e-2 || (dn <= a.tol && L.viol <= a.tol)) { L.status = 1; L.stop = 1; }
+                    else {
+                        L.mu = fmax(L.mu, 1.5 * L.max_mult + 1e-3);
+                        L.phi0 = L.f + L.mu * L.viol;
+                        L.dphi = gd - L.mu * (1.0 - L.sigma) * L.viol;
+                        if (L.dphi > -1e-14) L.dphi = -1e-14;
+                        L.alpha = 1.0;
+                        L.ls = 0;
+                        for (int j = 0; j < n; j++) L.xt[j] = L.x[j] + L.alpha * L.d[j];
+                        L.stop = 3;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (finish && tid == 0) L.stop = 1;
+        __syncthreads();
+    }
+    int next;
+    if (L.stop == 3) {   // evaluate the trial point
+        if (tid == 0) for (int j = 0; j < n; j++) st_coh(x_pub + j, L.xt[j]);
+        next = CMD_EVAL;
+    } else {             // finished: finalize_solution (RT/NLPclass.cu:422-538) on the last evaluation of x
+        if (tid == 0) {
+            ArmourSolveResult& r = a.out[b];
+            if (L.status == -1) r.status = -1;   // hand the problem back to the host form
+            else {
+                for (int j = 0; j < NV; j++) r.k_opt[j] = j < n ? L.x[j] : 0.0;
+                r.cost = L.f;
+                r.max_violation = L.viol;
+                r.feasible = L.bad == 0 ? 1 : 0;
+                r.iterations = L.iters;
+                r.evaluations = L.evals + 1;   // (+ the host form's evaluation for the verdict)
+                r.status = L.status;
+                r.time_ms = (double)(wall_clock64() - L.t_start);   // ticks; the host converts
+            }
+        }
+        next = CMD_DONE;
+    }
+    __syncthreads();
+    return next;
+}
+
+template <bool LL, int PPW>
+__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void armour_solve_kernel(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ ScanShared scan_sh;
+    __shared__ Leader L;
+    __shared__ int s_cmd;
+    __shared__ double s_x[NV];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.nb, jb = blockIdx.x - b * a.nb;
+    const bool leader = jb == 0;
+    const int n = a.tb.n, m = a.tb.m;
+    SolveCtl* c = a.ctl + b;
+    const int t0 = (int)(((long long)jb * a.n_tiles) / a.nb), t1 = (int)(((long long)(jb + 1) * a.n_tiles) / a.nb);
+    int role, r0, r1, rdummy;
+    tile_info(a, t0, role, r0, rdummy);
+    tile_info(a, t1 - 1, role, rdummy, r1);
+    SolveRow* my_rows = a.blk_rows + ((size_t)b * a.nb + jb) * a.cap_blk;
+    SolveRow* cand = a.qp_rows + (size_t)b * a.cap_rows;
+    unsigned char* is_active = a.flags + (size_t)b * 2 * (a.cap_rows + 2 * NV);
+    unsigned char* excluded = is_active + (a.cap_rows + 2 * NV);
+    double* g = a.g + (size_t)b * m;
+    double* jac = a.jac + (size_t)b * m * n;
+    if (leader && tid < 3 * NV) L.bz[tid] = tid < 3 * n ? a.tb.bez[(size_t)b * 3 * n + tid] : 0.0;
+    if (leader && tid >= 32 && tid < 32 + NV) L.qdes[tid - 32] = tid - 32 < n ? a.q_des[(size_t)b * n + tid - 32] : 0.0;
+    __syncthreads();
+    if (leader && tid == 0) {
+        L.t_start = wall_clock64();
+        for (int j = 0; j < NV; j++) {
+            L.x[j] = 0.0;   // get_starting_point: x = 0 (RT/NLPclass.cu:170-202)
+            double Hd = 1e-12;
+            if (j < n) {
+                const double dk = plan_dk(a, L.bz, j);
+                Hd = 2.0 * a.cost_scale * dk * dk;   // constant diagonal Hessian of the cost
+                if (Hd < 1e-12) Hd = 1e-12;
+            }
+            L.Hd[j] = Hd;
+        }
+        L.mu = 1.0; L.it = 0; L.iters = 0; L.evals = 0; L.status = 0; L.stage = ST_AFTER_FIRST; L.ncand = 0; L.sigma = 0.0;
+    }
+    const double* my_x = s_x;   // (a generic pointer into LDS: the tile functions take the point through a plain `const double*`)
+    unsigned phase = 0;
+    for (;;) {
+        // ---- wait until the leader has published this phase's point and command (one lane polls one word)
+        if (tid == 0) {
+            unsigned w;
+            while (((w = ld_coh(&c->go)) >> 3) < phase) __builtin_amdgcn_s_sleep(2);   // go = 8 * phase + command: one word, one round trip
+            asm volatile("" ::: "memory");
+            s_cmd = (int)(w & 7u);
+        }
+        __syncthreads();
+        const int cmd = s_cmd;
+        if (cmd == CMD_DONE) break;
+        if (tid < NV) s_x[tid] = tid < n ? ld_coh(&c->x[tid]) : 0.0;   // the phase's point, into LDS: the tile code reads it from there
+        __syncthreads();
+        // ---- evaluate my tiles at x (the tile code of armour_eval_g_jac)
+        for (int t = t0; t < t1; t++) {
+            int tr0, tr1;
+            tile_info(a, t, role, tr0, tr1);
+            if (role < a.lp.nbc) collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
+            else if (role < a.lp.nbc + a.lp.nbt) torque_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
+            else limit_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
+            __syncthreads();
+        }
+        // ---- scan my rows.  They were written by this block: same CU, same L1 -- visible after the barrier, no fence needed
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+        long long vfx = 0;
+        int cnt = 0, bad = 0;
+        scan_rows<3>(a, b, r0, r1, my_rows, a.cap_blk, scan_sh, vfx, cnt, bad);
+        BlockWord* mine = a.blk_word + (size_t)b * a.nb + jb;
+        if (tid == 0) { st_coh(&mine->viol, vfx); st_coh(&mine->bad, bad); st_coh(&mine->count, cnt); }
+        // ---- group barrier: a flag per block (199 atomics on one counter cost ~10 us per phase; 199 separate words cost nothing).
+        //      Every lane's coherent stores (candidate rows, the words above) have completed before the flag is written.
+        wait_my_memory_ops();
+        __syncthreads();
+        phase++;
+        if (tid == 0) st_coh(&mine->flag, phase);
+        if (!leader) continue;
+        for (;;) {   // the leader's 256 lanes poll the group's flags, four each
+            int all = 1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb && ld_coh(&a.blk_word[(size_t)b * a.nb + j2].flag) < phase) all = 0; }
+            if (__syncthreads_and(all)) break;
+        }
+        asm volatile("" ::: "memory");
+        // the phase's L1 violation and verdict count: integer sums of the blocks' words (any order gives the same number)
+        long long viol_fx = 0;
+        int nbad = 0;
+        {
+            long long v = 0;
+            int bd = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb) { v += ld_coh(&a.blk_word[(size_t)b * a.nb + j2].viol); bd += ld_coh(&a.blk_word[(size_t)b * a.nb + j2].bad); } }
+            scan_sh.red[tid] = v; scan_sh.redi[tid] = bd;
+            __syncthreads();
+            for (int s2 = 128; s2 > 0; s2 >>= 1) {
+                if (tid < s2) { scan_sh.red[tid] += scan_sh.red[tid + s2]; scan_sh.redi[tid] += scan_sh.redi[tid + s2]; }
+                __syncthreads();
+            }
+            viol_fx = scan_sh.red[0]; nbad = scan_sh.redi[0];
+            __syncthreads();
+        }
+        if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1)] = wall_clock64() - L.t_start;      // barrier passed
+        const int next = leader_step(a, L, b, viol_fx, nbad, cand, is_active, excluded, c->x);
+        if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1) + 1] = wall_clock64() - L.t_start;  // leader step done
+        if (tid == 0) {
+            wait_my_memory_ops();                          // x is at the memory side ...
+            st_coh(&c->go, phase * 8u + (unsigned)next);   // ... before the release (phase and command in one word) is
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, SolvePlan* plan) {
+    P2Launch lp;
+    size_t smem = 0;
+    bool dfc, six, exact;
+    int rc = armour_p2_plan(tb, max_link, max_torque, h_skip, 1, 0, 0, 0, &lp, &smem, &dfc, &six, &exact);
+    if (rc != ARMOUR_OK) return rc;
+    plan->lp = lp; plan->smem = smem; plan->six = six;
+    plan->n_tiles = lp.nbt + lp.nbc + 1;
+    const void* fn = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9> : six ? (const void*)armour_solve_kernel<true, 6> : (const void*)armour_solve_kernel<true, 9>;
+    plan->fn = fn;
+    int per_cu = 0, coop = 0;
+    HIPCHK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device));
+    if (!coop) { plan->capacity = 0; return ARMOUR_OK; }
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P2_BLOCK, smem));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    plan->capacity = per_cu * prop.multiProcessorCount;
+    int rate_khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device));
+    plan->ticks_per_ms = rate_khz > 0 ? (double)rate_khz : 100000.0;
+    return ARMOUR_OK;
+}
+
+int armour_solve_device_launch(const SolveArgs& args, const SolvePlan& plan, int B, hipStream_t stream) {
+    SolveArgs a = args;
+    void* params[1] = {&a};
+    HIPCHK(hipLaunchCooperativeKernel(plan.fn, dim3((unsigned)B * (unsigned)a.nb), dim3(P2_BLOCK), params, (unsigned)plan.smem, stream));
+    return ARMOUR_OK;
+}

@@ -256,7 +256,7 @@ class ArmourNLP:
         check(self.L.armour_check_feasible(self.h, _dp(g), feas.ctypes.data_as(C.POINTER(C.c_int32))))
         return feas.astype(bool)
 
-    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None):
+    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False):
         """OptimizeTNLP + finalize_solution for all B problems (RT/armour_main.cu:237-304): returns a list of dicts
         (k_opt, cost, feasible, iterations, evaluations, status, time_ms)."""
         opt = _lib.ArmourSolveOptions()
@@ -267,6 +267,8 @@ class ArmourNLP:
             opt.tolerance = tolerance
         if max_wall_time_s is not None:
             opt.max_wall_time_s = max_wall_time_s
+        if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) instead of the persistent kernel
+            opt.force_host_qp = 1.0
         res = (_lib.ArmourSolveResult * self.B)()
         check(self.L.armour_solve(self.h, C.byref(opt), res))
         return [dict(k_opt=np.array(r.k_opt[:self.n]), cost=r.cost, max_violation=r.max_violation, feasible=bool(r.feasible),

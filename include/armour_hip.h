@@ -169,7 +169,9 @@ typedef struct ArmourSolveOptions {
     int32_t max_line_search;  /* halvings per iteration (12) */
     double tolerance;         /* step / violation tolerance (1e-4 = IPOPT_OPTIMIZATION_TOLERANCE, RT/Parameters.h:50) */
     double max_wall_time_s;   /* 0 = unlimited (reference: 0.5 s - t(P1) - 0.05 s, RT/armour_main.cu:227-229) */
-    double reserved[4];
+    double force_host_qp;     /* 0 (default): the whole SQP iterate runs in one persistent kernel; != 0: evaluations on the device, 7-variable QPs on the
+                               * host, one launch per evaluation (the round-1 form; also the automatic fallback).  Both give the same iterates. */
+    double reserved[3];
 } ArmourSolveOptions;
 typedef struct ArmourSolveResult {
     double k_opt[ARMOUR_MAX_FACTORS];
