@@ -55,7 +55,17 @@ enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS
 #define PROF_CALL_T0
 #define PROF_CALL_END(N)
 #endif
-enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8 };
+enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8, ERR_DBG_BOUNDS = 128 };
+// -DDBG_BOUNDS (root-cause tooling, tools/gpu_fault_hunt.py): every LDS / arena index of the product merge and of the reduce
+// pass is range-checked BEFORE the access; a violation is recorded (flag 128, lstat[3] = code * 2^20 + the offending value's
+// low 20 bits, first one wins) and the index clamped to 0, so that a genuine out-of-range index shows up as a report
+// instead of a memory fault.
+#ifdef DBG_BOUNDS
+#define BCHK(w, ok, code, val) ((ok) ? true : (((w).lstat[ST_ERR] & ERR_DBG_BOUNDS) ? false : ((w).lstat[ST_ERR] |= ERR_DBG_BOUNDS, (w).lstat[3] = ((code) << 20) | ((int)(val) & 0xfffff), false)))
+#define BIDX(w, idx, lim, code) (BCHK(w, (idx) >= 0 && (idx) < (lim), code, idx) ? (idx) : 0)
+#else
+#define BIDX(w, idx, lim, code) (idx)
+#endif
 
 // A PZ slot (all fields wave-uniform).  id indexes the per-wave LDS count table.
 struct PZ {
@@ -285,7 +295,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             // round trip to memory per member -- 37 % of the chain's operator time was this pass.)  Same sums, same order.
 #pragma unroll
             for (int e = 0; e < SZ; e++) acc[e] = 0.0;
-            if (p < N) ev.coef(w.sidx[p], acc);
+            if (p < N) ev.coef(BIDX(w, (int)w.sidx[p], N, 5), acc);
             E_LAP(PR_E_COEF)
             {
                 double sh[SZ];
@@ -708,7 +718,7 @@ struct MulEval {
                     const int sb = max(rs * rl - 1, 0), se = min((rs + 1) * rl - 1, N);
                     len[u] = max(se - sb, 0);  // 0: the last run of an odd count has no sibling
                     ss[u] = len[u] > 0 ? sb : 0;
-                    ky[u] = K[pc];
+                    ky[u] = K[BIDX(w, pc, N, 1)];
                     // count the sibling's keys below ky -- and its equal key too if the sibling's term goes first on a tie
                     tg[u] = ky[u] + (uint64_t)(((r & 1) != 0) == by_a);
                     cnt[u] = 0;
@@ -717,16 +727,24 @@ struct MulEval {
                 for (int step = top; step > 0; step >>= 1) {
                     uint64_t v[U];
 #pragma unroll
-                    for (int u = 0; u < U; u++) v[u] = K[ss[u] + max(min(cnt[u] + step, len[u]), 1) - 1];
+                    for (int u = 0; u < U; u++) v[u] = K[BIDX(w, ss[u] + max(min(cnt[u] + step, len[u]), 1) - 1, N, 2)];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const int take = (int)(cnt[u] + step <= len[u]) & (int)(v[u] < tg[u]);  // (no short circuit: a branch would serialise the reads)
+#ifdef TREE_MERGE_SELECT_FORM  /* the value-identical rewrite that faulted in round 1; kept for the root-cause tooling only:
+                                  a bit mask over the product shapes (1: 3x3*3x1, 2: 3x3*3x3, 4: 1x1*1x1 incl. cross, 8: 1x1*3x1) */
+                        if constexpr ((((TREE_MERGE_SELECT_FORM) >> (SH::ASZ == 9 ? (SH::BSZ == 3 ? 0 : 1) : (SH::BSZ == 1 ? 2 : 3))) & 1) != 0)
+                            cnt[u] = take ? cnt[u] + step : cnt[u];
+                        else
+                            cnt[u] += take ? step : 0;
+#else
                         cnt[u] += take ? step : 0;
+#endif
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    if (ok[u]) { Ko[dst[u] + cnt[u]] = ky[u]; Vo[dst[u] + cnt[u]] = V[p0 + WAVE * u]; }
+                    if (ok[u]) { const int o__ = BIDX(w, dst[u] + cnt[u], N, 3); Ko[o__] = ky[u]; Vo[o__] = V[BIDX(w, p0 + WAVE * u, N, 4)]; }
             }
             WSYNC();
             cur ^= 1;
@@ -775,6 +793,9 @@ struct MulEval {
     __device__ inline void coef(int idx, double* c) const {
         int i, j;
         split(idx, i, j);
+#ifdef DBG_BOUNDS
+        if (i < 0 || i > a.cnt || j < 0 || j >= mb1) { i = 0; j = 0; }   // (reported by the caller-side checks of sidx below)
+#endif
         double ca[SH::ASZ], cb[SH::BSZ];
         if (i) {
             const GLB_AS double* pa = a.coef + (size_t)(i - 1) * a.stride + a.off;
@@ -869,6 +890,9 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
 
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
+#ifdef H1_FORCE_RA_SAVE  /* root-cause tooling: make this function save its return address on the stack, as the select form does */
+    asm volatile("; return address clobbered on purpose" ::: "s30", "s31");
+#endif
     PROF_CALL_T0
     typedef MulShape<AR, AC, BR, BC> SH;
     MulEval<SH> ev;
