@@ -38,17 +38,19 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                                                                   P2Launch lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int b = blockIdx.y, role = blockIdx.x;
-    const double* k0 = k_all + (size_t)b * tb.n;
-    double* g0 = g_all ? g_all + (size_t)b * tb.m : nullptr;
-    double* jac0 = jac_all ? jac_all + (size_t)b * tb.m * tb.n : nullptr;
+    const int n = tb.n, m = tb.m;   // (read together: one scalar load of the kernel argument block instead of two dependent ones)
+    const double* k0 = k_all + (size_t)b * n;
+    double* g0 = WANT_G ? g_all + (size_t)b * m : nullptr;
+    double* jac0 = WANT_J ? jac_all + (size_t)b * m * n : nullptr;
+    const double k_first = ((int)threadIdx.x < n) ? k0[threadIdx.x] : 0.0;   // issued before anything else: see p2_tiles.h
 #ifdef P2_ABLATE  // development only: skip roles to attribute kernel time
     if ((P2_ABLATE & 1) && role < lp.nbc) return;
     if ((P2_ABLATE & 2) && role >= lp.nbc && role < lp.nbc + lp.nbt) return;
     if ((P2_ABLATE & 4) && role >= lp.nbc + lp.nbt) return;
 #endif
-    if (role < lp.nbc) collision_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, g0, jac0, smem_raw);
-    else if (role < lp.nbc + lp.nbt) torque_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, g0, jac0, smem_raw);
-    else limit_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, g0, jac0, smem_raw);
+    if (role < lp.nbc) collision_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, k_first, g0, jac0, smem_raw);
+    else if (role < lp.nbc + lp.nbt) torque_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, k_first, g0, jac0, smem_raw);
+    else limit_block<WANT_G, WANT_J, MULTI, DFC, LL, PPW, EX>(tb, lp, b, role, k0, k_first, g0, jac0, smem_raw);
 }
 
 // link centres only (diagnostic file armour_joint_position_center.out): one thread per (b, l*T+t, axis)

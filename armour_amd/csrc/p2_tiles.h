@@ -212,18 +212,20 @@ __device__ inline void load_pass_uncond(const P2Tables& tb, const P2Launch& lp, 
 // the planes are still in flight; the barriers before the scan wait for LDS traffic only.
 template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW, bool EX>
 __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Launch& lp, const int b, const int role, const double* __restrict__ k0,
-                                   double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
+                                   const double k_first, double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
     KPow* kp2 = reinterpret_cast<KPow*>(smem_raw);  // double-buffered over the points
     double* lds = reinterpret_cast<double*>(smem_raw + 2 * sizeof(KPow));
     const int n = tb.n, T = tb.T, O = tb.O, Q = tb.Q, m = tb.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, known uniform: the plane dealing below runs on the scalar unit
-    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches)
+    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches);
+    // k_first: this thread's component of the first point (tid < n), fetched by the caller as early as it can -- a fresh k
+    // is an HBM miss, and at B = 1 the launch waits for it
     double* g0 = WANT_G ? g0_in : nullptr;
     double* jac0 = WANT_J ? jac0_in : nullptr;
     const int nsteps = MULTI ? lp.steps : 1;  // the one-point instantiation keeps the loop-free code of a single launch
     // this thread's component of the NEXT point's k is fetched one point ahead: a fresh k is an HBM miss
-    double k_next = (tid < n) ? k0[tid] : 0.0;
+    double k_next = k_first;
     (void)lane; (void)wv; (void)T; (void)O; (void)Q; (void)m; (void)kp2; (void)lds; (void)g0; (void)jac0; (void)nsteps; (void)k_next;
 #ifdef P2_TIMELINE
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -429,18 +431,20 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
 
 template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW, bool EX>
 __device__ __forceinline__ void torque_block(const P2Tables& tb, const P2Launch& lp, const int b, const int role, const double* __restrict__ k0,
-                                   double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
+                                   const double k_first, double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
     KPow* kp2 = reinterpret_cast<KPow*>(smem_raw);  // double-buffered over the points
     double* lds = reinterpret_cast<double*>(smem_raw + 2 * sizeof(KPow));
     const int n = tb.n, T = tb.T, O = tb.O, Q = tb.Q, m = tb.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, known uniform: the plane dealing below runs on the scalar unit
-    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches)
+    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches);
+    // k_first: this thread's component of the first point (tid < n), fetched by the caller as early as it can -- a fresh k
+    // is an HBM miss, and at B = 1 the launch waits for it
     double* g0 = WANT_G ? g0_in : nullptr;
     double* jac0 = WANT_J ? jac0_in : nullptr;
     const int nsteps = MULTI ? lp.steps : 1;  // the one-point instantiation keeps the loop-free code of a single launch
     // this thread's component of the NEXT point's k is fetched one point ahead: a fresh k is an HBM miss
-    double k_next = (tid < n) ? k0[tid] : 0.0;
+    double k_next = k_first;
     (void)lane; (void)wv; (void)T; (void)O; (void)Q; (void)m; (void)kp2; (void)lds; (void)g0; (void)jac0; (void)nsteps; (void)k_next;
     // ------------------------------------------------------------------ torque rows (row = t*n + j)
     double* terms = lds;  // [P2_TQ_ROWS][strideT][8]
@@ -510,18 +514,20 @@ __device__ __forceinline__ void torque_block(const P2Tables& tb, const P2Launch&
 
 template <bool WANT_G, bool WANT_J, bool MULTI, bool DFC, bool LL, int PPW, bool EX>
 __device__ __forceinline__ void limit_block(const P2Tables& tb, const P2Launch& lp, const int b, const int role, const double* __restrict__ k0,
-                                   double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
+                                   const double k_first, double* __restrict__ g0_in, double* __restrict__ jac0_in, unsigned char* smem_raw) {
     KPow* kp2 = reinterpret_cast<KPow*>(smem_raw);  // double-buffered over the points
     double* lds = reinterpret_cast<double*>(smem_raw + 2 * sizeof(KPow));
     const int n = tb.n, T = tb.T, O = tb.O, Q = tb.Q, m = tb.m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, known uniform: the plane dealing below runs on the scalar unit
-    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches)
+    // k0 / g0_in / jac0_in: THIS problem's k [n], g [m] and jac [m][n] (of the first point for multi-point launches);
+    // k_first: this thread's component of the first point (tid < n), fetched by the caller as early as it can -- a fresh k
+    // is an HBM miss, and at B = 1 the launch waits for it
     double* g0 = WANT_G ? g0_in : nullptr;
     double* jac0 = WANT_J ? jac0_in : nullptr;
     const int nsteps = MULTI ? lp.steps : 1;  // the one-point instantiation keeps the loop-free code of a single launch
     // this thread's component of the NEXT point's k is fetched one point ahead: a fresh k is an HBM miss
-    double k_next = (tid < n) ? k0[tid] : 0.0;
+    double k_next = k_first;
     (void)lane; (void)wv; (void)T; (void)O; (void)Q; (void)m; (void)kp2; (void)lds; (void)g0; (void)jac0; (void)nsteps; (void)k_next;
     // ------------------------------------------------------------------ joint limit rows
     // RT/Trajectory.cu:256-540.  One thread per (joint, position|velocity, piece): pieces 0-3 evaluate the curve

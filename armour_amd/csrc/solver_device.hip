@@ -707,12 +707,13 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
         if (tid < NV) s_x[tid] = tid < n ? ld_coh(&c->x[tid]) : 0.0;   // the phase's point, into LDS: the tile code reads it from there
         __syncthreads();
         // ---- evaluate my tiles at x (the tile code of armour_eval_g_jac)
+        const double kf = tid < n ? s_x[tid] : 0.0;
         for (int t = t0; t < t1; t++) {
             int tr0, tr1;
             tile_info(a, t, role, tr0, tr1);
-            if (role < a.lp.nbc) collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
-            else if (role < a.lp.nbc + a.lp.nbt) torque_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
-            else limit_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, g, jac, smem_raw);
+            if (role < a.lp.nbc) collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+            else if (role < a.lp.nbc + a.lp.nbt) torque_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+            else limit_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
             __syncthreads();
         }
         // ---- scan my rows.  They were written by this block: same CU, same L1 -- visible after the barrier, no fence needed
