@@ -86,6 +86,7 @@ struct SolveDeviceWork {
     unsigned char* qp_rows = nullptr; size_t qp_rows_cap = 0;
     unsigned char* flags = nullptr; size_t flags_cap = 0;
     double* q_des = nullptr; size_t q_des_cap = 0;
+    unsigned char* args = nullptr; size_t args_cap = 0;
 };
 
 struct ArmourPlanner {

@@ -352,7 +352,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)B * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
     if ((rc = grow_dev(&w.q_des, &w.q_des_cap, (size_t)B * n)) != ARMOUR_OK) return rc;
     ArmourSolveResult* hres = reinterpret_cast<ArmourSolveResult*>(armour_handle_pinned(h, 1, (size_t)B * sizeof(ArmourSolveResult)));
-    SolveCtl* hctl = reinterpret_cast<SolveCtl*>(armour_handle_pinned(h, 2, (size_t)B * sizeof(SolveCtl)));
+    SolveCtl* hctl = reinterpret_cast<SolveCtl*>(armour_handle_pinned(h, 2, (size_t)B * sizeof(SolveCtl) + sizeof(SolveArgs)));
     if (!hres || !hctl) return ARMOUR_EDEVICE;
     memset(hres, 0, (size_t)B * sizeof(ArmourSolveResult));
     memset(hctl, 0, (size_t)B * sizeof(SolveCtl));
@@ -381,7 +381,13 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
     a.stamps = hstamps;
     const auto t_launch = std::chrono::steady_clock::now();
-    if ((rc = armour_solve_device_launch(a, plan, B, h->stream)) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.args, &w.args_cap, sizeof(SolveArgs))) != ARMOUR_OK) return rc;
+    {   // (staged through page-locked memory: the copy is asynchronous and ordered before the launch on the handle's stream)
+        SolveArgs* hargs = reinterpret_cast<SolveArgs*>(reinterpret_cast<char*>(hctl) + (size_t)B * sizeof(SolveCtl));
+        *hargs = a;
+        HIPCHK(hipMemcpyAsync(w.args, hargs, sizeof(SolveArgs), hipMemcpyHostToDevice, h->stream));
+    }
+    if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(w.args), nb, plan, B, h->stream)) != ARMOUR_OK) return rc;
     for (;;) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) break;

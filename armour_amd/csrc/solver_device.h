@@ -54,4 +54,5 @@ struct SolvePlan {
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, p2::P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out);
 int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, SolvePlan* plan);
-int armour_solve_device_launch(const SolveArgs& args, const SolvePlan& plan, int B, hipStream_t stream);
+// d_args: the SolveArgs in device memory (the kernel reads them through the pointer)
+int armour_solve_device_launch(const SolveArgs* d_args, int nb, const SolvePlan& plan, int B, hipStream_t stream);

@@ -653,7 +653,11 @@ __device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long lon
 }
 
 template <bool LL, int PPW>
-__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void armour_solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void armour_solve_kernel(const SolveArgs* __restrict__ args) {
+    // The arguments come through device memory, not by value: the struct holds arrays that are indexed at run time (k_range[i]), and a
+    // by-value copy of it was materialised in EVERY lane's scratch -- 26 MB of writes per launch (rocprofv3 WRITE_SIZE) and scratch
+    // loads in the tile loops.  Read through the pointer, its fields are uniform scalar loads.
+    const SolveArgs& a = *args;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ ScanShared scan_sh;
     __shared__ Leader L;
@@ -792,9 +796,9 @@ int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torqu
     return ARMOUR_OK;
 }
 
-int armour_solve_device_launch(const SolveArgs& args, const SolvePlan& plan, int B, hipStream_t stream) {
-    SolveArgs a = args;
-    void* params[1] = {&a};
-    HIPCHK(hipLaunchCooperativeKernel(plan.fn, dim3((unsigned)B * (unsigned)a.nb), dim3(P2_BLOCK), params, (unsigned)plan.smem, stream));
+int armour_solve_device_launch(const SolveArgs* d_args, int nb, const SolvePlan& plan, int B, hipStream_t stream) {
+    const SolveArgs* p = d_args;
+    void* params[1] = {&p};
+    HIPCHK(hipLaunchCooperativeKernel(plan.fn, dim3((unsigned)B * (unsigned)nb), dim3(P2_BLOCK), params, (unsigned)plan.smem, stream));
     return ARMOUR_OK;
 }
