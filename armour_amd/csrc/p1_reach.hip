@@ -821,8 +821,24 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
 __host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
 
+// P1_WAVES_PER_SIMD: 1 (shipped) = no occupancy request, the kernels hold 256 VGPRs + spill AGPRs, one wave per SIMD.
+// 2 (development, `make EXTRA=-DP1_WAVES_PER_SIMD=2`) = every kernel of this file that calls the operators asks for two
+// waves per SIMD; with all of them agreeing the <= 256-register budget propagates to the non-inlined operator functions
+// (AMDGPU attributor, closed world of this object: 248 VGPRs, no AGPRs, a little more scratch) and a fifth one-wave block
+// fits a CU: B = 128 builds in 51.7 ms instead of 58.4.  NOT shipped: in that build, batches with >= 3 blocks per CU come out
+// wrong about every second launch, and what makes them wrong has not been found ("Two waves per SIMD",
+// profiles/r02_p1_two_waves_per_simd.txt) -- P1_FORCE_AGPR below is one of that hunt's controls.
+#ifndef P1_WAVES_PER_SIMD
+#define P1_WAVES_PER_SIMD 1
+#endif
+#if P1_WAVES_PER_SIMD > 1
+#define P1_OCC __attribute__((amdgpu_waves_per_eu(P1_WAVES_PER_SIMD, P1_WAVES_PER_SIMD)))
+#else
+#define P1_OCC
+#endif
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
+__global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg cf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chain c;
     c.cf = &cf;
@@ -844,6 +860,9 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_chain_kernel(P1Cfg cf) {
     unsigned long long* prof_lds = c.w.prof;  // (name kept from the LDS version: these are this wave's own counters now)
     for (int i = 0; i < PR_WORDS; i++) prof_lds[i] = 0;
     const long long prof_start = clock64();
+#endif
+#ifdef P1_FORCE_AGPR  // development: claim accumulation registers -- the same operator code, but the kernel descriptor allows one wave per SIMD only
+    __asm__ volatile("" ::: "a31");
 #endif
     c.w.cap_raw = cf.capRaw;
     c.w.cap_key = cf.capKey;
@@ -1018,7 +1037,7 @@ struct PzOpArgs {
     int out_cap;
 };
 
-__global__ __launch_bounds__(64) void armour_p1_pzop_kernel(P1Cfg cf, const PzOpArgs* ap) {
+__global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, const PzOpArgs* ap) {
     const PzOpArgs a = *ap;  // passed through memory: P1Cfg alone nearly fills the 4 KB kernel-argument segment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chain c;
@@ -1212,7 +1231,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (L3.idJS + L3.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
     auto ci_doubles = [&](const Layout& L) { return (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3; };
     auto lds_bytes = [&](int cap, int nw = 1) { return (size_t)nw * p1_wave_lds(cap, cap) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : L3)); };
-    auto waves_per_cu = [&](int cap) { return std::max(1, std::min(4, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };  // 4 = one wave per SIMD (the kernel needs > 256 registers)
+    static const int max_waves_env = [] { const char* e = getenv("ARMOUR_P1_MAX_WAVES_PER_CU"); return e ? atoi(e) : 4 * P1_WAVES_PER_SIMD; }();  // development override
+    auto waves_per_cu = [&](int cap) { return std::max(1, std::min(max_waves_env, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };
     float total_ms = 0;
     unsigned st[ST_WORDS];
     // one launch of the chain kernel over `n_items` work items (d_items == nullptr: all of them) with sort buffers of `cap`

@@ -107,12 +107,29 @@ __device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.k
 // Sum over the 64 lanes, returned in every lane.  Data-parallel-primitive moves inside the VALU (quad permutes, row
 // mirrors, row broadcasts) instead of six rounds of cross-lane shuffles through the LDS crossbar, which cost ~3 k cycles
 // per product operator in abs_sum alone (tools/gpu_pzop_cost.py).  Fixed summation tree: the same result in every launch shape.
+#ifdef NO_DPP  /* development: the same data movement through ds_bpermute instead of DPP moves */
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_take(double v) {
+    const int lane = (int)(threadIdx.x & 63), row = lane >> 4, li = lane & 15;
+    int src = lane; bool valid = true;
+    if (CTRL == 0xB1) src = lane ^ 1;
+    else if (CTRL == 0x4E) src = lane ^ 2;
+    else if (CTRL == 0x141) src = (lane & ~7) | (7 - (lane & 7));
+    else if (CTRL == 0x140) src = (lane & ~15) | (15 - li);
+    else if (CTRL == 0x142) { src = row * 16 - 1; valid = row > 0; }
+    else if (CTRL == 0x143) { src = 31; valid = row >= 2; }
+    else if (CTRL == 0x130) { src = lane + 1; valid = lane < 63; }
+    const double g = __shfl(v, valid ? src : lane, 64);
+    return (valid && ((ROW_MASK >> row) & 1)) ? g : 0.0;
+}
+#else
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_take(double v) {  // the value of the lane selected by CTRL; 0.0 where no lane is selected / the row is masked
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+#endif
 __device__ inline double wave_sum(double v) {
     v += dpp_take<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
     v += dpp_take<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
@@ -239,7 +256,14 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
                     if (p > 0 && (indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) == kp && w.sidx[p - 1] > w.sidx[p]) bad |= 4;
                     if (kp != ev.key(w.sidx[p])) bad |= 2;
                 }
-                if (__ballot(bad != 0) != 0ull && w.lane == 0) { w.lstat[ST_ERR] |= 64; w.lstat[3] = N; }
+                {
+                    const unsigned long long any = __ballot(bad != 0);
+                    if (any != 0ull && !(w.lstat[ST_ERR] & 64)) {
+                        int bits = 0;
+                        for (int b = 1; b <= 4; b <<= 1) if (__ballot((bad & b) != 0) != 0ull) bits |= b;
+                        if (w.lane == 0) { w.lstat[ST_ERR] |= 64; w.lstat[3] = (N & 0xffff) | (bits << 16) | ((indirect ? 1 : 0) << 20) | (__popcll(any) << 24); }
+                    }
+                }
             }
 #endif
         } else {
@@ -622,6 +646,7 @@ struct MulShape {
 // quotient is either an integer (d a power of two) or at least 2^-16 away from one, far more than the rounding error
 __device__ inline unsigned long long magic_u32(int d) { return (unsigned long long)(4294967296.0 / (double)d) + 1ull; }
 
+
 template <class SH>
 struct MulEval {
     static constexpr int kCountMax = WAVE;
@@ -654,7 +679,12 @@ struct MulEval {
 #ifdef DBG_NO_MERGE_MUL
         return false;
 #endif
+#ifndef DBG_NO_TREE
         if (can_tree(w, N)) { indirect = false; tree_merge(w, N); return true; }
+#endif
+#ifdef DBG_NO_RANK
+        return false;
+#endif
         if (!can_rank(w)) return false;  // too long for the tree's two buffers and too many runs to rank: the bitonic network
         indirect = true;
         return rank_merge(w, N);
