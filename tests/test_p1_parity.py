@@ -375,3 +375,21 @@ def test_non_finite_inputs_are_refused(sample_problem):
             nlp.set_parameters(bad["q0"], bad["qd0"], bad["qdd0"], bad["q_des"], bad["obstacles"])
     nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])   # the handle is still usable
     assert np.isfinite(nlp.eval_g(np.zeros(7))).all()
+
+
+@pytest.mark.parametrize("B,O", [(1, 20), (16, 20), (48, 10)])
+def test_builds_are_reproducible_from_launch_to_launch(B, O):
+    """The same batch built five times on fresh handles gives the same bits every time, in the three launch shapes (three waves per
+    item; one wave per item with three blocks per CU; the two-pass build).  A development build with two waves per SIMD failed
+    exactly this, about every second launch (profiles/r02_p1_two_waves_per_simd.txt) -- the shipped object must never."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    bp = random_batch(7, B, O)
+    ks = random_k(3, B)
+    first = None
+    for _ in range(5):
+        nlp = ArmourNLP(T=100).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        got = (nlp.torque_radius().copy(), nlp.link_generators().copy()) + tuple(a.copy() for a in nlp.eval_g_jac(ks))
+        first = first or got
+        for a, b in zip(got, first):
+            assert np.array_equal(a, b)
