@@ -208,7 +208,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     for (int i = 0; i < 6; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds);
     dev_free(&h->solve_dev.ctl); dev_free(&h->solve_dev.blk_word); dev_free(&h->solve_dev.blk_rows); dev_free(&h->solve_dev.qp_rows);
-    dev_free(&h->solve_dev.flags); dev_free(&h->solve_dev.q_des); dev_free(&h->solve_dev.args);
+    dev_free(&h->solve_dev.flags);
     dev_free(&h->d_jrs);
     armour_p1_free(h);
     dev_free(&h->d_link_count); dev_free(&h->d_link_center); dev_free(&h->d_link_indep);

@@ -80,13 +80,12 @@ struct P2Tables {
 
 // device buffers of the device-resident armour_solve (solver_device.hip), grown on demand and kept across solves
 struct SolveDeviceWork {
-    unsigned char* ctl = nullptr; size_t ctl_cap = 0;
+    unsigned char* ctl = nullptr; size_t ctl_cap = 0;            // one block: control words | goals | SolveArgs (one copy per solve)
     unsigned char* blk_word = nullptr; size_t word_cap = 0;
+    int words_clean = 0;                                         // the last launch ended normally: every block has cleared its flag word
     unsigned char* blk_rows = nullptr; size_t blk_rows_cap = 0;
     unsigned char* qp_rows = nullptr; size_t qp_rows_cap = 0;
     unsigned char* flags = nullptr; size_t flags_cap = 0;
-    double* q_des = nullptr; size_t q_des_cap = 0;
-    unsigned char* args = nullptr; size_t args_cap = 0;
 };
 
 struct ArmourPlanner {

@@ -37,8 +37,10 @@ constexpr double kInf = 1e300;
 
 // ---- tiny dense helpers (q <= NV) ----
 // solve M y = rhs for symmetric positive definite M (q x q, row-major NV stride) by Cholesky; false if not SPD
+// Divisions are taken once per pivot: every other use multiplies by the stored reciprocal (the device form runs this chain on one
+// wave, where a dependent fp64 division costs ~40x a multiplication; both forms use the same expressions, so they agree bit for bit).
 bool spd_solve(const double* M, int q, const double* rhs, double* y) {
-    double L[NV][NV];
+    double L[NV][NV], inv[NV];
     for (int i = 0; i < q; i++)
         for (int j = 0; j <= i; j++) {
             double s = M[i * NV + j];
@@ -46,20 +48,21 @@ bool spd_solve(const double* M, int q, const double* rhs, double* y) {
             if (i == j) {
                 if (s <= 1e-14 * std::fabs(M[i * NV + i]) || s <= 0) return false;
                 L[i][i] = std::sqrt(s);
+                inv[i] = 1.0 / L[i][i];
             } else {
-                L[i][j] = s / L[j][j];
+                L[i][j] = s * inv[j];
             }
         }
     double t[NV];
     for (int i = 0; i < q; i++) {
         double s = rhs[i];
         for (int k = 0; k < i; k++) s -= L[i][k] * t[k];
-        t[i] = s / L[i][i];
+        t[i] = s * inv[i];
     }
     for (int i = q - 1; i >= 0; i--) {
         double s = t[i];
         for (int k = i + 1; k < q; k++) s -= L[k][i] * y[k];
-        y[i] = s / L[i][i];
+        y[i] = s * inv[i];
     }
     return true;
 }
@@ -82,8 +85,8 @@ struct QpResult {
 QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = 400) {
     QpResult res;
     res.iterations = 0; res.feasible = true; res.max_mult = 0;
-    double x[NV];
-    for (int j = 0; j < n; j++) x[j] = -g0[j] / Gd[j];
+    double x[NV], invG[NV];
+    for (int j = 0; j < n; j++) { invG[j] = 1.0 / Gd[j]; x[j] = -g0[j] * invG[j]; }
     int A[NV];       // active row ids
     double u[NV + 1];  // multipliers of the active rows (+ the entering one)
     int q = 0;
@@ -113,11 +116,11 @@ QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<Q
                 for (int i = 0; i < q; i++) {
                     for (int k = 0; k <= i; k++) {
                         double s = 0;
-                        for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * rows[A[k]].a[j] / Gd[j];
+                        for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * rows[A[k]].a[j] * invG[j];
                         M[i * NV + k] = s; M[k * NV + i] = s;
                     }
                     double s = 0;
-                    for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * np[j] / Gd[j];
+                    for (int j = 0; j < n; j++) s += rows[A[i]].a[j] * np[j] * invG[j];
                     rhs[i] = s;
                 }
                 if (!spd_solve(M, q, rhs, r)) { excluded[p] = 1; break; }  // dependent active set: skip this row
@@ -126,7 +129,7 @@ QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<Q
             for (int j = 0; j < n; j++) {
                 double s = np[j];
                 for (int i = 0; i < q; i++) s -= rows[A[i]].a[j] * r[i];
-                z[j] = s / Gd[j];
+                z[j] = s * invG[j];
                 zz += z[j] * z[j];
                 znp += z[j] * np[j];
             }
@@ -344,28 +347,39 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     int cap_rows = std::min(2 * m, 8192);
     if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) { cap_blk = std::max(1, std::min(cap_blk, atoi(e))); }  // tests: force the overflow fallback
     SolveDeviceWork& w = h->solve_dev;
-    if ((rc = grow_dev(&w.ctl, &w.ctl_cap, (size_t)B * sizeof(SolveCtl))) != ARMOUR_OK) return rc;
-    if ((rc = grow_dev(&w.blk_word, &w.word_cap, (size_t)B * nb * sizeof(BlockWord))) != ARMOUR_OK) return rc;
-    HIPCHK(hipMemsetAsync(w.blk_word, 0, (size_t)B * nb * sizeof(BlockWord), h->stream));
+    // everything the host hands the kernel sits in ONE device block, filled by ONE copy from its page-locked mirror: the per-problem
+    // control words, the goals, the argument block (three copies and a fill ahead of the launch cost ~10 us of a 150 us solve)
+    const size_t off_qdes = ((size_t)B * sizeof(SolveCtl) + 255) & ~(size_t)255;
+    const size_t off_args = (off_qdes + (size_t)B * n * sizeof(double) + 255) & ~(size_t)255;
+    const size_t block_bytes = off_args + sizeof(SolveArgs);
+    if ((rc = grow_dev(&w.ctl, &w.ctl_cap, block_bytes)) != ARMOUR_OK) return rc;
+    // the blocks' flag words: zero before a launch.  Every block clears its own word when it leaves the kernel, so a fill is only
+    // needed when the array is new (or grew)
+    {
+        const size_t need = (size_t)B * nb * sizeof(BlockWord);
+        const size_t had = w.word_cap;
+        if ((rc = grow_dev(&w.blk_word, &w.word_cap, need)) != ARMOUR_OK) return rc;
+        if (w.word_cap != had || !w.words_clean) HIPCHK(hipMemsetAsync(w.blk_word, 0, w.word_cap, h->stream));
+        w.words_clean = 0;   // until this launch has been seen to end
+    }
     if ((rc = grow_dev(&w.blk_rows, &w.blk_rows_cap, (size_t)B * nb * cap_blk * sizeof(SolveRow))) != ARMOUR_OK) return rc;
     if ((rc = grow_dev(&w.qp_rows, &w.qp_rows_cap, (size_t)B * cap_rows * sizeof(SolveRow))) != ARMOUR_OK) return rc;
     if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)B * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
-    if ((rc = grow_dev(&w.q_des, &w.q_des_cap, (size_t)B * n)) != ARMOUR_OK) return rc;
     ArmourSolveResult* hres = reinterpret_cast<ArmourSolveResult*>(armour_handle_pinned(h, 1, (size_t)B * sizeof(ArmourSolveResult)));
-    SolveCtl* hctl = reinterpret_cast<SolveCtl*>(armour_handle_pinned(h, 2, (size_t)B * sizeof(SolveCtl) + sizeof(SolveArgs)));
-    if (!hres || !hctl) return ARMOUR_EDEVICE;
+    unsigned char* hblock = reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 2, block_bytes));
+    if (!hres || !hblock) return ARMOUR_EDEVICE;
+    SolveCtl* hctl = reinterpret_cast<SolveCtl*>(hblock);
     memset(hres, 0, (size_t)B * sizeof(ArmourSolveResult));
     memset(hctl, 0, (size_t)B * sizeof(SolveCtl));
     for (int b = 0; b < B; b++) { hctl[b].go = 1; /* phase 0: CMD_EVAL_GJ at x = 0 */ hres[b].status = -2; }
-    HIPCHK(hipMemcpyAsync(w.ctl, hctl, (size_t)B * sizeof(SolveCtl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(w.q_des, h->h_qdes.data(), (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    memcpy(hblock + off_qdes, h->h_qdes.data(), (size_t)B * n * sizeof(double));
     SolveArgs a;
     memset(&a, 0, sizeof(a));
     a.tb = tb; a.lp = plan.lp; a.nb = nb; a.n_tiles = plan.n_tiles; a.cap_blk = cap_blk; a.cap_rows = cap_rows;
     a.lo = h->d_bounds; a.hi = h->d_bounds + (size_t)B * m; a.g = h->d_g; a.jac = h->d_jac;
     a.ctl = reinterpret_cast<SolveCtl*>(w.ctl); a.blk_word = reinterpret_cast<BlockWord*>(w.blk_word);
     a.blk_rows = reinterpret_cast<SolveRow*>(w.blk_rows); a.qp_rows = reinterpret_cast<SolveRow*>(w.qp_rows); a.flags = w.flags;
-    a.q_des = w.q_des; a.out = hres;   // the kernel writes the results straight into page-locked host memory
+    a.q_des = reinterpret_cast<const double*>(reinterpret_cast<unsigned char*>(w.ctl) + off_qdes); a.out = hres;   // the kernel writes the results straight into page-locked host memory
     for (int i = 0; i < n; i++) if (h->robot.continuous[i]) a.continuous_mask |= 1 << i;
     a.max_iter = opt.max_iterations; a.max_ls = opt.max_line_search; a.tol = opt.tolerance;
     a.n_checked_collision = armour_checked_collision_rows(h);
@@ -381,18 +395,15 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
     a.stamps = hstamps;
     const auto t_launch = std::chrono::steady_clock::now();
-    if ((rc = grow_dev(&w.args, &w.args_cap, sizeof(SolveArgs))) != ARMOUR_OK) return rc;
-    {   // (staged through page-locked memory: the copy is asynchronous and ordered before the launch on the handle's stream)
-        SolveArgs* hargs = reinterpret_cast<SolveArgs*>(reinterpret_cast<char*>(hctl) + (size_t)B * sizeof(SolveCtl));
-        *hargs = a;
-        HIPCHK(hipMemcpyAsync(w.args, hargs, sizeof(SolveArgs), hipMemcpyHostToDevice, h->stream));
-    }
-    if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(w.args), nb, plan, B, h->stream)) != ARMOUR_OK) return rc;
+    memcpy(hblock + off_args, &a, sizeof(SolveArgs));
+    HIPCHK(hipMemcpyAsync(w.ctl, hblock, block_bytes, hipMemcpyHostToDevice, h->stream));   // (asynchronous from page-locked memory, ordered before the launch)
+    if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(reinterpret_cast<unsigned char*>(w.ctl) + off_args), nb, plan, B, h->stream)) != ARMOUR_OK) return rc;
     for (;;) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { armour_set_error("armour_solve (device form): %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
     }
+    w.words_clean = 1;
     for (int b = 0; b < B; b++)
         if (hres[b].status < 0) return 0;   // candidate buffers too small for some problem: the host form redoes the solve
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -400,8 +411,11 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         fprintf(stderr, "[armour_solve, device form] B=%d: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, nb, plan.n_tiles, ms,
                 std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
         for (int i = 0; i < 32 && (i < 2 || hstamps[i]); i++) fprintf(stderr, " %.1f", hstamps[i] / plan.ticks_per_ms * 1e3);
-        fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)\n", hstamps[32] / plan.ticks_per_ms * 1e3,
+        fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)", hstamps[32] / plan.ticks_per_ms * 1e3,
                 hstamps[33] / plan.ticks_per_ms * 1e3, hstamps[34] / plan.ticks_per_ms * 1e3, hstamps[40], hstamps[41]);
+        fprintf(stderr, " | QP parts of problem 0, all steps, us: row search %.1f, entering row %.1f, M + rhs %.1f, factor + solves %.1f, z + step lengths %.1f, update %.1f, closing barrier %.1f\n",
+                hstamps[44] / plan.ticks_per_ms * 1e3, hstamps[45] / plan.ticks_per_ms * 1e3, hstamps[46] / plan.ticks_per_ms * 1e3, hstamps[47] / plan.ticks_per_ms * 1e3,
+                hstamps[48] / plan.ticks_per_ms * 1e3, hstamps[49] / plan.ticks_per_ms * 1e3, hstamps[50] / plan.ticks_per_ms * 1e3);
     }
     for (int b = 0; b < B; b++) { results[b] = hres[b]; results[b].time_ms = ms; }
     return 1;

@@ -194,7 +194,7 @@ struct Leader {
     double bz[3 * NV], qdes[NV];
     // QP state and temporaries (thread 0 works on them with run-time indices: LDS, not scratch)
     double qx[NV], u[NV + 1], An[NV][NV], np[NV];
-    double M[NV * NV], Lc[NV][NV], rhs[NV], r[NV], z[NV];
+    double M[NV * NV], Lc[NV][NV], Lci[NV], invHd[NV], rhs[NV], r[NV], z[NV];   // Lci[i] = 1 / Lc[i][i], invHd[j] = 1 / Hd[j] (solver.hip spd_solve)
     double bp, up, max_mult, sigma;
     int A[NV], q, p, qp_iter, feasible, stop, added, chol_rows;
     unsigned char act[kFlagsInLds], exc[kFlagsInLds];
@@ -230,6 +230,7 @@ __device__ inline void qp_row(const SolveArgs& a, const Leader& L, const SolveRo
 //   * the Cholesky factor of M and the two triangular solves run in registers (fully unrolled, guarded by the active count) and
 //     the factor is extended row by row as rows enter the active set: row i of the factor depends on rows <= i of M only, so the
 //     numbers are those of the from-scratch factorisation the host form does at every step.
+template <int WPS>   // (one copy per compiled occupancy, see leader_step)
 __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const SolveRow* cand, unsigned char* is_active_g, unsigned char* excluded_g,
                                        int max_iter = 400) {
     const int n = a.tb.n, tid = threadIdx.x;
@@ -237,7 +238,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
     unsigned char* is_active = mrows <= kFlagsInLds ? L.act : is_active_g;
     unsigned char* excluded = mrows <= kFlagsInLds ? L.exc : excluded_g;
     if (tid == 0) {
-        for (int j = 0; j < n; j++) L.qx[j] = -L.gradf[j] / L.Hd[j];
+        for (int j = 0; j < NV; j++) { L.invHd[j] = 1.0 / L.Hd[j]; L.qx[j] = j < n ? -L.gradf[j] * L.invHd[j] : 0.0; }
         L.q = 0; L.qp_iter = 0; L.feasible = 1; L.max_mult = 0; L.stop = 0; L.chol_rows = 0;
     }
     for (int i = tid; i < mrows; i += 256) { is_active[i] = 0; excluded[i] = 0; }
@@ -247,6 +248,15 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
     for (int j = 0; j < NV; j++) my_a[j] = 0.0;
     if (one_row && tid < mrows) qp_row(a, L, cand, tid, my_a, my_b);
     __syncthreads();
+    // wave 0's QP state (the same values in all of its lanes): iterate, multipliers, active count, valid rows of the Cholesky factor
+    double qx[NV], u[NV + 1];
+#pragma unroll
+    for (int j = 0; j < NV; j++) { qx[j] = j < n ? L.qx[j] : 0.0; u[j] = 0.0; }
+    u[NV] = 0.0;
+    int q = 0, cv = 0;
+    long long* qst = a.stamps && blockIdx.x == 0 ? a.stamps + 44 : nullptr;   // ARMOUR_SOLVE_TIMING: ticks per part of the QP step, summed over the steps
+    long long q_t = qst ? wall_clock64() : 0;
+#define QP_LAP(slot) if (qst && tid == 0) { const long long n__ = wall_clock64(); qst[slot] += n__ - q_t; q_t = n__; }
     for (;;) {
         // most violated inactive row: smallest s = a_i'x - b_i below -1e-10, the first such row on ties
         double best = -1e-10;
@@ -290,6 +300,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
         }
         const int p = bi;
         __syncthreads();
+        QP_LAP(0)
         if (p < 0) break;
         if (one_row && tid == p) {   // the entering row's normal and right-hand side: from the thread that holds them
 #pragma unroll
@@ -297,20 +308,28 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
             L.bp = my_b;
         }
         __syncthreads();
+        QP_LAP(1)
         if (tid < 64) {
+            // Wave 0, all lanes in lockstep.  The small vectors (entering normal, iterate, multipliers, z, r) live in REGISTERS, the same
+            // values in every lane; LDS carries only what lanes exchange (M, rhs, the z entries) and what the other waves read (qx, flags).
+            // (With everything in LDS a step was a chain of ~150 dependent LDS round trips: 6 us.)
             L.p = p;
             if (++L.qp_iter > max_iter) { L.feasible = 0; L.stop = 1; }
             else {
                 if (!one_row) {
-                    double npr[NV], bpr;
-                    qp_row(a, L, cand, p, npr, bpr);
+                    double npr0[NV], bpr;
+                    qp_row(a, L, cand, p, npr0, bpr);
 #pragma unroll
-                    for (int j = 0; j < NV; j++) L.np[j] = npr[j];
+                    for (int j = 0; j < NV; j++) L.np[j] = npr0[j];
                     L.bp = bpr;
+                    WAVE_LDS_SYNC();
                 }
+                double npr[NV], ih[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) { npr[j] = L.np[j]; ih[j] = L.invHd[j]; }
+                const double bp = L.bp;
                 double up = 0.0;
                 bool added = false;
-                int q = L.q, cv = L.chol_rows;
                 for (int guard = 0; guard < 4 * NV + 8 && !added; guard++) {
                     // r = N* np,  z = G^-1 (np - N r)
                     double rr[NV];
@@ -323,7 +342,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
                             if (i < q && k <= i) {
                                 double s = 0;
 #pragma unroll
-                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * L.An[k][j] / L.Hd[j];   // (unrolled: the 7 divisions overlap)
+                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * L.An[k][j] * ih[j];
                                 L.M[i * NV + k] = s; L.M[k * NV + i] = s;
                             }
                         } else if (tid < NV * NV + NV) {
@@ -331,17 +350,20 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
                             if (i < q) {
                                 double s = 0;
 #pragma unroll
-                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * L.np[j] / L.Hd[j];
+                                for (int j = 0; j < NV; j++) if (j < n) s += L.An[i][j] * npr[j] * ih[j];
                                 L.rhs[i] = s;
                             }
                         }
                         WAVE_LDS_SYNC();
+                        QP_LAP(2)
                         // Cholesky M = Lc Lc' (spd_solve of solver.hip), rows [cv, q) new, in registers
-                        double Lr[NV][NV];
+                        double Lr[NV][NV], Li[NV];
 #pragma unroll
-                        for (int i = 0; i < NV; i++)
+                        for (int i = 0; i < NV; i++) {
+                            Li[i] = i < cv ? L.Lci[i] : 0.0;
 #pragma unroll
                             for (int k = 0; k <= i; k++) Lr[i][k] = i < cv ? L.Lc[i][k] : 0.0;
+                        }
                         bool spd = true;
 #pragma unroll
                         for (int i = 0; i < NV; i++) {
@@ -354,15 +376,16 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
                                         for (int k = 0; k < jj; k++) s -= Lr[i][k] * Lr[jj][k];
                                         if (jj == i) {
                                             if (s <= 1e-14 * fabs(L.M[i * NV + i]) || s <= 0) spd = false;
-                                            else Lr[i][i] = sqrt(s);
+                                            else { Lr[i][i] = sqrt(s); Li[i] = 1.0 / Lr[i][i]; }
                                         } else {
-                                            Lr[i][jj] = s / Lr[jj][jj];
+                                            Lr[i][jj] = s * Li[jj];
                                         }
                                     }
                                 }
                                 if (spd) {
 #pragma unroll
                                     for (int k = 0; k <= i; k++) L.Lc[i][k] = Lr[i][k];
+                                    L.Lci[i] = Li[i];
                                     cv = i + 1;
                                 }
                             }
@@ -376,7 +399,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
                                 double s = L.rhs[i];
 #pragma unroll
                                 for (int k = 0; k < i; k++) s -= Lr[i][k] * tt[k];
-                                tt[i] = s / Lr[i][i];
+                                tt[i] = s * Li[i];
                             }
                         }
 #pragma unroll
@@ -385,76 +408,95 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
                                 double s = tt[i];
 #pragma unroll
                                 for (int k = i + 1; k < NV; k++) if (k < q) s -= Lr[k][i] * rr[k];
-                                rr[i] = s / Lr[i][i];
+                                rr[i] = s * Li[i];
                             }
                         }
                     }
+                    QP_LAP(3)
+                    // z: lane j forms entry j (np_j - sum_i An[i][j] r_i in row order, times 1/Hd_j), then every lane takes all of them
+                    double zmine = 0.0;
+                    {
+                        const int j = tid < NV ? tid : 0;
+                        double s = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NV; i++) L.r[i] = rr[i];
-                    WAVE_LDS_SYNC();
-                    if (tid < n) {
-                        const int j = tid;
-                        double s = L.np[j];
-                        for (int i = 0; i < q; i++) s -= L.An[i][j] * L.r[i];
-                        L.z[j] = s / L.Hd[j];
+                        for (int jj = 0; jj < NV; jj++) if (jj == j) s = npr[jj];
+#pragma unroll
+                        for (int i = 0; i < NV; i++) if (i < q) s -= L.An[i][j] * rr[i];
+                        double ihj = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < NV; jj++) if (jj == j) ihj = ih[jj];
+                        zmine = s * ihj;
                     }
-                    WAVE_LDS_SYNC();
+                    double z[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) z[j] = j < n ? __shfl(zmine, j, 64) : 0.0;
                     double zz = 0, znp = 0;
-                    for (int j = 0; j < n; j++) {
-                        const double zj = L.z[j];
-                        zz += zj * zj;
-                        znp += zj * L.np[j];
-                    }
+#pragma unroll
+                    for (int j = 0; j < NV; j++) if (j < n) { zz += z[j] * z[j]; znp += z[j] * npr[j]; }
                     // step lengths
                     double t1 = kInf;
                     int l = -1;
 #pragma unroll
                     for (int i = 0; i < NV; i++)
-                        if (i < q && rr[i] > 1e-14) { const double ur = L.u[i] / rr[i]; if (ur < t1) { t1 = ur; l = i; } }
-                    double sp = -L.bp;
-                    for (int j = 0; j < n; j++) sp += L.np[j] * L.qx[j];
+                        if (i < q && rr[i] > 1e-14) { const double ur = u[i] / rr[i]; if (ur < t1) { t1 = ur; l = i; } }
+                    double sp = -bp;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) if (j < n) sp += npr[j] * qx[j];
                     double t2 = kInf;
                     if (zz > 1e-24 && znp > 1e-16) t2 = -sp / znp;
                     if (t2 < 0) t2 = 0;
                     const double t = t1 < t2 ? t1 : t2;
                     if (t >= kInf) { L.feasible = 0; break; }
-                    WAVE_LDS_SYNC();
-                    if (t2 >= kInf) {  // dual step only, drop the blocking row
-                        for (int i = 0; i < q; i++) L.u[i] -= t * L.r[i];
-                        up += t;
-                        is_active[L.A[l]] = 0;
-                        for (int i = l; i < q - 1; i++) { L.A[i] = L.A[i + 1]; L.u[i] = L.u[i + 1]; for (int j = 0; j < NV; j++) L.An[i][j] = L.An[i + 1][j]; }
-                        q--;
-                        if (cv > l) cv = l;
-                        continue;
+                    QP_LAP(4)
+                    const bool dual_only = t2 >= kInf;
+                    if (!dual_only) {
+#pragma unroll
+                        for (int j = 0; j < NV; j++) if (j < n) qx[j] += t * z[j];
                     }
-                    for (int j = 0; j < n; j++) L.qx[j] += t * L.z[j];
-                    for (int i = 0; i < q; i++) L.u[i] -= t * L.r[i];
+#pragma unroll
+                    for (int i = 0; i < NV; i++) if (i < q) u[i] -= t * rr[i];
                     up += t;
-                    if (t == t2) {  // full step: the row becomes active
+                    if (!dual_only && t == t2) {  // full step: the row becomes active
                         if (q >= n) { L.feasible = 0; break; }
-                        L.A[q] = p; L.u[q] = up;
-                        for (int j = 0; j < NV; j++) L.An[q][j] = L.np[j];
+#pragma unroll
+                        for (int i = 0; i < NV; i++) if (i == q) u[i] = up;
+                        if (tid < NV) L.An[q][tid] = L.np[tid];
+                        if (tid == 0) { L.A[q] = p; is_active[p] = 1; }
                         q++;
-                        is_active[p] = 1;
                         added = true;
-                    } else {        // partial step: drop the blocking row and try again
-                        is_active[L.A[l]] = 0;
-                        for (int i = l; i < q - 1; i++) { L.A[i] = L.A[i + 1]; L.u[i] = L.u[i + 1]; for (int j = 0; j < NV; j++) L.An[i][j] = L.An[i + 1][j]; }
+                    } else {        // dual step only, or a partial step: drop the blocking row (and try again)
+                        if (tid == 0) is_active[L.A[l]] = 0;
+                        WAVE_LDS_SYNC();
+                        for (int i = l; i < q - 1; i++) {   // (rare; rows move up one by one, every lane a column)
+                            if (tid < NV) L.An[i][tid] = L.An[i + 1][tid];
+                            if (tid == 0) L.A[i] = L.A[i + 1];
+                            WAVE_LDS_SYNC();
+                        }
+#pragma unroll
+                        for (int i = 0; i < NV; i++) if (i >= l && i < q - 1) u[i] = u[i + 1];
                         q--;
                         if (cv > l) cv = l;
                     }
                 }
+                if (tid < NV) L.qx[tid] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; j++) if (tid == j) L.qx[j] = qx[j];
                 L.added = added ? 1 : 0;
-                L.q = q;
-                L.chol_rows = cv;
                 if (!L.feasible) L.stop = 1;
-                else if (!L.added && !excluded[p]) excluded[p] = 1;  // could not make progress on this row
+                else if (!added && !excluded[p]) excluded[p] = 1;  // could not make progress on this row
             }
         }
+        QP_LAP(5)
         __threadfence_block();
         __syncthreads();
+        QP_LAP(6)
         if (L.stop) break;
+    }
+#undef QP_LAP
+    if (tid == 0) {
+        L.q = q; L.chol_rows = cv;
+#pragma unroll
+        for (int i = 0; i < NV; i++) L.u[i] = u[i];
     }
     __syncthreads();
     if (tid == 0)
@@ -536,6 +578,9 @@ __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, S
 // linearisation -- the host form evaluates the accepted point a second time, with identical results -- and the verdict of the
 // current point is always at hand: a solve that takes the full step needs one phase per SQP iteration, and none at the end.
 // `evals` counts what the host form would have evaluated, so both forms report the same numbers.
+// (WPS: one copy per compiled occupancy -- the compiler keeps this function out of line, and a copy shared by both kernel builds would be
+// compiled to the tighter register budget of the two)
+template <int WPS>
 __device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long long viol_fx, int bad, SolveRow* cand,
                                   unsigned char* is_active, unsigned char* excluded, double* x_pub) {
     const int n = a.tb.n, tid = threadIdx.x;
@@ -597,7 +642,7 @@ __device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long lon
             for (int attempt = 0; attempt < 4; attempt++) {
                 if (tid == 0) L.sigma = attempt == 0 ? 0.0 : attempt == 1 ? 0.5 : attempt == 2 ? 0.9 : 0.99;
                 __syncthreads();
-                solve_qp_device(a, L, cand, is_active, excluded);
+                solve_qp_device<WPS>(a, L, cand, is_active, excluded);
                 if (L.feasible) break;
                 __syncthreads();
             }
@@ -652,8 +697,12 @@ __device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long lon
     return next;
 }
 
-template <bool LL, int PPW>
-__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void armour_solve_kernel(const SolveArgs* __restrict__ args) {
+// WPS = waves per SIMD the kernel is compiled for.  2: <= 256 registers, two blocks per CU -- twice the blocks per problem, which is what
+// large batches need (B = 128, O = 20: 9.8 ms against 14.7).  1: 256 VGPRs + AGPRs as spill space, one block per CU -- the leader's QP
+// runs with far fewer spills (sample problem 0.142 -> 0.137 ms, one infeasible world 0.43 -> 0.35 ms, B = 16: 1.0 -> 0.82 ms); chosen
+// while one block per CU leaves a block at most 24 tiles to walk (armour_solve_device_capacity).
+template <bool LL, int PPW, int WPS>
+__global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void armour_solve_kernel(const SolveArgs* __restrict__ args) {
     // The arguments come through device memory, not by value: the struct holds arrays that are indexed at run time (k_range[i]), and a
     // by-value copy of it was materialised in EVERY lane's scratch -- 26 MB of writes per launch (rocprofv3 WRITE_SIZE) and scratch
     // loads in the tile loops.  Read through the pointer, its fields are uniform scalar loads.
@@ -707,7 +756,10 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
         }
         __syncthreads();
         const int cmd = s_cmd;
-        if (cmd == CMD_DONE) break;
+        if (cmd == CMD_DONE) {   // leave the flag word as the next launch expects it (nobody polls it any more: the leader has finished)
+            if (tid == 0) st_coh(&a.blk_word[(size_t)b * a.nb + jb].flag, 0u);
+            break;
+        }
         if (tid < NV) s_x[tid] = tid < n ? ld_coh(&c->x[tid]) : 0.0;   // the phase's point, into LDS: the tile code reads it from there
         __syncthreads();
         // ---- evaluate my tiles at x (the tile code of armour_eval_g_jac)
@@ -760,7 +812,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
             __syncthreads();
         }
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1)] = wall_clock64() - L.t_start;      // barrier passed
-        const int next = leader_step(a, L, b, viol_fx, nbad, cand, is_active, excluded, c->x);
+        const int next = leader_step<WPS>(a, L, b, viol_fx, nbad, cand, is_active, excluded, c->x);
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1) + 1] = wall_clock64() - L.t_start;  // leader step done
         if (tid == 0) {
             wait_my_memory_ops();                          // x is at the memory side ...
@@ -781,14 +833,25 @@ int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torqu
     if (rc != ARMOUR_OK) return rc;
     plan->lp = lp; plan->smem = smem; plan->six = six;
     plan->n_tiles = lp.nbt + lp.nbc + 1;
-    const void* fn = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9> : six ? (const void*)armour_solve_kernel<true, 6> : (const void*)armour_solve_kernel<true, 9>;
-    plan->fn = fn;
-    int per_cu = 0, coop = 0;
+    int coop = 0;
     HIPCHK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device));
     if (!coop) { plan->capacity = 0; return ARMOUR_OK; }
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P2_BLOCK, smem));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
+    // one block per CU (the 512-register build) while that still leaves a block at most 24 tiles to walk; otherwise two per CU
+    const void* fn1 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 1> : six ? (const void*)armour_solve_kernel<true, 6, 1> : (const void*)armour_solve_kernel<true, 9, 1>;
+    const void* fn2 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 2> : six ? (const void*)armour_solve_kernel<true, 6, 2> : (const void*)armour_solve_kernel<true, 9, 2>;
+    static const int wps_env = [] { const char* e = getenv("ARMOUR_SOLVE_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();  // development override
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn1, P2_BLOCK, smem));
+    const int cap1 = per_cu * prop.multiProcessorCount;
+    // (B = 16, O = 20: 16 blocks of 20 tiles per problem in the one-per-CU build: 0.83 ms; 32 blocks of 10 tiles in the other: 1.00 ms -- the
+    //  leader's serial QP weighs more than the tiles; at B = 128 it is the other way round: 14.7 against 9.8 ms)
+    const int blocks1 = cap1 / std::max(1, tb.B);
+    const bool one = wps_env ? wps_env == 1 : (blocks1 >= 1 && (plan->n_tiles + blocks1 - 1) / blocks1 <= 24);
+    const void* fn = one ? fn1 : fn2;
+    plan->fn = fn;
+    if (!one) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P2_BLOCK, smem));
     plan->capacity = per_cu * prop.multiProcessorCount;
     int rate_khz = 0;
     HIPCHK(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device));
