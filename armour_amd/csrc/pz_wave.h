@@ -918,6 +918,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
     WSYNC();
 }
 
+#ifndef PZW_HASH_PRODUCTS  /* the shipped product: sort ALL raw terms.  -DPZW_HASH_PRODUCTS: the hash-classified product of pz_hash.h (experimental, see its header) */
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
 #ifdef H1_FORCE_RA_SAVE  /* root-cause tooling: make this function save its return address on the stack, as the select form does */
@@ -1124,6 +1125,9 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
     WSYNC();
     PROF_CALL_END(N_in)
 }
+#else
+#include "pz_hash.h"
+#endif  // PZW_HASH_PRODUCTS
 
 // Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):
 //     out[c] = sA[c] * a[cA[c]] + sB[c] * a[cB[c]],  c = 0..2.

@@ -68,6 +68,9 @@ def run(name, op, operands, consts=None, reps=5):
     if pr.any():   # -DP1_PROFILE build: where the cycles went (slots of pz_wave.h)
         names = {0: "fill", 1: "sort", 2: "emit", 3: "abs_sum", 15: "rank", 16: "bitonic", 17: "lin-merge", 18: "mul-merge",
                  19: "emit:head", 20: "emit:coef", 21: "emit:run", 22: "emit:prune", 23: "emit:store"}
+        # (hash-classified products re-use the slots: fill = entry, rank = table clear, lin-merge = key loads of pass A, mul-merge = pass A,
+        #  emit:head = operand loads of pass B, emit:coef = pass B, bitonic = pass D, emit:run = sort of the final list, emit:store = pass E,
+        #  emit:prune = centre / radii)
         acc = sum(pr[i] for i in (0, 1, 2, 3))
         inside = pr[8] + pr[9] + pr[10]   # whole-call cycles measured inside the operator function(s)
         print("      " + ", ".join(f"{nm} {pr[i]:.0f}" for i, nm in names.items() if pr[i]) + f" | inside the operator functions {inside:.0f} "
