@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "pz_wave.h"
+#include "pz_tv.h"
 
 using namespace pzw;
 
@@ -69,6 +70,8 @@ struct P1Cfg {
     int fk_items;
     int* retry_list;
     unsigned* retry_count;
+    // time-vectorised build (p1_tv.inc.h): an item is a (problem, group of time steps) pair
+    int tv_groups, tv_lanes, tv_cap;
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -815,6 +818,8 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
     WSYNC();
 }
 
+#include "p1_tv.inc.h"
+
 // One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
 // NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
@@ -1118,6 +1123,7 @@ struct P1Work {
     double* d_torque_radius = nullptr; size_t tr_cap = 0;
     double* d_obstacles = nullptr; size_t obs_cap = 0;
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
+    unsigned char* tv_arena = nullptr; size_t tv_arena_total = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -1132,6 +1138,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
+    if (wk->tv_arena) (void)hipFree(wk->tv_arena);
     if (wk->ev0) (void)hipEventDestroy(wk->ev0);
     if (wk->ev1) (void)hipEventDestroy(wk->ev1);
     delete wk;
@@ -1319,12 +1326,64 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMemsetAsync(h->d_tq_count, 0, (size_t)B * n * T * sizeof(int), h->stream));
         HIPCHK(hipMemsetAsync(wk->d_torque_radius, 0, (size_t)B * n * T * sizeof(double), h->stream));
     }
+    // ---- Time-vectorised build (p1_tv.inc.h): one wave per (problem, group of <= 64 time steps), the symbolic work of an
+    // operator done once per group.  Batches only: a single problem has two groups, i.e. two waves, and is faster step by step
+    // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
+    bool built = false;
+    static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
+    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 160; }();  // below this the per-step kernel is faster (measured)
+    if (h->mode != ARMOUR_MODE_ARMTD && (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= tv_min_groups)) {
+        const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
+        const int capTv = h->lim.work_monomials;
+        const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv);
+        const int caps[2] = {4096, 8192};
+        for (int ci = groups > prop.multiProcessorCount ? 0 : 1; ci < 2 && !built; ci++) {
+            const int cap = caps[ci];
+            const size_t smem = tvchain::tv_lds_bytes(cap);
+            const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / smem)));
+            const int waves = std::min(groups, std::min(512, prop.multiProcessorCount * per_cu));
+            if ((size_t)waves * TL.total > wk->tv_arena_total) {
+                if (wk->tv_arena) (void)hipFree(wk->tv_arena);
+                wk->tv_arena = nullptr; wk->tv_arena_total = 0;
+                if (hipMalloc((void**)&wk->tv_arena, (size_t)waves * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
+                wk->tv_arena_total = (size_t)waves * TL.total;
+            }
+            HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            P1Cfg cf;
+            memset(&cf, 0, sizeof(cf));
+            cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
+            cf.capW = capTv; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+            cf.arena_bytes = TL.total; cf.arena = wk->tv_arena;
+            cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
+            cf.bez = h->d_bez;
+            cf.mode = h->mode; cf.jrs = h->d_jrs;
+            cf.link_count = h->d_link_count; cf.link_center = h->d_link_center; cf.link_indep = h->d_link_indep;
+            cf.link_keys = h->d_link_keys; cf.link_coeff = h->d_link_coeff;
+            cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
+            cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
+            cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
+            cf.n_items = groups; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv;
+            HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
+            HIPCHK(hipEventRecord(wk->ev0, h->stream));
+            hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(wk->ev1, h->stream));
+            HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
+            total_ms += ms;
+            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps, sort cap %d: %d waves (%d per CU, %zu B LDS, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, cap, waves, per_cu, smem, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (st[ST_ERR] == 0) built = true;
+            else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next size
+        }
+    }
     const int kFirstPassCap = 2048;
     const int* d_items = nullptr;
-    int n_items = B * T;
+    int n_items = built ? 0 : B * T;
     // (the second pass costs at least one item's latency, ~4 ms: worth it from about 16 items per CU)
     static const int two_pass_env = [] { const char* e = getenv("ARMOUR_P1_TWO_PASS"); return e ? atoi(e) : 1; }();  // development switch
-    if (two_pass_env && cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
+    if (!built && two_pass_env && cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
         if ((rc = launch(kFirstPassCap, nullptr, B * T, true)) != ARMOUR_OK) return rc;
         if ((rc = other_errors()) != ARMOUR_OK) return rc;
         int nretry = 0;

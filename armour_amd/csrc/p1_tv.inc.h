@@ -1,0 +1,512 @@
+// Time-vectorised reach-set build: one wavefront per (problem, group of <= 64 time steps), lane = time step, on the
+// arithmetic of pz_tv.h.  Included by p1_reach.hip (it shares P1Cfg, the JRS scalars and the host-side launch code).
+// The operator sequence is that of run_rnea / fk_step above -- the reference's RT/Dynamics.cu:69-181, RT/armour_main.cu:96-216
+// -- played by one wave in the order a 1-wave block of the per-step kernel plays it.
+
+namespace tvchain {
+
+using tv::TPZ;
+using tv::TView;
+using tv::TSeg;
+using tv::TW;
+
+constexpr int kTvNV = 32, kTvNS = 12, kTvNM = 2;
+
+__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)cap * 8) + ((size_t)cap * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
+
+struct TLayout {
+    int nJM, nJV, nJS;
+    size_t offV, offS, offM, offJM, offJV, offJS, total;
+    int idV, idS, idM, idJM, idJV, idJS;
+};
+__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW) {
+    TLayout L;
+    L.nJM = (J + 1) + J + 3 + J;  // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia
+    L.nJV = (J + 1) + J;          // trans P_i, link boxes
+    L.nJS = 3 * n + J + 4;        // qd, qda, qdda; mass; 4 raw temps
+    L.offV = 0;
+    L.offS = L.offV + (size_t)kTvNV * tv_slot_bytes(capW, 3);
+    L.offM = L.offS + (size_t)kTvNS * tv_slot_bytes(capW, 1);
+    L.offJM = L.offM + (size_t)kTvNM * tv_slot_bytes(capW, 9);
+    L.offJV = L.offJM + (size_t)L.nJM * tv_slot_bytes(kCapSmall, 9);
+    L.offJS = L.offJV + (size_t)L.nJV * tv_slot_bytes(kCapSmall, 3);
+    L.total = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1));
+    L.idV = 0; L.idS = L.idV + kTvNV; L.idM = L.idS + kTvNS; L.idJM = L.idM + kTvNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
+    return L;
+}
+
+__device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index, int cap, int sz, int id0) {
+    GLB_AS unsigned char* p = base + off + (size_t)index * tv_slot_bytes(cap, sz);
+    TPZ z;
+    z.keys = (GLB_AS uint64_t*)p;
+    z.hdr = (GLB_AS double*)(p + align64((size_t)cap * 8));
+    z.coef = z.hdr + (size_t)4 * sz * 64;
+    z.sz = sz; z.cap = cap; z.id = id0 + index;
+    return z;
+}
+
+struct TChain {
+    TW t;
+    const P1Cfg* cf;
+    GLB_AS unsigned char* arena;
+    TLayout L;
+    unsigned freeV, freeS;
+    int n, J;
+    int capW;
+    __device__ TPZ V(int i) const { return mk_tslot(arena, L.offV, i, capW, 3, L.idV); }
+    __device__ TPZ S(int i) const { return mk_tslot(arena, L.offS, i, capW, 1, L.idS); }
+    __device__ TPZ M(int i) const { return mk_tslot(arena, L.offM, i, capW, 9, L.idM); }
+    __device__ TPZ JM(int i) const { return mk_tslot(arena, L.offJM, i, kCapSmall, 9, L.idJM); }
+    __device__ TPZ JV(int i) const { return mk_tslot(arena, L.offJV, i, kCapSmall, 3, L.idJV); }
+    __device__ TPZ JS(int i) const { return mk_tslot(arena, L.offJS, i, kCapSmall, 1, L.idJS); }
+    __device__ TPZ R(int i) const { return JM(i); }
+    __device__ TPZ Rt(int i) const { return JM(J + 1 + i); }
+    __device__ TPZ rotRaw() const { return JM(2 * J + 1); }
+    __device__ TPZ rotS() const { return JM(2 * J + 2); }
+    __device__ TPZ rpy() const { return JM(2 * J + 3); }
+    __device__ TPZ inertia(int i) const { return JM(2 * J + 4 + i); }
+    __device__ TPZ Ptr(int i) const { return JV(i); }
+    __device__ TPZ linkbox(int i) const { return JV(J + 1 + i); }
+    __device__ TPZ qd(int i) const { return JS(i); }
+    __device__ TPZ qda(int i) const { return JS(n + i); }
+    __device__ TPZ qdda(int i) const { return JS(2 * n + i); }
+    __device__ TPZ mass(int i) const { return JS(3 * n + i); }
+    __device__ TPZ rawS(int i) const { return JS(3 * n + J + i); }
+
+    __device__ TPZ allocV() {
+        const int i = __ffs(freeV) - 1;
+        if (i < 0) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); return V(0); }
+        freeV &= ~(1u << i);
+        return V(i);
+    }
+    __device__ void freeVs(const TPZ& p) { freeV |= 1u << (p.id - L.idV); }
+    __device__ TPZ allocS() {
+        const int i = __ffs(freeS) - 1;
+        if (i < 0) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); return S(0); }
+        freeS &= ~(1u << i);
+        return S(i);
+    }
+
+    __device__ TPZ add(const TPZ& a, const TPZ& b, double sb = 1.0) {
+        TPZ o = allocV();
+        TSeg s[2] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), sb, -1}};
+        tv::lincomb<3, 2, false>(t, o, s);
+        return o;
+    }
+    __device__ TPZ addOneDim(const TPZ& p, const TPZ& a, int r) {
+        TPZ o = allocV();
+        TSeg s[2] = {{tv::view(t, p), 1.0, -1}, {tv::view(t, a), 1.0, r}};
+        tv::lincomb<3, 2, false>(t, o, s);
+        return o;
+    }
+    __device__ TPZ sum3(const TPZ& a, const TPZ& b, const TPZ& c3, int comp_c = -1) {
+        TPZ o = allocV();
+        TSeg s[3] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), 1.0, -1}, {tv::view(t, c3), 1.0, comp_c}};
+        tv::lincomb<3, 3, true>(t, o, s);
+        return o;
+    }
+    __device__ TPZ sum4(const TPZ& a, const TPZ& b, const TPZ& c3, const TPZ& d) {
+        TPZ o = allocV();
+        TSeg s[4] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), 1.0, -1}, {tv::view(t, c3), 1.0, -1}, {tv::view(t, d), 1.0, -1}};
+        tv::lincomb<3, 4, true>(t, o, s);
+        return o;
+    }
+    __device__ TPZ comb3(const TView& a, double sa, const TView& b, double sb, const TView& c3, double sc) {
+        TPZ o = allocS();
+        TSeg s[3] = {{a, sa, -1}, {b, sb, -1}, {c3, sc, -1}};
+        tv::lincomb<1, 3, true>(t, o, s);
+        return o;
+    }
+    __device__ TPZ crossPzMat(const TPZ& a, const double* b) {  // a x b
+        TPZ o = allocV();
+        const double sA[3] = {b[2], b[0], b[1]}, sB[3] = {-b[1], -b[2], -b[0]};
+        const int cA[3] = {1, 2, 0}, cB[3] = {2, 0, 1};
+        tv::cross_const(t, o, tv::view(t, a), sA, cA, sB, cB);
+        return o;
+    }
+    __device__ TPZ crossMatPz(const double* a, const TPZ& b) {  // a x b
+        TPZ o = allocV();
+        const double sA[3] = {a[1], a[2], a[0]}, sB[3] = {-a[2], -a[0], -a[1]};
+        const int cA[3] = {2, 0, 1}, cB[3] = {1, 2, 0};
+        tv::cross_const(t, o, tv::view(t, b), sA, cA, sB, cB);
+        return o;
+    }
+    __device__ TPZ crossPzPz(const TPZ& a, const TPZ& b) {
+        TPZ o = allocV();
+        tv::cross_pzpz(t, o, tv::view(t, a), tv::view(t, b));
+        return o;
+    }
+    __device__ TPZ mulMV(const TPZ& A, const TPZ& v) {
+        TPZ o = allocV();
+        tv::mul<3, 3, 3, 1>(t, o, tv::view(t, A), tv::view(t, v));
+        return o;
+    }
+    __device__ TPZ mulSV(const TPZ& s, const TPZ& v) {
+        TPZ o = allocV();
+        tv::mul<1, 1, 3, 1>(t, o, tv::view(t, s), tv::view(t, v));
+        return o;
+    }
+};
+
+// a raw (unsimplified) small PZ with per-lane coefficients, then simplify() into `out` (RT/PZsparse.cu:120-136,179-205)
+template <int SZ>
+__device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
+    const int lane = c.t.w.lane;
+    for (int e = 0; e < SZ; e++) {
+        tv::st_hdr(raw, tv::H_CEN, e, lane, cen[e]);
+        tv::st_hdr(raw, tv::H_IND, e, lane, 0.0);
+        tv::st_hdr(raw, tv::H_IND2, e, lane, 0.0);
+        tv::st_hdr(raw, tv::H_ASUM, e, lane, 0.0);
+    }
+    for (int i = 0; i < m; i++) {
+        if (lane == 0) raw.keys[i] = keys[i];
+        for (int e = 0; e < SZ; e++) raw.coef[((size_t)i * SZ + e) * 64 + lane] = coefs[i * SZ + e];
+    }
+    if (lane == 0) c.t.w.cnt[raw.id] = m;
+    WSYNC();
+    TSeg s[1] = {{tv::view(c.t, raw), 1.0, -1}};
+    tv::lincomb<SZ, 1, false>(c.t, out, s);
+}
+
+// JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations)
+__device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane) {
+    const P1Cfg& cf = *c.cf;
+    const int n = c.n, J = c.J;
+    const double* bz = cf.bez + (size_t)b * 3 * n;
+    for (int i = 0; i < J; i++) {
+        double rp[9];
+        rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
+        if (i < n && cf.rb.axes[i] != 0) {
+            const JrsScalars js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t_lane);
+            const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
+            double cen[9], co[4 * 9];
+            make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
+            make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
+            make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
+            make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
+            make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
+            const uint64_t keys[4] = {kk, kc, kk, ks};
+            build_simplified<9>(c, c.rotRaw(), c.rotS(), cen, 4, keys, co);
+            tv::set_const(c.t, c.rpy(), rp, nullptr);
+            tv::mul<3, 3, 3, 3>(c.t, c.R(i), tv::view(c.t, c.rpy()), tv::view(c.t, c.rotS()));
+            {
+                const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
+                const double co2[2] = {js.qd_k, js.qd_e};
+                build_simplified<1>(c, c.rawS(0), c.qd(i), &js.qd_c, 2, k2, co2);
+            }
+            {
+                const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
+                const double co2[2] = {js.qd_k, js.qda_e};
+                build_simplified<1>(c, c.rawS(0), c.qda(i), &js.qd_c, 2, k2, co2);
+            }
+            {
+                const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
+                const double co2[2] = {js.qdd_k, js.qdd_e};
+                build_simplified<1>(c, c.rawS(0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+            }
+        } else {
+            tv::set_const(c.t, c.R(i), rp, nullptr);
+        }
+        tv::transpose33(c.t, c.Rt(i), c.R(i));
+        tv::set_const(c.t, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+        {
+            double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
+            double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            tv::set_const(c.t, c.mass(i), &cf.rb.mass[i], zero9, &mi);
+            double ii[9];
+            for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
+            tv::set_const(c.t, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+        }
+        for (int j = 0; j < 3; j++) {
+            const uint64_t key = 1ull << ((j + 2) * n);
+            build_simplified<1>(c, c.rawS(0), c.rawS(1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+        }
+        TSeg s[3] = {{tv::view(c.t, c.rawS(1)), 1.0, 0}, {tv::view(c.t, c.rawS(2)), 1.0, 1}, {tv::view(c.t, c.rawS(3)), 1.0, 2}};
+        tv::lincomb<3, 3, false>(c.t, c.linkbox(i), s);
+    }
+    double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    tv::set_const(c.t, c.R(J), id, nullptr);
+    tv::set_const(c.t, c.Ptr(J), &cf.rb.trans[3 * J], nullptr);
+}
+
+// reduce_link_PZ (RT/PZsparse.cu:370-402) + the final link table entry, per lane.  Which class a monomial belongs to depends
+// on its key alone (wave-uniform); whether a lane HAS the monomial is whether its coefficient vector is non-zero.
+__device__ TV_NOINLINE void emit_link_tv(TChain& c, const TPZ& p, int b, int l, int t_lane) {
+    const P1Cfg& cf = *c.cf;
+    TW& t = c.t;
+    const int lane = t.w.lane;
+    const int n = c.n, cnt = tv::uni(t.w.cnt[p.id]);
+    const uint64_t kmax = 1ull << (2 * n), lmax = 1ull << (5 * n), kmask = kmax - 1;
+    const size_t idx = ((size_t)b * c.J + l) * cf.T + t_lane;
+    double* gens = cf.link_gens + (((size_t)b * cf.T + t_lane) * c.J + l) * 18;
+    double g[18];
+    for (int i = 0; i < 18; i++) g[i] = 0.0;
+    double ra[3] = {0, 0, 0};
+    int nk = 0, ng = 0;
+    for (int m0 = 0; m0 < cnt; m0 += 64) {
+        const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
+        const int nn = min(64, cnt - m0);
+        for (int q = 0; q < nn; q++) {
+            const uint64_t key = tv::readlane_u64(key_v, q);
+            const int m = m0 + q;
+            const double x = p.coef[((size_t)m * 3 + 0) * 64 + lane], y = p.coef[((size_t)m * 3 + 1) * 64 + lane], z = p.coef[((size_t)m * 3 + 2) * 64 + lane];
+            const bool has = t.active && (x != 0.0 || y != 0.0 || z != 0.0);
+            const bool isk = key < kmax;
+            const bool isg = !isk && key < lmax && (key & kmask) == 0;
+            if (has) {
+                if (isk) {
+                    if (nk < cf.capL) {
+                        cf.link_keys[idx * cf.capL + nk] = (uint32_t)key;
+                        cf.link_coeff[(idx * cf.capL + nk) * 3 + 0] = x; cf.link_coeff[(idx * cf.capL + nk) * 3 + 1] = y; cf.link_coeff[(idx * cf.capL + nk) * 3 + 2] = z;
+                    }
+                    nk++;
+                } else if (isg) {
+                    // (register arrays are not indexed by a per-lane value: three explicit generator columns)
+                    if (ng == 0) { g[0] = x; g[6] = y; g[12] = z; }
+                    else if (ng == 1) { g[1] = x; g[7] = y; g[13] = z; }
+                    else if (ng == 2) { g[2] = x; g[8] = y; g[14] = z; }
+                    ng++;
+                } else {
+                    ra[0] += fabs(x); ra[1] += fabs(y); ra[2] += fabs(z);
+                }
+            }
+        }
+    }
+    if (__ballot(t.active && ng > 3) != 0ull) pzw::flag(t.w, pzw::ERR_LINK_GENS);
+    if (__ballot(t.active && nk > cf.capL) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
+    if (t.active) {
+        if (nk > cf.capL) nk = cf.capL;
+        cf.link_count[idx] = nk;
+        for (int e = 0; e < 3; e++) {
+            const double r = p.hdr[((size_t)tv::H_IND * 3 + e) * 64 + lane] + ra[e];
+            cf.link_center[idx * 3 + e] = p.hdr[((size_t)tv::H_CEN * 3 + e) * 64 + lane];
+            cf.link_indep[idx * 3 + e] = r;
+            g[e * 6 + 3 + e] = r;
+        }
+        for (int i = 0; i < 18; i++) gens[i] = g[i];
+    }
+    WSYNC();
+}
+
+struct TFk { TPZ R, Rn, T; };
+
+__device__ TV_NOINLINE void fk_step_tv(TChain& c, TFk& f, int i, int b, int t_lane) {
+    TPZ tp = c.mulMV(f.R, c.Ptr(i));
+    TPZ nt = c.add(f.T, tp);
+    c.freeVs(tp); c.freeVs(f.T);
+    f.T = nt;
+    tv::mul<3, 3, 3, 3>(c.t, f.Rn, tv::view(c.t, f.R), tv::view(c.t, c.R(i)));
+    { TPZ s = f.R; f.R = f.Rn; f.Rn = s; }
+    TPZ l1 = c.mulMV(f.R, c.linkbox(i));
+    TPZ lk = c.add(l1, f.T);
+    emit_link_tv(c, lk, b, i, t_lane);
+    c.freeVs(l1); c.freeVs(lk);
+}
+
+// RT/Dynamics.cu:83-181 with nominal and interval parameters in one pass, and the forward kinematics; same operator order
+// as run_rnea in a 1-wave block.
+__device__ TV_NOINLINE void run_rnea_tv(TChain& c, TPZ* u, int b, int t_lane) {
+    const P1Cfg& cf = *c.cf;
+    TW& t = c.t;
+    const int J = c.J;
+    TFk fk;
+    fk.R = c.M(0); fk.Rn = c.M(1);
+    {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        tv::set_const(t, fk.R, id, nullptr);
+        fk.T = c.allocV();
+        tv::set_const(t, fk.T, nullptr, nullptr);
+    }
+    TPZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV(), lacc = c.allocV();
+    tv::set_const(t, wv, nullptr, nullptr);
+    tv::set_const(t, wdot, nullptr, nullptr);
+    tv::set_const(t, waux, nullptr, nullptr);
+    {
+        double g[3] = {0.0, 0.0, cf.rb.gravity};
+        tv::set_const(t, lacc, g, nullptr);
+    }
+    TPZ F[ARMOUR_MAX_JOINTS], N[ARMOUR_MAX_JOINTS];
+    for (int s = 0; s <= J; s++) {
+        TPZ nl = lacc, nw = wv, nd = wdot, na = waux;
+        if (s < J) {
+            {   // linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
+                const double* tr = &cf.rb.trans[3 * s];
+                TPZ c1 = c.crossPzMat(wdot, tr);
+                TPZ c2 = c.crossPzMat(waux, tr);
+                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
+                nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
+            }
+            {
+                const TPZ Rt = c.Rt(s);
+                const int ax = abs(cf.rb.axes[s]) - 1;
+                nw = c.mulMV(Rt, wv);
+                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
+                na = c.mulMV(Rt, waux);
+                nd = c.mulMV(Rt, wdot);
+                if (cf.rb.axes[s] != 0) {
+                    TPZ zero = c.allocV();
+                    tv::set_const(t, zero, nullptr, nullptr);
+                    TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
+                    TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
+                    TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
+                    TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
+                }
+            }
+        }
+        if (s >= 1) {
+            {   // N = I * wdot + cross(w_aux, I * w)
+                const TPZ I = c.inertia(s - 1);
+                TPZ t1 = c.mulMV(I, wdot);
+                TPZ t2 = c.mulMV(I, wv);
+                TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+                N[s - 1] = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
+            }
+            {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
+                const double* cm = &cf.rb.com[3 * (s - 1)];
+                TPZ c1 = c.crossPzMat(wdot, cm);
+                TPZ c2 = c.crossPzMat(waux, cm);
+                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
+                F[s - 1] = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
+            }
+        }
+        if (s < J) fk_step_tv(c, fk, s, b, t_lane);
+        c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); c.freeVs(lacc);
+        wv = nw; wdot = nd; waux = na; lacc = nl;
+        if (s == J) break;  // (the state of joint J-1 was freed above; nothing new was allocated for s == J)
+    }
+    c.freeVs(fk.T);
+    TPZ nn = c.allocV(), f = c.allocV();
+    tv::set_const(t, nn, nullptr, nullptr);
+    tv::set_const(t, f, nullptr, nullptr);
+    for (int i = J - 1; i >= 0; i--) {
+        const TPZ Rn = c.R(i + 1);
+        TPZ a1 = c.mulMV(Rn, nn);
+        TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], F[i]);
+        TPZ a2 = c.mulMV(Rn, f);
+        TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
+        TPZ n2 = c.sum4(N[i], a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);
+        nn = n2;
+        if (cf.rb.axes[i] != 0) {
+            const int ax = abs(cf.rb.axes[i]) - 1;
+            u[i] = c.comb3(tv::elem(t, n2, ax), 1.0, tv::view(t, c.qdda(i)), cf.rb.armature[i], tv::view(t, c.qd(i)), cf.rb.damping[i]);
+        }
+        TPZ f2 = c.add(a2, F[i]); c.freeVs(f);
+        f = f2;
+        c.freeVs(a2); c.freeVs(c2); c.freeVs(N[i]); c.freeVs(F[i]);
+    }
+    c.freeVs(nn); c.freeVs(f);
+}
+
+// disturbance, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205), per lane; see finish_torque above
+__device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t_lane) {
+    const P1Cfg& cf = *c.cf;
+    TW& t = c.t;
+    const int lane = t.w.lane;
+    const int n = c.n, T = cf.T;
+    const uint64_t kmax = 1ull << (2 * n);
+    Itv rho = {0.0, 0.0};
+    double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
+    for (int j = 0; j < n; j++) {
+        const TPZ& p = u_nom[j];
+        const double pcen = p.hdr[((size_t)tv::H_CEN) * 64 + lane], pind = p.hdr[((size_t)tv::H_IND) * 64 + lane], pind2 = p.hdr[((size_t)tv::H_IND2) * 64 + lane];
+        const double dcen = pcen - pcen;
+        const double rad = pind2 + pind;
+        const double lo = dcen - rad, hi = dcen + rad;
+        rho = iadd(rho, imul(iv(lo, hi), iv(lo, hi)));
+        tr[j] = cf.rb.alpha * (cf.rb.M_max - cf.rb.M_min) * cf.ub.eps + 0.5 * fmax(fabs(lo), fabs(hi));
+        const int cnt = tv::uni(t.w.cnt[p.id]);
+        const size_t idx = ((size_t)b * n + j) * T + t_lane;
+        double ra = 0.0;
+        int nk = 0;
+        for (int m0 = 0; m0 < cnt; m0 += 64) {
+            const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
+            const int nn = min(64, cnt - m0);
+            for (int q = 0; q < nn; q++) {
+                const uint64_t key = tv::readlane_u64(key_v, q);
+                const double x = p.coef[((size_t)(m0 + q)) * 64 + lane];
+                if (t.active && x != 0.0) {
+                    if (key < kmax) {
+                        if (nk < cf.capT) { cf.tq_keys[idx * cf.capT + nk] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + nk] = x; }
+                        nk++;
+                    } else {
+                        ra += fabs(x);
+                    }
+                }
+            }
+        }
+        if (__ballot(t.active && nk > cf.capT) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
+        if (nk > cf.capT) nk = cf.capT;
+        const double ind = pind + ra;
+        if (t.active) { cf.tq_count[idx] = nk; cf.tq_center[idx] = pcen; cf.tq_indep[idx] = ind; }
+        un_ind[j] = ind;
+    }
+    const double rho_hi = up(sqrt(rho.hi));
+    for (int j = 0; j < n; j++) {
+        double v = tr[j];
+        v += 0.5 * rho_hi;
+        v += un_ind[j];
+        v += cf.rb.friction[j];
+        if (t.active) cf.torque_radius[((size_t)b * n + j) * T + t_lane] = v;
+    }
+    WSYNC();
+}
+
+__host__ __device__ inline size_t tv_lds_bytes(int cap) { return (((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15) + kMaxSlots * sizeof(int); }
+
+// grid: one 64-lane block per resident wave, striding over the (problem, time group) items; group g of a problem holds the
+// time steps [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).
+__global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
+    const int groups_per_problem = cf.tv_groups, lanes_per_group = cf.tv_lanes, capTv = cf.tv_cap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TChain c;
+    c.cf = &cf;
+    c.n = cf.n; c.J = cf.J;
+    c.capW = capTv;
+    c.L = make_tlayout(cf.J, cf.n, capTv);
+    c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
+    LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
+    c.t.w.skey = (LDS_AS uint64_t*)lds;
+    c.t.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
+    c.t.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    c.t.w.cnt = (LDS_AS int*)(lds + ((((size_t)cf.capKey * 10 + pzw::ST_WORDS * sizeof(int)) + 15) & ~(size_t)15));
+    c.t.w.cap_raw = cf.capRaw;
+    c.t.w.cap_key = cf.capKey;
+    c.t.w.thr = cf.pr.simplify_threshold;
+    c.t.w.thr_sq = pzw::sq_threshold(c.t.w.thr);
+    c.t.w.lane = threadIdx.x;
+    if (threadIdx.x < pzw::ST_WORDS) c.t.w.lstat[threadIdx.x] = 0;
+    for (int it = blockIdx.x; it < cf.n_items; it += gridDim.x) {
+        const int b = it / groups_per_problem, g = it - b * groups_per_problem;
+        const int t0 = g * lanes_per_group;
+        const int nl = min(lanes_per_group, cf.T - t0);
+        c.t.active = (int)threadIdx.x < nl;
+        const int t_lane = t0 + min((int)threadIdx.x, nl - 1);  // idle lanes shadow the group's last step; they never write
+        c.freeV = 0xffffffffu; c.freeS = (1u << kTvNS) - 1u;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64) c.t.w.cnt[i] = 0;
+        __syncthreads();
+#ifdef TV_PROFILE
+        const long long tvp_start = clock64();
+        c.t.c_sort = c.t.c_walk = c.t.c_cc = c.t.n_raw = c.t.n_calls = c.t.n_emit = 0;
+#endif
+        build_jrs_tv(c, b, t_lane);
+#ifdef TV_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] jrs %lld cycles\n", it, (long long)clock64() - tvp_start);
+#endif
+        TPZ u_nom[ARMOUR_MAX_FACTORS];
+        run_rnea_tv(c, u_nom, b, t_lane);
+        finish_torque_tv(c, u_nom, b, t_lane);
+        __syncthreads();
+#ifdef TV_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] total %lld cycles: sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, (long long)clock64() - tvp_start, c.t.c_sort, c.t.c_walk, c.t.c_cc, c.t.n_calls, c.t.n_raw, c.t.n_emit);
+#endif
+    }
+    if (threadIdx.x == 0) {
+        if (c.t.w.lstat[pzw::ST_ERR]) atomicOr(&cf.status[pzw::ST_ERR], (unsigned)c.t.w.lstat[pzw::ST_ERR]);
+        atomicMax(&cf.status[pzw::ST_MAX_RAW], (unsigned)c.t.w.lstat[pzw::ST_MAX_RAW]);
+        atomicMax(&cf.status[pzw::ST_MAX_OUT], (unsigned)c.t.w.lstat[pzw::ST_MAX_OUT]);
+    }
+}
+
+}  // namespace tvchain

@@ -1,0 +1,703 @@
+// Time-vectorised polynomial-zonotope arithmetic for gfx950: one 64-lane wavefront carries 64 TIME STEPS of one planning
+// problem through the reference's operator sequence at once (lane = time step).
+//
+// Why.  The reference (RT/armour_main.cu:96-216) runs the same operator chain for every time interval; so did rounds 1-2 of
+// this repository, one wavefront per (problem, time step), with the 64 lanes sharing the SYMBOLIC work of one step (sorting
+// raw monomial keys).  But the monomial sets of neighbouring time steps are nearly the same -- measured on the reference's
+// own operator sequence, the union over 64 steps of an operator's result keys is 1.39 x the size of one step's -- while the
+// symbolic work (sort, run detection: ~2000 wave instructions per 64 raw terms) dwarfs the arithmetic.  Here the symbolic
+// work is done ONCE per 64 time steps on the union of the key sets, and the arithmetic runs in the lanes:
+//
+//   * a PZ is {keys u64[cap] (one sorted unique list for all lanes), coef f64[cap][sz][64], and per-lane header rows
+//     centre[sz][64], indep[sz][64], indep2[sz][64], asum[sz][64]} -- every "row" is 64 consecutive doubles, one per time
+//     step, so all arithmetic loads and stores are 512-byte coalesced and no value ever crosses lanes;
+//   * a monomial that time step t does not have (never generated there, or pruned there by simplify()) simply carries
+//     coefficient 0 in lane t.  That reproduces the per-step results EXACTLY: a zero factor makes a raw term 0, adding 0
+//     changes no sum, a sum of zeros is pruned and adds 0 to the radius -- so every lane computes what RT/PZsparse.cu
+//     computes for its time step, with the surviving terms added in the same (generation) order;
+//   * simplify()'s verdict (RT/PZsparse.cu:327-341) is taken per lane; a key stays in the union while ANY lane keeps it;
+//   * asum[e] = sum |coefficient| of entry e, accumulated by the producer in monomial order: the |centre| + sum |coef|
+//     term of the product radius (RT/PZsparse.cu:945-966) is then four row loads instead of a pass over both operands.
+//
+// The sort of the raw keys is pz_wave.h's (sort_terms with its three sorters) on the union key lists; what follows it here
+// is a serial, wave-uniform walk over the sorted raw terms whose loads are software-pipelined U entries ahead.
+#pragma once
+#include "pz_wave.h"
+
+namespace tv {
+
+using pzw::WAVE;
+using pzw::Wave;
+
+#define TV_NOINLINE __attribute__((noinline))
+
+struct TPZ {
+    GLB_AS uint64_t* keys;
+    GLB_AS double* coef;  // [cap][sz][64]
+    GLB_AS double* hdr;   // [4][sz][64]: centre, indep, indep2, asum
+    int sz, cap, id;
+};
+struct TView {
+    const GLB_AS uint64_t* keys;
+    const GLB_AS double* coef;
+    const GLB_AS double* hdr;
+    int cnt, stride, off, sz;  // stride = rows per monomial of the underlying PZ, off = first row of this view, sz = rows of the view
+};
+enum { H_CEN = 0, H_IND = 1, H_IND2 = 2, H_ASUM = 3 };
+
+struct TW {
+    Wave w;        // sort buffers, thresholds, lane, per-wave status, LDS count table (pz_wave.h)
+    bool active;   // this lane's time step exists (t < T)
+#ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
+    long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0;
+#endif
+};
+#ifdef TV_PROFILE
+#define TVP_T0 const long long tvp0__ = clock64();
+#define TVP_T1 const long long tvp1__ = clock64();
+#define TVP_END(t, N, E) { const long long tvp2__ = clock64(); (t).c_sort += tvp1__ - tvp0__; (t).c_walk += tvp2__ - tvp1__; (t).n_raw += (N); (t).n_calls += 1; (t).n_emit += (E); }
+#else
+#define TVP_T0
+#define TVP_T1
+#define TVP_END(t, N, E)
+#endif
+
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint64_t readlane_u64(uint64_t v, int l) {
+    return ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+
+__device__ inline TView view(const TW& t, const TPZ& p) { return TView{p.keys, p.coef, p.hdr, t.w.cnt[p.id], p.sz, 0, p.sz}; }
+__device__ inline TView elem(const TW& t, const TPZ& p, int r) { return TView{p.keys, p.coef, p.hdr, t.w.cnt[p.id], p.sz, r, 1}; }
+__device__ inline pzw::View kview(const TView& v) {  // what the sorters need: keys and count
+    pzw::View k;
+    k.keys = v.keys; k.coef = nullptr; k.cen = nullptr; k.ind = nullptr; k.ind2 = nullptr;
+    k.cnt = v.cnt; k.stride = v.stride; k.off = v.off; k.sz = v.sz;
+    return k;
+}
+// row e of monomial m / of header block `which` of a view, this lane's element
+__device__ inline double ld_coef(const TView& v, int m, int e, int lane) { return v.coef[((size_t)m * v.stride + v.off + e) * WAVE + lane]; }
+__device__ inline double ld_hdr(const TView& v, int which, int e, int lane) { return v.hdr[((size_t)which * v.stride + v.off + e) * WAVE + lane]; }
+__device__ inline void st_hdr(const TPZ& p, int which, int e, int lane, double x) { p.hdr[((size_t)which * p.sz + e) * WAVE + lane] = x; }
+
+// Result writer: keys by lane 0, coefficient rows by every lane (0 where the lane pruned the term), asum on the way.
+template <int SZ>
+struct Out {
+    GLB_AS uint64_t* keys;
+    GLB_AS double* coef;
+    int cap, n, lane;
+    double asum[SZ];
+    __device__ inline void init(const TPZ& o, int lane_) {
+        keys = o.keys; coef = o.coef; cap = uni(o.cap); n = 0; lane = lane_;
+#pragma unroll
+        for (int e = 0; e < SZ; e++) asum[e] = 0.0;
+    }
+    __device__ inline void emit(uint64_t key, const double* v) {
+        if (n < cap) {
+            if (lane == 0) keys[n] = key;
+#pragma unroll
+            for (int e = 0; e < SZ; e++) coef[((size_t)n * SZ + e) * WAVE + lane] = v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < SZ; e++) asum[e] += fabs(v[e]);
+        n++;
+    }
+    __device__ inline void finish(TW& t, const TPZ& o) {
+        if (n > cap) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); n = cap; }
+#pragma unroll
+        for (int e = 0; e < SZ; e++) st_hdr(o, H_ASUM, e, lane, asum[e]);
+        if (lane == 0) {
+            t.w.cnt[o.id] = n;
+            if (n > t.w.lstat[pzw::ST_MAX_OUT]) t.w.lstat[pzw::ST_MAX_OUT] = n;
+        }
+        WSYNC();
+    }
+};
+
+// simplify()'s verdict on one finished sum, per lane (RT/PZsparse.cu:327-341): a pruned term goes to the lane's radius and
+// its coefficient becomes 0.  Returns whether this lane keeps the term.
+template <int SZ>
+__device__ inline bool verdict(double thr, double thr_sq, bool active, double* acc, double* rad) {
+    bool small;
+    if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
+    else {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+        small = s <= thr_sq;
+    }
+    if (small || !active) {
+#pragma unroll
+        for (int e = 0; e < SZ; e++) { rad[e] += fabs(acc[e]); acc[e] = 0.0; }
+        return false;
+    }
+    return true;
+}
+
+// The serial walk over N raw terms sorted by (key, generation index).  `keyat(p)` = key of the p-th sorted term (LDS),
+// `idxat(p)` = its generation index; `P` supplies
+//     struct Regs;  void load(int idx, Regs&)   -- issue the row loads of one raw term (idx is wave-uniform)
+//     void add(const Regs&, bool first)          -- accumulate it (first: start a new sum)
+//     void close(uint64_t key)                   -- the run of equal keys is complete: verdict + emit
+// Loads run U terms ahead of their use.
+template <int U, class P, class KeyAt, class IdxAt>
+__device__ inline void walk_sorted(int lane, int N, const KeyAt& keyat, const IdxAt& idxat, P& pol) {
+    bool have = false;
+    uint64_t cur = 0;
+    for (int base = 0; base < N; base += WAVE) {
+        const int p = base + lane;
+        const uint64_t key_v = p < N ? keyat(p) : 0ull;
+        const int idx_v = p < N ? idxat(p) : 0;
+        const int n = min(WAVE, N - base);
+        for (int l0 = 0; l0 < n; l0 += U) {
+            typename P::Regs regs[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int l = min(l0 + u, n - 1);
+                pol.load(__builtin_amdgcn_readlane(idx_v, l), regs[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (l0 + u < n) {
+                    const uint64_t key = readlane_u64(key_v, l0 + u);
+                    if (have && key != cur) { pol.close(cur); have = false; }
+                    pol.add(regs[u], !have);
+                    have = true; cur = key;
+                }
+            }
+        }
+    }
+    if (have) pol.close(cur);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// product (RT/PZsparse.cu:864-994), shapes as in pz_wave.h
+template <class SH>
+struct MulCtx {
+    TView a, b;
+    int lane, mb1;
+    unsigned long long mb1_magic;
+    double thr, thr_sq;
+    bool active;
+    Out<SH::SZ>* o;
+    double acc[SH::SZ], rad[SH::SZ];
+    struct Regs { double ca[SH::ASZ], cb[SH::BSZ]; };
+    __device__ inline void load(int idx, Regs& r) const {
+        const int t = idx + 1;
+        const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
+        if (i) {
+            const GLB_AS double* pa = a.coef + ((size_t)(i - 1) * a.stride + a.off) * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
+        } else {
+            const GLB_AS double* pa = a.hdr + (size_t)a.off * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
+        }
+        if (j) {
+            const GLB_AS double* pb = b.coef + ((size_t)(j - 1) * b.stride + b.off) * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
+        } else {
+            const GLB_AS double* pb = b.hdr + (size_t)b.off * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
+        }
+    }
+    __device__ inline void add(const Regs& r, bool first) {
+        double c[SH::SZ];
+        SH::mul(r.ca, r.cb, c);
+#pragma unroll
+        for (int e = 0; e < SH::SZ; e++) acc[e] = first ? c[e] : acc[e] + c[e];
+    }
+    __device__ inline void close(uint64_t key) {
+        const bool keep = verdict<SH::SZ>(thr, thr_sq, active, acc, rad);
+        if (__ballot(keep) != 0ull) o->emit(key, acc);
+    }
+};
+
+template <int AR, int AC, int BR, int BC>
+__device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
+    typedef pzw::MulShape<AR, AC, BR, BC> SH;
+    constexpr int SZ = SH::SZ;
+    const int lane = t.w.lane;
+    TView a = a_, b = b_;
+    a.cnt = uni(a.cnt); b.cnt = uni(b.cnt);
+    int N = (a.cnt + 1) * (b.cnt + 1) - 1;
+    // per-lane centre and radii (RT/PZsparse.cu:868,944-989)
+    double ca[SH::ASZ], cb[SH::BSZ], ia[SH::ASZ], ib[SH::BSZ], ia2[SH::ASZ], ib2[SH::BSZ], r2[SH::ASZ], r3[SH::BSZ];
+#pragma unroll
+    for (int e = 0; e < SH::ASZ; e++) {
+        ca[e] = ld_hdr(a, H_CEN, e, lane); ia[e] = ld_hdr(a, H_IND, e, lane); ia2[e] = ld_hdr(a, H_IND2, e, lane);
+        r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < SH::BSZ; e++) {
+        cb[e] = ld_hdr(b, H_CEN, e, lane); ib[e] = ld_hdr(b, H_IND, e, lane); ib2[e] = ld_hdr(b, H_IND2, e, lane);
+        r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, lane);
+    }
+    double t2[SZ], t3[SZ], ii[SZ], cen[SZ], base[SZ], base2[SZ];
+    SH::mul(r2, ib, t2);
+    SH::mul(ia, r3, t3);
+    SH::mul(ia, ib, ii);
+    SH::mul(ca, cb, cen);
+#pragma unroll
+    for (int e = 0; e < SZ; e++) base[e] = ii[e] + (t2[e] + t3[e]);
+    SH::mul(r2, ib2, t2);
+    SH::mul(ia2, r3, t3);
+    SH::mul(ia2, ib2, ii);
+#pragma unroll
+    for (int e = 0; e < SZ; e++) base2[e] = ii[e] + (t2[e] + t3[e]);
+    WSYNC();
+
+    Out<SZ> o;
+    o.init(out, lane);
+    MulCtx<SH> cx;
+    cx.a = a; cx.b = b; cx.lane = lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) { cx.acc[e] = 0.0; cx.rad[e] = 0.0; }
+    if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
+    if (a.cnt == 0) {
+        // constant left operand (mass, inertia, the fixed rpy rotation): b's keys in b's order, no sort
+        for (int m0 = 0; m0 < b.cnt; m0 += WAVE) {
+            const uint64_t key_v = m0 + lane < b.cnt ? b.keys[m0 + lane] : 0ull;
+            const int n = min(WAVE, b.cnt - m0);
+            for (int l0 = 0; l0 < n; l0 += 4) {
+                typename MulCtx<SH>::Regs regs[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (l0 + u < n) { cx.add(regs[u], true); cx.close(readlane_u64(key_v, l0 + u)); }
+            }
+        }
+    } else {
+        constexpr int kU = (SH::ASZ + SH::BSZ > 12) ? 2 : 4;  // terms whose row loads are in flight together
+        pzw::MulEval<SH> ev;
+        ev.a = kview(a); ev.set_b(kview(b));
+        bool indirect = false;
+        TVP_T0
+        N = pzw::sort_terms(t.w, N, ev, indirect);
+        TVP_T1
+        const Wave& w = t.w;
+        if (indirect) walk_sorted<kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+        else walk_sorted<kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+        TVP_END(t, N, o.n)
+    }
+#pragma unroll
+    for (int e = 0; e < SZ; e++) {
+        st_hdr(out, H_CEN, e, lane, cen[e]);
+        st_hdr(out, H_IND, e, lane, base[e] + cx.rad[e]);
+        st_hdr(out, H_IND2, e, lane, base2[e] + cx.rad[e]);
+    }
+    o.finish(t, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cross(a, b) of 3x1 operands (RT/PZsparse.cu:1134-1151) with the three simplify() stages of the composition, per lane
+struct CrossCtx {
+    TView a, b;
+    int lane, mb1;
+    unsigned long long mb1_magic;
+    double thr, thr_sq;
+    bool active;
+    Out<3>* o;
+    double acc[6], rad[12];  // radii: 6 products | 3 differences | 3 stack
+    struct Regs { double ca[3], cb[3]; };
+    __device__ inline void load(int idx, Regs& r) const {
+        const int t = idx + 1;
+        const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
+        const GLB_AS double* pa = (i ? a.coef + (size_t)(i - 1) * 3 * WAVE : a.hdr) + lane;
+        const GLB_AS double* pb = (j ? b.coef + (size_t)(j - 1) * 3 * WAVE : b.hdr) + lane;
+#pragma unroll
+        for (int e = 0; e < 3; e++) { r.ca[e] = pa[e * WAVE]; r.cb[e] = pb[e * WAVE]; }
+    }
+    __device__ inline void add(const Regs& r, bool first) {
+        double p6[6];
+        p6[0] = r.ca[1] * r.cb[2]; p6[1] = r.ca[2] * r.cb[1];
+        p6[2] = r.ca[2] * r.cb[0]; p6[3] = r.ca[0] * r.cb[2];
+        p6[4] = r.ca[0] * r.cb[1]; p6[5] = r.ca[1] * r.cb[0];
+#pragma unroll
+        for (int e = 0; e < 6; e++) acc[e] = first ? p6[e] : acc[e] + p6[e];
+    }
+    __device__ inline void close(uint64_t key) {
+        double u[3] = {0.0, 0.0, 0.0};
+        bool anyc = false, keep = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double v0 = acc[2 * c], v1 = acc[2 * c + 1];
+            const bool h0 = !(fabs(v0) <= thr), h1 = !(fabs(v1) <= thr);
+            if (!h0) rad[2 * c] += fabs(v0);
+            if (!h1) rad[2 * c + 1] += fabs(v1);
+            if (h0 || h1) {
+                double wv = h0 ? 1.0 * v0 : -1.0 * v1;
+                if (h0 && h1) wv += -1.0 * v1;
+                if (fabs(wv) <= thr) rad[6 + c] += fabs(wv);
+                else { u[c] = wv; anyc = true; }
+            }
+        }
+        if (anyc) {
+            const double s = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+            keep = !(s <= thr_sq) && active;
+            if (!keep) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) { rad[9 + c] += fabs(u[c]); u[c] = 0.0; }
+            }
+        }
+        if (__ballot(keep) != 0ull) o->emit(key, u);
+    }
+};
+
+__device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
+    typedef pzw::MulShape<1, 1, 1, 1> SH;
+    const int lane = t.w.lane;
+    TView a = a_, b = b_;
+    a.cnt = uni(a.cnt); b.cnt = uni(b.cnt);
+    int N = (a.cnt + 1) * (b.cnt + 1) - 1;
+    double cenP[6], baseP[6], base2P[6];
+    {
+        double ca[3], cb[3], ia[3], ib[3], ia2[3], ib2[3], r2[3], r3[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            ca[e] = ld_hdr(a, H_CEN, e, lane); ia[e] = ld_hdr(a, H_IND, e, lane); ia2[e] = ld_hdr(a, H_IND2, e, lane);
+            r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, lane);
+            cb[e] = ld_hdr(b, H_CEN, e, lane); ib[e] = ld_hdr(b, H_IND, e, lane); ib2[e] = ld_hdr(b, H_IND2, e, lane);
+            r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, lane);
+        }
+        const int ia_[6] = {1, 2, 2, 0, 0, 1}, ib_[6] = {2, 1, 0, 2, 1, 0};
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            const int i = ia_[e], j = ib_[e];
+            cenP[e] = ca[i] * cb[j];
+            baseP[e] = ia[i] * ib[j] + (r2[i] * ib[j] + ia[i] * r3[j]);
+            base2P[e] = ia2[i] * ib2[j] + (r2[i] * ib2[j] + ia2[i] * r3[j]);
+        }
+    }
+    WSYNC();
+    Out<3> o;
+    o.init(out, lane);
+    CrossCtx cx;
+    cx.a = a; cx.b = b; cx.lane = lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
+#pragma unroll
+    for (int e = 0; e < 6; e++) cx.acc[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
+    if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
+    pzw::MulEval<SH> ev;
+    ev.a = kview(a); ev.set_b(kview(b));
+    ev.a.stride = 1; ev.a.off = 0; ev.b.stride = 1; ev.b.off = 0;
+    bool indirect = false;
+    TVP_T0
+    N = pzw::sort_terms(t.w, N, ev, indirect);
+    TVP_T1
+    const Wave& w = t.w;
+    if (indirect) walk_sorted<4>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<4>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    TVP_END(t, N, o.n)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double i0 = baseP[2 * c] + cx.rad[2 * c], i1 = baseP[2 * c + 1] + cx.rad[2 * c + 1];
+        const double j0 = base2P[2 * c] + cx.rad[2 * c], j1 = base2P[2 * c + 1] + cx.rad[2 * c + 1];
+        const double ir = (i0 * 1.0 + i1 * 1.0) + cx.rad[6 + c], jr = (j0 * 1.0 + j1 * 1.0) + cx.rad[6 + c];
+        st_hdr(out, H_CEN, c, lane, 0.0 + (1.0 * cenP[2 * c] + -1.0 * cenP[2 * c + 1]));
+        st_hdr(out, H_IND, c, lane, (0.0 + ir) + cx.rad[9 + c]);
+        st_hdr(out, H_IND2, c, lane, (0.0 + jr) + cx.rad[9 + c]);
+    }
+    o.finish(t, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sums: out = ((s0*x0 + s1*x1) + s2*x2) + ..., simplify() after every `+` when CHAIN, once at the end otherwise
+// (RT/PZsparse.cu:743-834,996-1030,1068-1116; the staging is described in pz_wave.h above lincomb_chain).
+struct TSeg {
+    TView v;
+    double scale;
+    int comp;  // -1: same shape as the result; otherwise a 1x1 source embedded into entry `comp`
+};
+
+template <int SZ, int NS, bool CHAIN>
+struct LinCtx {
+    TSeg s[NS];
+    int off[NS + 1];
+    int lane;
+    double thr, thr_sq;
+    bool active;
+    Out<SZ>* o;
+    double acc[SZ], ra[NS][SZ];
+    bool present;   // per lane
+    int last;       // source of the run's latest member (wave-uniform)
+    struct Regs { double c[SZ]; int k; };
+    __device__ inline int seg_of(int idx) const {
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < NS; i++) k += (idx >= off[i]) ? 1 : 0;
+        return k;
+    }
+    __device__ inline void load(int idx, Regs& r) const {
+        const int k = seg_of(idx);
+        r.k = k;
+#pragma unroll
+        for (int e = 0; e < SZ; e++) r.c[e] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            if (q == k) {
+                const TView& v = s[q].v;
+                const GLB_AS double* src = v.coef + ((size_t)(idx - off[q]) * v.stride + v.off) * WAVE + lane;
+                if (s[q].comp < 0) {
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) r.c[e] = s[q].scale * src[e * WAVE];
+                } else {
+                    const double x = s[q].scale * src[0];
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) r.c[e] = (e == s[q].comp) ? x : 0.0;
+                }
+            }
+        }
+    }
+    // simplify() of stage k (k >= 1) on what has been accumulated so far
+    __device__ inline void stage(int k) {
+        if (present) {
+            bool small;
+            if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
+            else {
+                double q = 0.0;
+#pragma unroll
+                for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
+                small = q <= thr_sq;
+            }
+            if (small) {
+#pragma unroll
+                for (int kk = 1; kk < NS; kk++)
+                    if (kk == k) {
+#pragma unroll
+                        for (int e = 0; e < SZ; e++) ra[kk][e] += fabs(acc[e]);
+                    }
+                present = false;
+            }
+        }
+    }
+    __device__ inline void add(const Regs& r, bool first) {
+        if (first) { present = false; last = -1; }
+        if constexpr (CHAIN) {
+            for (int k = max(last + 1, 1); k < r.k; k++) stage(k);  // stages without a member of this key
+        }
+#pragma unroll
+        for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + r.c[e] : r.c[e];
+        present = true;
+        if constexpr (CHAIN) { if (r.k >= 1) stage(r.k); }
+        last = r.k;
+    }
+    __device__ inline void close(uint64_t key) {
+        if constexpr (CHAIN) {
+            for (int k = max(last + 1, 1); k < NS; k++) stage(k);
+        } else {
+            // one simplify() at the end: pruned terms go to ra[0]
+            if (present) {
+                bool small;
+                if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
+                else {
+                    double q = 0.0;
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
+                    small = q <= thr_sq;
+                }
+                if (small) {
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) ra[0][e] += fabs(acc[e]);
+                    present = false;
+                }
+            }
+        }
+        const bool keep = present && active;
+        double v[SZ];
+#pragma unroll
+        for (int e = 0; e < SZ; e++) v[e] = keep ? acc[e] : 0.0;
+        if (__ballot(keep) != 0ull) o->emit(key, v);
+    }
+};
+
+template <int SZ, int NS, bool CHAIN>
+__device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
+    const int lane = t.w.lane;
+    LinCtx<SZ, NS, CHAIN> cx;
+    pzw::LinEval<SZ, NS> ev;
+    int N = 0;
+    double cen[SZ], indk[NS][SZ], ind2k[NS][SZ];
+#pragma unroll
+    for (int e = 0; e < SZ; e++) cen[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        cx.s[k] = segs[k];
+        cx.s[k].v.cnt = uni(cx.s[k].v.cnt);
+        ev.s[k].v = kview(cx.s[k].v); ev.s[k].scale = segs[k].scale; ev.s[k].comp = segs[k].comp;
+        cx.off[k] = N; ev.off[k] = N;
+        N += cx.s[k].v.cnt;
+        const TView& v = cx.s[k].v;
+        const double sc = segs[k].scale, asc = fabs(sc);
+#pragma unroll
+        for (int e = 0; e < SZ; e++) { indk[k][e] = 0.0; ind2k[k][e] = 0.0; }
+        if (segs[k].comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) {
+                const double c = sc * ld_hdr(v, H_CEN, e, lane);
+                cen[e] = (k == 0) ? c : cen[e] + c;
+                indk[k][e] = ld_hdr(v, H_IND, e, lane) * asc; ind2k[k][e] = ld_hdr(v, H_IND2, e, lane) * asc;
+            }
+        } else {
+            const double c = sc * ld_hdr(v, H_CEN, 0, lane), i1 = ld_hdr(v, H_IND, 0, lane) * asc, i2 = ld_hdr(v, H_IND2, 0, lane) * asc;
+#pragma unroll
+            for (int e = 0; e < SZ; e++)
+                if (e == segs[k].comp) { cen[e] = cen[e] + c; indk[k][e] = i1; ind2k[k][e] = i2; }
+        }
+    }
+    cx.off[NS] = N; ev.off[NS] = N;
+    WSYNC();  // every lane has read the sources' header rows before `out` (possibly one of them) is written
+    Out<SZ> o;
+    o.init(out, lane);
+    cx.lane = lane; cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
+    cx.present = false; cx.last = -1;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) cx.acc[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < SZ; e++) cx.ra[k][e] = 0.0;
+    bool indirect = false;
+    TVP_T0
+    N = pzw::sort_terms(t.w, N, ev, indirect);
+    TVP_T1
+    const Wave& w = t.w;
+    if (indirect) walk_sorted<4>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<4>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    TVP_END(t, N, o.n)
+#pragma unroll
+    for (int e = 0; e < SZ; e++) {
+        double r, r2;
+        if constexpr (CHAIN) {
+            // stage 1: (i0 + i1) + pruned; stage k: (previous + ik) + pruned
+            r = indk[0][e]; r2 = ind2k[0][e];
+#pragma unroll
+            for (int k = 1; k < NS; k++) { r = (r + indk[k][e]) + cx.ra[k][e]; r2 = (r2 + ind2k[k][e]) + cx.ra[k][e]; }
+        } else {
+            r = indk[0][e]; r2 = ind2k[0][e];
+#pragma unroll
+            for (int k = 1; k < NS; k++) { r = r + indk[k][e]; r2 = r2 + ind2k[k][e]; }
+            r = r + cx.ra[0][e]; r2 = r2 + cx.ra[0][e];
+        }
+        st_hdr(out, H_CEN, e, lane, cen[e]);
+        st_hdr(out, H_IND, e, lane, r);
+        st_hdr(out, H_IND2, e, lane, r2);
+    }
+    o.finish(t, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cross of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167): out[c] = sA[c]*a[cA[c]] +
+// sB[c]*a[cB[c]]; the key list is a's, so one ordered pass (see pz_wave.h cross_const for the two simplify() stages)
+__device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
+    const int lane = t.w.lane;
+    TView a = a_;
+    a.cnt = uni(a.cnt);
+    const double thr = t.w.thr, thr_sq = t.w.thr_sq;
+    const bool active = t.active;
+    double x0[3], cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
+    double i0[3], j0[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { x0[c] = ld_hdr(a, H_CEN, c, lane); i0[c] = ld_hdr(a, H_IND, c, lane); j0[c] = ld_hdr(a, H_IND2, c, lane); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double xa = 0, xb = 0, ia = 0, ib = 0, ja = 0, jb = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q == cA[c]) { xa = x0[q]; ia = i0[q]; ja = j0[q]; }
+            if (q == cB[c]) { xb = x0[q]; ib = i0[q]; jb = j0[q]; }
+        }
+        cen[c] = sA[c] * xa + sB[c] * xb;
+        ind[c] = ia * fabs(sA[c]) + ib * fabs(sB[c]);
+        ind2[c] = ja * fabs(sA[c]) + jb * fabs(sB[c]);
+    }
+    WSYNC();
+    Out<3> o;
+    o.init(out, lane);
+#ifdef TV_PROFILE
+    const long long cc0__ = clock64();
+#endif
+    for (int m0 = 0; m0 < a.cnt; m0 += WAVE) {
+        const uint64_t key_v = m0 + lane < a.cnt ? a.keys[m0 + lane] : 0ull;
+        const int n = min(WAVE, a.cnt - m0);
+        for (int l0 = 0; l0 < n; l0 += 4) {
+            double x[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = m0 + min(l0 + u, n - 1);
+#pragma unroll
+                for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, m, q, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (l0 + u < n) {
+                    double r[3];
+                    bool anyc = false, keep = false;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        double xa = 0, xb = 0;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { if (q == cA[c]) xa = x[u][q]; if (q == cB[c]) xb = x[u][q]; }
+                        double v = sA[c] * xa;
+                        v += sB[c] * xb;
+                        if (fabs(v) <= thr) { ra1[c] += fabs(v); v = 0.0; } else anyc = true;
+                        r[c] = v;
+                    }
+                    if (anyc) {
+                        keep = !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
+                        if (!keep) { ra2[0] += fabs(r[0]); ra2[1] += fabs(r[1]); ra2[2] += fabs(r[2]); r[0] = r[1] = r[2] = 0.0; }
+                    }
+                    if (__ballot(keep) != 0ull) o.emit(readlane_u64(key_v, l0 + u), r);
+                }
+            }
+        }
+    }
+#ifdef TV_PROFILE
+    t.c_cc += clock64() - cc0__;
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        st_hdr(out, H_CEN, c, lane, cen[c]);
+        st_hdr(out, H_IND, c, lane, (ind[c] + ra1[c]) + ra2[c]);
+        st_hdr(out, H_IND2, c, lane, (ind2[c] + ra1[c]) + ra2[c]);
+    }
+    o.finish(t, out);
+}
+
+// out = a^T for 3x3 (RT/PZsparse.cu:1050-1066): keys unchanged, no simplify
+__device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
+    const int lane = t.w.lane;
+    const int n = uni(t.w.cnt[a.id]);
+    for (int m = 0; m < n; m++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) out.coef[((size_t)m * 9 + (e % 3) * 3 + e / 3) * WAVE + lane] = a.coef[((size_t)m * 9 + e) * WAVE + lane];
+    for (int m = lane; m < n; m += WAVE) out.keys[m] = a.keys[m];
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) out.hdr[((size_t)h * 9 + (e % 3) * 3 + e / 3) * WAVE + lane] = a.hdr[((size_t)h * 9 + e) * WAVE + lane];
+    if (lane == 0) t.w.cnt[out.id] = n;
+    WSYNC();
+}
+
+// constant PZ: the same centre / radii in every lane (RT/PZsparse.cu:66-98); ind2 == nullptr: equal to ind
+__device__ TV_NOINLINE void set_const(TW& t, const TPZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
+    const int lane = t.w.lane;
+    for (int e = 0; e < out.sz; e++) {
+        st_hdr(out, H_CEN, e, lane, cen ? cen[e] : 0.0);
+        st_hdr(out, H_IND, e, lane, ind ? ind[e] : 0.0);
+        st_hdr(out, H_IND2, e, lane, ind2 ? ind2[e] : (ind ? ind[e] : 0.0));
+        st_hdr(out, H_ASUM, e, lane, 0.0);
+    }
+    if (lane == 0) t.w.cnt[out.id] = 0;
+    WSYNC();
+}
+
+}  // namespace tv

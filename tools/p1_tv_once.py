@@ -1,0 +1,8 @@
+import sys; sys.path.insert(0,'.')
+from armour_amd.planner import ArmourNLP
+from armour_amd.worlds import random_batch
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+pb = random_batch(0, B, 20)
+nlp = ArmourNLP(T=100)
+nlp.set_parameters(pb['q0'], pb['qd0'], pb['qdd0'], pb['q_des'], pb['obstacles'])
+print("B", B, "build ms", nlp.build_ms)
