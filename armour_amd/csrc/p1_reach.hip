@@ -71,7 +71,7 @@ struct P1Cfg {
     int* retry_list;
     unsigned* retry_count;
     // time-vectorised build (p1_tv.inc.h): an item is a (problem, group of time steps) pair
-    int tv_groups, tv_lanes, tv_cap;
+    int tv_groups, tv_lanes, tv_cap, tv_stage_rows;
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -1339,8 +1339,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int caps[2] = {4096, 8192};
         for (int ci = groups > prop.multiProcessorCount ? 0 : 1; ci < 2 && !built; ci++) {
             const int cap = caps[ci];
-            const size_t smem = tvchain::tv_lds_bytes(cap);
-            const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / smem)));
+            // staging area for the short operand of a product: what is left of the CU's LDS at the wave count the sort buffers allow
+            const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / (tvchain::tv_lds_fixed(cap) + 24 * 1024))));
+            const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - tvchain::tv_lds_fixed(cap) - 256) / 512);
+            const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows);
             const int waves = std::min(groups, std::min(512, prop.multiProcessorCount * per_cu));
             if ((size_t)waves * TL.total > wk->tv_arena_total) {
                 if (wk->tv_arena) (void)hipFree(wk->tv_arena);
@@ -1362,7 +1364,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-            cf.n_items = groups; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv;
+            cf.n_items = groups; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);

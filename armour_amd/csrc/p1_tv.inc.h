@@ -453,7 +453,9 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
     WSYNC();
 }
 
-__host__ __device__ inline size_t tv_lds_bytes(int cap) { return (((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15) + kMaxSlots * sizeof(int); }
+// LDS of one wave: sort buffers | status | count table | staging rows for a product's short operand
+__host__ __device__ inline size_t tv_lds_fixed(int cap) { return (((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15) + kMaxSlots * sizeof(int); }
+__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 
 // grid: one 64-lane block per resident wave, striding over the (problem, time group) items; group g of a problem holds the
 // time steps [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).
@@ -471,6 +473,8 @@ __global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
     c.t.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
     c.t.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
     c.t.w.cnt = (LDS_AS int*)(lds + ((((size_t)cf.capKey * 10 + pzw::ST_WORDS * sizeof(int)) + 15) & ~(size_t)15));
+    c.t.stage = (LDS_AS double*)(lds + tv_lds_fixed(cf.capKey));
+    c.t.stage_rows = cf.tv_stage_rows;
     c.t.w.cap_raw = cf.capRaw;
     c.t.w.cap_key = cf.capKey;
     c.t.w.thr = cf.pr.simplify_threshold;
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
         c.t.c_sort = c.t.c_walk = c.t.c_cc = c.t.n_raw = c.t.n_calls = c.t.n_emit = 0;
+        for (int q = 0; q < 3; q++) { c.t.c_type[q] = 0; c.t.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane);
 #ifdef TV_PROFILE
@@ -499,6 +504,8 @@ __global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
         finish_torque_tv(c, u_nom, b, t_lane);
         __syncthreads();
 #ifdef TV_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.t.c_type[0], c.t.n_type[0], c.t.c_type[1], c.t.n_type[1], c.t.c_type[2], c.t.n_type[2]);
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] total %lld cycles: sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, (long long)clock64() - tvp_start, c.t.c_sort, c.t.c_walk, c.t.c_cc, c.t.n_calls, c.t.n_raw, c.t.n_emit);
 #endif
     }

@@ -34,7 +34,7 @@ using pzw::Wave;
 struct TPZ {
     GLB_AS uint64_t* keys;
     GLB_AS double* coef;  // [cap][sz][64]
-    GLB_AS double* hdr;   // [4][sz][64]: centre, indep, indep2, asum
+    GLB_AS double* hdr;   // [4][sz][64]: indep, indep2, asum, centre
     int sz, cap, id;
 };
 struct TView {
@@ -43,23 +43,26 @@ struct TView {
     const GLB_AS double* hdr;
     int cnt, stride, off, sz;  // stride = rows per monomial of the underlying PZ, off = first row of this view, sz = rows of the view
 };
-enum { H_CEN = 0, H_IND = 1, H_IND2 = 2, H_ASUM = 3 };
+enum { H_IND = 0, H_IND2 = 1, H_ASUM = 2, H_CEN = 3 };  // the centre rows come LAST, i.e. directly before the coefficient rows: the centre is "monomial -1" (no branch in the row loads)
 
 struct TW {
     Wave w;        // sort buffers, thresholds, lane, per-wave status, LDS count table (pz_wave.h)
     bool active;   // this lane's time step exists (t < T)
+    LDS_AS double* stage;  // LDS staging area for the rows of a product's SHORT operand (stage_rows below)
+    int stage_rows;        // its capacity in rows of 64 doubles
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
     long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0;
+    long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
 #endif
 };
 #ifdef TV_PROFILE
 #define TVP_T0 const long long tvp0__ = clock64();
 #define TVP_T1 const long long tvp1__ = clock64();
-#define TVP_END(t, N, E) { const long long tvp2__ = clock64(); (t).c_sort += tvp1__ - tvp0__; (t).c_walk += tvp2__ - tvp1__; (t).n_raw += (N); (t).n_calls += 1; (t).n_emit += (E); }
+#define TVP_END(t, N, E, TY) { const long long tvp2__ = clock64(); (t).c_sort += tvp1__ - tvp0__; (t).c_walk += tvp2__ - tvp1__; (t).n_raw += (N); (t).n_calls += 1; (t).n_emit += (E); (t).c_type[TY] += tvp2__ - tvp1__; (t).n_type[TY] += (N); }
 #else
 #define TVP_T0
 #define TVP_T1
-#define TVP_END(t, N, E)
+#define TVP_END(t, N, E, TY)
 #endif
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -93,7 +96,11 @@ struct Out {
         for (int e = 0; e < SZ; e++) asum[e] = 0.0;
     }
     __device__ inline void emit(uint64_t key, const double* v) {
+#ifdef TV_EXP_NOSTORE  /* timing experiment only: results are garbage */
+        if (n < 0) {
+#else
         if (n < cap) {
+#endif
             if (lane == 0) keys[n] = key;
 #pragma unroll
             for (int e = 0; e < SZ; e++) coef[((size_t)n * SZ + e) * WAVE + lane] = v[e];
@@ -118,6 +125,8 @@ struct Out {
 // its coefficient becomes 0.  Returns whether this lane keeps the term.
 template <int SZ>
 __device__ inline bool verdict(double thr, double thr_sq, bool active, double* acc, double* rad) {
+    // (selects, not branches: a branch on a per-lane condition costs a dozen exec-mask instructions, and this runs once per
+    //  distinct raw key; adding 0.0 to a non-negative radius changes nothing)
     bool small;
     if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
     else {
@@ -126,12 +135,10 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
         for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
         small = s <= thr_sq;
     }
-    if (small || !active) {
+    const bool keep = !small && active;
 #pragma unroll
-        for (int e = 0; e < SZ; e++) { rad[e] += fabs(acc[e]); acc[e] = 0.0; }
-        return false;
-    }
-    return true;
+    for (int e = 0; e < SZ; e++) { rad[e] += keep ? 0.0 : fabs(acc[e]); acc[e] = keep ? acc[e] : 0.0; }
+    return keep;
 }
 
 // The serial walk over N raw terms sorted by (key, generation index).  `keyat(p)` = key of the p-th sorted term (LDS),
@@ -140,22 +147,42 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
 //     void add(const Regs&, bool first)          -- accumulate it (first: start a new sum)
 //     void close(uint64_t key)                   -- the run of equal keys is complete: verdict + emit
 // Loads run U terms ahead of their use.
+#ifdef TV_PROFILE
+__device__ long long g_tvprof[8];  // [0] load phase, [1] process phase, [2] chunk prologue, [3] batches
+#endif
 template <int U, class P, class KeyAt, class IdxAt>
-__device__ inline void walk_sorted(int lane, int N, const KeyAt& keyat, const IdxAt& idxat, P& pol) {
+__device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const IdxAt& idxat, P& pol) {
+    // N arrives from the sorter as a value the compiler must assume differs between lanes; as a loop bound it would put the
+    // whole walk under divergent control flow (every wave-uniform variable in it becomes a vector register with exec-mask
+    // bookkeeping around each update: measured 230 instructions per raw term).  One readfirstlane makes the walk scalar.
+    const int N = uni(N_);
     bool have = false;
     uint64_t cur = 0;
     for (int base = 0; base < N; base += WAVE) {
+#ifdef TV_PROFILE
+        long long wp0 = clock64();
+#endif
         const int p = base + lane;
         const uint64_t key_v = p < N ? keyat(p) : 0ull;
         const int idx_v = p < N ? idxat(p) : 0;
         const int n = min(WAVE, N - base);
+#ifdef TV_PROFILE
+        { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[2] += x - wp0; wp0 = x; }
+#endif
         for (int l0 = 0; l0 < n; l0 += U) {
             typename P::Regs regs[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int l = min(l0 + u, n - 1);
+#ifdef TV_EXP_HOTLOAD  /* timing experiment only: every term loads the same rows */
+                pol.load(l * 0, regs[u]);
+#else
                 pol.load(__builtin_amdgcn_readlane(idx_v, l), regs[u]);
+#endif
             }
+#ifdef TV_PROFILE
+            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) { g_tvprof[0] += x - wp0; g_tvprof[3] += 1; } wp0 = x; }
+#endif
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (l0 + u < n) {
@@ -165,14 +192,40 @@ __device__ inline void walk_sorted(int lane, int N, const KeyAt& keyat, const Id
                     have = true; cur = key;
                 }
             }
+#ifdef TV_PROFILE
+            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[1] += x - wp0; wp0 = x; }
+#endif
         }
     }
     if (have) pol.close(cur);
 }
 
+// Rows of one operand copied to LDS, centre first: term i (0 = centre, i >= 1 monomial i - 1), entry e at row i * sz + e.
+// The walk below visits the raw terms in key order, i.e. it jumps around in both operands; every jump into global memory
+// costs a round trip to the Infinity Cache or HBM (2-4 k cycles with a per-wave working set of megabytes).  The short
+// operand of a product -- a joint rotation, the joint's own velocity factor -- fits LDS, which leaves the walk ONE operand's
+// rows to fetch per raw term, so four times as many terms can be in flight in the same registers.
+__device__ inline bool stage_fits(const TW& t, const TView& v) { return (v.cnt + 1) * v.sz <= t.stage_rows; }
+__device__ inline void stage_rows_of(const TW& t, const TView& v, int lane) {
+    const int sz = v.sz;
+    for (int e = 0; e < sz; e++) t.stage[(size_t)e * WAVE + lane] = ld_hdr(v, H_CEN, e, lane);
+    const int rows = v.cnt * sz;
+    const GLB_AS double* src = v.coef + (size_t)v.off * WAVE + lane;  // (whole-PZ views: off = 0, stride = sz, rows are consecutive)
+    LDS_AS double* dst = t.stage + (size_t)sz * WAVE + lane;
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        double x[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) x[u] = src[(size_t)min(r0 + u, rows - 1) * WAVE];
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (r0 + u < rows) dst[(size_t)(r0 + u) * WAVE] = x[u];
+    }
+    WSYNC();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// product (RT/PZsparse.cu:864-994), shapes as in pz_wave.h
-template <class SH>
+// product (RT/PZsparse.cu:864-994), shapes as in pz_wave.h.  STAGE: 0 both operands from global memory, 1 a's rows staged in
+// LDS, 2 b's rows staged.
+template <class SH, int STAGE>
 struct MulCtx {
     TView a, b;
     int lane, mb1;
@@ -180,41 +233,93 @@ struct MulCtx {
     double thr, thr_sq;
     bool active;
     Out<SH::SZ>* o;
+    const LDS_AS double* stage;
     double acc[SH::SZ], rad[SH::SZ];
-    struct Regs { double ca[SH::ASZ], cb[SH::BSZ]; };
+    struct Regs { double ca[STAGE == 1 ? 1 : SH::ASZ], cb[STAGE == 2 ? 1 : SH::BSZ]; int i, j; };
+    static constexpr int kRegDoubles = (STAGE == 1 ? 0 : SH::ASZ) + (STAGE == 2 ? 0 : SH::BSZ);
+    static constexpr int kU = kRegDoubles <= 3 ? 16 : kRegDoubles <= 6 ? 8 : kRegDoubles <= 9 ? 6 : 4;  // terms whose row loads are in flight together
     __device__ inline void load(int idx, Regs& r) const {
         const int t = idx + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
-        if (i) {
-            const GLB_AS double* pa = a.coef + ((size_t)(i - 1) * a.stride + a.off) * WAVE + lane;
-#pragma unroll
-            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
-        } else {
-            const GLB_AS double* pa = a.hdr + (size_t)a.off * WAVE + lane;
+        r.i = i; r.j = j;
+        if constexpr (STAGE != 1) {
+            const GLB_AS double* pa = a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE + lane;  // i = 0: the centre rows, stored right before the coefficients
 #pragma unroll
             for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
         }
-        if (j) {
-            const GLB_AS double* pb = b.coef + ((size_t)(j - 1) * b.stride + b.off) * WAVE + lane;
-#pragma unroll
-            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
-        } else {
-            const GLB_AS double* pb = b.hdr + (size_t)b.off * WAVE + lane;
+        if constexpr (STAGE != 2) {
+            const GLB_AS double* pb = b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * WAVE + lane;
 #pragma unroll
             for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
         }
     }
     __device__ inline void add(const Regs& r, bool first) {
-        double c[SH::SZ];
-        SH::mul(r.ca, r.cb, c);
+        double c[SH::SZ], ca[SH::ASZ], cb[SH::BSZ];
+        if constexpr (STAGE == 1) {
+            const LDS_AS double* pa = stage + (size_t)r.i * SH::ASZ * WAVE + lane;
 #pragma unroll
-        for (int e = 0; e < SH::SZ; e++) acc[e] = first ? c[e] : acc[e] + c[e];
+            for (int e = 0; e < SH::ASZ; e++) ca[e] = pa[e * WAVE];
+        } else {
+#pragma unroll
+            for (int e = 0; e < SH::ASZ; e++) ca[e] = r.ca[e];
+        }
+        if constexpr (STAGE == 2) {
+            const LDS_AS double* pb = stage + (size_t)r.j * SH::BSZ * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) cb[e] = pb[e * WAVE];
+        } else {
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) cb[e] = r.cb[e];
+        }
+        SH::mul(ca, cb, c);
+        if (first) {  // (wave-uniform: a scalar branch, not SZ selects)
+#pragma unroll
+            for (int e = 0; e < SH::SZ; e++) acc[e] = c[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < SH::SZ; e++) acc[e] += c[e];
+        }
     }
     __device__ inline void close(uint64_t key) {
-        const bool keep = verdict<SH::SZ>(thr, thr_sq, active, acc, rad);
-        if (__ballot(keep) != 0ull) o->emit(key, acc);
+        // the common case first: no lane keeps the term (nine raw terms in ten are pruned) -- one test, SZ additions
+        bool small;
+        if constexpr (SH::SZ == 1) small = fabs(acc[0]) <= thr;
+        else {
+            double q = 0.0;
+#pragma unroll
+            for (int e = 0; e < SH::SZ; e++) q += acc[e] * acc[e];
+            small = q <= thr_sq;
+        }
+        if (__ballot(!small && active) == 0ull) {
+#pragma unroll
+            for (int e = 0; e < SH::SZ; e++) rad[e] += fabs(acc[e]);
+            return;
+        }
+        const bool keep = !small && active;
+#pragma unroll
+        for (int e = 0; e < SH::SZ; e++) { rad[e] += keep ? 0.0 : fabs(acc[e]); acc[e] = keep ? acc[e] : 0.0; }
+        o->emit(key, acc);
     }
 };
+
+template <class SH, int STAGE>
+__device__ inline void mul_ctx_init(MulCtx<SH, STAGE>& cx, const TW& t, const TView& a, const TView& b, Out<SH::SZ>* o) {
+    cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
+#pragma unroll
+    for (int e = 0; e < SH::SZ; e++) { cx.acc[e] = 0.0; cx.rad[e] = 0.0; }
+}
+template <class SH, int STAGE>
+__device__ inline void mul_walk(TW& t, int N, bool indirect, const pzw::MulEval<SH>& ev, const TView& a, const TView& b, Out<SH::SZ>* o, double* rad) {
+    MulCtx<SH, STAGE> cx;
+    mul_ctx_init(cx, t, a, b, o);
+    const Wave& w = t.w;
+    const int lane = w.lane;
+    if (indirect) walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+#pragma unroll
+    for (int e = 0; e < SH::SZ; e++) rad[e] = cx.rad[e];
+}
 
 template <int AR, int AC, int BR, int BC>
 __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
@@ -252,50 +357,56 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
 
     Out<SZ> o;
     o.init(out, lane);
-    MulCtx<SH> cx;
-    cx.a = a; cx.b = b; cx.lane = lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
-    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
+    double rad[SZ];
 #pragma unroll
-    for (int e = 0; e < SZ; e++) { cx.acc[e] = 0.0; cx.rad[e] = 0.0; }
+    for (int e = 0; e < SZ; e++) rad[e] = 0.0;
     if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
     if (a.cnt == 0) {
         // constant left operand (mass, inertia, the fixed rpy rotation): b's keys in b's order, no sort
+        MulCtx<SH, 0> cx;
+        mul_ctx_init(cx, t, a, b, &o);
         for (int m0 = 0; m0 < b.cnt; m0 += WAVE) {
             const uint64_t key_v = m0 + lane < b.cnt ? b.keys[m0 + lane] : 0ull;
             const int n = min(WAVE, b.cnt - m0);
-            for (int l0 = 0; l0 < n; l0 += 4) {
-                typename MulCtx<SH>::Regs regs[4];
+            constexpr int kUc = SH::ASZ + SH::BSZ > 12 ? 4 : 8;
+            for (int l0 = 0; l0 < n; l0 += kUc) {
+                typename MulCtx<SH, 0>::Regs regs[kUc];
 #pragma unroll
-                for (int u = 0; u < 4; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
+                for (int u = 0; u < kUc; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < kUc; u++)
                     if (l0 + u < n) { cx.add(regs[u], true); cx.close(readlane_u64(key_v, l0 + u)); }
             }
         }
+#pragma unroll
+        for (int e = 0; e < SZ; e++) rad[e] = cx.rad[e];
     } else {
-        constexpr int kU = (SH::ASZ + SH::BSZ > 12) ? 2 : 4;  // terms whose row loads are in flight together
         pzw::MulEval<SH> ev;
         ev.a = kview(a); ev.set_b(kview(b));
         bool indirect = false;
         TVP_T0
         N = pzw::sort_terms(t.w, N, ev, indirect);
         TVP_T1
-        const Wave& w = t.w;
-        if (indirect) walk_sorted<kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-        else walk_sorted<kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
-        TVP_END(t, N, o.n)
+        // the shorter operand's rows go to LDS when they fit (whole-PZ views only)
+        const bool a_short = a.cnt <= b.cnt;
+        const bool can_a = a.off == 0 && a.sz == a.stride && stage_fits(t, a), can_b = b.off == 0 && b.sz == b.stride && stage_fits(t, b);
+        if ((a_short && can_a) || (!can_b && can_a)) { stage_rows_of(t, a, lane); mul_walk<SH, 1>(t, N, indirect, ev, a, b, &o, rad); }
+        else if (can_b) { stage_rows_of(t, b, lane); mul_walk<SH, 2>(t, N, indirect, ev, a, b, &o, rad); }
+        else mul_walk<SH, 0>(t, N, indirect, ev, a, b, &o, rad);
+        TVP_END(t, N, o.n, 0)
     }
 #pragma unroll
     for (int e = 0; e < SZ; e++) {
         st_hdr(out, H_CEN, e, lane, cen[e]);
-        st_hdr(out, H_IND, e, lane, base[e] + cx.rad[e]);
-        st_hdr(out, H_IND2, e, lane, base2[e] + cx.rad[e]);
+        st_hdr(out, H_IND, e, lane, base[e] + rad[e]);
+        st_hdr(out, H_IND2, e, lane, base2[e] + rad[e]);
     }
     o.finish(t, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // cross(a, b) of 3x1 operands (RT/PZsparse.cu:1134-1151) with the three simplify() stages of the composition, per lane
+template <int STAGE>  // 0: both operands from global memory, 1: a's rows staged in LDS, 2: b's
 struct CrossCtx {
     TView a, b;
     int lane, mb1;
@@ -303,51 +414,99 @@ struct CrossCtx {
     double thr, thr_sq;
     bool active;
     Out<3>* o;
+    const LDS_AS double* stage;
     double acc[6], rad[12];  // radii: 6 products | 3 differences | 3 stack
-    struct Regs { double ca[3], cb[3]; };
+    struct Regs { double ca[STAGE == 1 ? 1 : 3], cb[STAGE == 2 ? 1 : 3]; int i, j; };
+    static constexpr int kU = STAGE == 0 ? 8 : 16;
     __device__ inline void load(int idx, Regs& r) const {
         const int t = idx + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
-        const GLB_AS double* pa = (i ? a.coef + (size_t)(i - 1) * 3 * WAVE : a.hdr) + lane;
-        const GLB_AS double* pb = (j ? b.coef + (size_t)(j - 1) * 3 * WAVE : b.hdr) + lane;
+        r.i = i; r.j = j;
+        if constexpr (STAGE != 1) {
+            const GLB_AS double* pa = a.coef + (ptrdiff_t)(i - 1) * 3 * WAVE + lane;  // i = 0: the centre rows
 #pragma unroll
-        for (int e = 0; e < 3; e++) { r.ca[e] = pa[e * WAVE]; r.cb[e] = pb[e * WAVE]; }
+            for (int e = 0; e < 3; e++) r.ca[e] = pa[e * WAVE];
+        }
+        if constexpr (STAGE != 2) {
+            const GLB_AS double* pb = b.coef + (ptrdiff_t)(j - 1) * 3 * WAVE + lane;
+#pragma unroll
+            for (int e = 0; e < 3; e++) r.cb[e] = pb[e * WAVE];
+        }
     }
     __device__ inline void add(const Regs& r, bool first) {
-        double p6[6];
-        p6[0] = r.ca[1] * r.cb[2]; p6[1] = r.ca[2] * r.cb[1];
-        p6[2] = r.ca[2] * r.cb[0]; p6[3] = r.ca[0] * r.cb[2];
-        p6[4] = r.ca[0] * r.cb[1]; p6[5] = r.ca[1] * r.cb[0];
+        double ca[3], cb[3];
 #pragma unroll
-        for (int e = 0; e < 6; e++) acc[e] = first ? p6[e] : acc[e] + p6[e];
+        for (int e = 0; e < 3; e++) {
+            if constexpr (STAGE == 1) ca[e] = stage[((size_t)r.i * 3 + e) * WAVE + lane]; else ca[e] = r.ca[e];
+            if constexpr (STAGE == 2) cb[e] = stage[((size_t)r.j * 3 + e) * WAVE + lane]; else cb[e] = r.cb[e];
+        }
+        double p6[6];
+        p6[0] = ca[1] * cb[2]; p6[1] = ca[2] * cb[1];
+        p6[2] = ca[2] * cb[0]; p6[3] = ca[0] * cb[2];
+        p6[4] = ca[0] * cb[1]; p6[5] = ca[1] * cb[0];
+        if (first) {  // (wave-uniform: a scalar branch, not six selects)
+#pragma unroll
+            for (int e = 0; e < 6; e++) acc[e] = p6[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 6; e++) acc[e] += p6[e];
+        }
     }
     __device__ inline void close(uint64_t key) {
-        double u[3] = {0.0, 0.0, 0.0};
-        bool anyc = false, keep = false;
+        // the common case first: all six products are below the threshold in every lane -- then each goes to its product's
+        // radius and nothing else happens (no difference, no stack entry)
+        {
+            bool all_small = true;
+#pragma unroll
+            for (int e = 0; e < 6; e++) all_small = all_small && (fabs(acc[e]) <= thr);
+            if (__ballot(!all_small) == 0ull) {
+#pragma unroll
+                for (int e = 0; e < 6; e++) rad[e] += fabs(acc[e]);
+                return;
+            }
+        }
+        // the three simplify() stages of the composed cross product, per lane, as selects (see verdict())
+        double u[3];
+        bool anyc = false;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double v0 = acc[2 * c], v1 = acc[2 * c + 1];
             const bool h0 = !(fabs(v0) <= thr), h1 = !(fabs(v1) <= thr);
-            if (!h0) rad[2 * c] += fabs(v0);
-            if (!h1) rad[2 * c + 1] += fabs(v1);
-            if (h0 || h1) {
-                double wv = h0 ? 1.0 * v0 : -1.0 * v1;
-                if (h0 && h1) wv += -1.0 * v1;
-                if (fabs(wv) <= thr) rad[6 + c] += fabs(wv);
-                else { u[c] = wv; anyc = true; }
-            }
+            rad[2 * c] += h0 ? 0.0 : fabs(v0);
+            rad[2 * c + 1] += h1 ? 0.0 : fabs(v1);
+            double wv = h0 ? 1.0 * v0 : -1.0 * v1;
+            const double wv2 = wv + -1.0 * v1;
+            wv = (h0 && h1) ? wv2 : wv;
+            const bool any01 = h0 || h1, smallw = fabs(wv) <= thr;
+            rad[6 + c] += (any01 && smallw) ? fabs(wv) : 0.0;
+            const bool kc = any01 && !smallw;
+            u[c] = kc ? wv : 0.0;
+            anyc = anyc || kc;
         }
-        if (anyc) {
-            const double s = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-            keep = !(s <= thr_sq) && active;
-            if (!keep) {
+        const double s = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        const bool keep = anyc && !(s <= thr_sq) && active;
 #pragma unroll
-                for (int c = 0; c < 3; c++) { rad[9 + c] += fabs(u[c]); u[c] = 0.0; }
-            }
-        }
+        for (int c = 0; c < 3; c++) { rad[9 + c] += (anyc && !keep) ? fabs(u[c]) : 0.0; u[c] = keep ? u[c] : 0.0; }
         if (__ballot(keep) != 0ull) o->emit(key, u);
     }
 };
+
+template <int STAGE>
+__device__ inline void cross_walk(TW& t, int N, bool indirect, const pzw::MulEval<pzw::MulShape<1, 1, 1, 1>>& ev, const TView& a, const TView& b, Out<3>* o, double* rad) {
+    CrossCtx<STAGE> cx;
+    cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
+#pragma unroll
+    for (int e = 0; e < 6; e++) cx.acc[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
+    const Wave& w = t.w;
+    const int lane = w.lane;
+    if (indirect) walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+#pragma unroll
+    for (int e = 0; e < 12; e++) rad[e] = cx.rad[e];
+}
 
 __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
     typedef pzw::MulShape<1, 1, 1, 1> SH;
@@ -377,13 +536,7 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     WSYNC();
     Out<3> o;
     o.init(out, lane);
-    CrossCtx cx;
-    cx.a = a; cx.b = b; cx.lane = lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
-    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
-#pragma unroll
-    for (int e = 0; e < 6; e++) cx.acc[e] = 0.0;
-#pragma unroll
-    for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
+    double rad[12];
     if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
     pzw::MulEval<SH> ev;
     ev.a = kview(a); ev.set_b(kview(b));
@@ -392,18 +545,22 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     TVP_T0
     N = pzw::sort_terms(t.w, N, ev, indirect);
     TVP_T1
-    const Wave& w = t.w;
-    if (indirect) walk_sorted<4>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    else walk_sorted<4>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    TVP_END(t, N, o.n)
+    {
+        const bool a_short = a.cnt <= b.cnt;
+        const bool can_a = stage_fits(t, a), can_b = stage_fits(t, b);
+        if ((a_short && can_a) || (!can_b && can_a)) { stage_rows_of(t, a, lane); cross_walk<1>(t, N, indirect, ev, a, b, &o, rad); }
+        else if (can_b) { stage_rows_of(t, b, lane); cross_walk<2>(t, N, indirect, ev, a, b, &o, rad); }
+        else cross_walk<0>(t, N, indirect, ev, a, b, &o, rad);
+    }
+    TVP_END(t, N, o.n, 1)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double i0 = baseP[2 * c] + cx.rad[2 * c], i1 = baseP[2 * c + 1] + cx.rad[2 * c + 1];
-        const double j0 = base2P[2 * c] + cx.rad[2 * c], j1 = base2P[2 * c + 1] + cx.rad[2 * c + 1];
-        const double ir = (i0 * 1.0 + i1 * 1.0) + cx.rad[6 + c], jr = (j0 * 1.0 + j1 * 1.0) + cx.rad[6 + c];
+        const double i0 = baseP[2 * c] + rad[2 * c], i1 = baseP[2 * c + 1] + rad[2 * c + 1];
+        const double j0 = base2P[2 * c] + rad[2 * c], j1 = base2P[2 * c + 1] + rad[2 * c + 1];
+        const double ir = (i0 * 1.0 + i1 * 1.0) + rad[6 + c], jr = (j0 * 1.0 + j1 * 1.0) + rad[6 + c];
         st_hdr(out, H_CEN, c, lane, 0.0 + (1.0 * cenP[2 * c] + -1.0 * cenP[2 * c + 1]));
-        st_hdr(out, H_IND, c, lane, (0.0 + ir) + cx.rad[9 + c]);
-        st_hdr(out, H_IND2, c, lane, (0.0 + jr) + cx.rad[9 + c]);
+        st_hdr(out, H_IND, c, lane, (0.0 + ir) + rad[9 + c]);
+        st_hdr(out, H_IND2, c, lane, (0.0 + jr) + rad[9 + c]);
     }
     o.finish(t, out);
 }
@@ -456,27 +613,25 @@ struct LinCtx {
             }
         }
     }
-    // simplify() of stage k (k >= 1) on what has been accumulated so far
-    __device__ inline void stage(int k) {
-        if (present) {
-            bool small;
-            if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
-            else {
-                double q = 0.0;
+    // simplify() of stage k (k >= 1) on what has been accumulated so far (selects: see verdict())
+    __device__ inline bool is_small() const {
+        if constexpr (SZ == 1) return fabs(acc[0]) <= thr;
+        else {
+            double q = 0.0;
 #pragma unroll
-                for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
-                small = q <= thr_sq;
-            }
-            if (small) {
-#pragma unroll
-                for (int kk = 1; kk < NS; kk++)
-                    if (kk == k) {
-#pragma unroll
-                        for (int e = 0; e < SZ; e++) ra[kk][e] += fabs(acc[e]);
-                    }
-                present = false;
-            }
+            for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
+            return q <= thr_sq;
         }
+    }
+    __device__ inline void stage(int k) {
+        const bool drop = present && is_small();
+#pragma unroll
+        for (int kk = 1; kk < NS; kk++)
+            if (kk == k) {
+#pragma unroll
+                for (int e = 0; e < SZ; e++) ra[kk][e] += drop ? fabs(acc[e]) : 0.0;
+            }
+        present = present && !drop;
     }
     __device__ inline void add(const Regs& r, bool first) {
         if (first) { present = false; last = -1; }
@@ -494,21 +649,10 @@ struct LinCtx {
             for (int k = max(last + 1, 1); k < NS; k++) stage(k);
         } else {
             // one simplify() at the end: pruned terms go to ra[0]
-            if (present) {
-                bool small;
-                if constexpr (SZ == 1) small = fabs(acc[0]) <= thr;
-                else {
-                    double q = 0.0;
+            const bool drop = present && is_small();
 #pragma unroll
-                    for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
-                    small = q <= thr_sq;
-                }
-                if (small) {
-#pragma unroll
-                    for (int e = 0; e < SZ; e++) ra[0][e] += fabs(acc[e]);
-                    present = false;
-                }
-            }
+            for (int e = 0; e < SZ; e++) ra[0][e] += drop ? fabs(acc[e]) : 0.0;
+            present = present && !drop;
         }
         const bool keep = present && active;
         double v[SZ];
@@ -569,9 +713,10 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     N = pzw::sort_terms(t.w, N, ev, indirect);
     TVP_T1
     const Wave& w = t.w;
-    if (indirect) walk_sorted<4>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    else walk_sorted<4>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    TVP_END(t, N, o.n)
+    constexpr int kU = SZ <= 3 ? 16 : 4;
+    if (indirect) walk_sorted<kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    TVP_END(t, N, o.n, 2)
 #pragma unroll
     for (int e = 0; e < SZ; e++) {
         double r, r2;
@@ -627,19 +772,19 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
     for (int m0 = 0; m0 < a.cnt; m0 += WAVE) {
         const uint64_t key_v = m0 + lane < a.cnt ? a.keys[m0 + lane] : 0ull;
         const int n = min(WAVE, a.cnt - m0);
-        for (int l0 = 0; l0 < n; l0 += 4) {
-            double x[4][3];
+        for (int l0 = 0; l0 < n; l0 += 16) {
+            double x[16][3];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int m = m0 + min(l0 + u, n - 1);
 #pragma unroll
                 for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, m, q, lane);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 16; u++) {
                 if (l0 + u < n) {
                     double r[3];
-                    bool anyc = false, keep = false;
+                    bool anyc = false;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         double xa = 0, xb = 0;
@@ -647,13 +792,14 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
                         for (int q = 0; q < 3; q++) { if (q == cA[c]) xa = x[u][q]; if (q == cB[c]) xb = x[u][q]; }
                         double v = sA[c] * xa;
                         v += sB[c] * xb;
-                        if (fabs(v) <= thr) { ra1[c] += fabs(v); v = 0.0; } else anyc = true;
-                        r[c] = v;
+                        const bool small = fabs(v) <= thr;
+                        ra1[c] += small ? fabs(v) : 0.0;
+                        r[c] = small ? 0.0 : v;
+                        anyc = anyc || !small;
                     }
-                    if (anyc) {
-                        keep = !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
-                        if (!keep) { ra2[0] += fabs(r[0]); ra2[1] += fabs(r[1]); ra2[2] += fabs(r[2]); r[0] = r[1] = r[2] = 0.0; }
-                    }
+                    const bool keep = anyc && !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { ra2[c] += (anyc && !keep) ? fabs(r[c]) : 0.0; r[c] = keep ? r[c] : 0.0; }
                     if (__ballot(keep) != 0ull) o.emit(readlane_u64(key_v, l0 + u), r);
                 }
             }

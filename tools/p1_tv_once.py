@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from armour_amd.planner import ArmourNLP
 from armour_amd.worlds import random_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
