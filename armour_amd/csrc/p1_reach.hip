@@ -1336,14 +1336,21 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
         const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv);
+        // Sort buffers of 4096 entries let several waves share a CU (the union raw-term counts seen are <= 2.4 k); a product that
+        // overflows them sends the launch to the next size.  While SIMDs would otherwise idle, the forward kinematics of every
+        // group runs as a work item of its own (a fifth of a chain that shares nothing with the RNEA but the JRS rotations).
         const int caps[2] = {4096, 8192};
-        for (int ci = groups > prop.multiProcessorCount ? 0 : 1; ci < 2 && !built; ci++) {
+        for (int ci = 0; ci < 2 && !built; ci++) {
             const int cap = caps[ci];
             // staging area for the short operand of a product: what is left of the CU's LDS at the wave count the sort buffers allow
             const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / (tvchain::tv_lds_fixed(cap) + 24 * 1024))));
             const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - tvchain::tv_lds_fixed(cap) - 256) / 512);
             const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows);
-            const int waves = std::min(groups, std::min(512, prop.multiProcessorCount * per_cu));
+            const int slots = std::min(512, prop.multiProcessorCount * per_cu);
+            static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
+            const bool split = tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots;
+            const int fk_items = split ? groups : 0;
+            const int waves = std::min(groups + fk_items, slots);
             if ((size_t)waves * TL.total > wk->tv_arena_total) {
                 if (wk->tv_arena) (void)hipFree(wk->tv_arena);
                 wk->tv_arena = nullptr; wk->tv_arena_total = 0;
@@ -1364,7 +1371,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-            cf.n_items = groups; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
+            cf.n_items = groups; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
@@ -1375,7 +1382,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
-            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps, sort cap %d: %d waves (%d per CU, %zu B LDS, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, cap, waves, per_cu, smem, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d waves (%d per CU, %zu B LDS, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, waves, per_cu, smem, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next size
         }

@@ -169,7 +169,7 @@ __device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& ou
 }
 
 // JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations)
-__device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane) {
+__device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_only) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
@@ -189,6 +189,7 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane) {
             build_simplified<9>(c, c.rotRaw(), c.rotS(), cen, 4, keys, co);
             tv::set_const(c.t, c.rpy(), rp, nullptr);
             tv::mul<3, 3, 3, 3>(c.t, c.R(i), tv::view(c.t, c.rpy()), tv::view(c.t, c.rotS()));
+            if (!kin_only) {
             {
                 const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
                 const double co2[2] = {js.qd_k, js.qd_e};
@@ -204,12 +205,13 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane) {
                 const double co2[2] = {js.qdd_k, js.qdd_e};
                 build_simplified<1>(c, c.rawS(0), c.qdda(i), &js.qdd_c, 2, k2, co2);
             }
+            }
         } else {
             tv::set_const(c.t, c.R(i), rp, nullptr);
         }
-        tv::transpose33(c.t, c.Rt(i), c.R(i));
+        if (!kin_only) tv::transpose33(c.t, c.Rt(i), c.R(i));
         tv::set_const(c.t, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
-        {
+        if (!kin_only) {
             double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
             double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             tv::set_const(c.t, c.mass(i), &cf.rb.mass[i], zero9, &mi);
@@ -305,13 +307,13 @@ __device__ TV_NOINLINE void fk_step_tv(TChain& c, TFk& f, int i, int b, int t_la
 
 // RT/Dynamics.cu:83-181 with nominal and interval parameters in one pass, and the forward kinematics; same operator order
 // as run_rnea in a 1-wave block.
-__device__ TV_NOINLINE void run_rnea_tv(TChain& c, TPZ* u, int b, int t_lane) {
+__device__ TV_NOINLINE void run_rnea_tv(TChain& c, TPZ* u, int b, int t_lane, bool with_fk) {
     const P1Cfg& cf = *c.cf;
     TW& t = c.t;
     const int J = c.J;
     TFk fk;
     fk.R = c.M(0); fk.Rn = c.M(1);
-    {
+    if (with_fk) {
         double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         tv::set_const(t, fk.R, id, nullptr);
         fk.T = c.allocV();
@@ -371,12 +373,12 @@ __device__ TV_NOINLINE void run_rnea_tv(TChain& c, TPZ* u, int b, int t_lane) {
                 F[s - 1] = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
             }
         }
-        if (s < J) fk_step_tv(c, fk, s, b, t_lane);
+        if (s < J && with_fk) fk_step_tv(c, fk, s, b, t_lane);
         c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); c.freeVs(lacc);
         wv = nw; wdot = nd; waux = na; lacc = nl;
         if (s == J) break;  // (the state of joint J-1 was freed above; nothing new was allocated for s == J)
     }
-    c.freeVs(fk.T);
+    if (with_fk) c.freeVs(fk.T);
     TPZ nn = c.allocV(), f = c.allocV();
     tv::set_const(t, nn, nullptr, nullptr);
     tv::set_const(t, f, nullptr, nullptr);
@@ -481,7 +483,12 @@ __global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
     c.t.w.thr_sq = pzw::sq_threshold(c.t.w.thr);
     c.t.w.lane = threadIdx.x;
     if (threadIdx.x < pzw::ST_WORDS) c.t.w.lstat[threadIdx.x] = 0;
-    for (int it = blockIdx.x; it < cf.n_items; it += gridDim.x) {
+    // items [0, n_items): the RNEA of a group; with fk_items > 0, items [n_items, n_items + fk_items) are the forward
+    // kinematics of group (it - n_items) -- it shares nothing with the RNEA but the JRS rotations, which it rebuilds -- and
+    // the first n_items then leave it out (the same split as the per-step kernel's)
+    for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
+        const bool fk_only = it0 >= cf.n_items;
+        const int it = fk_only ? it0 - cf.n_items : it0;
         const int b = it / groups_per_problem, g = it - b * groups_per_problem;
         const int t0 = g * lanes_per_group;
         const int nl = min(lanes_per_group, cf.T - t0);
@@ -495,13 +502,24 @@ __global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
         c.t.c_sort = c.t.c_walk = c.t.c_cc = c.t.n_raw = c.t.n_calls = c.t.n_emit = 0;
         for (int q = 0; q < 3; q++) { c.t.c_type[q] = 0; c.t.n_type[q] = 0; }
 #endif
-        build_jrs_tv(c, b, t_lane);
+        build_jrs_tv(c, b, t_lane, fk_only);
 #ifdef TV_PROFILE
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] jrs %lld cycles\n", it, (long long)clock64() - tvp_start);
 #endif
         TPZ u_nom[ARMOUR_MAX_FACTORS];
-        run_rnea_tv(c, u_nom, b, t_lane);
-        finish_torque_tv(c, u_nom, b, t_lane);
+        if (fk_only) {
+            TFk fk;
+            fk.R = c.M(0); fk.Rn = c.M(1);
+            double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            tv::set_const(c.t, fk.R, id, nullptr);
+            fk.T = c.allocV();
+            tv::set_const(c.t, fk.T, nullptr, nullptr);
+            for (int i = 0; i < c.J; i++) fk_step_tv(c, fk, i, b, t_lane);
+            c.freeVs(fk.T);
+        } else {
+            run_rnea_tv(c, u_nom, b, t_lane, cf.fk_items == 0);
+            finish_torque_tv(c, u_nom, b, t_lane);
+        }
         __syncthreads();
 #ifdef TV_PROFILE
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.t.c_type[0], c.t.n_type[0], c.t.c_type[1], c.t.n_type[1], c.t.c_type[2], c.t.n_type[2]);

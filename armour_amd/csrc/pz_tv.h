@@ -66,6 +66,12 @@ struct TW {
 #endif
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a pointer every lane holds alike, moved to scalar registers: row addresses are then scalar arithmetic plus a lane offset
+template <class T>
+__device__ inline T* uni_ptr(T* p) {
+    const uint64_t v = (uint64_t)p;
+    return (T*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
 __device__ inline uint64_t readlane_u64(uint64_t v, int l) {
     return ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
 }
@@ -91,7 +97,7 @@ struct Out {
     int cap, n, lane;
     double asum[SZ];
     __device__ inline void init(const TPZ& o, int lane_) {
-        keys = o.keys; coef = o.coef; cap = uni(o.cap); n = 0; lane = lane_;
+        keys = uni_ptr(o.keys); coef = uni_ptr(o.coef); cap = uni(o.cap); n = 0; lane = lane_;
 #pragma unroll
         for (int e = 0; e < SZ; e++) asum[e] = 0.0;
     }
@@ -305,6 +311,7 @@ struct MulCtx {
 template <class SH, int STAGE>
 __device__ inline void mul_ctx_init(MulCtx<SH, STAGE>& cx, const TW& t, const TView& a, const TView& b, Out<SH::SZ>* o) {
     cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.a.coef = uni_ptr(a.coef); cx.b.coef = uni_ptr(b.coef); cx.a.stride = uni(a.stride); cx.b.stride = uni(b.stride); cx.a.off = uni(a.off); cx.b.off = uni(b.off);
     cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) { cx.acc[e] = 0.0; cx.rad[e] = 0.0; }
@@ -495,6 +502,7 @@ template <int STAGE>
 __device__ inline void cross_walk(TW& t, int N, bool indirect, const pzw::MulEval<pzw::MulShape<1, 1, 1, 1>>& ev, const TView& a, const TView& b, Out<3>* o, double* rad) {
     CrossCtx<STAGE> cx;
     cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.a.coef = uni_ptr(a.coef); cx.b.coef = uni_ptr(b.coef);
     cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
 #pragma unroll
     for (int e = 0; e < 6; e++) cx.acc[e] = 0.0;
@@ -585,33 +593,53 @@ struct LinCtx {
     double acc[SZ], ra[NS][SZ];
     bool present;   // per lane
     int last;       // source of the run's latest member (wave-uniform)
-    struct Regs { double c[SZ]; int k; };
+    struct Regs { double x[SZ]; int idx; };  // (the source of a term is re-derived from idx where needed: sixteen terms' worth of
+                                             //  scale / component / source scalars do not fit the scalar registers)
     __device__ inline int seg_of(int idx) const {
         int k = 0;
 #pragma unroll
         for (int i = 1; i < NS; i++) k += (idx >= off[i]) ? 1 : 0;
         return k;
     }
+    // Only the loads: what is loaded must not be touched here, or the wave would wait for it before issuing the next term's
+    // loads.  The source is picked with scalar selects (idx and everything derived from it is wave-uniform).
     __device__ inline void load(int idx, Regs& r) const {
         const int k = seg_of(idx);
-        r.k = k;
+        const GLB_AS double* base = s[0].v.coef;
+        int stride = s[0].v.stride, voff = s[0].v.off, first = off[0], comp = s[0].comp;
 #pragma unroll
-        for (int e = 0; e < SZ; e++) r.c[e] = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS; q++) {
-            if (q == k) {
-                const TView& v = s[q].v;
-                const GLB_AS double* src = v.coef + ((size_t)(idx - off[q]) * v.stride + v.off) * WAVE + lane;
-                if (s[q].comp < 0) {
-#pragma unroll
-                    for (int e = 0; e < SZ; e++) r.c[e] = s[q].scale * src[e * WAVE];
-                } else {
-                    const double x = s[q].scale * src[0];
-#pragma unroll
-                    for (int e = 0; e < SZ; e++) r.c[e] = (e == s[q].comp) ? x : 0.0;
-                }
-            }
+        for (int q = 1; q < NS; q++) {
+            const bool me = (k == q);
+            base = me ? s[q].v.coef : base;
+            stride = me ? s[q].v.stride : stride; voff = me ? s[q].v.off : voff; first = me ? off[q] : first; comp = me ? s[q].comp : comp;
         }
+        r.idx = idx;
+        const GLB_AS double* src = base + ((size_t)(idx - first) * stride + voff) * WAVE + lane;
+        if (comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) r.x[e] = src[e * WAVE];
+        } else {
+            r.x[0] = src[0];
+#pragma unroll
+            for (int e = 1; e < SZ; e++) r.x[e] = 0.0;
+        }
+    }
+    // scale * embed(source entry); returns the source index
+    __device__ inline int term(const Regs& r, double* c) const {
+        const int k = seg_of(r.idx);
+        int comp = s[0].comp;
+        double scale = s[0].scale;
+#pragma unroll
+        for (int q = 1; q < NS; q++) { const bool me = (k == q); comp = me ? s[q].comp : comp; scale = me ? s[q].scale : scale; }
+        if (comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) c[e] = scale * r.x[e];
+        } else {
+            const double x = scale * r.x[0];
+#pragma unroll
+            for (int e = 0; e < SZ; e++) c[e] = (e == comp) ? x : 0.0;
+        }
+        return k;
     }
     // simplify() of stage k (k >= 1) on what has been accumulated so far (selects: see verdict())
     __device__ inline bool is_small() const {
@@ -635,14 +663,16 @@ struct LinCtx {
     }
     __device__ inline void add(const Regs& r, bool first) {
         if (first) { present = false; last = -1; }
+        double c[SZ];
+        const int rk = term(r, c);
         if constexpr (CHAIN) {
-            for (int k = max(last + 1, 1); k < r.k; k++) stage(k);  // stages without a member of this key
+            for (int k = max(last + 1, 1); k < rk; k++) stage(k);  // stages without a member of this key
         }
 #pragma unroll
-        for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + r.c[e] : r.c[e];
+        for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + c[e] : c[e];
         present = true;
-        if constexpr (CHAIN) { if (r.k >= 1) stage(r.k); }
-        last = r.k;
+        if constexpr (CHAIN) { if (rk >= 1) stage(rk); }
+        last = rk;
     }
     __device__ inline void close(uint64_t key) {
         if constexpr (CHAIN) {
@@ -674,7 +704,8 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         cx.s[k] = segs[k];
-        cx.s[k].v.cnt = uni(cx.s[k].v.cnt);
+        cx.s[k].v.cnt = uni(cx.s[k].v.cnt); cx.s[k].v.stride = uni(cx.s[k].v.stride); cx.s[k].v.off = uni(cx.s[k].v.off); cx.s[k].comp = uni(cx.s[k].comp);
+        cx.s[k].v.coef = uni_ptr(cx.s[k].v.coef);
         ev.s[k].v = kview(cx.s[k].v); ev.s[k].scale = segs[k].scale; ev.s[k].comp = segs[k].comp;
         cx.off[k] = N; ev.off[k] = N;
         N += cx.s[k].v.cnt;
@@ -713,7 +744,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     N = pzw::sort_terms(t.w, N, ev, indirect);
     TVP_T1
     const Wave& w = t.w;
-    constexpr int kU = SZ <= 3 ? 16 : 4;
+    constexpr int kU = SZ <= 3 ? 8 : 4;
     if (indirect) walk_sorted<kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
     else walk_sorted<kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
     TVP_END(t, N, o.n, 2)
