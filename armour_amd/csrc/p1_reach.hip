@@ -1331,7 +1331,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
     static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
-    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 160; }();  // below this the per-step kernel is faster (measured)
+    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 100; }();  // below this the per-step kernel is faster (measured: B = 48 at T = 100 is the break-even)
     if (h->mode != ARMOUR_MODE_ARMTD && (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= tv_min_groups)) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;

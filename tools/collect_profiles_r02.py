@@ -12,7 +12,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
 DST = os.path.join(ROOT, "profiles")
-KERNELS = ("armour_p2_eval_kernel", "armour_p1_chain_kernel", "armour_p1_planes_kernel", "armour_solve_kernel", "armour_solve_scan_kernel")
+KERNELS = ("armour_p2_eval_kernel", "armour_p1_chain_kernel", "armour_p1_tv_kernel", "armour_p1_planes_kernel", "armour_solve_kernel", "armour_solve_scan_kernel")
 
 
 def newest(pattern):
@@ -66,8 +66,11 @@ for tag, name, kern, workload, cmd in (
 sq = {}
 for B in (1, 128):
     shutil.copy(newest(os.path.join(SRC, f"p1_trace_B{B}", "**", "*kernel_stats.csv")), os.path.join(DST, f"r02_p1_B{B}_kernel_stats.csv"))
-    c = merge(counters(f"p1_sqa_B{B}"), counters(f"p1_sqb_B{B}"))["armour_p1_chain_kernel"]
+    both = merge(counters(f"p1_sqa_B{B}"), counters(f"p1_sqb_B{B}"))
+    kern = "armour_p1_tv_kernel" if "armour_p1_tv_kernel" in both else "armour_p1_chain_kernel"   # batches are built time-vectorised
+    c = both[kern]
     v = {k: x["mean_per_dispatch"] for k, x in c.items()}
+    v["kernel"] = kern
     v["dispatches"] = c["SQ_WAVES"]["dispatches"]
     v["derived"] = {"valu_insts_per_wave": v["SQ_INSTS_VALU"] / v["SQ_WAVES"], "wait_fraction_of_wave_cycles": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
                     "issue_fraction_of_wave_cycles": v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"],
@@ -75,9 +78,10 @@ for B in (1, 128):
     sq[f"B={B}"] = v
 json.dump({"command": "rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 tools/p1_once.py B  "
                       "(second pass: SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE)",
-           "kernel": "armour_p1_chain_kernel (the reach-set build of random worlds at O=20, T=100; means per dispatch over the dispatches of the run)",
+           "kernel": "the reach-set build of random worlds at O=20, T=100: armour_p1_chain_kernel (one wave per time step) for B = 1, armour_p1_tv_kernel "
+                     "(one wave per 50 time steps, lane = time step) for B = 128; means per dispatch over the dispatches of the run",
            "counters": sq}, open(os.path.join(DST, "r02_p1_sq.json"), "w"), indent=1)
 for B in (1, 128):
-    print(f"P1 B={B}:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sq[f"B={B}"]["derived"].items()})
+    print(f"P1 B={B}:", sq[f"B={B}"]["kernel"], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sq[f"B={B}"]["derived"].items()})
 for f in ("r02_bench_headline", "r02_bench_configs2", "r02_solve", "r02_p1_B1", "r02_p1_B128"):
     print("==", f); print("".join(open(os.path.join(DST, f + "_kernel_stats.csv")).readlines()[:5]))
