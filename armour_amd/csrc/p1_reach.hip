@@ -276,6 +276,7 @@ __device__ inline void rpy_matrix(double roll, double pitch, double yaw, double*
 
 // ------------------------------------------------------------------ per-wave state and slot pools
 struct Chain {
+    typedef PZ PZT;
     Wave w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -595,16 +596,22 @@ __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int 
 // RT/Dynamics.cu:69-81 + RT/armour_main.cu:121-124
 // Forward kinematics / forward occupancy (RT/Dynamics.cu:69-81), one joint per call so that role 2 can run it alongside
 // the RNEA phases of roles 0 and 1 (it shares nothing with them but the read-only JRS).
-struct FkState { PZ R, Rn, T; };
-__device__ PZW_NOINLINE void fk_begin(Chain& c, FkState& f) {
+// (templates on the chain type: the per-step chain of this file and the time-vectorised chain of p1_tv.inc.h run the same
+//  operator sequence and the same role choreography on two arithmetics; the operators are found by their argument types)
+template <class PZT> struct FkStateT { PZT R, Rn, T; };
+typedef FkStateT<PZ> FkState;
+template <class CH>
+__device__ PZW_NOINLINE void fk_begin(CH& c, FkStateT<typename CH::PZT>& f) {
     f.R = c.M(0); f.Rn = c.M(1);
     double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     set_const(c.w, f.R, id, nullptr);
     f.T = c.allocV();
     set_const(c.w, f.T, nullptr, nullptr);
 }
-__device__ PZW_NOINLINE void fk_step(Chain& c, FkState& f, int i, int b, int t) {
-    Wave& w = c.w;
+template <class CH>
+__device__ PZW_NOINLINE void fk_step(CH& c, FkStateT<typename CH::PZT>& f, int i, int b, int t) {
+    typedef typename CH::PZT PZ;
+    auto& w = c.w;
     PZ tp = c.mulMV(f.R, c.Ptr(i));
     PZ nt = c.add(f.T, tp);
     c.freeVs(tp); c.freeVs(f.T);
@@ -630,11 +637,13 @@ __device__ PZW_NOINLINE void fk_step(Chain& c, FkState& f, int i, int b, int t) 
 // A role allocates and frees only in its own part of the slot pool; what another role still reads is freed by its owner
 // after the next block barrier.  Results cross roles as slot indices in the LDS mailbox.
 enum { MB_WV = 0, MB_WDOT, MB_WAUX, MB_LACC, MB_F, MB_N = MB_F + ARMOUR_MAX_JOINTS, MB_A2 = MB_N + ARMOUR_MAX_JOINTS, MB_C2, MB_FF, MB_NN, MB_WORDS };
-__device__ PZW_NOINLINE void run_rnea(Chain& c, PZ* u, int b, int t) {
+template <class CH>
+__device__ PZW_NOINLINE void run_rnea(CH& c, typename CH::PZT* u, int b, int t) {
+    typedef typename CH::PZT PZ;
     const P1Cfg& cf = *c.cf;
-    Wave& w = c.w;
+    auto& w = c.w;
     const int J = c.J;
-    FkState fk;
+    FkStateT<PZ> fk;
     const bool with_fk = cf.fk_items == 0;  // otherwise another block runs this item's forward kinematics
     if (c.is(2) && with_fk) { c.role = 2; fk_begin(c, fk); }
     if (c.is(1)) {
@@ -1331,33 +1340,42 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
     static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
-    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 100; }();  // below this the per-step kernel is faster (measured: B = 48 at T = 100 is the break-even)
+    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 56; }();  // below this the per-step kernel is faster (measured: B = 28 at T = 100 is the break-even)
     if (h->mode != ARMOUR_MODE_ARMTD && (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= tv_min_groups)) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
-        const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv);
-        // Sort buffers of 4096 entries let several waves share a CU (the union raw-term counts seen are <= 2.4 k); a product that
-        // overflows them sends the launch to the next size.  While SIMDs would otherwise idle, the forward kinematics of every
-        // group runs as a work item of its own (a fifth of a chain that shares nothing with the RNEA but the JRS rotations).
-        const int caps[2] = {4096, 8192};
-        for (int ci = 0; ci < 2 && !built; ci++) {
-            const int cap = caps[ci];
-            // staging area for the short operand of a product: what is left of the CU's LDS at the wave count the sort buffers allow
-            const int per_cu = std::max(1, std::min(4, (int)((size_t)160 * 1024 / (tvchain::tv_lds_fixed(cap) + 24 * 1024))));
-            const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - tvchain::tv_lds_fixed(cap) - 256) / 512);
-            const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows);
+        // Block shapes, in the order tried: (a) while there is at most one group per CU, three waves per group -- the roles of
+        // run_rnea run concurrently, as in the per-step kernel's small launches: the latency of ONE chain is what such a batch pays;
+        // (b) one wave per group with sort buffers of 4096 entries (the union raw-term counts seen are <= 2.4 k), several waves per
+        // CU, the forward kinematics of every group as a work item of its own while slots are free; (c) the same with 8192 entries.
+        // A product that overflows the sort buffers sends the launch to the next shape; any other flag to the per-step path.
+        static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3
+        static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
+        struct Shape { int nw, cap; };
+        const Shape shapes[3] = {{kRoles, 4096}, {1, 4096}, {1, 8192}};
+        for (int si = 0; si < 3 && !built; si++) {
+            const int nw = shapes[si].nw, cap = shapes[si].cap;
+            if (nw == kRoles && (tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
+            if (nw == 1 && tv_nw_env == kRoles && si == 1) continue;
+            const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw);
+            // blocks per CU by LDS, with at least 8 KB of staging rows per wave; the staging area takes what is left
+            const size_t fixed = (size_t)nw * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_shared();
+            const int per_cu = nw == kRoles ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
+            if (fixed + (size_t)nw * 8 * 1024 > (size_t)160 * 1024 / per_cu) continue;
+            const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / ((size_t)nw * 512));
+            const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows, nw);
             const int slots = std::min(512, prop.multiProcessorCount * per_cu);
-            static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
-            const bool split = tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots;
+            const bool split = nw == kRoles ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
             const int fk_items = split ? groups : 0;
-            const int waves = std::min(groups + fk_items, slots);
-            if ((size_t)waves * TL.total > wk->tv_arena_total) {
+            const int blocks = std::min(groups + fk_items, slots);
+            if ((size_t)blocks * TL.total > wk->tv_arena_total) {
                 if (wk->tv_arena) (void)hipFree(wk->tv_arena);
                 wk->tv_arena = nullptr; wk->tv_arena_total = 0;
-                if (hipMalloc((void**)&wk->tv_arena, (size_t)waves * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
-                wk->tv_arena_total = (size_t)waves * TL.total;
+                if (hipMalloc((void**)&wk->tv_arena, (size_t)blocks * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
+                wk->tv_arena_total = (size_t)blocks * TL.total;
             }
-            HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             P1Cfg cf;
             memset(&cf, 0, sizeof(cf));
             cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
@@ -1374,7 +1392,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.n_items = groups; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
-            hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel, dim3(waves), dim3(WAVE), smem, h->stream, cf);
+            if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
+            else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(wk->ev1, h->stream));
             HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -1382,9 +1401,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
-            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d waves (%d per CU, %zu B LDS, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, waves, per_cu, smem, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d staging rows per wave, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw, per_cu, smem, stage_rows, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
-            else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next size
+            else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }
     }
     const int kFirstPassCap = 2048;

@@ -10,28 +10,31 @@ using tv::TView;
 using tv::TSeg;
 using tv::TW;
 
-constexpr int kTvNV = 32, kTvNS = 12, kTvNM = 2;
+constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots: 32 for one wave, 48 (split by role, kPartFirst / kPartCount) for three
 
-__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)cap * 8) + ((size_t)cap * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
+// (one spare key and one spare row block beyond `cap`)
+__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
 
 struct TLayout {
-    int nJM, nJV, nJS;
+    int nJM, nJV, nJS, nV, nroles;
     size_t offV, offS, offM, offJM, offJV, offJS, total;
     int idV, idS, idM, idJM, idJV, idJS;
 };
-__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW) {
+__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nroles) {
     TLayout L;
-    L.nJM = (J + 1) + J + 3 + J;  // R[0..J], R_t[0..J-1], raw rot, simplified rot, rpy; inertia
-    L.nJV = (J + 1) + J;          // trans P_i, link boxes
-    L.nJS = 3 * n + J + 4;        // qd, qda, qdda; mass; 4 raw temps
+    L.nroles = nroles;
+    L.nV = nroles == 1 ? kNVOneWave : kPartFirst[kRoles - 1] + kPartCount[kRoles - 1];
+    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
+    L.nJV = (J + 1) + J;                   // trans P_i, link boxes
+    L.nJS = 3 * n + J + 4 * nroles;        // qd, qda, qdda; mass; per role: 4 raw temps
     L.offV = 0;
-    L.offS = L.offV + (size_t)kTvNV * tv_slot_bytes(capW, 3);
+    L.offS = L.offV + (size_t)L.nV * tv_slot_bytes(capW, 3);
     L.offM = L.offS + (size_t)kTvNS * tv_slot_bytes(capW, 1);
     L.offJM = L.offM + (size_t)kTvNM * tv_slot_bytes(capW, 9);
     L.offJV = L.offJM + (size_t)L.nJM * tv_slot_bytes(kCapSmall, 9);
     L.offJS = L.offJV + (size_t)L.nJV * tv_slot_bytes(kCapSmall, 3);
     L.total = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1));
-    L.idV = 0; L.idS = L.idV + kTvNV; L.idM = L.idS + kTvNS; L.idJM = L.idM + kTvNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
+    L.idV = 0; L.idS = L.idV + L.nV; L.idM = L.idS + kTvNS; L.idJM = L.idM + kTvNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
     return L;
 }
 
@@ -39,20 +42,29 @@ __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index
     GLB_AS unsigned char* p = base + off + (size_t)index * tv_slot_bytes(cap, sz);
     TPZ z;
     z.keys = (GLB_AS uint64_t*)p;
-    z.hdr = (GLB_AS double*)(p + align64((size_t)cap * 8));
+    z.hdr = (GLB_AS double*)(p + align64((size_t)(cap + 1) * 8));
     z.coef = z.hdr + (size_t)4 * sz * 64;
     z.sz = sz; z.cap = cap; z.id = id0 + index;
     return z;
 }
 
+// The same interface as Chain above (run_rnea / fk_step are templates on it): roles, mailbox, slot pools, composite operators.
 struct TChain {
-    TW t;
+    typedef TPZ PZT;
+    TW w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
     TLayout L;
-    unsigned freeV, freeS;
-    int n, J;
-    int capW;
+    unsigned long long freeV;
+    unsigned freeS;
+    int n, J, capW;
+    int wid, nw;
+    LDS_AS int* mb;
+    int role = 0;
+    __device__ bool is(int r) const { return nw == 1 || wid == r; }
+    __device__ void bar() const { __syncthreads(); }
+    __device__ void post(int slot, const TPZ& p) const { if (w.w.lane == 0) mb[slot] = p.id - L.idV; }
+    __device__ TPZ take(int slot) const { return V(mb[slot]); }
     __device__ TPZ V(int i) const { return mk_tslot(arena, L.offV, i, capW, 3, L.idV); }
     __device__ TPZ S(int i) const { return mk_tslot(arena, L.offS, i, capW, 1, L.idS); }
     __device__ TPZ M(int i) const { return mk_tslot(arena, L.offM, i, capW, 9, L.idM); }
@@ -61,89 +73,91 @@ struct TChain {
     __device__ TPZ JS(int i) const { return mk_tslot(arena, L.offJS, i, kCapSmall, 1, L.idJS); }
     __device__ TPZ R(int i) const { return JM(i); }
     __device__ TPZ Rt(int i) const { return JM(J + 1 + i); }
-    __device__ TPZ rotRaw() const { return JM(2 * J + 1); }
-    __device__ TPZ rotS() const { return JM(2 * J + 2); }
-    __device__ TPZ rpy() const { return JM(2 * J + 3); }
-    __device__ TPZ inertia(int i) const { return JM(2 * J + 4 + i); }
+    __device__ int scratch(int r) const { return L.nroles == 1 ? 0 : r; }
+    __device__ TPZ rotRaw(int r) const { return JM(2 * J + 1 + 3 * scratch(r)); }
+    __device__ TPZ rotS(int r) const { return JM(2 * J + 2 + 3 * scratch(r)); }
+    __device__ TPZ rpy(int r) const { return JM(2 * J + 3 + 3 * scratch(r)); }
+    __device__ TPZ inertia(int i) const { return JM(2 * J + 1 + 3 * L.nroles + i); }
     __device__ TPZ Ptr(int i) const { return JV(i); }
     __device__ TPZ linkbox(int i) const { return JV(J + 1 + i); }
     __device__ TPZ qd(int i) const { return JS(i); }
     __device__ TPZ qda(int i) const { return JS(n + i); }
     __device__ TPZ qdda(int i) const { return JS(2 * n + i); }
     __device__ TPZ mass(int i) const { return JS(3 * n + i); }
-    __device__ TPZ rawS(int i) const { return JS(3 * n + J + i); }
+    __device__ TPZ rawS(int r, int i) const { return JS(3 * n + J + 4 * scratch(r) + i); }
 
     __device__ TPZ allocV() {
-        const int i = __ffs(freeV) - 1;
-        if (i < 0) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); return V(0); }
-        freeV &= ~(1u << i);
+        const unsigned long long part = L.nroles == 1 ? ~0ull : ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role];
+        const int i = __ffsll((long long)(freeV & part)) - 1;
+        if (i < 0) { pzw::flag(w.w, pzw::ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : kPartFirst[role]); }
+        freeV &= ~(1ull << i);
         return V(i);
     }
-    __device__ void freeVs(const TPZ& p) { freeV |= 1u << (p.id - L.idV); }
+    __device__ void freeVs(const TPZ& p) { freeV |= 1ull << (p.id - L.idV); }
     __device__ TPZ allocS() {
         const int i = __ffs(freeS) - 1;
-        if (i < 0) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); return S(0); }
+        if (i < 0) { pzw::flag(w.w, pzw::ERR_SLOT_OVERFLOW); return S(0); }
         freeS &= ~(1u << i);
         return S(i);
     }
 
     __device__ TPZ add(const TPZ& a, const TPZ& b, double sb = 1.0) {
         TPZ o = allocV();
-        TSeg s[2] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), sb, -1}};
-        tv::lincomb<3, 2, false>(t, o, s);
+        TSeg s[2] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, b), sb, -1}};
+        tv::lincomb<3, 2, false>(w, o, s);
         return o;
     }
     __device__ TPZ addOneDim(const TPZ& p, const TPZ& a, int r) {
         TPZ o = allocV();
-        TSeg s[2] = {{tv::view(t, p), 1.0, -1}, {tv::view(t, a), 1.0, r}};
-        tv::lincomb<3, 2, false>(t, o, s);
+        TSeg s[2] = {{tv::view(w, p), 1.0, -1}, {tv::view(w, a), 1.0, r}};
+        tv::lincomb<3, 2, false>(w, o, s);
         return o;
     }
     __device__ TPZ sum3(const TPZ& a, const TPZ& b, const TPZ& c3, int comp_c = -1) {
         TPZ o = allocV();
-        TSeg s[3] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), 1.0, -1}, {tv::view(t, c3), 1.0, comp_c}};
-        tv::lincomb<3, 3, true>(t, o, s);
+        TSeg s[3] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, b), 1.0, -1}, {tv::view(w, c3), 1.0, comp_c}};
+        tv::lincomb<3, 3, true>(w, o, s);
         return o;
     }
     __device__ TPZ sum4(const TPZ& a, const TPZ& b, const TPZ& c3, const TPZ& d) {
         TPZ o = allocV();
-        TSeg s[4] = {{tv::view(t, a), 1.0, -1}, {tv::view(t, b), 1.0, -1}, {tv::view(t, c3), 1.0, -1}, {tv::view(t, d), 1.0, -1}};
-        tv::lincomb<3, 4, true>(t, o, s);
+        TSeg s[4] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, b), 1.0, -1}, {tv::view(w, c3), 1.0, -1}, {tv::view(w, d), 1.0, -1}};
+        tv::lincomb<3, 4, true>(w, o, s);
         return o;
     }
     __device__ TPZ comb3(const TView& a, double sa, const TView& b, double sb, const TView& c3, double sc) {
         TPZ o = allocS();
         TSeg s[3] = {{a, sa, -1}, {b, sb, -1}, {c3, sc, -1}};
-        tv::lincomb<1, 3, true>(t, o, s);
+        tv::lincomb<1, 3, true>(w, o, s);
         return o;
     }
     __device__ TPZ crossPzMat(const TPZ& a, const double* b) {  // a x b
         TPZ o = allocV();
         const double sA[3] = {b[2], b[0], b[1]}, sB[3] = {-b[1], -b[2], -b[0]};
         const int cA[3] = {1, 2, 0}, cB[3] = {2, 0, 1};
-        tv::cross_const(t, o, tv::view(t, a), sA, cA, sB, cB);
+        tv::cross_const(w, o, tv::view(w, a), sA, cA, sB, cB);
         return o;
     }
     __device__ TPZ crossMatPz(const double* a, const TPZ& b) {  // a x b
         TPZ o = allocV();
         const double sA[3] = {a[1], a[2], a[0]}, sB[3] = {-a[2], -a[0], -a[1]};
         const int cA[3] = {2, 0, 1}, cB[3] = {1, 2, 0};
-        tv::cross_const(t, o, tv::view(t, b), sA, cA, sB, cB);
+        tv::cross_const(w, o, tv::view(w, b), sA, cA, sB, cB);
         return o;
     }
     __device__ TPZ crossPzPz(const TPZ& a, const TPZ& b) {
         TPZ o = allocV();
-        tv::cross_pzpz(t, o, tv::view(t, a), tv::view(t, b));
+        tv::cross_pzpz(w, o, tv::view(w, a), tv::view(w, b));
         return o;
     }
     __device__ TPZ mulMV(const TPZ& A, const TPZ& v) {
         TPZ o = allocV();
-        tv::mul<3, 3, 3, 1>(t, o, tv::view(t, A), tv::view(t, v));
+        tv::mul<3, 3, 3, 1>(w, o, tv::view(w, A), tv::view(w, v));
         return o;
     }
     __device__ TPZ mulSV(const TPZ& s, const TPZ& v) {
         TPZ o = allocV();
-        tv::mul<1, 1, 3, 1>(t, o, tv::view(t, s), tv::view(t, v));
+        tv::mul<1, 1, 3, 1>(w, o, tv::view(w, s), tv::view(w, v));
         return o;
     }
 };
@@ -151,7 +165,7 @@ struct TChain {
 // a raw (unsimplified) small PZ with per-lane coefficients, then simplify() into `out` (RT/PZsparse.cu:120-136,179-205)
 template <int SZ>
 __device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
-    const int lane = c.t.w.lane;
+    const int lane = c.w.w.lane;
     for (int e = 0; e < SZ; e++) {
         tv::st_hdr(raw, tv::H_CEN, e, lane, cen[e]);
         tv::st_hdr(raw, tv::H_IND, e, lane, 0.0);
@@ -162,18 +176,21 @@ __device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& ou
         if (lane == 0) raw.keys[i] = keys[i];
         for (int e = 0; e < SZ; e++) raw.coef[((size_t)i * SZ + e) * 64 + lane] = coefs[i * SZ + e];
     }
-    if (lane == 0) c.t.w.cnt[raw.id] = m;
+    if (lane == 0) c.w.w.cnt[raw.id] = m;
     WSYNC();
-    TSeg s[1] = {{tv::view(c.t, raw), 1.0, -1}};
-    tv::lincomb<SZ, 1, false>(c.t, out, s);
+    TSeg s[1] = {{tv::view(c.w, raw), 1.0, -1}};
+    tv::lincomb<SZ, 1, false>(c.w, out, s);
 }
 
-// JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations)
+// JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations).
+// Joint i is built by role i % 3 with that role's scratch slots; the caller follows with a block barrier.
 __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_only) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
     for (int i = 0; i < J; i++) {
+        const int role = i % kRoles;
+        if (!c.is(role)) continue;
         double rp[9];
         rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
         if (i < n && cf.rb.axes[i] != 0) {
@@ -186,56 +203,59 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
             make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
             make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
             const uint64_t keys[4] = {kk, kc, kk, ks};
-            build_simplified<9>(c, c.rotRaw(), c.rotS(), cen, 4, keys, co);
-            tv::set_const(c.t, c.rpy(), rp, nullptr);
-            tv::mul<3, 3, 3, 3>(c.t, c.R(i), tv::view(c.t, c.rpy()), tv::view(c.t, c.rotS()));
+            build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
+            tv::set_const(c.w, c.rpy(role), rp, nullptr);
+            tv::mul<3, 3, 3, 3>(c.w, c.R(i), tv::view(c.w, c.rpy(role)), tv::view(c.w, c.rotS(role)));
             if (!kin_only) {
-            {
-                const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
-                const double co2[2] = {js.qd_k, js.qd_e};
-                build_simplified<1>(c, c.rawS(0), c.qd(i), &js.qd_c, 2, k2, co2);
-            }
-            {
-                const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
-                const double co2[2] = {js.qd_k, js.qda_e};
-                build_simplified<1>(c, c.rawS(0), c.qda(i), &js.qd_c, 2, k2, co2);
-            }
-            {
-                const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
-                const double co2[2] = {js.qdd_k, js.qdd_e};
-                build_simplified<1>(c, c.rawS(0), c.qdda(i), &js.qdd_c, 2, k2, co2);
-            }
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
+                    const double co2[2] = {js.qd_k, js.qd_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
+                }
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
+                    const double co2[2] = {js.qd_k, js.qda_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
+                }
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
+                    const double co2[2] = {js.qdd_k, js.qdd_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+                }
             }
         } else {
-            tv::set_const(c.t, c.R(i), rp, nullptr);
+            tv::set_const(c.w, c.R(i), rp, nullptr);
         }
-        if (!kin_only) tv::transpose33(c.t, c.Rt(i), c.R(i));
-        tv::set_const(c.t, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+        if (!kin_only) tv::transpose33(c.w, c.Rt(i), c.R(i));
+        tv::set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
         if (!kin_only) {
             double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
             double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            tv::set_const(c.t, c.mass(i), &cf.rb.mass[i], zero9, &mi);
+            tv::set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
             double ii[9];
             for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
-            tv::set_const(c.t, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+            tv::set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
         }
         for (int j = 0; j < 3; j++) {
             const uint64_t key = 1ull << ((j + 2) * n);
-            build_simplified<1>(c, c.rawS(0), c.rawS(1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+            build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
         }
-        TSeg s[3] = {{tv::view(c.t, c.rawS(1)), 1.0, 0}, {tv::view(c.t, c.rawS(2)), 1.0, 1}, {tv::view(c.t, c.rawS(3)), 1.0, 2}};
-        tv::lincomb<3, 3, false>(c.t, c.linkbox(i), s);
+        TSeg s[3] = {{tv::view(c.w, c.rawS(role, 1)), 1.0, 0}, {tv::view(c.w, c.rawS(role, 2)), 1.0, 1}, {tv::view(c.w, c.rawS(role, 3)), 1.0, 2}};
+        tv::lincomb<3, 3, false>(c.w, c.linkbox(i), s);
     }
-    double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    tv::set_const(c.t, c.R(J), id, nullptr);
-    tv::set_const(c.t, c.Ptr(J), &cf.rb.trans[3 * J], nullptr);
+    if (c.is(0)) {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        tv::set_const(c.w, c.R(J), id, nullptr);
+        tv::set_const(c.w, c.Ptr(J), &cf.rb.trans[3 * J], nullptr);
+    }
 }
 
 // reduce_link_PZ (RT/PZsparse.cu:370-402) + the final link table entry, per lane.  Which class a monomial belongs to depends
 // on its key alone (wave-uniform); whether a lane HAS the monomial is whether its coefficient vector is non-zero.
-__device__ TV_NOINLINE void emit_link_tv(TChain& c, const TPZ& p, int b, int l, int t_lane) {
+// (Found by fk_step through its chain argument; `t_lane` is this lane's time step.)
+__device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int t_lane) {
     const P1Cfg& cf = *c.cf;
-    TW& t = c.t;
+    TW& t = c.w;
     const int lane = t.w.lane;
     const int n = c.n, cnt = tv::uni(t.w.cnt[p.id]);
     const uint64_t kmax = 1ull << (2 * n), lmax = 1ull << (5 * n), kmask = kmax - 1;
@@ -290,121 +310,10 @@ __device__ TV_NOINLINE void emit_link_tv(TChain& c, const TPZ& p, int b, int l, 
     WSYNC();
 }
 
-struct TFk { TPZ R, Rn, T; };
-
-__device__ TV_NOINLINE void fk_step_tv(TChain& c, TFk& f, int i, int b, int t_lane) {
-    TPZ tp = c.mulMV(f.R, c.Ptr(i));
-    TPZ nt = c.add(f.T, tp);
-    c.freeVs(tp); c.freeVs(f.T);
-    f.T = nt;
-    tv::mul<3, 3, 3, 3>(c.t, f.Rn, tv::view(c.t, f.R), tv::view(c.t, c.R(i)));
-    { TPZ s = f.R; f.R = f.Rn; f.Rn = s; }
-    TPZ l1 = c.mulMV(f.R, c.linkbox(i));
-    TPZ lk = c.add(l1, f.T);
-    emit_link_tv(c, lk, b, i, t_lane);
-    c.freeVs(l1); c.freeVs(lk);
-}
-
-// RT/Dynamics.cu:83-181 with nominal and interval parameters in one pass, and the forward kinematics; same operator order
-// as run_rnea in a 1-wave block.
-__device__ TV_NOINLINE void run_rnea_tv(TChain& c, TPZ* u, int b, int t_lane, bool with_fk) {
-    const P1Cfg& cf = *c.cf;
-    TW& t = c.t;
-    const int J = c.J;
-    TFk fk;
-    fk.R = c.M(0); fk.Rn = c.M(1);
-    if (with_fk) {
-        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        tv::set_const(t, fk.R, id, nullptr);
-        fk.T = c.allocV();
-        tv::set_const(t, fk.T, nullptr, nullptr);
-    }
-    TPZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV(), lacc = c.allocV();
-    tv::set_const(t, wv, nullptr, nullptr);
-    tv::set_const(t, wdot, nullptr, nullptr);
-    tv::set_const(t, waux, nullptr, nullptr);
-    {
-        double g[3] = {0.0, 0.0, cf.rb.gravity};
-        tv::set_const(t, lacc, g, nullptr);
-    }
-    TPZ F[ARMOUR_MAX_JOINTS], N[ARMOUR_MAX_JOINTS];
-    for (int s = 0; s <= J; s++) {
-        TPZ nl = lacc, nw = wv, nd = wdot, na = waux;
-        if (s < J) {
-            {   // linear_acc = R_t * (linear_acc + cross(wdot, tr) + cross(w, cross(w_aux, tr)))
-                const double* tr = &cf.rb.trans[3 * s];
-                TPZ c1 = c.crossPzMat(wdot, tr);
-                TPZ c2 = c.crossPzMat(waux, tr);
-                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-                TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
-                nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
-            }
-            {
-                const TPZ Rt = c.Rt(s);
-                const int ax = abs(cf.rb.axes[s]) - 1;
-                nw = c.mulMV(Rt, wv);
-                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
-                na = c.mulMV(Rt, waux);
-                nd = c.mulMV(Rt, wdot);
-                if (cf.rb.axes[s] != 0) {
-                    TPZ zero = c.allocV();
-                    tv::set_const(t, zero, nullptr, nullptr);
-                    TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
-                    TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
-                    TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
-                    TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
-                }
-            }
-        }
-        if (s >= 1) {
-            {   // N = I * wdot + cross(w_aux, I * w)
-                const TPZ I = c.inertia(s - 1);
-                TPZ t1 = c.mulMV(I, wdot);
-                TPZ t2 = c.mulMV(I, wv);
-                TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
-                N[s - 1] = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
-            }
-            {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
-                const double* cm = &cf.rb.com[3 * (s - 1)];
-                TPZ c1 = c.crossPzMat(wdot, cm);
-                TPZ c2 = c.crossPzMat(waux, cm);
-                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-                TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
-                F[s - 1] = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
-            }
-        }
-        if (s < J && with_fk) fk_step_tv(c, fk, s, b, t_lane);
-        c.freeVs(wv); c.freeVs(wdot); c.freeVs(waux); c.freeVs(lacc);
-        wv = nw; wdot = nd; waux = na; lacc = nl;
-        if (s == J) break;  // (the state of joint J-1 was freed above; nothing new was allocated for s == J)
-    }
-    if (with_fk) c.freeVs(fk.T);
-    TPZ nn = c.allocV(), f = c.allocV();
-    tv::set_const(t, nn, nullptr, nullptr);
-    tv::set_const(t, f, nullptr, nullptr);
-    for (int i = J - 1; i >= 0; i--) {
-        const TPZ Rn = c.R(i + 1);
-        TPZ a1 = c.mulMV(Rn, nn);
-        TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], F[i]);
-        TPZ a2 = c.mulMV(Rn, f);
-        TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
-        TPZ n2 = c.sum4(N[i], a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);
-        nn = n2;
-        if (cf.rb.axes[i] != 0) {
-            const int ax = abs(cf.rb.axes[i]) - 1;
-            u[i] = c.comb3(tv::elem(t, n2, ax), 1.0, tv::view(t, c.qdda(i)), cf.rb.armature[i], tv::view(t, c.qd(i)), cf.rb.damping[i]);
-        }
-        TPZ f2 = c.add(a2, F[i]); c.freeVs(f);
-        f = f2;
-        c.freeVs(a2); c.freeVs(c2); c.freeVs(N[i]); c.freeVs(F[i]);
-    }
-    c.freeVs(nn); c.freeVs(f);
-}
-
 // disturbance, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205), per lane; see finish_torque above
 __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t_lane) {
     const P1Cfg& cf = *c.cf;
-    TW& t = c.t;
+    TW& t = c.w;
     const int lane = t.w.lane;
     const int n = c.n, T = cf.T;
     const uint64_t kmax = 1ull << (2 * n);
@@ -455,82 +364,95 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
     WSYNC();
 }
 
-// LDS of one wave: sort buffers | status | count table | staging rows for a product's short operand
-__host__ __device__ inline size_t tv_lds_fixed(int cap) { return (((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15) + kMaxSlots * sizeof(int); }
-__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
+// LDS: NW x { sort buffers skey[cap] | sidx[cap] | status | staging rows for a product's short operand } | count table | mailbox
+__host__ __device__ inline size_t tv_lds_fixed(int cap) { return ((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
+__host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + MB_WORDS) * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int nw) { return (size_t)nw * tv_lds_wave(cap, stage_rows) + tv_lds_shared(); }
 
-// grid: one 64-lane block per resident wave, striding over the (problem, time group) items; group g of a problem holds the
-// time steps [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).
-__global__ __launch_bounds__(64) void armour_p1_tv_kernel(P1Cfg cf) {
+// One block per (problem, time group) item, striding over the items; group g of a problem holds the time steps
+// [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).  NW = 1: one wave plays every role in turn.  NW = 3: the roles of
+// run_rnea run concurrently on three waves, each with its own sort buffers and staging rows (one block per CU: the latency of
+// a chain is what a batch of 128 problems pays).
+// items [0, n_items): the RNEA of a group; with fk_items > 0, items [n_items, n_items + fk_items) are the forward kinematics
+// of group (it - n_items) -- it shares nothing with the RNEA but the JRS rotations, which it rebuilds -- and the first n_items
+// then leave it out (the same split as the per-step kernel's).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
     const int groups_per_problem = cf.tv_groups, lanes_per_group = cf.tv_lanes, capTv = cf.tv_cap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TChain c;
     c.cf = &cf;
     c.n = cf.n; c.J = cf.J;
     c.capW = capTv;
-    c.L = make_tlayout(cf.J, cf.n, capTv);
+    c.L = make_tlayout(cf.J, cf.n, capTv, NW);
     c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
+    c.nw = NW;
+    c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
-    c.t.w.skey = (LDS_AS uint64_t*)lds;
-    c.t.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
-    c.t.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
-    c.t.w.cnt = (LDS_AS int*)(lds + ((((size_t)cf.capKey * 10 + pzw::ST_WORDS * sizeof(int)) + 15) & ~(size_t)15));
-    c.t.stage = (LDS_AS double*)(lds + tv_lds_fixed(cf.capKey));
-    c.t.stage_rows = cf.tv_stage_rows;
-    c.t.w.cap_raw = cf.capRaw;
-    c.t.w.cap_key = cf.capKey;
-    c.t.w.thr = cf.pr.simplify_threshold;
-    c.t.w.thr_sq = pzw::sq_threshold(c.t.w.thr);
-    c.t.w.lane = threadIdx.x;
-    if (threadIdx.x < pzw::ST_WORDS) c.t.w.lstat[threadIdx.x] = 0;
-    // items [0, n_items): the RNEA of a group; with fk_items > 0, items [n_items, n_items + fk_items) are the forward
-    // kinematics of group (it - n_items) -- it shares nothing with the RNEA but the JRS rotations, which it rebuilds -- and
-    // the first n_items then leave it out (the same split as the per-step kernel's)
+    LDS_AS unsigned char* mine = lds + (size_t)c.wid * tv_lds_wave(cf.capKey, cf.tv_stage_rows);
+    c.w.w.skey = (LDS_AS uint64_t*)mine;
+    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
+    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 10);
+    c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(cf.capKey));
+    c.w.stage_rows = cf.tv_stage_rows;
+    LDS_AS unsigned char* shared = lds + (size_t)NW * tv_lds_wave(cf.capKey, cf.tv_stage_rows);
+    c.w.w.cnt = (LDS_AS int*)shared;
+    c.mb = c.w.w.cnt + kMaxSlots;
+    c.w.w.cap_raw = cf.capRaw;
+    c.w.w.cap_key = cf.capKey;
+    c.w.w.thr = cf.pr.simplify_threshold;
+    c.w.w.thr_sq = pzw::sq_threshold(c.w.w.thr);
+    c.w.w.lane = threadIdx.x & 63;
+    const int lane = c.w.w.lane;
+    if (lane < pzw::ST_WORDS) c.w.w.lstat[lane] = 0;
     for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
         const bool fk_only = it0 >= cf.n_items;
         const int it = fk_only ? it0 - cf.n_items : it0;
         const int b = it / groups_per_problem, g = it - b * groups_per_problem;
         const int t0 = g * lanes_per_group;
         const int nl = min(lanes_per_group, cf.T - t0);
-        c.t.active = (int)threadIdx.x < nl;
-        const int t_lane = t0 + min((int)threadIdx.x, nl - 1);  // idle lanes shadow the group's last step; they never write
-        c.freeV = 0xffffffffu; c.freeS = (1u << kTvNS) - 1u;
-        for (int i = threadIdx.x; i < kMaxSlots; i += 64) c.t.w.cnt[i] = 0;
+        c.w.active = lane < nl;
+        const int t_lane = t0 + min(lane, nl - 1);  // idle lanes shadow the group's last step; they never write
+        c.freeV = (1ull << c.L.nV) - 1ull;
+        c.freeS = (1u << kTvNS) - 1u;
+        c.role = 0;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.w.cnt[i] = 0;
         __syncthreads();
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
-        c.t.c_sort = c.t.c_walk = c.t.c_cc = c.t.n_raw = c.t.n_calls = c.t.n_emit = 0;
-        for (int q = 0; q < 3; q++) { c.t.c_type[q] = 0; c.t.n_type[q] = 0; }
+        c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
+        for (int q = 0; q < 3; q++) { c.w.c_type[q] = 0; c.w.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane, fk_only);
+        __syncthreads();
 #ifdef TV_PROFILE
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] jrs %lld cycles\n", it, (long long)clock64() - tvp_start);
 #endif
         TPZ u_nom[ARMOUR_MAX_FACTORS];
         if (fk_only) {
-            TFk fk;
-            fk.R = c.M(0); fk.Rn = c.M(1);
-            double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            tv::set_const(c.t, fk.R, id, nullptr);
-            fk.T = c.allocV();
-            tv::set_const(c.t, fk.T, nullptr, nullptr);
-            for (int i = 0; i < c.J; i++) fk_step_tv(c, fk, i, b, t_lane);
-            c.freeVs(fk.T);
+            if (c.is(2)) {
+                FkStateT<TPZ> fk;
+                c.role = 2;
+                fk_begin(c, fk);
+                for (int i = 0; i < c.J; i++) fk_step(c, fk, i, b, t_lane);
+                c.freeVs(fk.T);
+            }
         } else {
-            run_rnea_tv(c, u_nom, b, t_lane, cf.fk_items == 0);
-            finish_torque_tv(c, u_nom, b, t_lane);
+            run_rnea(c, u_nom, b, t_lane);
+            if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane);
         }
         __syncthreads();
 #ifdef TV_PROFILE
-        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.t.c_type[0], c.t.n_type[0], c.t.c_type[1], c.t.n_type[1], c.t.c_type[2], c.t.n_type[2]);
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
-        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] total %lld cycles: sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, (long long)clock64() - tvp_start, c.t.c_sort, c.t.c_walk, c.t.c_cc, c.t.n_calls, c.t.n_raw, c.t.n_emit);
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles: sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif
     }
-    if (threadIdx.x == 0) {
-        if (c.t.w.lstat[pzw::ST_ERR]) atomicOr(&cf.status[pzw::ST_ERR], (unsigned)c.t.w.lstat[pzw::ST_ERR]);
-        atomicMax(&cf.status[pzw::ST_MAX_RAW], (unsigned)c.t.w.lstat[pzw::ST_MAX_RAW]);
-        atomicMax(&cf.status[pzw::ST_MAX_OUT], (unsigned)c.t.w.lstat[pzw::ST_MAX_OUT]);
+    if (lane == 0) {  // every wave reports its own flags and maxima
+        if (c.w.w.lstat[pzw::ST_ERR]) atomicOr(&cf.status[pzw::ST_ERR], (unsigned)c.w.w.lstat[pzw::ST_ERR]);
+        atomicMax(&cf.status[pzw::ST_MAX_RAW], (unsigned)c.w.w.lstat[pzw::ST_MAX_RAW]);
+        atomicMax(&cf.status[pzw::ST_MAX_OUT], (unsigned)c.w.w.lstat[pzw::ST_MAX_OUT]);
     }
 }
 

@@ -310,11 +310,7 @@ def test_more_work_items_than_resident_waves():
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
 
 
-def test_two_pass_build_of_large_batches():
-    """From 16 items per CU on, the build first runs every (problem, time step) item with 2048-entry sort buffers (four
-    waves per CU) and rebuilds only the items that overflowed them with the full buffers: the tables must equal those of
-    single-problem handles (one pass, full buffers) bit for bit, including for a fast initial state whose products are
-    the ones that overflow."""
+def _two_pass_build_body():
     from armour_amd.planner import ArmourNLP
     from armour_amd.worlds import random_batch, random_k
     T, O, B = 100, 1, 42
@@ -329,6 +325,48 @@ def test_two_pass_build_of_large_batches():
         assert np.array_equal(g[b], g1[0]) and np.array_equal(jac[b], j1[0])
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
         assert np.array_equal(nlp.link_generators()[b], one.link_generators()[0])
+
+
+def test_two_pass_build_of_large_batches():
+    """The per-step kernel, from 16 items per CU on, first runs every (problem, time step) item with 2048-entry sort buffers
+    (four waves per CU) and rebuilds only the items that overflowed them with the full buffers: the tables must equal those
+    of single-problem handles (one pass, full buffers) bit for bit, including for a fast initial state whose products are
+    the ones that overflow.  A batch of this size is built time-vectorised by default (pz_tv.h), so the check runs in a
+    process of its own with ARMOUR_P1_TV=0 (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._two_pass_build_body(); print('two-pass ok')" % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ARMOUR_P1_TV="0"), cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "two-pass ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_batch_built_time_vectorised_against_single_problem_handles():
+    """The same batch in the default configuration: B = 42 is built time-vectorised (three waves per group of 50 time
+    steps), the single-problem handles step by step.  Keys, coefficients and centres equal bit for bit; radii, and through
+    them g, to rounding (the two kernels add the pruned amounts in different orders)."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, O, B = 100, 1, 42
+    bp = random_batch(500, B, O)
+    bp["qd0"][5] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = random_k(9, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b in (0, 5, 23, 41):
+        one = ArmourNLP(T=T).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        g1, j1 = one.eval_g_jac(ks[b])
+        assert np.abs(g[b] - g1[0]).max() <= 1e-12 * max(1.0, np.abs(g1[0]).max()) and np.abs(jac[b] - j1[0]).max() <= 1e-12 * max(1.0, np.abs(j1[0]).max())
+        assert np.abs(nlp.torque_radius()[b] - one.torque_radius()[0]).max() <= 1e-12
+        assert np.abs(nlp.link_generators()[b] - one.link_generators()[0]).max() <= 1e-12
+        for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
+            for i in range(cnt):
+                for t in (0, 49, 50, 99):
+                    c1, i1, k1, co1 = nlp.pz(which, i, t, b=b)
+                    c2, i2, k2, co2 = one.pz(which, i, t)
+                    assert np.array_equal(k1, k2) and np.array_equal(co1, co2) and np.array_equal(c1, c2), (b, which, i, t)
+                    assert np.abs(i1 - i2).max() <= 1e-12
+        one.close()
+    nlp.close()
 
 
 def test_two_handles_from_two_host_threads():
