@@ -101,6 +101,20 @@ struct Wave {
     int lane;
 };
 
+// Arguments of the (non-inlined) operators arrive by reference, i.e. as pointers into the caller's stack frame: every `w.field`,
+// `a.cnt`, `out.keys` inside a loop is a flat load the compiler may not hoist across the loop's stores, and a count read that way
+// is a per-lane value -- as a loop bound it puts the loop under divergent control flow.  The operators therefore start by
+// taking local copies (PZW_LOCALS) with the counts moved to scalar registers.
+__device__ inline int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline View uni_view(const View& v) { View u = v; u.cnt = uni_i(v.cnt); u.stride = uni_i(v.stride); u.off = uni_i(v.off); return u; }
+__device__ inline void uni_caps(struct Wave& w);
+#ifdef P1_PROFILE
+#define PZW_WAVE_LOCAL(w, w_) Wave& w = w_;
+#else
+#define PZW_WAVE_LOCAL(w, w_) Wave w = w_; uni_caps(w);
+#endif
+__device__ inline void uni_caps(Wave& w) { w.cap_raw = uni_i(w.cap_raw); w.cap_key = uni_i(w.cap_key); }
+__device__ inline PZ uni_pz(const PZ& p) { PZ u = p; u.cap = uni_i(p.cap); u.id = uni_i(p.id); return u; }
 __device__ inline View view(const Wave& w, const PZ& p) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, 0, p.sz}; }
 __device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, r, 1}; }
 
@@ -293,7 +307,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
     double ra[SZ];
 #pragma unroll
     for (int e = 0; e < SZ; e++) ra[e] = 0.0;
-    N = sort_terms(w, N, ev, indirect);
+    N = uni_i(sort_terms(w, N, ev, indirect));
     if (N > 0) {
         PROF_T0
         for (int base = 0; base < N; base += WAVE) {
@@ -451,7 +465,9 @@ struct LinEval {
 };
 
 template <int SZ, int NS>
-__device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
+__device__ PZW_NOINLINE void lincomb(Wave& w_, const PZ& out_, const Seg* segs) {
+    PZW_WAVE_LOCAL(w, w_)
+    const PZ out = uni_pz(out_);
     PROF_CALL_T0
     LinEval<SZ, NS> ev;
     int N = 0;
@@ -461,9 +477,10 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         ev.s[k] = segs[k];
+        ev.s[k].v = uni_view(segs[k].v);
         ev.off[k] = N;
-        N += segs[k].v.cnt;
-        const View& v = segs[k].v;
+        N += ev.s[k].v.cnt;
+        const View& v = ev.s[k].v;
         const double sc = segs[k].scale, asc = fabs(sc);
         if (segs[k].comp < 0) {
 #pragma unroll
@@ -496,7 +513,9 @@ __device__ PZW_NOINLINE void lincomb(Wave& w, const PZ& out, const Seg* segs) {
 // pruned into that stage's radius if its norm is <= threshold and takes no part in the later stages, exactly as the
 // intermediate PZ would have lost it.  Centre and radii are accumulated in the composed order.  NS = 2 is lincomb.
 template <int SZ, int NS>
-__device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* segs) {
+__device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* segs) {
+    PZW_WAVE_LOCAL(w, w_)
+    const PZ out = uni_pz(out_);
     PROF_CALL_T0
     LinEval<SZ, NS> ev;
     int N = 0;
@@ -506,9 +525,10 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         ev.s[k] = segs[k];
+        ev.s[k].v = uni_view(segs[k].v);
         ev.off[k] = N;
-        N += segs[k].v.cnt;
-        const View& v = segs[k].v;
+        N += ev.s[k].v.cnt;
+        const View& v = ev.s[k].v;
         const double sc = segs[k].scale, asc = fabs(sc);
 #pragma unroll
         for (int e = 0; e < SZ; e++) { indk[k][e] = 0.0; ind2k[k][e] = 0.0; }
@@ -540,7 +560,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w, const PZ& out, const Seg* se
     for (int k = 0; k < NS; k++)
 #pragma unroll
         for (int e = 0; e < SZ; e++) ra[k][e] = 0.0;
-    N = sort_terms(w, N, ev, indirect);
+    N = uni_i(sort_terms(w, N, ev, indirect));
     if (N > 0) {
         PROF_T0
         for (int base = 0; base < N; base += WAVE) {
@@ -920,7 +940,10 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
 
 #ifndef PZW_HASH_PRODUCTS  /* the shipped product: sort ALL raw terms.  -DPZW_HASH_PRODUCTS: the hash-classified product of pz_hash.h (experimental, see its header) */
 template <int AR, int AC, int BR, int BC>
-__device__ PZW_NOINLINE void mul(Wave& w, const PZ& out, const View& a, const View& b) {
+__device__ PZW_NOINLINE void mul(Wave& w_, const PZ& out_, const View& a_, const View& b_) {
+    PZW_WAVE_LOCAL(w, w_)
+    const PZ out = uni_pz(out_);
+    const View a = uni_view(a_), b = uni_view(b_);
 #ifdef H1_FORCE_RA_SAVE  /* root-cause tooling: make this function save its return address on the stack, as the select form does */
     asm volatile("; return address clobbered on purpose" ::: "s30", "s31");
 #endif
@@ -994,7 +1017,10 @@ struct CrossEval : MulEval<MulShape<1, 1, 1, 1>> {
     }
 };
 
-__device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, const View& b) {
+__device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_, const View& b_) {
+    PZW_WAVE_LOCAL(w, w_)
+    const PZ out = uni_pz(out_);
+    const View a = uni_view(a_), b = uni_view(b_);
     PROF_CALL_T0
     CrossEval ev;
     ev.a = a; ev.set_b(b);
@@ -1022,7 +1048,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
     int emitted = 0;
     bool any_pruned = false, indirect = false;
     double raP[6] = {0, 0, 0, 0, 0, 0}, raR[3] = {0, 0, 0}, raS[3] = {0, 0, 0};
-    N = sort_terms(w, N, ev, indirect);
+    N = uni_i(sort_terms(w, N, ev, indirect));
     if (N > 0) {
         PROF_T0
         for (int base = 0; base < N; base += WAVE) {
@@ -1135,8 +1161,11 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w, const PZ& out, const View& a, c
 // simplify() just adds the two coefficients per key and prunes |.| <= threshold -- and then stack()s the three
 // entries, whose simplify() merges equal keys with disjoint non-zero entries and prunes by the 3-vector norm.
 // Because the key list never changes, the whole thing is one ordered pass over a's monomials: no sort.
-__device__ PZW_NOINLINE void cross_const(Wave& w, const PZ& out, const View& a, const double* sA, const int* cA,
+__device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a_, const double* sA, const int* cA,
                                    const double* sB, const int* cB) {
+    PZW_WAVE_LOCAL(w, w_)
+    const PZ out = uni_pz(out_);
+    const View a = uni_view(a_);
     double cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
