@@ -102,11 +102,7 @@ struct Out {
         for (int e = 0; e < SZ; e++) asum[e] = 0.0;
     }
     __device__ inline void emit(uint64_t key, const double* v) {
-#ifdef TV_EXP_NOSTORE  /* timing experiment only: results are garbage */
-        if (n < 0) {
-#else
         if (n < cap) {
-#endif
             if (lane == 0) keys[n] = key;
 #pragma unroll
             for (int e = 0; e < SZ; e++) coef[((size_t)n * SZ + e) * WAVE + lane] = v[e];
@@ -180,11 +176,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int l = min(l0 + u, n - 1);
-#ifdef TV_EXP_HOTLOAD  /* timing experiment only: every term loads the same rows */
-                pol.load(l * 0, regs[u]);
-#else
                 pol.load(__builtin_amdgcn_readlane(idx_v, l), regs[u]);
-#endif
             }
 #ifdef TV_PROFILE
             { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) { g_tvprof[0] += x - wp0; g_tvprof[3] += 1; } wp0 = x; }
