@@ -1341,7 +1341,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     bool built = false;
     static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
     static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 56; }();  // below this the per-step kernel is faster (measured: B = 28 at T = 100 is the break-even)
-    if (h->mode != ARMOUR_MODE_ARMTD && (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= tv_min_groups)) {
+    const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
+    // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 40 there)
+    if (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= (armtd ? tv_min_groups * 3 / 2 : tv_min_groups)) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
         // Block shapes, in the order tried: (a) while there is at most one group per CU, three waves per group -- the roles of
@@ -1355,7 +1357,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const Shape shapes[3] = {{kRoles, 4096}, {1, 4096}, {1, 8192}};
         for (int si = 0; si < 3 && !built; si++) {
             const int nw = shapes[si].nw, cap = shapes[si].cap;
-            if (nw == kRoles && (tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
+            if (nw == kRoles && (armtd || tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
             if (nw == 1 && tv_nw_env == kRoles && si == 1) continue;
             const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw);
             // blocks per CU by LDS, with at least 8 KB of staging rows per wave; the staging area takes what is left
@@ -1365,9 +1367,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / ((size_t)nw * 512));
             const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows, nw);
             const int slots = std::min(512, prop.multiProcessorCount * per_cu);
-            const bool split = nw == kRoles ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
-            const int fk_items = split ? groups : 0;
-            const int blocks = std::min(groups + fk_items, slots);
+            const bool split = armtd ? true : nw == kRoles ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
+            const int fk_items = split ? groups : 0, rnea_items = armtd ? 0 : groups;
+            const int blocks = std::min(rnea_items + fk_items, slots);
             if ((size_t)blocks * TL.total > wk->tv_arena_total) {
                 if (wk->tv_arena) (void)hipFree(wk->tv_arena);
                 wk->tv_arena = nullptr; wk->tv_arena_total = 0;
@@ -1389,7 +1391,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-            cf.n_items = groups; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
+            cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);

@@ -194,7 +194,8 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
         double rp[9];
         rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
         if (i < n && cf.rb.axes[i] != 0) {
-            const JrsScalars js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t_lane);
+            const JrsScalars js = cf.mode == ARMOUR_MODE_ARMTD ? armtd_jrs_scalars(cf, bz[i], b, i, t_lane)   // (CMP/Trajectory.cu:29-61: offline tables)
+                                                               : jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t_lane);
             const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
             double cen[9], co[4 * 9];
             make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
