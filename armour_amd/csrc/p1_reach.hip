@@ -953,6 +953,44 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     }
 }
 
+// pair order of RT/CollisionChecking.cu:26-39: plane p pairs generators (a < b), enumerated row by row over the 9 generators
+__host__ __device__ constexpr int plane_pair_a(int p) { int a = 0, b = 1; for (int s = 0; s < p; s++) { if (++b == 9) { a++; b = a + 1; } } return a; }
+__host__ __device__ constexpr int plane_pair_b(int p) { int a = 0, b = 1; for (int s = 0; s < p; s++) { if (++b == 9) { a++; b = a + 1; } } return b; }
+
+// Planes 9 GRP .. 9 GRP + 8 of one row.  The generator indices are compile-time constants: indexed with run-time values the
+// 9 x 3 generator array lived in scratch memory, and its ~300 scratch loads per thread were what the kernel spent its time on
+// (2.0 ms for the 2.6 GB table of 128 worlds at O = 20, where a plain fill of the same addresses takes 0.45 ms).
+template <int GRP>
+__device__ inline void planes_of_group(const double (&G)[9][3], const double (&c)[3], bool in, int Q, int q, int o, int lt, int JT,
+                                       double* __restrict__ out, double* __restrict__ ll, double (&Cs)[ARMOUR_NPLANES][3][64], int lane) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        constexpr int p0 = GRP * 9;
+        const int p = p0 + k;
+        const int a_id = plane_pair_a(p), b_id = plane_pair_b(p);  // (constants once the loop is unrolled)
+        const double* ga = G[a_id];
+        const double* gb = G[b_id];
+        const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
+        const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
+        double C0 = 0, C1 = 0, C2 = 0;
+        if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
+        double dl = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
+        if (in) {
+            out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
+            out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+            out[armour_plane_index(Q, q, p, 4)] = dl;
+            if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
+                ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
+                ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
+                ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
+            }
+        }
+        Cs[p][0][lane] = C0; Cs[p][1][lane] = C1; Cs[p][2][lane] = C2;
+    }
+}
+
 // RT/CollisionChecking.cu:136-228: one thread per (b, q = (l*T+t)*O + o) builds the row's 36 half-spaces.
 // It also derives which planes can never win the row's arg-max: a plane whose normal is zero (the -1e8 sentinel
 // of :252-259) or bit-for-bit equal to +-the normal of an earlier plane of the same row reproduces values the
@@ -975,42 +1013,27 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     const double* ob = obstacles + ((size_t)b * O + o) * 12;
     const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
     double G[9][3], c[3];
+#pragma unroll
     for (int ax = 0; ax < 3; ax++) {
         c[ax] = ob[ax];
+#pragma unroll
         for (int g = 0; g < 3; g++) G[g][ax] = ob[(g + 1) * 3 + ax];
+#pragma unroll
         for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
     }
     double* out = planes + (size_t)b * armour_planes_per_problem(Q);
     if (in && grp == 0 && lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
-    // pair order of RT/CollisionChecking.cu:26-39: p enumerates (a_id < b_id) row by row; this thread's first pair
-    int a_id = 0, b_id = 1;
-    for (int s = 0; s < grp * 9; s++) { if (++b_id == 9) { a_id++; b_id = a_id + 1; } }
-    for (int k = 0; k < 9; k++) {
-        const int p = grp * 9 + k;
-        const double* ga = G[a_id];
-        const double* gb = G[b_id];
-        const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
-        const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
-        double C0 = 0, C1 = 0, C2 = 0;
-        if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
-        double dl = 0.0;
-        for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
-        if (in) {
-            out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
-            out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
-            out[armour_plane_index(Q, q, p, 4)] = dl;
-            if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
-                double* ll = planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T);
-                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
-                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
-                ll[armour_plane_ll_index(J * T, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
-            }
-        }
-        Cs[p][0][lane] = C0; Cs[p][1][lane] = C1; Cs[p][2][lane] = C2;
-        if (++b_id == 9) { a_id++; b_id = a_id + 1; }
+    // this wave's nine planes, with compile-time generator indices (see planes_of_group)
+    switch (grp) {
+        case 0: planes_of_group<0>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
+        case 1: planes_of_group<1>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
+        case 2: planes_of_group<2>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
+        default: planes_of_group<3>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
     }
     __syncthreads();
     // redundancy of this thread's planes: zero normal, or bit-for-bit +- the normal of an earlier plane of the row
+    // (measured and dropped: skipping the test for planes whose bit is already gone from the problem's mask -- no gain; the
+    //  kernel is bound by its two blocks per CU, i.e. by the 55 KB of normals the test keeps in LDS)
     unsigned long long skip = in ? 0ull : ~0ull;
     if (in) {
         for (int k = 0; k < 9; k++) {
