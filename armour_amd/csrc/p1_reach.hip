@@ -71,7 +71,7 @@ struct P1Cfg {
     int* retry_list;
     unsigned* retry_count;
     // time-vectorised build (p1_tv.inc.h): an item is a (problem, group of time steps) pair
-    int tv_groups, tv_lanes, tv_cap, tv_stage_rows;
+    int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -1387,8 +1387,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const size_t fixed = (size_t)nw * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_shared();
             const int per_cu = nw == kRoles ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
             if (fixed + (size_t)nw * 8 * 1024 > (size_t)160 * 1024 / per_cu) continue;
-            const int stage_rows = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / ((size_t)nw * 512));
-            const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows, nw);
+            const int stage_total = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / 512);
+            // three waves: wave 1 first gets the 37 rows a joint rotation needs, the rest is shared out evenly
+            const int stage_rows = nw == 1 ? stage_total : std::min(stage_total - 2 * 8, std::max(stage_total / 3, 37));
+            const int stage_other = nw == 1 ? 0 : (stage_total - stage_rows) / 2;
+            const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows, stage_other, nw);
             const int slots = std::min(512, prop.multiProcessorCount * per_cu);
             const bool split = armtd ? true : nw == kRoles ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
             const int fk_items = split ? groups : 0, rnea_items = armtd ? 0 : groups;
@@ -1414,7 +1417,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-            cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows;
+            cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
@@ -1426,7 +1429,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
-            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d staging rows per wave, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw, per_cu, smem, stage_rows, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }

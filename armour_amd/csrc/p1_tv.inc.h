@@ -369,7 +369,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 __host__ __device__ inline size_t tv_lds_fixed(int cap) { return ((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 __host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + MB_WORDS) * sizeof(int) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int nw) { return (size_t)nw * tv_lds_wave(cap, stage_rows) + tv_lds_shared(); }
+__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) { return (size_t)nw * tv_lds_fixed(cap) + (size_t)(stage_rows + (nw - 1) * stage_rows_other) * 64 * sizeof(double) + tv_lds_shared(); }
 
 // One block per (problem, time group) item, striding over the items; group g of a problem holds the time steps
 // [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).  NW = 1: one wave plays every role in turn.  NW = 3: the roles of
@@ -391,13 +391,17 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
     c.nw = NW;
     c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
-    LDS_AS unsigned char* mine = lds + (size_t)c.wid * tv_lds_wave(cf.capKey, cf.tv_stage_rows);
+    // per wave: sort buffers | status | staging rows.  In a three-wave block wave 1 -- the angular recursion, whose products all
+    // have a joint rotation (36 rows) as the short operand and which is the busiest role -- gets the larger staging area.
+    const int my_stage = (NW == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
+    const int stage_before = NW == 1 ? 0 : (c.wid > 0 ? cf.tv_stage_rows_other : 0) + (c.wid > 1 ? cf.tv_stage_rows : 0);
+    LDS_AS unsigned char* mine = lds + (size_t)c.wid * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
     c.w.w.skey = (LDS_AS uint64_t*)mine;
     c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
     c.w.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 10);
     c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(cf.capKey));
-    c.w.stage_rows = cf.tv_stage_rows;
-    LDS_AS unsigned char* shared = lds + (size_t)NW * tv_lds_wave(cf.capKey, cf.tv_stage_rows);
+    c.w.stage_rows = my_stage;
+    LDS_AS unsigned char* shared = lds + (size_t)NW * tv_lds_fixed(cf.capKey) + (size_t)(NW == 1 ? cf.tv_stage_rows : cf.tv_stage_rows + (NW - 1) * cf.tv_stage_rows_other) * 64 * sizeof(double);
     c.w.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.w.cnt + kMaxSlots;
     c.w.w.cap_raw = cf.capRaw;
