@@ -71,6 +71,7 @@ struct P1Cfg {
     int* retry_list;
     unsigned* retry_count;
     // time-vectorised build (p1_tv.inc.h): an item is a (problem, group of time steps) pair
+    int tv_free_running;  // three-wave blocks: run_rnea_tv3 (progress counters) instead of run_rnea (a barrier per joint)
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
 };
 
@@ -1374,6 +1375,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // (b) one wave per group with sort buffers of 4096 entries (the union raw-term counts seen are <= 2.4 k), several waves per
         // CU, the forward kinematics of every group as a work item of its own while slots are free; (c) the same with 8192 entries.
         // A product that overflows the sort buffers sends the launch to the next shape; any other flag to the per-step path.
+        static const int tv_free_env = [] { const char* e = getenv("ARMOUR_P1_TV_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
         static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3
         static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
         struct Shape { int nw, cap; };
@@ -1417,7 +1419,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
-            cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other;
+            cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
