@@ -1367,7 +1367,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 56; }();  // below this the per-step kernel is faster (measured: B = 28 at T = 100 is the break-even)
     const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 40 there)
-    if (tv_env >= 0 ? tv_env != 0 : B * ((T + 63) / 64) >= (armtd ? tv_min_groups * 3 / 2 : tv_min_groups)) {
+    // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
+    //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
+    if (tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 3 / 2 : tv_min_groups)) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
         // Block shapes, in the order tried: (a) while there is at most one group per CU, three waves per group -- the roles of
