@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: cache behaviour of armour_p1_chain_kernel (L2 hit rate, HBM traffic, vector-L1 traffic) at B = 1 and B = 128
+# dev: cache behaviour of the reach-set build kernels (armour_p1_chain_kernel at B = 1, armour_p1_tv_kernel at B = 128) (L2 hit rate, HBM traffic, vector-L1 traffic) at B = 1 and B = 128
 set -u
 export TMPDIR=/tmp
 R=$PWD
@@ -20,7 +20,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('gpurun_out/prof_p1cache/*/**/*counter_collection.csv', recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
-        if 'chain_kernel' in row['Kernel_Name']:
+        if 'chain_kernel' in row['Kernel_Name'] or 'tv_kernel' in row['Kernel_Name']:
             a = acc[row['Counter_Name']]; a[0] += float(row['Counter_Value']); a[1] += 1
     print(f.split('/')[2], {k: round(v[0] / v[1], 1) for k, v in acc.items()}, 'dispatches', {k: v[1] for k, v in acc.items()})
 PY
