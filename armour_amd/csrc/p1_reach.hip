@@ -1378,26 +1378,28 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // CU, the forward kinematics of every group as a work item of its own while slots are free; (c) the same with 8192 entries.
         // A product that overflows the sort buffers sends the launch to the next shape; any other flag to the per-step path.
         static const int tv_free_env = [] { const char* e = getenv("ARMOUR_P1_TV_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
-        static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3
+        static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3 | 4
         static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
         struct Shape { int nw, cap; };
-        const Shape shapes[3] = {{kRoles, 4096}, {1, 4096}, {1, 8192}};
-        for (int si = 0; si < 3 && !built; si++) {
+        const Shape shapes[4] = {{4, 4096}, {kRoles, 4096}, {1, 4096}, {1, 8192}};
+        for (int si = 0; si < 4 && !built; si++) {
             const int nw = shapes[si].nw, cap = shapes[si].cap;
-            if (nw == kRoles && (armtd || tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
-            if (nw == 1 && tv_nw_env == kRoles && si == 1) continue;
+            const bool multi = nw > 1;   // (a): the roles of the RNEA on three waves, with four the forward kinematics on a wave of its own
+            if (multi && (armtd || tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
+            if (multi && tv_nw_env > 1 && tv_nw_env != nw) continue;
+            if (!multi && tv_nw_env > 1 && si == 2) continue;
             const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw);
-            // blocks per CU by LDS, with at least 8 KB of staging rows per wave; the staging area takes what is left
-            const size_t fixed = (size_t)nw * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_shared();
-            const int per_cu = nw == kRoles ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
-            if (fixed + (size_t)nw * 8 * 1024 > (size_t)160 * 1024 / per_cu) continue;
+            // blocks per CU by LDS; the staging area takes what is left
+            const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed(tvchain::kTvFkCap) : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();
+            const int per_cu = multi ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
+            if (fixed + 512 * (multi ? 37 + 2 * (nw - 1) : 16) + 256 > (size_t)160 * 1024 / per_cu) continue;
             const int stage_total = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / 512);
-            // three waves: wave 1 first gets the 37 rows a joint rotation needs, the rest is shared out evenly
-            const int stage_rows = nw == 1 ? stage_total : std::min(stage_total - 2 * 8, std::max(stage_total / 3, 37));
-            const int stage_other = nw == 1 ? 0 : (stage_total - stage_rows) / 2;
+            // several waves: wave 1 first gets the 37 rows a joint rotation needs, the rest is shared out evenly
+            const int stage_rows = !multi ? stage_total : std::min(stage_total - 2 * (nw - 1), std::max(stage_total / nw, 37));
+            const int stage_other = !multi ? 0 : (stage_total - stage_rows) / (nw - 1);
             const size_t smem = tvchain::tv_lds_bytes(cap, stage_rows, stage_other, nw);
             const int slots = std::min(512, prop.multiProcessorCount * per_cu);
-            const bool split = armtd ? true : nw == kRoles ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
+            const bool split = armtd ? true : multi ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
             const int fk_items = split ? groups : 0, rnea_items = armtd ? 0 : groups;
             const int blocks = std::min(rnea_items + fk_items, slots);
             if ((size_t)blocks * TL.total > wk->tv_arena_total) {
@@ -1406,7 +1408,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                 if (hipMalloc((void**)&wk->tv_arena, (size_t)blocks * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
                 wk->tv_arena_total = (size_t)blocks * TL.total;
             }
-            if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             P1Cfg cf;
             memset(&cf, 0, sizeof(cf));
@@ -1424,7 +1427,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
-            if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
+            if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
+            else if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
             else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(wk->ev1, h->stream));

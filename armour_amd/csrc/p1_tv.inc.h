@@ -13,19 +13,22 @@ using tv::TW;
 constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots: 32 for one wave, 60 (split by role) for three
 // 3x1 pool of a three-wave block (run_rnea_tv3: the waves run ahead of each other, so a few joints' states are alive at a time)
 constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 26};
+// ... and of a four-wave block (the forward kinematics on a wave of its own)
+constexpr int kTvPart4First[4] = {0, 12, 34, 56}, kTvPart4Count[4] = {12, 22, 22, 6};
 
 // (one spare key and one spare row block beyond `cap`)
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
 
 struct TLayout {
-    int nJM, nJV, nJS, nV, nroles;
+    int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (1 or 3); npools: parts of the 3x1 pool (1, 3 or 4)
     size_t offV, offS, offM, offJM, offJV, offJS, total;
     int idV, idS, idM, idJM, idJV, idJS;
 };
-__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nroles) {
+__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves) {
     TLayout L;
-    L.nroles = nroles;
-    L.nV = nroles == 1 ? kNVOneWave : kTvPartFirst[kRoles - 1] + kTvPartCount[kRoles - 1];
+    const int nroles = nwaves == 1 ? 1 : kRoles;
+    L.nroles = nroles; L.npools = nwaves;
+    L.nV = nwaves == 1 ? kNVOneWave : nwaves == kRoles ? kTvPartFirst[kRoles - 1] + kTvPartCount[kRoles - 1] : kTvPart4First[3] + kTvPart4Count[3];
     L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
     L.nJV = (J + 1) + J;                   // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;        // qd, qda, qdda; mass; per role: 4 raw temps
@@ -89,9 +92,10 @@ struct TChain {
     __device__ TPZ rawS(int r, int i) const { return JS(3 * n + J + 4 * scratch(r) + i); }
 
     __device__ TPZ allocV() {
-        const unsigned long long part = L.nroles == 1 ? ~0ull : ((1ull << kTvPartCount[role]) - 1ull) << kTvPartFirst[role];
+        const unsigned long long part = L.npools == 1 ? ~0ull : L.npools == kRoles ? ((1ull << kTvPartCount[role]) - 1ull) << kTvPartFirst[role]
+                                                                                   : ((1ull << kTvPart4Count[role]) - 1ull) << kTvPart4First[role];
         const int i = __ffsll((long long)(freeV & part)) - 1;
-        if (i < 0) { pzw::flag(w.w, pzw::ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : kTvPartFirst[role]); }
+        if (i < 0) { pzw::flag(w.w, pzw::ERR_SLOT_OVERFLOW); return V(L.npools == 1 ? 0 : L.npools == kRoles ? kTvPartFirst[role] : kTvPart4First[role]); }
         freeV &= ~(1ull << i);
         return V(i);
     }
@@ -403,7 +407,8 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
     const P1Cfg& cf = *c.cf;
     TW& w = c.w;
     const int J = c.J;
-    const bool with_fk = cf.fk_items == 0;
+    const bool fk_wave = c.nw == 4;                       // the forward kinematics has a wave of its own
+    const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 1) {
@@ -478,6 +483,15 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         }
         c.bar();   // (A)
         for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
+    } else if (c.wid == 3) {
+        // the forward kinematics shares nothing with the recursion but the JRS rotations: wave 2 was the last to finish the
+        // forward pass while it carried it (14.1 M cycles against 9.4 / 10.1 M of the other two)
+        c.role = 3;
+        FkStateT<TPZ> fk;
+        fk_begin(c, fk);
+        for (int i = 0; i < J; i++) fk_step(c, fk, i, b, t_lane);
+        c.freeVs(fk.T);
+        c.bar();   // (A)
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
@@ -547,6 +561,8 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         }
         c.freeVs(nn);
         c.bar();   // (B)
+    } else if (c.wid == 3) {
+        c.bar();   // (B)
     } else {
         c.role = 2;
         c.bar();   // (B) both recursions are through: nobody reads N_i, F_i any more
@@ -558,7 +574,11 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
 __host__ __device__ inline size_t tv_lds_fixed(int cap) { return ((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 __host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + (MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS)) * sizeof(int) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) { return (size_t)nw * tv_lds_fixed(cap) + (size_t)(stage_rows + (nw - 1) * stage_rows_other) * 64 * sizeof(double) + tv_lds_shared(); }
+constexpr int kTvFkCap = 1024;  // sort buffers of the forward-kinematics wave of a four-wave block (its products have <= 0.9 k raw terms)
+__host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) {
+    const int nmain = nw == 4 ? 3 : nw;
+    return (size_t)nmain * tv_lds_fixed(cap) + (nw == 4 ? tv_lds_fixed(kTvFkCap) : 0) + (size_t)(stage_rows + (nw - 1) * stage_rows_other) * 64 * sizeof(double) + tv_lds_shared();
+}
 
 // One block per (problem, time group) item, striding over the items; group g of a problem holds the time steps
 // [g * lanes_per_group, min(T, (g + 1) * lanes_per_group)).  NW = 1: one wave plays every role in turn.  NW = 3: the roles of
@@ -583,18 +603,20 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
     // per wave: sort buffers | status | staging rows.  In a three-wave block wave 1 -- the angular recursion, whose products all
     // have a joint rotation (36 rows) as the short operand and which is the busiest role -- gets the larger staging area.
     const int my_stage = (NW == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
-    const int stage_before = NW == 1 ? 0 : (c.wid > 0 ? cf.tv_stage_rows_other : 0) + (c.wid > 1 ? cf.tv_stage_rows : 0);
-    LDS_AS unsigned char* mine = lds + (size_t)c.wid * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
+    const int my_cap = (NW == 4 && c.wid == 3) ? kTvFkCap : cf.capKey;
+    // waves 0..2: [sort buffers (cap) | status | staging]; wave 3 of a four-wave block: the same with kTvFkCap
+    const int stage_before = NW == 1 ? 0 : (c.wid > 0 ? cf.tv_stage_rows_other : 0) + (c.wid > 1 ? cf.tv_stage_rows : 0) + (c.wid > 2 ? cf.tv_stage_rows_other : 0);
+    LDS_AS unsigned char* mine = lds + (size_t)min(c.wid, 3) * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
     c.w.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
-    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 10);
-    c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(cf.capKey));
+    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap * 8);
+    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap * 10);
+    c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap));
     c.w.stage_rows = my_stage;
-    LDS_AS unsigned char* shared = lds + (size_t)NW * tv_lds_fixed(cf.capKey) + (size_t)(NW == 1 ? cf.tv_stage_rows : cf.tv_stage_rows + (NW - 1) * cf.tv_stage_rows_other) * 64 * sizeof(double);
+    LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NW) - tv_lds_shared();
     c.w.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.w.cnt + kMaxSlots;
-    c.w.w.cap_raw = cf.capRaw;
-    c.w.w.cap_key = cf.capKey;
+    c.w.w.cap_raw = my_cap;
+    c.w.w.cap_key = my_cap;
     c.w.w.thr = cf.pr.simplify_threshold;
     c.w.w.thr_sq = pzw::sq_threshold(c.w.w.thr);
     c.w.w.lane = threadIdx.x & 63;
@@ -633,7 +655,7 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
                 c.freeVs(fk.T);
             }
         } else {
-            if (NW == kRoles && cf.tv_free_running) run_rnea_tv3(c, u_nom, b, t_lane);
+            if (NW >= kRoles && cf.tv_free_running) run_rnea_tv3(c, u_nom, b, t_lane);
             else run_rnea(c, u_nom, b, t_lane);
             if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane);
         }
