@@ -12,9 +12,9 @@ using tv::TW;
 
 constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots: 32 for one wave, 60 (split by role) for three
 // 3x1 pool of a three-wave block (run_rnea_tv3: the waves run ahead of each other, so a few joints' states are alive at a time)
-constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 26};
+constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 28};
 // ... and of a four-wave block (the forward kinematics on a wave of its own)
-constexpr int kTvPart4First[4] = {0, 12, 34, 56}, kTvPart4Count[4] = {12, 22, 22, 6};
+constexpr int kTvPart4First[4] = {0, 10, 30, 52}, kTvPart4Count[4] = {10, 20, 22, 10};
 
 // (one spare key and one spare row block beyond `cap`)
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
@@ -386,7 +386,8 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 // freed by its owner once the counters show every reader past it (state_k: K joints back).  Same operators on the same
 // operands as run_rnea: bit-identical tables.
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_C2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_WORDS = T3_CNT + 8 };
+       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS,
+       T3_CNT = T3_A2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_WORDS = T3_CNT + 8 };
 __device__ inline int t3_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void t3_signal(TChain& c, int word, int value) {
     WSYNC();   // this wave's stores (result rows, keys, LDS count table, mailbox) are done
@@ -500,9 +501,8 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
             if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (first: it waits for nobody)
             if (s >= 1) {
                 t3_wait(c, T3_C1, s);
-                t3_wait(c, T3_C0, s);
-                const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2), lacc = t3_take(c, T3_LA + s);
-                {   // N = I * wdot + cross(w_aux, I * w)
+                const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
+                {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
                     const TPZ I = c.inertia(s - 1);
                     TPZ t1 = c.mulMV(I, wdot);
                     TPZ t2 = c.mulMV(I, wv);
@@ -510,6 +510,8 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
                     TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
                     t3_post(c, T3_N + s - 1, N);
                 }
+                t3_wait(c, T3_C0, s);
+                const TPZ lacc = t3_take(c, T3_LA + s);
                 {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
                     const double* cm = &cf.rb.com[3 * (s - 1)];
                     TPZ c1 = c.crossPzMat(wdot, cm);
@@ -526,6 +528,9 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         c.bar();   // (A)
     }
     // ---------------- backward: n = N + R n + com x F + p x (R f),  f = R f + F
+    // The f-recursion (wave 1) is the chain everything hangs on: R f, then f = R f + F.  The cross product p x (R f) that the
+    // n-recursion needs is a side product of it and goes to a wave that has nothing to do in this pass (wave 3, or wave 2).
+    const int helper = fk_wave ? 3 : 2;
     if (c.wid == 1) {
         c.role = 1;
         TPZ f = c.allocV();
@@ -533,15 +538,14 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         for (int i = J - 1; i >= 0; i--) {
             const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i);
             TPZ a2 = c.mulMV(Rn, f);
-            TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2);
-            t3_post(c, T3_C2 + i, c2);
+            t3_post(c, T3_A2 + i, a2);
             t3_signal(c, T3_B1, J - i);
-            TPZ f2 = c.add(a2, Fi); c.freeVs(f); c.freeVs(a2);
+            TPZ f2 = c.add(a2, Fi); c.freeVs(f);
             f = f2;
         }
         c.freeVs(f);
-        c.bar();   // (B) wave 0 has read every c2_i
-        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
+        c.bar();   // (B) the helper has read every R f
+        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_A2 + i));
     } else if (c.wid == 0) {
         c.role = 0;
         TPZ nn = c.allocV();
@@ -550,7 +554,7 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
             const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
             TPZ a1 = c.mulMV(Rn, nn);
             TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
-            t3_wait(c, T3_B1, J - i);
+            t3_wait(c, T3_B2, J - i);
             const TPZ c2 = t3_take(c, T3_C2 + i);
             TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
             nn = n2;
@@ -561,9 +565,19 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         }
         c.freeVs(nn);
         c.bar();   // (B)
-    } else if (c.wid == 3) {
-        c.bar();   // (B)
-    } else {
+    }
+    if (c.wid == helper) {
+        c.role = helper;
+        for (int i = J - 1; i >= 0; i--) {
+            t3_wait(c, T3_B1, J - i);
+            TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
+            t3_post(c, T3_C2 + i, c2);
+            t3_signal(c, T3_B2, J - i);
+        }
+        c.bar();   // (B) wave 0 has read every p x (R f)
+        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
+        if (helper == 2) { for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); } }
+    } else if (c.wid == 2) {   // (four waves: wave 3 is the helper)
         c.role = 2;
         c.bar();   // (B) both recursions are through: nobody reads N_i, F_i any more
         for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
