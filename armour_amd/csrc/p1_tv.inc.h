@@ -393,13 +393,24 @@ __device__ inline void t3_signal(TChain& c, int word, int value) {
     WSYNC();   // this wave's stores (result rows, keys, LDS count table, mailbox) are done
     if (c.w.w.lane == 0) __hip_atomic_store(&c.mb[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+#ifdef TV_PROFILE
+#define TVP_FWD(c) ((c).w.c_fwd = clock64())
+#else
+#define TVP_FWD(c) ((void)0)
+#endif
 __device__ inline void t3_wait(TChain& c, int word, int value) {
+#ifdef TV_PROFILE
+    const long long tw0 = clock64();
+#endif
     int spins = 0;
     while (t3_ld(&c.mb[word]) < value) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1 << 24)) { pzw::flag(c.w.w, pzw::ERR_SLOT_OVERFLOW); break; }   // never seen; ends the wait instead of the box
     }
     WSYNC();
+#ifdef TV_PROFILE
+    c.w.c_wait += clock64() - tw0;
+#endif
 }
 __device__ inline void t3_post(TChain& c, int word, const TPZ& p) { if (c.w.w.lane == 0) c.mb[word] = p.id - c.L.idV; }
 __device__ inline TPZ t3_take(const TChain& c, int word) { return c.V(t3_ld(&c.mb[word])); }
@@ -458,7 +469,7 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
             t3_post(c, T3_ST + 3 * (s + 1), nw); t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
             t3_signal(c, T3_C1, s + 1);
         }
-        c.bar();   // (A) the forward pass is over everywhere
+        TVP_FWD(c); c.bar();   // (A) the forward pass is over everywhere
         for (int k = freed; k <= J; k++)
             for (int e = 0; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
     } else if (c.wid == 0) {
@@ -482,7 +493,7 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
             t3_post(c, T3_LA + s + 1, nl);
             t3_signal(c, T3_C0, s + 1);
         }
-        c.bar();   // (A)
+        TVP_FWD(c); c.bar();   // (A)
         for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
     } else if (c.wid == 3) {
         // the forward kinematics shares nothing with the recursion but the JRS rotations: wave 2 was the last to finish the
@@ -492,7 +503,7 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
         fk_begin(c, fk);
         for (int i = 0; i < J; i++) fk_step(c, fk, i, b, t_lane);
         c.freeVs(fk.T);
-        c.bar();   // (A)
+        TVP_FWD(c); c.bar();   // (A)
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
@@ -525,7 +536,7 @@ __device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
             }
         }
         if (with_fk) c.freeVs(fk.T);
-        c.bar();   // (A)
+        TVP_FWD(c); c.bar();   // (A)
     }
     // ---------------- backward: n = N + R n + com x F + p x (R f),  f = R f + F
     // The f-recursion (wave 1) is the chain everything hangs on: R f, then f = R f + F.  The cross product p x (R f) that the
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
         __syncthreads();
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
-        c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
+        c.w.c_wait = c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
         for (int q = 0; q < 3; q++) { c.w.c_type[q] = 0; c.w.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane, fk_only);
@@ -677,9 +688,12 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
 #ifdef TV_PROFILE
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
-        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles: sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif
     }
+#ifdef TV_PROFILE
+    if (lane == 0 && blockIdx.x == 0) printf("[tv maxraw wave %d] %d out %d\n", c.wid, c.w.w.lstat[pzw::ST_MAX_RAW], c.w.w.lstat[pzw::ST_MAX_OUT]);
+#endif
     if (lane == 0) {  // every wave reports its own flags and maxima
         if (c.w.w.lstat[pzw::ST_ERR]) atomicOr(&cf.status[pzw::ST_ERR], (unsigned)c.w.w.lstat[pzw::ST_ERR]);
         atomicMax(&cf.status[pzw::ST_MAX_RAW], (unsigned)c.w.w.lstat[pzw::ST_MAX_RAW]);

@@ -4,5 +4,5 @@ from armour_amd.worlds import random_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pb = random_batch(0, B, 20)
 nlp = ArmourNLP(T=100)
-nlp.set_parameters(pb['q0'], pb['qd0'], pb['qdd0'], pb['q_des'], pb['obstacles'])
+for _ in range(4): nlp.set_parameters(pb["q0"], pb["qd0"], pb["qdd0"], pb["q_des"], pb["obstacles"])
 print("B", B, "build ms", nlp.build_ms)
