@@ -36,7 +36,7 @@ constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work
 // The 3x1 pool is split between the roles of a block (see run_rnea): each role allocates and frees only in its own part,
 // so three waves can run different operators at the same time without sharing allocator state.
 constexpr int kRoles = 3;
-constexpr int kPartFirst[kRoles] = {0, 10, 24}, kPartCount[kRoles] = {10, 14, 24};  // of the 48 slots of a 3-wave block
+constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28};  // of the 62 slots of a 3-wave block (run_rnea_free keeps a few joints' states alive)
 constexpr int kRoleN = 2;  // the role that computes (and later frees) the moments N_i (measured with it in role 0 / 1 / 2 and the forward kinematics split off: 2.06 / 2.01 / 1.95 ms)
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
@@ -71,7 +71,8 @@ struct P1Cfg {
     int* retry_list;
     unsigned* retry_count;
     // time-vectorised build (p1_tv.inc.h): an item is a (problem, group of time steps) pair
-    int tv_free_running;  // three-wave blocks: run_rnea_tv3 (progress counters) instead of run_rnea (a barrier per joint)
+    int tv_free_running;  // three-wave blocks: run_rnea_free (progress counters) instead of run_rnea (a barrier per joint)
+    int free_running;     // the same choice for the per-step kernel's three-wave blocks
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
 };
 
@@ -289,6 +290,19 @@ struct Chain {
     LDS_AS int* mb;            // LDS mailbox: slot indices handed from one role to another across a block barrier
     // role r runs on wave r of a 3-wave block, every role on the one wave of a 1-wave block
     __device__ bool is(int role) const { return nw == 1 || wid == role; }
+    __device__ Wave& wave() { return w; }
+    __device__ const Wave& wave() const { return w; }
+    // (profile hooks of run_rnea_free)
+#ifdef P1_PROFILE
+    long long fwd_done = 0;
+    __device__ long long prof_clock() const { return clock64(); }
+    __device__ void prof_waited(long long t0) { bar_wait += clock64() - t0; }
+    __device__ void prof_forward_done() { fwd_done = clock64(); }
+#else
+    __device__ long long prof_clock() const { return 0; }
+    __device__ void prof_waited(long long) {}
+    __device__ void prof_forward_done() {}
+#endif
 #ifdef P1_PROFILE
     mutable long long bar_wait = 0;
     __device__ void bar() const { const long long t0 = clock64(); __syncthreads(); bar_wait += clock64() - t0; }
@@ -773,6 +787,8 @@ __device__ PZW_NOINLINE void run_rnea(CH& c, typename CH::PZT* u, int b, int t) 
     c.bar();
 }
 
+#include "p1_free.inc.h"
+
 // disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
 __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
     const P1Cfg& cf = *c.cf;
@@ -834,7 +850,7 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
 // NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
 __host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
+__host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
 
 // P1_WAVES_PER_SIMD: 1 (shipped) = no occupancy request, the kernels hold 256 VGPRs + spill AGPRs, one wave per SIMD.
 // 2 (development, `make EXTRA=-DP1_WAVES_PER_SIMD=2`) = every kernel of this file that calls the operators asks for two
@@ -870,7 +886,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     LDS_AS unsigned char* shared = lds + (size_t)NW * p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
-    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
+    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15) & ~(size_t)15));
 #ifdef P1_PROFILE
     unsigned long long* prof_lds = c.w.prof;  // (name kept from the LDS version: these are this wave's own counters now)
     for (int i = 0; i < PR_WORDS; i++) prof_lds[i] = 0;
@@ -915,6 +931,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
                 for (int i = 0; i < c.J; i++) fk_step(c, fk, i, b, t);
                 c.freeVs(fk.T);
             }
+        } else if (NW >= kRoles && cf.free_running) {
+            run_rnea_free(c, u_nom, b, t);
         } else {
             run_rnea(c, u_nom, b, t);
         }
@@ -933,7 +951,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             printf("[t=%d] total %lld: N<=64 %llu (%llu calls), mid %llu (%llu calls, %llu terms), big %llu (%llu calls, %llu terms) | fill %llu sort %llu (rank %llu bitonic %llu linmerge %llu mulmerge %llu) emit %llu abs %llu\n", t, (long long)clock64() - ph0,
                    prof_lds[PR_CYC64], prof_lds[PR_SMALL], prof_lds[PR_CYC512], prof_lds[PR_N512], prof_lds[PR_TERMS512], prof_lds[PR_CYCBIG], prof_lds[PR_NBIG], prof_lds[PR_TERMSBIG],
                    prof_lds[PR_FILL], prof_lds[PR_SORT], prof_lds[PR_S_RANK], prof_lds[PR_S_BITONIC], prof_lds[PR_S_LINMERGE], prof_lds[PR_S_MULMERGE], prof_lds[PR_EMIT], prof_lds[PR_ABS]);
-        if (c.w.lane == 0 && (t == 60 || t == 0)) printf("[t=%d wave %d] waited %lld cycles at role barriers of %lld\n", t, c.wid, c.bar_wait, (long long)clock64() - ph0);
+        if (c.w.lane == 0 && (t == 60 || t == 0)) printf("[t=%d wave %d] waited %lld cycles at role barriers / mailbox waits of %lld; forward pass done at %lld\n", t, c.wid, c.bar_wait, (long long)clock64() - ph0, c.fwd_done - ph0);
         c.bar_wait = 0;
         if (threadIdx.x == 0 && blockIdx.x == 0)
             printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
@@ -1091,7 +1109,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     LDS_AS unsigned char* shared = lds + p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
-    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + MB_WORDS) * sizeof(int)) + 15) & ~(size_t)15));
+    c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15) & ~(size_t)15));
     c.w.cap_raw = cf.capRaw; c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.thr_sq = sq_threshold(c.w.thr);
@@ -1309,6 +1327,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
         cf.capW = h->lim.work_monomials; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
         cf.arena_bytes = L.total; cf.arena = wk->arena;
+        static const int free_env = [] { const char* e = getenv("ARMOUR_P1_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
+        cf.free_running = free_env;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
         cf.mode = h->mode; cf.jrs = h->d_jrs;

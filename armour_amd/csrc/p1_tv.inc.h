@@ -11,7 +11,7 @@ using tv::TSeg;
 using tv::TW;
 
 constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots: 32 for one wave, 60 (split by role) for three
-// 3x1 pool of a three-wave block (run_rnea_tv3: the waves run ahead of each other, so a few joints' states are alive at a time)
+// 3x1 pool of a three-wave block (run_rnea_free: the waves run ahead of each other, so a few joints' states are alive at a time)
 constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 28};
 // ... and of a four-wave block (the forward kinematics on a wave of its own)
 constexpr int kTvPart4First[4] = {0, 10, 30, 52}, kTvPart4Count[4] = {10, 20, 22, 10};
@@ -67,6 +67,17 @@ struct TChain {
     LDS_AS int* mb;
     int role = 0;
     __device__ bool is(int r) const { return nw == 1 || wid == r; }
+    __device__ pzw::Wave& wave() { return w.w; }
+    __device__ const pzw::Wave& wave() const { return w.w; }
+#ifdef TV_PROFILE
+    __device__ long long prof_clock() const { return clock64(); }
+    __device__ void prof_waited(long long t0) { w.c_wait += clock64() - t0; }
+    __device__ void prof_forward_done() { w.c_fwd = clock64(); }
+#else
+    __device__ long long prof_clock() const { return 0; }
+    __device__ void prof_waited(long long) {}
+    __device__ void prof_forward_done() {}
+#endif
     __device__ void bar() const { __syncthreads(); }
     __device__ void post(int slot, const TPZ& p) const { if (w.w.lane == 0) mb[slot] = p.id - L.idV; }
     __device__ TPZ take(int slot) const { return V(mb[slot]); }
@@ -371,234 +382,10 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
     WSYNC();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The RNEA of a three-wave block WITHOUT lock-step barriers.  run_rnea (above, shared with the per-step kernel) meets at a
-// block barrier after every joint, so every joint costs the slowest role's time -- and which role that is changes: the
-// angular recursion in the forward pass, the sums of the n-recursion in the backward pass (own work of the roles 14 / 19 /
-// 10 M cycles, but 28 M from start to end).  Here each wave runs its recursion as far as its inputs allow:
-//   forward   wave 1: state_{s+1} = f(state_s)                      never waits
-//             wave 0: lacc_{s+1} = f(lacc_s, state_s)               waits for state_s
-//             wave 2: N_{s-1}, F_{s-1} = f(state_s, lacc_s), FK     waits for state_s and lacc_s
-//   backward  wave 1: a2_i = R f, c2_i = p x a2_i, f = a2_i + F_i   never waits
-//             wave 0: n = N_i + R n + com x F_i + c2_i, u_i         waits for c2_i
-// Progress counters and slot handles live in LDS; a producer finishes its stores (s_waitcnt) and then raises its counter, a
-// consumer polls the counter (the waves of a block share the CU's L1: what __syncthreads() relied on as well).  A slot is
-// freed by its owner once the counters show every reader past it (state_k: K joints back).  Same operators on the same
-// operands as run_rnea: bit-identical tables.
-enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
-       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_A2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_WORDS = T3_CNT + 8 };
-__device__ inline int t3_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ inline void t3_signal(TChain& c, int word, int value) {
-    WSYNC();   // this wave's stores (result rows, keys, LDS count table, mailbox) are done
-    if (c.w.w.lane == 0) __hip_atomic_store(&c.mb[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#ifdef TV_PROFILE
-#define TVP_FWD(c) ((c).w.c_fwd = clock64())
-#else
-#define TVP_FWD(c) ((void)0)
-#endif
-__device__ inline void t3_wait(TChain& c, int word, int value) {
-#ifdef TV_PROFILE
-    const long long tw0 = clock64();
-#endif
-    int spins = 0;
-    while (t3_ld(&c.mb[word]) < value) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 24)) { pzw::flag(c.w.w, pzw::ERR_SLOT_OVERFLOW); break; }   // never seen; ends the wait instead of the box
-    }
-    WSYNC();
-#ifdef TV_PROFILE
-    c.w.c_wait += clock64() - tw0;
-#endif
-}
-__device__ inline void t3_post(TChain& c, int word, const TPZ& p) { if (c.w.w.lane == 0) c.mb[word] = p.id - c.L.idV; }
-__device__ inline TPZ t3_take(const TChain& c, int word) { return c.V(t3_ld(&c.mb[word])); }
-
-__device__ TV_NOINLINE void run_rnea_tv3(TChain& c, TPZ* u, int b, int t_lane) {
-    const P1Cfg& cf = *c.cf;
-    TW& w = c.w;
-    const int J = c.J;
-    const bool fk_wave = c.nw == 4;                       // the forward kinematics has a wave of its own
-    const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
-    constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
-    if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
-    if (c.wid == 1) {
-        c.role = 1;
-        TPZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV();
-        tv::set_const(w, wv, nullptr, nullptr);
-        tv::set_const(w, wdot, nullptr, nullptr);
-        tv::set_const(w, waux, nullptr, nullptr);
-        t3_post(c, T3_ST + 0, wv); t3_post(c, T3_ST + 1, wdot); t3_post(c, T3_ST + 2, waux);
-    }
-    if (c.wid == 0) {
-        c.role = 0;
-        TPZ lacc = c.allocV();
-        double g[3] = {0.0, 0.0, cf.rb.gravity};
-        tv::set_const(w, lacc, g, nullptr);
-        t3_post(c, T3_LA + 0, lacc);
-    }
-    c.bar();
-    // ---------------- forward: state_k / lacc_k = state and linear acceleration of joint k-1 (k = 0: the base)
-    if (c.wid == 1) {
-        c.role = 1;
-        int freed = 0;   // states [0, freed) have been given back
-        for (int s = 0; s < J; s++) {
-            while (freed + K < s + 1) {   // state_k, k = freed: read by wave 0 at step k (< J), by wave 2 at step k (>= 1), by this wave at step k (done)
-                const int k = freed;
-                if (k < J) t3_wait(c, T3_C0, k + 1);
-                if (k >= 1) t3_wait(c, T3_CC2, k);
-                for (int e = 0; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
-                freed++;
-            }
-            const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
-            const TPZ Rt = c.Rt(s);
-            const int ax = abs(cf.rb.axes[s]) - 1;
-            TPZ nw = c.mulMV(Rt, wv);
-            if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
-            TPZ na = c.mulMV(Rt, waux);
-            TPZ nd = c.mulMV(Rt, wdot);
-            if (cf.rb.axes[s] != 0) {
-                TPZ zero = c.allocV();
-                tv::set_const(w, zero, nullptr, nullptr);
-                TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
-                TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
-                TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
-                TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
-            }
-            t3_post(c, T3_ST + 3 * (s + 1), nw); t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
-            t3_signal(c, T3_C1, s + 1);
-        }
-        TVP_FWD(c); c.bar();   // (A) the forward pass is over everywhere
-        for (int k = freed; k <= J; k++)
-            for (int e = 0; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
-    } else if (c.wid == 0) {
-        c.role = 0;
-        int freed = 0;
-        for (int s = 0; s < J; s++) {
-            t3_wait(c, T3_C1, s);   // state_s
-            while (freed + K < s + 1) {   // lacc_k: read by wave 2 at step k (>= 1), by this wave at step k (done)
-                const int k = freed;
-                if (k >= 1) t3_wait(c, T3_CC2, k);
-                c.freeVs(t3_take(c, T3_LA + k));
-                freed++;
-            }
-            const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2), lacc = t3_take(c, T3_LA + s);
-            const double* tr = &cf.rb.trans[3 * s];
-            TPZ c1 = c.crossPzMat(wdot, tr);
-            TPZ c2 = c.crossPzMat(waux, tr);
-            TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
-            TPZ nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
-            t3_post(c, T3_LA + s + 1, nl);
-            t3_signal(c, T3_C0, s + 1);
-        }
-        TVP_FWD(c); c.bar();   // (A)
-        for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
-    } else if (c.wid == 3) {
-        // the forward kinematics shares nothing with the recursion but the JRS rotations: wave 2 was the last to finish the
-        // forward pass while it carried it (14.1 M cycles against 9.4 / 10.1 M of the other two)
-        c.role = 3;
-        FkStateT<TPZ> fk;
-        fk_begin(c, fk);
-        for (int i = 0; i < J; i++) fk_step(c, fk, i, b, t_lane);
-        c.freeVs(fk.T);
-        TVP_FWD(c); c.bar();   // (A)
-    } else {
-        c.role = 2;
-        FkStateT<TPZ> fk;
-        if (with_fk) fk_begin(c, fk);
-        for (int s = 0; s <= J; s++) {
-            if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (first: it waits for nobody)
-            if (s >= 1) {
-                t3_wait(c, T3_C1, s);
-                const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
-                {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
-                    const TPZ I = c.inertia(s - 1);
-                    TPZ t1 = c.mulMV(I, wdot);
-                    TPZ t2 = c.mulMV(I, wv);
-                    TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
-                    TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
-                    t3_post(c, T3_N + s - 1, N);
-                }
-                t3_wait(c, T3_C0, s);
-                const TPZ lacc = t3_take(c, T3_LA + s);
-                {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
-                    const double* cm = &cf.rb.com[3 * (s - 1)];
-                    TPZ c1 = c.crossPzMat(wdot, cm);
-                    TPZ c2 = c.crossPzMat(waux, cm);
-                    TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-                    TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
-                    TPZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
-                    t3_post(c, T3_F + s - 1, F);
-                }
-                t3_signal(c, T3_CC2, s);
-            }
-        }
-        if (with_fk) c.freeVs(fk.T);
-        TVP_FWD(c); c.bar();   // (A)
-    }
-    // ---------------- backward: n = N + R n + com x F + p x (R f),  f = R f + F
-    // The f-recursion (wave 1) is the chain everything hangs on: R f, then f = R f + F.  The cross product p x (R f) that the
-    // n-recursion needs is a side product of it and goes to a wave that has nothing to do in this pass (wave 3, or wave 2).
-    const int helper = fk_wave ? 3 : 2;
-    if (c.wid == 1) {
-        c.role = 1;
-        TPZ f = c.allocV();
-        tv::set_const(w, f, nullptr, nullptr);
-        for (int i = J - 1; i >= 0; i--) {
-            const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i);
-            TPZ a2 = c.mulMV(Rn, f);
-            t3_post(c, T3_A2 + i, a2);
-            t3_signal(c, T3_B1, J - i);
-            TPZ f2 = c.add(a2, Fi); c.freeVs(f);
-            f = f2;
-        }
-        c.freeVs(f);
-        c.bar();   // (B) the helper has read every R f
-        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_A2 + i));
-    } else if (c.wid == 0) {
-        c.role = 0;
-        TPZ nn = c.allocV();
-        tv::set_const(w, nn, nullptr, nullptr);
-        for (int i = J - 1; i >= 0; i--) {
-            const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
-            TPZ a1 = c.mulMV(Rn, nn);
-            TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
-            t3_wait(c, T3_B2, J - i);
-            const TPZ c2 = t3_take(c, T3_C2 + i);
-            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
-            nn = n2;
-            if (cf.rb.axes[i] != 0) {
-                const int ax = abs(cf.rb.axes[i]) - 1;
-                u[i] = c.comb3(tv::elem(w, n2, ax), 1.0, tv::view(w, c.qdda(i)), cf.rb.armature[i], tv::view(w, c.qd(i)), cf.rb.damping[i]);
-            }
-        }
-        c.freeVs(nn);
-        c.bar();   // (B)
-    }
-    if (c.wid == helper) {
-        c.role = helper;
-        for (int i = J - 1; i >= 0; i--) {
-            t3_wait(c, T3_B1, J - i);
-            TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
-            t3_post(c, T3_C2 + i, c2);
-            t3_signal(c, T3_B2, J - i);
-        }
-        c.bar();   // (B) wave 0 has read every p x (R f)
-        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
-        if (helper == 2) { for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); } }
-    } else if (c.wid == 2) {   // (four waves: wave 3 is the helper)
-        c.role = 2;
-        c.bar();   // (B) both recursions are through: nobody reads N_i, F_i any more
-        for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
-    }
-}
-
 // LDS: NW x { sort buffers skey[cap] | sidx[cap] | status | staging rows for a product's short operand } | count table | mailbox
 __host__ __device__ inline size_t tv_lds_fixed(int cap) { return ((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
-__host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + (MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS)) * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kMbWords) * sizeof(int) + 15) & ~(size_t)15; }
 constexpr int kTvFkCap = 1024;  // sort buffers of the forward-kinematics wave of a four-wave block (its products have <= 0.9 k raw terms)
 __host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) {
     const int nmain = nw == 4 ? 3 : nw;
@@ -680,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
                 c.freeVs(fk.T);
             }
         } else {
-            if (NW >= kRoles && cf.tv_free_running) run_rnea_tv3(c, u_nom, b, t_lane);
+            if (NW >= kRoles && cf.tv_free_running) run_rnea_free(c, u_nom, b, t_lane);
             else run_rnea(c, u_nom, b, t_lane);
             if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane);
         }
