@@ -16,9 +16,11 @@
 // operands as run_rnea: bit-identical tables.
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
        T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_A2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_WORDS = T3_CNT + 8 };
+       T3_CNT = T3_A2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 constexpr int kMbWords = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;  // LDS mailbox of run_rnea / run_rnea_free
 __device__ inline int t3_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class CH>
+__device__ inline bool w_lane0(const CH& c) { return c.wave().lane == 0; }
 template <class CH>
 __device__ inline void t3_signal(CH& c, int word, int value) {
     WSYNC();   // this wave's stores (result rows, keys, LDS count table, mailbox) are done
@@ -49,14 +51,20 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     const bool fk_wave = c.nw == 4;                       // the forward kinematics has a wave of its own
     const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
+    const int wave_w = fk_wave ? 3 : 2;   // the wave that runs the omega recursion (see below)
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 1) {
         c.role = 1;
-        TPZ wv = c.allocV(), wdot = c.allocV(), waux = c.allocV();
-        set_const(w, wv, nullptr, nullptr);
+        TPZ wdot = c.allocV(), waux = c.allocV();
         set_const(w, wdot, nullptr, nullptr);
         set_const(w, waux, nullptr, nullptr);
-        t3_post(c, T3_ST + 0, wv); t3_post(c, T3_ST + 1, wdot); t3_post(c, T3_ST + 2, waux);
+        t3_post(c, T3_ST + 1, wdot); t3_post(c, T3_ST + 2, waux);
+    }
+    if (c.wid == wave_w) {
+        c.role = wave_w;
+        TPZ wv = c.allocV();
+        set_const(w, wv, nullptr, nullptr);
+        t3_post(c, T3_ST + 0, wv);
     }
     if (c.wid == 0) {
         c.role = 0;
@@ -67,22 +75,36 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     }
     c.bar();
     // ---------------- forward: state_k / lacc_k = state and linear acceleration of joint k-1 (k = 0: the base)
+    // The angular velocity w_{s+1} = R_t w_s + qd_s depends on nothing but itself, and neither w_aux nor wdot reads it: it runs
+    // on a wave with time to spare (wave 2 of three, the forward-kinematics wave of four), which owns its slots.
+    auto omega_step = [&](int s, int& freed_w) {
+        while (freed_w + K < s + 1) {   // w_k: read by wave 0 at step k (< J), by wave 2 at step k (>= 1)
+            const int k = freed_w;
+            if (k < J) t3_wait(c, T3_C0, k + 1);
+            if (k >= 1) t3_wait(c, T3_CC2, k);
+            c.freeVs(t3_take(c, T3_ST + 3 * k));
+            freed_w++;
+        }
+        const TPZ wv = t3_take(c, T3_ST + 3 * s);
+        TPZ nw = c.mulMV(c.Rt(s), wv);
+        if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), abs(cf.rb.axes[s]) - 1); c.freeVs(nw); nw = t2; }
+        t3_post(c, T3_ST + 3 * (s + 1), nw);
+        t3_signal(c, T3_CA, s + 1);
+    };
     if (c.wid == 1) {
         c.role = 1;
         int freed = 0;   // states [0, freed) have been given back
         for (int s = 0; s < J; s++) {
-            while (freed + K < s + 1) {   // state_k, k = freed: read by wave 0 at step k (< J), by wave 2 at step k (>= 1), by this wave at step k (done)
+            while (freed + K < s + 1) {   // (wdot, w_aux)_k, k = freed: read by wave 0 at step k (< J), by wave 2 at step k (>= 1), by this wave at step k (done)
                 const int k = freed;
                 if (k < J) t3_wait(c, T3_C0, k + 1);
                 if (k >= 1) t3_wait(c, T3_CC2, k);
-                for (int e = 0; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
+                for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
                 freed++;
             }
-            const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
+            const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
             const TPZ Rt = c.Rt(s);
             const int ax = abs(cf.rb.axes[s]) - 1;
-            TPZ nw = c.mulMV(Rt, wv);
-            if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
             TPZ na = c.mulMV(Rt, waux);
             TPZ nd = c.mulMV(Rt, wdot);
             if (cf.rb.axes[s] != 0) {
@@ -93,17 +115,18 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
                 TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
             }
-            t3_post(c, T3_ST + 3 * (s + 1), nw); t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+            t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
             t3_signal(c, T3_C1, s + 1);
         }
         c.prof_forward_done(); c.bar();   // (A) the forward pass is over everywhere
         for (int k = freed; k <= J; k++)
-            for (int e = 0; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
+            for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
     } else if (c.wid == 0) {
         c.role = 0;
         int freed = 0;
         for (int s = 0; s < J; s++) {
             t3_wait(c, T3_C1, s);   // state_s
+            t3_wait(c, T3_CA, s);
             while (freed + K < s + 1) {   // lacc_k: read by wave 2 at step k (>= 1), by this wave at step k (done)
                 const int k = freed;
                 if (k >= 1) t3_wait(c, T3_CC2, k);
@@ -128,17 +151,25 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.role = 3;
         FkStateT<TPZ> fk;
         fk_begin(c, fk);
-        for (int i = 0; i < J; i++) fk_step(c, fk, i, b, t_lane);
+        int freed_w = 0;
+        for (int s = 0; s < J; s++) {
+            omega_step(s, freed_w);   // first: wave 0 waits for it
+            fk_step(c, fk, s, b, t_lane);
+        }
         c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
+        for (int k = freed_w; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
         if (with_fk) fk_begin(c, fk);
+        int freed_w = 0;
         for (int s = 0; s <= J; s++) {
-            if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (first: it waits for nobody)
+            if (s < J && wave_w == 2) omega_step(s, freed_w);   // (first: wave 0 waits for it)
+            if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (it waits for nobody)
             if (s >= 1) {
                 t3_wait(c, T3_C1, s);
+                t3_wait(c, T3_CA, s);
                 const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
                 {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
                     const TPZ I = c.inertia(s - 1);
@@ -164,6 +195,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         if (with_fk) c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
+        if (wave_w == 2) for (int k = freed_w; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
     }
     // ---------------- backward: n = N + R n + com x F + p x (R f),  f = R f + F
     // The f-recursion (wave 1) is the chain everything hangs on: R f, then f = R f + F.  The cross product p x (R f) that the
@@ -199,6 +231,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (cf.rb.axes[i] != 0) {
                 const int ax = abs(cf.rb.axes[i]) - 1;
                 u[i] = c.comb3(elem(w, n2, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i], view(w, c.qd(i)), cf.rb.damping[i]);
+                if (w_lane0(c)) c.mb[T3_U + i] = u[i].id - c.L.idS;
             }
         }
         c.freeVs(nn);

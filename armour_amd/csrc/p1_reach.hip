@@ -1410,7 +1410,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             if (!multi && tv_nw_env > 1 && si == 2) continue;
             const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw);
             // blocks per CU by LDS; the staging area takes what is left
-            const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed(tvchain::kTvFkCap) : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();
+            const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed_fk() : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();
             const int per_cu = multi ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
             if (fixed + 512 * (multi ? 37 + 2 * (nw - 1) : 16) + 256 > (size_t)160 * 1024 / per_cu) continue;
             const int stage_total = (int)(((size_t)160 * 1024 / per_cu - fixed - 256) / 512);

@@ -14,7 +14,7 @@ constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots
 // 3x1 pool of a three-wave block (run_rnea_free: the waves run ahead of each other, so a few joints' states are alive at a time)
 constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 28};
 // ... and of a four-wave block (the forward kinematics on a wave of its own)
-constexpr int kTvPart4First[4] = {0, 10, 30, 52}, kTvPart4Count[4] = {10, 20, 22, 10};
+constexpr int kTvPart4First[4] = {0, 10, 28, 50}, kTvPart4Count[4] = {10, 18, 22, 12};
 
 // (one spare key and one spare row block beyond `cap`)
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
@@ -329,7 +329,8 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
 }
 
 // disturbance, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205), per lane; see finish_torque above
-__device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t_lane) {
+// The tables of joint j are written by wave (j mod nshare) of the `nshare` waves that call this (all with the same u_nom).
+__device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t_lane, int share_id, int nshare) {
     const P1Cfg& cf = *c.cf;
     TW& t = c.w;
     const int lane = t.w.lane;
@@ -345,22 +346,32 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
         const double lo = dcen - rad, hi = dcen + rad;
         rho = iadd(rho, imul(iv(lo, hi), iv(lo, hi)));
         tr[j] = cf.rb.alpha * (cf.rb.M_max - cf.rb.M_min) * cf.ub.eps + 0.5 * fmax(fabs(lo), fabs(hi));
+        if (j % nshare != share_id) continue;
         const int cnt = tv::uni(t.w.cnt[p.id]);
         const size_t idx = ((size_t)b * n + j) * T + t_lane;
         double ra = 0.0;
         int nk = 0;
+        const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
         for (int m0 = 0; m0 < cnt; m0 += 64) {
             const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
             const int nn = min(64, cnt - m0);
-            for (int q = 0; q < nn; q++) {
-                const uint64_t key = tv::readlane_u64(key_v, q);
-                const double x = p.coef[((size_t)(m0 + q)) * 64 + lane];
-                if (t.active && x != 0.0) {
-                    if (key < kmax) {
-                        if (nk < cf.capT) { cf.tq_keys[idx * cf.capT + nk] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + nk] = x; }
-                        nk++;
+            constexpr int kU = 16;   // coefficient rows in flight
+            for (int q0 = 0; q0 < nn; q0 += kU) {
+                double xs[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) xs[u] = pc[(size_t)(m0 + min(q0 + u, nn - 1)) * 64];
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    if (q0 + u >= nn) break;
+                    const uint64_t key = tv::readlane_u64(key_v, q0 + u);
+                    const double x = xs[u];
+                    if (key < kmax) {   // (wave-uniform)
+                        if (t.active && x != 0.0) {
+                            if (nk < cf.capT) { cf.tq_keys[idx * cf.capT + nk] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + nk] = x; }
+                            nk++;
+                        }
                     } else {
-                        ra += fabs(x);
+                        ra += t.active ? fabs(x) : 0.0;   // (x = 0 adds nothing)
                     }
                 }
             }
@@ -372,7 +383,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
         un_ind[j] = ind;
     }
     const double rho_hi = up(sqrt(rho.hi));
-    for (int j = 0; j < n; j++) {
+    for (int j = share_id; j < n; j += nshare) {
         double v = tr[j];
         v += 0.5 * rho_hi;
         v += un_ind[j];
@@ -383,13 +394,17 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 }
 
 // LDS: NW x { sort buffers skey[cap] | sidx[cap] | status | staging rows for a product's short operand } | count table | mailbox
-__host__ __device__ inline size_t tv_lds_fixed(int cap) { return ((size_t)cap * 10 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_fixed(int cap_key, int cap_raw) { return ((size_t)cap_key * 8 + (size_t)cap_raw * 2 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_fixed(int cap) { return tv_lds_fixed(cap, cap); }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 __host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kMbWords) * sizeof(int) + 15) & ~(size_t)15; }
-constexpr int kTvFkCap = 1024;  // sort buffers of the forward-kinematics wave of a four-wave block (its products have <= 0.9 k raw terms)
+// sort buffers of the forward-kinematics wave of a four-wave block: its own products have <= 0.9 k raw terms; the omega recursion it also
+// carries has rotation x vector products, which are ranked (<= 4 runs over the vector's keys) and need room for the permutation only
+constexpr int kTvFkCap = 1024, kTvFkCapRaw = 2048;
+__host__ __device__ inline size_t tv_lds_fixed_fk() { return tv_lds_fixed(kTvFkCap, kTvFkCapRaw); }
 __host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) {
     const int nmain = nw == 4 ? 3 : nw;
-    return (size_t)nmain * tv_lds_fixed(cap) + (nw == 4 ? tv_lds_fixed(kTvFkCap) : 0) + (size_t)(stage_rows + (nw - 1) * stage_rows_other) * 64 * sizeof(double) + tv_lds_shared();
+    return (size_t)nmain * tv_lds_fixed(cap) + (nw == 4 ? tv_lds_fixed_fk() : 0) + (size_t)(stage_rows + (nw - 1) * stage_rows_other) * 64 * sizeof(double) + tv_lds_shared();
 }
 
 // One block per (problem, time group) item, striding over the items; group g of a problem holds the time steps
@@ -415,20 +430,21 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
     // per wave: sort buffers | status | staging rows.  In a three-wave block wave 1 -- the angular recursion, whose products all
     // have a joint rotation (36 rows) as the short operand and which is the busiest role -- gets the larger staging area.
     const int my_stage = (NW == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
-    const int my_cap = (NW == 4 && c.wid == 3) ? kTvFkCap : cf.capKey;
-    // waves 0..2: [sort buffers (cap) | status | staging]; wave 3 of a four-wave block: the same with kTvFkCap
+    const bool fk_bufs = NW == 4 && c.wid == 3;
+    const int my_cap_key = fk_bufs ? kTvFkCap : cf.capKey, my_cap_raw = fk_bufs ? kTvFkCapRaw : cf.capKey;
+    // waves 0..2: [sort buffers (cap) | status | staging]; wave 3 of a four-wave block: the same with the smaller buffers
     const int stage_before = NW == 1 ? 0 : (c.wid > 0 ? cf.tv_stage_rows_other : 0) + (c.wid > 1 ? cf.tv_stage_rows : 0) + (c.wid > 2 ? cf.tv_stage_rows_other : 0);
     LDS_AS unsigned char* mine = lds + (size_t)min(c.wid, 3) * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
     c.w.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap * 8);
-    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap * 10);
-    c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap));
+    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
+    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
+    c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap_key, my_cap_raw));
     c.w.stage_rows = my_stage;
     LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NW) - tv_lds_shared();
     c.w.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.w.cnt + kMaxSlots;
-    c.w.w.cap_raw = my_cap;
-    c.w.w.cap_key = my_cap;
+    c.w.w.cap_raw = my_cap_raw;
+    c.w.w.cap_key = my_cap_key;
     c.w.w.thr = cf.pr.simplify_threshold;
     c.w.w.thr_sq = pzw::sq_threshold(c.w.w.thr);
     c.w.w.lane = threadIdx.x & 63;
@@ -469,7 +485,16 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
         } else {
             if (NW >= kRoles && cf.tv_free_running) run_rnea_free(c, u_nom, b, t_lane);
             else run_rnea(c, u_nom, b, t_lane);
-            if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane);
+#ifdef TV_PROFILE
+            const long long tvp_rnea = clock64();
+#endif
+            if (NW >= kRoles && cf.tv_free_running) {   // every wave takes its share of the joints' tables (the 1x1 slots of u_nom: the mailbox, past the last barrier of the RNEA)
+                for (int j = 0; j < c.n; j++) u_nom[j] = c.S(t3_ld(&c.mb[T3_U + j]));
+                finish_torque_tv(c, u_nom, b, t_lane, c.wid, NW);
+            } else if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane, 0, 1);
+#ifdef TV_PROFILE
+            if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] rnea done at %lld, torque tables %lld cycles\n", it, c.wid, tvp_rnea - tvp_start, (long long)clock64() - tvp_rnea);
+#endif
         }
         __syncthreads();
 #ifdef TV_PROFILE
