@@ -283,31 +283,44 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
     for (int i = 0; i < 18; i++) g[i] = 0.0;
     double ra[3] = {0, 0, 0};
     int nk = 0, ng = 0;
+    const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
     for (int m0 = 0; m0 < cnt; m0 += 64) {
         const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
         const int nn = min(64, cnt - m0);
-        for (int q = 0; q < nn; q++) {
-            const uint64_t key = tv::readlane_u64(key_v, q);
-            const int m = m0 + q;
-            const double x = p.coef[((size_t)m * 3 + 0) * 64 + lane], y = p.coef[((size_t)m * 3 + 1) * 64 + lane], z = p.coef[((size_t)m * 3 + 2) * 64 + lane];
-            const bool has = t.active && (x != 0.0 || y != 0.0 || z != 0.0);
-            const bool isk = key < kmax;
-            const bool isg = !isk && key < lmax && (key & kmask) == 0;
-            if (has) {
+        constexpr int kU = 8;   // monomials whose three rows are in flight together
+        for (int q0 = 0; q0 < nn; q0 += kU) {
+            double xs[kU][3];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const GLB_AS double* pr = pc + (size_t)(m0 + min(q0 + u, nn - 1)) * 3 * 64;
+                xs[u][0] = pr[0]; xs[u][1] = pr[64]; xs[u][2] = pr[128];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                if (q0 + u >= nn) break;
+                const uint64_t key = tv::readlane_u64(key_v, q0 + u);
+                const double x = xs[u][0], y = xs[u][1], z = xs[u][2];
+                const bool has = t.active && (x != 0.0 || y != 0.0 || z != 0.0);
+                const bool isk = key < kmax;                               // (the class of a monomial is wave-uniform)
+                const bool isg = !isk && key < lmax && (key & kmask) == 0;
                 if (isk) {
-                    if (nk < cf.capL) {
-                        cf.link_keys[idx * cf.capL + nk] = (uint32_t)key;
-                        cf.link_coeff[(idx * cf.capL + nk) * 3 + 0] = x; cf.link_coeff[(idx * cf.capL + nk) * 3 + 1] = y; cf.link_coeff[(idx * cf.capL + nk) * 3 + 2] = z;
+                    if (has) {
+                        if (nk < cf.capL) {
+                            cf.link_keys[idx * cf.capL + nk] = (uint32_t)key;
+                            cf.link_coeff[(idx * cf.capL + nk) * 3 + 0] = x; cf.link_coeff[(idx * cf.capL + nk) * 3 + 1] = y; cf.link_coeff[(idx * cf.capL + nk) * 3 + 2] = z;
+                        }
+                        nk++;
                     }
-                    nk++;
                 } else if (isg) {
-                    // (register arrays are not indexed by a per-lane value: three explicit generator columns)
-                    if (ng == 0) { g[0] = x; g[6] = y; g[12] = z; }
-                    else if (ng == 1) { g[1] = x; g[7] = y; g[13] = z; }
-                    else if (ng == 2) { g[2] = x; g[8] = y; g[14] = z; }
-                    ng++;
+                    if (has) {
+                        // (register arrays are not indexed by a per-lane value: three explicit generator columns)
+                        if (ng == 0) { g[0] = x; g[6] = y; g[12] = z; }
+                        else if (ng == 1) { g[1] = x; g[7] = y; g[13] = z; }
+                        else if (ng == 2) { g[2] = x; g[8] = y; g[14] = z; }
+                        ng++;
+                    }
                 } else {
-                    ra[0] += fabs(x); ra[1] += fabs(y); ra[2] += fabs(z);
+                    ra[0] += has ? fabs(x) : 0.0; ra[1] += has ? fabs(y) : 0.0; ra[2] += has ? fabs(z) : 0.0;
                 }
             }
         }
