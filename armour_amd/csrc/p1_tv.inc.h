@@ -72,7 +72,7 @@ struct TChain {
 #ifdef TV_PROFILE
     __device__ long long prof_clock() const { return clock64(); }
     __device__ void prof_waited(long long t0) { w.c_wait += clock64() - t0; }
-    __device__ void prof_forward_done() { w.c_fwd = clock64(); }
+    __device__ void prof_forward_done() { w.c_fwd = clock64(); w.c_wait_fwd = w.c_wait; }
 #else
     __device__ long long prof_clock() const { return 0; }
     __device__ void prof_waited(long long) {}
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
 #ifdef TV_PROFILE
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
-        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld, %lld of it in the forward pass; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_wait_fwd, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif
     }
 #ifdef TV_PROFILE

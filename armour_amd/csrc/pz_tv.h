@@ -51,7 +51,7 @@ struct TW {
     LDS_AS double* stage;  // LDS staging area for the rows of a product's SHORT operand (stage_rows below)
     int stage_rows;        // its capacity in rows of 64 doubles
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
-    long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0;
+    long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0;
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
 #endif
 };
