@@ -431,3 +431,50 @@ def test_builds_are_reproducible_from_launch_to_launch(B, O):
         first = first or got
         for a, b in zip(got, first):
             assert np.array_equal(a, b)
+
+
+def _tables_digest_body(B):
+    """Prints a digest of everything a reach-set build leaves behind (run in a process of its own: the launch-shape switches
+    are read once per process)."""
+    import hashlib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, O = 100, 3
+    bp = random_batch(900, B, O)
+    bp["qd0"][B - 1] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    h = hashlib.sha256()
+    g, jac = nlp.eval_g_jac(random_k(4, B))
+    for a in (g, jac, nlp.torque_radius(), nlp.link_generators()):
+        h.update(np.ascontiguousarray(a).tobytes())
+    for b in (0, B - 1):
+        for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
+            for i in range(cnt):
+                for t in (0, 37, 50, 99):
+                    for a in nlp.pz(which, i, t, b=b):
+                        h.update(np.ascontiguousarray(a).tobytes())
+    print("digest", h.hexdigest())
+
+
+@pytest.mark.parametrize("B,settings", [
+    (1, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1"),
+         dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1", ARMOUR_P1_SPLIT_FK="0")]),
+    (2, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1")]),
+    (3, [dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="1"),
+         dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_FREE="0"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3", ARMOUR_P1_TV_FREE="0")]),
+], ids=["per-step, one problem", "per-step, two problems", "time-vectorised"])
+def test_wave_choreographies_leave_identical_tables(B, settings):
+    """Which wave of a block computes what -- one wave playing every role, three roles with a barrier per joint, three or four
+    free-running waves with the angular velocity, the torque tables and the helper products dealt out among them
+    (p1_free.inc.h) -- must not show in the result: every shape runs the same operators on the same operands.  The digest of
+    g, jac, torque radii, link generators and sampled link / torque PZs is equal across the shapes of one kernel, bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._tables_digest_body(%d)" % (root, os.path.join(root, "tests"), B)
+    digests = []
+    for env in settings:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=120)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("digest ")]
+        assert r.returncode == 0 and lines, (env, r.stdout[-1500:] + r.stderr[-1500:])
+        digests.append(lines[-1])
+    assert len(set(digests)) == 1, list(zip(settings, digests))
