@@ -274,6 +274,11 @@ int armour_refresh_table_stats(ArmourPlanner* h) {
     h->sum_link = sl; h->sum_torque = st; h->max_link = ml; h->max_torque = mt;
     h->h_plane_skip.assign((size_t)h->B, 0ull);
     if (h->O > 0) HIPCHK(hipMemcpy(h->h_plane_skip.data(), h->d_plane_skip, (size_t)h->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (h->O > 0 && getenv("ARMOUR_P1_TRACE")) {   // development: which planes the collision rows never need (p1_reach.hip, armour_p1_planes_kernel)
+        unsigned long long all_and = ~0ull, all_or = 0ull;
+        for (unsigned long long v : h->h_plane_skip) { all_and &= v; all_or |= v; }
+        fprintf(stderr, "[P1 planes] plane_skip of %d problem(s): AND 0x%09llx OR 0x%09llx\n", h->B, all_and & ((1ull << ARMOUR_NPLANES) - 1ull), all_or & ((1ull << ARMOUR_NPLANES) - 1ull));
+    }
     return ARMOUR_OK;
 }
 

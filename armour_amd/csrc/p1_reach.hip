@@ -979,9 +979,26 @@ __host__ __device__ constexpr int plane_pair_b(int p) { int a = 0, b = 1; for (i
 // Planes 9 GRP .. 9 GRP + 8 of one row.  The generator indices are compile-time constants: indexed with run-time values the
 // 9 x 3 generator array lived in scratch memory, and its ~300 scratch loads per thread were what the kernel spent its time on
 // (2.0 ms for the 2.6 GB table of 128 worlds at O = 20, where a plain fill of the same addresses takes 0.45 ms).
+// A normal up to its sign, as three bit patterns: +-0 -> +0, then the whole vector negated if its first non-zero component is
+// negative.  Two normals satisfy (E == C) || (E == -C) component by component exactly when these triples are equal bit for bit.
+__device__ inline void canonical_normal(double C0, double C1, double C2, unsigned long long (&b)[3]) {
+    const double z0 = C0 == 0.0 ? 0.0 : C0, z1 = C1 == 0.0 ? 0.0 : C1, z2 = C2 == 0.0 ? 0.0 : C2;
+    const bool neg = z0 != 0.0 ? z0 < 0.0 : z1 != 0.0 ? z1 < 0.0 : z2 < 0.0;
+    b[0] = (unsigned long long)__double_as_longlong(z0 == 0.0 ? 0.0 : neg ? -z0 : z0);
+    b[1] = (unsigned long long)__double_as_longlong(z1 == 0.0 ? 0.0 : neg ? -z1 : z1);
+    b[2] = (unsigned long long)__double_as_longlong(z2 == 0.0 ? 0.0 : neg ? -z2 : z2);
+}
+__device__ inline unsigned long long normal_signature(const unsigned long long (&b)[3]) {   // 64-bit mix of the triple (a filter: equal triples, equal signatures)
+    unsigned long long h = b[0] * 0x9E3779B97F4A7C15ull;
+    h = (h ^ (h >> 29)) + b[1] * 0xBF58476D1CE4E5B9ull;
+    h = (h ^ (h >> 31)) + b[2] * 0x94D049BB133111EBull;
+    h ^= h >> 30; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+    return h;
+}
+
 template <int GRP>
 __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c)[3], bool in, int Q, int q, int o, int lt, int JT,
-                                       double* __restrict__ out, double* __restrict__ ll, double (&Cs)[ARMOUR_NPLANES][3][64], int lane) {
+                                       double* __restrict__ out, double* __restrict__ ll, unsigned long long (&Sg)[ARMOUR_NPLANES][64], unsigned long long (&sig)[9], int lane) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         constexpr int p0 = GRP * 9;
@@ -1006,8 +1023,49 @@ __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
             }
         }
-        Cs[p][0][lane] = C0; Cs[p][1][lane] = C1; Cs[p][2][lane] = C2;
+        unsigned long long cb[3];
+        canonical_normal(C0, C1, C2, cb);
+        sig[k] = normal_signature(cb);
+        Sg[p][lane] = sig[k];
     }
+}
+
+// Which of this thread's nine planes (9 GRP .. 9 GRP + 8 of row q) repeat an earlier plane of the row or have no normal: bit k of the
+// result.  Every earlier signature is read once and compared with the nine own ones (no branches); only a plane with a matching
+// signature -- a third of them with box obstacles -- fetches normals (its own and the candidate's, from the table just written).
+template <int GRP>
+__device__ inline unsigned planes_redundant(const unsigned long long (&Sg)[ARMOUR_NPLANES][64], const unsigned long long (&sig)[9],
+                                            const double* out, int Q, int q, int lane) {
+    constexpr int p0 = GRP * 9;
+    unsigned long long cand[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cand[k] = 0ull;
+#pragma unroll
+    for (int e2 = 0; e2 < p0 + 8; e2++) {
+        const unsigned long long s = Sg[e2][lane];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            if (e2 < p0 + k) cand[k] |= s == sig[k] ? 1ull << e2 : 0ull;
+    }
+    unsigned red_mask = 0u;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (sig[k] != 0ull && cand[k] == 0ull) continue;   // (the zero normal's signature is 0)
+        const int p = p0 + k;
+        unsigned long long cb[3];
+        canonical_normal(out[armour_plane_index(Q, q, p, 0)], out[armour_plane_index(Q, q, p, 1)], out[armour_plane_index(Q, q, p, 2)], cb);
+        bool red = (cb[0] | cb[1] | cb[2]) == 0ull;
+        unsigned long long mm = cand[k];
+        while (mm != 0ull && !red) {
+            const int e2 = __ffsll((long long)mm) - 1;
+            mm &= mm - 1ull;
+            unsigned long long eb[3];   // same signature: compare the normals themselves
+            canonical_normal(out[armour_plane_index(Q, q, e2, 0)], out[armour_plane_index(Q, q, e2, 1)], out[armour_plane_index(Q, q, e2, 2)], eb);
+            red = eb[0] == cb[0] && eb[1] == cb[1] && eb[2] == cb[2];
+        }
+        if (red) red_mask |= 1u << k;
+    }
+    return red_mask;
 }
 
 // RT/CollisionChecking.cu:136-228: one thread per (b, q = (l*T+t)*O + o) builds the row's 36 half-spaces.
@@ -1021,8 +1079,8 @@ __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c
 __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
                                                                const double* __restrict__ obstacles, double* __restrict__ planes,
                                                                double* __restrict__ planes_ll, double* __restrict__ obs_center,
-                                                               unsigned long long* __restrict__ plane_skip) {
-    __shared__ double Cs[ARMOUR_NPLANES][3][64];  // [plane][axis][row of the block]: conflict-free across a wave
+                                                               unsigned long long* __restrict__ skip_part) {
+    __shared__ unsigned long long Sg[ARMOUR_NPLANES][64];  // [plane][row of the block]: signatures of the normals (18 KB; the normals themselves, 55 KB, held the kernel at two blocks per CU)
     const int Q = J * T * O;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + lane, b = blockIdx.y;
@@ -1043,30 +1101,27 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     double* out = planes + (size_t)b * armour_planes_per_problem(Q);
     if (in && grp == 0 && lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
     // this wave's nine planes, with compile-time generator indices (see planes_of_group)
+    double* ll = planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr;
+    unsigned long long sig[9];
     switch (grp) {
-        case 0: planes_of_group<0>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
-        case 1: planes_of_group<1>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
-        case 2: planes_of_group<2>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
-        default: planes_of_group<3>(G, c, in, Q, q, o, lt, J * T, out, planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr, Cs, lane); break;
+        case 0: planes_of_group<0>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
+        case 1: planes_of_group<1>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
+        case 2: planes_of_group<2>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
+        default: planes_of_group<3>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
     }
     __syncthreads();
     // redundancy of this thread's planes: zero normal, or bit-for-bit +- the normal of an earlier plane of the row
-    // (measured and dropped: skipping the test for planes whose bit is already gone from the problem's mask -- no gain; the
-    //  kernel is bound by its two blocks per CU, i.e. by the 55 KB of normals the test keeps in LDS)
-    unsigned long long skip = in ? 0ull : ~0ull;
+    unsigned long long skip = ~0ull;
     if (in) {
-        for (int k = 0; k < 9; k++) {
-            const int p = grp * 9 + k;
-            const double C0 = Cs[p][0][lane], C1 = Cs[p][1][lane], C2 = Cs[p][2][lane];
-            bool red = (C0 == 0.0 && C1 == 0.0 && C2 == 0.0);
-            for (int e2 = 0; e2 < p && !red; e2++) {
-                const double E0 = Cs[e2][0][lane], E1 = Cs[e2][1][lane], E2 = Cs[e2][2][lane];
-                red = (E0 == C0 && E1 == C1 && E2 == C2) || (E0 == -C0 && E1 == -C1 && E2 == -C2);
-            }
-            if (red) skip |= 1ull << p;
+        unsigned red = 0u;
+        switch (grp) {
+            case 0: red = planes_redundant<0>(Sg, sig, out, Q, q, lane); break;
+            case 1: red = planes_redundant<1>(Sg, sig, out, Q, q, lane); break;
+            case 2: red = planes_redundant<2>(Sg, sig, out, Q, q, lane); break;
+            default: red = planes_redundant<3>(Sg, sig, out, Q, q, lane); break;
         }
         // planes of the other three groups: not this thread's to clear
-        skip |= ~(((1ull << 9) - 1ull) << (grp * 9));
+        skip = ~(((unsigned long long)(~red & 0x1ffu)) << (grp * 9));
     }
     // AND over the wave, then one atomic per wave (each wave owns 9 of the 36 bits; the other bits are all ones)
 #pragma unroll
@@ -1074,7 +1129,24 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
         const unsigned lo = __shfl_xor((unsigned)skip, o2, 64), hi = __shfl_xor((unsigned)(skip >> 32), o2, 64);
         skip &= ((unsigned long long)hi << 32) | lo;
     }
-    if (lane == 0) atomicAnd(&plane_skip[b], skip);
+    // (one atomicAnd per wave on the problem's mask cost a seventh of the kernel: 112 k of them on 128 words at B = 128)
+    if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = skip;
+}
+
+// plane_skip[b] = AND of the planes kernel's per-wave masks of problem b
+__global__ __launch_bounds__(256) void armour_p1_skip_reduce_kernel(const unsigned long long* __restrict__ part, int per_problem, unsigned long long* __restrict__ plane_skip) {
+    __shared__ unsigned long long s[4];
+    const int b = blockIdx.x;
+    unsigned long long v = ~0ull;
+    for (int i = threadIdx.x; i < per_problem; i += 256) v &= part[(size_t)b * per_problem + i];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o2, 64), hi = __shfl_xor((unsigned)(v >> 32), o2, 64);
+        v &= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) plane_skip[b] = s[0] & s[1] & s[2] & s[3];
 }
 
 
@@ -1175,6 +1247,7 @@ struct P1Work {
     double* d_obstacles = nullptr; size_t obs_cap = 0;
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
     unsigned char* tv_arena = nullptr; size_t tv_arena_total = 0;
+    unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -1188,6 +1261,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
+    if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
     if (wk->tv_arena) (void)hipFree(wk->tv_arena);
     if (wk->ev0) (void)hipEventDestroy(wk->ev0);
@@ -1488,9 +1562,16 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (O > 0) {
         const int Q = J * T * O;
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
-        HIPCHK(hipMemsetAsync(h->d_plane_skip, 0xFF, (size_t)B * sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3((Q + 63) / 64, B), dim3(256), 0, h->stream, B, T, J, O,
-                           wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, h->d_plane_skip);
+        const int nbx = (Q + 63) / 64;
+        if ((size_t)B * nbx * 4 > wk->skip_part_cap) {
+            if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
+            wk->d_skip_part = nullptr;
+            HIPCHK(hipMalloc((void**)&wk->d_skip_part, (size_t)B * nbx * 4 * sizeof(unsigned long long)));
+            wk->skip_part_cap = (size_t)B * nbx * 4;
+        }
+        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
+                           wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part);
+        hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, wk->d_skip_part, nbx * 4, h->d_plane_skip);
         h->ll_shared = 1; h->d_from_center = 1;
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
