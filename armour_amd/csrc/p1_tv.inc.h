@@ -20,13 +20,13 @@ constexpr int kTvPart4First[4] = {0, 10, 28, 50}, kTvPart4Count[4] = {10, 18, 22
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
 
 struct TLayout {
-    int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (1 or 3); npools: parts of the 3x1 pool (1, 3 or 4)
+    int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (one per wave); npools: parts of the 3x1 pool (1, 3 or 4)
     size_t offV, offS, offM, offJM, offJV, offJS, total;
     int idV, idS, idM, idJM, idJV, idJS;
 };
 __host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves) {
     TLayout L;
-    const int nroles = nwaves == 1 ? 1 : kRoles;
+    const int nroles = nwaves;   // (a four-wave block builds the JRS on all four waves)
     L.nroles = nroles; L.npools = nwaves;
     L.nV = nwaves == 1 ? kNVOneWave : nwaves == kRoles ? kTvPartFirst[kRoles - 1] + kTvPartCount[kRoles - 1] : kTvPart4First[3] + kTvPart4Count[3];
     L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
@@ -200,13 +200,13 @@ __device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& ou
 }
 
 // JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations).
-// Joint i is built by role i % 3 with that role's scratch slots; the caller follows with a block barrier.
+// Joint i is built by wave i % (number of waves) with that wave's scratch slots; the caller follows with a block barrier.
 __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_only) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
     for (int i = 0; i < J; i++) {
-        const int role = i % kRoles;
+        const int role = i % c.L.nroles;
         if (!c.is(role)) continue;
         double rp[9];
         rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
