@@ -102,11 +102,12 @@ struct Out {
         for (int e = 0; e < SZ; e++) asum[e] = 0.0;
     }
     __device__ inline void emit(uint64_t key, const double* v) {
-        if (n < cap) {
-            if (lane == 0) keys[n] = key;
+        // no branches here (each one costs the walk a block of register moves behind it): a term beyond the capacity lands in the
+        // slot's spare row block (tv_slot_bytes) -- finish() flags the overflow -- and every lane stores the wave-uniform key
+        const int at = n < cap ? n : cap;
+        keys[at] = key;
 #pragma unroll
-            for (int e = 0; e < SZ; e++) coef[((size_t)n * SZ + e) * WAVE + lane] = v[e];
-        }
+        for (int e = 0; e < SZ; e++) coef[((size_t)at * SZ + e) * WAVE + lane] = v[e];
 #pragma unroll
         for (int e = 0; e < SZ; e++) asum[e] += fabs(v[e]);
         n++;
@@ -270,16 +271,12 @@ struct MulCtx {
             for (int e = 0; e < SH::BSZ; e++) cb[e] = r.cb[e];
         }
         SH::mul(ca, cb, c);
-        if (first) {  // (wave-uniform: a scalar branch, not SZ selects)
+        // (selects on the wave-uniform `first`, not a branch: every branch of the walk ends in a block of register moves that merges
+        //  the accumulators of its two sides -- about forty per raw term before this form)
 #pragma unroll
-            for (int e = 0; e < SH::SZ; e++) acc[e] = c[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < SH::SZ; e++) acc[e] += c[e];
-        }
+        for (int e = 0; e < SH::SZ; e++) { const double sum = acc[e] + c[e]; acc[e] = first ? c[e] : sum; }
     }
     __device__ inline void close(uint64_t key) {
-        // the common case first: no lane keeps the term (nine raw terms in ten are pruned) -- one test, SZ additions
         bool small;
         if constexpr (SH::SZ == 1) small = fabs(acc[0]) <= thr;
         else {
@@ -288,15 +285,17 @@ struct MulCtx {
             for (int e = 0; e < SH::SZ; e++) q += acc[e] * acc[e];
             small = q <= thr_sq;
         }
-        if (__ballot(!small && active) == 0ull) {
-#pragma unroll
-            for (int e = 0; e < SH::SZ; e++) rad[e] += fabs(acc[e]);
-            return;
-        }
         const bool keep = !small && active;
+        // the pruned amount goes to the radius in every lane that does not keep the term (all of them, nine times in ten) ...
 #pragma unroll
-        for (int e = 0; e < SH::SZ; e++) { rad[e] += keep ? 0.0 : fabs(acc[e]); acc[e] = keep ? acc[e] : 0.0; }
-        o->emit(key, acc);
+        for (int e = 0; e < SH::SZ; e++) rad[e] += keep ? 0.0 : fabs(acc[e]);
+        // ... and only a term some lane keeps is written
+        if (__ballot(keep) != 0ull) {
+            double v[SH::SZ];
+#pragma unroll
+            for (int e = 0; e < SH::SZ; e++) v[e] = keep ? acc[e] : 0.0;
+            o->emit(key, v);
+        }
     }
 };
 
@@ -443,36 +442,28 @@ struct CrossCtx {
         p6[0] = ca[1] * cb[2]; p6[1] = ca[2] * cb[1];
         p6[2] = ca[2] * cb[0]; p6[3] = ca[0] * cb[2];
         p6[4] = ca[0] * cb[1]; p6[5] = ca[1] * cb[0];
-        if (first) {  // (wave-uniform: a scalar branch, not six selects)
+        // (selects on the wave-uniform `first`: see MulCtx::add)
 #pragma unroll
-            for (int e = 0; e < 6; e++) acc[e] = p6[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 6; e++) acc[e] += p6[e];
-        }
+        for (int e = 0; e < 6; e++) { const double sum = acc[e] + p6[e]; acc[e] = first ? p6[e] : sum; }
     }
     __device__ inline void close(uint64_t key) {
-        // the common case first: all six products are below the threshold in every lane -- then each goes to its product's
-        // radius and nothing else happens (no difference, no stack entry)
-        {
-            bool all_small = true;
+        // first stage for everybody: a product below the threshold goes to its product's radius.  In the common case that is all
+        // six of them in every lane, and then nothing else happens (no difference, no stack entry)
+        bool h[6], anyh = false;
 #pragma unroll
-            for (int e = 0; e < 6; e++) all_small = all_small && (fabs(acc[e]) <= thr);
-            if (__ballot(!all_small) == 0ull) {
-#pragma unroll
-                for (int e = 0; e < 6; e++) rad[e] += fabs(acc[e]);
-                return;
-            }
+        for (int e = 0; e < 6; e++) {
+            h[e] = !(fabs(acc[e]) <= thr);
+            rad[e] += h[e] ? 0.0 : fabs(acc[e]);
+            anyh = anyh || h[e];
         }
-        // the three simplify() stages of the composed cross product, per lane, as selects (see verdict())
+        if (__ballot(anyh) == 0ull) return;
+        // the other two simplify() stages of the composed cross product, per lane, as selects (see verdict())
         double u[3];
         bool anyc = false;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double v0 = acc[2 * c], v1 = acc[2 * c + 1];
-            const bool h0 = !(fabs(v0) <= thr), h1 = !(fabs(v1) <= thr);
-            rad[2 * c] += h0 ? 0.0 : fabs(v0);
-            rad[2 * c + 1] += h1 ? 0.0 : fabs(v1);
+            const bool h0 = h[2 * c], h1 = h[2 * c + 1];
             double wv = h0 ? 1.0 * v0 : -1.0 * v1;
             const double wv2 = wv + -1.0 * v1;
             wv = (h0 && h1) ? wv2 : wv;
@@ -654,7 +645,8 @@ struct LinCtx {
         present = present && !drop;
     }
     __device__ inline void add(const Regs& r, bool first) {
-        if (first) { present = false; last = -1; }
+        present = first ? false : present;   // (selects on the wave-uniform `first`: see MulCtx::add)
+        last = first ? -1 : last;
         double c[SZ];
         const int rk = term(r, c);
         if constexpr (CHAIN) {
