@@ -586,26 +586,29 @@ struct LinCtx {
     }
     // Only the loads: what is loaded must not be touched here, or the wave would wait for it before issuing the next term's
     // loads.  The source is picked with scalar selects (idx and everything derived from it is wave-uniform).
+    // (row0[k] = address of source k's row of raw term 0 in THIS lane, i.e. coef + (off - first * stride) rows, set by prepare():
+    //  a raw term's rows are then row0 + idx * stride rows -- three selects per source instead of five and no subtraction; a
+    //  1x1 source loads its one row SZ times rather than branching, term() reads x[0] only)
+    const GLB_AS double* row0[NS];
+    __device__ inline void prepare() {
+#pragma unroll
+        for (int k = 0; k < NS; k++) row0[k] = s[k].v.coef + ((ptrdiff_t)s[k].v.off - (ptrdiff_t)off[k] * s[k].v.stride) * WAVE + lane;
+    }
     __device__ inline void load(int idx, Regs& r) const {
         const int k = seg_of(idx);
-        const GLB_AS double* base = s[0].v.coef;
-        int stride = s[0].v.stride, voff = s[0].v.off, first = off[0], comp = s[0].comp;
+        const GLB_AS double* base = row0[0];
+        int stride = s[0].v.stride, comp = s[0].comp;
 #pragma unroll
         for (int q = 1; q < NS; q++) {
             const bool me = (k == q);
-            base = me ? s[q].v.coef : base;
-            stride = me ? s[q].v.stride : stride; voff = me ? s[q].v.off : voff; first = me ? off[q] : first; comp = me ? s[q].comp : comp;
+            base = me ? row0[q] : base;
+            stride = me ? s[q].v.stride : stride; comp = me ? s[q].comp : comp;
         }
         r.idx = idx;
-        const GLB_AS double* src = base + ((size_t)(idx - first) * stride + voff) * WAVE + lane;
-        if (comp < 0) {
+        const GLB_AS double* src = base + (ptrdiff_t)idx * stride * WAVE;
+        const int step = comp < 0 ? WAVE : 0;
 #pragma unroll
-            for (int e = 0; e < SZ; e++) r.x[e] = src[e * WAVE];
-        } else {
-            r.x[0] = src[0];
-#pragma unroll
-            for (int e = 1; e < SZ; e++) r.x[e] = 0.0;
-        }
+        for (int e = 0; e < SZ; e++) r.x[e] = src[e * step];
     }
     // scale * embed(source entry); returns the source index
     __device__ inline int term(const Regs& r, double* c) const {
@@ -634,6 +637,13 @@ struct LinCtx {
             return q <= thr_sq;
         }
     }
+    // stage k if `run` (wave-uniform), as selects: no branch, no merge block behind it
+    __device__ inline void stage_if(int k, bool run) {
+        const bool drop = run && present && is_small();
+#pragma unroll
+        for (int e = 0; e < SZ; e++) ra[k][e] += drop ? fabs(acc[e]) : 0.0;
+        present = present && !drop;
+    }
     __device__ inline void stage(int k) {
         const bool drop = present && is_small();
 #pragma unroll
@@ -650,17 +660,22 @@ struct LinCtx {
         double c[SZ];
         const int rk = term(r, c);
         if constexpr (CHAIN) {
-            for (int k = max(last + 1, 1); k < rk; k++) stage(k);  // stages without a member of this key
+#pragma unroll
+            for (int k = 1; k < NS; k++) stage_if(k, k > last && k < rk);  // stages without a member of this key
         }
 #pragma unroll
         for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + c[e] : c[e];
         present = true;
-        if constexpr (CHAIN) { if (rk >= 1) stage(rk); }
+        if constexpr (CHAIN) {
+#pragma unroll
+            for (int k = 1; k < NS; k++) stage_if(k, k == rk);
+        }
         last = rk;
     }
     __device__ inline void close(uint64_t key) {
         if constexpr (CHAIN) {
-            for (int k = max(last + 1, 1); k < NS; k++) stage(k);
+#pragma unroll
+            for (int k = 1; k < NS; k++) stage_if(k, k > last);
         } else {
             // one simplify() at the end: pruned terms go to ra[0]
             const bool drop = present && is_small();
@@ -712,6 +727,8 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
         }
     }
     cx.off[NS] = N; ev.off[NS] = N;
+    cx.lane = lane;
+    cx.prepare();
     WSYNC();  // every lane has read the sources' header rows before `out` (possibly one of them) is written
     Out<SZ> o;
     o.init(out, lane);
