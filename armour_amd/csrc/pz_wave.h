@@ -415,9 +415,28 @@ struct LinEval {
         for (int i = 1; i < NS; i++) k += (idx >= off[i]) ? 1 : 0;
         return k;
     }
+    // (a source picked by a per-lane index is picked with selects: `s[k]` with a run-time k puts the whole array into scratch
+    //  memory, and every access becomes a memory round trip)
     __device__ inline uint64_t key(int idx) const {
         const int k = seg_of(idx);
-        return s[k].v.keys[idx - off[k]];
+        const GLB_AS uint64_t* keys = s[0].v.keys;
+        int first = off[0];
+#pragma unroll
+        for (int q = 1; q < NS; q++) { const bool me = (k == q); keys = me ? s[q].v.keys : keys; first = me ? off[q] : first; }
+        return keys[idx - first];
+    }
+    template <int K>
+    __device__ inline void coef_of(int idx, double* c) const {   // idx is a term of source K
+        const Seg& g = s[K];
+        const GLB_AS double* src = g.v.coef + (size_t)(idx - off[K]) * g.v.stride + g.v.off;
+        if (g.comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) c[e] = g.scale * src[e];
+        } else {
+            const double v = g.scale * src[0];
+#pragma unroll
+            for (int e = 0; e < SZ; e++) c[e] = (e == g.comp) ? v : 0.0;
+        }
     }
     // every source is a simplified PZ (sorted, unique keys): merge the NS runs by ranking each term with binary
     // searches in the other runs; ties across runs go to the earlier run (= generation order)
@@ -434,7 +453,10 @@ struct LinEval {
         for (int idx = w.lane; idx < N; idx += WAVE) {
             const int k = seg_of(idx);
             const uint64_t ky = w.skey[idx];
-            int rank = idx - off[k];
+            int first = off[0];
+#pragma unroll
+            for (int q = 1; q < NS; q++) first = (k == q) ? off[q] : first;
+            int rank = idx - first;
 #pragma unroll
             for (int k2 = 0; k2 < NS; k2++) {
                 if (k2 == k) continue;
@@ -451,18 +473,34 @@ struct LinEval {
     __device__ inline uint64_t key_lds(const Wave& w, int idx) const { return w.skey[idx]; }
     __device__ inline void coef(int idx, double* c) const {
         const int k = seg_of(idx);
-        const Seg& g = s[k];
-        const GLB_AS double* src = g.v.coef + (size_t)(idx - off[k]) * g.v.stride + g.v.off;
-        if (g.comp < 0) {
+        const GLB_AS double* cf = s[0].v.coef;
+        int first = off[0], stride = s[0].v.stride, voff = s[0].v.off, comp = s[0].comp;
+        double scale = s[0].scale;
 #pragma unroll
-            for (int e = 0; e < SZ; e++) c[e] = g.scale * src[e];
+        for (int q = 1; q < NS; q++) {
+            const bool me = (k == q);
+            cf = me ? s[q].v.coef : cf; first = me ? off[q] : first; stride = me ? s[q].v.stride : stride; voff = me ? s[q].v.off : voff;
+            comp = me ? s[q].comp : comp; scale = me ? s[q].scale : scale;
+        }
+        const GLB_AS double* src = cf + (size_t)(idx - first) * stride + voff;
+        if (comp < 0) {
+#pragma unroll
+            for (int e = 0; e < SZ; e++) c[e] = scale * src[e];
         } else {
-            const double v = g.scale * src[0];
+            const double v = scale * src[0];
 #pragma unroll
-            for (int e = 0; e < SZ; e++) c[e] = (e == g.comp) ? v : 0.0;
+            for (int e = 0; e < SZ; e++) c[e] = (e == comp) ? v : 0.0;
         }
     }
 };
+
+template <int SZ, int NS>
+__device__ inline void coef_static(const LinEval<SZ, NS>& ev, int k, int idx, double* c) {
+    if constexpr (NS >= 1) { if (k == 0) { ev.template coef_of<0>(idx, c); return; } }
+    if constexpr (NS >= 2) { if (k == 1) { ev.template coef_of<1>(idx, c); return; } }
+    if constexpr (NS >= 3) { if (k == 2) { ev.template coef_of<2>(idx, c); return; } }
+    if constexpr (NS >= 4) { if (k == 3) { ev.template coef_of<3>(idx, c); return; } }
+}
 
 template <int SZ, int NS>
 __device__ PZW_NOINLINE void lincomb(Wave& w_, const PZ& out_, const Seg* segs) {
@@ -582,7 +620,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
                     // the sources hold unique keys, so a run has at most one term per source, in source order
                     if (q < N && (indirect ? ev.key_lds(w, w.sidx[q]) : w.skey[q]) == key && ev.seg_of(w.sidx[q]) == k) {
                         double c[SZ];
-                        ev.coef(w.sidx[q], c);
+                        coef_static<SZ, NS>(ev, k, w.sidx[q], c);   // (k is a constant once the loop is unrolled)
 #pragma unroll
                         for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + c[e] : c[e];
                         present = true;
