@@ -15,8 +15,8 @@
 // freed by its owner once the counters show every reader past it (state_k: K joints back).  Same operators on the same
 // operands as run_rnea: bit-identical tables.
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
-       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_A2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
+       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS,
+       T3_CNT = T3_X2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 constexpr int kMbWords = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;  // LDS mailbox of run_rnea / run_rnea_free
 __device__ inline int t3_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <class CH>
@@ -52,6 +52,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
     const int wave_w = fk_wave ? 3 : 2;   // the wave that runs the omega recursion (see below)
+    // Four-wave blocks (release-build stamps: forward pass done after 7.4 / 8.8 / 10.4 / 12.8 M cycles on the forward-kinematics, angular,
+    // linear-acceleration and F / N waves): the angular wave builds the moments of the last two links once its recursion is through, the
+    // forward-kinematics wave the two constant cross products of every linear-acceleration step, and the F / N wave does everything that
+    // needs the state alone before it waits for the linear acceleration.  (Each of the three alone changes nothing: the pass ends with
+    // F of the last link, which needs the last linear acceleration.)
+    const int n_tail = fk_wave ? (J >= 4 ? 3 : 0) : 0;
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 1) {
         c.role = 1;
@@ -118,6 +124,16 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
             t3_signal(c, T3_C1, s + 1);
         }
+        for (int s = J; s > J - n_tail; s--) {   // N = I * wdot + cross(w_aux, I * w) of link s - 1
+            t3_wait(c, T3_CA, s);
+            const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
+            const TPZ I = c.inertia(s - 1);
+            TPZ t1 = c.mulMV(I, wdot);
+            TPZ t2 = c.mulMV(I, wv);
+            TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+            TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
+            t3_post(c, T3_N + s - 1, N);
+        }
         c.prof_forward_done(); c.bar();   // (A) the forward pass is over everywhere
         for (int k = freed; k <= J; k++)
             for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
@@ -135,10 +151,16 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             }
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2), lacc = t3_take(c, T3_LA + s);
             const double* tr = &cf.rb.trans[3 * s];
-            TPZ c1 = c.crossPzMat(wdot, tr);
-            TPZ c2 = c.crossPzMat(waux, tr);
-            TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
-            TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
+            TPZ c1 = wdot, c2 = waux;
+            if (fk_wave) {   // wdot x p, w_aux x p: from the forward-kinematics wave
+                t3_wait(c, T3_C3, s + 1);
+                c1 = t3_take(c, T3_X1 + s); c2 = t3_take(c, T3_X2 + s);
+            } else {
+                c1 = c.crossPzMat(wdot, tr);
+                c2 = c.crossPzMat(waux, tr);
+            }
+            TPZ c3 = c.crossPzPz(wv, c2); if (!fk_wave) c.freeVs(c2);
+            TPZ s2 = c.sum3(lacc, c1, c3); if (!fk_wave) c.freeVs(c1); c.freeVs(c3);
             TPZ nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
             t3_post(c, T3_LA + s + 1, nl);
             t3_signal(c, T3_C0, s + 1);
@@ -154,11 +176,25 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         int freed_w = 0;
         for (int s = 0; s < J; s++) {
             omega_step(s, freed_w);   // first: wave 0 waits for it
+            {   // the two cross products with the joint offset for wave 0's step s, at most two steps ahead of it
+                if (s >= 2) {
+                    t3_wait(c, T3_C0, s - 1);
+                    c.freeVs(t3_take(c, T3_X1 + s - 2)); c.freeVs(t3_take(c, T3_X2 + s - 2));
+                }
+                t3_wait(c, T3_C1, s);
+                const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
+                const double* tr = &cf.rb.trans[3 * s];
+                TPZ x1 = c.crossPzMat(wdot, tr);
+                TPZ x2 = c.crossPzMat(waux, tr);
+                t3_post(c, T3_X1 + s, x1); t3_post(c, T3_X2 + s, x2);
+                t3_signal(c, T3_C3, s + 1);
+            }
             fk_step(c, fk, s, b, t_lane);
         }
         c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
         for (int k = freed_w; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
+        for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
@@ -171,7 +207,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 t3_wait(c, T3_C1, s);
                 t3_wait(c, T3_CA, s);
                 const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
-                {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
+                if (s <= J - n_tail) {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
                     const TPZ I = c.inertia(s - 1);
                     TPZ t1 = c.mulMV(I, wdot);
                     TPZ t2 = c.mulMV(I, wv);
@@ -179,13 +215,13 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                     TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
                     t3_post(c, T3_N + s - 1, N);
                 }
-                t3_wait(c, T3_C0, s);
-                const TPZ lacc = t3_take(c, T3_LA + s);
-                {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com)))
+                {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com))): all but the last sum before the linear acceleration is needed
                     const double* cm = &cf.rb.com[3 * (s - 1)];
                     TPZ c1 = c.crossPzMat(wdot, cm);
                     TPZ c2 = c.crossPzMat(waux, cm);
                     TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                    t3_wait(c, T3_C0, s);
+                    const TPZ lacc = t3_take(c, T3_LA + s);
                     TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
                     TPZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
                     t3_post(c, T3_F + s - 1, F);
@@ -216,6 +252,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.freeVs(f);
         c.bar();   // (B) the helper has read every R f
         for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_A2 + i));
+        for (int i = J - n_tail; i < J; i++) c.freeVs(t3_take(c, T3_N + i));   // (the tail moments are this wave's)
     } else if (c.wid == 0) {
         c.role = 0;
         TPZ nn = c.allocV();
@@ -247,11 +284,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         c.bar();   // (B) wave 0 has read every p x (R f)
         for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
-        if (helper == 2) { for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); } }
+        if (helper == 2) { for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); } }
     } else if (c.wid == 2) {   // (four waves: wave 3 is the helper)
         c.role = 2;
         c.bar();   // (B) both recursions are through: nobody reads N_i, F_i any more
-        for (int i = 0; i < J; i++) { c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
+        for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
     }
 }
 

@@ -14,7 +14,7 @@ constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots
 // 3x1 pool of a three-wave block (run_rnea_free: the waves run ahead of each other, so a few joints' states are alive at a time)
 constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 28};
 // ... and of a four-wave block (the forward kinematics on a wave of its own)
-constexpr int kTvPart4First[4] = {0, 10, 28, 50}, kTvPart4Count[4] = {10, 18, 22, 12};
+constexpr int kTvPart4First[4] = {0, 8, 26, 48}, kTvPart4Count[4] = {8, 18, 22, 14};
 
 // (one spare key and one spare row block beyond `cap`)
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
@@ -512,7 +512,9 @@ __global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
         __syncthreads();
 #ifdef TV_PROFILE
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
+#ifdef TV_PROFILE_FULL
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
+#endif
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld, %lld of it in the forward pass; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_wait_fwd, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif
     }

@@ -30,6 +30,9 @@ using pzw::WAVE;
 using pzw::Wave;
 
 #define TV_NOINLINE __attribute__((noinline))
+#if defined(TV_PROFILE_FULL) && !defined(TV_PROFILE)
+#define TV_PROFILE   // -DTV_PROFILE: per-wave stamps and waits only; -DTV_PROFILE_FULL: also cycles per operator type (slows the walks)
+#endif
 
 struct TPZ {
     GLB_AS uint64_t* keys;
@@ -55,7 +58,7 @@ struct TW {
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
 #endif
 };
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
 #define TVP_T0 const long long tvp0__ = clock64();
 #define TVP_T1 const long long tvp1__ = clock64();
 #define TVP_END(t, N, E, TY) { const long long tvp2__ = clock64(); (t).c_sort += tvp1__ - tvp0__; (t).c_walk += tvp2__ - tvp1__; (t).n_raw += (N); (t).n_calls += 1; (t).n_emit += (E); (t).c_type[TY] += tvp2__ - tvp1__; (t).n_type[TY] += (N); }
@@ -150,7 +153,7 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
 //     void add(const Regs&, bool first)          -- accumulate it (first: start a new sum)
 //     void close(uint64_t key)                   -- the run of equal keys is complete: verdict + emit
 // Loads run U terms ahead of their use.
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
 __device__ long long g_tvprof[8];  // [0] load phase, [1] process phase, [2] chunk prologue, [3] batches
 #endif
 template <int U, class P, class KeyAt, class IdxAt>
@@ -162,14 +165,14 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
     bool have = false;
     uint64_t cur = 0;
     for (int base = 0; base < N; base += WAVE) {
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
         long long wp0 = clock64();
 #endif
         const int p = base + lane;
         const uint64_t key_v = p < N ? keyat(p) : 0ull;
         const int idx_v = p < N ? idxat(p) : 0;
         const int n = min(WAVE, N - base);
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
         { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[2] += x - wp0; wp0 = x; }
 #endif
         for (int l0 = 0; l0 < n; l0 += U) {
@@ -179,7 +182,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                 const int l = min(l0 + u, n - 1);
                 pol.load(__builtin_amdgcn_readlane(idx_v, l), regs[u]);
             }
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
             { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) { g_tvprof[0] += x - wp0; g_tvprof[3] += 1; } wp0 = x; }
 #endif
 #pragma unroll
@@ -191,7 +194,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                     have = true; cur = key;
                 }
             }
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
             { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[1] += x - wp0; wp0 = x; }
 #endif
         }
@@ -798,7 +801,7 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
     WSYNC();
     Out<3> o;
     o.init(out, lane);
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
     const long long cc0__ = clock64();
 #endif
     for (int m0 = 0; m0 < a.cnt; m0 += WAVE) {
@@ -837,7 +840,7 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
             }
         }
     }
-#ifdef TV_PROFILE
+#ifdef TV_PROFILE_FULL
     t.c_cc += clock64() - cc0__;
 #endif
 #pragma unroll
