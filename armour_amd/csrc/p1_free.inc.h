@@ -57,7 +57,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // forward-kinematics wave the two constant cross products of every linear-acceleration step, and the F / N wave does everything that
     // needs the state alone before it waits for the linear acceleration.  (Each of the three alone changes nothing: the pass ends with
     // F of the last link, which needs the last linear acceleration.)
-    const int n_tail = fk_wave ? (J >= 4 ? 3 : 0) : 0;
+    const int n_tail = J >= 4 ? 3 : 0;   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 1) {
         c.role = 1;
@@ -100,6 +100,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     if (c.wid == 1) {
         c.role = 1;
         int freed = 0;   // states [0, freed) have been given back
+        int freed_w1 = 0;
         for (int s = 0; s < J; s++) {
             while (freed + K < s + 1) {   // (wdot, w_aux)_k, k = freed: read by wave 0 at step k (< J), by wave 2 at step k (>= 1), by this wave at step k (done)
                 const int k = freed;
@@ -108,6 +109,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
                 freed++;
             }
+            if (wave_w == 1) omega_step(s, freed_w1);
             const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
             const TPZ Rt = c.Rt(s);
             const int ax = abs(cf.rb.axes[s]) - 1;
@@ -137,6 +139,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.prof_forward_done(); c.bar();   // (A) the forward pass is over everywhere
         for (int k = freed; k <= J; k++)
             for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
+        if (wave_w == 1) for (int k = freed_w1; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
     } else if (c.wid == 0) {
         c.role = 0;
         int freed = 0;

@@ -292,8 +292,8 @@ struct Chain {
     __device__ bool is(int role) const { return nw == 1 || wid == role; }
     __device__ Wave& wave() { return w; }
     __device__ const Wave& wave() const { return w; }
-    // (profile hooks of run_rnea_free)
-#ifdef P1_PROFILE
+    // (profile hooks of run_rnea_free; -DP1_STAMPS: these alone, without the per-operator counters of -DP1_PROFILE)
+#if defined(P1_PROFILE) || defined(P1_STAMPS)
     long long fwd_done = 0;
     __device__ long long prof_clock() const { return clock64(); }
     __device__ void prof_waited(long long t0) { bar_wait += clock64() - t0; }
@@ -303,7 +303,7 @@ struct Chain {
     __device__ void prof_waited(long long) {}
     __device__ void prof_forward_done() {}
 #endif
-#ifdef P1_PROFILE
+#if defined(P1_PROFILE) || defined(P1_STAMPS)
     mutable long long bar_wait = 0;
     __device__ void bar() const { const long long t0 = clock64(); __syncthreads(); bar_wait += clock64() - t0; }
 #else
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.role = 0;
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         __syncthreads();
-#ifdef P1_PROFILE
+#if defined(P1_PROFILE) || defined(P1_STAMPS)
         const long long ph0 = clock64();
 #endif
         build_jrs(c, b, t, fk_only);
@@ -955,6 +955,10 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.bar_wait = 0;
         if (threadIdx.x == 0 && blockIdx.x == 0)
             printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
+#endif
+#if defined(P1_STAMPS) && !defined(P1_PROFILE)
+        if (c.w.lane == 0 && t == 60 && !fk_only) printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits; forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.fwd_done - ph0);
+        c.bar_wait = 0;
 #endif
     }
 #ifdef P1_PROFILE
