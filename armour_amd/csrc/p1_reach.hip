@@ -294,10 +294,10 @@ struct Chain {
     __device__ const Wave& wave() const { return w; }
     // (profile hooks of run_rnea_free; -DP1_STAMPS: these alone, without the per-operator counters of -DP1_PROFILE)
 #if defined(P1_PROFILE) || defined(P1_STAMPS)
-    long long fwd_done = 0;
+    long long fwd_done = 0, wait_fwd = 0;
     __device__ long long prof_clock() const { return clock64(); }
     __device__ void prof_waited(long long t0) { bar_wait += clock64() - t0; }
-    __device__ void prof_forward_done() { fwd_done = clock64(); }
+    __device__ void prof_forward_done() { fwd_done = clock64(); wait_fwd = bar_wait; }
 #else
     __device__ long long prof_clock() const { return 0; }
     __device__ void prof_waited(long long) {}
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
 #endif
 #if defined(P1_STAMPS) && !defined(P1_PROFILE)
-        if (c.w.lane == 0 && t == 60 && !fk_only) printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits; forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.fwd_done - ph0);
+        if (c.w.lane == 0 && t == 60 && !fk_only) printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
         c.bar_wait = 0;
 #endif
     }
