@@ -58,7 +58,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // needs the state alone before it waits for the linear acceleration.  (Each of the three alone changes nothing: the pass ends with
     // F of the last link, which needs the last linear acceleration.)
     // (at most K + 1 of them: the states the tail reads must still be alive when the recursion ends -- it gives state k back K joints later)
-    const int n_tail = fk_wave ? (J >= 4 ? 3 : 0) : (J >= 5 ? 4 : J >= 4 ? 3 : 0);   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
+    const int n_tail = J >= 5 ? 4 : J >= 4 ? 3 : 0;   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 1) {
         c.role = 1;
