@@ -288,7 +288,13 @@ inline int worker_main(int argc, char** argv) {
     if (argc < 2 || (strcmp(argv[1], "armour") && strcmp(argv[1], "armtd"))) { fprintf(stderr, "usage: armour_worker armour|armtd [--serve] [buffer_dir] [T]\n"); return 2; }
     // started by armour_main / armtd_main (planner_client.cpp): if that front end dies -- e.g. killed by its caller --
     // this process, which holds the GPU and the socket, gets SIGTERM instead of living on as an orphan
-    prctl(PR_SET_PDEATHSIG, SIGTERM);
+    // Only when a front end did start it (ARMOUR_WORKER_PARENT = its pid): a worker started directly -- `rocprofv3 -- armour_worker ...
+    // --serve` from a script, nohup -- must not be terminated when the shell that launched it exits.  And the front end may have died
+    // before this line runs: then the worker has already been re-parented, the death signal would never come, and it leaves now.
+    if (const char* pp = getenv("ARMOUR_WORKER_PARENT")) {
+        prctl(PR_SET_PDEATHSIG, SIGTERM);
+        if ((long long)getppid() != atoll(pp)) { fprintf(stderr, "        HIP & C++: the front end that started this worker is gone\n"); return 1; }
+    }
     const char* kind = argv[1];
     const bool is_armour = !strcmp(kind, "armour");
     bool want_serve = false;

@@ -844,6 +844,29 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
     WSYNC();
 }
 
+// P1_WAVES_PER_SIMD: 1 (shipped) = no occupancy request, the kernels hold 256 VGPRs + spill AGPRs, one wave per SIMD.
+// 2 (development, `make EXTRA=-DP1_WAVES_PER_SIMD=2`) = every kernel of this file that calls the operators asks for two
+// waves per SIMD; with all of them agreeing the <= 256-register budget propagates to the non-inlined operator functions
+// (AMDGPU attributor, closed world of this object: 248 VGPRs, no AGPRs, a little more scratch) and a fifth one-wave block
+// fits a CU: B = 128 builds in 51.7 ms instead of 58.4.  NOT shipped: in that build, batches with >= 3 blocks per CU come out
+// wrong about every second launch, and what makes them wrong has not been found (DESIGN.md 4.2, "Two waves per SIMD",
+// profiles/r02_p1_two_waves_per_simd.txt).
+#ifndef P1_WAVES_PER_SIMD
+#define P1_WAVES_PER_SIMD 1
+#endif
+#if P1_WAVES_PER_SIMD > 1
+#define P1_OCC __attribute__((amdgpu_waves_per_eu(P1_WAVES_PER_SIMD, P1_WAVES_PER_SIMD)))
+#define P1_PIN_ONE_WAVE_PER_SIMD()
+#else
+// The shipped build PINS one wave per SIMD instead of relying on the operators happening to need more than 256 registers
+// (ADVICE r2): every kernel that calls the pz_wave / pz_tv operators asks for waves_per_eu(1, 1) and claims the whole
+// accumulation-register half of the unified file (a255), so its descriptor holds VGPRs + 256 > 256 registers whatever an edit or a
+// compiler update does to the vector-register count -- a second wave cannot be placed on the SIMD.  `make` then reads the
+// compiler's resource remarks for these kernels and fails unless each reports occupancy 1 (tools/check_p1_occupancy.py).
+#define P1_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define P1_PIN_ONE_WAVE_PER_SIMD() __asm__ volatile("" ::: "a255")
+#endif
+
 #include "p1_tv.inc.h"
 
 // One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
@@ -851,22 +874,6 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
 __host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
-
-// P1_WAVES_PER_SIMD: 1 (shipped) = no occupancy request, the kernels hold 256 VGPRs + spill AGPRs, one wave per SIMD.
-// 2 (development, `make EXTRA=-DP1_WAVES_PER_SIMD=2`) = every kernel of this file that calls the operators asks for two
-// waves per SIMD; with all of them agreeing the <= 256-register budget propagates to the non-inlined operator functions
-// (AMDGPU attributor, closed world of this object: 248 VGPRs, no AGPRs, a little more scratch) and a fifth one-wave block
-// fits a CU: B = 128 builds in 51.7 ms instead of 58.4.  NOT shipped: in that build, batches with >= 3 blocks per CU come out
-// wrong about every second launch, and what makes them wrong has not been found (DESIGN.md 4.2, "Two waves per SIMD",
-// profiles/r02_p1_two_waves_per_simd.txt) -- P1_FORCE_AGPR below is one of that hunt's controls.
-#ifndef P1_WAVES_PER_SIMD
-#define P1_WAVES_PER_SIMD 1
-#endif
-#if P1_WAVES_PER_SIMD > 1
-#define P1_OCC __attribute__((amdgpu_waves_per_eu(P1_WAVES_PER_SIMD, P1_WAVES_PER_SIMD)))
-#else
-#define P1_OCC
-#endif
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg cf) {
@@ -892,9 +899,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     for (int i = 0; i < PR_WORDS; i++) prof_lds[i] = 0;
     const long long prof_start = clock64();
 #endif
-#ifdef P1_FORCE_AGPR  // development: claim accumulation registers -- the same operator code, but the kernel descriptor allows one wave per SIMD only
-    __asm__ volatile("" ::: "a31");
-#endif
+    P1_PIN_ONE_WAVE_PER_SIMD();
     c.w.cap_raw = cf.capRaw;
     c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
@@ -1170,6 +1175,7 @@ struct PzOpArgs {
 };
 
 __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, const PzOpArgs* ap) {
+    P1_PIN_ONE_WAVE_PER_SIMD();
     const PzOpArgs a = *ap;  // passed through memory: P1Cfg alone nearly fills the 4 KB kernel-argument segment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chain c;
@@ -1569,7 +1575,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int nbx = (Q + 63) / 64;
         if ((size_t)B * nbx * 4 > wk->skip_part_cap) {
             if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
-            wk->d_skip_part = nullptr;
+            wk->d_skip_part = nullptr; wk->skip_part_cap = 0;
             HIPCHK(hipMalloc((void**)&wk->d_skip_part, (size_t)B * nbx * 4 * sizeof(unsigned long long)));
             wk->skip_part_cap = (size_t)B * nbx * 4;
         }

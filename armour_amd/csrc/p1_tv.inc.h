@@ -428,7 +428,8 @@ __host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stag
 // of group (it - n_items) -- it shares nothing with the RNEA but the JRS rotations, which it rebuilds -- and the first n_items
 // then leave it out (the same split as the per-step kernel's).
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void armour_p1_tv_kernel(P1Cfg cf) {
+__global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) {
+    P1_PIN_ONE_WAVE_PER_SIMD();
     const int groups_per_problem = cf.tv_groups, lanes_per_group = cf.tv_lanes, capTv = cf.tv_cap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TChain c;

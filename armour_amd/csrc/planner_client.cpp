@@ -24,7 +24,10 @@
 #include <spawn.h>
 #include <sys/wait.h>
 
+#include <unistd.h>
+
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -44,14 +47,32 @@ static int run_worker(const std::string& self, const char* kind, int argc, char*
     av.push_back(const_cast<char*>(kind));
     for (int i = 1; i < argc; i++) av.push_back(argv[i]);
     av.push_back(nullptr);
-    pid_t pid;
-    if (posix_spawn(&pid, path.c_str(), nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "        HIP & C++: cannot start %s\n", path.c_str()); return 1; }
-    g_child = pid;
+    // The relay is in place BEFORE the worker exists: the handlers are installed first and SIGTERM / SIGINT stay blocked until g_child
+    // is set, so a signal that arrives while the worker is being started is delivered to the handler right after and relayed --
+    // there is no window in which it kills this front end and leaves the worker behind.  (The worker gets the default, unblocked
+    // dispositions through the spawn attributes.)
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_handler = relay_signal;
     sigaction(SIGTERM, &sa, nullptr);
     sigaction(SIGINT, &sa, nullptr);
+    sigset_t relay_set, old_set, none;
+    sigemptyset(&relay_set); sigaddset(&relay_set, SIGTERM); sigaddset(&relay_set, SIGINT);
+    sigemptyset(&none);
+    sigprocmask(SIG_BLOCK, &relay_set, &old_set);
+    posix_spawnattr_t attr;
+    posix_spawnattr_init(&attr);
+    posix_spawnattr_setsigmask(&attr, &none);
+    posix_spawnattr_setsigdefault(&attr, &relay_set);
+    posix_spawnattr_setflags(&attr, POSIX_SPAWN_SETSIGMASK | POSIX_SPAWN_SETSIGDEF);
+    // tells the worker that a front end started it: only then does it ask for SIGTERM on this process's death (cli_common.h)
+    setenv("ARMOUR_WORKER_PARENT", std::to_string((long long)getpid()).c_str(), 1);
+    pid_t pid;
+    const int spawn_rc = posix_spawn(&pid, path.c_str(), nullptr, &attr, av.data(), environ);
+    posix_spawnattr_destroy(&attr);
+    if (spawn_rc != 0) { sigprocmask(SIG_SETMASK, &old_set, nullptr); fprintf(stderr, "        HIP & C++: cannot start %s\n", path.c_str()); return 1; }
+    g_child = pid;
+    sigprocmask(SIG_SETMASK, &old_set, nullptr);
     int status = 0;
     while (waitpid(pid, &status, 0) < 0) {}  // (EINTR after a relayed signal: keep waiting for the worker's own exit)
     return WIFEXITED(status) ? WEXITSTATUS(status) : 1;

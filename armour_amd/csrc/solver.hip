@@ -390,6 +390,11 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         const double left_ms = (opt.max_wall_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3;
         a.budget_ticks = left_ms > 0 ? (long long)(left_ms * plan.ticks_per_ms) : 0;
     }
+    // no wait of the persistent kernel outlasts the budget by more than a second (10 s without a budget: 60 iterations of a large batch
+    // stay far below); the host's own poll gives up a little later.  ARMOUR_SOLVE_HARD_CAP_S: development / tests.
+    static const double hard_cap_s = [] { const char* e = getenv("ARMOUR_SOLVE_HARD_CAP_S"); return e ? atof(e) : 0.0; }();
+    const double hard_s = hard_cap_s > 0 ? hard_cap_s : (a.budget_ticks >= 0 ? a.budget_ticks / plan.ticks_per_ms * 1e-3 + 1.0 : 10.0);
+    a.hard_ticks = std::max<long long>(1, (long long)(hard_s * 1e3 * plan.ticks_per_ms));
     const bool timing = getenv("ARMOUR_SOLVE_TIMING") != nullptr;
     long long* hstamps = timing ? reinterpret_cast<long long*>(armour_handle_pinned(h, 0, (size_t)B * 64 * sizeof(long long) + (size_t)B * n * sizeof(double))) : nullptr;
     if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
@@ -398,14 +403,20 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     memcpy(hblock + off_args, &a, sizeof(SolveArgs));
     HIPCHK(hipMemcpyAsync(w.ctl, hblock, block_bytes, hipMemcpyHostToDevice, h->stream));   // (asynchronous from page-locked memory, ordered before the launch)
     if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(reinterpret_cast<unsigned char*>(w.ctl) + off_args), nb, plan, B, h->stream)) != ARMOUR_OK) return rc;
-    for (;;) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
+    for (unsigned long long polls = 0;; polls++) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { armour_set_error("armour_solve (device form): %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
+        // the kernel bounds its own waits by hard_s; a stream that is still busy well after that is a device the caller must give up on
+        // (recover in a fresh process; never by re-exec of this one)
+        if ((polls & 0xfffull) == 0xfffull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() > 2.0 * hard_s + 5.0) {
+            armour_set_error("armour_solve (device form): the persistent kernel did not finish within %.1f s", 2.0 * hard_s + 5.0);
+            return ARMOUR_EDEVICE;
+        }
     }
     w.words_clean = 1;
     for (int b = 0; b < B; b++)
-        if (hres[b].status < 0) return 0;   // candidate buffers too small for some problem: the host form redoes the solve
+        if (hres[b].status < 0) { w.words_clean = 0; return 0; }   // candidate buffers too small for some problem, or a group lost a block: the host form redoes the solve
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (timing) {
         fprintf(stderr, "[armour_solve, device form] B=%d: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, nb, plan.n_tiles, ms,

@@ -38,6 +38,9 @@ struct SolveArgs {
     int n_checked_collision;       // collision rows finalize_solution re-checks (all of them; ARMTD: the first (n-1) links')
     double t_plan, cost_scale, tol, torque_slack, collision_slack;
     long long budget_ticks;        // wall-clock budget in wall_clock64() ticks; < 0: none
+    long long hard_ticks;          // > 0.  No wait inside the kernel outlasts this many ticks since the block started: a block that
+                                   // never hears from its leader leaves, a leader that never hears from a block hands the problem
+                                   // back with status -1 (the host form redoes the solve) -- the kernel always drains
     long long* stamps;             // development (ARMOUR_SOLVE_TIMING): [B][64] ticks since kernel start at (barrier passed, leader step done) of each phase; or null
 };
 

@@ -746,11 +746,19 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     }
     const double* my_x = s_x;   // (a generic pointer into LDS: the tile functions take the point through a plain `const double*`)
     unsigned phase = 0;
+    // Every wait below is bounded (a.hard_ticks since this block started, set by the host from the solve's time budget): if a block of
+    // the group never arrives -- a fault elsewhere, residency that does not match the occupancy query, competition for CUs -- the
+    // others leave instead of spinning with the GPU, and the leader hands the problem back (status -1: the host form redoes it).
+    const long long t_block = wall_clock64();
     for (;;) {
         // ---- wait until the leader has published this phase's point and command (one lane polls one word)
         if (tid == 0) {
             unsigned w;
-            while (((w = ld_coh(&c->go)) >> 3) < phase) __builtin_amdgcn_s_sleep(2);   // go = 8 * phase + command: one word, one round trip
+            unsigned spins = 0;
+            while (((w = ld_coh(&c->go)) >> 3) < phase) {   // go = 8 * phase + command: one word, one round trip
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 && wall_clock64() - t_block > a.hard_ticks) { w = (unsigned)CMD_DONE; break; }
+            }
             asm volatile("" ::: "memory");
             s_cmd = (int)(w & 7u);
         }
@@ -787,13 +795,24 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         phase++;
         if (tid == 0) st_coh(&mine->flag, phase);
         if (!leader) continue;
-        for (;;) {   // the leader's 256 lanes poll the group's flags, four each
+        bool group_lost = false;
+        for (unsigned spins = 0;; spins++) {   // the leader's 256 lanes poll the group's flags, four each
             int all = 1;
 #pragma unroll
             for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb && ld_coh(&a.blk_word[(size_t)b * a.nb + j2].flag) < phase) all = 0; }
             if (__syncthreads_and(all)) break;
+            if ((spins & 255u) == 255u && __syncthreads_or(wall_clock64() - t_block > a.hard_ticks ? 1 : 0)) { group_lost = true; break; }
         }
         asm volatile("" ::: "memory");
+        if (group_lost) {   // a block of this group never arrived: release the ones that did and hand the problem back to the host form
+            if (tid == 0) {
+                a.out[b].status = -1;
+                wait_my_memory_ops();
+                st_coh(&c->go, phase * 8u + (unsigned)CMD_DONE);
+                st_coh(&a.blk_word[(size_t)b * a.nb + jb].flag, 0u);
+            }
+            break;
+        }
         // the phase's L1 violation and verdict count: integer sums of the blocks' words (any order gives the same number)
         long long viol_fx = 0;
         int nbad = 0;
