@@ -59,6 +59,13 @@ class ArmourSolveResult(C.Structure):
                 ("iterations", C.c_int32), ("evaluations", C.c_int32), ("status", C.c_int32), ("time_ms", C.c_double)]
 
 
+class ArmourViolation(C.Structure):
+    _fields_ = [("l1_violation", C.c_double), ("worst", C.c_double), ("worst_row", C.c_int32), ("n_violated", C.c_int32),
+                ("n_outside_slack", C.c_int32), ("feasible", C.c_int32)]
+
+
+OPT_P1_BUILD = 1   # ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
+
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_robot_fetch", "armour_params_default", "armour_create", "armour_destroy",
@@ -68,6 +75,10 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
+    "armour_set_option", "armour_eval_violations_device", "armour_eval_violations",
+    "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
+    "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
+    "armour_batch_get_build_ms",
 ]
 
 _lib = None
@@ -156,6 +167,21 @@ def load():
     L.armour_p2_kernel_name.restype = C.c_char_p
     L.armour_debug_load_tables.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, ip, dp, C.POINTER(C.c_uint64), dp,
                                            C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]
+    L.armour_set_option.argtypes = [vp, C.c_int32, C.c_double]
+    L.armour_eval_violations_device.argtypes = [vp, vp, vp, vp]
+    L.armour_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
+    L.armour_batch_partition.argtypes = [C.c_int32, C.c_int32, ip]
+    L.armour_batch_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams), C.POINTER(ArmourLimits), ip, C.c_int32, C.POINTER(vp)]
+    L.armour_batch_destroy.argtypes = [vp]
+    L.armour_batch_destroy.restype = None
+    L.armour_batch_set_option.argtypes = [vp, C.c_int32, C.c_double]
+    L.armour_batch_set_problems.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, dp]
+    L.armour_batch_get_sizes.argtypes = [vp, ip, ip, ip, ip]
+    L.armour_batch_get_bounds.argtypes = [vp, dp, dp, dp, dp]
+    L.armour_batch_eval_g_jac.argtypes = [vp, dp, dp, dp]
+    L.armour_batch_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
+    L.armour_batch_solve.argtypes = [vp, C.POINTER(ArmourSolveOptions), C.POINTER(ArmourSolveResult)]
+    L.armour_batch_get_build_ms.argtypes = [vp, dp, dp]
     _lib = L
     return L
 

@@ -205,8 +205,8 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_step_graphs(h);
-    for (int i = 0; i < 6; i++) armour_free_pinned(h->solve_pin[i]);
-    dev_free(&h->d_bounds);
+    for (int i = 0; i < 8; i++) armour_free_pinned(h->solve_pin[i]);
+    dev_free(&h->d_bounds); dev_free(&h->d_viol);
     dev_free(&h->solve_dev.ctl); dev_free(&h->solve_dev.blk_word); dev_free(&h->solve_dev.blk_rows); dev_free(&h->solve_dev.qp_rows);
     dev_free(&h->solve_dev.flags);
     dev_free(&h->d_jrs);
@@ -650,6 +650,126 @@ extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t*
                 if (gb[off + i] < -h->robot.speed_limits[i] + h->ub.qde || gb[off + i] > h->robot.speed_limits[i] - h->ub.qde) { ok = false; break; }
         feasible[b] = ok ? 1 : 0;
     }
+    return ARMOUR_OK;
+}
+
+int armour_upload_bounds(ArmourPlanner* h) {
+    if (h->bounds_on_device) return ARMOUR_OK;
+    const size_t bm = (size_t)h->B * h->m;
+    h->h_gl.resize(bm); h->h_gu.resize(bm);
+    int rc = armour_get_bounds(h, nullptr, nullptr, h->h_gl.data(), h->h_gu.data());
+    if (rc != ARMOUR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->bounds_on_device = true;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value) {
+    if (!h) { armour_set_error("null handle"); return ARMOUR_EINVAL; }
+    if (option == ARMOUR_OPT_P1_BUILD && (value == 0.0 || value == 1.0 || value == 2.0)) { h->opt_p1_build = (int)value; return ARMOUR_OK; }
+    armour_set_error("armour_set_option: unknown option %d or bad value %g", option, value);
+    return ARMOUR_EINVAL;
+}
+
+// ---- reduced outputs: the row test of finalize_solution on the device (RT/NLPclass.cu:422-538; CMP/NLPclass.cu:391-402) ----
+namespace {
+struct ViolArgs {
+    int m, row0, Q, n_checked;   // rows per problem; first collision row; collision rows; how many of them the verdict re-checks
+    double torque_slack, collision_slack;
+    const double* g; const double* lo; const double* hi;   // [B][m] each
+    ArmourViolation* out;                                   // [B]
+};
+// One 256-thread block per problem.  Thread t takes rows t, t + 256, ... in ascending order and the partial records are
+// combined by a fixed tree, so a record depends on (problem, k) alone.  The outside-the-slack test repeats
+// armour_check_feasible's expressions on the uploaded bounds: (g_l - slack), (g_u + slack) are the host's
+// (-limit + radius) - slack and (limit - radius) + slack.
+__global__ __launch_bounds__(256) void armour_violation_kernel(ViolArgs a) {
+    __shared__ double s_l1[256], s_w[256];
+    __shared__ int s_row[256], s_nv[256], s_no[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* g = a.g + (size_t)b * a.m;
+    const double* lo = a.lo + (size_t)b * a.m;
+    const double* hi = a.hi + (size_t)b * a.m;
+    double l1 = 0.0, worst = 0.0;
+    int wrow = -1, nv = 0, no = 0;
+    for (int r = tid; r < a.m; r += 256) {
+        const double v = g[r], l = lo[r], u = hi[r];
+        const double viol = fmax(0.0, fmax(l - v, v - u));
+        l1 += viol;
+        if (viol > 0.0) nv++;
+        if (viol > worst) { worst = viol; wrow = r; }
+        bool outside;
+        if (r < a.row0) outside = v < l - a.torque_slack || v > u + a.torque_slack;
+        else if (r < a.row0 + a.Q) outside = (r - a.row0) < a.n_checked && v > a.collision_slack;
+        else outside = v < l || v > u;
+        if (outside) no++;
+    }
+    s_l1[tid] = l1; s_w[tid] = worst; s_row[tid] = wrow; s_nv[tid] = nv; s_no[tid] = no;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            s_l1[tid] += s_l1[tid + s]; s_nv[tid] += s_nv[tid + s]; s_no[tid] += s_no[tid + s];
+            const double ow = s_w[tid + s];
+            const int orow = s_row[tid + s];
+            // the larger violation wins; among equals the lower row
+            if (ow > s_w[tid] || (ow == s_w[tid] && orow >= 0 && (s_row[tid] < 0 || orow < s_row[tid]))) { s_w[tid] = ow; s_row[tid] = orow; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ArmourViolation o;
+        o.l1_violation = s_l1[0]; o.worst = s_w[0]; o.worst_row = s_row[0]; o.n_violated = s_nv[0]; o.n_outside_slack = s_no[0];
+        o.feasible = s_no[0] == 0 ? 1 : 0;
+        a.out[b] = o;
+    }
+}
+}  // namespace
+
+extern "C" int armour_eval_violations_device(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream) {
+    NEED_READY(h);
+    if (!d_k || !d_out) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = armour_upload_bounds(h);
+    if (rc != ARMOUR_OK) return rc;
+    const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const P2Tables tb = armour_make_tables(h);
+    // g only (the Jacobian tile, 7/8 of the output bytes, is neither computed nor written), into the handle's own g buffer
+    rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, h->d_g, nullptr, st);
+    if (rc != ARMOUR_OK) return rc;
+    ViolArgs a;
+    a.m = h->m; a.row0 = h->row0; a.Q = h->Q; a.n_checked = armour_checked_collision_rows(h);
+    a.torque_slack = h->params.torque_violation_threshold; a.collision_slack = h->params.collision_violation_threshold;
+    a.g = h->d_g; a.lo = h->d_bounds; a.hi = h->d_bounds + (size_t)h->B * h->m; a.out = d_out;
+    hipLaunchKernelGGL(armour_violation_kernel, dim3(h->B), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourViolation* out) {
+    NEED_READY(h);
+    if (!k || !out) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bn = (size_t)h->B * h->n;
+    if ((size_t)h->B > h->viol_cap) {
+        dev_free(&h->d_viol); h->viol_cap = 0;
+        int rc = dev_alloc(&h->d_viol, (size_t)h->B);
+        if (rc != ARMOUR_OK) return rc;
+        h->viol_cap = (size_t)h->B;
+    }
+    // page-locked staging on both sides: the two copies are asynchronous and ordered with the launches on the handle's stream
+    double* hk = armour_handle_pinned(h, 6, bn * sizeof(double));
+    ArmourViolation* hv = reinterpret_cast<ArmourViolation*>(armour_handle_pinned(h, 7, (size_t)h->B * sizeof(ArmourViolation)));
+    if (!hk || !hv) return ARMOUR_EDEVICE;
+    memcpy(hk, k, bn * sizeof(double));
+    HIPCHK(hipMemcpyAsync(h->d_k, hk, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = armour_eval_violations_device(h, h->d_k, h->d_viol, h->stream);
+    if (rc != ARMOUR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(hv, h->d_viol, (size_t)h->B * sizeof(ArmourViolation), hipMemcpyDeviceToHost, h->stream));
+    rc = spin_on_stream(h->stream);
+    if (rc != ARMOUR_OK) return rc;
+    memcpy(out, hv, (size_t)h->B * sizeof(ArmourViolation));
     return ARMOUR_OK;
 }
 

@@ -105,8 +105,10 @@ struct ArmourPlanner {
     double* d_jrs = nullptr;        // ARMTD mode: [B][n][6][T] c/g/r of cos, then of sin (the order of armtd.in)
     size_t jrs_cap = 0;
     // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
-    void* solve_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows
-    size_t solve_pin_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* solve_pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows; [6] k and [7] records of armour_eval_violations
+    size_t solve_pin_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int opt_p1_build = 0;           // ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
+    ArmourViolation* d_viol = nullptr; size_t viol_cap = 0;   // [B] records of armour_eval_violations
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
     bool bounds_on_device = false;
@@ -159,6 +161,8 @@ int armour_checked_collision_rows(const ArmourPlanner* h);
 double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);
+// g_l / g_u of the current problem set in h->d_bounds ([2][B][m]) and h->h_gl / h->h_gu; uploaded once per problem set (api.hip)
+int armour_upload_bounds(ArmourPlanner* h);
 
 // p1_reach.hip
 int armour_p1_build(ArmourPlanner* h, const double* obstacles);  // h->mode selects the ARMOUR or the ARMTD chain

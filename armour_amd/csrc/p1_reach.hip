@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 #include "pz_wave.h"
@@ -1247,6 +1248,11 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per kernel FUNCTION, not per launch: two host threads building on two handles
+// (armour_batch_*: one thread per device slot, and a device may host two slots) must not interleave "set the attribute" and "launch".
+// Held for the two calls only -- the kernels of different handles still run concurrently on their own streams.
+static std::mutex g_p1_launch_mu;
+
 struct P1Work {
     unsigned char* arena = nullptr;
     size_t arena_total = 0;
@@ -1392,8 +1398,6 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const Layout& L = three ? L3 : L1;
         const size_t smem = lds_bytes(cap, nw);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
-        if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const int per_cu = three ? 1 : waves_per_cu(cap);
         // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
         static const int split_env = [] { const char* e = getenv("ARMOUR_P1_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
@@ -1426,9 +1430,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
-        if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
-        else hipLaunchKernelGGL(armour_p1_chain_kernel<1>, dim3(waves), dim3(WAVE), smem, h->stream, cf);
-        HIPCHK(hipGetLastError());
+        {
+            std::lock_guard<std::mutex> lk(g_p1_launch_mu);
+            if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
+            else hipLaunchKernelGGL(armour_p1_chain_kernel<1>, dim3(waves), dim3(WAVE), smem, h->stream, cf);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1473,7 +1482,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 40 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
-    if (tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 3 / 2 : tv_min_groups)) {
+    // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels; the environment switch is development only)
+    const bool want_tv = h->opt_p1_build == 1 ? false : h->opt_p1_build == 2 ? true
+                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 3 / 2 : tv_min_groups);
+    if (want_tv) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
         // Block shapes, in the order tried: (a) while there is at most one group per CU, three waves per group -- the roles of
@@ -1512,9 +1524,6 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                 if (hipMalloc((void**)&wk->tv_arena, (size_t)blocks * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
                 wk->tv_arena_total = (size_t)blocks * TL.total;
             }
-            if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            else if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             P1Cfg cf;
             memset(&cf, 0, sizeof(cf));
             cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
@@ -1531,10 +1540,16 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
-            if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
-            else if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
-            else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
-            HIPCHK(hipGetLastError());
+            {
+                std::lock_guard<std::mutex> lk(g_p1_launch_mu);
+                if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                else if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
+                else if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
+                else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
+                HIPCHK(hipGetLastError());
+            }
             HIPCHK(hipEventRecord(wk->ev1, h->stream));
             HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));

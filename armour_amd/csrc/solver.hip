@@ -313,19 +313,6 @@ static int grow_dev(Tp** p, size_t* cap, size_t need) {
     return ARMOUR_OK;
 }
 
-static int upload_bounds(ArmourPlanner* h) {
-    if (h->bounds_on_device) return ARMOUR_OK;
-    const size_t bm = (size_t)h->B * h->m;
-    h->h_gl.resize(bm); h->h_gu.resize(bm);
-    int rc = armour_get_bounds(h, nullptr, nullptr, h->h_gl.data(), h->h_gu.data());
-    if (rc != ARMOUR_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->bounds_on_device = true;
-    return ARMOUR_OK;
-}
-
 static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, ArmourSolveResult* results, std::chrono::steady_clock::time_point t_begin) {
     const int B = h->B, n = h->n, m = h->m;
     const P2Tables tb = armour_make_tables(h);
@@ -340,7 +327,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
     if (force_dev < 2 && (plan.n_tiles + nb - 1) / nb > 100) return 0;
     if (const char* e = getenv("ARMOUR_SOLVE_BLOCKS")) nb = std::max(1, std::min(nb, atoi(e)));  // development / tests
-    if ((rc = upload_bounds(h)) != ARMOUR_OK) return rc;
+    if ((rc = armour_upload_bounds(h)) != ARMOUR_OK) return rc;
     // rows a block owns: at most ceil(n_tiles / nb) tiles of <= 64 rows, two candidates per row
     const int tiles_per_block = (plan.n_tiles + nb - 1) / nb;
     int cap_blk = std::min(2 * tiles_per_block * 64, 1024);

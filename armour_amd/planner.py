@@ -78,6 +78,114 @@ def desired_trajectory(q0, qd0, qdd0, k, t, k_range=None, duration=1.0, t_plan=0
     return q, qd, qdd
 
 
+def _violation_dict(v):
+    return dict(l1_violation=v.l1_violation, worst=v.worst, worst_row=v.worst_row, n_violated=v.n_violated,
+                n_outside_slack=v.n_outside_slack, feasible=bool(v.feasible))
+
+
+def _solve_options(L, max_iterations, tolerance, max_wall_time_s, host_qp):
+    opt = _lib.ArmourSolveOptions()
+    L.armour_solve_options_default(C.byref(opt))
+    if max_iterations is not None:
+        opt.max_iterations = max_iterations
+    if tolerance is not None:
+        opt.tolerance = tolerance
+    if max_wall_time_s is not None:
+        opt.max_wall_time_s = max_wall_time_s
+    if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) instead of the persistent kernel
+        opt.force_host_qp = 1.0
+    return opt
+
+
+def _solve_dicts(res, n):
+    return [dict(k_opt=np.array(r.k_opt[:n]), cost=r.cost, max_violation=r.max_violation, feasible=bool(r.feasible),
+                 iterations=r.iterations, evaluations=r.evaluations, status=r.status, time_ms=r.time_ms) for r in res]
+
+
+def batch_partition(B, n_slots):
+    """first[d] of armour_batch_*: slot d owns problems [first[d], first[d+1]) (pure host arithmetic in the library)."""
+    first = (C.c_int32 * (n_slots + 1))()
+    check(_lib.load().armour_batch_partition(B, n_slots, first))
+    return list(first)
+
+
+class ArmourBatchNLP:
+    """B independent planning problems dealt to several MI355X from ONE host thread (include/armour_hip.h, armour_batch_*):
+    one handle + stream + host thread per entry of `devices`, contiguous blocks of problems, results gathered in place."""
+
+    def __init__(self, devices, robot=None, params=None, T=128, limits=None):
+        self.L = _lib.load()
+        self.robot = robot if robot is not None else kinova_robot()
+        self.params = params if params is not None else default_params(T)
+        self.T, self.J, self.n = self.params.num_time_steps, self.robot.num_joints, self.robot.num_factors
+        self.limits = limits if limits is not None else ArmourLimits()
+        self.devices = list(devices)
+        dv = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        check(self.L.armour_batch_create(C.byref(self.robot), C.byref(self.params), C.byref(self.limits), dv, len(self.devices), C.byref(h)))
+        self.h = h
+        self.B = self.O = self.m = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.armour_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        check(self.L.armour_batch_set_option(self.h, option, float(value)))
+        return self
+
+    def set_parameters(self, q0, qd0, qdd0, q_des, obstacles):
+        q0, qd0, qdd0, q_des = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in (q0, qd0, qdd0, q_des)]
+        B = q0.shape[0]
+        obs = np.asarray(obstacles, dtype=np.float64)
+        obs = np.ascontiguousarray(obs.reshape(B, -1, 12)) if obs.size else np.zeros((B, 0, 12))
+        O = obs.shape[1]
+        check(self.L.armour_batch_set_problems(self.h, B, O, _dp(q0), _dp(qd0), _dp(qdd0), _dp(q_des), _dp(obs) if O else None))
+        b, n, m, g = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.armour_batch_get_sizes(self.h, C.byref(b), C.byref(n), C.byref(m), C.byref(g)))
+        self.B, self.O, self.m = b.value, O, m.value
+        return self
+
+    def _k(self, x):
+        return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.B, self.n))
+
+    def get_bounds_info(self):
+        xl, xu = np.zeros(self.n), np.zeros(self.n)
+        gl, gu = np.zeros((self.B, self.m)), np.zeros((self.B, self.m))
+        check(self.L.armour_batch_get_bounds(self.h, _dp(xl), _dp(xu), _dp(gl), _dp(gu)))
+        return xl, xu, gl, gu
+
+    def eval_g_jac(self, x):
+        g, jac = np.zeros((self.B, self.m)), np.zeros((self.B, self.m, self.n))
+        check(self.L.armour_batch_eval_g_jac(self.h, _dp(self._k(x)), _dp(g), _dp(jac)))
+        return g, jac
+
+    def eval_violations(self, x):
+        out = (_lib.ArmourViolation * self.B)()
+        check(self.L.armour_batch_eval_violations(self.h, _dp(self._k(x)), out))
+        return [_violation_dict(v) for v in out]
+
+    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False):
+        opt = _solve_options(self.L, max_iterations, tolerance, max_wall_time_s, host_qp)
+        res = (_lib.ArmourSolveResult * self.B)()
+        check(self.L.armour_batch_solve(self.h, C.byref(opt), res))
+        return _solve_dicts(res, self.n)
+
+    @property
+    def build_ms(self):
+        v = C.c_double()
+        per = (C.c_double * len(self.devices))()
+        check(self.L.armour_batch_get_build_ms(self.h, C.byref(v), per))
+        return v.value
+
+
 class ArmourNLP:
     """B independent planning problems on one MI355X (B = 1 is the reference's use)."""
 
@@ -255,6 +363,23 @@ class ArmourNLP:
         feas = np.zeros(self.B, dtype=np.int32)
         check(self.L.armour_check_feasible(self.h, _dp(g), feas.ctypes.data_as(C.POINTER(C.c_int32))))
         return feas.astype(bool)
+
+    def set_option(self, option, value):
+        """Per-handle option (include/armour_hip.h): e.g. set_option(_lib.OPT_P1_BUILD, 1) holds the reach-set build to the
+        per-time-step kernel (bit-identical tables for a problem whatever the batch size)."""
+        check(self.L.armour_set_option(self.h, option, float(value)))
+        return self
+
+    def eval_violations(self, x):
+        """Reduced outputs: one record per problem -- the row test of finalize_solution (RT/NLPclass.cu:422-538) applied on
+        the device, g never leaves it.  Returns a list of dicts."""
+        out = (_lib.ArmourViolation * self.B)()
+        check(self.L.armour_eval_violations(self.h, _dp(self._k(x)), out))
+        return [_violation_dict(v) for v in out]
+
+    def eval_violations_device(self, d_k, d_out, stream=0):
+        """Asynchronous: d_k [B][n] doubles, d_out [B] ArmourViolation records (32 B each), device pointers (ints)."""
+        check(self.L.armour_eval_violations_device(self.h, d_k, d_out, stream))
 
     def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False):
         """OptimizeTNLP + finalize_solution for all B problems (RT/armour_main.cu:237-304): returns a list of dicts

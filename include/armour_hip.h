@@ -77,6 +77,21 @@ int armour_device_available(void);
 int armour_alloc_pinned(uint64_t bytes, void** out);
 void armour_free_pinned(void* p);
 
+/* ---- per-handle options ---- */
+/* ARMOUR_OPT_P1_BUILD selects the reach-set build kernel of armour_set_problems* (value 0, 1 or 2):
+ *   0  automatic (default): one wavefront per (problem, time step) for small batches, the time-vectorised kernel (one wavefront per
+ *      50-64 time steps of a problem) from B*T >= 2300 on;
+ *   1  always per time step;   2  always time-vectorised.
+ * TOLERANCE CONTRACT.  Both kernels run the reference's operator sequence on the same operands and produce identical monomial keys,
+ * coefficients and centres bit for bit; they add the pruned amounts of simplify() (RT/PZsparse.cu:327-341) into the independent
+ * radii in a different order (per-lane partial sums + a wave reduction against a running sum in key order), so radii -- and through
+ * them torque_radius, the link generators, g and jac -- may differ by rounding between the two: <= 1e-12 absolute on every table
+ * and output, far inside the parity tolerances (tests/test_baseline_configs.py).  Within ONE kernel results are bit-reproducible
+ * and independent of the batch mates and of the batch size.  A caller that needs bit-identical tables for the same problem across
+ * batch sizes (or across the ranks of a sharded batch, whose shard sizes differ) sets option 1 (or 2) on every handle. */
+#define ARMOUR_OPT_P1_BUILD 1
+int armour_set_option(ArmourPlanner* h, int32_t option, double value);
+
 /* ---- P1: reach-set build, once per planning iteration ---- */
 /* Replaces RT/armour_main.cu:36-216 (parse armour.in, JRS, FK, RNEA x2, torque radius, half-space tables)
  * for B problems at once.  obstacles: [B][O][12], each = column-major Z=[c g1 g2 g3]
@@ -137,6 +152,50 @@ int armour_eval_g_jac_device_multi(ArmourPlanner* h, const double* d_k, int32_t 
 /* finalize_solution feasibility re-check, RT/NLPclass.cu:422-538: feasible[b] = 1/0 from g[B][m] (host). */
 int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t* feasible);
 
+/* ---- reduced outputs for throughput callers ---- */
+/* A batch that evaluates 1e5 points/s cannot pull g and jac (2.29 MB per problem-evaluation at O = 50) over PCIe.  These entries run
+ * the same fused kernel for g only, keep it on the device and hand back one record per problem: the row test of
+ * armtd_NLP::finalize_solution (RT/NLPclass.cu:422-538; ARMTD mode: CMP/NLPclass.cu:391-402) applied on the device.
+ *   l1_violation      sum over all rows of max(0, g_l - g, g - g_u)   (bounds of armour_get_bounds)
+ *   worst, worst_row  the largest single-row violation and its row (lowest row among equals; -1 / 0.0 if no row is violated)
+ *   n_violated        rows with a violation > 0
+ *   n_outside_slack   rows finalize_solution rejects: torque rows beyond the bound by more than torque_violation_threshold, checked
+ *                     collision rows above collision_violation_threshold, position / velocity rows outside their bounds
+ *   feasible          n_outside_slack == 0: the verdict of armour_check_feasible on the same g
+ * Sums run in a fixed order: the record depends on (problem, k) only, not on the batch or the device. */
+typedef struct ArmourViolation {
+    double l1_violation, worst;
+    int32_t worst_row, n_violated, n_outside_slack, feasible;
+} ArmourViolation;
+/* d_k [B][n] and d_out [B] are device pointers; enqueued on `stream` (NULL = the handle's), not synchronised. */
+int armour_eval_violations_device(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream);
+/* host pointers, synchronous: 56 B in and 32 B out per problem instead of 8 m (1 + n) bytes */
+int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourViolation* out);
+
+/* ---- in-process multi-device batch ---- */
+/* One caller thread (MATLAB / MEX, a Python host) drives several GPUs: an ArmourBatch owns one ArmourPlanner per entry of `devices`
+ * (an ordinal may repeat: two handles, two streams on one device).  B independent planning problems are dealt to the handles in
+ * contiguous blocks -- device slot d owns problems [first[d], first[d+1]) with first[d] = d*(B/G) + min(d, B%G), the partition of
+ * armour_amd/sharding.py -- and every call runs one host thread per slot, each driving its own handle and stream; the caller's
+ * arrays are problem-major exactly as for a single handle and results are gathered in place.  There is no data-path collective and
+ * no device-to-device traffic (problems share nothing).  The reference has no counterpart: it runs one problem per process
+ * (RT/armour_main.cu); this is the in-process form of bench.py's one-rank-per-GPU sharding. */
+typedef struct ArmourBatch ArmourBatch;
+int armour_batch_partition(int32_t B, int32_t n_slots, int32_t* first /* [n_slots + 1] */);   /* pure host arithmetic (no GPU needed) */
+int armour_batch_create(const ArmourRobot* robot, const ArmourParams* params, const ArmourLimits* limits,
+                        const int32_t* devices, int32_t n_devices, ArmourBatch** out);
+void armour_batch_destroy(ArmourBatch* bt);
+int armour_batch_set_option(ArmourBatch* bt, int32_t option, double value);
+int armour_batch_set_problems(ArmourBatch* bt, int32_t B, int32_t O, const double* q0, const double* qd0, const double* qdd0,
+                              const double* q_des, const double* obstacles);
+int armour_batch_get_sizes(const ArmourBatch* bt, int32_t* B, int32_t* n, int32_t* m, int32_t* n_slots);
+int armour_batch_get_bounds(ArmourBatch* bt, double* x_l, double* x_u, double* g_l, double* g_u);
+int armour_batch_eval_g_jac(ArmourBatch* bt, const double* k, double* g, double* jac);             /* full outputs (parity path) */
+int armour_batch_eval_violations(ArmourBatch* bt, const double* k, ArmourViolation* out /* [B] */);  /* reduced outputs */
+/* declared after ArmourSolveOptions below: armour_batch_solve */
+/* ms of the slowest slot's last reach-set build (device time); per_slot may be NULL or [n_slots] */
+int armour_batch_get_build_ms(ArmourBatch* bt, double* max_ms, double* per_slot);
+
 /* ---- caller side of the path: the trajectory the planner hands to the controller ---- */
 /* uarmtd_planner.desired_trajectory, traj_type 'bernstein' (KSI/uarmtd_planner.m:846-925, with
  * PZM/utility/match_deg5_bernstein_coefficients.m and bernstein_to_poly.m): position / velocity / acceleration at time
@@ -184,6 +243,7 @@ typedef struct ArmourSolveResult {
 } ArmourSolveResult;
 void armour_solve_options_default(ArmourSolveOptions* opt);
 int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt, ArmourSolveResult* results /* [B] */);
+int armour_batch_solve(ArmourBatch* bt, const ArmourSolveOptions* opt, ArmourSolveResult* results /* [B] */);
 /* test hook for the dense QP: min 1/2 x'diag(Gd)x + g0'x  s.t. lo <= A x <= hi (A row-major [m][n], n <= 7,
  * |bound| >= 1e18 = absent).  Host-only: runs without a GPU. */
 int armour_debug_qp(int32_t n, const double* Gd, const double* g0, int32_t m, const double* A, const double* lo,

@@ -1,0 +1,157 @@
+"""The round-3 boundary entries (include/armour_hip.h): reduced outputs (armour_eval_violations*), the in-process
+multi-device batch (armour_batch_*) and the per-handle build option.
+
+CPU part: the partition arithmetic equals armour_amd/sharding.py's (the one bench.py shards ranks with).
+GPU part, all through the C ABI:
+  * the violation record of every problem equals what numpy computes from the full g and the bounds
+    (RT/NLPclass.cu:422-538 restated in armour_check_feasible), including the verdict, for feasible and infeasible points;
+  * a batch over device slots [0, 0] (two handles, two host threads, one device -- what a 1-GPU box can exercise) gives
+    bit-identical g / jac / violation records / solver results to ONE handle holding the same problems, and its bounds
+    gather in place;
+  * ARMOUR_OPT_P1_BUILD = 1 and 2 reproduce each other's keys / coefficients bit for bit and the radii to the stated
+    1e-12 (the tolerance contract of the header), and option 1 makes a world's tables independent of the batch size."""
+import numpy as np
+import pytest
+
+
+def test_partition_matches_sharding_rule():
+    from armour_amd.planner import batch_partition
+    from armour_amd.sharding import shard_range
+    for B in (1, 2, 7, 8, 9, 127, 128, 1000, 1024):
+        for G in (1, 2, 3, 4, 8):
+            first = batch_partition(B, G)
+            assert first[0] == 0 and first[-1] == B and len(first) == G + 1
+            for r in range(G):
+                assert (first[r], first[r + 1]) == shard_range(B, r, G)
+            sizes = np.diff(first)
+            assert sizes.max() - sizes.min() <= 1 and (sizes >= 0).all()
+
+
+def test_partition_rejects_bad_arguments():
+    import ctypes as C
+    from armour_amd import _lib
+    L = _lib.load()
+    first = (C.c_int32 * 4)()
+    assert L.armour_batch_partition(5, 0, first) == _lib.EINVAL
+    assert L.armour_batch_partition(-1, 2, first) == _lib.EINVAL
+
+
+def _reference_records(nlp, g):
+    """numpy restatement of the record from the full g (the checker)."""
+    _, _, gl, gu = nlp.get_bounds_info()
+    feas = nlp.finalize_solution(g)
+    out = []
+    for b in range(nlp.B):
+        viol = np.maximum(0.0, np.maximum(gl[b] - g[b], g[b] - gu[b]))
+        wr = int(np.argmax(viol)) if viol.max() > 0 else -1
+        out.append(dict(l1=float(viol.sum()), worst=float(viol.max()), worst_row=wr, n_violated=int((viol > 0).sum()), feasible=bool(feas[b])))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,O", [(1, 20), (5, 7), (40, 12)])
+def test_violation_records_equal_the_row_test_on_the_full_g(B, O):
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T = 100 if B < 40 else 60
+    bp = random_batch(4200 + B, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    for s, scale in enumerate((0.0, 0.3, 1.0)):   # x = 0 (often feasible), small and full-range points
+        k = random_k(900 + s, B) * scale
+        g, _ = nlp.eval_g_jac(k)
+        ref = _reference_records(nlp, g)
+        rec = nlp.eval_violations(k)
+        for b in range(B):
+            r, e = rec[b], ref[b]
+            assert r["feasible"] == e["feasible"] and (r["n_outside_slack"] == 0) == e["feasible"], (b, r, e)
+            assert r["n_violated"] == e["n_violated"] and r["worst_row"] == e["worst_row"], (b, r, e)
+            assert r["worst"] == e["worst"]                                  # one row's value: bit-equal
+            assert abs(r["l1_violation"] - e["l1"]) <= 1e-12 * max(1.0, e["l1"])   # a sum in another order
+        again = nlp.eval_violations(k)
+        assert again == rec                                                  # fixed summation order: bit-reproducible
+    nlp.close()
+
+
+@pytest.mark.gpu
+def test_violation_records_through_the_device_entry():
+    import ctypes as C
+    import torch
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    B, O, T = 6, 9, 100
+    bp = random_batch(77, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    k = random_k(5, B)
+    d_k = torch.tensor(k, device="cuda")
+    d_out = torch.zeros(B * C.sizeof(_lib.ArmourViolation), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    nlp.eval_violations_device(d_k.data_ptr(), d_out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    raw = d_out.cpu().numpy().tobytes()
+    recs = (_lib.ArmourViolation * B).from_buffer_copy(raw)
+    host = nlp.eval_violations(k)
+    for b in range(B):
+        assert (recs[b].l1_violation, recs[b].worst, recs[b].worst_row, recs[b].n_violated, recs[b].n_outside_slack, bool(recs[b].feasible)) == \
+               (host[b]["l1_violation"], host[b]["worst"], host[b]["worst_row"], host[b]["n_violated"], host[b]["n_outside_slack"], host[b]["feasible"])
+    nlp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", [[0], [0, 0], [0, 0, 0]])
+def test_batch_over_device_slots_equals_one_handle(slots):
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourBatchNLP, ArmourNLP, batch_partition
+    from armour_amd.worlds import random_batch, random_k
+    B, O, T = 7, 8, 100
+    bp = random_batch(31, B, O)
+    one = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    bt = ArmourBatchNLP(slots, T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    assert (bt.B, bt.m, bt.n) == (one.B, one.m, one.n)
+    assert batch_partition(B, len(slots))[-1] == B
+    k = random_k(3, B)
+    g1, j1 = one.eval_g_jac(k)
+    g2, j2 = bt.eval_g_jac(k)
+    assert np.array_equal(g1, g2) and np.array_equal(j1, j2)          # same kernels on the same per-problem tables
+    b1, b2 = one.get_bounds_info(), bt.get_bounds_info()
+    for a, c in zip(b1, b2):
+        assert np.array_equal(a, c)
+    assert one.eval_violations(k) == bt.eval_violations(k)
+    s1, s2 = one.solve(), bt.solve()
+    for r1, r2 in zip(s1, s2):
+        assert np.array_equal(r1["k_opt"], r2["k_opt"]) and r1["feasible"] == r2["feasible"] and r1["status"] == r2["status"]
+        assert r1["cost"] == r2["cost"] and r1["iterations"] == r2["iterations"]
+    assert bt.build_ms > 0
+    # errors of a worker thread reach the caller: an out-of-range capacity on one slot's problems
+    with pytest.raises(_lib.ArmourError):
+        bad = bp["q0"].copy(); bad[B - 1, 0] = np.nan
+        bt.set_parameters(bad, bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    one.close(); bt.close()
+
+
+@pytest.mark.gpu
+def test_build_option_pins_the_kernel_and_states_the_tolerance():
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    B, O, T = 3, 4, 100
+    bp = random_batch(611, B, O)
+    per_step = ArmourNLP(T=T).set_option(_lib.OPT_P1_BUILD, 1).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    tv = ArmourNLP(T=T).set_option(_lib.OPT_P1_BUILD, 2).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    single = ArmourNLP(T=T).set_option(_lib.OPT_P1_BUILD, 1).set_parameters(bp["q0"][1], bp["qd0"][1], bp["qdd0"][1], bp["q_des"][1], bp["obstacles"][1])
+    for which, cnt in (("link", per_step.J), ("torque", per_step.n)):
+        for i in range(cnt):
+            for t in range(0, T, 7):
+                for b in range(B):
+                    c1, r1, k1, co1 = per_step.pz(which, i, t, b=b)
+                    c2, r2, k2, co2 = tv.pz(which, i, t, b=b)
+                    assert np.array_equal(k1, k2) and np.array_equal(co1, co2) and np.array_equal(c1, c2)   # bit for bit
+                    assert np.abs(r1 - r2).max() <= 1e-12                                                   # the contract
+                cs, rs, ks, cos = single.pz(which, i, t)
+                c1, r1, k1, co1 = per_step.pz(which, i, t, b=1)
+                assert np.array_equal(ks, k1) and np.array_equal(cos, co1) and np.array_equal(cs, c1) and np.array_equal(rs, r1)
+    assert np.abs(per_step.torque_radius() - tv.torque_radius()).max() <= 1e-12
+    assert np.array_equal(per_step.torque_radius()[1], single.torque_radius()[0])   # option 1: independent of the batch size
+    with pytest.raises(_lib.ArmourError):
+        per_step.set_option(_lib.OPT_P1_BUILD, 3)
+    per_step.close(); tv.close(); single.close()
