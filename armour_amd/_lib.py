@@ -75,7 +75,7 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_set_option", "armour_eval_violations_device", "armour_eval_violations",
+    "armour_get_plane_skip", "armour_set_option", "armour_eval_violations_device", "armour_eval_violations",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
     "armour_batch_get_build_ms",
@@ -167,6 +167,7 @@ def load():
     L.armour_p2_kernel_name.restype = C.c_char_p
     L.armour_debug_load_tables.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, ip, dp, C.POINTER(C.c_uint64), dp,
                                            C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]
+    L.armour_get_plane_skip.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.armour_set_option.argtypes = [vp, C.c_int32, C.c_double]
     L.armour_eval_violations_device.argtypes = [vp, vp, vp, vp]
     L.armour_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]

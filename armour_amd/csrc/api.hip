@@ -130,7 +130,8 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.planes = h->d_planes; tb.planes_ll = h->d_planes_ll; tb.ll_shared = h->ll_shared;
     // recomputing d = A.c in the kernel trades 8 B per plane and row for 5 flops: pays once the launch is bandwidth-bound
     // (measured: -25 % at B = 128, O = 50; +1 % at B = 1)
-    tb.obs_center = (h->d_from_center && h->B >= 8) ? h->d_obs_center : nullptr;
+    // (a lean table of >= 8 problems has no d column at all: p1_reach.hip)
+    tb.obs_center = (h->d_from_center && (h->B >= 8 || !h->planes_have_d)) ? h->d_obs_center : nullptr;
     tb.plane_skip = h->d_plane_skip; tb.bez = h->d_bez;
     for (int i = 0; i < ARMOUR_MAX_FACTORS; i++) tb.k_range[i] = h->params.k_range[i];
     tb.duration = h->params.duration;
@@ -387,6 +388,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
         UP(h->d_planes_ll, pll);
         h->ll_shared = shared ? 1 : 0;
         h->d_from_center = 0;  // loaded tables: use the d column as given
+        h->planes_lean = 0; h->planes_have_d = 1;
     }
     HIPCHK(hipMemset(h->d_plane_skip, 0, (size_t)B * sizeof(unsigned long long)));  // loaded tables: evaluate every plane
 #undef UP
@@ -848,6 +850,15 @@ extern "C" int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, do
     const size_t ppp = armour_planes_per_problem(h->Q);
     std::vector<double> pl(h->Q > 0 ? (size_t)B * ppp : 0);
     if (pl.empty()) return ARMOUR_OK;
+    if (h->planes_lean) {
+        // the resident table holds only what the fused evaluation reads: build the full one, with the same kernel code, into a scratch buffer
+        double* d_full = nullptr;
+        HIPCHK(hipMalloc((void**)&d_full, pl.size() * sizeof(double)));
+        int rc = armour_p1_full_planes(h, d_full);
+        if (rc == ARMOUR_OK && hipMemcpy(pl.data(), d_full, pl.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { armour_set_error("copy of the half-space table failed"); rc = ARMOUR_EDEVICE; }
+        (void)hipFree(d_full);
+        if (rc != ARMOUR_OK) return rc;
+    } else
     HIPCHK(hipMemcpy(pl.data(), h->d_planes, pl.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int b = 0; b < B; b++)
         for (int t = 0; t < T; t++)
@@ -873,6 +884,13 @@ extern "C" int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, co
             armour_set_error("armour_debug_pz_op: bad operand"); return ARMOUR_EINVAL;
         }
     return armour_p1_debug_pz_op(h, op, nops, sz, cnt, keys, coef, cen, ind, ind2, consts, r, out_cap, out_keys, out_coef, out_misc);
+}
+
+extern "C" int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip) {
+    NEED_READY(h);
+    if (!plane_skip) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    for (int b = 0; b < h->B; b++) plane_skip[b] = (uint64_t)h->h_plane_skip[b];
+    return ARMOUR_OK;
 }
 
 extern "C" int armour_get_build_ms(ArmourPlanner* h, double* ms) {

@@ -132,6 +132,9 @@ struct ArmourPlanner {
     double* d_planes = nullptr;
     double* d_obs_center = nullptr;
     int d_from_center = 0;  // the d column of the table is exactly A.c of the stored normals and obs_center (tables built by P1)
+    int planes_lean = 0;    // the table holds only what the fused evaluation reads (p1_reach.hip planes_of_group); armour_get_hyperplanes rebuilds the full one
+    int planes_have_d = 1;  // its d column is stored (loaded tables, full tables, lean tables of < 8 problems)
+    double planes_ms = 0;   // device time of the half-space kernels of the last build
     double* d_planes_ll = nullptr;
     int ll_shared = 0;  // the link x link normals of the loaded table are identical over the obstacles (always so for tables built by P1)
     unsigned long long* d_plane_skip = nullptr;
@@ -167,6 +170,7 @@ int armour_upload_bounds(ArmourPlanner* h);
 // p1_reach.hip
 int armour_p1_build(ArmourPlanner* h, const double* obstacles);  // h->mode selects the ARMOUR or the ARMTD chain
 void armour_p1_free(ArmourPlanner* h);
+int armour_p1_full_planes(ArmourPlanner* h, double* d_full);
 int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, const int* cnt, const uint64_t* const* keys,
                           const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
                           int r, int out_cap, uint64_t* out_keys, double* out_coef, double* out_misc);

@@ -998,36 +998,62 @@ __device__ inline void canonical_normal(double C0, double C1, double C2, unsigne
     b[1] = (unsigned long long)__double_as_longlong(z1 == 0.0 ? 0.0 : neg ? -z1 : z1);
     b[2] = (unsigned long long)__double_as_longlong(z2 == 0.0 ? 0.0 : neg ? -z2 : z2);
 }
-__device__ inline unsigned long long normal_signature(const unsigned long long (&b)[3]) {   // 64-bit mix of the triple (a filter: equal triples, equal signatures)
+// Signature of a canonical normal.  The zero normal and the three unit axes -- every redundant plane of a world of axis-aligned boxes is
+// one of those -- get the EXACT codes 0..3 (equal codes <=> equal normals, nothing to verify); any other normal a 63-bit mix of the
+// triple with the top bit set (a filter: equal triples give equal signatures, a match is verified on the normals themselves).
+constexpr unsigned long long kOneBits = 0x3FF0000000000000ull;
+__device__ inline unsigned long long normal_signature(const unsigned long long (&b)[3]) {
+    if ((b[0] | b[1] | b[2]) == 0ull) return 0ull;
+    if (b[0] == kOneBits && (b[1] | b[2]) == 0ull) return 1ull;
+    if (b[1] == kOneBits && (b[0] | b[2]) == 0ull) return 2ull;
+    if (b[2] == kOneBits && (b[0] | b[1]) == 0ull) return 3ull;
     unsigned long long h = b[0] * 0x9E3779B97F4A7C15ull;
     h = (h ^ (h >> 29)) + b[1] * 0xBF58476D1CE4E5B9ull;
     h = (h ^ (h >> 31)) + b[2] * 0x94D049BB133111EBull;
     h ^= h >> 30; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
-    return h;
+    return h | (1ull << 63);
+}
+__device__ inline unsigned long long skipped_signature(int p) { return 0x7FFFFFFFFFFFFF00ull + (unsigned long long)p; }   // (top bit clear, > 3: equals no normal's signature)
+
+// the normal of one generator pair exactly as RT/CollisionChecking.cu:176-190 computes it (cross product, norm, three divisions)
+__device__ inline void pair_normal(const double* ga, const double* gb, double& C0, double& C1, double& C2) {
+    const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
+    const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
+    C0 = 0; C1 = 0; C2 = 0;
+    if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
 }
 
-template <int GRP>
+// What a table built by P1 holds (`lean`): only what the fused evaluation reads (p2_tiles.h: collision_block with LL) --
+//   planes 0..20 (an obstacle generator in the pair): the normal and delta;   planes 21..35 (link x link): delta only, their
+//   normals once per (link, time step) in the compact planes_ll;   d = A.c only when `store_d` (small batches read it, batches
+//   of >= 8 problems recompute it from the obstacle centres);   nothing at all for the planes of `pre`, which are redundant in every
+//   row of the problem by the CLASS of their generators (armour_p1_plane_class_kernel) and therefore in plane_skip.
+// With axis-aligned box obstacles that is 480 B per row instead of 1440 B.  The full table (`LEAN` false: every plane, every
+// component, the reference's layout content) is built on demand for armour_get_hyperplanes.
+template <int GRP, bool LEAN>
 __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c)[3], bool in, int Q, int q, int o, int lt, int JT,
-                                       double* __restrict__ out, double* __restrict__ ll, unsigned long long (&Sg)[ARMOUR_NPLANES][64], unsigned long long (&sig)[9], int lane) {
+                                       double* __restrict__ out, double* __restrict__ ll, unsigned long long (&Sg)[ARMOUR_NPLANES][64], unsigned long long (&sig)[9], int lane,
+                                       unsigned long long pre, bool store_d) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         constexpr int p0 = GRP * 9;
         const int p = p0 + k;
+        if (LEAN && ((pre >> p) & 1ull)) {   // (wave-uniform) redundant everywhere by class: neither computed nor stored
+            sig[k] = skipped_signature(p);
+            Sg[p][lane] = sig[k];
+            continue;
+        }
         const int a_id = plane_pair_a(p), b_id = plane_pair_b(p);  // (constants once the loop is unrolled)
-        const double* ga = G[a_id];
-        const double* gb = G[b_id];
-        const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
-        const double nrm = sqrt(cr0 * cr0 + cr1 * cr1 + cr2 * cr2);
-        double C0 = 0, C1 = 0, C2 = 0;
-        if (nrm > 0) { C0 = cr0 / nrm; C1 = cr1 / nrm; C2 = cr2 / nrm; }
+        double C0, C1, C2;
+        pair_normal(G[a_id], G[b_id], C0, C1, C2);
         double dl = 0.0;
 #pragma unroll
         for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
         if (in) {
-            out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2;
-            out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
+            if (!LEAN || p < ARMOUR_FIRST_LL_PLANE) { out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2; }
+            if (!LEAN || store_d) out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
             out[armour_plane_index(Q, q, p, 4)] = dl;
-            if (o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
+            if (ll && o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 2)] = C2;
@@ -1040,12 +1066,28 @@ __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c
     }
 }
 
+// canonical normal of plane p of this thread's row, recomputed from the generators in memory (run-time pair indices: only the
+// verification path below uses it -- indexing the register copy G with them would move it to scratch memory)
+__device__ inline void canonical_normal_of_plane(const double* ob, const double* lg, int p, unsigned long long (&cb)[3]) {
+    int a = 0, b = 1;
+    for (int s = 0; s < p; s++) { if (++b == 9) { a++; b = a + 1; } }
+    double ga[3], gb[3];
+    for (int ax = 0; ax < 3; ax++) {
+        ga[ax] = a < 3 ? ob[(a + 1) * 3 + ax] : lg[ax * 6 + (a - 3)];
+        gb[ax] = b < 3 ? ob[(b + 1) * 3 + ax] : lg[ax * 6 + (b - 3)];
+    }
+    double C0, C1, C2;
+    pair_normal(ga, gb, C0, C1, C2);
+    canonical_normal(C0, C1, C2, cb);
+}
+
 // Which of this thread's nine planes (9 GRP .. 9 GRP + 8 of row q) repeat an earlier plane of the row or have no normal: bit k of the
-// result.  Every earlier signature is read once and compared with the nine own ones (no branches); only a plane with a matching
-// signature -- a third of them with box obstacles -- fetches normals (its own and the candidate's, from the table just written).
+// result.  Every earlier signature is read once and compared with the nine own ones (no branches).  Equal EXACT codes (zero normal,
+// unit axes) decide at once; equal hashed signatures -- two general normals, which no workload of the suite produces -- are verified on
+// the normals themselves, recomputed from the generators.  Nothing is read back from the table.
 template <int GRP>
 __device__ inline unsigned planes_redundant(const unsigned long long (&Sg)[ARMOUR_NPLANES][64], const unsigned long long (&sig)[9],
-                                            const double* out, int Q, int q, int lane) {
+                                            const double* ob, const double* lg, int lane, unsigned long long pre) {
     constexpr int p0 = GRP * 9;
     unsigned long long cand[9];
 #pragma unroll
@@ -1057,20 +1099,22 @@ __device__ inline unsigned planes_redundant(const unsigned long long (&Sg)[ARMOU
         for (int k = 0; k < 9; k++)
             if (e2 < p0 + k) cand[k] |= s == sig[k] ? 1ull << e2 : 0ull;
     }
-    unsigned red_mask = 0u;
+    unsigned red_mask = (unsigned)((pre >> p0) & 0x1ffull);   // redundant by class in every row of the problem (not computed at all)
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        if (sig[k] != 0ull && cand[k] == 0ull) continue;   // (the zero normal's signature is 0)
-        const int p = p0 + k;
+        if (sig[k] == 0ull) { red_mask |= 1u << k; continue; }                      // no normal
+        if (cand[k] == 0ull) continue;
+        if (sig[k] <= 3ull) { red_mask |= 1u << k; continue; }                      // a unit axis an earlier plane has as well: exact
+        if (!(sig[k] >> 63)) continue;                                              // (a skipped plane's own code)
         unsigned long long cb[3];
-        canonical_normal(out[armour_plane_index(Q, q, p, 0)], out[armour_plane_index(Q, q, p, 1)], out[armour_plane_index(Q, q, p, 2)], cb);
-        bool red = (cb[0] | cb[1] | cb[2]) == 0ull;
+        canonical_normal_of_plane(ob, lg, p0 + k, cb);
+        bool red = false;
         unsigned long long mm = cand[k];
         while (mm != 0ull && !red) {
             const int e2 = __ffsll((long long)mm) - 1;
             mm &= mm - 1ull;
             unsigned long long eb[3];   // same signature: compare the normals themselves
-            canonical_normal(out[armour_plane_index(Q, q, e2, 0)], out[armour_plane_index(Q, q, e2, 1)], out[armour_plane_index(Q, q, e2, 2)], eb);
+            canonical_normal_of_plane(ob, lg, e2, eb);
             red = eb[0] == cb[0] && eb[1] == cb[1] && eb[2] == cb[2];
         }
         if (red) red_mask |= 1u << k;
@@ -1084,12 +1128,13 @@ __device__ inline unsigned planes_redundant(const unsigned long long (&Sg)[ARMOU
 // strict-> scan of :268-279 has already seen (d and delta follow the normal exactly), so skipping it changes
 // neither the maximum nor the winning normal.  The AND over all rows of a problem goes to plane_skip[b]; with
 // axis-aligned box obstacles that is 12 of the 36 planes (all obstacle x error-generator and error x error pairs).
-// Four threads per row (wave w of the 256-thread block builds planes 9w .. 9w+8 of the block's 64 rows); the normals
-// go through LDS so that each thread can test its planes against all earlier planes of its row.
+// Four threads per row (wave w of the 256-thread block builds planes 9w .. 9w+8 of the block's 64 rows); the signatures of the
+// normals go through LDS so that each thread can test its planes against all earlier planes of its row.
+template <bool LEAN>
 __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
                                                                const double* __restrict__ obstacles, double* __restrict__ planes,
                                                                double* __restrict__ planes_ll, double* __restrict__ obs_center,
-                                                               unsigned long long* __restrict__ skip_part) {
+                                                               unsigned long long* __restrict__ skip_part, const unsigned long long* __restrict__ pre_mask, int store_d) {
     __shared__ unsigned long long Sg[ARMOUR_NPLANES][64];  // [plane][row of the block]: signatures of the normals (18 KB; the normals themselves, 55 KB, held the kernel at two blocks per CU)
     const int Q = J * T * O;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1099,6 +1144,8 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     const int o = qc % O, lt = qc / O, l = lt / T, t = lt - l * T;
     const double* ob = obstacles + ((size_t)b * O + o) * 12;
     const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+    // planes that are redundant in every row of this problem by the class of their generators (wave-uniform)
+    const unsigned long long pre = LEAN ? __builtin_amdgcn_readfirstlane((unsigned)(pre_mask[b] & 0xffffffffull)) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pre_mask[b] >> 32)) << 32) : 0ull;
     double G[9][3], c[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
@@ -1109,26 +1156,27 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
         for (int g = 0; g < 6; g++) G[3 + g][ax] = lg[ax * 6 + g];
     }
     double* out = planes + (size_t)b * armour_planes_per_problem(Q);
-    if (in && grp == 0 && lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
+    if (obs_center && in && grp == 0 && lt == 0) { obs_center[((size_t)b * 3 + 0) * O + o] = c[0]; obs_center[((size_t)b * 3 + 1) * O + o] = c[1]; obs_center[((size_t)b * 3 + 2) * O + o] = c[2]; }
     // this wave's nine planes, with compile-time generator indices (see planes_of_group)
     double* ll = planes_ll ? planes_ll + (size_t)b * armour_planes_ll_per_problem(J * T) : nullptr;
     unsigned long long sig[9];
     switch (grp) {
-        case 0: planes_of_group<0>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
-        case 1: planes_of_group<1>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
-        case 2: planes_of_group<2>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
-        default: planes_of_group<3>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane); break;
+        case 0: planes_of_group<0, LEAN>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane, pre, store_d != 0); break;
+        case 1: planes_of_group<1, LEAN>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane, pre, store_d != 0); break;
+        case 2: planes_of_group<2, LEAN>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane, pre, store_d != 0); break;
+        default: planes_of_group<3, LEAN>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane, pre, store_d != 0); break;
     }
+    if (!skip_part) return;   // (the full table for armour_get_hyperplanes: the masks exist already)
     __syncthreads();
     // redundancy of this thread's planes: zero normal, or bit-for-bit +- the normal of an earlier plane of the row
     unsigned long long skip = ~0ull;
     if (in) {
         unsigned red = 0u;
         switch (grp) {
-            case 0: red = planes_redundant<0>(Sg, sig, out, Q, q, lane); break;
-            case 1: red = planes_redundant<1>(Sg, sig, out, Q, q, lane); break;
-            case 2: red = planes_redundant<2>(Sg, sig, out, Q, q, lane); break;
-            default: red = planes_redundant<3>(Sg, sig, out, Q, q, lane); break;
+            case 0: red = planes_redundant<0>(Sg, sig, ob, lg, lane, pre); break;
+            case 1: red = planes_redundant<1>(Sg, sig, ob, lg, lane, pre); break;
+            case 2: red = planes_redundant<2>(Sg, sig, ob, lg, lane, pre); break;
+            default: red = planes_redundant<3>(Sg, sig, ob, lg, lane, pre); break;
         }
         // planes of the other three groups: not this thread's to clear
         skip = ~(((unsigned long long)(~red & 0x1ffu)) << (grp * 9));
@@ -1141,6 +1189,69 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     }
     // (one atomicAnd per wave on the problem's mask cost a seventh of the kernel: 112 k of them on 128 words at B = 128)
     if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = skip;
+}
+
+// Class pre-pass of the lean table: which planes are redundant in EVERY row of a problem by the class of their two generators alone
+// -- a generator that is the zero vector or has exactly one non-zero component (every generator of an axis-aligned box obstacle and
+// the three error generators diag(independent) of a link).  A pair with a zero generator, or two generators on the same axis, has the
+// zero normal; two generators on different axes i, j have the normal +-e_k exactly (the one non-zero product of the cross product is
+// x = fl(alpha * beta), the norm sqrt(fl(x * x)) = |x| exactly while x * x neither overflows nor underflows, x / |x| = +-1), which an
+// earlier pair of the same class repeats bit for bit.  One thread per row, integer logic on nine class codes; the result is a
+// subset of what the signature test of armour_p1_planes_kernel finds (that test still produces plane_skip), known BEFORE the planes are
+// computed, so that the lean kernel neither computes nor stores those planes.
+__global__ __launch_bounds__(256) void armour_p1_plane_class_kernel(int T, int J, int O, const double* __restrict__ link_gens,
+                                                                    const double* __restrict__ obstacles, unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long s[4];
+    const int Q = J * T * O;
+    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    unsigned long long m = ~0ull;
+    if (q < Q) {
+        const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
+        const double* ob = obstacles + ((size_t)b * O + o) * 12;
+        const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+        int cls[9];     // 0: zero vector; 1..3: only component x / y / z is non-zero; 4: anything else
+        double mag[9];  // |the one non-zero component|
+#pragma unroll
+        for (int g = 0; g < 9; g++) {
+            double v[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) v[ax] = g < 3 ? ob[(g + 1) * 3 + ax] : lg[ax * 6 + (g - 3)];
+            const int nz = (v[0] != 0.0) + (v[1] != 0.0) + (v[2] != 0.0);
+            cls[g] = nz == 0 ? 0 : nz > 1 ? 4 : v[0] != 0.0 ? 1 : v[1] != 0.0 ? 2 : 3;
+            mag[g] = fabs(v[0]) + fabs(v[1]) + fabs(v[2]);
+            if (!(mag[g] == mag[g]) || mag[g] > 1e100) cls[g] = 4;   // NaN / inf / huge: no claim
+        }
+        m = 0ull;
+        unsigned seen = 0u;   // bit k: an earlier pair of this row has the normal +-e_k by class
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < 9; a++)
+#pragma unroll
+            for (int bb = a + 1; bb < 9; bb++, p++) {
+                const int ca = cls[a], cb = cls[bb];
+                bool red = false;
+                if (ca == 0 || cb == 0) red = ca != 4 && cb != 4 ? true : false;   // (0 x anything finite = 0; a general partner is finite unless flagged above, but make no claim)
+                else if (ca < 4 && cb < 4) {
+                    if (ca == cb) red = true;
+                    else {
+                        const double x = mag[a] * mag[bb];
+                        if (x > 1e-100 && x < 1e100) {   // x * x is a normal number: the norm is |x| exactly
+                            const int k = 6 - ca - cb;
+                            if (seen & (1u << k)) red = true; else seen |= 1u << k;
+                        }
+                    }
+                }
+                if (red) m |= 1ull << p;
+            }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)m, o2, 64), hi = __shfl_xor((unsigned)(m >> 32), o2, 64);
+        m &= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = s[0] & s[1] & s[2] & s[3];
 }
 
 // plane_skip[b] = AND of the planes kernel's per-wave masks of problem b
@@ -1587,23 +1698,41 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (O > 0) {
         const int Q = J * T * O;
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
-        const int nbx = (Q + 63) / 64;
-        if ((size_t)B * nbx * 4 > wk->skip_part_cap) {
+        const int nbx = (Q + 63) / 64, nbc = (Q + 255) / 256;
+        // [B][nbx][4] per-wave masks of the planes kernel | [B][nbc] per-block masks of the class pre-pass | [B] its result
+        const size_t part_words = (size_t)B * nbx * 4, pre_words = (size_t)B * nbc;
+        if (part_words + pre_words + (size_t)B > wk->skip_part_cap) {
             if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
             wk->d_skip_part = nullptr; wk->skip_part_cap = 0;
-            HIPCHK(hipMalloc((void**)&wk->d_skip_part, (size_t)B * nbx * 4 * sizeof(unsigned long long)));
-            wk->skip_part_cap = (size_t)B * nbx * 4;
+            HIPCHK(hipMalloc((void**)&wk->d_skip_part, (part_words + pre_words + (size_t)B) * sizeof(unsigned long long)));
+            wk->skip_part_cap = part_words + pre_words + (size_t)B;
         }
-        hipLaunchKernelGGL(armour_p1_planes_kernel, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
-                           wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part);
+        unsigned long long* d_pre_part = wk->d_skip_part + part_words;
+        unsigned long long* d_pre = d_pre_part + pre_words;
+        // The table holds what the fused evaluation reads and nothing else (planes_of_group): ARMOUR_P1_FULL_PLANES=1 (development) builds
+        // the full one.  d = A.c is stored for the small batches that read it; batches of >= 8 problems recompute it (armour_make_tables).
+        static const int full_env = [] { const char* e = getenv("ARMOUR_P1_FULL_PLANES"); return e ? atoi(e) : 0; }();
+        const bool lean = !full_env;
+        const int store_d = B >= 8 ? 0 : 1;
+        if (lean) {
+            hipLaunchKernelGGL(armour_p1_plane_class_kernel, dim3(nbc, B), dim3(256), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part);
+            hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, d_pre_part, nbc, d_pre);
+            hipLaunchKernelGGL(armour_p1_planes_kernel<true>, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, d_pre, store_d);
+        } else {
+            hipLaunchKernelGGL(armour_p1_planes_kernel<false>, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, nullptr, 1);
+        }
         hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, wk->d_skip_part, nbx * 4, h->d_plane_skip);
         h->ll_shared = 1; h->d_from_center = 1;
+        h->planes_lean = lean ? 1 : 0; h->planes_have_d = (!lean || store_d) ? 1 : 0;
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
+        h->planes_ms = ms;
     }
     h->build_ms = total_ms;  // device time of every launch of this build, retries included
 
@@ -1611,5 +1740,19 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     h->h_link_gens.resize((size_t)B * T * J * 18);
     HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, h->h_torque_radius.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, h->h_link_gens.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return ARMOUR_OK;
+}
+
+// The FULL half-space table of the current problem set -- every plane, all five components, what RT/CollisionChecking.cu:215-227 holds --
+// into `d_full` ([B][5][36][Q] doubles, device): the same kernel code as the build's, with nothing left out.  For armour_get_hyperplanes
+// (parity tests, diagnostics); the product path reads the lean table.
+int armour_p1_full_planes(ArmourPlanner* h, double* d_full) {
+    P1Work* wk = (P1Work*)h->p1;
+    if (!wk || !wk->d_link_gens || !wk->d_obstacles || h->O <= 0) { armour_set_error("no reach sets on the device to rebuild the half-space table from"); return ARMOUR_ESTATE; }
+    const int Q = h->J * h->T * h->O, nbx = (Q + 63) / 64;
+    hipLaunchKernelGGL(armour_p1_planes_kernel<false>, dim3(nbx, h->B), dim3(256), 0, h->stream, h->B, h->T, h->J, h->O,
+                       wk->d_link_gens, wk->d_obstacles, d_full, nullptr, nullptr, nullptr, nullptr, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return ARMOUR_OK;
 }

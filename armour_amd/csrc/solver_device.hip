@@ -775,7 +775,14 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         for (int t = t0; t < t1; t++) {
             int tr0, tr1;
             tile_info(a, t, role, tr0, tr1);
-            if (role < a.lp.nbc) collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+            if (role < a.lp.nbc) {
+                // d = A.c recomputed from the obstacle centres where the launch of armour_eval_g_jac does the same (batches of >= 8
+                // problems, whose tables hold no d column: api.hip armour_make_tables) -- the same rows bit for bit either way
+                if constexpr (LL) {
+                    if (a.tb.obs_center) collision_block<true, true, false, true, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+                    else collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+                } else collision_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
+            }
             else if (role < a.lp.nbc + a.lp.nbt) torque_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
             else limit_block<true, true, false, false, LL, PPW, false>(a.tb, a.lp, b, role, my_x, kf, g, jac, smem_raw);
             __syncthreads();

@@ -487,6 +487,33 @@ class ArmourNLP:
         check(self.L.armour_get_build_ms(self.h, C.byref(v)))
         return v.value
 
+    def plane_skip(self):
+        """[B] uint64: bit p set = half-space p is never needed by any collision row of the problem (armour_get_plane_skip)."""
+        out = np.zeros(self.B, dtype=np.uint64)
+        check(self.L.armour_get_plane_skip(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def effective_bytes(self):
+        """Bytes ONE fused evaluation of all B problems moves by the layout it actually reads (tables built by P1; p2_tiles.h
+        collision_block with the compact link x link normals, p1_reach.hip planes_of_group): per collision row and live plane
+        below 21 the normal and delta (32 B), per live plane from 21 on delta alone (8 B), plus d (8 B per live plane) for the
+        batches of < 8 problems that read it instead of recomputing it; the compact normals once per (link, time step); the
+        obstacle centres; the link / torque PZ tables with their counts, centres and radii; k in, g and the dense Jacobian out.
+        Unlike algorithmic_bytes() -- defined by the reference's formulation, 1440 B per row -- a fraction of the HBM peak computed
+        from this number cannot exceed 1."""
+        ts = self.table_sizes()
+        JT, Q, nT = self.J * self.T, self.J * self.T * self.O, self.n * self.T
+        dfc = self.B >= 8                       # armour_make_tables (api.hip)
+        total = 0
+        for sk in self.plane_skip():
+            live = [p for p in range(36) if not (int(sk) >> p) & 1]
+            lo, hi = sum(1 for p in live if p < 21), sum(1 for p in live if p >= 21)
+            per_row = 32 * lo + 8 * hi + (0 if dfc else 8 * (lo + hi))
+            total += Q * per_row + JT * hi * 24 + (24 * self.O if dfc else 0)
+        total += 32 * ts["sum_link"] + 16 * ts["sum_torque"] + self.B * (JT * 52 + nT * 20)
+        total += self.B * (8 * self.m * (1 + self.n) + 8 * self.n)
+        return total
+
     def algorithmic_bytes(self):
         """B_alg of one fused eval over all B problems:
         1440*T*J*O per problem + 32*SumM_link + 16*SumM_torque + 8*m*(1+n) per problem."""

@@ -44,6 +44,18 @@ def random_problem(seed, num_obstacles):
     return dict(q0=q0, qd0=qd0, qdd0=qdd0, q_des=q_des, obstacles=obs)
 
 
+def random_fetch_problem(seed, num_obstacles):
+    """One world for the Fetch preset (CMP/FetchInfo.h:86-89: joint and speed limits): a random state inside the joint limits and
+    `num_obstacles` random boxes -- BASELINE configs[4] uses 100."""
+    rng = np.random.default_rng(seed)
+    lb = np.array([-1.6056, -1.221, -np.pi, -2.251, -np.pi, -2.16, -np.pi]) + 0.3
+    ub = np.array([1.6056, 1.518, np.pi, 2.251, np.pi, 2.16, np.pi]) - 0.3
+    speed = np.array([1.256, 1.454, 1.571, 1.521, 1.571, 2.268, 2.268])
+    q0 = rng.uniform(lb, ub)
+    return dict(q0=q0, qd0=rng.uniform(-0.5, 0.5, 7) * speed, qdd0=rng.uniform(-1, 1, 7), q_des=q0 + rng.uniform(-0.3, 0.3, 7),
+                obstacles=random_problem(seed, num_obstacles)["obstacles"])
+
+
 def random_batch(first_seed, batch, num_obstacles):
     """`batch` worlds with seeds first_seed..first_seed+batch-1, stacked: q0 [B,7] ... obstacles [B,O,12]."""
     ps = [random_problem(first_seed + b, num_obstacles) for b in range(batch)]

@@ -98,23 +98,38 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
             best_t, best_rate = th, rate
     reps = int(max(20, min(20000, budget_s * best_rate)))
     secs = o.time_eval(ks, reps, threads=best_t)
+    # the reach-set build (P1, RT/armour_main.cu:96-216: OpenMP over the time steps) as its own timed figure: the same world at
+    # 1 thread, at the reference's 32 (NUM_THREADS, RT/Parameters.h:35) and at all cores; best of 2 builds each (1 at one thread)
+    p1 = {}
+    for th in sorted({1, min(32, max_threads()), max_threads()}):
+        ms = []
+        for _ in range(1 if th == 1 else 2):
+            ob = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"], threads=th)
+            ms.append(ob.build_ms)
+        p1[str(th)] = min(ms)
     return {
         "value": reps / secs, "unit": "iters/s", "cores": best_t, "kind": "port",
         "sample": f"{reps} fused eval_g+eval_jac_g of 1 world (seed {seed}, O={O}, T={T}) at 64 cycling k points, "
-                  f"OpenMP over time steps as RT/NLPclass.cu:304,376; reach-set build {o.build_ms:.0f} ms on the same cores",
-        "p1_build_ms": o.build_ms,
+                  f"OpenMP over time steps as RT/NLPclass.cu:304,376",
+        "p1_build_ms_by_threads": p1, "p1_build_ms": min(p1.values()),
+        "p1_sample": f"reach-set build (JRS, FK, RNEA x2, torque radius, half-space tables) of the same world, ms, by OpenMP threads",
     }
 
 
 def measured_traffic(B, O, T):
-    """HBM bytes per P2 launch from the newest committed rocprofv3 PMC passes of this same command
-    (profiles/r*_bench_headline_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).
-    None when no profile of this config exists."""
-    if (B, O, T) != (1, 20, 100):
+    """HBM bytes per P2 launch from the newest committed rocprofv3 PMC passes of this same configuration
+    (profiles/r*_bench_{headline,configs2}_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md), with the file, the commit and the date the profile was taken at -- the number is read from a
+    committed file, not measured in this run, so the line says which build it belongs to.  None when no profile of this
+    configuration exists."""
+    name = {(1, 20, 100): "headline", (128, 50, 100): "configs2"}.get((B, O, T))
+    if name is None:
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_headline_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{name}_pmc.json")), reverse=True):
         try:
-            return float(json.load(open(path))["p2_hbm_traffic_bytes_per_launch"])
+            d = json.load(open(path))
+            return {"bytes": float(d["p2_hbm_traffic_bytes_per_launch"]), "profile": os.path.relpath(path, ROOT),
+                    "profile_commit": d.get("commit"), "profile_date": d.get("date"), "l2_hit_rate": d.get("l2_hit_rate")}
         except Exception:
             continue
     return None
@@ -189,12 +204,21 @@ class Timed:
 
 
 def summarise(nlp, wall, ev, K, world, extra=None):
-    b_alg = nlp.algorithmic_bytes()
+    """Three byte counts per launch, each divided by the HIP-event launch time:
+      algorithmic  the reference formulation's bytes (1440 B per collision row + PZ tables + outputs) -- the yardstick
+                   `roofline.achieved` is defined on; the kernel may legitimately move fewer (planes never needed are not stored)
+      effective    what the layout the kernel actually reads holds (ArmourNLP.effective_bytes): a fraction from it cannot exceed 1
+      traffic      HBM bytes by the rocprofv3 counters of the newest committed profile of this configuration (or None)"""
+    b_alg, b_eff = nlp.algorithmic_bytes(), nlp.effective_bytes()
     med_wall, med_ev = statistics.median(wall), statistics.median(ev)
     launch_us = med_ev * 1e6 / K
     achieved = b_alg / (launch_us * 1e-6) / 1e9
+    eff = b_eff / (launch_us * 1e-6) / 1e9
+    tr = measured_traffic(nlp.B, nlp.O, nlp.T)
     out = {"problem_evals_per_s": world * nlp.B * K / med_wall, "ms_per_step": med_wall * 1e3 / K, "launch_us": launch_us,
            "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+           "effective_bytes_per_launch": b_eff, "effective_GBps": eff, "frac_effective": eff / HBM_PEAK_GBS,
+           "traffic": tr, "frac_by_traffic": (tr["bytes"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tr else None,
            "repeats": len(wall), "wall_ms_min_med_max": [min(wall) * 1e3, med_wall * 1e3, max(wall) * 1e3],
            "p1_set_problems_ms_per_problem": nlp.build_ms / nlp.B}
     if extra:
@@ -219,6 +243,40 @@ def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle
         spot = tm.check(picks)
     out = summarise(nlp, wall, ev, K, world, {"checked": "finite + device entry == host entry" + (" + oracle on problems 0 and B-1" if spot else ""),
                                                "oracle_spot_check": spot} if check_oracle is not None else {"checked": None})
+    nlp.close()
+    return out
+
+
+def fetch_config(device, dev, T, K, R, check):
+    """BASELINE configs[4] (never `value`): the Fetch preset (CMP/FetchInfo.h: 9 links, 7 factors, mixed joint axes) with +-50 % mass /
+    inertia uncertainty on the last link (the payload), 100 obstacles, one planning problem: reach-set build ms, fused evaluation
+    us, and g / jac of the last timed step against the CPU oracle.  (The "8-DOF" of BASELINE.json would need an 8th factor, which the
+    reference's 64-bit monomial key cannot hold: RT/PZsparse.h:8-21.)"""
+    import numpy as np
+    from armour_amd.planner import ArmourNLP, default_params, fetch_robot
+    from armour_amd.worlds import random_fetch_problem
+    O = 100
+    p = random_fetch_problem(11, O)
+    nlp = ArmourNLP(robot=fetch_robot(0.5), params=default_params(T), device=device)
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])   # (the second build: code objects loaded)
+    tm = Timed(nlp, dev, 311, K, 4, False)
+    wall, ev = tm.run(R)
+    spot = None
+    if check:
+        from oracle.cpu_oracle import Oracle
+        from oracle.cpu_oracle import default_params as oracle_params
+        from oracle.cpu_oracle import fetch_robot as oracle_fetch
+        o = Oracle(robot=oracle_fetch(0.5), params=oracle_params(T)).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        k_last = tm.ks[-1].cpu().numpy()
+        g_ref, jac_ref = o.eval_g_jac(k_last[0])
+        dg = float(np.abs(tm.d_g.cpu().numpy()[0] - g_ref).max())
+        dj = float(np.abs(tm.d_jac.cpu().numpy()[0] - jac_ref).max())
+        assert dg <= 1e-9 and dj <= 1e-8, (dg, dj)
+        spot = {"max_abs_dg": dg, "max_abs_djac": dj, "oracle_build_ms": o.build_ms}
+    out = summarise(nlp, wall, ev, K, 1, {"robot": "fetch (CMP/FetchInfo.h), last link +-50 % mass / inertia", "links": nlp.J, "obstacles": O,
+                                          "constraints_m": nlp.m, "p1_set_problems_ms": nlp.build_ms, "oracle_spot_check": spot,
+                                          "table_sizes": nlp.table_sizes()})
     nlp.close()
     return out
 
@@ -334,7 +392,9 @@ def main():
             "timing": {"repeats": R, "statistic": "median of the max-over-ranks wall time of K steps (barrier + synchronize on both sides)",
                        "wall_ms_min_med_max": s["wall_ms_min_med_max"]},
             "roofline": {"bound": "hbm", "achieved": s["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": s["frac_of_hbm_peak"], "traffic": measured_traffic(B, O, T),
+                         "frac": s["frac_of_hbm_peak"], "traffic": s["traffic"]["bytes"] if s["traffic"] else None,
+                         "traffic_source": s["traffic"], "frac_by_traffic": s["frac_by_traffic"],
+                         "effective_bytes_per_launch": s["effective_bytes_per_launch"], "frac_effective": s["frac_effective"],
                          "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],
                          "launch_us": s["launch_us"]},
             "p1_set_problems_ms": {"device": p1_dev_ms, "wall": p1_wall_ms, "per_problem_device": p1_dev_ms / B},
@@ -400,7 +460,8 @@ def main():
         KX = max(4, min(K, 40))
         chk = None if args.no_check or args.no_sync_probe else True
         if world == 1:
-            oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk)}
+            oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk),
+                  "configs[4]: Fetch, payload +-50 %, O=100, batch 1, T=100": fetch_config(local_rank, dev, T, max(KX, 20), R, chk is not None)}
         else:
             oc = {f"configs[3]: O=20, batch 128 per GPU ({128 * world} worlds over {world} GPUs), T=100":
                   extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False)}

@@ -268,6 +268,11 @@ int armour_get_table_sizes(ArmourPlanner* h, int64_t* out4);
 /* half-space tables in the reference's layout (RT/CollisionChecking.cu:215-227):
  * A [B][T][J][O][36][3], d and delta [B][T][J][O][36]; any pointer may be NULL. */
 int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, double* delta);
+/* plane_skip [B]: bit p set = half-space p is redundant in EVERY collision row of the problem (zero normal, or bit for bit +- the
+ * normal of an earlier plane of its row: RT/CollisionChecking.cu:252-259,268-279 can then neither take its value nor its normal), so
+ * the table holds nothing for it and the fused evaluation does not read it.  With axis-aligned box obstacles 12 of the 36 planes.
+ * For the byte accounting of bench.py (what one evaluation reads) and for tests. */
+int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip);
 /* ms spent in the last armour_set_problems (device time, hipEvent) */
 int armour_get_build_ms(ArmourPlanner* h, double* ms);
 /* name of the P2 kernel as it appears in rocprofv3 kernel traces */

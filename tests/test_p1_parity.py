@@ -232,15 +232,8 @@ def test_kinova_with_gripper_payload():
 
 
 def _fetch_problem(seed, O):
-    """a random state inside Fetch's joint limits (CMP/FetchInfo.h:86-89) and O random boxes"""
-    from armour_amd.worlds import random_problem
-    rng = np.random.default_rng(seed)
-    lb = np.array([-1.6056, -1.221, -np.pi, -2.251, -np.pi, -2.16, -np.pi]) + 0.3
-    ub = np.array([1.6056, 1.518, np.pi, 2.251, np.pi, 2.16, np.pi]) - 0.3
-    speed = np.array([1.256, 1.454, 1.571, 1.521, 1.571, 2.268, 2.268])
-    q0 = rng.uniform(lb, ub)
-    return dict(q0=q0, qd0=rng.uniform(-0.5, 0.5, 7) * speed, qdd0=rng.uniform(-1, 1, 7), q_des=q0 + rng.uniform(-0.3, 0.3, 7),
-                obstacles=random_problem(seed, O)["obstacles"])
+    from armour_amd.worlds import random_fetch_problem
+    return random_fetch_problem(seed, O)
 
 
 @pytest.mark.parametrize("mode", ["armour", "armtd"])
