@@ -444,9 +444,12 @@ def _compress_mat(A, k_id):
 
 
 def create_jrs_online(q, dq, ddq, joint_axes, taylor_degree=1, ultimate_bound=0.0191, k_r=10.0, k_range=np.pi / 36, n_t=100,
-                      add_ultimate_bound=True):
+                      add_ultimate_bound=True, full=False, time_indices=None):
     """PZM/create_jrs_online.m, traj_type 'bernstein': per time interval and joint the position set Q (with tracking error)
-    and its rotation matrix set R, in terms of the trajectory parameters k_1..k_n (ids 1..n) alone."""
+    and its rotation matrix set R, in terms of the trajectory parameters k_1..k_n (ids 1..n) alone.
+    full=True returns a dict with everything the dynamics half of the planner reads (:165-178): Q, Qd (velocity with the velocity
+    error E_v), Qd_a (auxiliary velocity: desired + K_r E_p), Qdd_a (auxiliary acceleration: desired + K_r E_v), R, R_t.
+    time_indices: build only these intervals (the others are None) -- the intervals are independent of each other."""
     q, dq, ddq = (np.asarray(v, dtype=float).reshape(-1) for v in (q, dq, ddq))
     n_q = q.size
     dt = 1.0 / n_t
@@ -454,9 +457,10 @@ def create_jrs_online(q, dq, ddq, joint_axes, taylor_degree=1, ultimate_bound=0.
     K = [PZ(0.0, [[1.0]], None, [[1]], [j + 1]) for j in range(n_q)]
     t_ids = list(range(next_id, next_id + n_t)); next_id += n_t
     Tm = [PZ(dt * i + dt / 2, [[dt / 2]], None, [[1]], [t_ids[i]]) for i in range(n_t)]
-    E_p = []
+    E_p, E_v = [], []
     for j in range(n_q):
         E_p.append(PZ(0.0, [[ultimate_bound / k_r]], None, [[1]], [next_id]) if add_ultimate_bound else 0.0)
+        E_v.append(PZ(0.0, [[2 * ultimate_bound]], None, [[1]], [next_id + 1]) if add_ultimate_bound else 0.0)
         next_id += 2          # (e1, e2: position and velocity error each get an id, create_jrs_online.m:125-133)
     alpha = []
     for j in range(n_q):
@@ -471,22 +475,36 @@ def create_jrs_online(q, dq, ddq, joint_axes, taylor_degree=1, ultimate_bound=0.
                 acc = acc + term
             al.append(acc)
         alpha.append(al)
+    sc = lambda f, x: times(float(f), x) if isinstance(x, PZ) else f * x
+    mul = lambda a, b: times(a, b) if isinstance(a, PZ) or isinstance(b, PZ) else a * b
     Q, R = [], []
+    out = dict(Q=Q, Qd=[], Qd_a=[], Qdd_a=[], R=R, R_t=[])
     for i in range(n_t):
-        Qi, Ri = [], []
+        if time_indices is not None and i not in time_indices:
+            for v in out.values():
+                v.append(None)
+            continue
+        Qi, Ri, Qdi, Qdai, Qddai, Rti = [], [], [], [], [], []
         for j in range(n_q):
-            Qd = 0.0
+            Qd_, Qv_, Qa_ = 0.0, 0.0, 0.0
             for k in range(6):
-                Tk = power(Tm[i], k)
-                a = alpha[j][k]
-                term = times(a, Tk) if isinstance(a, PZ) or isinstance(Tk, PZ) else a * Tk
-                Qd = Qd + term
-            Qe = Qd + E_p[j]
+                Qd_ = Qd_ + mul(alpha[j][k], power(Tm[i], k))
+                if full and k > 0:
+                    Qv_ = Qv_ + mul(sc(k, alpha[j][k]), power(Tm[i], k - 1))             # :156-158
+                if full and k > 1:
+                    Qa_ = Qa_ + mul(sc(k * (k - 1), alpha[j][k]), power(Tm[i], k - 2))   # :159-161
+            Qe = Qd_ + E_p[j]
             Rj = _rotations_from_q(Qe, joint_axes[:, j], taylor_degree)
             Qi.append(_compress(Qe, j + 1))
             Ri.append(_compress_mat(Rj, j + 1))
+            if full:
+                Qdi.append(_compress(Qv_ + E_v[j], j + 1))                                # Qd   = Qd_des + E_v          (:167)
+                Qdai.append(_compress(Qv_ + sc(k_r, E_p[j]), j + 1))                      # Qd_a = Qd_des + k_r E_p      (:168)
+                Qddai.append(_compress(Qa_ + sc(k_r, E_v[j]), j + 1))                     # Qdd_a = Qdd_des + k_r E_v    (:169)
+                Rti.append(_compress_mat(transpose(Rj), j + 1))                           # get_pz_rotations_from_q.m: every page transposed
         Q.append(Qi); R.append(Ri)
-    return Q, R
+        out["Qd"].append(Qdi); out["Qd_a"].append(Qdai); out["Qdd_a"].append(Qddai); out["R_t"].append(Rti)
+    return out if full else (Q, R)
 
 
 def pzfk(R_in, T0, P, zono_order=40):
@@ -565,3 +583,185 @@ def eval_obstacle_constraint(con, k, n_q):
     v = A @ slice_pz(fo, k) - b
     m = int(np.argmax(v))
     return -v[m], -(grad_slice(fo, k, n_q) @ A[m])
+
+
+# ------------------------------------------------------------------------------------------------ the dynamics half
+# KSI/uarmtd_planner.m:471-559 (input constraints) and :562-576,622-690 (joint limits, pruning) on PZM/utility/poly_zonotope_rnea.m.
+def _vec(p):
+    return p if isinstance(p, PZ) else PZ(np.asarray(p, dtype=float).reshape(-1))
+
+
+def scalar_times_axis(p, z):
+    """a 1-D set times a numeric column: `joint_vel{j} * z(:, i)` (poly_zonotope_rnea.m:92; CORA mtimes with a numeric matrix)"""
+    z = np.asarray(z, dtype=float).reshape(-1, 1)
+    if not isinstance(p, PZ):
+        return PZ(float(p) * z[:, 0])
+    return PZ(p.c[0] * z[:, 0], z @ p.G if p.G.shape[1] else None, z @ p.Grest if p.Grest.shape[1] else None, p.E, p.id)
+
+
+def _skew(z):
+    return np.array([[0.0, -z[2], z[1]], [z[2], 0.0, -z[0]], [-z[1], z[0], 0.0]])
+
+
+def cross(a, b):
+    """@polyZonotope_ROAHM/cross.m: the skew matrix (set) of a, times b; either operand may be a numeric 3-vector"""
+    if not isinstance(a, PZ):
+        M = _skew(np.asarray(a, dtype=float).reshape(-1))
+        return mtimes(M, b) if isinstance(b, PZ) else PZ(M @ np.asarray(b, dtype=float).reshape(-1))
+    G = np.stack([_skew(a.G[:, j]) for j in range(a.G.shape[1])], axis=2) if a.G.shape[1] else None
+    R = np.stack([_skew(a.Grest[:, j]) for j in range(a.Grest.shape[1])], axis=2) if a.Grest.shape[1] else None
+    A = MatPZ(_skew(a.c), G, R, a.E, a.id)
+    return mtimes(A, b if isinstance(b, PZ) else np.asarray(b, dtype=float).reshape(-1))
+
+
+def inertial_params(robot, uncertain, zono_order=40):
+    """urdfs/urdf_utils/get_inertial_params.m:114-196, set_type 'polynomial_zonotope', track_inertial_generators false: per link the
+    mass as a 3 x 3 matrix set m I_3 (+ one independent page dm I_3), the centre of mass as a point set (com_range [1, 1]) and the
+    inertia about it with one independent page per distinct symmetric entry (d = relative uncertainty x |entry|).  `uncertain` False:
+    the nominal parameters (pz_nominal), True: mass / inertia within +- the robot's uncertainty (pz_interval; the reference's
+    uncertain_mass_range [0.97, 1.03], urdfs/urdf_utils/load_robot_params.m:9)."""
+    from .robot_geometry import joint_frames
+    T0, P, axes, _, _ = joint_frames(robot)
+    n = len(axes)
+    mass, com, I = [], [], []
+    for i in range(n):
+        um = (robot.mass_uncertainty_link[i] or robot.mass_uncertainty) if uncertain else 0.0
+        ui = (robot.inertia_uncertainty_link[i] or robot.inertia_uncertainty) if uncertain else 0.0
+        m = robot.mass[i]
+        mass.append(MatPZ(m * np.eye(3), None, (um * abs(m) * np.eye(3))[:, :, None] if um else None))
+        com.append(np.array(robot.com[3 * i:3 * i + 3]))
+        Ic = np.array(robot.inertia[9 * i:9 * i + 9]).reshape(3, 3)
+        pages = []
+        for a in range(3):
+            for b in range(a, 3):
+                if ui and Ic[a, b] != 0.0:
+                    Gp = np.zeros((3, 3)); Gp[a, b] = Gp[b, a] = ui * abs(Ic[a, b])
+                    pages.append(Gp)
+        I.append(MatPZ(Ic, None, np.stack(pages, axis=2) if pages else None))
+    Pn = np.array(robot.trans)[:3 * (n + 1)].reshape(n + 1, 3).T     # (the last column: the frame after the last joint)
+    return dict(mass=mass, com=com, I=I, T0=T0, P=Pn, axes=axes, n=n, zono_order=zono_order, gravity=robot.gravity)
+
+
+def poly_zonotope_rnea(R_in, R_t_in, qd, qd_aux, qdd, use_gravity, prm):
+    """PZM/utility/poly_zonotope_rnea.m:1-239 (all joints revolute): passivity RNEA on sets, Girard reduction to `zono_order`
+    after every operation the reference reduces after.  R_in / R_t_in: MatPZ per joint; qd, qd_aux, qdd: 1-D PZ (or numbers)
+    per joint.  Returns (u, f, n): the joint torque sets and the link force / moment sets."""
+    n, zo = prm["n"], prm["zono_order"]
+    red = lambda x: reduce(x, zo)
+    T0, P, z = prm["T0"], prm["P"], prm["axes"]
+    R = [mtimes(MatPZ(T0[i]), R_in[i]) for i in range(n)]                       # :49
+    R_t = [mtimes(R_t_in[i], MatPZ(T0[i].T)) for i in range(n)]                 # :50
+    w_p, wa_p, wd_p = np.zeros(3), np.zeros(3), np.zeros(3)                     # base frame (:69-72)
+    la_p = np.array([0.0, 0.0, prm["gravity"]]) if use_gravity else np.zeros(3)   # linear_acc0 = -gravity' (:75-77)
+    F, N = [], []
+    for i in range(n):
+        jv, ja, jva = scalar_times_axis(qd[i], z[i]), scalar_times_axis(qdd[i], z[i]), scalar_times_axis(qd_aux[i], z[i])
+        Rt = R_t[i]
+        w = red(plus(mtimes(Rt, w_p), jv))                                        # (6.45) :92,139-140
+        wa = red(plus(mtimes(Rt, wa_p), jva))                                     # :95,143-144
+        prod1 = red(mtimes(Rt, wa_p))                                             # :147-150
+        prod2 = red(jv)
+        wd = red(plus(plus(mtimes(Rt, wd_p), cross(prod1, prod2)), ja))           # (6.46) :151-154
+        if i == 0:   # (6.47) :103-105 -- the reference's first joint uses cross(w0, cross(w0, P)), both zero at the base
+            inner = plus(plus(_vec(la_p), cross(wd_p, P[:, i])), cross(w_p, cross(w_p, P[:, i])))
+        else:        # :157-159
+            inner = plus(plus(la_p, cross(wd_p, P[:, i])), cross(w_p, cross(wa_p, P[:, i])))
+        la = red(mtimes(Rt, inner))
+        com = prm["com"][i]
+        p0 = red(cross(wd, com))                                                  # (6.48) :187-194
+        p1 = red(cross(wa, com))
+        lac = red(plus(plus(la, p0), cross(w, p1)))
+        F.append(red(mtimes(prm["mass"][i], lac)))                                # (6.49) :197-198
+        q0 = red(mtimes(prm["I"][i], wd))                                         # (6.50) :201-207
+        q1 = red(mtimes(prm["I"][i], w))
+        N.append(red(plus(q0, cross(wa, q1))))
+        w_p, wa_p, wd_p, la_p = w, wa, wd, la
+    f = [None] * n + [PZ(np.zeros(3))]
+    nn = [None] * n + [PZ(np.zeros(3))]
+    R.append(MatPZ(np.eye(3)))                                                    # :213 (the frame after the last joint: no rotation here)
+    for i in range(n - 1, -1, -1):
+        f[i] = red(plus(mtimes(R[i + 1], f[i + 1]), F[i]))                        # (6.51) :218-219
+        p0 = red(mtimes(R[i + 1], nn[i + 1]))                                     # (6.52) :222-230
+        p1 = red(mtimes(R[i + 1], f[i + 1]))
+        nn[i] = red(plus(plus(plus(N[i], p0), cross(prm["com"][i], F[i])), cross(P[:, i + 1], p1)))
+    u = [mtimes(z[i].reshape(1, 3), nn[i]) for i in range(n)]                     # (6.53) :237
+    return u, f[:n], nn[:n]
+
+
+def _buffered(p, sign):
+    """c +- sum |Grest| with the independent part removed (KSI/uarmtd_planner.m:541-547): a PZ in k alone"""
+    buf = np.abs(p.Grest).sum(axis=1)
+    return PZ(p.c + sign * buf, p.G, None, p.E, p.id)
+
+
+def input_constraints(q0, qd0, qdd0, robot, torque_limits, time_indices, n_t=100, zono_order=40, alpha_constant=10.0,
+                      ultimate_bound=0.0191, k_r=10.0, use_robust_input=True, **jrs_kw):
+    """KSI/uarmtd_planner.m:471-549: for the chosen time intervals the nominal torque sets tau_nom (PZ-RNEA with the nominal
+    parameters), the disturbance w = tau_int - tau_nom against the interval parameters, the Lyapunov-function bound V (PZ-RNEA
+    of the tracking-error set r without gravity), rho_max = || max(|w.inf|, |w.sup|) ||, v_norm = alpha V_diff.sup / ultimate_bound
+    + rho_max, and the two constraint sets per joint
+        u_ub = (tau_nom + v_norm, buffered upwards by its independent part) - u_max  <= 0
+        u_lb = -(tau_nom - v_norm, buffered downwards)                   + u_min  <= 0.
+    Returns {i: dict(tau_nom, v_norm, rho_max, V_sup, u_ub, u_lb)}; the reference's data-dependent pruning is `needed` below."""
+    jrs = create_jrs_online(q0, qd0, qdd0, inertial_params(robot, False)["axes"].T, ultimate_bound=ultimate_bound, k_r=k_r, n_t=n_t,
+                            full=True, time_indices=set(time_indices), **jrs_kw)
+    nom, itv = inertial_params(robot, False, zono_order), inertial_params(robot, True, zono_order)
+    n = nom["n"]
+    lim = np.asarray(torque_limits, dtype=float).reshape(-1)
+    out = {}
+    for i in time_indices:
+        R, R_t, dq, dqa, ddqa = jrs["R"][i], jrs["R_t"][i], jrs["Qd"][i], jrs["Qd_a"][i], jrs["Qdd_a"][i]
+        tau_nom, _, _ = poly_zonotope_rnea(R, R_t, dq, dqa, ddqa, True, nom)
+        v_norm, rho_max, V_sup = 0.0, 0.0, 0.0
+        if use_robust_input:
+            tau_int, _, _ = poly_zonotope_rnea(R, R_t, dq, dqa, ddqa, True, itv)
+            w = [reduce(tau_int[j] - tau_nom[j], zono_order) for j in range(n)]                        # :478-481
+            r = [PZ(0.0, None, [[ultimate_bound]]) for _ in range(n)]                                   # :455-457
+            zero = [PZ(0.0) for _ in range(n)]
+            V_cell, _, _ = poly_zonotope_rnea(R, R_t, zero, zero, r, False, itv)                       # :482
+            V = 0.0
+            for j in range(n):
+                V = reduce(plus(V, times(times(0.5, r[j]), V_cell[j])), zono_order) if isinstance(V, PZ) else reduce(times(times(0.5, r[j]), V_cell[j]), zono_order)
+            V_diff = reduce(V - V, zono_order)                                                          # :488-490
+            V_sup = float(interval(V_diff)[1][0])
+            wl = np.array([interval(w[j])[0][0] for j in range(n)]); wu = np.array([interval(w[j])[1][0] for j in range(n)])
+            rho_max = float(np.linalg.norm(np.maximum(np.abs(wl), np.abs(wu))))                         # :507-512
+            v_norm = alpha_constant * V_sup / ultimate_bound + rho_max                                  # :516
+        u_ub, u_lb = [], []
+        for j in range(n):
+            ub = remove_dependence(tau_nom[j] + v_norm, n)                                              # :531-536
+            lb = remove_dependence(tau_nom[j] - v_norm, n)
+            u_ub.append(_buffered(ub, +1.0) - lim[j])                                                   # :537-540 (limits(2, j) = +u_max)
+            u_lb.append(times(-1.0, _buffered(lb, -1.0)) + (-lim[j]))                                   # limits(1, j) = -u_max
+        out[i] = dict(tau_nom=tau_nom, v_norm=v_norm, rho_max=rho_max, V_sup=V_sup, u_ub=u_ub, u_lb=u_lb)
+    return out
+
+
+def joint_limit_constraints(q0, qd0, qdd0, robot, time_indices, n_t=100, **jrs_kw):
+    """KSI/uarmtd_planner.m:562-576: position / velocity sets buffered by their independent part against the joint limits.
+    (The reference adds the buffer with the same sign on the lower bound, `-1*(c + buf) + lower` -- kept; a continuous joint has
+    limits +-1000 here as in RT/KinovaWithoutGripperInfo.h:76-77, +-inf in the MATLAB agent: never active either way.)"""
+    from .robot_geometry import joint_frames
+    axes = joint_frames(robot)[2]
+    n = len(axes)
+    jrs = create_jrs_online(q0, qd0, qdd0, axes.T, n_t=n_t, full=True, time_indices=set(time_indices), **jrs_kw)
+    out = {}
+    for i in time_indices:
+        row = []
+        for j in range(n):
+            qs, vs = remove_dependence(jrs["Q"][i][j], n), remove_dependence(jrs["Qd"][i][j], n)
+            qb, vb = _buffered(qs, +1.0), _buffered(vs, +1.0)
+            row.append(dict(q_ub=qb - robot.state_limits_ub[j], q_lb=times(-1.0, qb) + robot.state_limits_lb[j],
+                            dq_ub=vb - robot.speed_limits[j], dq_lb=times(-1.0, vb) + (-robot.speed_limits[j])))
+        out[i] = row
+    return out
+
+
+def needed(con):
+    """the reference keeps a constraint only if it can be violated: `~(interval(con).sup < 0)` (KSI/uarmtd_planner.m:628,640,659,...)"""
+    return not (interval(con)[1][0] < 0)
+
+
+def eval_constraint(con, k, n_q):
+    """slice and gradient of a 1-D constraint set at k (KSI/uarmtd_planner.m:632-634): (value, d value / d k [n_q])"""
+    return float(slice_pz(con, k)[0]), grad_slice(con, k, n_q)[:, 0]

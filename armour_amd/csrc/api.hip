@@ -609,14 +609,23 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     HIPCHK(hipSetDevice(h->device));
     const size_t bn = (size_t)h->B * h->n, bm = (size_t)h->B * h->m;
     const P2Tables tb = armour_make_tables(h);
-    if (in_pinned(k, bn * sizeof(double)) && in_pinned(g, bm * sizeof(double)) && in_pinned(jac, bm * h->n * sizeof(double))) {
-        // all buffers page-locked by armour_alloc_pinned: the kernel reads k and writes g / jac in host memory itself
+    // Buffers from armour_alloc_pinned.  Default (mode 0): the copies below run as true asynchronous DMA transfers (k in, g / jac out)
+    // ordered with the launch on the handle's stream -- 2 x 8 m (1 + n) bytes cross PCIe once, in two large transfers.
+    // ARMOUR_PINNED_MODE=1 is the round-2 form: the kernel reads k from and writes g / jac to host memory itself (zero copy).  It
+    // measured 39-43 us per call on some boxes and ~0.9 ms on freshly started ones (BENCH_r02.json, profiles/r03_pinned_probe.txt:
+    // every block's k read and every row tile's stores become individual PCIe transactions whose cost depends on how the host
+    // mapping is set up), and once did not return at all, so it is no longer chosen by default.  Mode 2: only k is read in place.
+    static const int pinned_mode = [] { const char* e = getenv("ARMOUR_PINNED_MODE"); return e ? atoi(e) : 0; }();
+    const bool all_pinned = in_pinned(k, bn * sizeof(double)) && in_pinned(g, bm * sizeof(double)) && in_pinned(jac, bm * h->n * sizeof(double));
+    if (all_pinned && pinned_mode == 1) {
         int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), k, g, jac, h->stream);
         if (rc != ARMOUR_OK) return rc;
         return spin_on_stream(h->stream);
     }
-    HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->d_k, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
+    const double* k_dev = h->d_k;
+    if (all_pinned && pinned_mode == 2) k_dev = k;
+    else HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), k_dev, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
     if (rc != ARMOUR_OK) return rc;
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
