@@ -1134,7 +1134,8 @@ template <bool LEAN>
 __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int J, int O, const double* __restrict__ link_gens,
                                                                const double* __restrict__ obstacles, double* __restrict__ planes,
                                                                double* __restrict__ planes_ll, double* __restrict__ obs_center,
-                                                               unsigned long long* __restrict__ skip_part, const unsigned long long* __restrict__ pre_mask, int store_d) {
+                                                               unsigned long long* __restrict__ skip_part, const unsigned long long* __restrict__ pre_mask,
+                                                               const unsigned long long* __restrict__ live_mask, int store_d) {
     __shared__ unsigned long long Sg[ARMOUR_NPLANES][64];  // [plane][row of the block]: signatures of the normals (18 KB; the normals themselves, 55 KB, held the kernel at two blocks per CU)
     const int Q = J * T * O;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1167,6 +1168,17 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
         default: planes_of_group<3, LEAN>(G, c, in, Q, q, o, lt, J * T, out, ll, Sg, sig, lane, pre, store_d != 0); break;
     }
     if (!skip_part) return;   // (the full table for armour_get_hyperplanes: the masks exist already)
+    // plane_skip[b] is an AND over the problem's rows, so a plane that ONE row needs is settled: armour_p1_plane_sample_kernel ran the
+    // exact test on a few rows of the problem beforehand.  If every plane is either redundant everywhere by class (`pre`) or known
+    // to be needed (`live`) -- always so for box obstacles -- the result is `pre` and this block skips the signature exchange and the
+    // ~800 compares per row of the test; otherwise (wave-uniform) it runs the full test as before.  Identical masks either way.
+    if (LEAN) {
+        const unsigned long long lv = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(live_mask[b] & 0xffffffffull)) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(live_mask[b] >> 32)) << 32);
+        if (((pre | lv) & ((1ull << ARMOUR_NPLANES) - 1ull)) == ((1ull << ARMOUR_NPLANES) - 1ull)) {
+            if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = ~lv;
+            return;
+        }
+    }
     __syncthreads();
     // redundancy of this thread's planes: zero normal, or bit-for-bit +- the normal of an earlier plane of the row
     unsigned long long skip = ~0ull;
@@ -1189,6 +1201,33 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     }
     // (one atomicAnd per wave on the problem's mask cost a seventh of the kernel: 112 k of them on 128 words at B = 128)
     if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = skip;
+}
+
+// The exact redundancy test on `n_samples` rows spread over problem b (one block per problem, lane p = plane p): which planes are NEEDED
+// by at least one of them -- a non-zero normal that no earlier plane of that row repeats up to the sign.  Same normals bit for bit as
+// the planes kernel computes (pair_normal), compared as canonical triples, no hashing.
+__global__ __launch_bounds__(64) void armour_p1_plane_sample_kernel(int T, int J, int O, int n_samples, const double* __restrict__ link_gens,
+                                                                    const double* __restrict__ obstacles, unsigned long long* __restrict__ live_mask) {
+    __shared__ unsigned long long tri[ARMOUR_NPLANES][3];
+    const int Q = J * T * O, b = blockIdx.x, p = threadIdx.x;
+    unsigned long long live = 0ull;
+    for (int sidx = 0; sidx < n_samples; sidx++) {
+        const int q = (int)(((long long)sidx * Q) / n_samples + (sidx * 7) % (O > 0 ? O : 1)) % Q;
+        const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
+        const double* ob = obstacles + ((size_t)b * O + o) * 12;
+        const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
+        unsigned long long cb[3] = {0ull, 0ull, 0ull};
+        if (p < ARMOUR_NPLANES) {
+            canonical_normal_of_plane(ob, lg, p, cb);
+            tri[p][0] = cb[0]; tri[p][1] = cb[1]; tri[p][2] = cb[2];
+        }
+        __syncthreads();
+        bool needed = p < ARMOUR_NPLANES && (cb[0] | cb[1] | cb[2]) != 0ull;
+        for (int e2 = 0; e2 < p && needed; e2++) needed = !(tri[e2][0] == cb[0] && tri[e2][1] == cb[1] && tri[e2][2] == cb[2]);
+        live |= __ballot(needed);
+        __syncthreads();
+    }
+    if (p == 0) live_mask[b] = live;
 }
 
 // Class pre-pass of the lean table: which planes are redundant in EVERY row of a problem by the class of their two generators alone
@@ -1699,16 +1738,17 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int Q = J * T * O;
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
         const int nbx = (Q + 63) / 64, nbc = (Q + 255) / 256;
-        // [B][nbx][4] per-wave masks of the planes kernel | [B][nbc] per-block masks of the class pre-pass | [B] its result
+        // [B][nbx][4] per-wave masks of the planes kernel | [B][nbc] per-block masks of the class pre-pass | [B] its result | [B] planes a sampled row needs
         const size_t part_words = (size_t)B * nbx * 4, pre_words = (size_t)B * nbc;
-        if (part_words + pre_words + (size_t)B > wk->skip_part_cap) {
+        if (part_words + pre_words + 2 * (size_t)B > wk->skip_part_cap) {
             if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
             wk->d_skip_part = nullptr; wk->skip_part_cap = 0;
-            HIPCHK(hipMalloc((void**)&wk->d_skip_part, (part_words + pre_words + (size_t)B) * sizeof(unsigned long long)));
-            wk->skip_part_cap = part_words + pre_words + (size_t)B;
+            HIPCHK(hipMalloc((void**)&wk->d_skip_part, (part_words + pre_words + 2 * (size_t)B) * sizeof(unsigned long long)));
+            wk->skip_part_cap = part_words + pre_words + 2 * (size_t)B;
         }
         unsigned long long* d_pre_part = wk->d_skip_part + part_words;
         unsigned long long* d_pre = d_pre_part + pre_words;
+        unsigned long long* d_live = d_pre + B;
         // The table holds what the fused evaluation reads and nothing else (planes_of_group): ARMOUR_P1_FULL_PLANES=1 (development) builds
         // the full one.  d = A.c is stored for the small batches that read it; batches of >= 8 problems recompute it (armour_make_tables).
         static const int full_env = [] { const char* e = getenv("ARMOUR_P1_FULL_PLANES"); return e ? atoi(e) : 0; }();
@@ -1717,11 +1757,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (lean) {
             hipLaunchKernelGGL(armour_p1_plane_class_kernel, dim3(nbc, B), dim3(256), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part);
             hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, d_pre_part, nbc, d_pre);
+            hipLaunchKernelGGL(armour_p1_plane_sample_kernel, dim3(B), dim3(64), 0, h->stream, T, J, O, 16, wk->d_link_gens, wk->d_obstacles, d_live);
             hipLaunchKernelGGL(armour_p1_planes_kernel<true>, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, d_pre, store_d);
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, d_pre, d_live, store_d);
         } else {
             hipLaunchKernelGGL(armour_p1_planes_kernel<false>, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
-                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, nullptr, 1);
+                               wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, nullptr, nullptr, 1);
         }
         hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, wk->d_skip_part, nbx * 4, h->d_plane_skip);
         h->ll_shared = 1; h->d_from_center = 1;
@@ -1751,7 +1792,7 @@ int armour_p1_full_planes(ArmourPlanner* h, double* d_full) {
     if (!wk || !wk->d_link_gens || !wk->d_obstacles || h->O <= 0) { armour_set_error("no reach sets on the device to rebuild the half-space table from"); return ARMOUR_ESTATE; }
     const int Q = h->J * h->T * h->O, nbx = (Q + 63) / 64;
     hipLaunchKernelGGL(armour_p1_planes_kernel<false>, dim3(nbx, h->B), dim3(256), 0, h->stream, h->B, h->T, h->J, h->O,
-                       wk->d_link_gens, wk->d_obstacles, d_full, nullptr, nullptr, nullptr, nullptr, 1);
+                       wk->d_link_gens, wk->d_obstacles, d_full, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return ARMOUR_OK;
