@@ -1015,6 +1015,12 @@ __device__ inline unsigned long long normal_signature(const unsigned long long (
 }
 __device__ inline unsigned long long skipped_signature(int p) { return 0x7FFFFFFFFFFFFF00ull + (unsigned long long)p; }   // (top bit clear, > 3: equals no normal's signature)
 
+// a 64-bit value every lane holds alike, moved to scalar registers (readfirstlane returns a SIGNED int: widen through unsigned)
+__device__ inline unsigned long long uniform_u64(unsigned long long v) {
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull)) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+}
+
 // the normal of one generator pair exactly as RT/CollisionChecking.cu:176-190 computes it (cross product, norm, three divisions)
 __device__ inline void pair_normal(const double* ga, const double* gb, double& C0, double& C1, double& C2) {
     const double cr0 = ga[1] * gb[2] - ga[2] * gb[1], cr1 = ga[2] * gb[0] - ga[0] * gb[2], cr2 = ga[0] * gb[1] - ga[1] * gb[0];
@@ -1146,7 +1152,7 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     const double* ob = obstacles + ((size_t)b * O + o) * 12;
     const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
     // planes that are redundant in every row of this problem by the class of their generators (wave-uniform)
-    const unsigned long long pre = LEAN ? __builtin_amdgcn_readfirstlane((unsigned)(pre_mask[b] & 0xffffffffull)) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pre_mask[b] >> 32)) << 32) : 0ull;
+    const unsigned long long pre = LEAN ? uniform_u64(pre_mask[b]) : 0ull;
     double G[9][3], c[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     // to be needed (`live`) -- always so for box obstacles -- the result is `pre` and this block skips the signature exchange and the
     // ~800 compares per row of the test; otherwise (wave-uniform) it runs the full test as before.  Identical masks either way.
     if (LEAN) {
-        const unsigned long long lv = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(live_mask[b] & 0xffffffffull)) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(live_mask[b] >> 32)) << 32);
+        const unsigned long long lv = uniform_u64(live_mask[b]);
         if (((pre | lv) & ((1ull << ARMOUR_NPLANES) - 1ull)) == ((1ull << ARMOUR_NPLANES) - 1ull)) {
             if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = ~lv;
             return;

@@ -471,3 +471,64 @@ def test_wave_choreographies_leave_identical_tables(B, settings):
         assert r.returncode == 0 and lines, (env, r.stdout[-1500:] + r.stderr[-1500:])
         digests.append(lines[-1])
     assert len(set(digests)) == 1, list(zip(settings, digests))
+
+
+def _exact_plane_skip(gens, obstacles):
+    """numpy restatement of the row test behind plane_skip (p1_reach.hip planes_redundant): per row the 36 pair normals exactly as
+    RT/CollisionChecking.cu:176-190 computes them (cross product, norm, three divisions -- IEEE operations, the same bits), a plane
+    redundant iff its normal is zero or equals an earlier plane's up to the sign; AND over all rows."""
+    T, J = gens.shape[0], gens.shape[1]
+    pairs = [(a, b) for a in range(9) for b in range(a + 1, 9)]
+    mask = (1 << 36) - 1
+    for ob in np.asarray(obstacles).reshape(-1, 12):
+        for t in range(T):
+            for l in range(J):
+                G = [ob[3 * (g + 1):3 * (g + 1) + 3] for g in range(3)] + [gens[t, l, :, g] for g in range(6)]
+                seen, row = [], 0
+                for p, (a, b) in enumerate(pairs):
+                    ga, gb = G[a], G[b]
+                    cr = np.array([ga[1] * gb[2] - ga[2] * gb[1], ga[2] * gb[0] - ga[0] * gb[2], ga[0] * gb[1] - ga[1] * gb[0]])
+                    nrm = np.sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2])
+                    C = cr / nrm if nrm > 0 else np.zeros(3)
+                    C = np.where(C == 0, 0.0, C)
+                    nz = [x for x in C if x != 0]
+                    key = tuple(-C if (nz and nz[0] < 0) else C)
+                    if not nz or key in seen:
+                        row |= 1 << p
+                    seen.append(key)
+                mask &= row
+    return mask
+
+
+@pytest.mark.gpu
+def test_plane_skip_masks_equal_the_exact_row_test():
+    """The lean half-space table (round 3) derives plane_skip from a class pre-pass plus the exact test on sampled rows, and runs the
+    full signature test only where those leave a plane open.  Whatever the path, the mask must be what the exact row test gives on
+    the device's own link generators: box worlds (12 of 36 planes, every block takes the shortcut), a world with a rotated obstacle
+    (the shortcut still settles it: fewer planes drop out), one with a flat box (a zero generator)."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    T = 20
+    box = random_problem(91, 4)
+    c, s = np.cos(0.4), np.sin(0.4)
+    rot = random_problem(92, 3)
+    Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    rot["obstacles"][1, 3:] = (Rz @ rot["obstacles"][1, 3:].reshape(3, 3).T).T.reshape(-1)      # obstacle 1: generators rotated about z
+    flat = random_problem(93, 3)
+    flat["obstacles"][0, 9:12] = 0.0                                                             # obstacle 0: no extent along z
+    expected_counts = {}
+    for name, p in (("box", box), ("rotated", rot), ("flat", flat)):
+        nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        got = int(nlp.plane_skip()[0])
+        want = _exact_plane_skip(nlp.link_generators()[0], p["obstacles"])
+        assert got == want, (name, hex(got), hex(want))
+        expected_counts[name] = bin(got).count("1")
+        nlp.close()
+    assert expected_counts["box"] == 12 and expected_counts["rotated"] < 12
+    # a batch: one mask per problem, each equal to its single-problem handle's
+    probs = [box, random_problem(94, 4), random_problem(95, 4)]
+    st = {k: np.stack([q[k] for q in probs]) for k in box}
+    nb = ArmourNLP(T=T).set_parameters(st["q0"], st["qd0"], st["qdd0"], st["q_des"], st["obstacles"])
+    for b, q in enumerate(probs):
+        assert int(nb.plane_skip()[b]) == _exact_plane_skip(nb.link_generators()[b], q["obstacles"])
+    nb.close()
