@@ -898,7 +898,7 @@ extern "C" int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, co
 extern "C" int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip) {
     NEED_READY(h);
     if (!plane_skip) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
-    for (int b = 0; b < h->B; b++) plane_skip[b] = (uint64_t)h->h_plane_skip[b];
+    for (int b = 0; b < h->B; b++) plane_skip[b] = (uint64_t)h->h_plane_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull);
     return ARMOUR_OK;
 }
 

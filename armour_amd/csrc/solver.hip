@@ -317,16 +317,29 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     const int B = h->B, n = h->n, m = h->m;
     const P2Tables tb = armour_make_tables(h);
     SolvePlan plan;
-    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, &plan);
+    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, &plan);
     if (rc != ARMOUR_OK) return rc;
-    if (plan.capacity < B) return 0;
-    int nb = std::min(std::min(plan.n_tiles, plan.capacity / B), 1024);
-    // A block walks its tiles one after the other (~4 us each).  With many problems AND many obstacles the blocks per problem are
-    // few and the tiles many: there the host-driven form, whose evaluations are single full-occupancy launches, is the faster
-    // one (measured at B = 128: O = 20, 77 tiles per block: 11 ms against 15 ms; O = 50, 181 tiles per block: 50 ms against 30 ms).
+    if (plan.capacity < 1) return 0;
+    // A block walks its tiles one after the other (~4 us each), so what a phase costs is the tiles PER BLOCK, and the co-resident
+    // grid has to be shared by the problems of a launch.  Round 2 ran the whole batch in one launch and fell back to the host form
+    // where that left a block more than 100 tiles (B = 128 at O = 50: 4 blocks per problem, 159 tiles each, 50 ms against the host
+    // form's 30).  Now such a batch is cut into SUB-BATCHES launched back to back on the handle's stream -- each a persistent
+    // cooperative launch of its own over problems [b0, b0 + Bs) of the same tables, with enough blocks per problem for about
+    // `sub_tiles` tiles per block; iterates and results do not depend on the cut (a problem's blocks see only that problem).
+    static const int sub_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_SUB_TILES"); return e ? std::max(1, atoi(e)) : 24; }();   // development: tiles per block aimed at
     static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
-    if (force_dev < 2 && (plan.n_tiles + nb - 1) / nb > 100) return 0;
+    int Bs = B;
+    if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > 40) {
+        const int nb_want = std::min(plan.n_tiles, (plan.n_tiles + sub_tiles - 1) / sub_tiles);
+        Bs = std::max(1, std::min(B, plan.capacity / std::max(1, nb_want)));
+        if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, &plan)) != ARMOUR_OK) return rc;
+        Bs = std::max(1, std::min(Bs, plan.capacity));
+    }
+    (void)force_dev;
+    int nb = std::min(std::min(plan.n_tiles, plan.capacity / Bs), 1024);
     if (const char* e = getenv("ARMOUR_SOLVE_BLOCKS")) nb = std::max(1, std::min(nb, atoi(e)));  // development / tests
+    if (const char* e = getenv("ARMOUR_SOLVE_SUB_BATCH")) Bs = std::max(1, std::min(Bs, atoi(e)));  // development / tests: force the cut
+    const int n_launch = (B + Bs - 1) / Bs;
     if ((rc = armour_upload_bounds(h)) != ARMOUR_OK) return rc;
     // rows a block owns: at most ceil(n_tiles / nb) tiles of <= 64 rows, two candidates per row
     const int tiles_per_block = (plan.n_tiles + nb - 1) / nb;
@@ -338,7 +351,8 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     // control words, the goals, the argument block (three copies and a fill ahead of the launch cost ~10 us of a 150 us solve)
     const size_t off_qdes = ((size_t)B * sizeof(SolveCtl) + 255) & ~(size_t)255;
     const size_t off_args = (off_qdes + (size_t)B * n * sizeof(double) + 255) & ~(size_t)255;
-    const size_t block_bytes = off_args + sizeof(SolveArgs);
+    const size_t args_stride = (sizeof(SolveArgs) + 255) & ~(size_t)255;
+    const size_t block_bytes = off_args + (size_t)n_launch * args_stride;
     if ((rc = grow_dev(&w.ctl, &w.ctl_cap, block_bytes)) != ARMOUR_OK) return rc;
     // the blocks' flag words: zero before a launch.  Every block clears its own word when it leaves the kernel, so a fill is only
     // needed when the array is new (or grew)
@@ -373,8 +387,8 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     a.t_plan = h->params.t_plan; a.cost_scale = h->params.cost_scale;
     a.torque_slack = h->params.torque_violation_threshold; a.collision_slack = h->params.collision_violation_threshold;
     a.budget_ticks = -1;
-    if (opt.max_wall_time_s > 0) {
-        const double left_ms = (opt.max_wall_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3;
+    if (opt.max_wall_time_s > 0) {   // (sub-batches run one after the other: each gets an equal share of what is left)
+        const double left_ms = (opt.max_wall_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3 / n_launch;
         a.budget_ticks = left_ms > 0 ? (long long)(left_ms * plan.ticks_per_ms) : 0;
     }
     // no wait of the persistent kernel outlasts the budget by more than a second (10 s without a budget: 60 iterations of a large batch
@@ -387,17 +401,19 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
     a.stamps = hstamps;
     const auto t_launch = std::chrono::steady_clock::now();
-    memcpy(hblock + off_args, &a, sizeof(SolveArgs));
-    HIPCHK(hipMemcpyAsync(w.ctl, hblock, block_bytes, hipMemcpyHostToDevice, h->stream));   // (asynchronous from page-locked memory, ordered before the launch)
-    if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(reinterpret_cast<unsigned char*>(w.ctl) + off_args), nb, plan, B, h->stream)) != ARMOUR_OK) return rc;
+    for (int li = 0; li < n_launch; li++) { a.b0 = li * Bs; memcpy(hblock + off_args + (size_t)li * args_stride, &a, sizeof(SolveArgs)); }
+    HIPCHK(hipMemcpyAsync(w.ctl, hblock, block_bytes, hipMemcpyHostToDevice, h->stream));   // (asynchronous from page-locked memory, ordered before the launches)
+    for (int li = 0; li < n_launch; li++)
+        if ((rc = armour_solve_device_launch(reinterpret_cast<const SolveArgs*>(reinterpret_cast<unsigned char*>(w.ctl) + off_args + (size_t)li * args_stride), nb, plan,
+                                             std::min(Bs, B - li * Bs), h->stream)) != ARMOUR_OK) return rc;
     for (unsigned long long polls = 0;; polls++) {  // poll the stream: the whole solve is tens of microseconds, a sleeping wait would dominate it
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { armour_set_error("armour_solve (device form): %s", hipGetErrorString(q)); return ARMOUR_EDEVICE; }
         // the kernel bounds its own waits by hard_s; a stream that is still busy well after that is a device the caller must give up on
         // (recover in a fresh process; never by re-exec of this one)
-        if ((polls & 0xfffull) == 0xfffull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() > 2.0 * hard_s + 5.0) {
-            armour_set_error("armour_solve (device form): the persistent kernel did not finish within %.1f s", 2.0 * hard_s + 5.0);
+        if ((polls & 0xfffull) == 0xfffull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() > n_launch * (2.0 * hard_s + 5.0)) {
+            armour_set_error("armour_solve (device form): the persistent kernel did not finish within %.1f s", n_launch * (2.0 * hard_s + 5.0));
             return ARMOUR_EDEVICE;
         }
     }
@@ -406,7 +422,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         if (hres[b].status < 0) { w.words_clean = 0; return 0; }   // candidate buffers too small for some problem, or a group lost a block: the host form redoes the solve
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (timing) {
-        fprintf(stderr, "[armour_solve, device form] B=%d: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, nb, plan.n_tiles, ms,
+        fprintf(stderr, "[armour_solve, device form] B=%d in %d launch(es) of <= %d problems: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, n_launch, Bs, nb, plan.n_tiles, ms,
                 std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
         for (int i = 0; i < 32 && (i < 2 || hstamps[i]); i++) fprintf(stderr, " %.1f", hstamps[i] / plan.ticks_per_ms * 1e3);
         fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)", hstamps[32] / plan.ticks_per_ms * 1e3,

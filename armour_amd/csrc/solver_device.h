@@ -23,6 +23,8 @@ struct SolveArgs {
     P2Tables tb;
     p2::P2Launch lp;
     int nb, n_tiles;               // blocks per problem; row tiles per problem
+    int b0;                        // first problem of this launch: a batch too large to give every problem enough co-resident blocks runs as
+                                   // several launches back to back, each over problems [b0, b0 + gridDim.x / nb) of the same tables
     int cap_blk, cap_rows;         // candidate rows a block / a problem may hand over
     const double* lo; const double* hi;   // bounds [B][m]
     double* g; double* jac;        // [B][m], [B][m][n]
@@ -56,6 +58,7 @@ struct SolvePlan {
 
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, p2::P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out);
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, SolvePlan* plan);
+// b_launch: problems per launch the occupancy choice is made for (the whole batch, or a sub-batch of it)
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, SolvePlan* plan);
 // d_args: the SolveArgs in device memory (the kernel reads them through the pointer)
 int armour_solve_device_launch(const SolveArgs* d_args, int nb, const SolvePlan& plan, int B, hipStream_t stream);

@@ -713,7 +713,8 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     __shared__ int s_cmd;
     __shared__ double s_x[NV];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / a.nb, jb = blockIdx.x - b * a.nb;
+    const int b_local = blockIdx.x / a.nb, jb = blockIdx.x - b_local * a.nb;
+    const int b = a.b0 + b_local;
     const bool leader = jb == 0;
     const int n = a.tb.n, m = a.tb.m;
     SolveCtl* c = a.ctl + b;
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host side
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, SolvePlan* plan) {
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, SolvePlan* plan) {
     P2Launch lp;
     size_t smem = 0;
     bool dfc, six, exact;
@@ -873,7 +874,7 @@ int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torqu
     const int cap1 = per_cu * prop.multiProcessorCount;
     // (B = 16, O = 20: 16 blocks of 20 tiles per problem in the one-per-CU build: 0.83 ms; 32 blocks of 10 tiles in the other: 1.00 ms -- the
     //  leader's serial QP weighs more than the tiles; at B = 128 it is the other way round: 14.7 against 9.8 ms)
-    const int blocks1 = cap1 / std::max(1, tb.B);
+    const int blocks1 = cap1 / std::max(1, b_launch);
     const bool one = wps_env ? wps_env == 1 : (blocks1 >= 1 && (plan->n_tiles + blocks1 - 1) / blocks1 <= 24);
     const void* fn = one ? fn1 : fn2;
     plan->fn = fn;

@@ -372,8 +372,31 @@ def main():
     p1_dev_ms = nlp.build_ms
 
     n, m = nlp.n, nlp.m
+
+    def sync_probe():
+        # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
+        k1 = np.full((B, n), 0.25)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            nlp.eval_g_jac(k1)
+        sync_us = (time.perf_counter() - t1) / 20 * 1e6
+        nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
+        tt = []
+        for _ in range(50):
+            t1 = time.perf_counter()
+            nlp.eval_g_jac(k1, pinned=True)
+            tt.append((time.perf_counter() - t1) * 1e6)
+        return {"pageable": sync_us, "pinned": statistics.median(tt), "pinned_mean": sum(tt) / len(tt), "pinned_max": max(tt)}
+
+    probe_early = {}
+    if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:   # development: where in this process does the page-locked call get slow?
+        probe_early["after_set_parameters"] = sync_probe()
     tm = Timed(nlp, dev, rank, K, W, use_dist)
+    if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:
+        probe_early["after_graph_built"] = sync_probe()
     wall, ev = tm.run(R)
+    if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:
+        probe_early["after_timed_run"] = sync_probe()
     if not args.no_check and not args.no_sync_probe:
         tm.check()   # finite, and the synchronous host entry reproduces the device entry bit for bit
 
@@ -401,17 +424,9 @@ def main():
             "table_sizes": nlp.table_sizes(),
         }
         if not args.no_sync_probe:
-            # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
-            k1 = tm.ks[0].cpu().numpy()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                nlp.eval_g_jac(k1)
-            sync_us = (time.perf_counter() - t1) / 20 * 1e6
-            nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
-            t1 = time.perf_counter()
-            for _ in range(50):
-                nlp.eval_g_jac(k1, pinned=True)
-            out["sync_host_call_us"] = {"pageable": sync_us, "pinned": (time.perf_counter() - t1) / 50 * 1e6}
+            out["sync_host_call_us"] = sync_probe()
+            if probe_early:
+                out["sync_host_call_us_at"] = probe_early
         if not args.headline_only:
             # extra (never `value`): P points of the same problems per launch, tables held in registers across points
             P = 16

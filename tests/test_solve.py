@@ -84,6 +84,13 @@ def test_device_resident_solve_equals_the_host_driven_one(seed, O, T, B, monkeyp
         for a, c in zip(host, nlp.solve()):
             assert _same_solution(a, c), (blocks, a, c)
     monkeypatch.delenv("ARMOUR_SOLVE_BLOCKS")
+    # a batch cut into sub-batches launched back to back (round 3: what large batches with many obstacles do by themselves)
+    if B > 1:
+        for sub in ("1", "2"):
+            monkeypatch.setenv("ARMOUR_SOLVE_SUB_BATCH", sub)
+            for a, c in zip(host, nlp.solve()):
+                assert _same_solution(a, c), ("sub-batch", sub, a, c)
+        monkeypatch.delenv("ARMOUR_SOLVE_SUB_BATCH")
     # tighter tolerance / more iterations: longer iterate sequences
     for a, c in zip(nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True), nlp.solve(tolerance=1e-7, max_iterations=100)):
         assert _same_solution(a, c), (a, c)
@@ -226,3 +233,23 @@ def test_resident_planner_serves_both_file_protocols(tmp_path, sample_problem):
     fp.write_armour_in(tmp_path / fp.IN_NAME, p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
     assert subprocess.run([exe, str(tmp_path), "128"], capture_output=True, timeout=300).returncode == 0   # no resident planner: runs itself
     assert open(tmp_path / "armour.out").read().split()[:-1] == alone["armour.out"][:-1]
+
+
+def test_large_batches_solve_in_sub_batches_on_the_device():
+    """at B = 128, O = 50 a single persistent launch left every problem 4 blocks of 159 tiles (50 ms) and the
+    solve fell back to the host-driven form (30 ms).  The batch is now cut into sub-batches with ~24 tiles per block; same iterates
+    as the host form for every problem (a sampled third compared here), and the device form is the faster one."""
+    import time
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    T, O, B = 100, 50, 128
+    bp = random_batch(5000, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    nlp.solve(); nlp.solve(host_qp=True)          # (code objects, buffers)
+    t0 = time.perf_counter(); dev = nlp.solve(); t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter(); host = nlp.solve(host_qp=True); t_host = time.perf_counter() - t0
+    for b in range(0, B, 3):
+        assert _same_solution(host[b], dev[b]), (b, host[b], dev[b])
+    print(f"armour_solve B={B} O={O}: device form {t_dev * 1e3:.1f} ms, host form {t_host * 1e3:.1f} ms")
+    assert t_dev <= 1.1 * t_host, (t_dev, t_host)
+    nlp.close()
