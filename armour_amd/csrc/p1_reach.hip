@@ -38,10 +38,6 @@ constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work
 // so three waves can run different operators at the same time without sharing allocator state.
 constexpr int kRoles = 3;
 constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28};  // of the 62 slots of a 3-wave block (run_rnea_free keeps a few joints' states alive)
-// ... and of a 4-wave block (round 3: the forward kinematics, the omega recursion and the constant cross products on a wave of their own,
-// as the time-vectorised kernel's four-wave blocks have had since round 2: p1_tv.inc.h kTvPart4First)
-constexpr int kPart4First[4] = {0, 8, 26, 48}, kPart4Count[4] = {8, 18, 22, 14};
-constexpr int kFkCapKey = 1024, kFkCapRaw = 2048;   // sort buffers of that fourth wave: its products stay below 0.9 k raw terms; the ranked rotation x vector products of omega need room for the permutation only
 constexpr int kRoleN = 2;  // the role that computes (and later frees) the moments N_i (measured with it in role 0 / 1 / 2 and the forward kinematics split off: 2.06 / 2.01 / 1.95 ms)
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
@@ -94,7 +90,7 @@ struct Layout {
 __host__ __device__ inline Layout make_layout(int J, int n, int capW, int nroles) {
     Layout L;
     L.nroles = nroles;
-    L.nV = nroles == 1 ? kNVOneWave : nroles == kRoles ? kPartFirst[kRoles - 1] + kPartCount[kRoles - 1] : kPart4First[3] + kPart4Count[3];
+    L.nV = nroles == 1 ? kNVOneWave : kPartFirst[kRoles - 1] + kPartCount[kRoles - 1];
     L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
     L.nJV = (J + 1) + J;              // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;   // qd, qda, qdda; mass; per role: 4 raw temps
@@ -342,10 +338,9 @@ struct Chain {
 
     int role = 0;  // the role the code being executed belongs to: selects the part of the 3x1 pool allocV() draws from
     __device__ PZ allocV() {
-        const unsigned long long part = L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role]
-                                                                                   : ((1ull << kPart4Count[role]) - 1ull) << kPart4First[role];
+        const unsigned long long part = L.nroles == 1 ? ~0ull : ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role];
         const int i = __ffsll((long long)(freeV & part)) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : kPartFirst[role]); }
         freeV &= ~(1ull << i);
         return V(i);
     }
@@ -892,14 +887,11 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     c.nw = NW;
     c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
-    // waves 0..2: sort buffers of capKey / capRaw entries; wave 3 of a four-wave block: the small ones (kFkCapKey / kFkCapRaw)
-    const bool fk_bufs = NW == 4 && c.wid == 3;
-    const int my_cap_key = fk_bufs ? kFkCapKey : cf.capKey, my_cap_raw = fk_bufs ? kFkCapRaw : cf.capRaw;
     LDS_AS unsigned char* mine = lds + (size_t)c.wid * p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
-    c.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
-    LDS_AS unsigned char* shared = lds + (size_t)(NW == 4 ? 3 : NW) * p1_wave_lds(cf.capKey, cf.capRaw) + (NW == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0);
+    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
+    c.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    LDS_AS unsigned char* shared = lds + (size_t)NW * p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
     c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15) & ~(size_t)15));
@@ -909,8 +901,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     const long long prof_start = clock64();
 #endif
     P1_PIN_ONE_WAVE_PER_SIMD();
-    c.w.cap_raw = my_cap_raw;
-    c.w.cap_key = my_cap_key;
+    c.w.cap_raw = cf.capRaw;
+    c.w.cap_key = cf.capKey;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x & 63;
@@ -1542,12 +1534,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
     if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
-    const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles), L4 = make_layout(J, n, h->lim.work_monomials, 4);
-    if (L4.idJS + L4.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
+    const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles);
+    if (L3.idJS + L3.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
     auto ci_doubles = [&](const Layout& L) { return (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3; };
-    auto lds_bytes = [&](int cap, int nw = 1) {
-        return (size_t)(nw == 4 ? 3 : nw) * p1_wave_lds(cap, cap) + (nw == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : nw == kRoles ? L3 : L4));
-    };
+    auto lds_bytes = [&](int cap, int nw = 1) { return (size_t)nw * p1_wave_lds(cap, cap) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : L3)); };
     static const int max_waves_env = [] { const char* e = getenv("ARMOUR_P1_MAX_WAVES_PER_CU"); return e ? atoi(e) : 4 * P1_WAVES_PER_SIMD; }();  // development override
     auto waves_per_cu = [&](int cap) { return std::max(1, std::min(max_waves_env, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };
     float total_ms = 0;
@@ -1558,19 +1548,13 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
         static const int nw_env = [] { const char* e = getenv("ARMOUR_P1_WAVES"); return e ? atoi(e) : 0; }();  // development override
-        // (round 3) ... FOUR waves when the block's LDS holds the fourth wave's small sort buffers as well: the forward kinematics,
-        // the omega recursion and the constant cross products of the linear acceleration leave the three recursion waves for a wave
-        // of their own (run_rnea_free, the choreography of the time-vectorised kernel's four-wave blocks) and no item is issued twice
-        const bool multi = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
-                           : nw_env ? nw_env >= 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
-        static const int free_env0 = [] { const char* e = getenv("ARMOUR_P1_FREE"); return e ? atoi(e) : 1; }();
-        const bool four = multi && free_env0 && (nw_env ? nw_env == 4 : lds_bytes(cap, 4) <= (size_t)160 * 1024);
-        const bool three = multi && !four;
-        const int nw = four ? 4 : three ? kRoles : 1;
-        const Layout& L = four ? L4 : three ? L3 : L1;
+        const bool three = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
+                           : nw_env ? nw_env == 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
+        const int nw = three ? kRoles : 1;
+        const Layout& L = three ? L3 : L1;
         const size_t smem = lds_bytes(cap, nw);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
-        const int per_cu = multi ? 1 : waves_per_cu(cap);
+        const int per_cu = three ? 1 : waves_per_cu(cap);
         // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
         static const int split_env = [] { const char* e = getenv("ARMOUR_P1_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
         const bool split = split_env >= 0 ? (split_env != 0 && three) : (three && 2 * n_items <= prop.multiProcessorCount);
@@ -1604,11 +1588,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
         {
             std::lock_guard<std::mutex> lk(g_p1_launch_mu);
-            if (four) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            else if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            if (four) hipLaunchKernelGGL(armour_p1_chain_kernel<4>, dim3(waves), dim3(WAVE * 4), smem, h->stream, cf);
-            else if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
+            if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
             else hipLaunchKernelGGL(armour_p1_chain_kernel<1>, dim3(waves), dim3(WAVE), smem, h->stream, cf);
             HIPCHK(hipGetLastError());
         }
