@@ -1209,31 +1209,48 @@ __global__ __launch_bounds__(256) void armour_p1_planes_kernel(int B, int T, int
     if (lane == 0) skip_part[((size_t)b * gridDim.x + blockIdx.x) * 4 + grp] = skip;
 }
 
-// The exact redundancy test on `n_samples` rows spread over problem b (one block per problem, lane p = plane p): which planes are NEEDED
-// by at least one of them -- a non-zero normal that no earlier plane of that row repeats up to the sign.  Same normals bit for bit as
-// the planes kernel computes (pair_normal), compared as canonical triples, no hashing.
-__global__ __launch_bounds__(64) void armour_p1_plane_sample_kernel(int T, int J, int O, int n_samples, const double* __restrict__ link_gens,
-                                                                    const double* __restrict__ obstacles, unsigned long long* __restrict__ live_mask) {
-    __shared__ unsigned long long tri[ARMOUR_NPLANES][3];
-    const int Q = J * T * O, b = blockIdx.x, p = threadIdx.x;
-    unsigned long long live = 0ull;
-    for (int sidx = 0; sidx < n_samples; sidx++) {
-        const int q = (int)(((long long)sidx * Q) / n_samples + (sidx * 7) % (O > 0 ? O : 1)) % Q;
+// The exact redundancy test on sampled rows of problem b -- one block per problem, wave s takes sample s, lane p = plane p -- gives the
+// planes NEEDED by at least one of them (a non-zero normal that no earlier plane of that row repeats up to the sign): same normals bit
+// for bit as the planes kernel computes (pair_normal), compared as canonical triples, no hashing.  The same block ANDs the class
+// pre-pass's per-block words of the problem into pre_mask[b] (one launch less in front of the planes kernel).
+constexpr int kPlaneSamples = 16;
+__global__ __launch_bounds__(64 * kPlaneSamples) void armour_p1_plane_sample_kernel(int T, int J, int O, const double* __restrict__ link_gens,
+                                                                                    const double* __restrict__ obstacles, const unsigned long long* __restrict__ pre_part, int n_part,
+                                                                                    unsigned long long* __restrict__ pre_mask, unsigned long long* __restrict__ live_mask) {
+    __shared__ unsigned long long tri[kPlaneSamples][ARMOUR_NPLANES][3];
+    __shared__ unsigned long long s_live[kPlaneSamples], s_pre[kPlaneSamples];
+    const int Q = J * T * O, b = blockIdx.x, p = threadIdx.x & 63, sidx = threadIdx.x >> 6;
+    {
+        const int q = (int)(((long long)sidx * Q) / kPlaneSamples + (sidx * 7) % O) % Q;
         const int o = q % O, lt = q / O, l = lt / T, t = lt - l * T;
         const double* ob = obstacles + ((size_t)b * O + o) * 12;
         const double* lg = link_gens + (((size_t)b * T + t) * J + l) * 18;
         unsigned long long cb[3] = {0ull, 0ull, 0ull};
         if (p < ARMOUR_NPLANES) {
             canonical_normal_of_plane(ob, lg, p, cb);
-            tri[p][0] = cb[0]; tri[p][1] = cb[1]; tri[p][2] = cb[2];
+            tri[sidx][p][0] = cb[0]; tri[sidx][p][1] = cb[1]; tri[sidx][p][2] = cb[2];
         }
         __syncthreads();
         bool needed = p < ARMOUR_NPLANES && (cb[0] | cb[1] | cb[2]) != 0ull;
-        for (int e2 = 0; e2 < p && needed; e2++) needed = !(tri[e2][0] == cb[0] && tri[e2][1] == cb[1] && tri[e2][2] == cb[2]);
-        live |= __ballot(needed);
-        __syncthreads();
+        for (int e2 = 0; e2 < p && needed; e2++) needed = !(tri[sidx][e2][0] == cb[0] && tri[sidx][e2][1] == cb[1] && tri[sidx][e2][2] == cb[2]);
+        const unsigned long long live = __ballot(needed);
+        // the class pre-pass's words of this problem, ANDed by all threads of the block
+        unsigned long long m = ~0ull;
+        for (int i = threadIdx.x; i < n_part; i += blockDim.x) m &= pre_part[(size_t)b * n_part + i];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)m, o2, 64), hi = __shfl_xor((unsigned)(m >> 32), o2, 64);
+            m &= ((unsigned long long)hi << 32) | lo;
+        }
+        if (p == 0) { s_live[sidx] = live; s_pre[sidx] = m; }
     }
-    if (p == 0) live_mask[b] = live;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long live = 0ull, pre = ~0ull;
+        for (int i = 0; i < kPlaneSamples; i++) { live |= s_live[i]; pre &= s_pre[i]; }
+        live_mask[b] = live;
+        pre_mask[b] = pre;
+    }
 }
 
 // Class pre-pass of the lean table: which planes are redundant in EVERY row of a problem by the class of their two generators alone
@@ -1762,8 +1779,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int store_d = B >= 8 ? 0 : 1;
         if (lean) {
             hipLaunchKernelGGL(armour_p1_plane_class_kernel, dim3(nbc, B), dim3(256), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part);
-            hipLaunchKernelGGL(armour_p1_skip_reduce_kernel, dim3(B), dim3(256), 0, h->stream, d_pre_part, nbc, d_pre);
-            hipLaunchKernelGGL(armour_p1_plane_sample_kernel, dim3(B), dim3(64), 0, h->stream, T, J, O, 16, wk->d_link_gens, wk->d_obstacles, d_live);
+            hipLaunchKernelGGL(armour_p1_plane_sample_kernel, dim3(B), dim3(64 * kPlaneSamples), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part, nbc, d_pre, d_live);
             hipLaunchKernelGGL(armour_p1_planes_kernel<true>, dim3(nbx, B), dim3(256), 0, h->stream, B, T, J, O,
                                wk->d_link_gens, wk->d_obstacles, h->d_planes, h->d_planes_ll, h->d_obs_center, wk->d_skip_part, d_pre, d_live, store_d);
         } else {

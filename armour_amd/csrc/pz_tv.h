@@ -172,6 +172,10 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
         const uint64_t key_v = p < N ? keyat(p) : 0ull;
         const int idx_v = p < N ? idxat(p) : 0;
         const int n = min(WAVE, N - base);
+        // what a term's loads need -- which source, where its rows start -- is worked out for the chunk's 64 terms at once, one term per
+        // lane on the vector unit, and the serial loop below picks a term's descriptor out with a few v_readlane instead of redoing
+        // the source selection with scalar selects per term (measured on lincomb<3, 4>: 35 of the ~110 instructions per raw term)
+        const typename P::Desc dv = pol.describe(idx_v);
 #ifdef TV_PROFILE_FULL
         { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[2] += x - wp0; wp0 = x; }
 #endif
@@ -180,7 +184,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int l = min(l0 + u, n - 1);
-                pol.load(__builtin_amdgcn_readlane(idx_v, l), regs[u]);
+                pol.load(dv, l, __builtin_amdgcn_readlane(idx_v, l), regs[u]);
             }
 #ifdef TV_PROFILE_FULL
             { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) { g_tvprof[0] += x - wp0; g_tvprof[3] += 1; } wp0 = x; }
@@ -240,6 +244,9 @@ struct MulCtx {
     struct Regs { double ca[STAGE == 1 ? 1 : SH::ASZ], cb[STAGE == 2 ? 1 : SH::BSZ]; int i, j; };
     static constexpr int kRegDoubles = (STAGE == 1 ? 0 : SH::ASZ) + (STAGE == 2 ? 0 : SH::BSZ);
     static constexpr int kU = kRegDoubles <= 3 ? 16 : kRegDoubles <= 6 ? 8 : kRegDoubles <= 9 ? 6 : 4;  // terms whose row loads are in flight together
+    struct Desc {};
+    __device__ inline Desc describe(int) const { return Desc{}; }
+    __device__ inline void load(const Desc&, int, int idx, Regs& r) const { load(idx, r); }
     __device__ inline void load(int idx, Regs& r) const {
         const int t = idx + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
@@ -419,6 +426,9 @@ struct CrossCtx {
     double acc[6], rad[12];  // radii: 6 products | 3 differences | 3 stack
     struct Regs { double ca[STAGE == 1 ? 1 : 3], cb[STAGE == 2 ? 1 : 3]; int i, j; };
     static constexpr int kU = STAGE == 0 ? 8 : 16;
+    struct Desc {};
+    __device__ inline Desc describe(int) const { return Desc{}; }
+    __device__ inline void load(const Desc&, int, int idx, Regs& r) const { load(idx, r); }
     __device__ inline void load(int idx, Regs& r) const {
         const int t = idx + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
@@ -579,43 +589,51 @@ struct LinCtx {
     double acc[SZ], ra[NS][SZ];
     bool present;   // per lane
     int last;       // source of the run's latest member (wave-uniform)
-    struct Regs { double x[SZ]; int idx; };  // (the source of a term is re-derived from idx where needed: sixteen terms' worth of
-                                             //  scale / component / source scalars do not fit the scalar registers)
+    struct Regs { double x[SZ]; int k; };   // k: the term's source (wave-uniform)
     __device__ inline int seg_of(int idx) const {
         int k = 0;
 #pragma unroll
         for (int i = 1; i < NS; i++) k += (idx >= off[i]) ? 1 : 0;
         return k;
     }
-    // Only the loads: what is loaded must not be touched here, or the wave would wait for it before issuing the next term's
-    // loads.  The source is picked with scalar selects (idx and everything derived from it is wave-uniform).
-    // (row0[k] = address of source k's row of raw term 0 in THIS lane, i.e. coef + (off - first * stride) rows, set by prepare():
-    //  a raw term's rows are then row0 + idx * stride rows -- three selects per source instead of five and no subtraction; a
-    //  1x1 source loads its one row SZ times rather than branching, term() reads x[0] only)
+    // row0[k] = address of source k's row of raw term 0 WITHOUT the lane offset, i.e. coef + (off - first * stride) rows, set by prepare():
+    // a raw term's rows then start at row0 + idx * stride rows.  A 1x1 source loads its one row SZ times rather than branching (term()
+    // reads x[0] only).
     const GLB_AS double* row0[NS];
     __device__ inline void prepare() {
 #pragma unroll
-        for (int k = 0; k < NS; k++) row0[k] = s[k].v.coef + ((ptrdiff_t)s[k].v.off - (ptrdiff_t)off[k] * s[k].v.stride) * WAVE + lane;
+        for (int k = 0; k < NS; k++) row0[k] = s[k].v.coef + ((ptrdiff_t)s[k].v.off - (ptrdiff_t)off[k] * s[k].v.stride) * WAVE;
     }
-    __device__ inline void load(int idx, Regs& r) const {
-        const int k = seg_of(idx);
+    // per-lane descriptors of the chunk's terms (lane l describes the chunk's l-th term): source, byte address of its first row, row step
+    struct Desc { int k; unsigned lo, hi; int step; };
+    __device__ inline Desc describe(int idx_lane) const {
+        Desc d;
+        d.k = seg_of(idx_lane);
         const GLB_AS double* base = row0[0];
         int stride = s[0].v.stride, comp = s[0].comp;
 #pragma unroll
         for (int q = 1; q < NS; q++) {
-            const bool me = (k == q);
+            const bool me = (d.k == q);
             base = me ? row0[q] : base;
             stride = me ? s[q].v.stride : stride; comp = me ? s[q].comp : comp;
         }
-        r.idx = idx;
-        const GLB_AS double* src = base + (ptrdiff_t)idx * stride * WAVE;
-        const int step = comp < 0 ? WAVE : 0;
+        const uint64_t a = (uint64_t)(base + (ptrdiff_t)idx_lane * stride * WAVE);
+        d.lo = (unsigned)a; d.hi = (unsigned)(a >> 32);
+        d.step = comp < 0 ? WAVE : 0;
+        return d;
+    }
+    // Only the loads: what is loaded must not be touched here, or the wave would wait for it before issuing the next term's loads.
+    __device__ inline void load(const Desc& d, int l, int, Regs& r) const {
+        r.k = __builtin_amdgcn_readlane(d.k, l);
+        const uint64_t a = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.hi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.lo, l);
+        const int step = __builtin_amdgcn_readlane(d.step, l);
+        const GLB_AS double* src = (const GLB_AS double*)a + lane;
 #pragma unroll
         for (int e = 0; e < SZ; e++) r.x[e] = src[e * step];
     }
-    // scale * embed(source entry); returns the source index
-    __device__ inline int term(const Regs& r, double* c) const {
-        const int k = seg_of(r.idx);
+    // scale * embed(source entry)
+    __device__ inline void term(const Regs& r, double* c) const {
+        const int k = r.k;
         int comp = s[0].comp;
         double scale = s[0].scale;
 #pragma unroll
@@ -628,9 +646,7 @@ struct LinCtx {
 #pragma unroll
             for (int e = 0; e < SZ; e++) c[e] = (e == comp) ? x : 0.0;
         }
-        return k;
     }
-    // simplify() of stage k (k >= 1) on what has been accumulated so far (selects: see verdict())
     __device__ inline bool is_small() const {
         if constexpr (SZ == 1) return fabs(acc[0]) <= thr;
         else {
@@ -640,45 +656,45 @@ struct LinCtx {
             return q <= thr_sq;
         }
     }
-    // stage k if `run` (wave-uniform), as selects: no branch, no merge block behind it
-    __device__ inline void stage_if(int k, bool run) {
-        const bool drop = run && present && is_small();
-#pragma unroll
-        for (int e = 0; e < SZ; e++) ra[k][e] += drop ? fabs(acc[e]) : 0.0;
-        present = present && !drop;
-    }
-    __device__ inline void stage(int k) {
+    // simplify() of stage k (1 <= k < NS, wave-uniform) on what has been accumulated so far: a lane whose sum is small drops it into that
+    // stage's radius (selects, not branches on the per-lane verdict; the stage index is wave-uniform and picks the radius registers)
+    __device__ inline void stage_at(int k) {
         const bool drop = present && is_small();
+        double v[SZ];
+#pragma unroll
+        for (int e = 0; e < SZ; e++) v[e] = drop ? fabs(acc[e]) : 0.0;
 #pragma unroll
         for (int kk = 1; kk < NS; kk++)
             if (kk == k) {
 #pragma unroll
-                for (int e = 0; e < SZ; e++) ra[kk][e] += drop ? fabs(acc[e]) : 0.0;
+                for (int e = 0; e < SZ; e++) ra[kk][e] += v[e];
             }
         present = present && !drop;
     }
+    // The composed simplify() stages of a run of equal keys (pz_wave.h lincomb_chain): after source k (k >= 1) has been added -- or found
+    // absent -- what is accumulated is tested.  Between two tests without a new member the sum does not change, so of the stages
+    // (last, rk) that have no member of this key only the FIRST can prune (a sum it keeps passes the later ones unchanged, a sum it
+    // drops is gone): one evaluation where the first version of this walk did NS - 1, identical results.
     __device__ inline void add(const Regs& r, bool first) {
-        present = first ? false : present;   // (selects on the wave-uniform `first`: see MulCtx::add)
-        last = first ? -1 : last;
         double c[SZ];
-        const int rk = term(r, c);
+        term(r, c);
+        const int rk = r.k;
         if constexpr (CHAIN) {
-#pragma unroll
-            for (int k = 1; k < NS; k++) stage_if(k, k > last && k < rk);  // stages without a member of this key
+            const int kf = last + 1 > 1 ? last + 1 : 1;
+            if (!first && kf < rk) stage_at(kf);   // (wave-uniform condition; `first`: nothing accumulated yet)
         }
 #pragma unroll
-        for (int e = 0; e < SZ; e++) acc[e] = present ? acc[e] + c[e] : c[e];
+        for (int e = 0; e < SZ; e++) acc[e] = (present && !first) ? acc[e] + c[e] : c[e];
         present = true;
         if constexpr (CHAIN) {
-#pragma unroll
-            for (int k = 1; k < NS; k++) stage_if(k, k == rk);
+            if (rk >= 1) stage_at(rk);
         }
         last = rk;
     }
     __device__ inline void close(uint64_t key) {
         if constexpr (CHAIN) {
-#pragma unroll
-            for (int k = 1; k < NS; k++) stage_if(k, k > last);
+            const int kf = last + 1 > 1 ? last + 1 : 1;
+            if (kf < NS) stage_at(kf);
         } else {
             // one simplify() at the end: pruned terms go to ra[0]
             const bool drop = present && is_small();
