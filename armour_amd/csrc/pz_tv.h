@@ -664,11 +664,11 @@ struct LinCtx {
 #pragma unroll
         for (int e = 0; e < SZ; e++) v[e] = drop ? fabs(acc[e]) : 0.0;
 #pragma unroll
-        for (int kk = 1; kk < NS; kk++)
-            if (kk == k) {
+        for (int kk = 1; kk < NS; kk++) {
+            const bool me = (kk == k);
 #pragma unroll
-                for (int e = 0; e < SZ; e++) ra[kk][e] += v[e];
-            }
+            for (int e = 0; e < SZ; e++) ra[kk][e] += me ? v[e] : 0.0;
+        }
         present = present && !drop;
     }
     // The composed simplify() stages of a run of equal keys (pz_wave.h lincomb_chain): after source k (k >= 1) has been added -- or found
