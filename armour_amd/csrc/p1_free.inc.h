@@ -17,7 +17,30 @@
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
        T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS,
        T3_CNT = T3_X2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
-constexpr int kMbWords = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;  // LDS mailbox of run_rnea / run_rnea_free
+// LDS mailbox of run_rnea / run_rnea_free, followed by the two walk-helper channels of the time-vectorised four-wave blocks
+// (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
+constexpr int kHelpBase = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;
+constexpr int kMbWords = kHelpBase + 2 * tv::HJ_WORDS;
+// an operator of `c`'s wave that shares its walk with the helper wave on channel k (chains without walk helpers: plain call)
+template <class CH, class Fn>
+__device__ inline auto with_walk_helper(CH& c, int k, bool on, Fn fn) {
+    if constexpr (CH::kWalkHelpers) {
+        c.w.hch = on ? c.mb + kHelpBase + k * tv::HJ_WORDS : nullptr;
+        auto r = fn();
+        c.w.hch = nullptr;
+        return r;
+    } else return fn();
+}
+// (`tmp`: a scratch slot the helper keeps for the whole pass -- the primary reads the partial sums in its header rows after the
+//  hand-back, so it must not be given to another operator of the helper wave in between)
+template <class CH>
+__device__ inline void serve_walk_helper(CH& c, int k, const typename CH::PZT& tmp) {
+    if constexpr (CH::kWalkHelpers) {
+        c.w.hch = c.mb + kHelpBase + k * tv::HJ_WORDS;
+        tv::serve_walk(c.w, tmp);
+        c.w.hch = nullptr;
+    }
+}
 __device__ inline int t3_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <class CH>
 __device__ inline bool w_lane0(const CH& c) { return c.wave().lane == 0; }
@@ -60,6 +83,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // (at most K + 1 of them: the states the tail reads must still be alive when the recursion ends -- it gives state k back K joints later)
     const int n_tail = J >= 5 ? 4 : J >= 4 ? 3 : 0;   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
+    // walk helpers (four-wave blocks of the time-vectorised kernel, backward pass): both channels start empty, every wave's job count at 0
+    const bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
+    if constexpr (CH::kWalkHelpers) {
+        if (threadIdx.x < 2 * tv::HJ_WORDS) c.mb[kHelpBase + threadIdx.x] = 0;
+        c.w.hseq = 0; c.w.hch = nullptr; c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16;
+    }
     if (c.wid == 1) {
         c.role = 1;
         TPZ wdot = c.allocV(), waux = c.allocV();
@@ -247,10 +276,10 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         set_const(w, f, nullptr, nullptr);
         for (int i = J - 1; i >= 0; i--) {
             const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i);
-            TPZ a2 = c.mulMV(Rn, f);
+            TPZ a2 = with_walk_helper(c, 0, walk_helpers, [&] { return c.mulMV(Rn, f); });
             t3_post(c, T3_A2 + i, a2);
             t3_signal(c, T3_B1, J - i);
-            TPZ f2 = c.add(a2, Fi); c.freeVs(f);
+            TPZ f2 = with_walk_helper(c, 0, walk_helpers, [&] { return c.add(a2, Fi); }); c.freeVs(f);
             f = f2;
         }
         c.freeVs(f);
@@ -263,11 +292,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         set_const(w, nn, nullptr, nullptr);
         for (int i = J - 1; i >= 0; i--) {
             const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
-            TPZ a1 = c.mulMV(Rn, nn);
+            TPZ a1 = with_walk_helper(c, 1, walk_helpers, [&] { return c.mulMV(Rn, nn); });
             TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
             t3_wait(c, T3_B2, J - i);
             const TPZ c2 = t3_take(c, T3_C2 + i);
-            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
+            TPZ n2 = with_walk_helper(c, 1, walk_helpers, [&] { return c.sum4(Ni, a1, c1, c2); }); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
             nn = n2;
             if (cf.rb.axes[i] != 0) {
                 const int ax = abs(cf.rb.axes[i]) - 1;
@@ -280,17 +309,26 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     }
     if (c.wid == helper) {
         c.role = helper;
+        TPZ htmp = c.allocV();
         for (int i = J - 1; i >= 0; i--) {
+            if (walk_helpers) serve_walk_helper(c, 1, htmp);   // R n of joint i
             t3_wait(c, T3_B1, J - i);
             TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
             t3_post(c, T3_C2 + i, c2);
             t3_signal(c, T3_B2, J - i);
+            if (walk_helpers) serve_walk_helper(c, 1, htmp);   // the four-term sum of joint i
         }
+        c.freeVs(htmp);
         c.bar();   // (B) wave 0 has read every p x (R f)
         for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
         if (helper == 2) { for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); } }
     } else if (c.wid == 2) {   // (four waves: wave 3 is the helper)
         c.role = 2;
+        if (walk_helpers) {   // this wave has nothing of its own in the backward pass: it walks half of the f-recursion's R f and R f + F
+            TPZ htmp = c.allocV();
+            for (int i = J - 1; i >= 0; i--) { serve_walk_helper(c, 0, htmp); serve_walk_helper(c, 0, htmp); }
+            c.freeVs(htmp);
+        }
         c.bar();   // (B) both recursions are through: nobody reads N_i, F_i any more
         for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
     }

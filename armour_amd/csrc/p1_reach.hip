@@ -75,6 +75,7 @@ struct P1Cfg {
     int tv_free_running;  // three-wave blocks: run_rnea_free (progress counters) instead of run_rnea (a barrier per joint)
     int free_running;     // the same choice for the per-step kernel's three-wave blocks
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
+    int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -280,6 +281,7 @@ __device__ inline void rpy_matrix(double roll, double pitch, double yaw, double*
 // ------------------------------------------------------------------ per-wave state and slot pools
 struct Chain {
     typedef PZ PZT;
+    static constexpr bool kWalkHelpers = false;   // (the time-vectorised chain has them: p1_tv.inc.h)
     Wave w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -1711,6 +1713,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
+            static const int tv_help_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELPERS"); return e ? atoi(e) : 1; }();  // development switch: 0 = every walk on its own wave
+            cf.tv_walk_helpers = tv_help_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {

@@ -56,6 +56,7 @@ __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index
 // The same interface as Chain above (run_rnea / fk_step are templates on it): roles, mailbox, slot pools, composite operators.
 struct TChain {
     typedef TPZ PZT;
+    static constexpr bool kWalkHelpers = true;   // pz_tv.h "One walk on two waves"; used by run_rnea_free in four-wave blocks
     TW w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
         c.w.c_wait = c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
+        c.w.c_hwait = c.w.n_shared = c.w.n_shared_terms = 0;
         for (int q = 0; q < 3; q++) { c.w.c_type[q] = 0; c.w.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane, fk_only);
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
 #ifdef TV_PROFILE_FULL
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
 #endif
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] shared walks: %lld jobs, %lld raw terms; waited %lld cycles on the helper channel\n", it, c.wid, c.w.n_shared, c.w.n_shared_terms, c.w.c_hwait);
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld, %lld of it in the forward pass; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_wait_fwd, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif
     }

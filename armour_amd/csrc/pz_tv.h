@@ -53,8 +53,12 @@ struct TW {
     bool active;   // this lane's time step exists (t < T)
     LDS_AS double* stage;  // LDS staging area for the rows of a product's SHORT operand (stage_rows below)
     int stage_rows;        // its capacity in rows of 64 doubles
+    // walk helper (below, "One walk on two waves"): the channel to a wave that has nothing of its own to do right now, or nullptr
+    LDS_AS int* hch = nullptr;
+    int hseq = 0;          // jobs posted (primary) / served (helper) on that channel so far
+    int hnum = 16;         // the primary keeps hnum / 32 of a shared walk's terms
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
-    long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0;
+    long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0, c_hwait = 0, n_shared = 0, n_shared_terms = 0;
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
 #endif
 };
@@ -69,6 +73,33 @@ struct TW {
 #endif
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One walk on two waves.  The serial walk over the sorted raw terms is what an operator costs (the sort is 5 %), and in the
+// backward pass of the RNEA two of a block's four waves have nothing to do while the f- and the n-recursion -- one product and
+// one sum per joint each, strictly one after the other -- are what the pass takes.  There the wave that owns an operator (the
+// PRIMARY) sorts as before, then hands the upper part [S, N) of the sorted terms to an idle HELPER wave through a channel of words
+// in LDS and walks [0, S) itself.  S sits on a boundary between runs of equal keys, so no sum crosses it.  The helper walks its part
+// with the same code on the primary's sorted arrays (and staged rows) in LDS, emits into a scratch slot of its own, and -- once the
+// primary has posted how many terms IT kept -- moves its rows down behind them in the result; the primary then adds the helper's
+// partial sums of the pruned amounts (and of |coefficient|) to its own.  Keys, coefficients and centres are exactly those of the
+// one-wave walk; the radii add the same numbers as two partial sums instead of one running sum (<= 1e-12, the tolerance the
+// time-vectorised build already states against the per-step one).
+enum { HJ_SEQ = 0, HJ_WALKED, HJ_N0SEQ, HJ_DONE,           // progress words (sequence numbers)
+       HJ_KIND, HJ_S, HJ_N, HJ_INDIRECT, HJ_N0, HJ_NH,
+       HJ_SKEY, HJ_SIDX, HJ_STAGE,                          // the primary's LDS buffers (addresses)
+       HJ_OUT_KEYS, HJ_OUT_COEF = HJ_OUT_KEYS + 2, HJ_OUT_CAP = HJ_OUT_COEF + 2,
+       HJ_HDR = HJ_OUT_CAP + 1,                             // the helper's scratch slot: header rows (partial sums) and coefficient rows, written by the helper
+       HJ_TMP_COEF = HJ_HDR + 2,
+       HJ_SEG0 = 24, HJ_SEG_WORDS = 8,                      // per source: coef address (2), cnt, stride, off, comp, scale (2)
+       HJ_WORDS = HJ_SEG0 + 4 * HJ_SEG_WORDS };
+enum { HK_NONE = 0, HK_MUL_3331_A_STAGED = 1, HK_LIN2 = 2, HK_LIN4_CHAIN = 3 };
+constexpr int kHelperMinTerms = 192;   // below this a walk is not worth two hand-overs
+
+__device__ inline int lds_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void lds_st_ptr(LDS_AS int* p, const GLB_AS void* q) { const uint64_t v = (uint64_t)q; p[0] = (int)(unsigned)v; p[1] = (int)(unsigned)(v >> 32); }
+template <class T>
+__device__ inline T* lds_ld_ptr(LDS_AS int* p) { return (T*)(((uint64_t)(unsigned)p[1] << 32) | (unsigned)p[0]); }
 // a pointer every lane holds alike, moved to scalar registers: row addresses are then scalar arithmetic plus a lane offset
 template <class T>
 __device__ inline T* uni_ptr(T* p) {
@@ -157,14 +188,14 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
 __device__ long long g_tvprof[8];  // [0] load phase, [1] process phase, [2] chunk prologue, [3] batches
 #endif
 template <int U, class P, class KeyAt, class IdxAt>
-__device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const IdxAt& idxat, P& pol) {
+__device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const IdxAt& idxat, P& pol, int N0_ = 0) {
     // N arrives from the sorter as a value the compiler must assume differs between lanes; as a loop bound it would put the
     // whole walk under divergent control flow (every wave-uniform variable in it becomes a vector register with exec-mask
     // bookkeeping around each update: measured 230 instructions per raw term).  One readfirstlane makes the walk scalar.
-    const int N = uni(N_);
+    const int N = uni(N_), N0 = uni(N0_);   // the sorted terms [N0, N): a part of a walk shared with a helper wave starts at N0 > 0
     bool have = false;
     uint64_t cur = 0;
-    for (int base = 0; base < N; base += WAVE) {
+    for (int base = N0; base < N; base += WAVE) {
 #ifdef TV_PROFILE_FULL
         long long wp0 = clock64();
 #endif
@@ -317,16 +348,102 @@ __device__ inline void mul_ctx_init(MulCtx<SH, STAGE>& cx, const TW& t, const TV
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) { cx.acc[e] = 0.0; cx.rad[e] = 0.0; }
 }
+// (sw: the wave whose LDS buffers hold the sorted terms -- this wave's own, or the primary's when a helper walks a part of them;
+//  the sorted terms [N0, N))
 template <class SH, int STAGE>
-__device__ inline void mul_walk(TW& t, int N, bool indirect, const pzw::MulEval<SH>& ev, const TView& a, const TView& b, Out<SH::SZ>* o, double* rad) {
+__device__ inline void mul_walk(TW& t, const Wave& sw, const LDS_AS double* stage, int N0, int N, bool indirect, const pzw::MulEval<SH>& ev, const TView& a, const TView& b,
+                                Out<SH::SZ>* o, double* rad) {
     MulCtx<SH, STAGE> cx;
     mul_ctx_init(cx, t, a, b, o);
-    const Wave& w = t.w;
-    const int lane = w.lane;
-    if (indirect) walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    cx.stage = stage;
+    const Wave& w = sw;
+    const int lane = t.w.lane;
+    if (indirect) walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
+    else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) rad[e] = cx.rad[e];
+}
+
+// rows [r_lo, r_hi) of a block of 64-double rows from src to dst (both already offset by the lane), 32 rows in flight
+__device__ inline void move_rows(const GLB_AS double* src, GLB_AS double* dst, int r_lo, int r_hi) {
+    for (int r0 = r_lo; r0 < r_hi; r0 += 32) {
+        double x[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) x[u] = src[(size_t)min(r0 + u, r_hi - 1) * WAVE];
+#pragma unroll
+        for (int u = 0; u < 32; u++) if (r0 + u < r_hi) dst[(size_t)(r0 + u) * WAVE] = x[u];
+    }
+}
+
+// ---- the primary's side of a shared walk
+// The split point: about `num / den` of the N sorted terms for the primary, moved up to the next boundary between runs of equal keys.
+template <class KeyAt>
+__device__ inline int split_point(int N, int num, int den, const KeyAt& keyat) {
+    int S = uni((int)((long long)N * num / den));
+    if (S < 1) S = 1;
+    while (S < N && keyat(S) == keyat(S - 1)) S++;
+    return uni(S);
+}
+__device__ inline void hj_signal(const TW& t, LDS_AS int* p, int v) {
+    WSYNC();   // this wave's stores (rows, keys, channel words) are done
+    if (t.w.lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ inline void hj_wait(TW& t, LDS_AS int* p, int v) {
+#ifdef TV_PROFILE
+    const long long hw0__ = clock64();
+#endif
+    int spins = 0;
+    while (lds_ld(p) < v) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 23)) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); break; }   // never seen; ends the wait instead of the box
+    }
+    WSYNC();
+#ifdef TV_PROFILE
+    t.c_hwait += clock64() - hw0__;
+#endif
+}
+// no helper work for this operator: the helper's job counter still advances (both sides count the operators of the pass)
+// (the channel holds ONE job: the helper acknowledges every job, also an empty one, in HJ_DONE, and the primary does not write the
+//  next job's words before the previous acknowledgement is in)
+__device__ inline void hj_post_none(TW& t) {
+    hj_wait(t, &t.hch[HJ_DONE], t.hseq);
+    t.hseq++;
+    if (t.w.lane == 0) t.hch[HJ_KIND] = HK_NONE;
+    hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+}
+// common part of a job: the range, the primary's sorted arrays, the result slot.  (Increments the job counter.)
+__device__ inline void hj_post_common(TW& t, int kind, int S, int N, bool indirect, const TPZ& out) {
+    hj_wait(t, &t.hch[HJ_DONE], t.hseq);
+    t.hseq++;
+    if (t.w.lane == 0) {
+        LDS_AS int* ch = t.hch;
+        ch[HJ_KIND] = kind; ch[HJ_S] = S; ch[HJ_N] = N; ch[HJ_INDIRECT] = indirect ? 1 : 0;
+        ch[HJ_SKEY] = (int)(uintptr_t)t.w.skey; ch[HJ_SIDX] = (int)(uintptr_t)t.w.sidx; ch[HJ_STAGE] = (int)(uintptr_t)t.stage;
+        lds_st_ptr(&ch[HJ_OUT_KEYS], out.keys); lds_st_ptr(&ch[HJ_OUT_COEF], out.coef); ch[HJ_OUT_CAP] = out.cap;
+    }
+}
+__device__ inline void hj_post_seg(TW& t, int k, const TView& v, double scale, int comp) {
+    if (t.w.lane == 0) {
+        LDS_AS int* sg = t.hch + HJ_SEG0 + k * HJ_SEG_WORDS;
+        lds_st_ptr(&sg[0], v.coef); sg[2] = v.cnt; sg[3] = v.stride; sg[4] = v.off; sg[5] = comp;
+        const uint64_t sb = (uint64_t)__double_as_longlong(scale);
+        sg[6] = (int)(unsigned)sb; sg[7] = (int)(unsigned)(sb >> 32);
+    }
+}
+// after the primary's own part: post how many terms it kept, wait until the helper has moved its rows behind them, and return the
+// helper's count; its partial sums are then in the header rows of its scratch slot (`hdr`: [4][3][64], rows H_IND.. as the caller laid out)
+// (the move of the helper's rows behind the primary's is the one serial step of a shared walk: both waves take half of it)
+__device__ inline int hj_collect(TW& t, int n0, const GLB_AS double*& hdr, const TPZ& out) {
+    if (t.w.lane == 0) t.hch[HJ_N0] = n0;
+    hj_signal(t, &t.hch[HJ_N0SEQ], t.hseq);
+    hj_wait(t, &t.hch[HJ_WALKED], t.hseq);
+    const int nh = uni(t.hch[HJ_NH]);
+    const int room = out.cap - n0 > 0 ? out.cap - n0 : 0, ncopy = nh < room ? nh : room;
+    const GLB_AS double* src = lds_ld_ptr<const GLB_AS double>(&t.hch[HJ_TMP_COEF]) + t.w.lane;
+    move_rows(src, out.coef + (size_t)n0 * 3 * WAVE + t.w.lane, 0, (ncopy * 3) / 2);
+    hj_wait(t, &t.hch[HJ_DONE], t.hseq);
+    hdr = lds_ld_ptr<const GLB_AS double>(&t.hch[HJ_HDR]);
+    return nh;
 }
 
 template <int AR, int AC, int BR, int BC>
@@ -371,6 +488,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
     if (a.cnt == 0) {
         // constant left operand (mass, inertia, the fixed rpy rotation): b's keys in b's order, no sort
+        if (t.hch != nullptr && AR == 3 && AC == 3 && BR == 3 && BC == 1) hj_post_none(t);
         MulCtx<SH, 0> cx;
         mul_ctx_init(cx, t, a, b, &o);
         for (int m0 = 0; m0 < b.cnt; m0 += WAVE) {
@@ -398,9 +516,42 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         // the shorter operand's rows go to LDS when they fit (whole-PZ views only)
         const bool a_short = a.cnt <= b.cnt;
         const bool can_a = a.off == 0 && a.sz == a.stride && stage_fits(t, a), can_b = b.off == 0 && b.sz == b.stride && stage_fits(t, b);
-        if ((a_short && can_a) || (!can_b && can_a)) { stage_rows_of(t, a, lane); mul_walk<SH, 1>(t, N, indirect, ev, a, b, &o, rad); }
-        else if (can_b) { stage_rows_of(t, b, lane); mul_walk<SH, 2>(t, N, indirect, ev, a, b, &o, rad); }
-        else mul_walk<SH, 0>(t, N, indirect, ev, a, b, &o, rad);
+        constexpr bool kSplittable = (AR == 3 && AC == 3 && BR == 3 && BC == 1);   // rotation x vector: the products of the backward recursions
+        const bool stage_a = (a_short && can_a) || (!can_b && can_a);
+        bool shared = false;
+        if constexpr (kSplittable) {
+            if (t.hch != nullptr) {
+                if (stage_a && N >= kHelperMinTerms) shared = true; else hj_post_none(t);
+            }
+        }
+        if (stage_a) {
+            stage_rows_of(t, a, lane);
+            int S = N;
+            if constexpr (kSplittable) {
+                if (shared) {
+                    const Wave& w = t.w;
+                    S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
+                    hj_post_common(t, HK_MUL_3331_A_STAGED, S, N, indirect, out);
+#ifdef TV_PROFILE
+                    t.n_shared += 1; t.n_shared_terms += N;
+#endif
+                    hj_post_seg(t, 0, a, 1.0, -1); hj_post_seg(t, 1, b, 1.0, -1);
+                    hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+                }
+            }
+            mul_walk<SH, 1>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+            if constexpr (kSplittable) {
+                if (shared) {
+                    const GLB_AS double* hdr;
+                    const int nh = hj_collect(t, o.n, hdr, out);
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) { rad[e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane]; o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane]; }
+                    o.n += nh;
+                }
+            }
+        }
+        else if (can_b) { stage_rows_of(t, b, lane); mul_walk<SH, 2>(t, t.w, t.stage, 0, N, indirect, ev, a, b, &o, rad); }
+        else mul_walk<SH, 0>(t, t.w, t.stage, 0, N, indirect, ev, a, b, &o, rad);
         TVP_END(t, N, o.n, 0)
     }
 #pragma unroll
@@ -765,8 +916,43 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     TVP_T1
     const Wave& w = t.w;
     constexpr int kU = SZ <= 3 ? 8 : 4;
-    if (indirect) walk_sorted<kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    else walk_sorted<kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    // the sums of the backward recursions (f = R f + F; n = ((N + R n) + c x F) + p x R f) share their walk with an idle wave
+    constexpr bool kSplittable = SZ == 3 && ((NS == 2 && !CHAIN) || (NS == 4 && CHAIN));
+    bool shared = false;
+    int S = N;
+    if constexpr (kSplittable) {
+        if (t.hch != nullptr) {
+            if (N >= kHelperMinTerms) {
+                shared = true;
+                S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
+                hj_post_common(t, CHAIN ? HK_LIN4_CHAIN : HK_LIN2, S, N, indirect, out);
+#ifdef TV_PROFILE
+                t.n_shared += 1; t.n_shared_terms += N;
+#endif
+#pragma unroll
+                for (int k = 0; k < NS; k++) hj_post_seg(t, k, cx.s[k].v, cx.s[k].scale, cx.s[k].comp);
+                hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+            } else hj_post_none(t);
+        }
+    }
+    if (indirect) walk_sorted<kU>(lane, S, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    else walk_sorted<kU>(lane, S, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    if constexpr (kSplittable) {
+        if (shared) {   // the helper's rows are behind ours now; its partial sums of the pruned amounts, stage by stage, and of |coefficient|
+            const GLB_AS double* hdr;
+            const int nh = hj_collect(t, o.n, hdr, out);
+#pragma unroll
+            for (int e = 0; e < SZ; e++) {
+                if constexpr (CHAIN) {
+                    cx.ra[1][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
+                    cx.ra[2][e] += hdr[((size_t)H_IND2 * SZ + e) * WAVE + lane];
+                    cx.ra[3][e] += hdr[((size_t)H_CEN * SZ + e) * WAVE + lane];
+                } else cx.ra[0][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
+                o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane];
+            }
+            o.n += nh;
+        }
+    }
     TVP_END(t, N, o.n, 2)
 #pragma unroll
     for (int e = 0; e < SZ; e++) {
@@ -787,6 +973,110 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
         st_hdr(out, H_IND2, e, lane, r2);
     }
     o.finish(t, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The helper's side of a shared walk ("One walk on two waves" above): wait for the primary's next operator on this wave's channel;
+// if it shares its walk, walk the upper part of its sorted terms into `tmp` (a scratch slot of this wave), leave the partial sums in
+// tmp's header rows, and move the rows down behind the primary's once it has posted its count.
+__device__ inline TView hj_seg_view(LDS_AS int* ch, int k, int sz) {
+    LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
+    TView v;
+    v.keys = nullptr; v.hdr = nullptr;
+    v.coef = lds_ld_ptr<const GLB_AS double>(&sg[0]);
+    v.cnt = uni(sg[2]); v.stride = uni(sg[3]); v.off = uni(sg[4]); v.sz = sz;
+    return v;
+}
+__device__ TV_NOINLINE void serve_walk(TW& t, const TPZ& tmp) {
+    LDS_AS int* ch = t.hch;
+    const int lane = t.w.lane;
+    t.hseq++;
+    hj_wait(t, &ch[HJ_SEQ], t.hseq);
+    const int kind = uni(ch[HJ_KIND]);
+    if (kind == HK_NONE) { hj_signal(t, &ch[HJ_DONE], t.hseq); return; }
+    const int S = uni(ch[HJ_S]), N = uni(ch[HJ_N]);
+    const bool indirect = uni(ch[HJ_INDIRECT]) != 0;
+    Wave sw = t.w;   // the PRIMARY's sorted terms
+    sw.skey = (LDS_AS uint64_t*)(uintptr_t)(unsigned)uni(ch[HJ_SKEY]);
+    sw.sidx = (LDS_AS uint16_t*)(uintptr_t)(unsigned)uni(ch[HJ_SIDX]);
+    Out<3> o;
+    o.init(tmp, lane);
+    double part[4][3];   // header rows of tmp: [H_IND] [H_IND2] [H_ASUM] [H_CEN]
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) part[q][e] = 0.0;
+    if (kind == HK_MUL_3331_A_STAGED) {
+        typedef pzw::MulShape<3, 3, 3, 1> SH;
+        const TView a = hj_seg_view(ch, 0, 9), b = hj_seg_view(ch, 1, 3);
+        pzw::MulEval<SH> ev;
+        ev.a = kview(a); ev.set_b(kview(b));
+        const LDS_AS double* stage = (const LDS_AS double*)(uintptr_t)(unsigned)uni(ch[HJ_STAGE]);
+        mul_walk<SH, 1>(t, sw, stage, S, N, indirect, ev, a, b, &o, part[H_IND]);
+    } else if (kind == HK_LIN2) {
+        LinCtx<3, 2, false> cx;
+        pzw::LinEval<3, 2> ev;   // (key_lds reads the primary's key buffer only)
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
+            cx.s[k].v = hj_seg_view(ch, k, 3); cx.s[k].comp = uni(sg[5]);
+            cx.s[k].scale = __longlong_as_double((long long)(((uint64_t)(unsigned)sg[7] << 32) | (unsigned)sg[6]));
+            cx.off[k] = tot; tot += cx.s[k].v.cnt;
+        }
+        cx.off[2] = tot;
+        cx.lane = lane; cx.prepare();
+        cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
+#pragma unroll
+        for (int e = 0; e < 3; e++) { cx.acc[e] = 0.0; cx.ra[0][e] = 0.0; cx.ra[1][e] = 0.0; }
+        if (indirect) walk_sorted<8>(lane, N, [&](int p) { return ev.key_lds(sw, sw.sidx[p]); }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+        else walk_sorted<8>(lane, N, [&](int p) { return sw.skey[p]; }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+#pragma unroll
+        for (int e = 0; e < 3; e++) part[H_IND][e] = cx.ra[0][e];
+    } else {
+        LinCtx<3, 4, true> cx;
+        pzw::LinEval<3, 4> ev;
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
+            cx.s[k].v = hj_seg_view(ch, k, 3); cx.s[k].comp = uni(sg[5]);
+            cx.s[k].scale = __longlong_as_double((long long)(((uint64_t)(unsigned)sg[7] << 32) | (unsigned)sg[6]));
+            cx.off[k] = tot; tot += cx.s[k].v.cnt;
+        }
+        cx.off[4] = tot;
+        cx.lane = lane; cx.prepare();
+        cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
+#pragma unroll
+        for (int e = 0; e < 3; e++) cx.acc[e] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 3; e++) cx.ra[k][e] = 0.0;
+        if (indirect) walk_sorted<8>(lane, N, [&](int p) { return ev.key_lds(sw, sw.sidx[p]); }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+        else walk_sorted<8>(lane, N, [&](int p) { return sw.skey[p]; }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+#pragma unroll
+        for (int e = 0; e < 3; e++) { part[H_IND][e] = cx.ra[1][e]; part[H_IND2][e] = cx.ra[2][e]; part[H_CEN][e] = cx.ra[3][e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) part[H_ASUM][e] = o.asum[e];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) st_hdr(tmp, q, e, lane, part[q][e]);
+    const int nh = uni(o.n < tmp.cap ? o.n : tmp.cap);
+    if (o.n > tmp.cap) pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW);
+    if (lane == 0) { ch[HJ_NH] = nh; lds_st_ptr(&ch[HJ_HDR], tmp.hdr); lds_st_ptr(&ch[HJ_TMP_COEF], tmp.coef); }
+    hj_signal(t, &ch[HJ_WALKED], t.hseq);
+    // ... and once the primary has finished its part: our rows behind its n0
+    hj_wait(t, &ch[HJ_N0SEQ], t.hseq);
+    const int n0 = uni(ch[HJ_N0]), cap = uni(ch[HJ_OUT_CAP]);
+    GLB_AS uint64_t* ok = lds_ld_ptr<GLB_AS uint64_t>(&ch[HJ_OUT_KEYS]);
+    GLB_AS double* oc = lds_ld_ptr<GLB_AS double>(&ch[HJ_OUT_COEF]);
+    const int room = cap - n0 > 0 ? cap - n0 : 0, ncopy = nh < room ? nh : room;   // (an overflow of the result is flagged by the primary's finish())
+    for (int m = lane; m < ncopy; m += WAVE) ok[n0 + m] = tmp.keys[m];
+    move_rows(tmp.coef + lane, oc + (size_t)n0 * 3 * WAVE + lane, (ncopy * 3) / 2, ncopy * 3);   // (the primary moves the lower half)
+    hj_signal(t, &ch[HJ_DONE], t.hseq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -24,17 +24,33 @@
 //                    ids 1..7 of jrs_info.k_id (PZM/create_jrs_online.m:225); same mapping as armour_amd/cora.py
 //   [q, qd, qdd] = armour_hip_mex('traj', q0, qd0, qdd0, k, t)     desired trajectory of a plan at time t (the Bernstein form of
 //                    KSI/uarmtd_planner.m:846-905 in the NLP's own closed form; k_range and duration of the handle's parameters)
+//   v = armour_hip_mex('violations', k)                            reduced outputs (armour_eval_violations): 6 x 1 =
+//                    [l1_violation; worst; worst_row (1-based, 0 = none); n_violated; n_outside_slack; feasible] -- g stays on the device
 //   armour_hip_mex('destroy')
+//
+// Several GPUs from the one MATLAB thread (armour_batch_*: one handle, stream and host thread per device slot; problems dealt in
+// contiguous blocks):
+//   armour_hip_mex('batch_create', T, devices)                     devices: vector of HIP device ordinals (one may repeat)
+//   armour_hip_mex('batch_set_problems', Q0, QD0, QDD0, Q_DES, Z)  7 x B each, Z = (12 nObs) x B: column b = the obstacles of problem b
+//   [K_opt, feasible, info] = armour_hip_mex('batch_solve'[, max_wall_time_s])   7 x B, 1 x B, 5 x B (rows as 'solve')
+//   V = armour_hip_mex('batch_violations', K)                      K 7 x B -> 6 x B (rows as 'violations')
+//   [G, JAC] = armour_hip_mex('batch_eval', K)                     m x B and (n m) x B: column b = g / the row-major Jacobian of problem b
+//   armour_hip_mex('batch_destroy')
 #include <string.h>
 
 #include "armour_hip.h"
 #include "mex.h"
 
 static ArmourPlanner* g_h = nullptr;
+static ArmourBatch* g_bt = nullptr;
 static ArmourParams g_pr;
 
 static void cleanup(void) {
     if (g_h) { armour_destroy(g_h); g_h = nullptr; }
+    if (g_bt) { armour_batch_destroy(g_bt); g_bt = nullptr; }
+}
+static void violation_column(const ArmourViolation& v, double* p) {
+    p[0] = v.l1_violation; p[1] = v.worst; p[2] = v.worst_row + 1; p[3] = v.n_violated; p[4] = v.n_outside_slack; p[5] = v.feasible;
 }
 static void chk(int rc) {
     if (rc < 0) mexErrMsgTxt(armour_last_error());
@@ -53,14 +69,83 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         ArmourParams& pr = g_pr;
         armour_robot_kinova_gen3_no_gripper(&rb);
         armour_params_default(&pr, (int)mxGetScalar(prhs[1]));
-        cleanup();
+        if (g_h) { armour_destroy(g_h); g_h = nullptr; }
         chk(armour_create(&rb, &pr, nullptr, 0, &g_h));
         if (!mexIsLocked()) { mexAtExit(cleanup); mexLock(); }
         return;
     }
     if (!strcmp(cmd, "destroy")) {
-        cleanup();
-        if (mexIsLocked()) mexUnlock();
+        if (g_h) { armour_destroy(g_h); g_h = nullptr; }
+        if (!g_bt && mexIsLocked()) mexUnlock();
+        return;
+    }
+    // ---- the multi-device batch (its own object next to the single handle)
+    if (!strcmp(cmd, "batch_create")) {
+        need(nrhs >= 3 && mxGetNumberOfElements(prhs[2]) >= 1 && mxGetNumberOfElements(prhs[2]) <= 64, "batch_create needs T and a vector of device ordinals");
+        ArmourRobot rb;
+        ArmourParams pr;
+        armour_robot_kinova_gen3_no_gripper(&rb);
+        armour_params_default(&pr, (int)mxGetScalar(prhs[1]));
+        int32_t dev[64];
+        const int nd = (int)mxGetNumberOfElements(prhs[2]);
+        for (int i = 0; i < nd; i++) dev[i] = (int32_t)mxGetPr(prhs[2])[i];
+        if (g_bt) { armour_batch_destroy(g_bt); g_bt = nullptr; }
+        chk(armour_batch_create(&rb, &pr, nullptr, dev, nd, &g_bt));
+        if (!mexIsLocked()) { mexAtExit(cleanup); mexLock(); }
+        return;
+    }
+    if (!strcmp(cmd, "batch_destroy")) {
+        if (g_bt) { armour_batch_destroy(g_bt); g_bt = nullptr; }
+        if (!g_h && mexIsLocked()) mexUnlock();
+        return;
+    }
+    if (!strncmp(cmd, "batch_", 6)) {
+        need(g_bt != nullptr, "call armour_hip_mex('batch_create', T, devices) first");
+        if (!strcmp(cmd, "batch_set_problems")) {
+            need(nrhs == 6, "batch_set_problems needs Q0, QD0, QDD0, Q_DES (7 x B) and Z ((12 nObs) x B)");
+            const int B = (int)(mxGetNumberOfElements(prhs[1]) / 7);
+            for (int i = 1; i <= 4; i++) need((int)mxGetNumberOfElements(prhs[i]) == 7 * B && B >= 1, "state matrices must be 7 x B");
+            const size_t nz = mxGetNumberOfElements(prhs[5]);
+            need(nz % ((size_t)12 * B) == 0, "Z must be (12 nObs) x B");
+            chk(armour_batch_set_problems(g_bt, B, (int)(nz / 12 / B), mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5])));
+            return;
+        }
+        int B, n, m, ns;
+        chk(armour_batch_get_sizes(g_bt, &B, &n, &m, &ns));
+        if (!strcmp(cmd, "batch_solve")) {
+            ArmourSolveOptions so;
+            armour_solve_options_default(&so);
+            if (nrhs > 1) so.max_wall_time_s = mxGetScalar(prhs[1]);
+            ArmourSolveResult* r = (ArmourSolveResult*)mxMalloc(sizeof(ArmourSolveResult) * B);
+            chk(armour_batch_solve(g_bt, &so, r));
+            plhs[0] = mxCreateDoubleMatrix(n, B, mxREAL);
+            mxArray* feas = mxCreateDoubleMatrix(1, B, mxREAL);
+            mxArray* info = mxCreateDoubleMatrix(5, B, mxREAL);
+            for (int b = 0; b < B; b++) {
+                memcpy(mxGetPr(plhs[0]) + (size_t)b * n, r[b].k_opt, n * sizeof(double));
+                mxGetPr(feas)[b] = r[b].feasible != 0;
+                double* p = mxGetPr(info) + (size_t)b * 5;
+                p[0] = r[b].cost; p[1] = r[b].iterations; p[2] = r[b].evaluations; p[3] = r[b].status; p[4] = r[b].time_ms;
+            }
+            mxFree(r);
+            if (nlhs > 1) plhs[1] = feas; else mxDestroyArray(feas);
+            if (nlhs > 2) plhs[2] = info; else mxDestroyArray(info);
+        } else if (!strcmp(cmd, "batch_violations")) {
+            need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n * B, "batch_violations needs K (n x B)");
+            ArmourViolation* v = (ArmourViolation*)mxMalloc(sizeof(ArmourViolation) * B);
+            chk(armour_batch_eval_violations(g_bt, mxGetPr(prhs[1]), v));
+            plhs[0] = mxCreateDoubleMatrix(6, B, mxREAL);
+            for (int b = 0; b < B; b++) violation_column(v[b], mxGetPr(plhs[0]) + (size_t)b * 6);
+            mxFree(v);
+        } else if (!strcmp(cmd, "batch_eval")) {
+            need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n * B, "batch_eval needs K (n x B)");
+            plhs[0] = mxCreateDoubleMatrix(m, B, mxREAL);
+            mxArray* jac = mxCreateDoubleMatrix((mwSize)n * m, B, mxREAL);
+            chk(armour_batch_eval_g_jac(g_bt, mxGetPr(prhs[1]), mxGetPr(plhs[0]), mxGetPr(jac)));
+            if (nlhs > 1) plhs[1] = jac; else mxDestroyArray(jac);
+        } else {
+            mexErrMsgTxt("unknown command");
+        }
         return;
     }
     need(g_h != nullptr, "call armour_hip_mex('create', T) first");
@@ -151,6 +236,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             double* p = mxGetPr(plhs[2]);
             p[0] = r.cost; p[1] = r.iterations; p[2] = r.evaluations; p[3] = r.status; p[4] = r.time_ms;
         }
+    } else if (!strcmp(cmd, "violations")) {
+        need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n, "violations needs k (n x 1)");
+        ArmourViolation v;
+        chk(armour_eval_violations(g_h, mxGetPr(prhs[1]), &v));
+        plhs[0] = col(6);
+        violation_column(v, mxGetPr(plhs[0]));
     } else if (!strcmp(cmd, "pz")) {
         char which[16];
         need(nrhs == 4 && !mxGetString(prhs[1], which, sizeof(which)), "pz needs which ('link'|'torque'), i, t");

@@ -154,3 +154,44 @@ def test_every_command_against_the_ctypes_binding(mexlib, sample_problem):
     with pytest.raises(RuntimeError, match="create"):
         mex(1, "eval", k)
     nlp.close()
+
+
+@pytest.mark.gpu
+def test_batch_commands_drive_device_slots_from_one_thread(mexlib):
+    """The multi-device batch through the gateway (armour_batch_*): two device slots on the one GPU of this box, every result
+    against ArmourBatchNLP / a single handle over the same problems."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    mex = Mex(mexlib)
+    T, B, O = 100, 5, 6
+    bp = random_batch(77, B, O)
+    with pytest.raises(RuntimeError, match="batch_create"):
+        mex(1, "batch_violations", np.zeros((7, B)))
+    mex(0, "batch_create", T, np.array([0.0, 0.0]))
+    assert mexlib.mexh_is_locked() == 1
+    Z = bp["obstacles"].reshape(B, O * 12).T                      # (12 nObs) x B
+    mex(0, "batch_set_problems", bp["q0"].T, bp["qd0"].T, bp["qdd0"].T, bp["q_des"].T, Z)
+    one = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    K = random_k(9, B)
+    V, = mex(1, "batch_violations", K.T)
+    ref = one.eval_violations(K)
+    for b in range(B):
+        assert (V[0, b], V[1, b], int(V[2, b]) - 1, int(V[3, b]), int(V[4, b]), bool(V[5, b])) == \
+               (ref[b]["l1_violation"], ref[b]["worst"], ref[b]["worst_row"], ref[b]["n_violated"], ref[b]["n_outside_slack"], ref[b]["feasible"])
+    G, JAC = mex(2, "batch_eval", K.T)
+    g_ref, jac_ref = one.eval_g_jac(K)
+    assert np.array_equal(G.T, g_ref) and np.array_equal(JAC.T.reshape(B, one.m, one.n), jac_ref)
+    K_opt, feas, info = mex(3, "batch_solve")
+    sol = one.solve()
+    for b in range(B):
+        assert np.array_equal(K_opt[:, b], sol[b]["k_opt"]) and bool(feas[0, b]) == sol[b]["feasible"] and info[3, b] == sol[b]["status"]
+    # the single-handle 'violations' command next to it
+    mex(0, "create", T)
+    mex(0, "set_problem", bp["q0"][2], bp["qd0"][2], bp["qdd0"][2], bp["q_des"][2], bp["obstacles"][2].T)
+    v, = mex(1, "violations", K[2])
+    assert (v[0, 0], v[1, 0], int(v[2, 0]) - 1, bool(v[5, 0])) == (ref[2]["l1_violation"], ref[2]["worst"], ref[2]["worst_row"], ref[2]["feasible"])
+    mex(0, "destroy")
+    assert mexlib.mexh_is_locked() == 1                           # the batch object still holds the gateway
+    mex(0, "batch_destroy")
+    assert mexlib.mexh_is_locked() == 0
+    one.close()

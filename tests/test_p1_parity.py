@@ -426,9 +426,9 @@ def test_builds_are_reproducible_from_launch_to_launch(B, O):
             assert np.array_equal(a, b)
 
 
-def _tables_digest_body(B):
+def _tables_digest_body(B, dump=None):
     """Prints a digest of everything a reach-set build leaves behind (run in a process of its own: the launch-shape switches
-    are read once per process)."""
+    are read once per process).  dump: also save the arrays to this .npz (exact part and radii separately)."""
     import hashlib
     from armour_amd.planner import ArmourNLP
     from armour_amd.worlds import random_batch, random_k
@@ -440,20 +440,26 @@ def _tables_digest_body(B):
     g, jac = nlp.eval_g_jac(random_k(4, B))
     for a in (g, jac, nlp.torque_radius(), nlp.link_generators()):
         h.update(np.ascontiguousarray(a).tobytes())
+    exact, radii = [], [nlp.torque_radius().ravel(), nlp.link_generators().ravel(), g.ravel(), jac.ravel()]
     for b in (0, B - 1):
         for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
             for i in range(cnt):
                 for t in (0, 37, 50, 99):
-                    for a in nlp.pz(which, i, t, b=b):
+                    cen, ind, keys, co = nlp.pz(which, i, t, b=b)
+                    for a in (cen, ind, keys, co):
                         h.update(np.ascontiguousarray(a).tobytes())
+                    exact += [cen.ravel(), keys.astype(np.float64).ravel(), co.ravel()]
+                    radii.append(ind.ravel())
     print("digest", h.hexdigest())
+    if dump:
+        np.savez(dump, exact=np.concatenate(exact), radii=np.concatenate(radii))
 
 
 @pytest.mark.parametrize("B,settings", [
     (1, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1"),
          dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1", ARMOUR_P1_SPLIT_FK="0")]),
     (2, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1")]),
-    (3, [dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="1"),
+    (3, [dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_HELPERS="0"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="1"),
          dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_FREE="0"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3", ARMOUR_P1_TV_FREE="0")]),
 ], ids=["per-step, one problem", "per-step, two problems", "time-vectorised"])
 def test_wave_choreographies_leave_identical_tables(B, settings):
@@ -471,6 +477,28 @@ def test_wave_choreographies_leave_identical_tables(B, settings):
         assert r.returncode == 0 and lines, (env, r.stdout[-1500:] + r.stderr[-1500:])
         digests.append(lines[-1])
     assert len(set(digests)) == 1, list(zip(settings, digests))
+
+
+def test_walk_helpers_only_reorder_the_sums_of_the_radii(tmp_path):
+    """Round 3: in the backward pass of a four-wave time-vectorised block the two idle waves each walk the upper part of the
+    f- / n-recursion's sorted raw terms (pz_tv.h "One walk on two waves").  Against the same build with every walk on its own wave:
+    centres, monomial keys and coefficients equal bit for bit; the independent radii -- and torque radius, link generators, g, jac
+    through them -- differ by the rounding of two partial sums instead of one running sum, <= 1e-12.  And the shared walk is
+    deterministic: two runs give the same bits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("off", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_HELPERS="0")), ("on", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4")),
+                     ("on2", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4"))):
+        f = str(tmp_path / (tag + ".npz"))
+        code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._tables_digest_body(3, %r)" % (root, os.path.join(root, "tests"), f)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (env, r.stdout[-1500:] + r.stderr[-1500:])
+        out[tag] = dict(np.load(f))
+    assert np.array_equal(out["on"]["exact"], out["off"]["exact"])
+    assert np.abs(out["on"]["radii"] - out["off"]["radii"]).max() <= 1e-12
+    assert not np.array_equal(out["on"]["radii"], out["off"]["radii"])        # (the helpers did take part)
+    assert np.array_equal(out["on"]["radii"], out["on2"]["radii"]) and np.array_equal(out["on"]["exact"], out["on2"]["exact"])
 
 
 def _exact_plane_skip(gens, obstacles):
