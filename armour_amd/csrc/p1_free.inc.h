@@ -87,7 +87,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     const bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
     if constexpr (CH::kWalkHelpers) {
         if (threadIdx.x < 2 * tv::HJ_WORDS) c.mb[kHelpBase + threadIdx.x] = 0;
-        c.w.hseq = 0; c.w.hch = nullptr; c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16;
+        c.w.hseq = 0; c.w.hch = nullptr; c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16; c.w.hmin = cf.tv_help_min;
     }
     if (c.wid == 1) {
         c.role = 1;
@@ -292,11 +292,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         set_const(w, nn, nullptr, nullptr);
         for (int i = J - 1; i >= 0; i--) {
             const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
-            TPZ a1 = with_walk_helper(c, 1, walk_helpers, [&] { return c.mulMV(Rn, nn); });
+            TPZ a1 = with_walk_helper(c, 1, walk_helpers && cf.tv_help_n, [&] { return c.mulMV(Rn, nn); });
             TPZ c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
             t3_wait(c, T3_B2, J - i);
             const TPZ c2 = t3_take(c, T3_C2 + i);
-            TPZ n2 = with_walk_helper(c, 1, walk_helpers, [&] { return c.sum4(Ni, a1, c1, c2); }); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
+            TPZ n2 = with_walk_helper(c, 1, walk_helpers && cf.tv_help_n, [&] { return c.sum4(Ni, a1, c1, c2); }); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
             nn = n2;
             if (cf.rb.axes[i] != 0) {
                 const int ax = abs(cf.rb.axes[i]) - 1;
@@ -311,12 +311,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.role = helper;
         TPZ htmp = c.allocV();
         for (int i = J - 1; i >= 0; i--) {
-            if (walk_helpers) serve_walk_helper(c, 1, htmp);   // R n of joint i
+            if (walk_helpers && cf.tv_help_n) serve_walk_helper(c, 1, htmp);   // R n of joint i
             t3_wait(c, T3_B1, J - i);
             TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
             t3_post(c, T3_C2 + i, c2);
             t3_signal(c, T3_B2, J - i);
-            if (walk_helpers) serve_walk_helper(c, 1, htmp);   // the four-term sum of joint i
+            if (walk_helpers && cf.tv_help_n) serve_walk_helper(c, 1, htmp);   // the four-term sum of joint i
         }
         c.freeVs(htmp);
         c.bar();   // (B) wave 0 has read every p x (R f)

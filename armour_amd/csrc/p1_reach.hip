@@ -75,6 +75,7 @@ struct P1Cfg {
     int tv_free_running;  // three-wave blocks: run_rnea_free (progress counters) instead of run_rnea (a barrier per joint)
     int free_running;     // the same choice for the per-step kernel's three-wave blocks
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
+    int tv_help_min, tv_help_n;  // shared walks: smallest walk that is shared; whether the n-recursion shares its walks as well (development switches)
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
 };
 
@@ -1715,6 +1716,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
             static const int tv_help_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELPERS"); return e ? atoi(e) : 1; }();  // development switch: 0 = every walk on its own wave
             cf.tv_walk_helpers = tv_help_env;
+            static const int tv_help_min_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_MIN"); return e ? atoi(e) : 192; }();
+            static const int tv_help_n_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_N"); return e ? atoi(e) : 1; }();
+            cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {

@@ -57,6 +57,7 @@ struct TW {
     LDS_AS int* hch = nullptr;
     int hseq = 0;          // jobs posted (primary) / served (helper) on that channel so far
     int hnum = 16;         // the primary keeps hnum / 32 of a shared walk's terms
+    int hmin = 192;        // walks with fewer sorted terms stay on one wave (two hand-overs cost more than half of such a walk)
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
     long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0, c_hwait = 0, n_shared = 0, n_shared_terms = 0;
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
@@ -94,7 +95,6 @@ enum { HJ_SEQ = 0, HJ_WALKED, HJ_N0SEQ, HJ_DONE,           // progress words (se
        HJ_SEG0 = 24, HJ_SEG_WORDS = 8,                      // per source: coef address (2), cnt, stride, off, comp, scale (2)
        HJ_WORDS = HJ_SEG0 + 4 * HJ_SEG_WORDS };
 enum { HK_NONE = 0, HK_MUL_3331_A_STAGED = 1, HK_LIN2 = 2, HK_LIN4_CHAIN = 3 };
-constexpr int kHelperMinTerms = 192;   // below this a walk is not worth two hand-overs
 
 __device__ inline int lds_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void lds_st_ptr(LDS_AS int* p, const GLB_AS void* q) { const uint64_t v = (uint64_t)q; p[0] = (int)(unsigned)v; p[1] = (int)(unsigned)(v >> 32); }
@@ -521,7 +521,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         bool shared = false;
         if constexpr (kSplittable) {
             if (t.hch != nullptr) {
-                if (stage_a && N >= kHelperMinTerms) shared = true; else hj_post_none(t);
+                if (stage_a && N >= t.hmin) shared = true; else hj_post_none(t);
             }
         }
         if (stage_a) {
@@ -922,7 +922,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     int S = N;
     if constexpr (kSplittable) {
         if (t.hch != nullptr) {
-            if (N >= kHelperMinTerms) {
+            if (N >= t.hmin) {
                 shared = true;
                 S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
                 hj_post_common(t, CHAIN ? HK_LIN4_CHAIN : HK_LIN2, S, N, indirect, out);
