@@ -106,10 +106,12 @@ static int ensure_capacity(ArmourPlanner* h, int B, int O) {
     TRY(dev_alloc(&h->d_bez, (size_t)nb * 3 * h->n));
     const size_t mmax = (size_t)h->n * h->T + (size_t)h->J * h->T * no + 4 * h->n;
     TRY(dev_alloc(&h->d_k, (size_t)nb * h->n));
-    TRY(dev_alloc(&h->d_g, (size_t)nb * mmax));
-    // d_jac doubles as the scratch of armour_get_link_centers (B*T*J*3 doubles): m*n >= T*J*3 does not hold for every
-    // robot armour_create accepts (n*n < 3J with O = 0), so size it for both uses
-    TRY(dev_alloc(&h->d_jac, std::max((size_t)nb * mmax * h->n, (size_t)nb * h->T * h->J * 3)));
+    // g and jac staging: ONE allocation, jac placed directly behind the g of the current problem set (begin_problem_set), so that the
+    // synchronous host call can bring both back with a single device-to-host transfer when the caller's buffers are adjacent too.
+    // The jac part doubles as the scratch of armour_get_link_centers (B*T*J*3 doubles): m*n >= T*J*3 does not hold for every
+    // robot armour_create accepts (n*n < 3J with O = 0), so it is sized for both uses
+    TRY(dev_alloc(&h->d_g, (size_t)nb * mmax + std::max((size_t)nb * mmax * h->n, (size_t)nb * h->T * h->J * 3)));
+    h->d_jac = h->d_g + (size_t)nb * mmax;
     TRY(dev_alloc(&h->d_bounds, (size_t)2 * nb * mmax));
 #undef TRY
     h->allocB = nb;
@@ -217,7 +219,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     dev_free(&h->d_tq_count); dev_free(&h->d_tq_center); dev_free(&h->d_tq_indep);
     dev_free(&h->d_tq_keys); dev_free(&h->d_tq_coeff);
     dev_free(&h->d_planes); dev_free(&h->d_planes_ll); dev_free(&h->d_obs_center); dev_free(&h->d_plane_skip); dev_free(&h->d_bez);
-    dev_free(&h->d_k); dev_free(&h->d_g); dev_free(&h->d_jac);
+    dev_free(&h->d_k); dev_free(&h->d_g); h->d_jac = nullptr;   // (d_jac lives inside d_g's allocation)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -245,6 +247,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     h->mode = mode;
     h->row0 = mode == ARMOUR_MODE_ARMTD ? 0 : h->n * h->T;  // CMP/NLPclass.cu:42-43: no torque rows
     h->m = h->row0 + h->Q + 4 * h->n;
+    h->d_jac = h->d_g + (size_t)B * h->m;   // directly behind this problem set's g (the allocation holds max_B * m_max * (1 + n) doubles)
     const size_t bn = (size_t)B * h->n;
     h->h_q0.assign(q0, q0 + bn); h->h_qd0.assign(qd0, qd0 + bn);
     h->h_qdes.assign(q_des, q_des + bn);
@@ -627,6 +630,10 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     else HIPCHK(hipMemcpyAsync(h->d_k, k, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), k_dev, g ? h->d_g : nullptr, jac ? h->d_jac : nullptr, h->stream);
     if (rc != ARMOUR_OK) return rc;
+    if (g && jac && jac == g + bm) {   // the caller's g and jac are one block (as the device copies are): one transfer instead of two
+        HIPCHK(hipMemcpyAsync(g, h->d_g, bm * (1 + (size_t)h->n) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        return spin_on_stream(h->stream);
+    }
     if (g) HIPCHK(hipMemcpyAsync(g, h->d_g, bm * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, h->d_jac, bm * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     return spin_on_stream(h->stream);

@@ -334,7 +334,9 @@ class ArmourNLP:
         """pinned=True returns views of page-locked buffers owned by this object (valid until the next call)."""
         if pinned:
             k = self._pinned("k", (self.B, self.n)); k[...] = np.asarray(x, dtype=np.float64).reshape(self.B, self.n)
-            g, jac = self._pinned("g", (self.B, self.m)), self._pinned("jac", (self.B, self.m, self.n))
+            # g and jac in ONE page-locked block, jac directly behind g: armour_eval_g_jac then brings both back in one transfer
+            gj = self._pinned("gjac", (self.B * self.m * (1 + self.n),))
+            g, jac = gj[:self.B * self.m].reshape(self.B, self.m), gj[self.B * self.m:].reshape(self.B, self.m, self.n)
         else:
             k, g, jac = self._k(x), np.zeros((self.B, self.m)), np.zeros((self.B, self.m, self.n))
         check(self.L.armour_eval_g_jac(self.h, _dp(k), _dp(g), _dp(jac)))

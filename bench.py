@@ -386,7 +386,8 @@ def main():
             t1 = time.perf_counter()
             nlp.eval_g_jac(k1, pinned=True)
             tt.append((time.perf_counter() - t1) * 1e6)
-        return {"pageable": sync_us, "pinned": statistics.median(tt), "pinned_mean": sum(tt) / len(tt), "pinned_max": max(tt)}
+        return {"pageable": sync_us, "pinned": statistics.median(tt), "pinned_mean": sum(tt) / len(tt), "pinned_max": max(tt), "pinned_argmax": tt.index(max(tt)),
+                "note": "pinned = median of 50 calls with buffers from armour_alloc_pinned (k in, g | jac out as asynchronous DMA transfers on the handle's stream)"}
 
     probe_early = {}
     if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:   # development: where in this process does the page-locked call get slow?
