@@ -21,10 +21,15 @@ enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX
 // (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
 constexpr int kHelpBase = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;
 constexpr int kMbWords = kHelpBase + 2 * tv::HJ_WORDS;
+// the time-vectorised blocks: four channels (eight-wave blocks: one per role wave, to its dedicated helper) and the helpers' status words
+constexpr int kHelpChannels = 4;
+constexpr int kHelpStat = kHelpBase + kHelpChannels * tv::HJ_WORDS;
+constexpr int kTvMbWords = kHelpStat + kHelpChannels * pzw::ST_WORDS;
 // an operator of `c`'s wave that shares its walk with the helper wave on channel k (chains without walk helpers: plain call)
 template <class CH, class Fn>
 __device__ inline auto with_walk_helper(CH& c, int k, bool on, Fn fn) {
     if constexpr (CH::kWalkHelpers) {
+        if (c.w.hded) return fn();   // (a dedicated helper is behind every operator anyway)
         c.w.hch = on ? c.mb + kHelpBase + k * tv::HJ_WORDS : nullptr;
         auto r = fn();
         c.w.hch = nullptr;
@@ -84,10 +89,13 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     const int n_tail = J >= 5 ? 4 : J >= 4 ? 3 : 0;   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     // walk helpers (four-wave blocks of the time-vectorised kernel, backward pass): both channels start empty, every wave's job count at 0
-    const bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
+    bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
     if constexpr (CH::kWalkHelpers) {
-        if (threadIdx.x < 2 * tv::HJ_WORDS) c.mb[kHelpBase + threadIdx.x] = 0;
-        c.w.hseq = 0; c.w.hch = nullptr; c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16; c.w.hmin = cf.tv_help_min;
+        if (c.w.hded) walk_helpers = false;   // eight-wave blocks: every role wave has a helper of its own, the idle waves of this pass stay idle
+        else {
+            if (threadIdx.x < 2 * tv::HJ_WORDS) c.mb[kHelpBase + threadIdx.x] = 0;
+            c.w.hseq = 0; c.w.hch = nullptr; c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16; c.w.hmin = cf.tv_help_min;
+        }
     }
     if (c.wid == 1) {
         c.role = 1;

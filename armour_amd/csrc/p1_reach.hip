@@ -76,6 +76,7 @@ struct P1Cfg {
     int free_running;     // the same choice for the per-step kernel's three-wave blocks
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
     int tv_help_min, tv_help_n;  // shared walks: smallest walk that is shared; whether the n-recursion shares its walks as well (development switches)
+    int tv_help_shift;    // eight-wave blocks: role wave p's helper is wave 4 + (p + shift) % 4
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
 };
 
@@ -870,6 +871,21 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
 #define P1_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define P1_PIN_ONE_WAVE_PER_SIMD() __asm__ volatile("" ::: "a255")
 #endif
+
+// The time-vectorised kernels (p1_tv.inc.h) take TWO waves per SIMD when built with -DP1_TV_WAVES_PER_SIMD=2: their eight-wave
+// blocks put a dedicated helper wave behind each of the four role waves (pz_tv.h "Dedicated helpers").  The attribute sits on
+// every instantiation of the kernel so that the operator functions they share are compiled for 256 registers.
+#ifndef P1_TV_WAVES_PER_SIMD
+#define P1_TV_WAVES_PER_SIMD P1_WAVES_PER_SIMD
+#endif
+#if P1_TV_WAVES_PER_SIMD > 1
+#define P1_TV_OCC __attribute__((amdgpu_waves_per_eu(P1_TV_WAVES_PER_SIMD, P1_TV_WAVES_PER_SIMD)))
+#define P1_TV_PIN()
+#else
+#define P1_TV_OCC P1_OCC
+#define P1_TV_PIN() P1_PIN_ONE_WAVE_PER_SIMD()
+#endif
+constexpr bool kTvDedicatedHelpers = P1_TV_WAVES_PER_SIMD > 1;
 
 #include "p1_tv.inc.h"
 
@@ -1672,15 +1688,21 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         static const int tv_free_env = [] { const char* e = getenv("ARMOUR_P1_TV_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
         static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3 | 4
         static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
+        static const int tv_ded_env = [] { const char* e = getenv("ARMOUR_P1_TV_DEDICATED"); return e ? atoi(e) : 1; }();  // development switch: 0 = no eight-wave blocks
+        static const int tv_shift_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_SHIFT"); return e ? atoi(e) : 0; }();
         struct Shape { int nw, cap; };
-        const Shape shapes[4] = {{4, 4096}, {kRoles, 4096}, {1, 4096}, {1, 8192}};
-        for (int si = 0; si < 4 && !built; si++) {
-            const int nw = shapes[si].nw, cap = shapes[si].cap;
+        // (8: four role waves + four dedicated helper waves, two waves per SIMD -- only in a build whose operators fit 256 registers)
+        const Shape shapes[5] = {{8, 4096}, {4, 4096}, {kRoles, 4096}, {1, 4096}, {1, 8192}};
+        for (int si = 0; si < 5 && !built; si++) {
+            const int nw_launch = shapes[si].nw, cap = shapes[si].cap;
+            if (nw_launch == 8 && (!kTvDedicatedHelpers || !tv_ded_env || !tv_free_env)) continue;
+            const int nw = nw_launch == 8 ? 4 : nw_launch;   // the waves that play roles
+            const int nhelp = nw_launch == 8 ? 4 : 0;
             const bool multi = nw > 1;   // (a): the roles of the RNEA on three waves, with four the forward kinematics on a wave of its own
             if (multi && (armtd || tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
-            if (multi && tv_nw_env > 1 && tv_nw_env != nw) continue;
-            if (!multi && tv_nw_env > 1 && si == 2) continue;
-            const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw);
+            if (multi && tv_nw_env > 1 && tv_nw_env != nw_launch) continue;
+            if (!multi && tv_nw_env > 1 && si == 3) continue;
+            const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw, nhelp);
             // blocks per CU by LDS; the staging area takes what is left
             const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed_fk() : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();
             const int per_cu = multi ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
@@ -1718,15 +1740,19 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tv_walk_helpers = tv_help_env;
             static const int tv_help_min_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_MIN"); return e ? atoi(e) : 192; }();
             static const int tv_help_n_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_N"); return e ? atoi(e) : 1; }();
-            cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env;
+            cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env; cf.tv_help_shift = tv_shift_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {
                 std::lock_guard<std::mutex> lk(g_p1_launch_mu);
-                if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                if constexpr (kTvDedicatedHelpers) { if (nw_launch == 8) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); }
+                if (nw_launch == 8) {}
+                else if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 else if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
+                if constexpr (kTvDedicatedHelpers) { if (nw_launch == 8) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<8>, dim3(blocks), dim3(WAVE * 8), smem, h->stream, cf); }
+                if (nw_launch == 8) {}
+                else if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
                 else if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
                 else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
                 HIPCHK(hipGetLastError());
@@ -1737,7 +1763,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
-            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }

@@ -21,10 +21,13 @@ __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align6
 
 struct TLayout {
     int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (one per wave); npools: parts of the 3x1 pool (1, 3 or 4)
-    size_t offV, offS, offM, offJM, offJV, offJS, total;
+    size_t offV, offS, offM, offJM, offJV, offJS, offH, total;
     int idV, idS, idM, idJM, idJV, idJS;
 };
-__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves) {
+// scratch slot of a dedicated helper wave (pz_tv.h serve_loop): a 3x1 work slot with 16 partial-sum rows where the header rows are
+__host__ __device__ inline size_t tv_helper_slot_bytes(int cap) { return tv_slot_bytes(cap, 3) + (size_t)4 * 64 * sizeof(double); }
+// nwaves: the waves that play roles (1, 3 or 4); nhelp: dedicated helper waves behind them (0, or 4 in an eight-wave block)
+__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves, int nhelp = 0) {
     TLayout L;
     const int nroles = nwaves;   // (a four-wave block builds the JRS on all four waves)
     L.nroles = nroles; L.npools = nwaves;
@@ -38,7 +41,8 @@ __host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwav
     L.offJM = L.offM + (size_t)kTvNM * tv_slot_bytes(capW, 9);
     L.offJV = L.offJM + (size_t)L.nJM * tv_slot_bytes(kCapSmall, 9);
     L.offJS = L.offJV + (size_t)L.nJV * tv_slot_bytes(kCapSmall, 3);
-    L.total = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1));
+    L.offH = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1));
+    L.total = align64(L.offH + (size_t)nhelp * tv_helper_slot_bytes(capW));
     L.idV = 0; L.idS = L.idV + L.nV; L.idM = L.idS + kTvNS; L.idJM = L.idM + kTvNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
     return L;
 }
@@ -79,7 +83,10 @@ struct TChain {
     __device__ void prof_waited(long long) {}
     __device__ void prof_forward_done() {}
 #endif
-    __device__ void bar() const { __syncthreads(); }
+    __device__ void bar() {   // (a dedicated helper joins every block barrier of its primary)
+        if (w.hded) tv::hj_post_ctl(w, tv::HK_BAR);
+        __syncthreads();
+    }
     __device__ void post(int slot, const TPZ& p) const { if (w.w.lane == 0) mb[slot] = p.id - L.idV; }
     __device__ TPZ take(int slot) const { return V(mb[slot]); }
     __device__ TPZ V(int i) const { return mk_tslot(arena, L.offV, i, capW, 3, L.idV); }
@@ -88,6 +95,15 @@ struct TChain {
     __device__ TPZ JM(int i) const { return mk_tslot(arena, L.offJM, i, kCapSmall, 9, L.idJM); }
     __device__ TPZ JV(int i) const { return mk_tslot(arena, L.offJV, i, kCapSmall, 3, L.idJV); }
     __device__ TPZ JS(int i) const { return mk_tslot(arena, L.offJS, i, kCapSmall, 1, L.idJS); }
+    __device__ TPZ H(int i) const {   // helper wave i's scratch slot (no entry in the count table: only its keys, rows and partial-sum rows are used)
+        GLB_AS unsigned char* p = arena + L.offH + (size_t)i * tv_helper_slot_bytes(capW);
+        TPZ z;
+        z.keys = (GLB_AS uint64_t*)p;
+        z.hdr = (GLB_AS double*)(p + align64((size_t)(capW + 1) * 8));
+        z.coef = z.hdr + (size_t)16 * 64;
+        z.sz = 3; z.cap = capW; z.id = 0;
+        return z;
+    }
     __device__ TPZ R(int i) const { return JM(i); }
     __device__ TPZ Rt(int i) const { return JM(J + 1 + i); }
     __device__ int scratch(int r) const { return L.nroles == 1 ? 0 : r; }
@@ -411,7 +427,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 __host__ __device__ inline size_t tv_lds_fixed(int cap_key, int cap_raw) { return ((size_t)cap_key * 8 + (size_t)cap_raw * 2 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t tv_lds_fixed(int cap) { return tv_lds_fixed(cap, cap); }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
-__host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kMbWords) * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kTvMbWords) * sizeof(int) + 15) & ~(size_t)15; }
 // sort buffers of the forward-kinematics wave of a four-wave block: its own products have <= 0.9 k raw terms; the omega recursion it also
 // carries has rotation x vector products, which are ranked (<= 4 runs over the vector's keys) and need room for the permutation only
 constexpr int kTvFkCap = 1024, kTvFkCapRaw = 2048;
@@ -428,34 +444,38 @@ __host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stag
 // items [0, n_items): the RNEA of a group; with fk_items > 0, items [n_items, n_items + fk_items) are the forward kinematics
 // of group (it - n_items) -- it shares nothing with the RNEA but the JRS rotations, which it rebuilds -- and the first n_items
 // then leave it out (the same split as the per-step kernel's).
+// NW = 8: four role waves and a dedicated helper wave behind each (pz_tv.h "Dedicated helpers"): two waves per SIMD.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) {
-    P1_PIN_ONE_WAVE_PER_SIMD();
+__global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg cf) {
+    P1_TV_PIN();
+    constexpr int NP = NW == 8 ? 4 : NW;   // the waves that play roles
     const int groups_per_problem = cf.tv_groups, lanes_per_group = cf.tv_lanes, capTv = cf.tv_cap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TChain c;
     c.cf = &cf;
     c.n = cf.n; c.J = cf.J;
     c.capW = capTv;
-    c.L = make_tlayout(cf.J, cf.n, capTv, NW);
+    c.L = make_tlayout(cf.J, cf.n, capTv, NP, NW == 8 ? 4 : 0);
     c.arena = (GLB_AS unsigned char*)cf.arena + (size_t)blockIdx.x * cf.arena_bytes;
-    c.nw = NW;
+    c.nw = NP;
     c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool helper_wave = NW == 8 && c.wid >= NP;
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
     // per wave: sort buffers | status | staging rows.  In a three-wave block wave 1 -- the angular recursion, whose products all
     // have a joint rotation (36 rows) as the short operand and which is the busiest role -- gets the larger staging area.
-    const int my_stage = (NW == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
-    const bool fk_bufs = NW == 4 && c.wid == 3;
+    const int my_stage = (NP == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
+    const bool fk_bufs = NP == 4 && c.wid == 3;
     const int my_cap_key = fk_bufs ? kTvFkCap : cf.capKey, my_cap_raw = fk_bufs ? kTvFkCapRaw : cf.capKey;
     // waves 0..2: [sort buffers (cap) | status | staging]; wave 3 of a four-wave block: the same with the smaller buffers
-    const int stage_before = NW == 1 ? 0 : (c.wid > 0 ? cf.tv_stage_rows_other : 0) + (c.wid > 1 ? cf.tv_stage_rows : 0) + (c.wid > 2 ? cf.tv_stage_rows_other : 0);
-    LDS_AS unsigned char* mine = lds + (size_t)min(c.wid, 3) * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
+    const int lw = min(c.wid, 3);   // (a helper wave has no buffers of its own: the address below is not used)
+    const int stage_before = NP == 1 ? 0 : (lw > 0 ? cf.tv_stage_rows_other : 0) + (lw > 1 ? cf.tv_stage_rows : 0) + (lw > 2 ? cf.tv_stage_rows_other : 0);
+    LDS_AS unsigned char* mine = lds + (size_t)lw * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
     c.w.w.skey = (LDS_AS uint64_t*)mine;
     c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
     c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
     c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap_key, my_cap_raw));
     c.w.stage_rows = my_stage;
-    LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NW) - tv_lds_shared();
+    LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NP) - tv_lds_shared();
     c.w.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.w.cnt + kMaxSlots;
     c.w.w.cap_raw = my_cap_raw;
@@ -464,7 +484,18 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
     c.w.w.thr_sq = pzw::sq_threshold(c.w.w.thr);
     c.w.w.lane = threadIdx.x & 63;
     const int lane = c.w.w.lane;
+    if constexpr (NW == 8) {
+        // channel p: role wave p -> helper wave NP + (p + shift) % NP (which SIMD a wave lands on is the dispatcher's choice; the shift is a tuning knob)
+        const int shift = cf.tv_help_shift & 3;
+        const int p = helper_wave ? ((c.wid - NP - shift) & 3) : c.wid;
+        if (helper_wave) c.w.w.lstat = c.mb + kHelpStat + (c.wid - NP) * pzw::ST_WORDS;
+        if (threadIdx.x < kHelpChannels * tv::HJ_WORDS) c.mb[kHelpBase + threadIdx.x] = 0;
+        c.w.hch = c.mb + kHelpBase + p * tv::HJ_WORDS;
+        c.w.hded = true; c.w.hseq = 0;
+        c.w.hnum = cf.tv_walk_helpers > 1 ? cf.tv_walk_helpers : 16; c.w.hmin = cf.tv_help_min;
+    }
     if (lane < pzw::ST_WORDS) c.w.w.lstat[lane] = 0;
+    if constexpr (NW == 8) __syncthreads();   // the channels are empty before anybody posts or polls
     for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
         const bool fk_only = it0 >= cf.n_items;
         const int it = fk_only ? it0 - cf.n_items : it0;
@@ -473,11 +504,14 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
         const int nl = min(lanes_per_group, cf.T - t0);
         c.w.active = lane < nl;
         const int t_lane = t0 + min(lane, nl - 1);  // idle lanes shadow the group's last step; they never write
+        if constexpr (NW == 8) {
+            if (helper_wave) { tv::serve_loop(c.w, c.H(c.wid - NP)); continue; }   // until the primary's HK_EXIT at the end of the item
+        }
         c.freeV = (1ull << c.L.nV) - 1ull;
         c.freeS = (1u << kTvNS) - 1u;
         c.role = 0;
-        for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.w.cnt[i] = 0;
-        __syncthreads();
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NP) c.w.w.cnt[i] = 0;
+        c.bar();
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
         c.w.c_wait = c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
         for (int q = 0; q < 3; q++) { c.w.c_type[q] = 0; c.w.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane, fk_only);
-        __syncthreads();
+        c.bar();
 #ifdef TV_PROFILE
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] jrs %lld cycles\n", it, (long long)clock64() - tvp_start);
 #endif
@@ -499,24 +533,25 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_tv_kernel(P1Cfg cf) 
                 c.freeVs(fk.T);
             }
         } else {
-            if (NW >= kRoles && cf.tv_free_running) run_rnea_free(c, u_nom, b, t_lane);
+            if (NP >= kRoles && cf.tv_free_running) run_rnea_free(c, u_nom, b, t_lane);
             else run_rnea(c, u_nom, b, t_lane);
 #ifdef TV_PROFILE
             const long long tvp_rnea = clock64();
 #endif
-            if (NW >= kRoles && cf.tv_free_running) {   // every wave takes its share of the joints' tables (the 1x1 slots of u_nom: the mailbox, past the last barrier of the RNEA)
+            if (NP >= kRoles && cf.tv_free_running) {   // every wave takes its share of the joints' tables (the 1x1 slots of u_nom: the mailbox, past the last barrier of the RNEA)
                 for (int j = 0; j < c.n; j++) u_nom[j] = c.S(t3_ld(&c.mb[T3_U + j]));
-                finish_torque_tv(c, u_nom, b, t_lane, c.wid, NW);
+                finish_torque_tv(c, u_nom, b, t_lane, c.wid, NP);
             } else if (c.is(0)) finish_torque_tv(c, u_nom, b, t_lane, 0, 1);
 #ifdef TV_PROFILE
             if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] rnea done at %lld, torque tables %lld cycles\n", it, c.wid, tvp_rnea - tvp_start, (long long)clock64() - tvp_rnea);
 #endif
         }
-        __syncthreads();
+        c.bar();
+        if constexpr (NW == 8) tv::hj_post_ctl(c.w, tv::HK_EXIT);
 #ifdef TV_PROFILE
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
 #ifdef TV_PROFILE_FULL
-        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, process phase %lld, chunk prologue %lld cycles, %lld batches\n", it, tv::g_tvprof[0], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3]);
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, wait for the loads %lld, process phase %lld, chunk prologue %lld cycles, %lld batches, %lld terms\n", it, tv::g_tvprof[0], tv::g_tvprof[4], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3], tv::g_tvprof[5]);
 #endif
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] shared walks: %lld jobs, %lld raw terms; waited %lld cycles on the helper channel\n", it, c.wid, c.w.n_shared, c.w.n_shared_terms, c.w.c_hwait);
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld, %lld of it in the forward pass; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_wait_fwd, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);

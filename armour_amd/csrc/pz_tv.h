@@ -58,6 +58,7 @@ struct TW {
     int hseq = 0;          // jobs posted (primary) / served (helper) on that channel so far
     int hnum = 16;         // the primary keeps hnum / 32 of a shared walk's terms
     int hmin = 192;        // walks with fewer sorted terms stay on one wave (two hand-overs cost more than half of such a walk)
+    bool hded = false;     // the channel belongs to a DEDICATED helper wave (eight-wave blocks, below): it serves whatever is posted, nothing is counted
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
     long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0, c_hwait = 0, n_shared = 0, n_shared_terms = 0;
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
@@ -94,7 +95,14 @@ enum { HJ_SEQ = 0, HJ_WALKED, HJ_N0SEQ, HJ_DONE,           // progress words (se
        HJ_TMP_COEF = HJ_HDR + 2,
        HJ_SEG0 = 24, HJ_SEG_WORDS = 8,                      // per source: coef address (2), cnt, stride, off, comp, scale (2)
        HJ_WORDS = HJ_SEG0 + 4 * HJ_SEG_WORDS };
-enum { HK_NONE = 0, HK_MUL_3331_A_STAGED = 1, HK_LIN2 = 2, HK_LIN4_CHAIN = 3 };
+enum { HK_NONE = 0, HK_MUL_3331_A_STAGED = 1, HK_LIN2 = 2, HK_LIN4_CHAIN = 3,
+       // kinds only a dedicated helper serves (its scratch slot has room for their partial sums)
+       HK_MUL_3331_UNSTAGED = 4, HK_MUL_3331_B_STAGED = 5, HK_LIN3_CHAIN = 6, HK_CROSS_UNSTAGED = 7, HK_CROSS_A_STAGED = 8, HK_CROSS_B_STAGED = 9, HK_CROSS_CONST = 10,
+       HK_BAR = 100, HK_EXIT = 101 };   // control: join the block barrier the primary is about to enter / this item is over
+// Dedicated helpers.  A block of EIGHT waves -- two per SIMD, which the operators' 256 vector registers allow -- gives each of the four role
+// waves a helper of its own for the whole item: the helper sits in serve_loop() on its primary's channel, walks the upper part of every
+// operator large enough to share, mirrors the primary's block barriers (HK_BAR) and leaves at HK_EXIT.  What a lone wave cannot hide -- the
+// latency between its own dependent instructions, an LDS read, a row load -- the SIMD fills with the other wave's instructions.
 
 __device__ inline int lds_ld(LDS_AS int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void lds_st_ptr(LDS_AS int* p, const GLB_AS void* q) { const uint64_t v = (uint64_t)q; p[0] = (int)(unsigned)v; p[1] = (int)(unsigned)(v >> 32); }
@@ -208,7 +216,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
         // the source selection with scalar selects per term (measured on lincomb<3, 4>: 35 of the ~110 instructions per raw term)
         const typename P::Desc dv = pol.describe(idx_v);
 #ifdef TV_PROFILE_FULL
-        { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[2] += x - wp0; wp0 = x; }
+        { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd((unsigned long long*)&g_tvprof[2], (unsigned long long)(x - wp0)); wp0 = x; }
 #endif
         for (int l0 = 0; l0 < n; l0 += U) {
             typename P::Regs regs[U];
@@ -218,7 +226,17 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                 pol.load(dv, l, __builtin_amdgcn_readlane(idx_v, l), regs[u]);
             }
 #ifdef TV_PROFILE_FULL
-            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) { g_tvprof[0] += x - wp0; g_tvprof[3] += 1; } wp0 = x; }
+            {   // (profile build only: the wait for the row loads on its own, and the counters' own traffic drained before the process phase is timed)
+                const long long x0 = clock64();
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const long long x1 = clock64();
+                if (lane == 0 && blockIdx.x == 0) {
+                    atomicAdd((unsigned long long*)&g_tvprof[0], (unsigned long long)(x0 - wp0)); atomicAdd((unsigned long long*)&g_tvprof[4], (unsigned long long)(x1 - x0));
+                    atomicAdd((unsigned long long*)&g_tvprof[3], 1ull); atomicAdd((unsigned long long*)&g_tvprof[5], (unsigned long long)min(U, n - l0));
+                }
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wp0 = clock64();
+            }
 #endif
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -230,7 +248,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                 }
             }
 #ifdef TV_PROFILE_FULL
-            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) g_tvprof[1] += x - wp0; wp0 = x; }
+            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd((unsigned long long*)&g_tvprof[1], (unsigned long long)(x - wp0)); wp0 = x; }
 #endif
         }
     }
@@ -272,18 +290,46 @@ struct MulCtx {
     Out<SH::SZ>* o;
     const LDS_AS double* stage;
     double acc[SH::SZ], rad[SH::SZ];
-    struct Regs { double ca[STAGE == 1 ? 1 : SH::ASZ], cb[STAGE == 2 ? 1 : SH::BSZ]; int i, j; };
+    struct Regs { double ca[STAGE == 1 ? 1 : SH::ASZ], cb[STAGE == 2 ? 1 : SH::BSZ]; int i, j; };   // i, j: the staged operand's term index (rows in LDS)
     static constexpr int kRegDoubles = (STAGE == 1 ? 0 : SH::ASZ) + (STAGE == 2 ? 0 : SH::BSZ);
     static constexpr int kU = kRegDoubles <= 3 ? 16 : kRegDoubles <= 6 ? 8 : kRegDoubles <= 9 ? 6 : 4;  // terms whose row loads are in flight together
-    struct Desc {};
-    __device__ inline Desc describe(int) const { return Desc{}; }
-    __device__ inline void load(const Desc&, int, int idx, Regs& r) const { load(idx, r); }
+    // per-lane descriptors of the chunk's terms (lane l describes the chunk's l-th sorted term): the index split and the row addresses are
+    // worked out for 64 terms at once on the vector unit; per term the serial loop then needs a few v_readlane instead of a chain of
+    // twenty dependent scalar instructions (split by magic multiply, 64-bit address arithmetic) in front of every term's loads
+    struct Desc { unsigned alo, ahi, blo, bhi; int i, j; };
+    __device__ inline Desc describe(int idx_lane) const {
+        Desc d;
+        const int t = idx_lane + 1;
+        const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
+        d.i = i; d.j = j;
+        const uint64_t pa = (uint64_t)(a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE);   // i = 0: the centre rows, stored right before the coefficients
+        const uint64_t pb = (uint64_t)(b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * WAVE);
+        d.alo = (unsigned)pa; d.ahi = (unsigned)(pa >> 32); d.blo = (unsigned)pb; d.bhi = (unsigned)(pb >> 32);
+        return d;
+    }
+    __device__ inline void load(const Desc& d, int l, int, Regs& r) const {
+        if constexpr (STAGE == 1) r.i = __builtin_amdgcn_readlane(d.i, l);
+        if constexpr (STAGE == 2) r.j = __builtin_amdgcn_readlane(d.j, l);
+        if constexpr (STAGE != 1) {
+            const uint64_t pa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.ahi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.alo, l);
+            const GLB_AS double* p = (const GLB_AS double*)pa + lane;
+#pragma unroll
+            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = p[e * WAVE];
+        }
+        if constexpr (STAGE != 2) {
+            const uint64_t pb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.bhi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.blo, l);
+            const GLB_AS double* p = (const GLB_AS double*)pb + lane;
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = p[e * WAVE];
+        }
+    }
+    // (generation index known as a scalar: the ordered pass of a product with a constant left operand)
     __device__ inline void load(int idx, Regs& r) const {
         const int t = idx + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
         r.i = i; r.j = j;
         if constexpr (STAGE != 1) {
-            const GLB_AS double* pa = a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE + lane;  // i = 0: the centre rows, stored right before the coefficients
+            const GLB_AS double* pa = a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE + lane;
 #pragma unroll
             for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
         }
@@ -406,9 +452,17 @@ __device__ inline void hj_wait(TW& t, LDS_AS int* p, int v) {
 // (the channel holds ONE job: the helper acknowledges every job, also an empty one, in HJ_DONE, and the primary does not write the
 //  next job's words before the previous acknowledgement is in)
 __device__ inline void hj_post_none(TW& t) {
+    if (t.hded) return;   // (a dedicated helper counts nothing)
     hj_wait(t, &t.hch[HJ_DONE], t.hseq);
     t.hseq++;
     if (t.w.lane == 0) t.hch[HJ_KIND] = HK_NONE;
+    hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+}
+// control job for a dedicated helper (HK_BAR, HK_EXIT)
+__device__ inline void hj_post_ctl(TW& t, int kind) {
+    hj_wait(t, &t.hch[HJ_DONE], t.hseq);
+    t.hseq++;
+    if (t.w.lane == 0) t.hch[HJ_KIND] = kind;
     hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
 }
 // common part of a job: the range, the primary's sorted arrays, the result slot.  (Increments the job counter.)
@@ -518,40 +572,39 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         const bool can_a = a.off == 0 && a.sz == a.stride && stage_fits(t, a), can_b = b.off == 0 && b.sz == b.stride && stage_fits(t, b);
         constexpr bool kSplittable = (AR == 3 && AC == 3 && BR == 3 && BC == 1);   // rotation x vector: the products of the backward recursions
         const bool stage_a = (a_short && can_a) || (!can_b && can_a);
+        const int stage = stage_a ? 1 : can_b ? 2 : 0;
         bool shared = false;
         if constexpr (kSplittable) {
             if (t.hch != nullptr) {
-                if (stage_a && N >= t.hmin) shared = true; else hj_post_none(t);
+                if ((stage_a || t.hded) && N >= t.hmin) shared = true; else hj_post_none(t);   // (an opportunistic helper serves the staged-rotation form only)
             }
         }
-        if (stage_a) {
-            stage_rows_of(t, a, lane);
-            int S = N;
-            if constexpr (kSplittable) {
-                if (shared) {
-                    const Wave& w = t.w;
-                    S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
-                    hj_post_common(t, HK_MUL_3331_A_STAGED, S, N, indirect, out);
+        if (stage == 1) stage_rows_of(t, a, lane); else if (stage == 2) stage_rows_of(t, b, lane);
+        int S = N;
+        if constexpr (kSplittable) {
+            if (shared) {
+                const Wave& w = t.w;
+                S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
+                hj_post_common(t, stage == 1 ? HK_MUL_3331_A_STAGED : stage == 2 ? HK_MUL_3331_B_STAGED : HK_MUL_3331_UNSTAGED, S, N, indirect, out);
 #ifdef TV_PROFILE
-                    t.n_shared += 1; t.n_shared_terms += N;
+                t.n_shared += 1; t.n_shared_terms += N;
 #endif
-                    hj_post_seg(t, 0, a, 1.0, -1); hj_post_seg(t, 1, b, 1.0, -1);
-                    hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
-                }
-            }
-            mul_walk<SH, 1>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
-            if constexpr (kSplittable) {
-                if (shared) {
-                    const GLB_AS double* hdr;
-                    const int nh = hj_collect(t, o.n, hdr, out);
-#pragma unroll
-                    for (int e = 0; e < SZ; e++) { rad[e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane]; o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane]; }
-                    o.n += nh;
-                }
+                hj_post_seg(t, 0, a, 1.0, -1); hj_post_seg(t, 1, b, 1.0, -1);
+                hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
             }
         }
-        else if (can_b) { stage_rows_of(t, b, lane); mul_walk<SH, 2>(t, t.w, t.stage, 0, N, indirect, ev, a, b, &o, rad); }
-        else mul_walk<SH, 0>(t, t.w, t.stage, 0, N, indirect, ev, a, b, &o, rad);
+        if (stage == 1) mul_walk<SH, 1>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        else if (stage == 2) mul_walk<SH, 2>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        else mul_walk<SH, 0>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        if constexpr (kSplittable) {
+            if (shared) {
+                const GLB_AS double* hdr;
+                const int nh = hj_collect(t, o.n, hdr, out);
+#pragma unroll
+                for (int e = 0; e < SZ; e++) { rad[e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane]; o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane]; }
+                o.n += nh;
+            }
+        }
         TVP_END(t, N, o.n, 0)
     }
 #pragma unroll
@@ -577,22 +630,30 @@ struct CrossCtx {
     double acc[6], rad[12];  // radii: 6 products | 3 differences | 3 stack
     struct Regs { double ca[STAGE == 1 ? 1 : 3], cb[STAGE == 2 ? 1 : 3]; int i, j; };
     static constexpr int kU = STAGE == 0 ? 8 : 16;
-    struct Desc {};
-    __device__ inline Desc describe(int) const { return Desc{}; }
-    __device__ inline void load(const Desc&, int, int idx, Regs& r) const { load(idx, r); }
-    __device__ inline void load(int idx, Regs& r) const {
-        const int t = idx + 1;
+    struct Desc { unsigned alo, ahi, blo, bhi; int i, j; };   // (see MulCtx::Desc)
+    __device__ inline Desc describe(int idx_lane) const {
+        Desc d;
+        const int t = idx_lane + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
-        r.i = i; r.j = j;
+        d.i = i; d.j = j;
+        const uint64_t pa = (uint64_t)(a.coef + (ptrdiff_t)(i - 1) * 3 * WAVE), pb = (uint64_t)(b.coef + (ptrdiff_t)(j - 1) * 3 * WAVE);   // i, j = 0: the centre rows
+        d.alo = (unsigned)pa; d.ahi = (unsigned)(pa >> 32); d.blo = (unsigned)pb; d.bhi = (unsigned)(pb >> 32);
+        return d;
+    }
+    __device__ inline void load(const Desc& d, int l, int, Regs& r) const {
+        if constexpr (STAGE == 1) r.i = __builtin_amdgcn_readlane(d.i, l);
+        if constexpr (STAGE == 2) r.j = __builtin_amdgcn_readlane(d.j, l);
         if constexpr (STAGE != 1) {
-            const GLB_AS double* pa = a.coef + (ptrdiff_t)(i - 1) * 3 * WAVE + lane;  // i = 0: the centre rows
+            const uint64_t pa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.ahi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.alo, l);
+            const GLB_AS double* p = (const GLB_AS double*)pa + lane;
 #pragma unroll
-            for (int e = 0; e < 3; e++) r.ca[e] = pa[e * WAVE];
+            for (int e = 0; e < 3; e++) r.ca[e] = p[e * WAVE];
         }
         if constexpr (STAGE != 2) {
-            const GLB_AS double* pb = b.coef + (ptrdiff_t)(j - 1) * 3 * WAVE + lane;
+            const uint64_t pb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.bhi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.blo, l);
+            const GLB_AS double* p = (const GLB_AS double*)pb + lane;
 #pragma unroll
-            for (int e = 0; e < 3; e++) r.cb[e] = pb[e * WAVE];
+            for (int e = 0; e < 3; e++) r.cb[e] = p[e * WAVE];
         }
     }
     __device__ inline void add(const Regs& r, bool first) {
@@ -645,20 +706,21 @@ struct CrossCtx {
     }
 };
 
+// (sw, stage, [N0, N): as mul_walk)
 template <int STAGE>
-__device__ inline void cross_walk(TW& t, int N, bool indirect, const pzw::MulEval<pzw::MulShape<1, 1, 1, 1>>& ev, const TView& a, const TView& b, Out<3>* o, double* rad) {
+__device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* stage, int N0, int N, bool indirect, const pzw::MulEval<pzw::MulShape<1, 1, 1, 1>>& ev, const TView& a, const TView& b, Out<3>* o, double* rad) {
     CrossCtx<STAGE> cx;
     cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
     cx.a.coef = uni_ptr(a.coef); cx.b.coef = uni_ptr(b.coef);
-    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = stage;
 #pragma unroll
     for (int e = 0; e < 6; e++) cx.acc[e] = 0.0;
 #pragma unroll
     for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
-    const Wave& w = t.w;
-    const int lane = w.lane;
-    if (indirect) walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx);
-    else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx);
+    const Wave& w = sw;
+    const int lane = t.w.lane;
+    if (indirect) walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
+    else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
     for (int e = 0; e < 12; e++) rad[e] = cx.rad[e];
 }
@@ -703,9 +765,33 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     {
         const bool a_short = a.cnt <= b.cnt;
         const bool can_a = stage_fits(t, a), can_b = stage_fits(t, b);
-        if ((a_short && can_a) || (!can_b && can_a)) { stage_rows_of(t, a, lane); cross_walk<1>(t, N, indirect, ev, a, b, &o, rad); }
-        else if (can_b) { stage_rows_of(t, b, lane); cross_walk<2>(t, N, indirect, ev, a, b, &o, rad); }
-        else cross_walk<0>(t, N, indirect, ev, a, b, &o, rad);
+        const int stage = ((a_short && can_a) || (!can_b && can_a)) ? 1 : can_b ? 2 : 0;
+        if (stage == 1) stage_rows_of(t, a, lane); else if (stage == 2) stage_rows_of(t, b, lane);
+        // a dedicated helper walks the upper part of the sorted terms (whole-PZ 3x1 operands)
+        const bool shared = t.hch != nullptr && t.hded && N >= t.hmin;
+        int S = N;
+        if (shared) {
+            const Wave& w = t.w;
+            S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
+            hj_post_common(t, stage == 1 ? HK_CROSS_A_STAGED : stage == 2 ? HK_CROSS_B_STAGED : HK_CROSS_UNSTAGED, S, N, indirect, out);
+#ifdef TV_PROFILE
+            t.n_shared += 1; t.n_shared_terms += N;
+#endif
+            hj_post_seg(t, 0, a, 1.0, -1); hj_post_seg(t, 1, b, 1.0, -1);
+            hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+        }
+        if (stage == 1) cross_walk<1>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        else if (stage == 2) cross_walk<2>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        else cross_walk<0>(t, t.w, t.stage, 0, S, indirect, ev, a, b, &o, rad);
+        if (shared) {   // the helper's partial radii: rows 0..11 of its partial-sum block, |coefficient| sums in rows 12..14
+            const GLB_AS double* hdr;
+            const int nh = hj_collect(t, o.n, hdr, out);
+#pragma unroll
+            for (int e = 0; e < 12; e++) rad[e] += hdr[(size_t)e * WAVE + lane];
+#pragma unroll
+            for (int e = 0; e < 3; e++) o.asum[e] += hdr[(size_t)(12 + e) * WAVE + lane];
+            o.n += nh;
+        }
     }
     TVP_END(t, N, o.n, 1)
 #pragma unroll
@@ -917,15 +1003,16 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     const Wave& w = t.w;
     constexpr int kU = SZ <= 3 ? 8 : 4;
     // the sums of the backward recursions (f = R f + F; n = ((N + R n) + c x F) + p x R f) share their walk with an idle wave
-    constexpr bool kSplittable = SZ == 3 && ((NS == 2 && !CHAIN) || (NS == 4 && CHAIN));
+    // (the three-term chained sums of the forward pass: with a dedicated helper only)
+    constexpr bool kSplittable = SZ == 3 && ((NS == 2 && !CHAIN) || (NS == 4 && CHAIN) || (NS == 3 && CHAIN));
     bool shared = false;
     int S = N;
     if constexpr (kSplittable) {
-        if (t.hch != nullptr) {
+        if (t.hch != nullptr && (NS != 3 || t.hded)) {
             if (N >= t.hmin) {
                 shared = true;
                 S = indirect ? split_point(N, t.hnum, 32, [&](int p) { return ev.key_lds(w, w.sidx[p]); }) : split_point(N, t.hnum, 32, [&](int p) { return w.skey[p]; });
-                hj_post_common(t, CHAIN ? HK_LIN4_CHAIN : HK_LIN2, S, N, indirect, out);
+                hj_post_common(t, !CHAIN ? HK_LIN2 : NS == 4 ? HK_LIN4_CHAIN : HK_LIN3_CHAIN, S, N, indirect, out);
 #ifdef TV_PROFILE
                 t.n_shared += 1; t.n_shared_terms += N;
 #endif
@@ -946,7 +1033,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
                 if constexpr (CHAIN) {
                     cx.ra[1][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
                     cx.ra[2][e] += hdr[((size_t)H_IND2 * SZ + e) * WAVE + lane];
-                    cx.ra[3][e] += hdr[((size_t)H_CEN * SZ + e) * WAVE + lane];
+                    if constexpr (NS == 4) cx.ra[3][e] += hdr[((size_t)H_CEN * SZ + e) * WAVE + lane];
                 } else cx.ra[0][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
                 o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane];
             }
@@ -976,143 +1063,16 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The helper's side of a shared walk ("One walk on two waves" above): wait for the primary's next operator on this wave's channel;
-// if it shares its walk, walk the upper part of its sorted terms into `tmp` (a scratch slot of this wave), leave the partial sums in
-// tmp's header rows, and move the rows down behind the primary's once it has posted its count.
-__device__ inline TView hj_seg_view(LDS_AS int* ch, int k, int sz) {
-    LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
-    TView v;
-    v.keys = nullptr; v.hdr = nullptr;
-    v.coef = lds_ld_ptr<const GLB_AS double>(&sg[0]);
-    v.cnt = uni(sg[2]); v.stride = uni(sg[3]); v.off = uni(sg[4]); v.sz = sz;
-    return v;
-}
-__device__ TV_NOINLINE void serve_walk(TW& t, const TPZ& tmp) {
-    LDS_AS int* ch = t.hch;
-    const int lane = t.w.lane;
-    t.hseq++;
-    hj_wait(t, &ch[HJ_SEQ], t.hseq);
-    const int kind = uni(ch[HJ_KIND]);
-    if (kind == HK_NONE) { hj_signal(t, &ch[HJ_DONE], t.hseq); return; }
-    const int S = uni(ch[HJ_S]), N = uni(ch[HJ_N]);
-    const bool indirect = uni(ch[HJ_INDIRECT]) != 0;
-    Wave sw = t.w;   // the PRIMARY's sorted terms
-    sw.skey = (LDS_AS uint64_t*)(uintptr_t)(unsigned)uni(ch[HJ_SKEY]);
-    sw.sidx = (LDS_AS uint16_t*)(uintptr_t)(unsigned)uni(ch[HJ_SIDX]);
-    Out<3> o;
-    o.init(tmp, lane);
-    double part[4][3];   // header rows of tmp: [H_IND] [H_IND2] [H_ASUM] [H_CEN]
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int e = 0; e < 3; e++) part[q][e] = 0.0;
-    if (kind == HK_MUL_3331_A_STAGED) {
-        typedef pzw::MulShape<3, 3, 3, 1> SH;
-        const TView a = hj_seg_view(ch, 0, 9), b = hj_seg_view(ch, 1, 3);
-        pzw::MulEval<SH> ev;
-        ev.a = kview(a); ev.set_b(kview(b));
-        const LDS_AS double* stage = (const LDS_AS double*)(uintptr_t)(unsigned)uni(ch[HJ_STAGE]);
-        mul_walk<SH, 1>(t, sw, stage, S, N, indirect, ev, a, b, &o, part[H_IND]);
-    } else if (kind == HK_LIN2) {
-        LinCtx<3, 2, false> cx;
-        pzw::LinEval<3, 2> ev;   // (key_lds reads the primary's key buffer only)
-        int tot = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
-            cx.s[k].v = hj_seg_view(ch, k, 3); cx.s[k].comp = uni(sg[5]);
-            cx.s[k].scale = __longlong_as_double((long long)(((uint64_t)(unsigned)sg[7] << 32) | (unsigned)sg[6]));
-            cx.off[k] = tot; tot += cx.s[k].v.cnt;
-        }
-        cx.off[2] = tot;
-        cx.lane = lane; cx.prepare();
-        cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
-#pragma unroll
-        for (int e = 0; e < 3; e++) { cx.acc[e] = 0.0; cx.ra[0][e] = 0.0; cx.ra[1][e] = 0.0; }
-        if (indirect) walk_sorted<8>(lane, N, [&](int p) { return ev.key_lds(sw, sw.sidx[p]); }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
-        else walk_sorted<8>(lane, N, [&](int p) { return sw.skey[p]; }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
-#pragma unroll
-        for (int e = 0; e < 3; e++) part[H_IND][e] = cx.ra[0][e];
-    } else {
-        LinCtx<3, 4, true> cx;
-        pzw::LinEval<3, 4> ev;
-        int tot = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
-            cx.s[k].v = hj_seg_view(ch, k, 3); cx.s[k].comp = uni(sg[5]);
-            cx.s[k].scale = __longlong_as_double((long long)(((uint64_t)(unsigned)sg[7] << 32) | (unsigned)sg[6]));
-            cx.off[k] = tot; tot += cx.s[k].v.cnt;
-        }
-        cx.off[4] = tot;
-        cx.lane = lane; cx.prepare();
-        cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
-#pragma unroll
-        for (int e = 0; e < 3; e++) cx.acc[e] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int e = 0; e < 3; e++) cx.ra[k][e] = 0.0;
-        if (indirect) walk_sorted<8>(lane, N, [&](int p) { return ev.key_lds(sw, sw.sidx[p]); }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
-        else walk_sorted<8>(lane, N, [&](int p) { return sw.skey[p]; }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
-#pragma unroll
-        for (int e = 0; e < 3; e++) { part[H_IND][e] = cx.ra[1][e]; part[H_IND2][e] = cx.ra[2][e]; part[H_CEN][e] = cx.ra[3][e]; }
-    }
-#pragma unroll
-    for (int e = 0; e < 3; e++) part[H_ASUM][e] = o.asum[e];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int e = 0; e < 3; e++) st_hdr(tmp, q, e, lane, part[q][e]);
-    const int nh = uni(o.n < tmp.cap ? o.n : tmp.cap);
-    if (o.n > tmp.cap) pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW);
-    if (lane == 0) { ch[HJ_NH] = nh; lds_st_ptr(&ch[HJ_HDR], tmp.hdr); lds_st_ptr(&ch[HJ_TMP_COEF], tmp.coef); }
-    hj_signal(t, &ch[HJ_WALKED], t.hseq);
-    // ... and once the primary has finished its part: our rows behind its n0
-    hj_wait(t, &ch[HJ_N0SEQ], t.hseq);
-    const int n0 = uni(ch[HJ_N0]), cap = uni(ch[HJ_OUT_CAP]);
-    GLB_AS uint64_t* ok = lds_ld_ptr<GLB_AS uint64_t>(&ch[HJ_OUT_KEYS]);
-    GLB_AS double* oc = lds_ld_ptr<GLB_AS double>(&ch[HJ_OUT_COEF]);
-    const int room = cap - n0 > 0 ? cap - n0 : 0, ncopy = nh < room ? nh : room;   // (an overflow of the result is flagged by the primary's finish())
-    for (int m = lane; m < ncopy; m += WAVE) ok[n0 + m] = tmp.keys[m];
-    move_rows(tmp.coef + lane, oc + (size_t)n0 * 3 * WAVE + lane, (ncopy * 3) / 2, ncopy * 3);   // (the primary moves the lower half)
-    hj_signal(t, &ch[HJ_DONE], t.hseq);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // cross of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167): out[c] = sA[c]*a[cA[c]] +
 // sB[c]*a[cB[c]]; the key list is a's, so one ordered pass (see pz_wave.h cross_const for the two simplify() stages)
-__device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
+// (monomials [m_lo, m_hi) of a: the whole list, or the part of it one of two waves takes)
+__device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, int m_hi, const double* sA, const int* cA, const double* sB, const int* cB, Out<3>& o, double* ra1, double* ra2) {
     const int lane = t.w.lane;
-    TView a = a_;
-    a.cnt = uni(a.cnt);
     const double thr = t.w.thr, thr_sq = t.w.thr_sq;
     const bool active = t.active;
-    double x0[3], cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
-    double i0[3], j0[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { x0[c] = ld_hdr(a, H_CEN, c, lane); i0[c] = ld_hdr(a, H_IND, c, lane); j0[c] = ld_hdr(a, H_IND2, c, lane); }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        double xa = 0, xb = 0, ia = 0, ib = 0, ja = 0, jb = 0;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (q == cA[c]) { xa = x0[q]; ia = i0[q]; ja = j0[q]; }
-            if (q == cB[c]) { xb = x0[q]; ib = i0[q]; jb = j0[q]; }
-        }
-        cen[c] = sA[c] * xa + sB[c] * xb;
-        ind[c] = ia * fabs(sA[c]) + ib * fabs(sB[c]);
-        ind2[c] = ja * fabs(sA[c]) + jb * fabs(sB[c]);
-    }
-    WSYNC();
-    Out<3> o;
-    o.init(out, lane);
-#ifdef TV_PROFILE_FULL
-    const long long cc0__ = clock64();
-#endif
-    for (int m0 = 0; m0 < a.cnt; m0 += WAVE) {
-        const uint64_t key_v = m0 + lane < a.cnt ? a.keys[m0 + lane] : 0ull;
-        const int n = min(WAVE, a.cnt - m0);
+    for (int m0 = m_lo; m0 < m_hi; m0 += WAVE) {
+        const uint64_t key_v = m0 + lane < m_hi ? a.keys[m0 + lane] : 0ull;
+        const int n = min(WAVE, m_hi - m0);
         for (int l0 = 0; l0 < n; l0 += 16) {
             double x[16][3];
 #pragma unroll
@@ -1146,6 +1106,60 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
             }
         }
     }
+}
+__device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
+    const int lane = t.w.lane;
+    TView a = a_;
+    a.cnt = uni(a.cnt);
+    double x0[3], cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
+    double i0[3], j0[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { x0[c] = ld_hdr(a, H_CEN, c, lane); i0[c] = ld_hdr(a, H_IND, c, lane); j0[c] = ld_hdr(a, H_IND2, c, lane); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double xa = 0, xb = 0, ia = 0, ib = 0, ja = 0, jb = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q == cA[c]) { xa = x0[q]; ia = i0[q]; ja = j0[q]; }
+            if (q == cB[c]) { xb = x0[q]; ib = i0[q]; jb = j0[q]; }
+        }
+        cen[c] = sA[c] * xa + sB[c] * xb;
+        ind[c] = ia * fabs(sA[c]) + ib * fabs(sB[c]);
+        ind2[c] = ja * fabs(sA[c]) + jb * fabs(sB[c]);
+    }
+    WSYNC();
+    Out<3> o;
+    o.init(out, lane);
+#ifdef TV_PROFILE_FULL
+    const long long cc0__ = clock64();
+#endif
+    // a dedicated helper takes the upper part of a's monomials (the key list is a's: no sort, the split is one of the list)
+    const bool shared = t.hch != nullptr && t.hded && 2 * a.cnt >= t.hmin;
+    int S = a.cnt;
+    if (shared) {
+        S = uni((int)((long long)a.cnt * t.hnum / 32));
+        hj_post_common(t, HK_CROSS_CONST, S, a.cnt, false, out);
+        hj_post_seg(t, 0, a, 1.0, -1);
+        if (lane == 0) {
+            LDS_AS int* sg = t.hch + HJ_SEG0 + HJ_SEG_WORDS;   // source 1: a's key list, the last component indices; sources 2, 3: the scales and the other indices
+            lds_st_ptr(&sg[0], a.keys); sg[2] = cA[2]; sg[3] = cB[2];
+            for (int q = 0; q < 3; q++) {
+                const uint64_t ua = (uint64_t)__double_as_longlong(sA[q]), ub = (uint64_t)__double_as_longlong(sB[q]);
+                sg[HJ_SEG_WORDS + 2 * q] = (int)(unsigned)ua; sg[HJ_SEG_WORDS + 2 * q + 1] = (int)(unsigned)(ua >> 32);
+                sg[2 * HJ_SEG_WORDS + 2 * q] = (int)(unsigned)ub; sg[2 * HJ_SEG_WORDS + 2 * q + 1] = (int)(unsigned)(ub >> 32);
+            }
+            sg[HJ_SEG_WORDS + 6] = cA[0]; sg[HJ_SEG_WORDS + 7] = cA[1]; sg[2 * HJ_SEG_WORDS + 6] = cB[0]; sg[2 * HJ_SEG_WORDS + 7] = cB[1];
+        }
+        hj_signal(t, &t.hch[HJ_SEQ], t.hseq);
+    }
+    cross_const_range(t, a, 0, S, sA, cA, sB, cB, o, ra1, ra2);
+    if (shared) {   // the helper's partial sums: rows 0..2 first stage, 3..5 second stage, 6..8 |coefficient|
+        const GLB_AS double* hdr;
+        const int nh = hj_collect(t, o.n, hdr, out);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { ra1[c] += hdr[(size_t)c * WAVE + lane]; ra2[c] += hdr[(size_t)(3 + c) * WAVE + lane]; o.asum[c] += hdr[(size_t)(6 + c) * WAVE + lane]; }
+        o.n += nh;
+    }
 #ifdef TV_PROFILE_FULL
     t.c_cc += clock64() - cc0__;
 #endif
@@ -1156,6 +1170,148 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
         st_hdr(out, H_IND2, c, lane, (ind2[c] + ra1[c]) + ra2[c]);
     }
     o.finish(t, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The helper's side of a shared walk ("One walk on two waves" above): wait for the primary's next operator on this wave's channel;
+// if it shares its walk, walk the upper part of its sorted terms into `tmp` (a scratch slot of this wave), leave the partial sums in
+// tmp's header rows, and move the rows down behind the primary's once it has posted its count.  Returns the job's kind.
+// (tmp.hdr: 12 rows in a 3x1 work slot -- enough for the kinds an opportunistic helper serves -- and 16 in a dedicated helper's slot)
+__device__ inline TView hj_seg_view(LDS_AS int* ch, int k, int sz) {
+    LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
+    TView v;
+    v.keys = nullptr; v.hdr = nullptr;
+    v.coef = lds_ld_ptr<const GLB_AS double>(&sg[0]);
+    v.cnt = uni(sg[2]); v.stride = uni(sg[3]); v.off = uni(sg[4]); v.sz = sz;
+    return v;
+}
+__device__ inline double hj_seg_double(LDS_AS int* p) { return __longlong_as_double((long long)(((uint64_t)(unsigned)p[1] << 32) | (unsigned)p[0])); }
+template <int NS, bool CHAIN>
+__device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int S, int N, bool indirect, Out<3>& o, double (&ra)[4][3]) {
+    const int lane = t.w.lane;
+    LinCtx<3, NS, CHAIN> cx;
+    pzw::LinEval<3, NS> ev;   // (key_lds reads the primary's key buffer only)
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        LDS_AS int* sg = ch + HJ_SEG0 + k * HJ_SEG_WORDS;
+        cx.s[k].v = hj_seg_view(ch, k, 3); cx.s[k].comp = uni(sg[5]);
+        cx.s[k].scale = hj_seg_double(&sg[6]);
+        cx.off[k] = tot; tot += cx.s[k].v.cnt;
+    }
+    cx.off[NS] = tot;
+    cx.lane = lane; cx.prepare();
+    cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
+#pragma unroll
+    for (int e = 0; e < 3; e++) cx.acc[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) cx.ra[k][e] = 0.0;
+    if (indirect) walk_sorted<8>(lane, N, [&](int p) { return ev.key_lds(sw, sw.sidx[p]); }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+    else walk_sorted<8>(lane, N, [&](int p) { return sw.skey[p]; }, [&](int p) { return (int)sw.sidx[p]; }, cx, S);
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) ra[k][e] = cx.ra[k][e];
+}
+__device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
+    LDS_AS int* ch = t.hch;
+    const int lane = t.w.lane;
+    t.hseq++;
+    hj_wait(t, &ch[HJ_SEQ], t.hseq);
+    const int kind = uni(ch[HJ_KIND]);
+    if (kind == HK_NONE || kind == HK_BAR || kind == HK_EXIT) { hj_signal(t, &ch[HJ_DONE], t.hseq); return kind; }
+    const int S = uni(ch[HJ_S]), N = uni(ch[HJ_N]);
+    const bool indirect = uni(ch[HJ_INDIRECT]) != 0;
+    Wave sw = t.w;   // the PRIMARY's sorted terms
+    sw.skey = (LDS_AS uint64_t*)(uintptr_t)(unsigned)uni(ch[HJ_SKEY]);
+    sw.sidx = (LDS_AS uint16_t*)(uintptr_t)(unsigned)uni(ch[HJ_SIDX]);
+    const LDS_AS double* stage = (const LDS_AS double*)(uintptr_t)(unsigned)uni(ch[HJ_STAGE]);
+    Out<3> o;
+    o.init(tmp, lane);
+    GLB_AS double* pp = tmp.hdr + lane;   // partial sums, row q at pp[q * WAVE]
+    if (kind == HK_MUL_3331_A_STAGED || kind == HK_MUL_3331_B_STAGED || kind == HK_MUL_3331_UNSTAGED) {
+        typedef pzw::MulShape<3, 3, 3, 1> SH;
+        const TView a = hj_seg_view(ch, 0, 9), b = hj_seg_view(ch, 1, 3);
+        pzw::MulEval<SH> ev;
+        ev.a = kview(a); ev.set_b(kview(b));
+        double rad[3];
+        if (kind == HK_MUL_3331_A_STAGED) mul_walk<SH, 1>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+        else if (kind == HK_MUL_3331_B_STAGED) mul_walk<SH, 2>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+        else mul_walk<SH, 0>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+#pragma unroll
+        for (int e = 0; e < 3; e++) { pp[(size_t)(H_IND * 3 + e) * WAVE] = rad[e]; pp[(size_t)(H_ASUM * 3 + e) * WAVE] = o.asum[e]; }
+    } else if (kind == HK_LIN2 || kind == HK_LIN3_CHAIN || kind == HK_LIN4_CHAIN) {
+        double ra[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 3; e++) ra[k][e] = 0.0;
+        if (kind == HK_LIN2) { serve_lincomb<2, false>(t, ch, sw, S, N, indirect, o, ra); }
+        else if (kind == HK_LIN3_CHAIN) serve_lincomb<3, true>(t, ch, sw, S, N, indirect, o, ra);
+        else serve_lincomb<4, true>(t, ch, sw, S, N, indirect, o, ra);
+        // rows: [H_IND] = the unchained sum's pruned amounts or stage 1's, [H_IND2] = stage 2's, [H_CEN] = stage 3's
+        const int first = kind == HK_LIN2 ? 0 : 1;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            pp[(size_t)(H_IND * 3 + e) * WAVE] = kind == HK_LIN2 ? ra[0][e] : ra[1][e];
+            pp[(size_t)(H_IND2 * 3 + e) * WAVE] = ra[2][e];
+            pp[(size_t)(H_CEN * 3 + e) * WAVE] = ra[3][e];
+            pp[(size_t)(H_ASUM * 3 + e) * WAVE] = o.asum[e];
+        }
+        (void)first;
+    } else if (kind == HK_CROSS_A_STAGED || kind == HK_CROSS_B_STAGED || kind == HK_CROSS_UNSTAGED) {
+        typedef pzw::MulShape<1, 1, 1, 1> SH;
+        const TView a = hj_seg_view(ch, 0, 3), b = hj_seg_view(ch, 1, 3);
+        pzw::MulEval<SH> ev;
+        ev.a = kview(a); ev.set_b(kview(b));
+        ev.a.stride = 1; ev.a.off = 0; ev.b.stride = 1; ev.b.off = 0;
+        double rad[12];
+        if (kind == HK_CROSS_A_STAGED) cross_walk<1>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+        else if (kind == HK_CROSS_B_STAGED) cross_walk<2>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+        else cross_walk<0>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
+#pragma unroll
+        for (int e = 0; e < 12; e++) pp[(size_t)e * WAVE] = rad[e];
+#pragma unroll
+        for (int e = 0; e < 3; e++) pp[(size_t)(12 + e) * WAVE] = o.asum[e];
+    } else {   // HK_CROSS_CONST: monomials [S, N) of the operand
+        LDS_AS int* sg = ch + HJ_SEG0 + HJ_SEG_WORDS;
+        TView a = hj_seg_view(ch, 0, 3);
+        a.keys = lds_ld_ptr<const GLB_AS uint64_t>(&sg[0]);
+        double sA[3], sB[3];
+        int cA[3], cB[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { sA[q] = hj_seg_double(&sg[HJ_SEG_WORDS + 2 * q]); sB[q] = hj_seg_double(&sg[2 * HJ_SEG_WORDS + 2 * q]); }
+        cA[0] = uni(sg[HJ_SEG_WORDS + 6]); cA[1] = uni(sg[HJ_SEG_WORDS + 7]); cA[2] = uni(sg[2]);
+        cB[0] = uni(sg[2 * HJ_SEG_WORDS + 6]); cB[1] = uni(sg[2 * HJ_SEG_WORDS + 7]); cB[2] = uni(sg[3]);
+        double ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
+        cross_const_range(t, a, S, N, sA, cA, sB, cB, o, ra1, ra2);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { pp[(size_t)c * WAVE] = ra1[c]; pp[(size_t)(3 + c) * WAVE] = ra2[c]; pp[(size_t)(6 + c) * WAVE] = o.asum[c]; }
+    }
+    const int nh = uni(o.n < tmp.cap ? o.n : tmp.cap);
+    if (o.n > tmp.cap) pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW);
+    if (lane == 0) { ch[HJ_NH] = nh; lds_st_ptr(&ch[HJ_HDR], tmp.hdr); lds_st_ptr(&ch[HJ_TMP_COEF], tmp.coef); }
+    hj_signal(t, &ch[HJ_WALKED], t.hseq);
+    // ... and once the primary has finished its part: our rows behind its n0
+    hj_wait(t, &ch[HJ_N0SEQ], t.hseq);
+    const int n0 = uni(ch[HJ_N0]), cap = uni(ch[HJ_OUT_CAP]);
+    GLB_AS uint64_t* ok = lds_ld_ptr<GLB_AS uint64_t>(&ch[HJ_OUT_KEYS]);
+    GLB_AS double* oc = lds_ld_ptr<GLB_AS double>(&ch[HJ_OUT_COEF]);
+    const int room = cap - n0 > 0 ? cap - n0 : 0, ncopy = nh < room ? nh : room;   // (an overflow of the result is flagged by the primary's finish())
+    for (int m = lane; m < ncopy; m += WAVE) ok[n0 + m] = tmp.keys[m];
+    move_rows(tmp.coef + lane, oc + (size_t)n0 * 3 * WAVE + lane, (ncopy * 3) / 2, ncopy * 3);   // (the primary moves the lower half)
+    hj_signal(t, &ch[HJ_DONE], t.hseq);
+    return kind;
+}
+// a dedicated helper's item: serve until the primary says the item is over, joining every block barrier it enters
+__device__ inline void serve_loop(TW& t, const TPZ& tmp) {
+    for (;;) {
+        const int kind = serve_walk(t, tmp);
+        if (kind == HK_BAR) __syncthreads();
+        if (kind == HK_EXIT) break;
+    }
 }
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066): keys unchanged, no simplify

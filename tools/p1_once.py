@@ -9,3 +9,4 @@ nlp = ArmourNLP(T=100)
 for _ in range(3):
     nlp.set_parameters(pb['q0'], pb['qd0'], pb['qdd0'], pb['q_des'], pb['obstacles'])
 print("B", B, "build ms", nlp.build_ms)
+nlp.close()

@@ -8,3 +8,4 @@ nlp = ArmourNLP(T=100).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], 
 for _ in range(N):
     s = nlp.solve()[0]
 print("solved", N, "times:", {k: s[k] for k in ("feasible", "iterations", "evaluations", "status")})
+nlp.close()   # free the handle before interpreter exit (under rocprofv3 a handle freed from the exit handlers crashed inside the tool library)
