@@ -1252,7 +1252,6 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
         else if (kind == HK_LIN3_CHAIN) serve_lincomb<3, true>(t, ch, sw, S, N, indirect, o, ra);
         else serve_lincomb<4, true>(t, ch, sw, S, N, indirect, o, ra);
         // rows: [H_IND] = the unchained sum's pruned amounts or stage 1's, [H_IND2] = stage 2's, [H_CEN] = stage 3's
-        const int first = kind == HK_LIN2 ? 0 : 1;
 #pragma unroll
         for (int e = 0; e < 3; e++) {
             pp[(size_t)(H_IND * 3 + e) * WAVE] = kind == HK_LIN2 ? ra[0][e] : ra[1][e];
@@ -1260,7 +1259,6 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
             pp[(size_t)(H_CEN * 3 + e) * WAVE] = ra[3][e];
             pp[(size_t)(H_ASUM * 3 + e) * WAVE] = o.asum[e];
         }
-        (void)first;
     } else if (kind == HK_CROSS_A_STAGED || kind == HK_CROSS_B_STAGED || kind == HK_CROSS_UNSTAGED) {
         typedef pzw::MulShape<1, 1, 1, 1> SH;
         const TView a = hj_seg_view(ch, 0, 3), b = hj_seg_view(ch, 1, 3);
