@@ -289,6 +289,7 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
 // on its key alone (wave-uniform); whether a lane HAS the monomial is whether its coefficient vector is non-zero.
 // (Found by fk_step through its chain argument; `t_lane` is this lane's time step.)
 __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int t_lane) {
+    TVP_FN(c.w, 7)
     const P1Cfg& cf = *c.cf;
     TW& t = c.w;
     const int lane = t.w.lane;
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
         const long long tvp_start = clock64();
         c.w.c_wait = c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
         c.w.c_hwait = c.w.n_shared = c.w.n_shared_terms = 0;
+        for (int q = 0; q < 8; q++) { c.w.c_fn[q] = 0; c.w.n_fn[q] = 0; }
         for (int q = 0; q < 3; q++) { c.w.c_type[q] = 0; c.w.n_type[q] = 0; }
 #endif
         build_jrs_tv(c, b, t_lane, fk_only);
@@ -553,6 +555,8 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
 #ifdef TV_PROFILE_FULL
         if (threadIdx.x == 0 && blockIdx.x == 0) printf("[tv item %d] walk: load phase %lld, wait for the loads %lld, process phase %lld, chunk prologue %lld cycles, %lld batches, %lld terms\n", it, tv::g_tvprof[0], tv::g_tvprof[4], tv::g_tvprof[1], tv::g_tvprof[2], tv::g_tvprof[3], tv::g_tvprof[5]);
 #endif
+        if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] whole calls (cycles / calls): sorted product %lld / %lld, constant-left product %lld / %lld, cross %lld / %lld, sums %lld / %lld, constant cross %lld / %lld, helper service %lld / %lld, set+transpose %lld / %lld, link tables %lld / %lld\n", it, c.wid,
+                                                 c.w.c_fn[0], c.w.n_fn[0], c.w.c_fn[1], c.w.n_fn[1], c.w.c_fn[2], c.w.n_fn[2], c.w.c_fn[3], c.w.n_fn[3], c.w.c_fn[4], c.w.n_fn[4], c.w.c_fn[5], c.w.n_fn[5], c.w.c_fn[6], c.w.n_fn[6], c.w.c_fn[7], c.w.n_fn[7]);
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] shared walks: %lld jobs, %lld raw terms; waited %lld cycles on the helper channel\n", it, c.wid, c.w.n_shared, c.w.n_shared_terms, c.w.c_hwait);
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] total %lld cycles (waited %lld, %lld of it in the forward pass; forward done at %lld): sort %lld walk %lld cross_const %lld | %lld sorted operator calls, %lld raw terms, %lld emitted\n", it, c.wid, (long long)clock64() - tvp_start, c.w.c_wait, c.w.c_wait_fwd, c.w.c_fwd - tvp_start, c.w.c_sort, c.w.c_walk, c.w.c_cc, c.w.n_calls, c.w.n_raw, c.w.n_emit);
 #endif

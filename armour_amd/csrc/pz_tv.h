@@ -62,8 +62,21 @@ struct TW {
 #ifdef TV_PROFILE  // development: cycles in the sorts, in the walks, raw terms walked, operator calls
     long long c_sort = 0, c_walk = 0, c_cc = 0, n_raw = 0, n_calls = 0, n_emit = 0, c_wait = 0, c_fwd = 0, c_wait_fwd = 0, c_hwait = 0, n_shared = 0, n_shared_terms = 0;
     long long c_type[3] = {0, 0, 0}, n_type[3] = {0, 0, 0};  // walk cycles / raw terms of mul, cross, sums
+    long long c_fn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_fn[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // whole-call cycles / calls: 0 sorted product, 1 product with a constant left operand, 2 cross, 3 sum, 4 constant cross, 5 helper service, 6 set / transpose, 7 link tables
 #endif
 };
+#ifdef TV_PROFILE
+struct TvFn {   // whole-call time of an operator, by kind (the kind may be set late)
+    TW& t; int kind; long long t0;
+    __device__ TvFn(TW& t_, int k) : t(t_), kind(k), t0(clock64()) {}
+    __device__ ~TvFn() { t.c_fn[kind] += clock64() - t0; t.n_fn[kind] += 1; }
+};
+#define TVP_FN(t, k) ::tv::TvFn tvfn__(t, k);
+#define TVP_FN_KIND(k) tvfn__.kind = (k);
+#else
+#define TVP_FN(t, k)
+#define TVP_FN_KIND(k)
+#endif
 #ifdef TV_PROFILE_FULL
 #define TVP_T0 const long long tvp0__ = clock64();
 #define TVP_T1 const long long tvp1__ = clock64();
@@ -507,6 +520,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     const int lane = t.w.lane;
     TView a = a_, b = b_;
     a.cnt = uni(a.cnt); b.cnt = uni(b.cnt);
+    TVP_FN(t, a.cnt == 0 ? 1 : 0)
     int N = (a.cnt + 1) * (b.cnt + 1) - 1;
     // per-lane centre and radii (RT/PZsparse.cu:868,944-989)
     double ca[SH::ASZ], cb[SH::BSZ], ia[SH::ASZ], ib[SH::BSZ], ia2[SH::ASZ], ib2[SH::BSZ], r2[SH::ASZ], r3[SH::BSZ];
@@ -726,6 +740,7 @@ __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* st
 }
 
 __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
+    TVP_FN(t, 2)
     typedef pzw::MulShape<1, 1, 1, 1> SH;
     const int lane = t.w.lane;
     TView a = a_, b = b_;
@@ -949,6 +964,7 @@ struct LinCtx {
 
 template <int SZ, int NS, bool CHAIN>
 __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
+    TVP_FN(t, 3)
     const int lane = t.w.lane;
     LinCtx<SZ, NS, CHAIN> cx;
     pzw::LinEval<SZ, NS> ev;
@@ -1108,6 +1124,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
     }
 }
 __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
+    TVP_FN(t, 4)
     const int lane = t.w.lane;
     TView a = a_;
     a.cnt = uni(a.cnt);
@@ -1216,6 +1233,7 @@ __device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int 
         for (int e = 0; e < 3; e++) ra[k][e] = cx.ra[k][e];
 }
 __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
+    TVP_FN(t, 5)
     LDS_AS int* ch = t.hch;
     const int lane = t.w.lane;
     t.hseq++;
@@ -1314,6 +1332,7 @@ __device__ inline void serve_loop(TW& t, const TPZ& tmp) {
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066): keys unchanged, no simplify
 __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
+    TVP_FN(t, 6)
     const int lane = t.w.lane;
     const int n = uni(t.w.cnt[a.id]);
     for (int m = 0; m < n; m++)
@@ -1330,6 +1349,7 @@ __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
 
 // constant PZ: the same centre / radii in every lane (RT/PZsparse.cu:66-98); ind2 == nullptr: equal to ind
 __device__ TV_NOINLINE void set_const(TW& t, const TPZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
+    TVP_FN(t, 6)
     const int lane = t.w.lane;
     for (int e = 0; e < out.sz; e++) {
         st_hdr(out, H_CEN, e, lane, cen ? cen[e] : 0.0);
