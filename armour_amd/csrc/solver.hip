@@ -326,7 +326,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     // form's 30).  Now such a batch is cut into SUB-BATCHES launched back to back on the handle's stream -- each a persistent
     // cooperative launch of its own over problems [b0, b0 + Bs) of the same tables, with enough blocks per problem for about
     // `sub_tiles` tiles per block; iterates and results do not depend on the cut (a problem's blocks see only that problem).
-    static const int sub_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_SUB_TILES"); return e ? std::max(1, atoi(e)) : 24; }();   // development: tiles per block aimed at
+    static const int sub_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_SUB_TILES"); return e ? std::max(1, atoi(e)) : 48; }();   // tiles per block aimed at (swept on B = 64 ... 256, O = 20 ... 50: profiles/r03_solve_subtiles.txt)
     static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
     int Bs = B;
     if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > 40) {
