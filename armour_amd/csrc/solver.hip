@@ -328,8 +328,12 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     // `sub_tiles` tiles per block; iterates and results do not depend on the cut (a problem's blocks see only that problem).
     static const int sub_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_SUB_TILES"); return e ? std::max(1, atoi(e)) : 48; }();   // tiles per block aimed at (swept on B = 64 ... 256, O = 20 ... 50: profiles/r03_solve_subtiles.txt)
     static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
+    // When to cut (profiles/r03_solve_subtiles.txt, swept with candidate buffers large enough never to overflow): one launch is best or within
+    // 3 % up to ~154 tiles per block (B = 128 at O = 20 / 30 / 40: 10.2 / 15.0 / 13.3 ms; B = 256 at O = 20: 19.7 against 24.9 cut); at 159
+    // (B = 128, O = 50) the cut wins, 14.3 against 18.7 ms.  The threshold sits between those two measurements.
+    static const int cut_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_CUT_TILES"); return e ? std::max(1, atoi(e)) : 156; }();
     int Bs = B;
-    if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > 40) {
+    if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > cut_tiles) {
         const int nb_want = std::min(plan.n_tiles, (plan.n_tiles + sub_tiles - 1) / sub_tiles);
         Bs = std::max(1, std::min(B, plan.capacity / std::max(1, nb_want)));
         if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, &plan)) != ARMOUR_OK) return rc;
@@ -343,8 +347,10 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if ((rc = armour_upload_bounds(h)) != ARMOUR_OK) return rc;
     // rows a block owns: at most ceil(n_tiles / nb) tiles of <= 64 rows, two candidates per row
     const int tiles_per_block = (plan.n_tiles + nb - 1) / nb;
-    int cap_blk = std::min(2 * tiles_per_block * 64, 1024);
-    int cap_rows = std::min(2 * m, 8192);
+    // (an overflow of either sends the whole batch to the host-driven form, i.e. costs a second solve: B = 128 at O = 20 with 77 tiles per
+    //  block overflowed 1024 rows per block on two of four world seeds -- 25 ms instead of 10; the buffers are 72 B per row)
+    int cap_blk = std::min(2 * tiles_per_block * 64, 4096);
+    int cap_rows = std::min(2 * m, 16384);
     if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) { cap_blk = std::max(1, std::min(cap_blk, atoi(e))); }  // tests: force the overflow fallback
     SolveDeviceWork& w = h->solve_dev;
     // everything the host hands the kernel sits in ONE device block, filled by ONE copy from its page-locked mirror: the per-problem
