@@ -449,10 +449,15 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, n = h->n, m = h->m;
     {
-        // default: the device-resident form; `force_host_qp` (or ARMOUR_SOLVE_DEVICE=0) keeps the host-driven form below,
-        // which is also the fallback -- both produce the same iterates
+        // The device-resident form for batches, the host-driven form below for up to four problems (force_host_qp: > 0 host form, < 0 device form
+        // whatever the batch; ARMOUR_SOLVE_DEVICE=0|2: never / always the device form -- development).  Both produce the same iterates.  Why four:
+        // the leader wavefront takes 6 us per QP step where a host core takes 0.3, and problems that end infeasible take hundreds of steps; on
+        // random worlds (O = 20) the host form is faster in 36 of 36 batches of 1-3 problems (0.22 against 0.44 ms for one), even at 4, and the
+        // persistent kernel in 33 of 36 from 6 on (profiles/r03_solve_small_batches.txt).  It also remains the fallback.
         static const int dev_env = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
-        if (dev_env && opt.force_host_qp == 0.0) {
+        constexpr int kDeviceFormMinBatch = 5;
+        const bool want_device = opt.force_host_qp > 0.0 ? false : opt.force_host_qp < 0.0 ? true : dev_env == 0 ? false : dev_env >= 2 ? true : B >= kDeviceFormMinBatch;
+        if (want_device) {
             HIPCHK(hipSetDevice(h->device));
             const int r = solve_on_device(h, opt, results, t_begin);
             if (r != 0) return r < 0 ? r : ARMOUR_OK;

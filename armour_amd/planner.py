@@ -83,7 +83,7 @@ def _violation_dict(v):
                 n_outside_slack=v.n_outside_slack, feasible=bool(v.feasible))
 
 
-def _solve_options(L, max_iterations, tolerance, max_wall_time_s, host_qp):
+def _solve_options(L, max_iterations, tolerance, max_wall_time_s, host_qp, device_qp=False):
     opt = _lib.ArmourSolveOptions()
     L.armour_solve_options_default(C.byref(opt))
     if max_iterations is not None:
@@ -92,8 +92,10 @@ def _solve_options(L, max_iterations, tolerance, max_wall_time_s, host_qp):
         opt.tolerance = tolerance
     if max_wall_time_s is not None:
         opt.max_wall_time_s = max_wall_time_s
-    if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) instead of the persistent kernel
+    if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) whatever the batch size
         opt.force_host_qp = 1.0
+    elif device_qp:   # the persistent-kernel form whatever the batch size (automatic: from 5 problems on)
+        opt.force_host_qp = -1.0
     return opt
 
 
@@ -172,8 +174,8 @@ class ArmourBatchNLP:
         check(self.L.armour_batch_eval_violations(self.h, _dp(self._k(x)), out))
         return [_violation_dict(v) for v in out]
 
-    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False):
-        opt = _solve_options(self.L, max_iterations, tolerance, max_wall_time_s, host_qp)
+    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False, device_qp=False):
+        opt = _solve_options(self.L, max_iterations, tolerance, max_wall_time_s, host_qp, device_qp)
         res = (_lib.ArmourSolveResult * self.B)()
         check(self.L.armour_batch_solve(self.h, C.byref(opt), res))
         return _solve_dicts(res, self.n)
@@ -383,19 +385,11 @@ class ArmourNLP:
         """Asynchronous: d_k [B][n] doubles, d_out [B] ArmourViolation records (32 B each), device pointers (ints)."""
         check(self.L.armour_eval_violations_device(self.h, d_k, d_out, stream))
 
-    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False):
+    def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False, device_qp=False):
         """OptimizeTNLP + finalize_solution for all B problems (RT/armour_main.cu:237-304): returns a list of dicts
-        (k_opt, cost, feasible, iterations, evaluations, status, time_ms)."""
-        opt = _lib.ArmourSolveOptions()
-        self.L.armour_solve_options_default(C.byref(opt))
-        if max_iterations is not None:
-            opt.max_iterations = max_iterations
-        if tolerance is not None:
-            opt.tolerance = tolerance
-        if max_wall_time_s is not None:
-            opt.max_wall_time_s = max_wall_time_s
-        if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) instead of the persistent kernel
-            opt.force_host_qp = 1.0
+        (k_opt, cost, feasible, iterations, evaluations, status, time_ms).  host_qp / device_qp hold the solver to one of its two forms
+        (same iterates; automatic: the persistent kernel from 5 problems on)."""
+        opt = _solve_options(self.L, max_iterations, tolerance, max_wall_time_s, host_qp, device_qp)
         res = (_lib.ArmourSolveResult * self.B)()
         check(self.L.armour_solve(self.h, C.byref(opt), res))
         return [dict(k_opt=np.array(r.k_opt[:self.n]), cost=r.cost, max_violation=r.max_violation, feasible=bool(r.feasible),

@@ -228,8 +228,12 @@ typedef struct ArmourSolveOptions {
     int32_t max_line_search;  /* halvings per iteration (12) */
     double tolerance;         /* step / violation tolerance (1e-4 = IPOPT_OPTIMIZATION_TOLERANCE, RT/Parameters.h:50) */
     double max_wall_time_s;   /* 0 = unlimited (reference: 0.5 s - t(P1) - 0.05 s, RT/armour_main.cu:227-229) */
-    double force_host_qp;     /* 0 (default): the whole SQP iterate runs in one persistent kernel; != 0: evaluations on the device, 7-variable QPs on the
-                               * host, one launch per evaluation (the round-1 form; also the automatic fallback).  Both give the same iterates. */
+    double force_host_qp;     /* which of the two forms of the solver runs -- both give the same iterates bit for bit:
+                               *   0 (default) automatic: batches of more than 4 problems run the whole SQP iterate in one persistent kernel, smaller ones
+                               *     keep the evaluations on the device and solve the 7-variable QPs on the host, one launch per evaluation (measured on
+                               *     random worlds: the host does a QP step in 0.3 us against 6 us on one wavefront, and infeasible problems take
+                               *     hundreds of them; the persistent kernel wins from 6 problems on);
+                               *   > 0: the host-QP form whatever the batch;   < 0: the persistent-kernel form whatever the batch. */
     double reserved[3];
 } ArmourSolveOptions;
 typedef struct ArmourSolveResult {

@@ -77,23 +77,25 @@ def test_device_resident_solve_equals_the_host_driven_one(seed, O, T, B, monkeyp
     bp = random_batch(seed, B, O)
     nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
     host = nlp.solve(host_qp=True)
-    dev = nlp.solve()
+    dev = nlp.solve(device_qp=True)          # (automatic: the persistent kernel from 5 problems on -- these batches are smaller, so it is asked for)
     for a, c in zip(host, dev):
+        assert _same_solution(a, c), (a, c)
+    for a, c in zip(host, nlp.solve()):      # ... and whatever the automatic choice is, the same again
         assert _same_solution(a, c), (a, c)
     for blocks in ("1", "5", "64"):
         monkeypatch.setenv("ARMOUR_SOLVE_BLOCKS", blocks)
-        for a, c in zip(host, nlp.solve()):
+        for a, c in zip(host, nlp.solve(device_qp=True)):
             assert _same_solution(a, c), (blocks, a, c)
     monkeypatch.delenv("ARMOUR_SOLVE_BLOCKS")
     # a batch cut into sub-batches launched back to back (round 3: what large batches with many obstacles do by themselves)
     if B > 1:
         for sub in ("1", "2"):
             monkeypatch.setenv("ARMOUR_SOLVE_SUB_BATCH", sub)
-            for a, c in zip(host, nlp.solve()):
+            for a, c in zip(host, nlp.solve(device_qp=True)):
                 assert _same_solution(a, c), ("sub-batch", sub, a, c)
         monkeypatch.delenv("ARMOUR_SOLVE_SUB_BATCH")
     # tighter tolerance / more iterations: longer iterate sequences
-    for a, c in zip(nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True), nlp.solve(tolerance=1e-7, max_iterations=100)):
+    for a, c in zip(nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True), nlp.solve(tolerance=1e-7, max_iterations=100, device_qp=True)):
         assert _same_solution(a, c), (a, c)
 
 
@@ -104,7 +106,7 @@ def test_device_resident_solve_in_armtd_mode():
     p = random_problem(4, 8)
     jrs, kr = synthetic_offline_jrs(p["qd0"], T=T)
     nlp = ArmourNLP(T=T).set_parameters_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
-    a, c = nlp.solve(host_qp=True)[0], nlp.solve()[0]
+    a, c = nlp.solve(host_qp=True)[0], nlp.solve(device_qp=True)[0]
     assert _same_solution(a, c), (a, c)
 
 
