@@ -253,9 +253,10 @@ def test_first_order_derivative_check_through_one_multi_point_launch(sample_prob
 
 
 def test_first_pinned_calls_of_a_fresh_handle_are_fast(sample_problem):
-    """the synchronous host call with page-locked buffers cost ~0.9 ms per call on freshly started boxes while the
-    kernel wrote g / jac into host memory itself, and once never returned.  With DMA copies (the default now) none of the first 20
-    calls of a fresh handle may take 1 ms, and the settled call stays below the pageable one."""
+    """the driver's bench reported ~0.9 ms per synchronous host call with page-locked buffers.  (That was a mean with one
+    ~40 ms pause of the interpreter's garbage collector in it -- DESIGN.md section 5 -- so the collector is held off here: the library's call is
+    what is timed.)  None of the first 20 calls of a fresh handle may take 1 ms, and the settled call stays below the pageable one."""
+    import gc
     import time
     from armour_amd.planner import ArmourNLP
     T = 100
@@ -263,10 +264,14 @@ def test_first_pinned_calls_of_a_fresh_handle_are_fast(sample_problem):
     k = PZ_TESTS_K[None, :]
     g0, j0 = nlp.eval_g_jac(k)
     times = []
-    for _ in range(20):
-        t0 = time.perf_counter()
-        g, jac = nlp.eval_g_jac(k, pinned=True)
-        times.append(time.perf_counter() - t0)
+    gc.collect(); gc.disable()
+    try:
+        for _ in range(20):
+            t0 = time.perf_counter()
+            g, jac = nlp.eval_g_jac(k, pinned=True)
+            times.append(time.perf_counter() - t0)
+    finally:
+        gc.enable()
     assert np.array_equal(g, g0) and np.array_equal(jac, j0)
     assert max(times[1:]) < 1e-3, [round(t * 1e6) for t in times]      # (call 0 allocates the page-locked buffers)
     tp = []
