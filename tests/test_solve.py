@@ -249,8 +249,15 @@ def test_large_batches_solve_in_sub_batches_on_the_device():
     bp = random_batch(5000, B, O)
     nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
     nlp.solve(); nlp.solve(host_qp=True)          # (code objects, buffers)
-    t0 = time.perf_counter(); dev = nlp.solve(); t_dev = time.perf_counter() - t0
-    t0 = time.perf_counter(); host = nlp.solve(host_qp=True); t_host = time.perf_counter() - t0
+    import gc
+    gc.collect(); gc.disable()                    # (a collector pause of this interpreter is tens of ms: not the library's)
+    try:
+        t_dev = t_host = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter(); dev = nlp.solve(); t_dev = min(t_dev, time.perf_counter() - t0)
+            t0 = time.perf_counter(); host = nlp.solve(host_qp=True); t_host = min(t_host, time.perf_counter() - t0)
+    finally:
+        gc.enable()
     for b in range(0, B, 3):
         assert _same_solution(host[b], dev[b]), (b, host[b], dev[b])
     print(f"armour_solve B={B} O={O}: device form {t_dev * 1e3:.1f} ms, host form {t_host * 1e3:.1f} ms")
