@@ -1676,7 +1676,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
     // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels; the environment switch is development only)
     const bool want_tv = h->opt_p1_build == 1 ? false : h->opt_p1_build == 2 ? true
-                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 3 / 2 : tv_min_groups);
+                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 15 / 8 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
     if (want_tv) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
