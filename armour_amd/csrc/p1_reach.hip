@@ -1671,7 +1671,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
     static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 32; }();  // below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
     const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
-    // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 40 there)
+    // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 30 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
     // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels; the environment switch is development only)
