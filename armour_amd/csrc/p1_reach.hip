@@ -1699,7 +1699,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int nw = nw_launch == 8 ? 4 : nw_launch;   // the waves that play roles
             const int nhelp = nw_launch == 8 ? 4 : 0;
             const bool multi = nw > 1;   // (a): the roles of the RNEA on three waves, with four the forward kinematics on a wave of its own
-            if (multi && (armtd || tv_nw_env == 1 || (tv_nw_env == 0 && groups > prop.multiProcessorCount))) continue;
+            // (multi-wave blocks also when there are more groups than CUs: the blocks loop over the groups.  Measured against one wave per group,
+            //  two or three groups per CU at a time -- B = 160: 18.1 against 23.1 ms, 256: 20.0 against 24.1, 384: 29.7 against 43.9, 512: 38.8 against
+            //  47.2 (profiles/r03_p1_breakeven.txt) -- the shared walks are what the one-wave shape lacks)
+            if (multi && (armtd || tv_nw_env == 1)) continue;
             if (multi && tv_nw_env > 1 && tv_nw_env != nw_launch) continue;
             if (!multi && tv_nw_env > 1 && si == 3) continue;
             const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw, nhelp);

@@ -152,3 +152,34 @@ def test_whole_planning_iterations_at_batch_128():
         assert np.abs(s1["k_opt"] - sols[b]["k_opt"]).max() <= 1e-9 and s1["feasible"] == sols[b]["feasible"], b
         one.close()
     nlp.close()
+
+
+def test_batch_with_more_groups_than_compute_units():
+    """A batch of 150 worlds has 300 groups of 50 time steps for 256 CUs: the four-wave blocks of the time-vectorised build loop over the
+    groups (round 3; before, such batches took the one-wave-per-group shape, still reachable through ARMOUR_P1_TV_WAVES=1).  Sampled
+    worlds -- first and second round of the loop -- against single-problem handles on the per-step kernel: keys, coefficients and
+    centres bit for bit, radii to the stated 1e-12; and one against the live oracle."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    T, B, O = 100, 150, 4
+    bp = random_batch(8100, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    ks = random_k(17, B)
+    g, jac = nlp.eval_g_jac(ks)
+    for b in (0, 77, 127, 128, 149):
+        one = ArmourNLP(T=T).set_option(_lib.OPT_P1_BUILD, 1).set_parameters(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+        for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
+            for i in range(cnt):
+                for t in range(0, T, 9):
+                    c1, r1, k1, co1 = one.pz(which, i, t)
+                    c2, r2, k2, co2 = nlp.pz(which, i, t, b=b)
+                    assert np.array_equal(k1, k2) and np.array_equal(co1, co2) and np.array_equal(c1, c2), (b, which, i, t)
+                    assert np.abs(r1 - r2).max() <= 1e-12
+        assert np.abs(one.torque_radius()[0] - nlp.torque_radius()[b]).max() <= 1e-12
+        g1, j1 = one.eval_g_jac(ks[b])
+        assert np.abs(g1[0] - g[b]).max() <= 1e-11 and np.abs(j1[0] - jac[b]).max() <= 1e-11
+        one.close()
+    o = _oracle(T, bp, 149)
+    _tables_equal_oracle(nlp, o, 149)
+    nlp.close()
