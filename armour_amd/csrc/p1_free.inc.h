@@ -77,6 +77,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     auto& w = c.w;
     const int J = c.J;
     const bool fk_wave = c.nw == 4;                       // the forward kinematics has a wave of its own
+    constexpr bool fused_cross = CH::kFusedCross;         // (time-vectorised chain) wdot x p and wdot x com are taken inside the sums that add them
     const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
     const int wave_w = fk_wave ? 3 : 2;   // the wave that runs the omega recursion (see below)
@@ -193,15 +194,19 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2), lacc = t3_take(c, T3_LA + s);
             const double* tr = &cf.rb.trans[3 * s];
             TPZ c1 = wdot, c2 = waux;
-            if (fk_wave) {   // wdot x p, w_aux x p: from the forward-kinematics wave
+            if (fk_wave) {   // wdot x p, w_aux x p: from the forward-kinematics wave (wdot x p only where it is a PZ of its own)
                 t3_wait(c, T3_C3, s + 1);
-                c1 = t3_take(c, T3_X1 + s); c2 = t3_take(c, T3_X2 + s);
+                if constexpr (!fused_cross) c1 = t3_take(c, T3_X1 + s);
+                c2 = t3_take(c, T3_X2 + s);
             } else {
-                c1 = c.crossPzMat(wdot, tr);
+                if constexpr (!fused_cross) c1 = c.crossPzMat(wdot, tr);
                 c2 = c.crossPzMat(waux, tr);
             }
             TPZ c3 = c.crossPzPz(wv, c2); if (!fk_wave) c.freeVs(c2);
-            TPZ s2 = c.sum3(lacc, c1, c3); if (!fk_wave) c.freeVs(c1); c.freeVs(c3);
+            TPZ s2;
+            if constexpr (fused_cross) s2 = c.sum3x(lacc, wdot, tr, c3);   // (lacc + wdot x p) + c3, the cross product inside the sum
+            else { s2 = c.sum3(lacc, c1, c3); if (!fk_wave) c.freeVs(c1); }
+            c.freeVs(c3);
             TPZ nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
             t3_post(c, T3_LA + s + 1, nl);
             t3_signal(c, T3_C0, s + 1);
@@ -220,14 +225,15 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             {   // the two cross products with the joint offset for wave 0's step s, at most two steps ahead of it
                 if (s >= 2) {
                     t3_wait(c, T3_C0, s - 1);
-                    c.freeVs(t3_take(c, T3_X1 + s - 2)); c.freeVs(t3_take(c, T3_X2 + s - 2));
+                    if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s - 2));
+                    c.freeVs(t3_take(c, T3_X2 + s - 2));
                 }
                 t3_wait(c, T3_C1, s);
                 const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
                 const double* tr = &cf.rb.trans[3 * s];
-                TPZ x1 = c.crossPzMat(wdot, tr);
+                if constexpr (!fused_cross) { TPZ x1 = c.crossPzMat(wdot, tr); t3_post(c, T3_X1 + s, x1); }
                 TPZ x2 = c.crossPzMat(waux, tr);
-                t3_post(c, T3_X1 + s, x1); t3_post(c, T3_X2 + s, x2);
+                t3_post(c, T3_X2 + s, x2);
                 t3_signal(c, T3_C3, s + 1);
             }
             fk_step(c, fk, s, b, t_lane);
@@ -235,7 +241,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
         for (int k = freed_w; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
-        for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
+        for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
@@ -258,12 +264,16 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 }
                 {   // F = m * (linear_acc + cross(wdot, com) + cross(w, cross(w_aux, com))): all but the last sum before the linear acceleration is needed
                     const double* cm = &cf.rb.com[3 * (s - 1)];
-                    TPZ c1 = c.crossPzMat(wdot, cm);
+                    TPZ c1 = wdot;
+                    if constexpr (!fused_cross) c1 = c.crossPzMat(wdot, cm);
                     TPZ c2 = c.crossPzMat(waux, cm);
                     TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
                     t3_wait(c, T3_C0, s);
                     const TPZ lacc = t3_take(c, T3_LA + s);
-                    TPZ s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); c.freeVs(c3);
+                    TPZ s2;
+                    if constexpr (fused_cross) s2 = c.sum3x(lacc, wdot, cm, c3);   // (lacc + wdot x com) + c3
+                    else { s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); }
+                    c.freeVs(c3);
                     TPZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
                     t3_post(c, T3_F + s - 1, F);
                 }

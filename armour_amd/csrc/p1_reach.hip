@@ -284,6 +284,7 @@ __device__ inline void rpy_matrix(double roll, double pitch, double yaw, double*
 struct Chain {
     typedef PZ PZT;
     static constexpr bool kWalkHelpers = false;   // (the time-vectorised chain has them: p1_tv.inc.h)
+    static constexpr bool kFusedCross = false;    // (likewise)
     Wave w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;

@@ -61,6 +61,7 @@ __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index
 struct TChain {
     typedef TPZ PZT;
     static constexpr bool kWalkHelpers = true;   // pz_tv.h "One walk on two waves"; used by run_rnea_free in four-wave blocks
+    static constexpr bool kFusedCross = true;    // run_rnea_free: (a + cross(w, b)) + c with the constant cross product taken inside the sum's walk (sum3x)
     TW w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -151,6 +152,13 @@ struct TChain {
         TPZ o = allocV();
         TSeg s[3] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, b), 1.0, -1}, {tv::view(w, c3), 1.0, comp_c}};
         tv::lincomb<3, 3, true>(w, o, s);
+        return o;
+    }
+    // (a + cross(w, bvec)) + c3: the sum3 of a, crossPzMat(w, bvec), c3 without the cross product as a PZ of its own (pz_tv.h LinCtx, XK)
+    __device__ TPZ sum3x(const TPZ& a, const TPZ& wv, const double* bvec, const TPZ& c3) {
+        TPZ o = allocV();
+        TSeg s[3] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, wv), 1.0, -1}, {tv::view(w, c3), 1.0, -1}};
+        tv::lincomb<3, 3, true, 1>(w, o, s, bvec);
         return o;
     }
     __device__ TPZ sum4(const TPZ& a, const TPZ& b, const TPZ& c3, const TPZ& d) {

@@ -830,7 +830,13 @@ struct TSeg {
     int comp;  // -1: same shape as the result; otherwise a 1x1 source embedded into entry `comp`
 };
 
-template <int SZ, int NS, bool CHAIN>
+// XK >= 0: source XK is not read as it is but as cross(source, b) with a constant vector b -- the constant cross product of pz_tv.h's
+// cross_const (a x b: out[c] = sA[c] * x[cA[c]] + sB[c] * x[cB[c]], cA = {1, 2, 0}, cB = {2, 0, 1}) with its two simplify() stages, applied to
+// every term of the source as the walk meets it instead of being written out as a PZ of its own first and read back here (its rows were two
+// fifths of a block's row writes).  The source's keys are the operand's: a monomial the cross product would have pruned in every lane is a
+// member with coefficient 0 in every lane, which changes no sum and no verdict.  The pruned amounts xr1 / xr2 accumulate in the operand's key
+// order, as cross_const accumulates them.
+template <int SZ, int NS, bool CHAIN, int XK = -1>
 struct LinCtx {
     TSeg s[NS];
     int off[NS + 1];
@@ -839,6 +845,7 @@ struct LinCtx {
     bool active;
     Out<SZ>* o;
     double acc[SZ], ra[NS][SZ];
+    double xsA[XK >= 0 ? 3 : 1], xsB[XK >= 0 ? 3 : 1], xr1[XK >= 0 ? 3 : 1], xr2[XK >= 0 ? 3 : 1];   // XK >= 0: the constants and the two stages' pruned amounts
     bool present;   // per lane
     int last;       // source of the run's latest member (wave-uniform)
     struct Regs { double x[SZ]; int k; };   // k: the term's source (wave-uniform)
@@ -884,8 +891,30 @@ struct LinCtx {
         for (int e = 0; e < SZ; e++) r.x[e] = src[e * step];
     }
     // scale * embed(source entry)
-    __device__ inline void term(const Regs& r, double* c) const {
+    __device__ inline void term(const Regs& r, double* c) {
         const int k = r.k;
+        if constexpr (XK >= 0) {
+            static_assert(SZ == 3, "a constant cross product is a 3x1 source");
+            if (k == XK) {   // (wave-uniform) cross_const's arithmetic on this term, in its order
+                const double x0 = r.x[0], x1 = r.x[1], x2 = r.x[2];
+                const double xa[3] = {x1, x2, x0}, xb[3] = {x2, x0, x1};
+                double rr[3];
+                bool anyc = false;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double v = xsA[q] * xa[q];
+                    v += xsB[q] * xb[q];
+                    const bool small = fabs(v) <= thr;
+                    xr1[q] += small ? fabs(v) : 0.0;
+                    rr[q] = small ? 0.0 : v;
+                    anyc = anyc || !small;
+                }
+                const bool keep = anyc && !(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] <= thr_sq) && active;
+#pragma unroll
+                for (int q = 0; q < 3; q++) { xr2[q] += (anyc && !keep) ? fabs(rr[q]) : 0.0; c[q] = s[XK].scale * (keep ? rr[q] : 0.0); }
+                return;
+            }
+        }
         int comp = s[0].comp;
         double scale = s[0].scale;
 #pragma unroll
@@ -962,14 +991,16 @@ struct LinCtx {
     }
 };
 
-template <int SZ, int NS, bool CHAIN>
-__device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
+// xb (XK >= 0): the constant vector b of the cross product source XK stands for
+template <int SZ, int NS, bool CHAIN, int XK = -1>
+__device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, const double* xb = nullptr) {
     TVP_FN(t, 3)
     const int lane = t.w.lane;
-    LinCtx<SZ, NS, CHAIN> cx;
+    LinCtx<SZ, NS, CHAIN, XK> cx;
     pzw::LinEval<SZ, NS> ev;
     int N = 0;
     double cen[SZ], indk[NS][SZ], ind2k[NS][SZ];
+    double xind[3] = {0.0, 0.0, 0.0}, xind2[3] = {0.0, 0.0, 0.0};   // XK >= 0: the cross product's radii before its pruned amounts
 #pragma unroll
     for (int e = 0; e < SZ; e++) cen[e] = 0.0;
 #pragma unroll
@@ -984,7 +1015,24 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
         const double sc = segs[k].scale, asc = fabs(sc);
 #pragma unroll
         for (int e = 0; e < SZ; e++) { indk[k][e] = 0.0; ind2k[k][e] = 0.0; }
-        if (segs[k].comp < 0) {
+        if (XK >= 0 && k == XK) {
+            if constexpr (XK >= 0) {
+                // centre and radii of cross(source, b) as cross_const forms them; its pruned amounts join the radii after the walk
+                const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
+                cx.xsA[0] = b2; cx.xsA[1] = b0; cx.xsA[2] = b1; cx.xsB[0] = -b1; cx.xsB[1] = -b2; cx.xsB[2] = -b0;
+                double x0[3], i0[3], j0[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { x0[q] = ld_hdr(v, H_CEN, q, lane); i0[q] = ld_hdr(v, H_IND, q, lane); j0[q] = ld_hdr(v, H_IND2, q, lane); cx.xr1[q] = 0.0; cx.xr2[q] = 0.0; }
+                const int cA[3] = {1, 2, 0}, cB[3] = {2, 0, 1};
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const double cq = sc * (cx.xsA[q] * x0[cA[q]] + cx.xsB[q] * x0[cB[q]]);
+                    cen[q] = (k == 0) ? cq : cen[q] + cq;
+                    xind[q] = i0[cA[q]] * fabs(cx.xsA[q]) + i0[cB[q]] * fabs(cx.xsB[q]);
+                    xind2[q] = j0[cA[q]] * fabs(cx.xsA[q]) + j0[cB[q]] * fabs(cx.xsB[q]);
+                }
+            }
+        } else if (segs[k].comp < 0) {
 #pragma unroll
             for (int e = 0; e < SZ; e++) {
                 const double c = sc * ld_hdr(v, H_CEN, e, lane);
@@ -1020,7 +1068,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
     constexpr int kU = SZ <= 3 ? 8 : 4;
     // the sums of the backward recursions (f = R f + F; n = ((N + R n) + c x F) + p x R f) share their walk with an idle wave
     // (the three-term chained sums of the forward pass: with a dedicated helper only)
-    constexpr bool kSplittable = SZ == 3 && ((NS == 2 && !CHAIN) || (NS == 4 && CHAIN) || (NS == 3 && CHAIN));
+    constexpr bool kSplittable = XK < 0 && SZ == 3 && ((NS == 2 && !CHAIN) || (NS == 4 && CHAIN) || (NS == 3 && CHAIN));
     bool shared = false;
     int S = N;
     if constexpr (kSplittable) {
@@ -1057,6 +1105,11 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs) {
         }
     }
     TVP_END(t, N, o.n, 2)
+    if constexpr (XK >= 0) {   // (cross_const: ind = (ind + ra1) + ra2, then this sum's |scale|)
+        const double asc = fabs(cx.s[XK].scale);
+#pragma unroll
+        for (int q = 0; q < 3; q++) { indk[XK][q] = ((xind[q] + cx.xr1[q]) + cx.xr2[q]) * asc; ind2k[XK][q] = ((xind2[q] + cx.xr1[q]) + cx.xr2[q]) * asc; }
+    }
 #pragma unroll
     for (int e = 0; e < SZ; e++) {
         double r, r2;
