@@ -78,6 +78,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     const int J = c.J;
     const bool fk_wave = c.nw == 4;                       // the forward kinematics has a wave of its own
     constexpr bool fused_cross = CH::kFusedCross;         // (time-vectorised chain) wdot x p and wdot x com are taken inside the sums that add them
+    // The w_aux recursion w_aux_{s+1} = R_t w_aux_s + qda_s depends on nothing but itself (like omega): in four-wave blocks of the time-vectorised
+    // chain it runs on the forward-kinematics wave next to omega, which hands the angular wave R_t w_aux_s for the one product of wdot's step
+    // that needs it, and does its forward kinematics -- which nobody waits for -- behind the recursions.  The angular wave's step, the chain the
+    // forward pass hangs on, is then three operators long instead of five.  (Measured: B = 128 9.77 -> 9.64 ms, 64: 8.86 -> 8.62, 16: 7.72 -> 7.52;
+    // with the forward kinematics still interleaved the same move is SLOWER, 10.2 ms: the angular wave then waits for a wave that is busy.)
+    const bool aux3 = CH::kFusedCross && fk_wave && cf.tv_aux_on_fk_wave != 0;   // (uses the slots of wdot x p, which are free when that product is taken inside the sum)
     const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
     const int wave_w = fk_wave ? 3 : 2;   // the wave that runs the omega recursion (see below)
@@ -100,16 +106,17 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     }
     if (c.wid == 1) {
         c.role = 1;
-        TPZ wdot = c.allocV(), waux = c.allocV();
+        TPZ wdot = c.allocV();
         set_const(w, wdot, nullptr, nullptr);
-        set_const(w, waux, nullptr, nullptr);
-        t3_post(c, T3_ST + 1, wdot); t3_post(c, T3_ST + 2, waux);
+        t3_post(c, T3_ST + 1, wdot);
+        if (!aux3) { TPZ waux = c.allocV(); set_const(w, waux, nullptr, nullptr); t3_post(c, T3_ST + 2, waux); }
     }
     if (c.wid == wave_w) {
         c.role = wave_w;
         TPZ wv = c.allocV();
         set_const(w, wv, nullptr, nullptr);
         t3_post(c, T3_ST + 0, wv);
+        if (aux3) { TPZ waux = c.allocV(); set_const(w, waux, nullptr, nullptr); t3_post(c, T3_ST + 2, waux); }   // (w_aux belongs to the wave that runs its recursion)
     }
     if (c.wid == 0) {
         c.role = 0;
@@ -128,13 +135,14 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (k < J) t3_wait(c, T3_C0, k + 1);
             if (k >= 1) t3_wait(c, T3_CC2, k);
             c.freeVs(t3_take(c, T3_ST + 3 * k));
+            if (aux3) c.freeVs(t3_take(c, T3_ST + 3 * k + 2));   // (w_aux_k: the same readers)
             freed_w++;
         }
         const TPZ wv = t3_take(c, T3_ST + 3 * s);
         TPZ nw = c.mulMV(c.Rt(s), wv);
         if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), abs(cf.rb.axes[s]) - 1); c.freeVs(nw); nw = t2; }
         t3_post(c, T3_ST + 3 * (s + 1), nw);
-        t3_signal(c, T3_CA, s + 1);
+        if (!aux3) t3_signal(c, T3_CA, s + 1);   // (with w_aux on this wave: raised once w_aux_{s+1} is posted as well)
     };
     if (c.wid == 1) {
         c.role = 1;
@@ -145,24 +153,27 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 const int k = freed;
                 if (k < J) t3_wait(c, T3_C0, k + 1);
                 if (k >= 1) t3_wait(c, T3_CC2, k);
-                for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
+                for (int e = 1; e < (aux3 ? 2 : 3); e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
                 freed++;
             }
             if (wave_w == 1) omega_step(s, freed_w1);
-            const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
+            const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1);
             const TPZ Rt = c.Rt(s);
             const int ax = abs(cf.rb.axes[s]) - 1;
-            TPZ na = c.mulMV(Rt, waux);
+            TPZ na = wdot;
+            if (!aux3) na = c.mulMV(Rt, t3_take(c, T3_ST + 3 * s + 2));
             TPZ nd = c.mulMV(Rt, wdot);
             if (cf.rb.axes[s] != 0) {
                 TPZ zero = c.allocV();
                 set_const(w, zero, nullptr, nullptr);
                 TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
+                if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_X1 + s); }   // R_t w_aux_s from the forward-kinematics wave
                 TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
                 TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
-                TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2;
+                if (!aux3) { TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2; }
             }
-            t3_post(c, T3_ST + 3 * (s + 1) + 1, nd); t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+            t3_post(c, T3_ST + 3 * (s + 1) + 1, nd);
+            if (!aux3) t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
             t3_signal(c, T3_C1, s + 1);
         }
         for (int s = J; s > J - n_tail; s--) {   // N = I * wdot + cross(w_aux, I * w) of link s - 1
@@ -177,7 +188,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         c.prof_forward_done(); c.bar();   // (A) the forward pass is over everywhere
         for (int k = freed; k <= J; k++)
-            for (int e = 1; e < 3; e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
+            for (int e = 1; e < (aux3 ? 2 : 3); e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
         if (wave_w == 1) for (int k = freed_w1; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
     } else if (c.wid == 0) {
         c.role = 0;
@@ -220,15 +231,29 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         FkStateT<TPZ> fk;
         fk_begin(c, fk);
         int freed_w = 0;
+        int freed_na = 0;   // (aux3) R_t w_aux_k, k < freed_na, have been given back
         for (int s = 0; s < J; s++) {
             omega_step(s, freed_w);   // first: wave 0 waits for it
+            if (aux3) {   // the w_aux recursion: R_t w_aux_s for the angular wave's step s, then w_aux_{s+1} = R_t w_aux_s + qda_s
+                while (freed_na + 1 < s) {   // R_t w_aux_k: read by the angular wave at step k
+                    t3_wait(c, T3_C1, freed_na + 1);
+                    if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_X1 + freed_na));   // (a fixed joint: it IS w_aux_{k+1})
+                    freed_na++;
+                }
+                const TPZ waux = t3_take(c, T3_ST + 3 * s + 2);
+                TPZ na = c.mulMV(c.Rt(s), waux);
+                t3_post(c, T3_X1 + s, na);
+                if (cf.rb.axes[s] != 0) na = c.addOneDim(na, c.qda(s), abs(cf.rb.axes[s]) - 1);
+                t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+                t3_signal(c, T3_CA, s + 1);   // omega_{s+1}, w_aux_{s+1} and R_t w_aux_s are posted
+            }
             {   // the two cross products with the joint offset for wave 0's step s, at most two steps ahead of it
                 if (s >= 2) {
                     t3_wait(c, T3_C0, s - 1);
                     if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s - 2));
                     c.freeVs(t3_take(c, T3_X2 + s - 2));
                 }
-                t3_wait(c, T3_C1, s);
+                if (!aux3) t3_wait(c, T3_C1, s);   // (w_aux_s is this wave's own otherwise)
                 const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
                 const double* tr = &cf.rb.trans[3 * s];
                 if constexpr (!fused_cross) { TPZ x1 = c.crossPzMat(wdot, tr); t3_post(c, T3_X1 + s, x1); }
@@ -236,11 +261,13 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 t3_post(c, T3_X2 + s, x2);
                 t3_signal(c, T3_C3, s + 1);
             }
-            fk_step(c, fk, s, b, t_lane);
+            if (!aux3) fk_step(c, fk, s, b, t_lane);
         }
+        if (aux3) for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);   // (behind the recursions the other waves wait for)
         c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
-        for (int k = freed_w; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
+        for (int k = freed_w; k <= J; k++) { c.freeVs(t3_take(c, T3_ST + 3 * k)); if (aux3) c.freeVs(t3_take(c, T3_ST + 3 * k + 2)); }
+        if (aux3) for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_X1 + k));
         for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
     } else {
         c.role = 2;

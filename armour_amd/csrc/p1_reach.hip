@@ -76,6 +76,7 @@ struct P1Cfg {
     int free_running;     // the same choice for the per-step kernel's three-wave blocks
     int tv_groups, tv_lanes, tv_cap, tv_stage_rows, tv_stage_rows_other;  // staging rows of wave 1 (or of the only wave) / of the other waves
     int tv_help_min, tv_help_n;  // shared walks: smallest walk that is shared; whether the n-recursion shares its walks as well (development switches)
+    int tv_aux_on_fk_wave;  // four-wave blocks: the w_aux recursion runs on the forward-kinematics wave (p1_free.inc.h)
     int tv_help_shift;    // eight-wave blocks: role wave p's helper is wave 4 + (p + shift) % 4
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
 };
@@ -1745,6 +1746,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             static const int tv_help_min_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_MIN"); return e ? atoi(e) : 192; }();
             static const int tv_help_n_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_N"); return e ? atoi(e) : 1; }();
             cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env; cf.tv_help_shift = tv_shift_env;
+            static const int tv_aux3_env = [] { const char* e = getenv("ARMOUR_P1_TV_AUX3"); return e ? atoi(e) : 1; }();   // development switch
+            cf.tv_aux_on_fk_wave = tv_aux3_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {
