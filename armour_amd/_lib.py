@@ -74,7 +74,7 @@ EXPORTS = [
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_prepare_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
-    "armour_get_hyperplanes", "armour_get_build_ms", "armour_p2_kernel_name", "armour_debug_load_tables",
+    "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
     "armour_get_plane_skip", "armour_set_option", "armour_eval_violations_device", "armour_eval_violations",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
@@ -164,6 +164,7 @@ def load():
     L.armour_get_table_sizes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.armour_get_hyperplanes.argtypes = [vp, dp, dp, dp]
     L.armour_get_build_ms.argtypes = [vp, dp]
+    L.armour_get_build_info.argtypes = [vp, ip]
     L.armour_p2_kernel_name.restype = C.c_char_p
     L.armour_debug_load_tables.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, ip, dp, C.POINTER(C.c_uint64), dp,
                                            C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]

@@ -333,6 +333,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
                                         const double* A, const double* d, const double* delta, const double* torque_radius) {
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
+    h->build_ms = 0; h->build_info[0] = h->build_info[1] = h->build_info[2] = h->build_info[3] = 0;   // no reach-set kernel ran
     const int J = h->J, T = h->T, n = h->n, capL = h->lim.link_monomials, capT = h->lim.torque_monomials;
     const size_t nl = (size_t)B * J * T, nt = (size_t)B * n * T;
     // centres arrive as [..][2][sz]: slot 0 = centre, slot 1 = independent radius
@@ -912,5 +913,12 @@ extern "C" int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip) {
 extern "C" int armour_get_build_ms(ArmourPlanner* h, double* ms) {
     NEED_READY(h);
     *ms = h->build_ms;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_build_info(ArmourPlanner* h, int32_t* out4) {
+    NEED_READY(h);
+    if (!out4) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    for (int i = 0; i < 4; i++) out4[i] = h->build_info[i];
     return ARMOUR_OK;
 }

@@ -144,6 +144,7 @@ struct ArmourPlanner {
     double* d_g = nullptr;
     double* d_jac = nullptr;
     double build_ms = 0;
+    int build_info[4] = {0, 0, 0, 0};          // armour_get_build_info: kernel of the last reach-set build, waves per block, sort-buffer entries, launches
     int max_link = 0, max_torque = 0;          // largest monomial counts in the current tables (LDS sizing of P2)
     long long sum_link = 0, sum_torque = 0;
     // P1 workspace (p1_reach.hip)

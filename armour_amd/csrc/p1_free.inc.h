@@ -15,8 +15,8 @@
 // freed by its owner once the counters show every reader past it (state_k: K joints back).  Same operators on the same
 // operands as run_rnea: bit-identical tables.
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
-       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_X2 + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
+       T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS, T3_NA = T3_X2 + ARMOUR_MAX_JOINTS,
+       T3_CNT = T3_NA + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 // LDS mailbox of run_rnea / run_rnea_free, followed by the two walk-helper channels of the time-vectorised four-wave blocks
 // (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
 constexpr int kHelpBase = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;
@@ -83,7 +83,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // that needs it, and does its forward kinematics -- which nobody waits for -- behind the recursions.  The angular wave's step, the chain the
     // forward pass hangs on, is then three operators long instead of five.  (Measured: B = 128 9.77 -> 9.64 ms, 64: 8.86 -> 8.62, 16: 7.72 -> 7.52;
     // with the forward kinematics still interleaved the same move is SLOWER, 10.2 ms: the angular wave then waits for a wave that is busy.)
-    const bool aux3 = CH::kFusedCross && fk_wave && cf.tv_aux_on_fk_wave != 0;   // (uses the slots of wdot x p, which are free when that product is taken inside the sum)
+    const bool aux3 = fk_wave && cf.tv_aux_on_fk_wave != 0;
     const bool with_fk = cf.fk_items == 0 && !fk_wave;   // ... otherwise wave 2 runs it (unless other blocks do)
     constexpr int K = 3;  // joints a producer may run ahead of the slowest reader of its results
     const int wave_w = fk_wave ? 3 : 2;   // the wave that runs the omega recursion (see below)
@@ -167,7 +167,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 TPZ zero = c.allocV();
                 set_const(w, zero, nullptr, nullptr);
                 TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
-                if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_X1 + s); }   // R_t w_aux_s from the forward-kinematics wave
+                if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_NA + s); }   // R_t w_aux_s from the forward-kinematics wave
                 TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
                 TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
                 if (!aux3) { TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2; }
@@ -228,8 +228,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         // the forward kinematics shares nothing with the recursion but the JRS rotations: wave 2 was the last to finish the
         // forward pass while it carried it (14.1 M cycles against 9.4 / 10.1 M of the other two)
         c.role = 3;
+        const bool w3_fk = cf.fk_items == 0;   // (the per-step kernel issues the forward kinematics of a lone problem as items of their own)
         FkStateT<TPZ> fk;
-        fk_begin(c, fk);
+        if (w3_fk) fk_begin(c, fk);
         int freed_w = 0;
         int freed_na = 0;   // (aux3) R_t w_aux_k, k < freed_na, have been given back
         for (int s = 0; s < J; s++) {
@@ -237,12 +238,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (aux3) {   // the w_aux recursion: R_t w_aux_s for the angular wave's step s, then w_aux_{s+1} = R_t w_aux_s + qda_s
                 while (freed_na + 1 < s) {   // R_t w_aux_k: read by the angular wave at step k
                     t3_wait(c, T3_C1, freed_na + 1);
-                    if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_X1 + freed_na));   // (a fixed joint: it IS w_aux_{k+1})
+                    if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_NA + freed_na));   // (a fixed joint: it IS w_aux_{k+1})
                     freed_na++;
                 }
                 const TPZ waux = t3_take(c, T3_ST + 3 * s + 2);
                 TPZ na = c.mulMV(c.Rt(s), waux);
-                t3_post(c, T3_X1 + s, na);
+                t3_post(c, T3_NA + s, na);
                 if (cf.rb.axes[s] != 0) na = c.addOneDim(na, c.qda(s), abs(cf.rb.axes[s]) - 1);
                 t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
                 t3_signal(c, T3_CA, s + 1);   // omega_{s+1}, w_aux_{s+1} and R_t w_aux_s are posted
@@ -254,20 +255,23 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                     c.freeVs(t3_take(c, T3_X2 + s - 2));
                 }
                 if (!aux3) t3_wait(c, T3_C1, s);   // (w_aux_s is this wave's own otherwise)
-                const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
                 const double* tr = &cf.rb.trans[3 * s];
-                if constexpr (!fused_cross) { TPZ x1 = c.crossPzMat(wdot, tr); t3_post(c, T3_X1 + s, x1); }
-                TPZ x2 = c.crossPzMat(waux, tr);
+                TPZ x2 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 2), tr);
                 t3_post(c, T3_X2 + s, x2);
+                if constexpr (!fused_cross) {   // wdot x p where it is a PZ of its own
+                    if (aux3) t3_wait(c, T3_C1, s);
+                    TPZ x1 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 1), tr);
+                    t3_post(c, T3_X1 + s, x1);
+                }
                 t3_signal(c, T3_C3, s + 1);
             }
-            if (!aux3) fk_step(c, fk, s, b, t_lane);
+            if (!aux3 && w3_fk) fk_step(c, fk, s, b, t_lane);
         }
-        if (aux3) for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);   // (behind the recursions the other waves wait for)
-        c.freeVs(fk.T);
+        if (aux3 && w3_fk) for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);   // (behind the recursions the other waves wait for)
+        if (w3_fk) c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
         for (int k = freed_w; k <= J; k++) { c.freeVs(t3_take(c, T3_ST + 3 * k)); if (aux3) c.freeVs(t3_take(c, T3_ST + 3 * k + 2)); }
-        if (aux3) for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_X1 + k));
+        if (aux3) for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_NA + k));
         for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
     } else {
         c.role = 2;

@@ -38,10 +38,14 @@ constexpr int kNS = 24, kNM = 2;   // 1x1 and 3x3 work slots per block; 3x1 work
 // so three waves can run different operators at the same time without sharing allocator state.
 constexpr int kRoles = 3;
 constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28};  // of the 62 slots of a 3-wave block (run_rnea_free keeps a few joints' states alive)
+// ... and of a 4-wave block (round 3: the forward kinematics, the omega recursion and the constant cross products on a wave of their own,
+// as the time-vectorised kernel's four-wave blocks have had since round 2: p1_tv.inc.h kTvPart4First)
+constexpr int kPart4First[4] = {0, 8, 23, 43}, kPart4Count[4] = {8, 15, 20, 20};   // (63 slots: the free mask is one 64-bit word, built as (1 << nV) - 1)
+constexpr int kFkCapKey = 1024, kFkCapRaw = 2048;   // sort buffers of that fourth wave: its products stay below 0.9 k raw terms; the ranked rotation x vector products of omega need room for the permutation only
 constexpr int kRoleN = 2;  // the role that computes (and later frees) the moments N_i (measured with it in role 0 / 1 / 2 and the forward kinematics split off: 2.06 / 2.01 / 1.95 ms)
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
 constexpr int kCapSmall = 8;                 // capacity of the JRS / constant slots
-constexpr int kMaxSlots = 192;
+constexpr int kMaxSlots = 208;
 
 struct P1Cfg {
     int B, T, J, n, O;
@@ -94,7 +98,7 @@ struct Layout {
 __host__ __device__ inline Layout make_layout(int J, int n, int capW, int nroles) {
     Layout L;
     L.nroles = nroles;
-    L.nV = nroles == 1 ? kNVOneWave : kPartFirst[kRoles - 1] + kPartCount[kRoles - 1];
+    L.nV = nroles == 1 ? kNVOneWave : nroles == kRoles ? kPartFirst[kRoles - 1] + kPartCount[kRoles - 1] : kPart4First[3] + kPart4Count[3];
     L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
     L.nJV = (J + 1) + J;              // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;   // qd, qda, qdda; mass; per role: 4 raw temps
@@ -344,16 +348,17 @@ struct Chain {
 
     int role = 0;  // the role the code being executed belongs to: selects the part of the 3x1 pool allocV() draws from
     __device__ PZ allocV() {
-        const unsigned long long part = L.nroles == 1 ? ~0ull : ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role];
+        const unsigned long long part = L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role]
+                                                                                   : ((1ull << kPart4Count[role]) - 1ull) << kPart4First[role];
         const int i = __ffsll((long long)(freeV & part)) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return V(L.nroles == 1 ? 0 : kPartFirst[role]); }
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 100 + role; return V(L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
         freeV &= ~(1ull << i);
         return V(i);
     }
     __device__ void freeVs(const PZ& p) { freeV |= 1ull << (p.id - L.idV); }
     __device__ PZ allocS() {
         const int i = __ffs(freeS) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); return S(0); }
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 200 + role; return S(0); }
         freeS &= ~(1u << i);
         return S(i);
     }
@@ -908,11 +913,14 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     c.nw = NW;
     c.wid = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
+    // waves 0..2: sort buffers of capKey / capRaw entries; wave 3 of a four-wave block: the small ones (kFkCapKey / kFkCapRaw)
+    const bool fk_bufs = NW == 4 && c.wid == 3;
+    const int my_cap_key = fk_bufs ? kFkCapKey : cf.capKey, my_cap_raw = fk_bufs ? kFkCapRaw : cf.capRaw;
     LDS_AS unsigned char* mine = lds + (size_t)c.wid * p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)cf.capKey * 8);
-    c.w.lstat = (LDS_AS int*)(mine + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
-    LDS_AS unsigned char* shared = lds + (size_t)NW * p1_wave_lds(cf.capKey, cf.capRaw);
+    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
+    c.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
+    LDS_AS unsigned char* shared = lds + (size_t)(NW == 4 ? 3 : NW) * p1_wave_lds(cf.capKey, cf.capRaw) + (NW == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
     c.ci = (LDS_AS double*)(shared + ((((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15) & ~(size_t)15));
@@ -922,8 +930,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     const long long prof_start = clock64();
 #endif
     P1_PIN_ONE_WAVE_PER_SIMD();
-    c.w.cap_raw = cf.capRaw;
-    c.w.cap_key = cf.capKey;
+    c.w.cap_raw = my_cap_raw;
+    c.w.cap_key = my_cap_key;
     c.w.thr = cf.pr.simplify_threshold;
     c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x & 63;
@@ -1572,13 +1580,16 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
     if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
-    const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles);
-    if (L3.idJS + L3.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
+    const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles), L4 = make_layout(J, n, h->lim.work_monomials, 4);
+    if (L4.idJS + L4.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
     auto ci_doubles = [&](const Layout& L) { return (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3; };
-    auto lds_bytes = [&](int cap, int nw = 1) { return (size_t)nw * p1_wave_lds(cap, cap) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : L3)); };
+    auto lds_bytes = [&](int cap, int nw = 1) {
+        return (size_t)(nw == 4 ? 3 : nw) * p1_wave_lds(cap, cap) + (nw == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : nw == kRoles ? L3 : L4));
+    };
     static const int max_waves_env = [] { const char* e = getenv("ARMOUR_P1_MAX_WAVES_PER_CU"); return e ? atoi(e) : 4 * P1_WAVES_PER_SIMD; }();  // development override
     auto waves_per_cu = [&](int cap) { return std::max(1, std::min(max_waves_env, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };
     float total_ms = 0;
+    h->build_info[0] = h->build_info[1] = h->build_info[2] = h->build_info[3] = 0;
     unsigned st[ST_WORDS];
     // one launch of the chain kernel over `n_items` work items (d_items == nullptr: all of them) with sort buffers of `cap`
     // entries; with `collect` the items that overflow them are listed in wk->d_retry instead of failing the launch
@@ -1586,16 +1597,32 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
         static const int nw_env = [] { const char* e = getenv("ARMOUR_P1_WAVES"); return e ? atoi(e) : 0; }();  // development override
-        const bool three = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
-                           : nw_env ? nw_env == 3 : (!collect && n_items <= prop.multiProcessorCount && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
-        const int nw = three ? kRoles : 1;
-        const Layout& L = three ? L3 : L1;
+        // (round 3) ... FOUR waves when the block's LDS holds the fourth wave's small sort buffers as well: the forward kinematics,
+        // the omega recursion and the constant cross products of the linear acceleration leave the three recursion waves for a wave
+        // of their own (run_rnea_free, the choreography of the time-vectorised kernel's four-wave blocks) and no item is issued twice
+        static const int free_env0 = [] { const char* e = getenv("ARMOUR_P1_FREE"); return e ? atoi(e) : 1; }();
+        const bool fits4 = free_env0 && lds_bytes(cap, 4) <= (size_t)160 * 1024;
+        // Four-wave blocks take an item in 1.17 ms, one per CU at a time; one-wave blocks in 2.7 ms, waves_per_cu of them per CU.  With more
+        // items than CUs the blocks loop, and what decides is the number of rounds either shape needs (measured, B problems of 100 steps,
+        // four waves against one: B = 3..5 2.3-2.6 against 2.8-3.1 ms, 6..7 3.5-3.7 against 3.2-3.5, 8..10 4.4-4.8 against 5.2-5.7,
+        // 12 6.0 either way, 14..15 7.0 against 6.3: profiles/r03_p1_four_waves.txt)
+        const int cus = prop.multiProcessorCount;
+        const long long r4 = (n_items + cus - 1) / cus, r1 = (n_items + (long long)cus * waves_per_cu(cap) - 1) / ((long long)cus * waves_per_cu(cap));
+        const bool multi = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
+                           : nw_env ? nw_env >= 3
+                           : collect ? false
+                           : fits4 ? 4 * r4 < 9 * r1
+                                   : (n_items <= cus && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
+        const bool four = multi && free_env0 && (nw_env ? nw_env == 4 : fits4);
+        const bool three = multi && !four;
+        const int nw = four ? 4 : three ? kRoles : 1;
+        const Layout& L = four ? L4 : three ? L3 : L1;
         const size_t smem = lds_bytes(cap, nw);
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
-        const int per_cu = three ? 1 : waves_per_cu(cap);
+        const int per_cu = multi ? 1 : waves_per_cu(cap);
         // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
         static const int split_env = [] { const char* e = getenv("ARMOUR_P1_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
-        const bool split = split_env >= 0 ? (split_env != 0 && three) : (three && 2 * n_items <= prop.multiProcessorCount);
+        const bool split = split_env >= 0 ? (split_env != 0 && multi) : (multi && 2 * n_items <= prop.multiProcessorCount);
         const int fk_items = split ? n_items : 0;
         const int waves = std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
@@ -1620,15 +1647,19 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
         cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
         cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
+        static const int aux3_env = [] { const char* e = getenv("ARMOUR_P1_AUX3"); return e ? atoi(e) : 1; }();   // development switch
+        cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
         {
             std::lock_guard<std::mutex> lk(g_p1_launch_mu);
-            if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (four) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else if (three) HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             else HIPCHK(hipFuncSetAttribute((const void*)armour_p1_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
+            if (four) hipLaunchKernelGGL(armour_p1_chain_kernel<4>, dim3(waves), dim3(WAVE * 4), smem, h->stream, cf);
+            else if (three) hipLaunchKernelGGL(armour_p1_chain_kernel<kRoles>, dim3(waves), dim3(WAVE * kRoles), smem, h->stream, cf);
             else hipLaunchKernelGGL(armour_p1_chain_kernel<1>, dim3(waves), dim3(WAVE), smem, h->stream, cf);
             HIPCHK(hipGetLastError());
         }
@@ -1638,6 +1669,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
+        h->build_info[0] = ARMOUR_P1_KERNEL_PER_STEP; h->build_info[1] = nw; h->build_info[2] = cap; h->build_info[3]++;
 #ifdef P1_PROFILE
         {
             unsigned long long pr[PR_WORDS];
@@ -1770,6 +1802,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
+            h->build_info[0] = ARMOUR_P1_KERNEL_TIME_VECTORISED; h->build_info[1] = nw_launch; h->build_info[2] = cap; h->build_info[3]++;
             if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape

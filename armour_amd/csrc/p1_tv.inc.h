@@ -14,7 +14,7 @@ constexpr int kTvNS = 12, kTvNM = 2;   // 1x1 and 3x3 work slots; 3x1 work slots
 // 3x1 pool of a three-wave block (run_rnea_free: the waves run ahead of each other, so a few joints' states are alive at a time)
 constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22, 28};
 // ... and of a four-wave block (the forward kinematics on a wave of its own)
-constexpr int kTvPart4First[4] = {0, 8, 22, 44}, kTvPart4Count[4] = {8, 14, 22, 18};   // (the forward-kinematics wave also owns w_aux and R_t w_aux: p1_free.inc.h, aux3)
+constexpr int kTvPart4First[4] = {0, 8, 23, 43}, kTvPart4Count[4] = {8, 15, 20, 20};   // (the forward-kinematics wave also owns w_aux and R_t w_aux: p1_free.inc.h, aux3)
 
 // (one spare key and one spare row block beyond `cap`)
 __host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }

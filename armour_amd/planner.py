@@ -483,6 +483,13 @@ class ArmourNLP:
         check(self.L.armour_get_build_ms(self.h, C.byref(v)))
         return v.value
 
+    def build_info(self):
+        """How the last set_parameters built its tables (armour_get_build_info): kernel "per_step" | "time_vectorised",
+        waves per block and sort-buffer entries of its last launch, reach-set launches in all."""
+        out = (C.c_int32 * 4)()
+        check(self.L.armour_get_build_info(self.h, out))
+        return {"kernel": {0: None, 1: "per_step", 2: "time_vectorised"}[out[0]], "waves": out[1], "sort_entries": out[2], "launches": out[3]}
+
     def plane_skip(self):
         """[B] uint64: bit p set = half-space p is never needed by any collision row of the problem (armour_get_plane_skip)."""
         out = np.zeros(self.B, dtype=np.uint64)

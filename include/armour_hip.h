@@ -279,6 +279,14 @@ int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, double* delta
 int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip);
 /* ms spent in the last armour_set_problems (device time, hipEvent) */
 int armour_get_build_ms(ArmourPlanner* h, double* ms);
+/* how the last armour_set_problems built its tables: out4 = {kernel that produced them (ARMOUR_P1_KERNEL_*), waves per block of
+ * its last launch, sort-buffer entries per wave of that launch, launches of reach-set kernels in all}.  A launch whose sort buffers or
+ * slot pools overflow is repeated with the next block shape (and a time-vectorised build that cannot be helped that way is repeated
+ * step by step), so `launches` > 1 tells a caller that the limits in ArmourLimits are too small for the fast path; tools and tests
+ * read the kernel.  {0,0,0,0} after armour_debug_load_tables. */
+#define ARMOUR_P1_KERNEL_PER_STEP 1
+#define ARMOUR_P1_KERNEL_TIME_VECTORISED 2
+int armour_get_build_info(ArmourPlanner* h, int32_t* out4);
 /* name of the P2 kernel as it appears in rocprofv3 kernel traces */
 const char* armour_p2_kernel_name(void);
 

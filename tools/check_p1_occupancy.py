@@ -42,8 +42,8 @@ def main(argv):
         regs = int(r.get("VGPRs", "0")) + int(r.get("AGPRs", "0"))
         if occ > allow or (allow == 1 and regs <= 256):
             bad.append(f"{name}: occupancy {occ}, {r.get('VGPRs')} VGPRs + {r.get('AGPRs')} AGPRs")
-    if seen < 6:   # chain<1>, chain<3>, pzop, tv<1>, tv<3>, tv<4>
-        print(f"check_p1_occupancy: only {seen} of the 6 operator kernels found in {argv[1]}", file=sys.stderr)
+    if seen < 7:   # chain<1>, chain<3>, chain<4>, pzop, tv<1>, tv<3>, tv<4>
+        print(f"check_p1_occupancy: only {seen} of the 7 operator kernels found in {argv[1]}", file=sys.stderr)
         return 2
     if bad:
         print("check_p1_occupancy: these kernels would share a SIMD with a second wave:\n  " + "\n  ".join(bad), file=sys.stderr)

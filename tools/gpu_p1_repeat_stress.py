@@ -9,7 +9,7 @@ from armour_amd.planner import ArmourNLP
 from armour_amd.worlds import random_batch, random_k
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 total_bad = 0
-for B, O in ((1, 20), (2, 20), (3, 20), (12, 20), (16, 20), (40, 10), (64, 20), (128, 20), (150, 5), (300, 3)):
+for B, O in ((1, 20), (2, 20), (3, 20), (5, 20), (9, 20), (12, 20), (16, 20), (40, 10), (64, 20), (128, 20), (150, 5), (300, 3)):
     bp = random_batch(7, B, O)
     ks = random_k(3, B)
     first = None
@@ -20,8 +20,9 @@ for B, O in ((1, 20), (2, 20), (3, 20), (12, 20), (16, 20), (40, 10), (64, 20), 
         h = hashlib.sha1(np.ascontiguousarray(nlp.torque_radius()).tobytes() + np.ascontiguousarray(nlp.link_generators()).tobytes()
                          + np.ascontiguousarray(g).tobytes() + np.ascontiguousarray(jac).tobytes()).hexdigest()
         first = first or h
+        info = nlp.build_info()
         bad += h != first
         del nlp
     total_bad += bad
-    print(f"B={B:4d} O={O:3d}: {REPS} builds, {bad} differ from the first ({first[:12]})", flush=True)
+    print(f"B={B:4d} O={O:3d}: {REPS} builds, {bad} differ from the first ({first[:12]})  [{info['kernel']}, {info['waves']} wave(s) per block, {info['launches']} launch(es)]", flush=True)
 print("TOTAL differing builds:", total_bad)
