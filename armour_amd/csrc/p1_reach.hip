@@ -496,57 +496,69 @@ __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, 
 }
 
 // JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67).
-// The joints are independent of each other: joint i is built by role i % 3 (with that role's scratch slots), so a 3-wave
-// block builds three joints at a time.  The caller follows with a block barrier.
+// The joints are independent of each other: joint i is built by wave i % (waves of the block), with that wave's scratch slots.  (One joint
+// is ~135 k cycles of tiny operators, each a round trip through the arena: on three waves of four this phase was 0.40 M of the 2.5 M cycles
+// of a lone problem's time step.  Dealing the three parts of a joint -- rotation, velocity polynomials, link box -- to different waves
+// balances better but evaluates jrs_scalars twice per joint, and came out slower: profiles/r03_p1_four_waves.txt.)  What the item does not
+// read is not built: a chain that stops at the forward kinematics has no velocity polynomials, an RNEA item whose forward kinematics runs
+// as an item of its own no link boxes.
+// The caller follows with a block barrier.
 __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
+    const bool boxes = kin_only || cf.fk_items == 0;
     for (int i = 0; i < J; i++) {
-        const int role = i % kRoles;
+        const int role = c.nw == 1 ? 0 : i % c.nw;   // the wave that builds joint i, with its own scratch slots
         if (!c.is(role)) continue;
-        double rp[9];
-        rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
-        if (i < n && cf.rb.axes[i] != 0) {
-            JrsScalars js;
+        const bool actuated = i < n && cf.rb.axes[i] != 0;
+        JrsScalars js;
+        const uint64_t kk = 1ull << (2 * i);
+        if (actuated) {
             if (cf.mode == ARMOUR_MODE_ARMTD) js = armtd_jrs_scalars(cf, bz[i], b, i, t);
             else js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t);
-            const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
-            // rotation about the joint axis from cos / sin polynomials, then R = R_rpy * Rz (:129-134)
-            double cen[9], co[4 * 9];
-            make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
-            make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
-            make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
-            make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
-            make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
-            const uint64_t keys[4] = {kk, kc, kk, ks};
-            build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
-            set_const(c.w, c.rpy(role), rp, nullptr);
-            mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
-            // qd_des, qda_des, qdda_des (:176-243); a chain that stops at the forward kinematics has none
-            if (!kin_only) {
-            {
-                const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
-                const double co2[2] = {js.qd_k, js.qd_e};
-                build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
-            }
-            {
-                const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
-                const double co2[2] = {js.qd_k, js.qda_e};
-                build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
-            }
-            {
-                const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
-                const double co2[2] = {js.qdd_k, js.qdd_e};
-                build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
-            }
-            }
-        } else {
-            set_const(c.w, c.R(i), rp, nullptr);
         }
-        transpose33(c.w, c.Rt(i), c.R(i));
-        set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+        {
+            double rp[9];
+            rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
+            if (actuated) {
+                const uint64_t kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
+                // rotation about the joint axis from cos / sin polynomials, then R = R_rpy * Rz (:129-134)
+                double cen[9], co[4 * 9];
+                make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
+                make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
+                make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
+                make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
+                make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
+                const uint64_t keys[4] = {kk, kc, kk, ks};
+                build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
+                set_const(c.w, c.rpy(role), rp, nullptr);
+                mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
+            } else {
+                set_const(c.w, c.R(i), rp, nullptr);
+            }
+            transpose33(c.w, c.Rt(i), c.R(i));
+            set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+        }
         if (!kin_only) {
+            // qd_des, qda_des, qdda_des (:176-243)
+            if (actuated) {
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
+                    const double co2[2] = {js.qd_k, js.qd_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
+                }
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
+                    const double co2[2] = {js.qd_k, js.qda_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
+                }
+                {
+                    const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
+                    const double co2[2] = {js.qdd_k, js.qdd_e};
+                    build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
+                }
+            }
             // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
             double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
             double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -555,13 +567,15 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
             for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
             set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
         }
-        // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
-        for (int j = 0; j < 3; j++) {
-            const uint64_t key = 1ull << ((j + 2) * n);
-            build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+        if (boxes) {
+            // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
+            for (int j = 0; j < 3; j++) {
+                const uint64_t key = 1ull << ((j + 2) * n);
+                build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
+            }
+            Seg s[3] = {{view(c.w, c.rawS(role, 1)), 1.0, 0}, {view(c.w, c.rawS(role, 2)), 1.0, 1}, {view(c.w, c.rawS(role, 3)), 1.0, 2}};
+            lincomb<3, 3>(c.w, c.linkbox(i), s);
         }
-        Seg s[3] = {{view(c.w, c.rawS(role, 1)), 1.0, 0}, {view(c.w, c.rawS(role, 2)), 1.0, 1}, {view(c.w, c.rawS(role, 3)), 1.0, 2}};
-        lincomb<3, 3>(c.w, c.linkbox(i), s);
     }
     if (c.is(0)) {
         double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
