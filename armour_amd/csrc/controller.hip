@@ -6,6 +6,7 @@
 // (model file -> CoM frames -> interval model, robot_models.cpp:124-255) is host arithmetic done once per call from
 // the ArmourRobot constants; the per-state arithmetic is controller_core.h.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -126,6 +127,98 @@ __global__ __launch_bounds__(64) void armour_controller_kernel(const CtlArgs* __
     if (!ok) atomicOr(status, 1);
 }
 
+// Latency form for few states -- the simulator's own call pattern is ONE state per ODE step (kinova_controller.cpp:19-84), and one lane
+// working through robust_update is 1.35 ms of dependent interval arithmetic.  A block of four waves, lane = state in every wave:
+//   wave 0  the nominal RNEA, and at the end the robust input from everybody's torques;
+//   wave 3  the interval kinematics (Xli_i, Sb_i), published joint by joint through LDS;
+//   wave 1  the interval dynamics of the torque enclosure, wave 2 those of M r, both reading the kinematics as they appear.
+// Every quantity is computed by the same code in the same order as in the one-thread form: results are bit-identical
+// (tests/test_controller.py).  Lanes past the last state shadow it, so that every wave runs its loops whole.  16 states per block: the
+// kinematics of 64 would need 130 KB of LDS (and the first version, with a 154 KB dynamic allocation, ended in a memory-aperture violation
+// that the core dump did not explain); with 16 everything is static and below 64 KB.
+#define CTL_LDS __attribute__((address_space(3)))
+constexpr int kSplitStates = 16;
+constexpr int kKinWords = 18;   // Xli: R 9 + p 3, Sb: w 3 + v 3 intervals per joint
+struct SplitLds {
+    double u_nom[ARMOUR_MAX_FACTORS][kSplitStates];
+    double u_int[ARMOUR_MAX_FACTORS][2][kSplitStates], Mr[ARMOUR_MAX_FACTORS][2][kSplitStates];   // intervals as {lo, hi} planes
+    double kin[ARMOUR_MAX_FACTORS][kKinWords][2][kSplitStates];
+    int joints_published;
+};
+__device__ inline void lds_put(CTL_LDS double (*p)[kSplitStates], int lane, Itv v) { p[0][lane] = v.lo; p[1][lane] = v.hi; }
+__device__ inline Itv lds_get(const CTL_LDS double (*p)[kSplitStates], int lane) { return Itv{p[0][lane], p[1][lane]}; }
+__global__ __launch_bounds__(256) void armour_controller_split_kernel(const CtlArgs* __restrict__ ap, int B, const double* __restrict__ q,
+                                                                      const double* __restrict__ qd, const double* __restrict__ q_des,
+                                                                      const double* __restrict__ qd_des, const double* __restrict__ qdd_des,
+                                                                      double* __restrict__ u, double* __restrict__ tau, double* __restrict__ v,
+                                                                      int* __restrict__ status) {
+    __shared__ CtlArgs sa;
+    __shared__ SplitLds xs;
+    CTL_LDS SplitLds& x = *(CTL_LDS SplitLds*)&xs;   // (LDS-typed: ds instructions, no generic pointers into the exchange area)
+    for (unsigned i2 = threadIdx.x; i2 < sizeof(CtlArgs) / sizeof(double); i2 += blockDim.x)
+        reinterpret_cast<double*>(&sa)[i2] = reinterpret_cast<const double*>(ap)[i2];
+    if (threadIdx.x == 0) x.joints_published = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b0 = blockIdx.x * kSplitStates + lane;
+    const bool active = lane < kSplitStates && b0 < B;
+    const int slot = lane < kSplitStates ? lane : kSplitStates - 1;   // (idle lanes shadow the last state of the block; only lanes < kSplitStates write)
+    const bool own = lane < kSplitStates;
+    const int b = min(blockIdx.x * kSplitStates + slot, B - 1);
+    const CtlArgs& a = sa;
+    const int n = a.md.n;
+    double lq[ARMOUR_MAX_FACTORS], lqd[ARMOUR_MAX_FACTORS], lqdes[ARMOUR_MAX_FACTORS], lqddes[ARMOUR_MAX_FACTORS], lqdddes[ARMOUR_MAX_FACTORS];
+    double qa_d[ARMOUR_MAX_FACTORS], qa_dd[ARMOUR_MAX_FACTORS], r[ARMOUR_MAX_FACTORS];
+    for (int i = 0; i < n; i++) {
+        lq[i] = q[(size_t)b * n + i]; lqd[i] = qd[(size_t)b * n + i];
+        lqdes[i] = q_des[(size_t)b * n + i]; lqddes[i] = qd_des[(size_t)b * n + i]; lqdddes[i] = qdd_des[(size_t)b * n + i];
+    }
+    const double r_norm = robust_prepare(n, a.Kr, lq, lqd, lqdes, lqddes, lqdddes, qa_d, qa_dd, r);   // (every wave for itself: a few dozen operations)
+    // the kinematics of joint i are in LDS once joints_published > i
+    CTL_LDS SplitLds* const xp = &x;   // (the lambdas below capture by value: nothing of this frame is reached through a pointer)
+    auto get = [xp, slot](int i, Xf<Itv>& Xli, Tw<Itv>& Sb) {
+        CTL_LDS SplitLds& x = *xp;
+        while (__hip_atomic_load(&x.joints_published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= i) __builtin_amdgcn_s_sleep(1);
+        for (int e = 0; e < 9; e++) Xli.R.a[e] = lds_get(x.kin[i][e], slot);
+        for (int e = 0; e < 3; e++) { Xli.p.x[e] = lds_get(x.kin[i][9 + e], slot); Sb.w.x[e] = lds_get(x.kin[i][12 + e], slot); Sb.v.x[e] = lds_get(x.kin[i][15 + e], slot); }
+    };
+    if (wave == 0) {
+        double t[ARMOUR_MAX_FACTORS];
+        pass_rnea<double>(a.md, lq, lqd, qa_d, qa_dd, false, true, t);
+        if (own) for (int i = 0; i < n; i++) x.u_nom[i][lane] = t[i];
+    } else if (wave == 3) {
+        rnea_kinematics(a.imd, lq, [xp, own, lane](int i, const Xf<Itv>& Xli, const Tw<Itv>& Sb) {
+            CTL_LDS SplitLds& x = *xp;
+            if (own) {
+                for (int e = 0; e < 9; e++) lds_put(x.kin[i][e], lane, Xli.R.a[e]);
+                for (int e = 0; e < 3; e++) { lds_put(x.kin[i][9 + e], lane, Xli.p.x[e]); lds_put(x.kin[i][12 + e], lane, Sb.w.x[e]); lds_put(x.kin[i][15 + e], lane, Sb.v.x[e]); }
+            }
+            // (the wave runs in lockstep: lane 0's release store follows every lane's writes of this joint)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&x.joints_published, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
+    } else if (wave == 1) {
+        Itv t[ARMOUR_MAX_FACTORS];
+        rnea_dynamics(a.imd, get, lqd, qa_d, qa_dd, false, true, t);
+        if (own) for (int i = 0; i < n; i++) lds_put(x.u_int[i], lane, t[i]);
+    } else if (__ballot(r_norm > a.r_norm_threshold) != 0) {   // (no lane needs M r: nothing to do)
+        Itv t[ARMOUR_MAX_FACTORS];
+        double zero[ARMOUR_MAX_FACTORS];
+        for (int i = 0; i < n; i++) zero[i] = 0.0;
+        rnea_dynamics(a.imd, get, zero, zero, r, false, false, t);
+        if (own) for (int i = 0; i < n; i++) lds_put(x.Mr[i], lane, t[i]);
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        double lt[ARMOUR_MAX_FACTORS], lu[ARMOUR_MAX_FACTORS], lv[ARMOUR_MAX_FACTORS];
+        Itv ui[ARMOUR_MAX_FACTORS], mr[ARMOUR_MAX_FACTORS];
+        for (int i = 0; i < n; i++) { lt[i] = x.u_nom[i][lane]; ui[i] = lds_get(x.u_int[i], lane); mr[i] = lds_get(x.Mr[i], lane); }
+        const bool ok = robust_combine(n, a.alpha, a.V_max, a.r_norm_threshold, r, r_norm, lt, ui, mr, lu, lv);
+        for (int i = 0; i < n; i++) { u[(size_t)b * n + i] = lu[i]; tau[(size_t)b * n + i] = lt[i]; v[(size_t)b * n + i] = lv[i]; }
+        if (!ok) atomicOr(status, 1);
+    }
+}
+
 // Per-thread cache across calls: the MEX gateway this replaces is called once per ODE step with ONE state, so the fixed
 // cost of a call matters more than the kernel.  Kept: the prepared models on the device (rebuilt only when the robot or the
 // controller parameters change), the device buffer, and a page-locked staging buffer so that a small call is one H2D
@@ -160,6 +253,7 @@ int ctl_wait(hipStream_t st) {
     }
 }
 
+constexpr int kSplitMaxStates = kSplitStates * 256;   // up to one four-wave block per CU
 constexpr size_t kStagedDoubles = (size_t)1 << 20;  // calls up to this many input doubles go through the page-locked buffer
 
 }  // namespace
@@ -221,8 +315,15 @@ extern "C" int armour_robust_controller(const ArmourRobot* robot, double model_u
         for (int k = 0; k < 5; k++) HIPCHK(hipMemcpyAsync(d_in + (size_t)k * bn, in[k], bn * sizeof(double), hipMemcpyHostToDevice, c.stream));
     }
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(double), c.stream));
-    hipLaunchKernelGGL(armour_controller_kernel, dim3((B + 63) / 64), dim3(64), 0, c.stream, c.d_args, B, d_in, d_in + bn, d_in + 2 * bn, d_in + 3 * bn, d_in + 4 * bn,
-                       d_out, d_out + bn, d_out + 2 * bn, d_status);
+    // few states: four waves per 16 states (latency); many: one lane per state (throughput) -- bit-identical results
+    static const int split_env = [] { const char* e = getenv("ARMOUR_CTL_SPLIT"); return e ? atoi(e) : -1; }();   // development override: 0 never, 1 always
+    const bool split = split_env >= 0 ? split_env != 0 : B <= kSplitMaxStates;
+    if (split)
+        hipLaunchKernelGGL(armour_controller_split_kernel, dim3((B + kSplitStates - 1) / kSplitStates), dim3(256), 0, c.stream, c.d_args, B, d_in,
+                           d_in + bn, d_in + 2 * bn, d_in + 3 * bn, d_in + 4 * bn, d_out, d_out + bn, d_out + 2 * bn, d_status);
+    else
+        hipLaunchKernelGGL(armour_controller_kernel, dim3((B + 63) / 64), dim3(64), 0, c.stream, c.d_args, B, d_in, d_in + bn, d_in + 2 * bn, d_in + 3 * bn, d_in + 4 * bn,
+                           d_out, d_out + bn, d_out + 2 * bn, d_status);
     HIPCHK(hipGetLastError());
     int st = 0;
     if (staged) {

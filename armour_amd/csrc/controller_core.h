@@ -18,6 +18,10 @@
 namespace ctl {
 
 #define CTL_HD __host__ __device__ inline
+// The halves of the RNEA go into their caller whole, with their getter / putter.  (As functions of their own they reached the kernel's frame --
+// the kinematics store, the lambdas' captures -- through generic pointers, and both kernels built that way ended in a memory-aperture violation
+// on the MI355X; inlined, no generic pointer into a frame is left.)
+#define CTL_FLATTEN __attribute__((always_inline))
 
 struct Itv { double lo, hi; };
 // nextafter(x, -+inf): one step of the bit pattern for finite x -- the library call is ~10x the instructions and the
@@ -146,43 +150,78 @@ struct Model {
     Tw<S> gravity;
 };
 
-// passRNEA / passRNEA_Int (rnea.cpp:6-96, :98-185), serial chain (lam[i] = i - 1)
-template <class S>
-CTL_HD void pass_rnea(const Model<S>& md, const double* q, const double* qd, const double* qda, const double* qdd, bool apply_friction,
-                      bool apply_gravity, S* tau) {
+// passRNEA / passRNEA_Int (rnea.cpp:6-96, :98-185), serial chain (lam[i] = i - 1), in two halves:
+//   kinematics -- per joint the twist axis in body coordinates Sb_i and the transform from the parent's frame Xli_i: functions of q and the
+//                 model alone (rnea.cpp:22-31 / :114-123), so the two interval passes of a controller update share one evaluation;
+//   dynamics   -- the velocity / acceleration / wrench recursions and the backward projection (:33-95 / :125-184), which read (Xli_i, Sb_i)
+//                 joint by joint through `get`: from the caller's arrays, or from LDS as another wave produces them (controller.hip).
+// Operation for operation the code of the one-function form: results are unchanged to the bit.
+template <class S, class Put>
+CTL_HD CTL_FLATTEN void rnea_kinematics(const Model<S>& md, const double* q, Put put) {
+    Xf<S> Xbw = md.XTree[0];
+    for (int i = 0; i < md.n; i++) {
+        if (i > 0) Xbw = apply(Xbw, md.XTree[i]);
+        const Tw<S> Sb = invapply(Xbw, md.S_[i]);
+        const Xf<S> Xli = apply(xf_joint(Sb, -q[i]), inverse(md.XTree[i]));
+        put(i, Xli, Sb);
+    }
+}
+template <class S, class Get>
+CTL_HD CTL_FLATTEN void rnea_dynamics(const Model<S>& md, Get get, const double* qd, const double* qda, const double* qdd, bool apply_friction, bool apply_gravity,
+                          S* tau) {
     const int n = md.n;
     Tw<S> neg_g{vzero<S>(), vzero<S>()};
     if (apply_gravity) neg_g = -md.gravity;
-    Tw<S> v[ARMOUR_MAX_FACTORS], va[ARMOUR_MAX_FACTORS], a[ARMOUR_MAX_FACTORS], Sb[ARMOUR_MAX_FACTORS];
+    Tw<S> v, va, a;
     Wr<S> f[ARMOUR_MAX_FACTORS];
-    Xf<S> Xbw[ARMOUR_MAX_FACTORS], Xli[ARMOUR_MAX_FACTORS];
     for (int i = 0; i < n; i++) {
-        Xbw[i] = i > 0 ? apply(Xbw[i - 1], md.XTree[i]) : md.XTree[i];
-        Sb[i] = invapply(Xbw[i], md.S_[i]);
-        Xli[i] = apply(xf_joint(Sb[i], -q[i]), inverse(md.XTree[i]));
+        Xf<S> Xli; Tw<S> Sb;
+        get(i, Xli, Sb);
         if (i == 0) {
-            v[i] = scale(Sb[i], qd[i]);
-            va[i] = scale(Sb[i], qda[i]);
-            a[i] = (apply(Xli[i], neg_g) + scale(Sb[i], qdd[i])) + cross(v[i], va[i]);
+            v = scale(Sb, qd[i]);
+            va = scale(Sb, qda[i]);
+            a = (apply(Xli, neg_g) + scale(Sb, qdd[i])) + cross(v, va);
         } else {
-            v[i] = apply(Xli[i], v[i - 1]) + scale(Sb[i], qd[i]);
-            const Tw<S> temp = scale(Sb[i], qda[i]);
-            va[i] = apply(Xli[i], va[i - 1]) + temp;
-            a[i] = (apply(Xli[i], a[i - 1]) + scale(Sb[i], qdd[i])) + cross(v[i], temp);
+            v = apply(Xli, v) + scale(Sb, qd[i]);
+            const Tw<S> temp = scale(Sb, qda[i]);
+            va = apply(Xli, va) + temp;
+            a = (apply(Xli, a) + scale(Sb, qdd[i])) + cross(v, temp);
         }
         Wr<S> vIv;  // "v x Iv Jon's way"
-        vIv.tau = cross(va[i].w, md.I[i].I_bar * v[i].w);
-        vIv.tau = vIv.tau + md.I[i].I_bar * cross(va[i].w, v[i].w);
-        vIv.f = lscale(md.I[i].m, cross(va[i].w, v[i].v));
-        f[i] = apply(md.I[i], a[i]) + vIv;
+        vIv.tau = cross(va.w, md.I[i].I_bar * v.w);
+        vIv.tau = vIv.tau + md.I[i].I_bar * cross(va.w, v.w);
+        vIv.f = lscale(md.I[i].m, cross(va.w, v.v));
+        f[i] = apply(md.I[i], a) + vIv;
     }
     for (int i = n - 1; i >= 0; i--) {
-        tau[i] = dot(Sb[i], f[i]);
+        Xf<S> Xli; Tw<S> Sb;
+        get(i, Xli, Sb);
+        tau[i] = dot(Sb, f[i]);
         tau[i] = tau[i] + md.transI[i] * qdd[i];
         tau[i] = tau[i] + Sc<S>::of(md.damping[i] * qd[i]);
         if (apply_friction) tau[i] = tau[i] + Sc<S>::of(md.friction[i] * ((qd[i] > 0) - (qd[i] < 0)));
-        if (i > 0) f[i - 1] = f[i - 1] + invapply(Xli[i], f[i]);
+        if (i > 0) f[i - 1] = f[i - 1] + invapply(Xli, f[i]);
     }
+}
+template <class S> struct KinStore {   // the kinematics of one state in the caller's own memory
+    Xf<S> Xli[ARMOUR_MAX_FACTORS];
+    Tw<S> Sb[ARMOUR_MAX_FACTORS];
+};
+template <class S>
+CTL_HD CTL_FLATTEN void rnea_kinematics(const Model<S>& md, const double* q, KinStore<S>& k) {
+    rnea_kinematics(md, q, [&](int i, const Xf<S>& Xli, const Tw<S>& Sb) { k.Xli[i] = Xli; k.Sb[i] = Sb; });
+}
+template <class S>
+CTL_HD CTL_FLATTEN void rnea_dynamics(const Model<S>& md, const KinStore<S>& k, const double* qd, const double* qda, const double* qdd, bool apply_friction,
+                          bool apply_gravity, S* tau) {
+    rnea_dynamics(md, [&](int i, Xf<S>& Xli, Tw<S>& Sb) { Xli = k.Xli[i]; Sb = k.Sb[i]; }, qd, qda, qdd, apply_friction, apply_gravity, tau);
+}
+template <class S>
+CTL_HD CTL_FLATTEN void pass_rnea(const Model<S>& md, const double* q, const double* qd, const double* qda, const double* qdd, bool apply_friction,
+                      bool apply_gravity, S* tau) {
+    KinStore<S> k;
+    rnea_kinematics(md, q, k);
+    rnea_dynamics(md, k, qd, qda, qdd, apply_friction, apply_gravity, tau);
 }
 
 CTL_HD double clamp_angle(double x) {  // robust_controller.hpp:11-16
@@ -193,23 +232,25 @@ CTL_HD double clamp_angle(double x) {  // robust_controller.hpp:11-16
     return r;
 }
 
-// RobustController::update, ARMOUR method (robust_controller.cpp:63-168).  Returns false if the nominal torque leaves the
-// interval torque (the reference throws).  u = tau = u_nominal - v.
-CTL_HD bool robust_update(const Model<double>& md, const Model<Itv>& imd, const double* Kr, double alpha, double V_max, double r_norm_threshold,
-                          const double* q, const double* q_d, const double* qd, const double* qd_d, const double* qd_dd, double* u, double* u_nominal,
-                          double* v_out) {
-    const int n = md.n;
-    double qa_d[ARMOUR_MAX_FACTORS], qa_dd[ARMOUR_MAX_FACTORS], r[ARMOUR_MAX_FACTORS], zero[ARMOUR_MAX_FACTORS];
+// RobustController::update, ARMOUR method (robust_controller.cpp:63-168), in three pieces so that the three RNEA passes between
+// `prepare` and `combine` can run on different waves (controller.hip, the latency kernel) -- one thread running all of it is robust_update.
+// prepare: modified reference velocity / acceleration and the tracking error r (:70-83); returns |r|
+CTL_HD CTL_FLATTEN double robust_prepare(int n, const double* Kr, const double* q, const double* q_d, const double* qd, const double* qd_d, const double* qd_dd,
+                             double* qa_d, double* qa_dd, double* r) {
     for (int i = 0; i < n; i++) {
         const double q_diff = clamp_angle(qd[i] - q[i]);
         qa_d[i] = qd_d[i] + Kr[i] * q_diff;
         qa_dd[i] = qd_dd[i] + Kr[i] * (qd_d[i] - q_d[i]);
         r[i] = (qd_d[i] - q_d[i]) + Kr[i] * q_diff;
-        zero[i] = 0.0;
     }
-    pass_rnea<double>(md, q, q_d, qa_d, qa_dd, false, true, u_nominal);
-    Itv u_int[ARMOUR_MAX_FACTORS];
-    pass_rnea<Itv>(imd, q, q_d, qa_d, qa_dd, false, true, u_int);
+    double r_norm = 0.0;
+    for (int i = 0; i < n; i++) r_norm += r[i] * r[i];
+    return sqrt(r_norm);
+}
+// combine: the robust input from the nominal torque, the interval torque and (when |r| is above the threshold) the interval M r (:88-166).
+// Returns false if the nominal torque leaves the interval torque (the reference throws).  u = tau = u_nominal - v.
+CTL_HD CTL_FLATTEN bool robust_combine(int n, double alpha, double V_max, double r_norm_threshold, const double* r, double r_norm, const double* u_nominal,
+                           const Itv* u_int, const Itv* Mr, double* u, double* v_out) {
     bool ok = true;
     double bound_sq = 0.0;
     for (int i = 0; i < n; i++) {
@@ -219,12 +260,7 @@ CTL_HD bool robust_update(const Model<double>& md, const Model<Itv>& imd, const 
         bound_sq += bnd * bnd;
         v_out[i] = 0.0;
     }
-    double r_norm = 0.0;
-    for (int i = 0; i < n; i++) r_norm += r[i] * r[i];
-    r_norm = sqrt(r_norm);
     if (r_norm > r_norm_threshold) {
-        Itv Mr[ARMOUR_MAX_FACTORS];
-        pass_rnea<Itv>(imd, q, zero, zero, r, false, false, Mr);
         Itv V{0.0, 0.0};
         for (int i = 0; i < n; i++) V = V + (0.5 * r[i]) * Mr[i];
         const double h = -V.hi + V_max;
@@ -233,6 +269,21 @@ CTL_HD bool robust_update(const Model<double>& md, const Model<Itv>& imd, const 
     }
     for (int i = 0; i < n; i++) u[i] = u_nominal[i] - v_out[i];
     return ok;
+}
+CTL_HD CTL_FLATTEN bool robust_update(const Model<double>& md, const Model<Itv>& imd, const double* Kr, double alpha, double V_max, double r_norm_threshold,
+                          const double* q, const double* q_d, const double* qd, const double* qd_d, const double* qd_dd, double* u, double* u_nominal,
+                          double* v_out) {
+    const int n = md.n;
+    double qa_d[ARMOUR_MAX_FACTORS], qa_dd[ARMOUR_MAX_FACTORS], r[ARMOUR_MAX_FACTORS], zero[ARMOUR_MAX_FACTORS];
+    const double r_norm = robust_prepare(n, Kr, q, q_d, qd, qd_d, qd_dd, qa_d, qa_dd, r);
+    for (int i = 0; i < n; i++) zero[i] = 0.0;
+    pass_rnea<double>(md, q, q_d, qa_d, qa_dd, false, true, u_nominal);
+    Itv u_int[ARMOUR_MAX_FACTORS], Mr[ARMOUR_MAX_FACTORS];
+    KinStore<Itv> k;   // (both interval passes are at the same q: one kinematics)
+    rnea_kinematics(imd, q, k);
+    rnea_dynamics(imd, k, q_d, qa_d, qa_dd, false, true, u_int);
+    if (r_norm > r_norm_threshold) rnea_dynamics(imd, k, zero, zero, r, false, false, Mr);
+    return robust_combine(n, alpha, V_max, r_norm_threshold, r, r_norm, u_nominal, u_int, Mr, u, v_out);
 }
 
 }  // namespace ctl

@@ -90,3 +90,19 @@ def test_device_controller_matches_the_cpu_restatement():
     assert not v[5].any()
     u1, tau1, v1 = kinova_controller(KR, ALPHA, V_MAX, R_THR, q[3], qd[3], q_des[3], qd_des[3], qdd_des[3])
     assert np.array_equal(u1, u[3]) and np.array_equal(tau1, tau[3]) and np.array_equal(v1, v[3])
+
+
+@pytest.mark.gpu
+def test_latency_and_throughput_kernels_agree_bit_for_bit():
+    """Few states run the three RNEA passes of an update on three waves (controller.hip, the latency kernel), many run one lane per state:
+    the same states give the same bits either way, with and without a robust input."""
+    from armour_amd.controller import kinova_controller
+    B = 64 * 256 + 1000                                       # past the latency kernel's limit
+    q, qd, q_des, qd_des, qdd_des = _states(11, B)
+    q_des[70], qd_des[70] = q[70], qd[70]                     # r = 0: the third pass is skipped
+    bulk = kinova_controller(KR, ALPHA, V_MAX, R_THR, q, qd, q_des, qd_des, qdd_des, eps=0.03)
+    for lo, hi in ((0, 1), (64, 130), (16000, 16200)):
+        few = kinova_controller(KR, ALPHA, V_MAX, R_THR, q[lo:hi], qd[lo:hi], q_des[lo:hi], qd_des[lo:hi], qdd_des[lo:hi], eps=0.03)
+        for a, b in zip(few, bulk):
+            assert np.array_equal(np.asarray(a).reshape(hi - lo, 7), b[lo:hi])
+    assert not bulk[2][70].any()

@@ -16,7 +16,7 @@ rng = np.random.default_rng(0)
 L = _lib.load()
 rb = kinova_robot()
 dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-for B in (1, 64, 1000, 100000, 1000000):
+for B in [int(x) for x in sys.argv[1:]] or (1, 64, 1000, 4096, 16384, 65536, 100000, 1000000):
     q = rng.uniform(-np.pi, np.pi, (B, 7)); qd = rng.uniform(-1, 1, (B, 7))
     a = [np.ascontiguousarray(x) for x in (q, qd, q + 0.01, qd + 0.02, rng.uniform(-2, 2, (B, 7)))]
     kr = np.full(7, 10.0)
