@@ -21,7 +21,11 @@ namespace ctl {
 // The halves of the RNEA go into their caller whole, with their getter / putter.  (As functions of their own they reached the kernel's frame --
 // the kinematics store, the lambdas' captures -- through generic pointers, and both kernels built that way ended in a memory-aperture violation
 // on the MI355X; inlined, no generic pointer into a frame is left.)
+#ifdef CTL_NO_FLATTEN   // (development: the halves as functions of their own, to reproduce the fault described above)
+#define CTL_FLATTEN
+#else
 #define CTL_FLATTEN __attribute__((always_inline))
+#endif
 
 struct Itv { double lo, hi; };
 // nextafter(x, -+inf): one step of the bit pattern for finite x -- the library call is ~10x the instructions and the
