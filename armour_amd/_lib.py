@@ -65,6 +65,7 @@ class ArmourViolation(C.Structure):
 
 
 OPT_P1_BUILD = 1   # ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
+OPT_P1_WORK_MEMORY_MB = 2   # ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's work memory, MiB (0: none)
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [

@@ -688,6 +688,7 @@ int armour_upload_bounds(ArmourPlanner* h) {
 extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value) {
     if (!h) { armour_set_error("null handle"); return ARMOUR_EINVAL; }
     if (option == ARMOUR_OPT_P1_BUILD && (value == 0.0 || value == 1.0 || value == 2.0)) { h->opt_p1_build = (int)value; return ARMOUR_OK; }
+    if (option == ARMOUR_OPT_P1_WORK_MEMORY_MB && value >= 0.0 && value <= 1e9) { h->opt_p1_work_mb = value; return ARMOUR_OK; }
     armour_set_error("armour_set_option: unknown option %d or bad value %g", option, value);
     return ARMOUR_EINVAL;
 }

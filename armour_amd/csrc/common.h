@@ -108,6 +108,7 @@ struct ArmourPlanner {
     void* solve_pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows; [6] k and [7] records of armour_eval_violations
     size_t solve_pin_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int opt_p1_build = 0;           // ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
+    double opt_p1_work_mb = 0;      // ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's arena, MiB (0: none)
     ArmourViolation* d_viol = nullptr; size_t viol_cap = 0;   // [B] records of armour_eval_violations
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)

@@ -1766,7 +1766,16 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int slots = std::min(512, prop.multiProcessorCount * per_cu);
             const bool split = armtd ? true : multi ? false : (tv_split_env >= 0 ? tv_split_env != 0 : 2 * groups <= slots);
             const int fk_items = split ? groups : 0, rnea_items = armtd ? 0 : groups;
-            const int blocks = std::min(rnea_items + fk_items, slots);
+            int blocks = std::min(rnea_items + fk_items, slots);
+            if (h->opt_p1_work_mb > 0) {   // ARMOUR_OPT_P1_WORK_MEMORY_MB: fewer blocks, looping over the groups
+                const double max_blocks = h->opt_p1_work_mb * 1048576.0 / (double)TL.total;
+                if (max_blocks < 1.0) continue;   // (not even one block of this shape: the next shape, in the end the per-step kernel)
+                blocks = (int)std::min((double)blocks, max_blocks);
+            }
+            if (wk->tv_arena && h->opt_p1_work_mb > 0 && wk->tv_arena_total > (size_t)(h->opt_p1_work_mb * 1048576.0)) {   // the cap was lowered: give the surplus back
+                (void)hipFree(wk->tv_arena);
+                wk->tv_arena = nullptr; wk->tv_arena_total = 0;
+            }
             if ((size_t)blocks * TL.total > wk->tv_arena_total) {
                 if (wk->tv_arena) (void)hipFree(wk->tv_arena);
                 wk->tv_arena = nullptr; wk->tv_arena_total = 0;

@@ -90,6 +90,12 @@ void armour_free_pinned(void* p);
  * and independent of the batch mates and of the batch size.  A caller that needs bit-identical tables for the same problem across
  * batch sizes (or across the ranks of a sharded batch, whose shard sizes differ) sets option 1 (or 2) on every handle. */
 #define ARMOUR_OPT_P1_BUILD 1
+/* ARMOUR_OPT_P1_WORK_MEMORY_MB caps the device memory the time-vectorised build keeps for its work slots, in MiB (0 = no cap, the
+ * default: one block of ~112 MiB per compute unit while the batch has that many groups of time steps, 28.6 GiB on a 256-CU device,
+ * held until armour_destroy).  With a cap the build runs on fewer blocks, which loop over the groups -- same tables bit for bit, the
+ * build time grows with the rounds (a batch of 128 problems on half the blocks: about twice) -- so that several handles, or other
+ * tenants of the device, fit beside it.  A cap below one block's slots sends batches to the step-by-step kernel (a few GiB at most). */
+#define ARMOUR_OPT_P1_WORK_MEMORY_MB 2
 int armour_set_option(ArmourPlanner* h, int32_t option, double value);
 
 /* ---- P1: reach-set build, once per planning iteration ---- */

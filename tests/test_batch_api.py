@@ -155,3 +155,37 @@ def test_build_option_pins_the_kernel_and_states_the_tolerance():
     with pytest.raises(_lib.ArmourError):
         per_step.set_option(_lib.OPT_P1_BUILD, 3)
     per_step.close(); tv.close(); single.close()
+
+
+@pytest.mark.gpu
+def test_work_memory_cap_changes_the_block_count_not_the_tables():
+    """ARMOUR_OPT_P1_WORK_MEMORY_MB: the time-vectorised build on fewer blocks (they loop over the groups) gives the same tables bit for
+    bit; a cap below one block's slots sends the batch to the step-by-step kernel (radii to the tolerance contract)."""
+    import hashlib
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_k
+    B, O, T = 24, 3, 100
+    bp = random_batch(77, B, O)
+    ks = random_k(5, B)
+
+    def build(cap_mb):
+        nlp = ArmourNLP(T=T)
+        if cap_mb is not None:
+            nlp.set_option(_lib.OPT_P1_WORK_MEMORY_MB, cap_mb)
+        nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        g, jac = nlp.eval_g_jac(ks)
+        digest = hashlib.sha1(np.ascontiguousarray(nlp.torque_radius()).tobytes() + np.ascontiguousarray(nlp.link_generators()).tobytes()
+                              + np.ascontiguousarray(g).tobytes() + np.ascontiguousarray(jac).tobytes()).hexdigest()
+        info, tr = nlp.build_info(), nlp.torque_radius().copy()
+        nlp.close()
+        return digest, info, tr
+
+    free_digest, free_info, free_tr = build(None)
+    assert free_info["kernel"] == "time_vectorised" and free_info["launches"] == 1
+    capped_digest, capped_info, _ = build(5 * 120)            # room for five blocks of ~112 MiB: 48 groups in ten rounds
+    assert capped_info["kernel"] == "time_vectorised" and capped_digest == free_digest
+    tiny_digest, tiny_info, tiny_tr = build(50)               # not one block: step by step
+    assert tiny_info["kernel"] == "per_step" and np.abs(tiny_tr - free_tr).max() <= 1e-12
+    with pytest.raises(_lib.ArmourError):
+        ArmourNLP(T=T).set_option(_lib.OPT_P1_WORK_MEMORY_MB, -1)
