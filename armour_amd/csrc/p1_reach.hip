@@ -495,6 +495,147 @@ __device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, 
     lincomb<SZ, 1>(c.w, out, s);
 }
 
+// ---- the small PZs of the JRS in closed form -------------------------------------------------------------------------------------------
+// A joint's rotation, its velocity / acceleration polynomials and its link box are PZs of one to four raw terms whose keys and order are known
+// in advance.  Built through the operators (a raw slot, lincomb's simplify(), the constant-left product, transpose33) each of them is a chain of
+// round trips through the arena: ~135 k cycles per joint, 0.2 M of a time step's 2.4 M.  Here every lane evaluates the same few expressions in
+// registers -- exactly the operators' arithmetic, in their order, including the order in which the wave reduction adds the pruned amounts of
+// lanes 0..3 -- and lane 0 writes the finished slots.  Same tables bit for bit (the launch digests of tools/gpu_p1_repeat_stress.py are those
+// of the operator form).
+__device__ inline double quad_sum(double r0, double r1, double r2, double r3) { return (r0 + r1) + (r2 + r3); }   // wave_sum() of four lanes
+// (No register array below is indexed by a run-time value -- the first version kept the surviving terms in arrays indexed by their count, which
+//  the compiler put into scratch memory: 57 k cycles for a rotation that is 9 k of arithmetic.  A term's place in the output is a run-time
+//  ADDRESS instead.)
+// PZsparse(cos / sin polynomials about the joint axis) (RT/PZsparse.cu:211-250: four raw terms {k: cos_k, e_c: cos_e, k: sin_k, e_s: sin_e},
+// simplify()) -> R_i = R_rpy * it (:129-134) and its transpose
+__device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js, const double* rp) {
+    const P1Cfg& cf = *c.cf;
+    const Wave& w = c.w;
+    const int n = c.n, ax = cf.rb.axes[i];
+    const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);   // kk < kc < ks: the sorted order
+    double cen[9], m0[9], m1[9], m2[9], t2[9];
+    make_rotation(cen, js.cos_c, js.sin_c, ax, false);
+    make_rotation(m0, js.cos_k, 0.0, ax, true);
+    make_rotation(m1, js.cos_e, 0.0, ax, true);
+    make_rotation(t2, 0.0, js.sin_k, ax, true);
+    make_rotation(m2, 0.0, js.sin_e, ax, true);
+#pragma unroll
+    for (int e = 0; e < 9; e++) m0[e] = 1.0 * m0[e] + 1.0 * t2[e];   // the two k terms, summed in generation order
+    // simplify(): sorted positions 0 (k, head), 1 (k, member), 2 (e_c), 3 (e_s); a pruned term's |.| goes to the radius from its head's lane
+    const bool k0 = !norm_le<9>(m0, w), k1 = !norm_le<9>(m1, w), k2 = !norm_le<9>(m2, w);
+    double rind[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) rind[e] = 0.0 + quad_sum(k0 ? 0.0 : fabs(m0[e]), 0.0, k1 ? 0.0 : fabs(m1[e]), k2 ? 0.0 : fabs(m2[e]));
+    // R = R_rpy * rot (mul<3,3,3,3> with a constant left operand: emit_presorted over rot's surviving monomials, one per lane)
+    typedef MulShape<3, 3, 3, 3> SH;
+    double arp[9], base[9], Rcen[9], a0[9], a1[9], a2[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) arp[e] = fabs(rp[e]) + 0.0;
+    SH::mul(arp, rind, base);           // (|c_a| + sum |coef_a|) * indep_b; the two terms with indep_a = 0 are exact zeros
+    SH::mul(rp, cen, Rcen);
+    SH::mul(rp, m0, a0);
+    SH::mul(rp, m1, a1);
+    SH::mul(rp, m2, a2);
+    const bool K0 = k0 && !norm_le<9>(a0, w), K1 = k1 && !norm_le<9>(a1, w), K2 = k2 && !norm_le<9>(a2, w);
+    // lanes of the product's reduction = places among rot's survivors
+    const bool second_is_1 = k0 && k1, second_is_2 = (k0 != k1) && k2, third_is_2 = k0 && k1 && k2;
+    double Rind[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        const double q0 = (k0 && !K0) ? fabs(a0[e]) : 0.0, q1 = (k1 && !K1) ? fabs(a1[e]) : 0.0, q2 = (k2 && !K2) ? fabs(a2[e]) : 0.0;
+        const double l0 = k0 ? q0 : k1 ? q1 : k2 ? q2 : 0.0;
+        const double l1 = second_is_1 ? q1 : second_is_2 ? q2 : 0.0;
+        const double l2 = third_is_2 ? q2 : 0.0;
+        Rind[e] = (0.0 + (base[e] + 0.0)) + quad_sum(l0, l1, l2, 0.0);
+    }
+    if (w.lane == 0) {
+        const PZ R = c.R(i), Rt = c.Rt(i);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int e = r * 3 + cc, et = cc * 3 + r;
+                R.cen[e] = Rcen[e]; R.ind[e] = Rind[e]; R.ind2[e] = Rind[e];
+                Rt.cen[et] = Rcen[e]; Rt.ind[et] = Rind[e]; Rt.ind2[et] = Rind[e];
+            }
+        int pos = 0;
+        if (K0) {
+            R.keys[pos] = kk; Rt.keys[pos] = kk;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) { R.coef[(size_t)pos * 9 + r * 3 + cc] = a0[r * 3 + cc]; Rt.coef[(size_t)pos * 9 + cc * 3 + r] = a0[r * 3 + cc]; }
+            pos++;
+        }
+        if (K1) {
+            R.keys[pos] = kc; Rt.keys[pos] = kc;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) { R.coef[(size_t)pos * 9 + r * 3 + cc] = a1[r * 3 + cc]; Rt.coef[(size_t)pos * 9 + cc * 3 + r] = a1[r * 3 + cc]; }
+            pos++;
+        }
+        if (K2) {
+            R.keys[pos] = ks; Rt.keys[pos] = ks;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) { R.coef[(size_t)pos * 9 + r * 3 + cc] = a2[r * 3 + cc]; Rt.coef[(size_t)pos * 9 + cc * 3 + r] = a2[r * 3 + cc]; }
+            pos++;
+        }
+        c.w.cnt[R.id] = pos; c.w.cnt[Rt.id] = pos;
+    }
+}
+// PZsparse(centre, {k: a, e: b}) of a velocity / acceleration polynomial (:176-243), simplify()
+__device__ inline void jrs_scalar_direct(Chain& c, const PZ& out, double cen, uint64_t k0, double a, uint64_t k1, double b) {
+    const Wave& w = c.w;
+    const double va = 1.0 * a, vb = 1.0 * b;
+    const bool ka = !norm1_le(va, w.thr), kb = !norm1_le(vb, w.thr);
+    const double ind = 0.0 + quad_sum(ka ? 0.0 : fabs(va), kb ? 0.0 : fabs(vb), 0.0, 0.0);
+    if (w.lane == 0) {
+        out.cen[0] = cen; out.ind[0] = ind; out.ind2[0] = ind;
+        int pos = 0;
+        if (ka) { out.keys[pos] = k0; out.coef[pos] = va; pos++; }
+        if (kb) { out.keys[pos] = k1; out.coef[pos] = vb; pos++; }
+        c.w.cnt[out.id] = pos;
+    }
+}
+// link box (RT/Dynamics.cu:49-61): three 1x1 PZs {centre_j, one generator on key field (j + 2) n}, each simplify()d, then stack()ed and
+// simplify()d.  A generator that survives its own simplify() (|g| > threshold) survives the stack's (norm of (0, g, 0) > threshold) as well.
+__device__ inline void jrs_linkbox_direct(Chain& c, int i) {
+    const P1Cfg& cf = *c.cf;
+    const Wave& w = c.w;
+    const int n = c.n;
+    const double g0 = 1.0 * cf.rb.link_zonotope_generators[3 * i], g1 = 1.0 * cf.rb.link_zonotope_generators[3 * i + 1], g2 = 1.0 * cf.rb.link_zonotope_generators[3 * i + 2];
+    const bool k0 = !norm1_le(g0, w.thr), k1 = !norm1_le(g1, w.thr), k2 = !norm1_le(g2, w.thr);
+    if (w.lane == 0) {
+        const PZ out = c.linkbox(i);
+        const double i0 = 0.0 + (k0 ? 0.0 : 0.0 + quad_sum(fabs(g0), 0.0, 0.0, 0.0)) * 1.0, i1 = 0.0 + (k1 ? 0.0 : 0.0 + quad_sum(fabs(g1), 0.0, 0.0, 0.0)) * 1.0,
+                     i2 = 0.0 + (k2 ? 0.0 : 0.0 + quad_sum(fabs(g2), 0.0, 0.0, 0.0)) * 1.0;
+        out.cen[0] = 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i]); out.cen[1] = 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i + 1]); out.cen[2] = 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i + 2]);
+        out.ind[0] = i0 + 0.0; out.ind[1] = i1 + 0.0; out.ind[2] = i2 + 0.0;
+        out.ind2[0] = i0 + 0.0; out.ind2[1] = i1 + 0.0; out.ind2[2] = i2 + 0.0;
+        int pos = 0;
+        if (k0) { out.keys[pos] = 1ull << (2 * n); out.coef[(size_t)pos * 3] = 1.0 * g0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
+        if (k1) { out.keys[pos] = 1ull << (3 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 1.0 * g1; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
+        if (k2) { out.keys[pos] = 1ull << (4 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 1.0 * g2; pos++; }
+        c.w.cnt[out.id] = pos;
+    }
+}
+// constant PZs without a local array on the way (set_const takes pointers: a caller's array behind them lives in scratch memory)
+__device__ inline void jrs_mass_inertia_direct(Chain& c, int i) {
+    const P1Cfg& cf = *c.cf;
+    const Wave& w = c.w;
+    const PZ pm = c.mass(i), pi = c.inertia(i);
+    if (w.lane == 0) {
+        pm.cen[0] = cf.rb.mass[i]; pm.ind[0] = 0.0; pm.ind2[0] = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
+        c.w.cnt[pm.id] = 0; c.w.cnt[pi.id] = 0;
+        const double unc = armour_inertia_uncertainty(&cf.rb, i);
+#pragma unroll
+        for (int e = 0; e < 9; e++) { const double v = cf.rb.inertia[9 * i + e]; pi.cen[e] = v; pi.ind[e] = 0.0; pi.ind2[e] = unc * fabs(v); }
+    }
+}
+
 // JRS of one time interval (RT/Trajectory.cu:63-254) + the constant PZs of KinematicsDynamics (RT/Dynamics.cu:6-67).
 // The joints are independent of each other: joint i is built by wave i % (waves of the block), with that wave's scratch slots.  (One joint
 // is ~135 k cycles of tiny operators, each a round trip through the arena: on three waves of four this phase was 0.40 M of the 2.5 M cycles
@@ -522,61 +663,27 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
             double rp[9];
             rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
             if (actuated) {
-                const uint64_t kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
-                // rotation about the joint axis from cos / sin polynomials, then R = R_rpy * Rz (:129-134)
-                double cen[9], co[4 * 9];
-                make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
-                make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
-                make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
-                make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
-                make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
-                const uint64_t keys[4] = {kk, kc, kk, ks};
-                build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
-                set_const(c.w, c.rpy(role), rp, nullptr);
-                mul<3, 3, 3, 3>(c.w, c.R(i), view(c.w, c.rpy(role)), view(c.w, c.rotS(role)));
+                jrs_rotation_direct(c, i, js, rp);   // R_i and its transpose (:129-134)
             } else {
                 set_const(c.w, c.R(i), rp, nullptr);
+                transpose33(c.w, c.Rt(i), c.R(i));
             }
-            transpose33(c.w, c.Rt(i), c.R(i));
             set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
         }
         if (!kin_only) {
             // qd_des, qda_des, qdda_des (:176-243)
             if (actuated) {
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
-                    const double co2[2] = {js.qd_k, js.qd_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
-                }
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
-                    const double co2[2] = {js.qd_k, js.qda_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
-                }
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
-                    const double co2[2] = {js.qdd_k, js.qdd_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
-                }
+                jrs_scalar_direct(c, c.qd(i), js.qd_c, kk, js.qd_k, 1ull << (2 * n + i), js.qd_e);
+                jrs_scalar_direct(c, c.qda(i), js.qd_c, kk, js.qd_k, 1ull << (3 * n + i), js.qda_e);
+                jrs_scalar_direct(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, 1ull << (4 * n + i), js.qdd_e);
             }
-            // mass / inertia: radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
-            double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
-            double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
-            double ii[9];
-            for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
-            set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+            jrs_mass_inertia_direct(c, i);   // radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
         }
         if (boxes) {
-            // link bounding box: three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
-            for (int j = 0; j < 3; j++) {
-                const uint64_t key = 1ull << ((j + 2) * n);
-                build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
-            }
-            Seg s[3] = {{view(c.w, c.rawS(role, 1)), 1.0, 0}, {view(c.w, c.rawS(role, 2)), 1.0, 1}, {view(c.w, c.rawS(role, 3)), 1.0, 2}};
-            lincomb<3, 3>(c.w, c.linkbox(i), s);
+            jrs_linkbox_direct(c, i);   // three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
         }
     }
+    WSYNC();   // lane 0's slot writes are visible to the wave (the caller's block barrier does the same for the block)
     if (c.is(0)) {
         double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
         set_const(c.w, c.R(J), id, nullptr);
