@@ -224,6 +224,169 @@ __device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& ou
     tv::lincomb<SZ, 1, false>(c.w, out, s);
 }
 
+// ---- the small PZs of the JRS in closed form (p1_reach.hip has the per-step twin and the reasons) ------------------------------------------
+// Every lane evaluates the operators' arithmetic for ITS time step in registers, in their order -- lincomb<SZ,1>'s simplify() of the raw terms,
+// the constant-left product's, transpose33's copies, the stack's -- and writes its rows; which rows exist is the wave's vote, as in the walks
+// (a key stays while any lane keeps it; a lane that pruned it stores 0 and has |.| in its radius).  Same tables bit for bit as through the
+// operators (launch digests, tools/gpu_p1_repeat_stress.py), without their round trips through the arena: a dozen per joint.
+template <int SZ>
+__device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, uint64_t key, const double* v) {
+    if (lane == 0) out.keys[pos] = key;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) out.coef[((size_t)pos * SZ + e) * 64 + lane] = v[e];
+}
+__device__ inline bool jrs_small9(const double* m, double thr_sq) {
+    double q = 0.0;
+#pragma unroll
+    for (int e = 0; e < 9; e++) q += m[e] * m[e];
+    return q <= thr_sq;
+}
+// rotation about the joint axis from the cos / sin polynomials (four raw terms {k: cos_k, e_c: cos_e, k: sin_k, e_s: sin_e}, simplify()),
+// R_i = R_rpy * it, and (with_rt) the transpose
+__device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars& js, const double* rp, bool with_rt) {
+    const P1Cfg& cf = *c.cf;
+    const int lane = c.w.w.lane, n = c.n, ax = cf.rb.axes[i];
+    const double thr_sq = c.w.w.thr_sq;
+    const bool active = c.w.active;
+    const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);   // kk < kc < ks: the sorted order
+    double cen[9], m0[9], m1[9], m2[9], t2[9];
+    make_rotation(cen, js.cos_c, js.sin_c, ax, false);
+    make_rotation(m0, js.cos_k, 0.0, ax, true);
+    make_rotation(m1, js.cos_e, 0.0, ax, true);
+    make_rotation(t2, 0.0, js.sin_k, ax, true);
+    make_rotation(m2, 0.0, js.sin_e, ax, true);
+#pragma unroll
+    for (int e = 0; e < 9; e++) { cen[e] = 1.0 * cen[e]; m0[e] = 1.0 * m0[e] + 1.0 * t2[e]; m1[e] = 1.0 * m1[e]; m2[e] = 1.0 * m2[e]; }
+    // simplify(), per lane; the pruned amounts join the lane's radius in key order
+    const bool d0 = jrs_small9(m0, thr_sq), d1 = jrs_small9(m1, thr_sq), d2 = jrs_small9(m2, thr_sq);
+    const bool k0 = !d0 && active, k1 = !d1 && active, k2 = !d2 && active;
+    const bool e0 = __ballot(k0) != 0ull, e1 = __ballot(k1) != 0ull, e2 = __ballot(k2) != 0ull;   // rows of rot that exist (wave-uniform)
+    double rind[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        double ra = 0.0;
+        ra += d0 ? fabs(m0[e]) : 0.0; ra += d1 ? fabs(m1[e]) : 0.0; ra += d2 ? fabs(m2[e]) : 0.0;
+        rind[e] = 0.0 + ra;
+        m0[e] = k0 ? m0[e] : 0.0; m1[e] = k1 ? m1[e] : 0.0; m2[e] = k2 ? m2[e] : 0.0;   // what the rows hold
+    }
+    // R = R_rpy * rot: the constant-left product over rot's rows
+    typedef pzw::MulShape<3, 3, 3, 3> SH;
+    double arp[9], base[9], Rcen[9], a0[9], a1[9], a2[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) arp[e] = fabs(rp[e]) + 0.0;
+    SH::mul(arp, rind, base);           // (|c_a| + asum_a) * indep_b; the two terms with indep_a = 0 are exact zeros
+    SH::mul(rp, cen, Rcen);
+    SH::mul(rp, m0, a0);
+    SH::mul(rp, m1, a1);
+    SH::mul(rp, m2, a2);
+    const bool K0 = e0 && !jrs_small9(a0, thr_sq) && active, K1 = e1 && !jrs_small9(a1, thr_sq) && active, K2 = e2 && !jrs_small9(a2, thr_sq) && active;
+    const bool E0 = __ballot(K0) != 0ull, E1 = __ballot(K1) != 0ull, E2 = __ballot(K2) != 0ull;
+    const TPZ R = c.R(i), Rt = c.Rt(i);
+    double Rind[9], asum[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        double rad = 0.0, as = 0.0;
+        rad += (e0 && !K0) ? fabs(a0[e]) : 0.0; rad += (e1 && !K1) ? fabs(a1[e]) : 0.0; rad += (e2 && !K2) ? fabs(a2[e]) : 0.0;
+        a0[e] = K0 ? a0[e] : 0.0; a1[e] = K1 ? a1[e] : 0.0; a2[e] = K2 ? a2[e] : 0.0;
+        as += E0 ? fabs(a0[e]) : 0.0; as += E1 ? fabs(a1[e]) : 0.0; as += E2 ? fabs(a2[e]) : 0.0;
+        Rind[e] = (0.0 + (base[e] + 0.0)) + rad;
+        asum[e] = as;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int e = r * 3 + cc, et = cc * 3 + r;
+            tv::st_hdr(R, tv::H_CEN, e, lane, Rcen[e]); tv::st_hdr(R, tv::H_IND, e, lane, Rind[e]); tv::st_hdr(R, tv::H_IND2, e, lane, Rind[e]); tv::st_hdr(R, tv::H_ASUM, e, lane, asum[e]);
+            if (with_rt) { tv::st_hdr(Rt, tv::H_CEN, et, lane, Rcen[e]); tv::st_hdr(Rt, tv::H_IND, et, lane, Rind[e]); tv::st_hdr(Rt, tv::H_IND2, et, lane, Rind[e]); tv::st_hdr(Rt, tv::H_ASUM, et, lane, asum[e]); }
+        }
+    int pos = 0;
+    double tr[9];
+    if (E0) {
+        jrs_put_row<9>(R, pos, lane, kk, a0);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a0[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, kk, tr); }
+        pos++;
+    }
+    if (E1) {
+        jrs_put_row<9>(R, pos, lane, kc, a1);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a1[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, kc, tr); }
+        pos++;
+    }
+    if (E2) {
+        jrs_put_row<9>(R, pos, lane, ks, a2);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a2[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, ks, tr); }
+        pos++;
+    }
+    if (lane == 0) { c.w.w.cnt[R.id] = pos; if (with_rt) c.w.w.cnt[Rt.id] = pos; }
+}
+// PZsparse(centre, {k: a, e: b}) of a velocity / acceleration polynomial, simplify()
+__device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double cen, uint64_t key0, double a, uint64_t key1, double b) {
+    const int lane = c.w.w.lane;
+    const double thr = c.w.w.thr;
+    const bool active = c.w.active;
+    double va = 1.0 * a, vb = 1.0 * b;
+    const bool da = fabs(va) <= thr, db = fabs(vb) <= thr;
+    const bool ka = !da && active, kb = !db && active;
+    const bool ea = __ballot(ka) != 0ull, eb = __ballot(kb) != 0ull;
+    double ra = 0.0;
+    ra += da ? fabs(va) : 0.0; ra += db ? fabs(vb) : 0.0;
+    va = ka ? va : 0.0; vb = kb ? vb : 0.0;
+    double as = 0.0;
+    as += ea ? fabs(va) : 0.0; as += eb ? fabs(vb) : 0.0;
+    tv::st_hdr(out, tv::H_CEN, 0, lane, 1.0 * cen); tv::st_hdr(out, tv::H_IND, 0, lane, 0.0 + ra); tv::st_hdr(out, tv::H_IND2, 0, lane, 0.0 + ra); tv::st_hdr(out, tv::H_ASUM, 0, lane, as);
+    int pos = 0;
+    if (ea) { jrs_put_row<1>(out, pos, lane, key0, &va); pos++; }
+    if (eb) { jrs_put_row<1>(out, pos, lane, key1, &vb); pos++; }
+    if (lane == 0) c.w.w.cnt[out.id] = pos;
+}
+// link box: three 1x1 PZs {centre_j, one generator on key field (j + 2) n}, each simplify()d, then stack()ed and simplify()d
+__device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
+    const P1Cfg& cf = *c.cf;
+    const int lane = c.w.w.lane, n = c.n;
+    const double thr = c.w.w.thr, thr_sq = c.w.w.thr_sq;
+    const bool active = c.w.active;
+    const TPZ out = c.linkbox(i);
+    double x[3], ind1[3];
+    bool ex1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {   // the 1x1 PZs
+        const double g = 1.0 * cf.rb.link_zonotope_generators[3 * i + j];
+        const bool d = fabs(g) <= thr, k = !d && active;
+        ex1[j] = __ballot(k) != 0ull;
+        ind1[j] = 0.0 + (0.0 + (d ? fabs(g) : 0.0));
+        x[j] = k ? g : 0.0;
+    }
+    // stack(): term j embedded in entry j; the runs come in the order of j
+    double ra[3] = {0.0, 0.0, 0.0}, as[3] = {0.0, 0.0, 0.0};
+    bool k2[3], ex2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double v = 1.0 * x[j];
+        const bool d = ex1[j] && (0.0 + v * v + 0.0 * 0.0 <= thr_sq);   // (the norm of (0, v, 0): zeros add nothing)
+        ra[j] += d ? fabs(v) : 0.0;
+        k2[j] = ex1[j] && !d && active;
+        ex2[j] = __ballot(k2[j]) != 0ull;
+        x[j] = k2[j] ? v : 0.0;
+        as[j] += ex2[j] ? fabs(x[j]) : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const double i0 = e == 0 ? ind1[0] * 1.0 : 0.0, i1 = e == 1 ? ind1[1] * 1.0 : 0.0, i2 = e == 2 ? ind1[2] * 1.0 : 0.0;
+        const double r = ((i0 + i1) + i2) + ra[e];
+        tv::st_hdr(out, tv::H_CEN, e, lane, 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i + e]));
+        tv::st_hdr(out, tv::H_IND, e, lane, r); tv::st_hdr(out, tv::H_IND2, e, lane, r); tv::st_hdr(out, tv::H_ASUM, e, lane, as[e]);
+    }
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (ex2[j]) {
+            const double v[3] = {j == 0 ? x[0] : 0.0, j == 1 ? x[1] : 0.0, j == 2 ? x[2] : 0.0};
+            jrs_put_row<3>(out, pos, lane, 1ull << ((j + 2) * n), v);
+            pos++;
+        }
+    if (lane == 0) c.w.w.cnt[out.id] = pos;
+}
+
 // JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations).
 // Joint i is built by wave i % (number of waves) with that wave's scratch slots; the caller follows with a block barrier.
 __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_only) {
@@ -238,54 +401,34 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
         if (i < n && cf.rb.axes[i] != 0) {
             const JrsScalars js = cf.mode == ARMOUR_MODE_ARMTD ? armtd_jrs_scalars(cf, bz[i], b, i, t_lane)   // (CMP/Trajectory.cu:29-61: offline tables)
                                                                : jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t_lane);
-            const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);
-            double cen[9], co[4 * 9];
-            make_rotation(cen, js.cos_c, js.sin_c, cf.rb.axes[i], false);
-            make_rotation(co + 0, js.cos_k, 0.0, cf.rb.axes[i], true);
-            make_rotation(co + 9, js.cos_e, 0.0, cf.rb.axes[i], true);
-            make_rotation(co + 18, 0.0, js.sin_k, cf.rb.axes[i], true);
-            make_rotation(co + 27, 0.0, js.sin_e, cf.rb.axes[i], true);
-            const uint64_t keys[4] = {kk, kc, kk, ks};
-            build_simplified<9>(c, c.rotRaw(role), c.rotS(role), cen, 4, keys, co);
-            tv::set_const(c.w, c.rpy(role), rp, nullptr);
-            tv::mul<3, 3, 3, 3>(c.w, c.R(i), tv::view(c.w, c.rpy(role)), tv::view(c.w, c.rotS(role)));
+            const uint64_t kk = 1ull << (2 * i);
+            jrs_rotation_direct_tv(c, i, js, rp, !kin_only);
             if (!kin_only) {
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (2 * n + i)};
-                    const double co2[2] = {js.qd_k, js.qd_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qd(i), &js.qd_c, 2, k2, co2);
-                }
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (3 * n + i)};
-                    const double co2[2] = {js.qd_k, js.qda_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qda(i), &js.qd_c, 2, k2, co2);
-                }
-                {
-                    const uint64_t k2[2] = {kk, 1ull << (4 * n + i)};
-                    const double co2[2] = {js.qdd_k, js.qdd_e};
-                    build_simplified<1>(c, c.rawS(role, 0), c.qdda(i), &js.qdd_c, 2, k2, co2);
-                }
+                jrs_scalar_direct_tv(c, c.qd(i), js.qd_c, kk, js.qd_k, 1ull << (2 * n + i), js.qd_e);
+                jrs_scalar_direct_tv(c, c.qda(i), js.qd_c, kk, js.qd_k, 1ull << (3 * n + i), js.qda_e);
+                jrs_scalar_direct_tv(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, 1ull << (4 * n + i), js.qdd_e);
             }
         } else {
             tv::set_const(c.w, c.R(i), rp, nullptr);
+            if (!kin_only) tv::transpose33(c.w, c.Rt(i), c.R(i));
         }
-        if (!kin_only) tv::transpose33(c.w, c.Rt(i), c.R(i));
         tv::set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
-        if (!kin_only) {
-            double mi = armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i]);
-            double zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            tv::set_const(c.w, c.mass(i), &cf.rb.mass[i], zero9, &mi);
-            double ii[9];
-            for (int e = 0; e < 9; e++) ii[e] = armour_inertia_uncertainty(&cf.rb, i) * fabs(cf.rb.inertia[9 * i + e]);
-            tv::set_const(c.w, c.inertia(i), &cf.rb.inertia[9 * i], zero9, ii);
+        if (!kin_only) {   // mass and inertia: constants with a second radius (no local arrays behind set_const's pointers: they would live in scratch memory)
+            const int lane = c.w.w.lane;
+            const TPZ pm = c.mass(i), pi = c.inertia(i);
+            tv::st_hdr(pm, tv::H_CEN, 0, lane, cf.rb.mass[i]); tv::st_hdr(pm, tv::H_IND, 0, lane, 0.0);
+            tv::st_hdr(pm, tv::H_IND2, 0, lane, armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i])); tv::st_hdr(pm, tv::H_ASUM, 0, lane, 0.0);
+            const double unc = armour_inertia_uncertainty(&cf.rb, i);
+#pragma unroll
+            for (int e = 0; e < 9; e++) {
+                const double v = cf.rb.inertia[9 * i + e];
+                tv::st_hdr(pi, tv::H_CEN, e, lane, v); tv::st_hdr(pi, tv::H_IND, e, lane, 0.0); tv::st_hdr(pi, tv::H_IND2, e, lane, unc * fabs(v)); tv::st_hdr(pi, tv::H_ASUM, e, lane, 0.0);
+            }
+            if (lane == 0) { c.w.w.cnt[pm.id] = 0; c.w.w.cnt[pi.id] = 0; }
         }
-        for (int j = 0; j < 3; j++) {
-            const uint64_t key = 1ull << ((j + 2) * n);
-            build_simplified<1>(c, c.rawS(role, 0), c.rawS(role, 1 + j), &cf.rb.link_zonotope_center[3 * i + j], 1, &key, &cf.rb.link_zonotope_generators[3 * i + j]);
-        }
-        TSeg s[3] = {{tv::view(c.w, c.rawS(role, 1)), 1.0, 0}, {tv::view(c.w, c.rawS(role, 2)), 1.0, 1}, {tv::view(c.w, c.rawS(role, 3)), 1.0, 2}};
-        tv::lincomb<3, 3, false>(c.w, c.linkbox(i), s);
+        jrs_linkbox_direct_tv(c, i);
     }
+    WSYNC();   // this wave's rows and counts are written (the caller's block barrier does the same for the block)
     if (c.is(0)) {
         double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         tv::set_const(c.w, c.R(J), id, nullptr);
