@@ -164,9 +164,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (!aux3) na = c.mulMV(Rt, t3_take(c, T3_ST + 3 * s + 2));
             TPZ nd = c.mulMV(Rt, wdot);
             if (cf.rb.axes[s] != 0) {
-                TPZ zero = c.allocV();
-                set_const(w, zero, nullptr, nullptr);
-                TPZ temp = c.addOneDim(zero, c.qd(s), ax); c.freeVs(zero);
+                TPZ temp = c.embedOneDim(c.qd(s), ax);   // addOneDimPZ(0, qd_s, axis) (RT/Dynamics.cu:119-120)
                 if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_NA + s); }   // R_t w_aux_s from the forward-kinematics wave
                 TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
                 TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;

@@ -377,6 +377,13 @@ struct Chain {
         lincomb<3, 2>(w, o, s);
         return o;
     }
+    __device__ PZ embedOneDim(const PZ& a, int r) {   // addOneDimPZ(PZsparse(0,0,0), a, r): the same two operators as before
+        PZ zero = allocV();
+        set_const(w, zero, nullptr, nullptr);
+        PZ o = addOneDim(zero, a, r);
+        freeVs(zero);
+        return o;
+    }
     __device__ PZ stack(const PZ& r0, const PZ& r1, const PZ& r2) {  // RT/PZsparse.cu:1087-1116
         PZ o = allocV();
         Seg s[3] = {{view(w, r0), 1.0, 0}, {view(w, r1), 1.0, 1}, {view(w, r2), 1.0, 2}};

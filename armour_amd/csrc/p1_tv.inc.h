@@ -148,6 +148,45 @@ struct TChain {
         tv::lincomb<3, 2, false>(w, o, s);
         return o;
     }
+    // addOneDimPZ(PZsparse(0,0,0), a, r) in closed form: a 1x1 PZ (two monomials for a joint velocity) embedded in entry r of a 3-vector.  Through
+    // the operators -- a zero constant, then lincomb<3,2> over the two rows -- this was two operators' worth of round trips on the angular wave's
+    // chain, once per joint.  The arithmetic of that lincomb per lane, in its order: centre 0 + 1*c, radius (0 + 1*ind) + pruned, a row kept while
+    // any lane keeps it (the norm of (0, x, 0) is |x|), asum over the rows kept.
+    __device__ TPZ embedOneDim(const TPZ& a, int r) {
+        TPZ o = allocV();
+        const int lane = w.w.lane, n = tv::uni(w.w.cnt[a.id]);
+        const double thr_sq = w.w.thr_sq;
+        const TView av = tv::view(w, a);
+        const double cen = 0.0 + 1.0 * tv::ld_hdr(av, tv::H_CEN, 0, lane);
+        const double ind = 0.0 + tv::ld_hdr(av, tv::H_IND, 0, lane) * 1.0, ind2 = 0.0 + tv::ld_hdr(av, tv::H_IND2, 0, lane) * 1.0;
+        double ra = 0.0, as = 0.0;
+        int pos = 0;
+        for (int m = 0; m < n; m++) {
+            const double x = 1.0 * a.coef[(size_t)m * 64 + lane];
+            const bool small = x * x <= thr_sq;
+            ra += small ? fabs(x) : 0.0;
+            const bool keep = !small && w.active;
+            if (__ballot(keep) != 0ull) {
+                const double v = keep ? x : 0.0;
+                if (lane == 0) o.keys[pos] = a.keys[m];
+#pragma unroll
+                for (int e = 0; e < 3; e++) o.coef[((size_t)pos * 3 + e) * 64 + lane] = (e == r) ? v : 0.0;
+                as += fabs(v);
+                pos++;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const bool me = e == r;
+            tv::st_hdr(o, tv::H_CEN, e, lane, me ? cen : 0.0);
+            tv::st_hdr(o, tv::H_IND, e, lane, me ? ind + ra : 0.0);
+            tv::st_hdr(o, tv::H_IND2, e, lane, me ? ind2 + ra : 0.0);
+            tv::st_hdr(o, tv::H_ASUM, e, lane, me ? as : 0.0);
+        }
+        if (lane == 0) w.w.cnt[o.id] = pos;
+        WSYNC();
+        return o;
+    }
     __device__ TPZ sum3(const TPZ& a, const TPZ& b, const TPZ& c3, int comp_c = -1) {
         TPZ o = allocV();
         TSeg s[3] = {{tv::view(w, a), 1.0, -1}, {tv::view(w, b), 1.0, -1}, {tv::view(w, c3), 1.0, comp_c}};
