@@ -656,19 +656,35 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
     const bool boxes = kin_only || cf.fk_items == 0;
+    // The scalar work of a joint -- the trigonometry of its fixed rotation (14 k cycles) and jrs_scalars (19 k) -- is the same in all 64 lanes
+    // of the per-step wave: lane i does it for joint i instead, all of this wave's joints at once, and the joint loop below reads lane i's
+    // results.  Same functions on the same arguments: same bits.
+    const int lane = c.w.lane;
+    const int il = lane < J ? lane : J - 1;   // (the other lanes shadow the last joint)
+    const bool il_actuated = il < n && cf.rb.axes[il] != 0;
+    double rp_l[9];
+    rpy_matrix(cf.rb.rots[3 * il], cf.rb.rots[3 * il + 1], cf.rb.rots[3 * il + 2], rp_l);
+    JrsScalars js_l;
+    {
+        const int ia = il_actuated ? il : 0;   // (a lane without an actuated joint of its own computes joint 0's: never read)
+        if (cf.mode == ARMOUR_MODE_ARMTD) js_l = armtd_jrs_scalars(cf, bz[ia], b, ia, t);
+        else js_l = jrs_scalars(cf, bz[ia], bz[n + ia], bz[2 * n + ia], ia, t);
+    }
+    auto bcast = [&](double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
     for (int i = 0; i < J; i++) {
         const int role = c.nw == 1 ? 0 : i % c.nw;   // the wave that builds joint i, with its own scratch slots
         if (!c.is(role)) continue;
         const bool actuated = i < n && cf.rb.axes[i] != 0;
         JrsScalars js;
         const uint64_t kk = 1ull << (2 * i);
-        if (actuated) {
-            if (cf.mode == ARMOUR_MODE_ARMTD) js = armtd_jrs_scalars(cf, bz[i], b, i, t);
-            else js = jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t);
-        }
+        js.cos_c = bcast(js_l.cos_c, i); js.cos_k = bcast(js_l.cos_k, i); js.cos_e = bcast(js_l.cos_e, i);
+        js.sin_c = bcast(js_l.sin_c, i); js.sin_k = bcast(js_l.sin_k, i); js.sin_e = bcast(js_l.sin_e, i);
+        js.qd_c = bcast(js_l.qd_c, i); js.qd_k = bcast(js_l.qd_k, i); js.qd_e = bcast(js_l.qd_e, i); js.qda_e = bcast(js_l.qda_e, i);
+        js.qdd_c = bcast(js_l.qdd_c, i); js.qdd_k = bcast(js_l.qdd_k, i); js.qdd_e = bcast(js_l.qdd_e, i);
         {
             double rp[9];
-            rpy_matrix(cf.rb.rots[3 * i], cf.rb.rots[3 * i + 1], cf.rb.rots[3 * i + 2], rp);
+#pragma unroll
+            for (int e = 0; e < 9; e++) rp[e] = bcast(rp_l[e], i);
             if (actuated) {
                 jrs_rotation_direct(c, i, js, rp);   // R_i and its transpose (:129-134)
             } else {
