@@ -639,6 +639,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
             }
         };
         for (int b = 0; b < B; b++) searching[b] = 0;
+        bool linearised_at_trial = false;
         const auto q0 = now();
         if (nthreads <= 1) work(0, B);
         else {
@@ -656,7 +657,13 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                 need = need || searching[b];
             }
             if (!need) break;
-            if ((rc = eval(false)) != ARMOUR_OK) return rc;
+            // The full step is accepted nine times in ten, and the new linearisation is then wanted at exactly this point: the first trial is
+            // evaluated WITH the Jacobian and the candidate rows (the same fused launch, 2 us more), and if every problem that was searching
+            // takes it the round trip of the re-linearisation below is saved (an evaluation request less in flight, not in `evaluations`: that
+            // counts what the algorithm asked for, in both forms of the solver).
+            const bool speculative = ls == 0;
+            if ((rc = eval(speculative)) != ARMOUR_OK) return rc;
+            if (speculative) linearised_at_trial = true;
             if ((rc = armour_eval_f(h, hk, fb.data())) != ARMOUR_OK) return rc;
             for (int b = 0; b < B; b++) {
                 if (!searching[b]) continue;
@@ -669,12 +676,13 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                     st[b].f = fb[b]; st[b].viol = v; searching[b] = 0; st[b].iters++;
                 } else {
                     alpha[b] *= 0.5;
+                    linearised_at_trial = false;   // (this problem moves to another point: the linearisation taken at the full step is not its)
                 }
             }
         }
-        // ---- new linearisation at the accepted points ----
+        // ---- new linearisation at the accepted points (already there if every searching problem took its full step) ----
         for (int b = 0; b < B; b++) for (int j = 0; j < n; j++) hk[b * n + j] = st[b].x[j];
-        if ((rc = eval(true)) != ARMOUR_OK) return rc;
+        if (!linearised_at_trial && (rc = eval(true)) != ARMOUR_OK) return rc;
         if ((rc = armour_eval_grad_f(h, hk, gfb.data())) != ARMOUR_OK) return rc;
         for (int b = 0; b < B; b++) {
             if (st[b].done) continue;
