@@ -208,7 +208,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_step_graphs(h);
-    for (int i = 0; i < 8; i++) armour_free_pinned(h->solve_pin[i]);
+    for (int i = 0; i < 9; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds); dev_free(&h->d_viol);
     dev_free(&h->solve_dev.ctl); dev_free(&h->solve_dev.blk_word); dev_free(&h->solve_dev.blk_rows); dev_free(&h->solve_dev.qp_rows);
     dev_free(&h->solve_dev.flags);
@@ -240,6 +240,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
     h->bounds_on_device = false;
+    h->stats_fresh = false;
     drop_step_graphs(h);  // they bake in the tables of the previous problem set
     int rc = ensure_capacity(h, B, O);
     if (rc != ARMOUR_OK) return rc;
@@ -267,6 +268,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
 }
 
 int armour_refresh_table_stats(ArmourPlanner* h) {
+    if (h->stats_fresh) { h->stats_fresh = false; return ARMOUR_OK; }   // (the build read them back with its own results: p1_reach.hip)
     const size_t nl = (size_t)h->B * h->J * h->T, nt = (size_t)h->B * h->n * h->T;
     std::vector<int> lc(nl), tc(nt);
     HIPCHK(hipMemcpy(lc.data(), h->d_link_count, nl * sizeof(int), hipMemcpyDeviceToHost));

@@ -21,6 +21,7 @@
 // kernel builds the half-space table one thread per (problem, link, time, obstacle) row.
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -1703,6 +1704,17 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     return ARMOUR_OK;
 }
 
+// Wait for the build's stream: a lone problem's build is ~1 ms, and an interrupt-driven wake-up after hipStreamSynchronize adds tens of
+// microseconds to each of the build's waits; so poll for a while (2 ms) and only then sleep (batches take 8 ms and more: they sleep).
+static hipError_t p1_wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; spins++) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipErrorNotReady) return q;
+        if ((spins & 63) == 63 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) return hipStreamSynchronize(st);
+    }
+}
+
 int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (!h->p1) {
         P1Work* nw = new P1Work();
@@ -1809,7 +1821,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(p1_wait_stream(h->stream));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
@@ -1951,7 +1963,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             }
             HIPCHK(hipEventRecord(wk->ev1, h->stream));
             HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(p1_wait_stream(h->stream));
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
@@ -2018,7 +2030,23 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         h->planes_lean = lean ? 1 : 0; h->planes_have_d = (!lean || store_d) ? 1 : 0;
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    // What the host keeps of a build -- torque radii, link generators, the monomial counts behind the table statistics, the plane masks -- comes
+    // back through ONE page-locked block, queued behind the half-space kernels and waited for once (five blocking copies from pageable memory
+    // and a wait of their own before: 0.1 ms of a lone problem's 1.2 ms call).  Large batches keep the plain copies.
+    const size_t n_tr = (size_t)B * n * T, n_lg = (size_t)B * T * J * 18, n_lc = (size_t)B * J * T, n_tc = (size_t)B * n * T;
+    const size_t off_lg = n_tr * sizeof(double), off_lc = off_lg + n_lg * sizeof(double), off_tc = off_lc + n_lc * sizeof(int),
+                 off_ps = (off_tc + n_tc * sizeof(int) + 7) & ~(size_t)7, rb_bytes = off_ps + (size_t)B * sizeof(unsigned long long);
+    unsigned char* rb = rb_bytes <= ((size_t)4 << 20) ? reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 8, rb_bytes)) : nullptr;
+    if (rb) {
+        HIPCHK(hipMemcpyAsync(rb, wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rb + off_lg, wk->d_link_gens, n_lg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rb + off_lc, h->d_link_count, n_lc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rb + off_tc, h->d_tq_count, n_tc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (O > 0) HIPCHK(hipMemcpyAsync(rb + off_ps, h->d_plane_skip, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (O > 0 || rb) HIPCHK(p1_wait_stream(h->stream));
+    if (O > 0) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
@@ -2026,10 +2054,25 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     }
     h->build_ms = total_ms;  // device time of every launch of this build, retries included
 
-    h->h_torque_radius.resize((size_t)B * n * T);
-    h->h_link_gens.resize((size_t)B * T * J * 18);
-    HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, h->h_torque_radius.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, h->h_link_gens.size() * sizeof(double), hipMemcpyDeviceToHost));
+    h->h_torque_radius.resize(n_tr);
+    h->h_link_gens.resize(n_lg);
+    if (rb) {
+        memcpy(h->h_torque_radius.data(), rb, n_tr * sizeof(double));
+        memcpy(h->h_link_gens.data(), rb + off_lg, n_lg * sizeof(double));
+        const int* lc = reinterpret_cast<const int*>(rb + off_lc);
+        const int* tc = reinterpret_cast<const int*>(rb + off_tc);
+        long long sl = 0, st2 = 0;
+        int ml = 0, mt = 0;
+        for (size_t i = 0; i < n_lc; i++) { sl += lc[i]; if (lc[i] > ml) ml = lc[i]; }
+        for (size_t i = 0; i < n_tc; i++) { st2 += tc[i]; if (tc[i] > mt) mt = tc[i]; }
+        h->sum_link = sl; h->sum_torque = st2; h->max_link = ml; h->max_torque = mt;
+        h->h_plane_skip.assign((size_t)B, 0ull);
+        if (O > 0) memcpy(h->h_plane_skip.data(), rb + off_ps, (size_t)B * sizeof(unsigned long long));
+        h->stats_fresh = !getenv("ARMOUR_P1_TRACE");   // (the trace line of armour_refresh_table_stats wants its own pass)
+    } else {
+        HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, n_lg * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return ARMOUR_OK;
 }
 
