@@ -388,6 +388,34 @@ def test_build_info_names_the_kernel_that_built_the_tables():
         one.close(); nlp.close()
 
 
+@pytest.mark.parametrize("threshold", [3e-4, 5e-3, 3e-2])
+def test_other_simplify_thresholds_against_the_oracle(threshold):
+    """The default threshold (5e-4, RT/Parameters.h) prunes the error terms of most rotations and nothing else of the JRS; a smaller one keeps more
+    of them, large ones also prune velocity terms and k-dependent rotation terms -- the branches of the closed-form JRS constructors
+    (p1_reach.hip jrs_*_direct, p1_tv.inc.h jrs_*_direct_tv) that the default never takes.  Both kernels against the oracle."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP, default_params
+    from armour_amd.worlds import random_batch
+    from oracle.cpu_oracle import Oracle
+    from oracle.cpu_oracle import default_params as oracle_params
+    T, O, B = 24, 2, 3
+    pd, po = default_params(T), oracle_params(T)
+    pd.simplify_threshold = threshold; po.simplify_threshold = threshold
+    bp = None
+    for seed in range(900, 930):   # a batch none of whose pruning decisions sits on the threshold (the oracle reports the closest one)
+        cand = random_batch(seed, B, O)
+        os_ = [Oracle(params=po).set_problem(cand["q0"][b], cand["qd0"][b], cand["qdd0"][b], cand["q_des"][b], cand["obstacles"][b]) for b in range(B)]
+        if min(o.min_margin() for o in os_) > 1e-9:
+            bp = cand
+            break
+    assert bp is not None
+    for build in (1, 2):   # per time step, time-vectorised
+        nlp = ArmourNLP(params=pd).set_option(_lib.OPT_P1_BUILD, build).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        assert nlp.build_info()["kernel"] == ("per_step" if build == 1 else "time_vectorised")
+        _compare_tables(nlp, os_)
+        nlp.close()
+
+
 def test_two_handles_from_two_host_threads():
     """One handle = one stream; handles are independent (include/armour_hip.h): two host threads building and evaluating
     different worlds at the same time get the results of serial runs."""
