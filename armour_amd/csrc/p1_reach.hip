@@ -1761,13 +1761,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // Four-wave blocks take an item in 1.17 ms, one per CU at a time; one-wave blocks in 2.7 ms, waves_per_cu of them per CU.  With more
         // items than CUs the blocks loop, and what decides is the number of rounds either shape needs (measured, B problems of 100 steps,
         // four waves against one: B = 3..5 2.3-2.6 against 2.8-3.1 ms, 6..7 3.5-3.7 against 3.2-3.5, 8..10 4.4-4.8 against 5.2-5.7,
-        // 12 6.0 either way, 14..15 7.0 against 6.3: profiles/r03_p1_four_waves.txt)
+        // 12 6.0 either way, 14..15 7.0 against 6.3: profiles/r03_p1_four_waves.txt; re-measured at the end of round 3 with both shapes faster:
+        // a round of four-wave items 1.0 ms, of one-wave items 2.6 ms -- B = 11 5.07 against 5.27, 16 7.16 against 7.70, 14 6.2 against 5.7)
         const int cus = prop.multiProcessorCount;
         const long long r4 = (n_items + cus - 1) / cus, r1 = (n_items + (long long)cus * waves_per_cu(cap) - 1) / ((long long)cus * waves_per_cu(cap));
         const bool multi = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
                            : nw_env ? nw_env >= 3
                            : collect ? false
-                           : fits4 ? 4 * r4 < 9 * r1
+                           : fits4 ? 100 * r4 < 258 * r1
                                    : (n_items <= cus && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
         const bool four = multi && free_env0 && (nw_env ? nw_env == 4 : fits4);
         const bool three = multi && !four;
@@ -1859,14 +1860,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
     static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
-    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 32; }();  // below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
+    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 36; }();  // below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
     const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 30 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
     // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels; the environment switch is development only)
     const bool want_tv = h->opt_p1_build == 1 ? false : h->opt_p1_build == 2 ? true
-                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 15 / 8 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
+                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 5 / 3 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
     if (want_tv) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;

@@ -80,7 +80,7 @@ void armour_free_pinned(void* p);
 /* ---- per-handle options ---- */
 /* ARMOUR_OPT_P1_BUILD selects the reach-set build kernel of armour_set_problems* (value 0, 1 or 2):
  *   0  automatic (default): one wavefront per (problem, time step) for small batches, the time-vectorised kernel (one wavefront per
- *      50-64 time steps of a problem) from B*T >= 1600 on;
+ *      50-64 time steps of a problem) from B*T >= 1800 on;
  *   1  always per time step;   2  always time-vectorised.
  * TOLERANCE CONTRACT.  Both kernels run the reference's operator sequence on the same operands and produce identical monomial keys,
  * coefficients and centres bit for bit; they add the pruned amounts of simplify() (RT/PZsparse.cu:327-341) into the independent

@@ -363,15 +363,15 @@ def test_batch_built_time_vectorised_against_single_problem_handles():
 
 
 def test_build_info_names_the_kernel_that_built_the_tables():
-    """armour_get_build_info: a lone problem is built step by step by four-wave blocks in one launch, a batch of 16 time-vectorised by
+    """armour_get_build_info: a lone problem is built step by step by four-wave blocks in one launch, a batch of 18 time-vectorised by
     four-wave blocks in one launch -- for the 8-link Kinova and for the 9-link Fetch alike (a slot pool sized for 8 links once sent every
     Fetch batch through a failed time-vectorised launch and then down the per-step path, silently: the tables were right, the build slow)."""
     from armour_amd.planner import ArmourNLP, default_params, fetch_robot
     from armour_amd.worlds import random_batch
     T, O = 100, 2
-    fp = [_fetch_problem(40 + b, O) for b in range(16)]
+    fp = [_fetch_problem(40 + b, O) for b in range(18)]
     fb = {k: np.stack([p[k] for p in fp]) for k in fp[0]}
-    kb = random_batch(40, 16, O)
+    kb = random_batch(40, 18, O)
     for make, bp in ((lambda: ArmourNLP(T=T), kb), (lambda: ArmourNLP(robot=fetch_robot(0.5), params=default_params(T)), fb)):
         one = make().set_parameters(bp["q0"][0], bp["qd0"][0], bp["qdd0"][0], bp["q_des"][0], bp["obstacles"][0])
         assert one.build_info() == {"kernel": "per_step", "waves": 4, "sort_entries": 4096, "launches": 1}
