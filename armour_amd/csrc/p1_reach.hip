@@ -100,7 +100,7 @@ __host__ __device__ inline Layout make_layout(int J, int n, int capW, int nroles
     Layout L;
     L.nroles = nroles;
     L.nV = nroles == 1 ? kNVOneWave : nroles == kRoles ? kPartFirst[kRoles - 1] + kPartCount[kRoles - 1] : kPart4First[3] + kPart4Count[3];
-    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
+    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: three scratch slots (raw rot, simplified rot, rpy: unused since the JRS is built in closed form, kept so that slot numbers stay what the profiles and notes refer to); inertia
     L.nJV = (J + 1) + J;              // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;   // qd, qda, qdda; mass; per role: 4 raw temps
     L.offV = 0;
@@ -484,23 +484,6 @@ __device__ PZW_NOINLINE JrsScalars armtd_jrs_scalars(const P1Cfg& cf, double q0,
     js.sin_e = (fabs(c0) * rs + fabs(s0) * rc) * 4.0;
     js.qd_c = js.qd_k = js.qd_e = js.qda_e = js.qdd_c = js.qdd_k = js.qdd_e = 0.0;
     return js;
-}
-
-// write a raw (unsimplified) small PZ from lane 0 and simplify it into `out` (the constructors that end with
-// simplify(): RT/PZsparse.cu:120-136,179-205)
-template <int SZ>
-__device__ inline void build_simplified(Chain& c, const PZ& raw, const PZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
-    if (c.w.lane == 0) {
-        for (int e = 0; e < SZ; e++) { raw.cen[e] = cen[e]; raw.ind[e] = 0.0; raw.ind2[e] = 0.0; }
-        for (int i = 0; i < m; i++) {
-            raw.keys[i] = keys[i];
-            for (int e = 0; e < SZ; e++) raw.coef[i * SZ + e] = coefs[i * SZ + e];
-        }
-        c.w.cnt[raw.id] = m;
-    }
-    WSYNC();
-    Seg s[1] = {{view(c.w, raw), 1.0, -1}};
-    lincomb<SZ, 1>(c.w, out, s);
 }
 
 // ---- the small PZs of the JRS in closed form -------------------------------------------------------------------------------------------

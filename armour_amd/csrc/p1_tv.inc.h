@@ -32,7 +32,7 @@ __host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwav
     const int nroles = nwaves;   // (a four-wave block builds the JRS on all four waves)
     L.nroles = nroles; L.npools = nwaves;
     L.nV = nwaves == 1 ? kNVOneWave : nwaves == kRoles ? kTvPartFirst[kRoles - 1] + kTvPartCount[kRoles - 1] : kTvPart4First[3] + kTvPart4Count[3];
-    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: raw rot, simplified rot, rpy; inertia
+    L.nJM = (J + 1) + J + 3 * nroles + J;  // R[0..J], R_t[0..J-1], per role: three scratch slots (raw rot, simplified rot, rpy: unused since the JRS is built in closed form, kept so that slot numbers stay what the profiles and notes refer to); inertia
     L.nJV = (J + 1) + J;                   // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;        // qd, qda, qdda; mass; per role: 4 raw temps
     L.offV = 0;
@@ -242,26 +242,6 @@ struct TChain {
         return o;
     }
 };
-
-// a raw (unsimplified) small PZ with per-lane coefficients, then simplify() into `out` (RT/PZsparse.cu:120-136,179-205)
-template <int SZ>
-__device__ inline void build_simplified(TChain& c, const TPZ& raw, const TPZ& out, const double* cen, int m, const uint64_t* keys, const double* coefs) {
-    const int lane = c.w.w.lane;
-    for (int e = 0; e < SZ; e++) {
-        tv::st_hdr(raw, tv::H_CEN, e, lane, cen[e]);
-        tv::st_hdr(raw, tv::H_IND, e, lane, 0.0);
-        tv::st_hdr(raw, tv::H_IND2, e, lane, 0.0);
-        tv::st_hdr(raw, tv::H_ASUM, e, lane, 0.0);
-    }
-    for (int i = 0; i < m; i++) {
-        if (lane == 0) raw.keys[i] = keys[i];
-        for (int e = 0; e < SZ; e++) raw.coef[((size_t)i * SZ + e) * 64 + lane] = coefs[i * SZ + e];
-    }
-    if (lane == 0) c.w.w.cnt[raw.id] = m;
-    WSYNC();
-    TSeg s[1] = {{tv::view(c.w, raw), 1.0, -1}};
-    tv::lincomb<SZ, 1, false>(c.w, out, s);
-}
 
 // ---- the small PZs of the JRS in closed form (p1_reach.hip has the per-step twin and the reasons) ------------------------------------------
 // Every lane evaluates the operators' arithmetic for ITS time step in registers, in their order -- lincomb<SZ,1>'s simplify() of the raw terms,
