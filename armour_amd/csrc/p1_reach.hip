@@ -930,7 +930,9 @@ __device__ PZW_NOINLINE void run_rnea(CH& c, typename CH::PZT* u, int b, int t) 
 #include "p1_free.inc.h"
 
 // disturbance w = u_int - u_nom, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205)
-__device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
+// (part / parts: the waves of a free-running block share the joints' tables -- joint j on wave j % parts -- after the last barrier of the RNEA;
+//  the radii every table entry needs are a few LDS reads, which every wave does for itself)
+__device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t, int part = 0, int parts = 1) {
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, T = cf.T;
@@ -946,6 +948,8 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
         const double lo = dcen - rad, hi = dcen + rad;
         rho = iadd(rho, imul(iv(lo, hi), iv(lo, hi)));
         tr[j] = cf.rb.alpha * (cf.rb.M_max - cf.rb.M_min) * cf.ub.eps + 0.5 * fmax(fabs(lo), fabs(hi));
+        un_ind[j] = 0.0;
+        if (j % parts != part) continue;
         // reduce(u_nom) (RT/PZsparse.cu:352-368) straight into the final torque table
         const PZ& p = u_nom[j];
         const int cnt = w.cnt[p.id];
@@ -975,6 +979,7 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t) {
     // sqrt of the interval sum: Boost clamps a negative lower bound to 0; only .upper() is used (:185-188)
     const double rho_hi = up(sqrt(rho.hi));
     for (int j = 0; j < n; j++) {
+        if (j % parts != part) continue;
         double v = tr[j];
         v += 0.5 * rho_hi;
         v += un_ind[j];
@@ -1102,7 +1107,12 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #ifdef P1_PROFILE
         const long long ph3 = clock64();
 #endif
-        if (!fk_only && c.is(0)) finish_torque(c, u_nom, b, t);
+        if (!fk_only) {
+            if (NW >= kRoles && cf.free_running) {   // every wave takes its share of the joints' tables (the 1x1 slots of u_nom: the mailbox, past the last barrier of the RNEA)
+                for (int j = 0; j < c.n; j++) u_nom[j] = c.S(t3_ld(&c.mb[T3_U + j]));
+                finish_torque(c, u_nom, b, t, c.wid, NW);
+            } else if (c.is(0)) finish_torque(c, u_nom, b, t);
+        }
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
             // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
