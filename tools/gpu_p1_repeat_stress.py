@@ -9,7 +9,7 @@ from armour_amd.planner import ArmourNLP
 from armour_amd.worlds import random_batch, random_k
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 total_bad = 0
-for B, O in ((1, 20), (2, 20), (3, 20), (5, 20), (9, 20), (12, 20), (16, 20), (40, 10), (64, 20), (128, 20), (150, 5), (300, 3)):
+for B, O in ((1, 20), (2, 20), (3, 20), (5, 20), (9, 20), (12, 20), (14, 20), (16, 20), (40, 10), (64, 20), (128, 20), (150, 5), (300, 3)):
     bp = random_batch(7, B, O)
     ks = random_k(3, B)
     first = None
