@@ -16,20 +16,42 @@
 
 void armour_set_error(const char* fmt, ...);
 
-// doubles per problem in the plane table and the offset (within one problem) of component c of plane p of row q.
-// planes[b][c][p][q]: the row index q = (l*T + t)*O + o is the fastest axis, so a wave reads 64 consecutive rows with
-// one coalesced 512-B request per (component, plane) and consecutive planes / components of a row are Q*8 / 36*Q*8
-// bytes apart -- a wave's 45 requests land on 45 different HBM pages/channels.  (A tiled variant that made each
-// block's 92 KB contiguous was measured 18 % slower at B=128, O=50: it concentrates a block on few channels.)
-__host__ __device__ inline size_t armour_planes_per_problem(int Q) { return (size_t)ARMOUR_PLANE_COMPONENTS * ARMOUR_NPLANES * (size_t)Q; }
-__host__ __device__ inline size_t armour_plane_index(int Q, int q, int p, int c) { return ((size_t)c * ARMOUR_NPLANES + p) * (size_t)Q + q; }
-// The pair order of RT/CollisionChecking.cu:26-39 puts the 3 obstacle generators first, so planes 21..35 pair two of the
-// 6 link generators: their NORMALS do not depend on the obstacle.  They are also kept once per (link, time step) in
-// planes_ll[b][c in {Ax,Ay,Az}][p - 21][lt] (lt = l*T + t), which P2 reads instead of O identical copies.
+// The half-space table of one problem, layout v2 (round 4).  The row index q = (l*T + t)*O + o is the fastest axis and every array
+// of rows is Qs = armour_row_stride(Q) long -- Q rounded up to 16 doubles, so that each array starts on a 128-B line (with the
+// unpadded Q of rounds 1-3 every second array of configs[2] started 64 B into a line and a wave's 512-B read spanned 5 lines
+// instead of 4).  Components are PAIRED so that the fused evaluation reads 16 B per lane (1 KB per wave instruction):
+//   AB  [36][Qs] double2 {Ax, Ay}
+//   CD  [36][Qs] double2 {Az, delta}           delta of planes 0..20 only (an obstacle generator in the pair)
+//   DLL [ 8][Qs] double2 {delta of link x link plane 21 + 2i, delta of plane 22 + 2i}
+//   D   [36][Qs] double  d                     (read only by launches that do not recompute d = A.c, i.e. < 8 problems)
+// consecutive planes of a row are Qs*16 B apart: a wave's requests still land on different HBM pages / channels.  (A tiled variant
+// that made each block's rows contiguous was measured 18 % slower at B=128, O=50: it concentrates a block on few channels.)
+// armour_plane_index() is the single definition of this layout: the index, in doubles, of component c of plane p of row q.
 #define ARMOUR_FIRST_LL_PLANE 21
 #define ARMOUR_N_LL_PLANES 15
-__host__ __device__ inline size_t armour_planes_ll_per_problem(int JT) { return (size_t)3 * ARMOUR_N_LL_PLANES * (size_t)JT; }
-__host__ __device__ inline size_t armour_plane_ll_index(int JT, int lt, int pll, int c) { return ((size_t)c * ARMOUR_N_LL_PLANES + pll) * (size_t)JT + lt; }
+__host__ __device__ inline int armour_row_stride(int Q) { return (Q + 15) & ~15; }
+__host__ __device__ inline size_t armour_planes_ab_offset(int Q) { (void)Q; return 0; }
+__host__ __device__ inline size_t armour_planes_cd_offset(int Q) { return (size_t)2 * ARMOUR_NPLANES * armour_row_stride(Q); }
+__host__ __device__ inline size_t armour_planes_dll_offset(int Q) { return (size_t)4 * ARMOUR_NPLANES * armour_row_stride(Q); }
+__host__ __device__ inline size_t armour_planes_d_offset(int Q) { return (size_t)(4 * ARMOUR_NPLANES + 16) * armour_row_stride(Q); }
+__host__ __device__ inline size_t armour_planes_per_problem(int Q) { return (size_t)(5 * ARMOUR_NPLANES + 16) * armour_row_stride(Q); }
+__host__ __device__ inline size_t armour_plane_index(int Q, int q, int p, int c) {
+    const size_t Qs = (size_t)armour_row_stride(Q);
+    if (c < 2) return ((size_t)p * Qs + q) * 2 + c;
+    if (c == 2) return armour_planes_cd_offset(Q) + ((size_t)p * Qs + q) * 2;
+    if (c == 3) return armour_planes_d_offset(Q) + (size_t)p * Qs + q;
+    if (p < ARMOUR_FIRST_LL_PLANE) return armour_planes_cd_offset(Q) + ((size_t)p * Qs + q) * 2 + 1;
+    return armour_planes_dll_offset(Q) + ((size_t)((p - ARMOUR_FIRST_LL_PLANE) >> 1) * Qs + q) * 2 + ((p - ARMOUR_FIRST_LL_PLANE) & 1);
+}
+// The pair order of RT/CollisionChecking.cu:26-39 puts the 3 obstacle generators first, so planes 21..35 pair two of the
+// 6 link generators: their NORMALS do not depend on the obstacle.  They are also kept once per (link, time step) in
+// planes_ll[b][lt][48] (lt = l*T + t; entry 3*(p - 21) + c, c in {Ax,Ay,Az}; 45 used, 384 B = three lines per (link, time step)),
+// which P2 reads instead of O identical copies: the 64 rows of a collision block touch 64/O + 1 such records.
+// tables of at least this many collision rows (or of >= 8 problems) carry no d column: the fused evaluation recomputes d = A.c
+#define ARMOUR_RECOMPUTE_D_ROWS 32768
+#define ARMOUR_LL_RECORD 48
+__host__ __device__ inline size_t armour_planes_ll_per_problem(int JT) { return (size_t)ARMOUR_LL_RECORD * (size_t)JT; }
+__host__ __device__ inline size_t armour_plane_ll_index(int JT, int lt, int pll, int c) { (void)JT; return (size_t)lt * ARMOUR_LL_RECORD + (size_t)pll * 3 + c; }
 
 #define HIPCHK(expr)                                                                                     \
     do {                                                                                                 \
@@ -44,9 +66,9 @@ __host__ __device__ inline size_t armour_plane_ll_index(int JT, int lt, int pll,
 //
 // Final link / torque PZs hold only k-dependent monomials (key < 2^(2n)); keys are stored as u32.
 //   link  index: (b*J + l)*T + t     torque index: (b*n + j)*T + t
-// Half-space table: planes[b][c][p][q], c in {Ax,Ay,Az,d,delta}, p in [0,36), q = (l*T + t)*O + o -- the row index is
-// the fastest axis and is also the output row order of the collision block (RT/NLPclass.cu:117-164:
-// g[nT + (l*T+t)*O + o]).  armour_plane_index() is the single definition of this layout.
+// Half-space table: component pairs x plane p in [0,36) x row q = (l*T + t)*O + o -- the row index is the fastest axis and
+// is also the output row order of the collision block (RT/NLPclass.cu:117-164: g[nT + (l*T+t)*O + o]).
+// armour_plane_index() above is the single definition of this layout.
 struct P2Tables {
     int B, T, J, n, O, Q, m;
     int capL, capT;
@@ -61,9 +83,9 @@ struct P2Tables {
     const double* tq_indep;     // [..]
     const uint32_t* tq_keys;    // [..][capT]
     const double* tq_coeff;     // [..][capT]
-    const double* planes;       // [B][5][36][Q]
+    const double* planes;       // [B][armour_planes_per_problem(Q)], see armour_plane_index
     const double* obs_center;   // [B][3][O] obstacle centres; when non-null P2 computes d = A.c itself instead of reading it (tables built by P1)
-    const double* planes_ll;    // [B][3][15][J*T], see armour_plane_ll_index; used when ll_shared != 0
+    const double* planes_ll;    // [B][J*T][48], see armour_plane_ll_index; used when ll_shared != 0
     int ll_shared;
     int mode;  // ARMOUR_MODE_*: which trajectory the joint-limit rows belong to
     const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem

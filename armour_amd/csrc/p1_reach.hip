@@ -1223,9 +1223,14 @@ __device__ inline void planes_of_group(const double (&G)[9][3], const double (&c
 #pragma unroll
         for (int j = 0; j < 9; j++) dl += fabs(C0 * G[j][0] + C1 * G[j][1] + C2 * G[j][2]);
         if (in) {
-            if (!LEAN || p < ARMOUR_FIRST_LL_PLANE) { out[armour_plane_index(Q, q, p, 0)] = C0; out[armour_plane_index(Q, q, p, 1)] = C1; out[armour_plane_index(Q, q, p, 2)] = C2; }
+            // (layout: common.h armour_plane_index -- {Ax,Ay} and {Az,delta} are 16-B pairs, written as such)
+            if (!LEAN || p < ARMOUR_FIRST_LL_PLANE) *reinterpret_cast<double2*>(out + armour_plane_index(Q, q, p, 0)) = make_double2(C0, C1);
+            if (p < ARMOUR_FIRST_LL_PLANE) *reinterpret_cast<double2*>(out + armour_plane_index(Q, q, p, 2)) = make_double2(C2, dl);
+            else {
+                if (!LEAN) out[armour_plane_index(Q, q, p, 2)] = C2;
+                out[armour_plane_index(Q, q, p, 4)] = dl;
+            }
             if (!LEAN || store_d) out[armour_plane_index(Q, q, p, 3)] = C0 * c[0] + C1 * c[1] + C2 * c[2];
-            out[armour_plane_index(Q, q, p, 4)] = dl;
             if (ll && o == 0 && p >= ARMOUR_FIRST_LL_PLANE) {  // link x link normal: the same for every obstacle of this (l, t), kept once
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 0)] = C0;
                 ll[armour_plane_ll_index(JT, lt, p - ARMOUR_FIRST_LL_PLANE, 1)] = C1;
@@ -2006,10 +2011,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         unsigned long long* d_pre = d_pre_part + pre_words;
         unsigned long long* d_live = d_pre + B;
         // The table holds what the fused evaluation reads and nothing else (planes_of_group): ARMOUR_P1_FULL_PLANES=1 (development) builds
-        // the full one.  d = A.c is stored for the small batches that read it; batches of >= 8 problems recompute it (armour_make_tables).
+        // the full one.  d = A.c is stored for the small launches that read it; batches of >= 8 problems or >= 32 768 rows recompute it (armour_make_tables).
         static const int full_env = [] { const char* e = getenv("ARMOUR_P1_FULL_PLANES"); return e ? atoi(e) : 0; }();
         const bool lean = !full_env;
-        const int store_d = B >= 8 ? 0 : 1;
+        // (round 4, one box, interleaved: configs[4] -- one problem, 90 000 rows, a 60 MB table -- 13.1 us with d recomputed against 15.8 stored;
+        //  configs[1] -- 14 000 rows, L2-resident -- 5.05 against 5.02: the launch that streams its table from beyond L2 wants the fewer bytes)
+        const int store_d = (B >= 8 || (long long)B * Q >= ARMOUR_RECOMPUTE_D_ROWS) ? 0 : 1;
         if (lean) {
             hipLaunchKernelGGL(armour_p1_plane_class_kernel, dim3(nbc, B), dim3(256), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part);
             hipLaunchKernelGGL(armour_p1_plane_sample_kernel, dim3(B), dim3(64 * kPlaneSamples), 0, h->stream, T, J, O, wk->d_link_gens, wk->d_obstacles, d_pre_part, nbc, d_pre, d_live);

@@ -76,6 +76,24 @@ __global__ void armour_p2_slice_links_kernel(P2Tables tb, const double* __restri
 
 const char* armour_p2_kernel_name(void) { return "armour_p2_eval_kernel"; }
 
+// What the EX kernels assume of a problem's live planes (p2_tiles.h collision_block): 24 of them; the first twelve pair an obstacle
+// generator (waves 0 and 1, six each); the last twelve are link x link planes, six CONSECUTIVE ones per wave starting at an even
+// p - 21 (their normals are then 144 contiguous, 16-B aligned bytes of the compact record and their deltas three aligned pairs).
+// Worlds of axis-aligned boxes -- the reference's -- give planes {0..11 of the obstacle pairs} + 21..32.
+bool armour_p2_ex_layout_ok(unsigned long long skip) {
+    unsigned long long live = ~skip & ((1ull << ARMOUR_NPLANES) - 1ull);
+    if (__builtin_popcountll(live) != 24) return false;
+    int pl[24];
+    for (int i = 0; i < 24; i++) { pl[i] = __builtin_ctzll(live); live &= live - 1ull; }
+    if (pl[11] >= ARMOUR_FIRST_LL_PLANE || pl[12] < ARMOUR_FIRST_LL_PLANE) return false;
+    for (int w = 2; w < 4; w++) {
+        const int p0 = pl[6 * w];
+        if ((p0 - ARMOUR_FIRST_LL_PLANE) & 1) return false;
+        for (int i = 1; i < 6; i++) if (pl[6 * w + i] != p0 + i) return false;
+    }
+    return true;
+}
+
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out) {
     P2Launch lp;
@@ -104,7 +122,7 @@ int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsig
     // ... exactly 24 (6 per wave) and the blocks slice in one pass: the EX kernels (development switch ARMOUR_P2_EX=0 turns them off)
     static const bool ex_on = [] { const char* e = getenv("ARMOUR_P2_EX"); return !e || atoi(e) != 0; }();
     bool exact = six && ex_on && lp.max_pairs <= lp.pair_chunk;
-    for (int b = 0; exact && b < tb.B; b++) exact = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) == 24;
+    for (int b = 0; exact && b < tb.B; b++) exact = armour_p2_ex_layout_ok(h_skip[b]);
     *lp_out = lp; *smem_out = smem; *dfc_out = dfc; *six_out = six; *exact_out = exact;
     return ARMOUR_OK;
 }

@@ -118,6 +118,10 @@ __device__ inline double interval_center(double c, double r) {
 __host__ __device__ inline unsigned long long div_magic(int d) { return ((1ull << 40) + (unsigned long long)d - 1ull) / (unsigned long long)d; }
 __device__ inline int fast_div(int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); }
 
+// 16-B table entries as a NATIVE vector: a load of HIP's double2 (a struct) is split into two 8-B loads by the optimiser before the
+// two plane-loading paths of the EX kernels are merged, and the backend cannot pair them again afterwards (seen in the ISA)
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 struct P2Launch {
     int nbc, nbt;       // collision / torque block counts
     int max_pairs;      // (l,t) pairs a collision block can touch
@@ -247,11 +251,17 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
     // 1. issue this lane's share of the live planes x 5 components first: nothing below depends on them until
     //    step 3.  Planes flagged in plane_skip[b] (degenerate or exact duplicates in every row, see
     //    armour_p1_planes_kernel) are not fetched; the live ones are dealt to the 4 waves in ascending order.
-    const double* pl = tb.planes + (size_t)b * armour_planes_per_problem(Q) + q;  // layout: common.h armour_plane_index
-    const size_t cs = (size_t)ARMOUR_NPLANES * Q;
+    // layout: common.h armour_plane_index -- 16-B pairs {Ax,Ay}, {Az,delta}, {delta,delta} of two link x link planes; row stride Qs
+    const size_t Qs = (size_t)armour_row_stride(Q);
+    const double* pl0 = tb.planes + (size_t)b * armour_planes_per_problem(Q);
+    const v2d* plAB = reinterpret_cast<const v2d*>(pl0) + q;
+    const v2d* plCD = reinterpret_cast<const v2d*>(pl0 + armour_planes_cd_offset(Q)) + q;
+    const v2d* plLL = reinterpret_cast<const v2d*>(pl0 + armour_planes_dll_offset(Q)) + q;
+    const double* plD = pl0 + armour_planes_d_offset(Q) + q;
     const int JT = tb.J * T;
     const int q_lt = fast_div(q, lp.magic_O), q_o = q - q_lt * O;  // q = (l*T + t)*O + o
-    const double* pll = tb.planes_ll + (size_t)b * armour_planes_ll_per_problem(JT) + q_lt;
+    // compact link x link normals: one 384-B record per (link, time step), entry 3*(p - 21) + c
+    const double* pll = tb.planes_ll + (size_t)b * armour_planes_ll_per_problem(JT) + (size_t)q_lt * ARMOUR_LL_RECORD;
     unsigned long long live = ~(lp.skip_by_value ? lp.skip0 : tb.plane_skip[b]) & ((1ull << ARMOUR_NPLANES) - 1ull);
     const bool plane0_live = (live & 1ull) != 0;
     const int na = __popcll(live), base = na >> 2, rem = na & 3;
@@ -263,28 +273,65 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
     const bool single_pass = npairs <= lp.pair_chunk;
     PassRegs pr;
     if (EX) load_pass_uncond(tb, lp, b, lt_first, npairs, pr);
+    // EX launches (armour_p2_plan: ex_layout_ok): waves 0 and 1 hold six planes with an obstacle generator each -- {Ax,Ay}, {Az,delta}:
+    // twelve 16-B loads; waves 2 and 3 six CONSECUTIVE link x link planes each, starting at an even p - 21: their 18 normal components
+    // are 144 contiguous, 16-B aligned bytes of the (link, time step) record -- nine loads whose 64 lanes touch 64/O + 1 records -- and
+    // their deltas three 16-B pairs.  Twelve loads [+ six of d] either way, issued by common code from per-wave ADDRESSES into the same
+    // registers, so that the compiler's vmcnt for the slicing below is exact; what the registers mean is sorted out after the slicing.
+    v2d raw[EX ? 12 : 1];
+    bool ll_wave = false;
+    if (EX) {
+        static_assert(!EX || PPW == 6, "the EX kernels hold six planes per wave");
+        ll_wave = wv >= 2;
+        const v2d* ra[12];
+        const double* da[6];
+        if (ll_wave) {
+            const int pll0 = __builtin_ctzll(live) - ARMOUR_FIRST_LL_PLANE;
+            const v2d* nrm = reinterpret_cast<const v2d*>(pll + (size_t)pll0 * 3);
+#pragma unroll
+            for (int j = 0; j < 9; j++) ra[j] = nrm + j;
+#pragma unroll
+            for (int j = 0; j < 3; j++) ra[9 + j] = plLL + (size_t)((pll0 >> 1) + j) * Qs;
+#pragma unroll
+            for (int i = 0; i < 6; i++) da[i] = plD + (size_t)(ARMOUR_FIRST_LL_PLANE + pll0 + i) * Qs;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const size_t o = (size_t)__builtin_ctzll(live) * Qs;
+                live &= live - 1ull;
+                ra[2 * i] = plAB + o; ra[2 * i + 1] = plCD + o; da[i] = plD + o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 12; j++) raw[j] = *ra[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { dd[i] = 0.0; if (!DFC) dd[i] = *da[i]; }
+    } else {
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
         a0[i] = 0.0; a1[i] = 0.0; a2[i] = 0.0; dd[i] = 0.0; dl[i] = 0.0;
-        if (EX || i < my_cnt) {
+        if (i < my_cnt) {
             const int pidx = __builtin_ctzll(live);
-            const size_t o = (size_t)pidx * Q;
+            const size_t o = (size_t)pidx * Qs;
             live &= live - 1ull;
             // (non-temporal loads were measured 7 % slower at B=128, O=50: default cache policy kept)
             if (LL && pidx >= ARMOUR_FIRST_LL_PLANE) {
                 // link x link plane: its normal is the same for the O obstacles of a (link, time step) and is read from
-                // the compact copy -- a wave touches 64/O + 1 distinct addresses instead of 64
-                const double* al = pll + (size_t)(pidx - ARMOUR_FIRST_LL_PLANE) * JT;
-                a0[i] = al[0]; a1[i] = al[(size_t)ARMOUR_N_LL_PLANES * JT]; a2[i] = al[(size_t)2 * ARMOUR_N_LL_PLANES * JT];
+                // the compact copy -- a wave touches 64/O + 1 distinct records instead of 64 rows
+                const double* al = pll + (size_t)(pidx - ARMOUR_FIRST_LL_PLANE) * 3;
+                a0[i] = al[0]; a1[i] = al[1]; a2[i] = al[2];
+                dl[i] = pl0[armour_plane_index(Q, q, pidx, 4)];
             } else {
-                a0[i] = pl[o]; a1[i] = pl[cs + o]; a2[i] = pl[2 * cs + o];
+                const v2d ab = plAB[o], cd = plCD[o];
+                a0[i] = ab.x; a1[i] = ab.y; a2[i] = cd.x; dl[i] = cd.y;
+                if (!LL && pidx >= ARMOUR_FIRST_LL_PLANE) dl[i] = pl0[armour_plane_index(Q, q, pidx, 4)];
             }
-            if (!DFC) dd[i] = pl[3 * cs + o];
-            dl[i] = pl[4 * cs + o];
+            if (!DFC) dd[i] = plD[o];
         }
 #if defined(P2_ABLATE) && (P2_ABLATE & 8)
         a0[i] = 1.0 + i; a1[i] = 0.5; a2[i] = 0.25; dd[i] = 0.1; dl[i] = 0.2;
 #endif
+    }
     }
     // d = A . c_obstacle (RT/CollisionChecking.cu:200-202): with the obstacle centres at hand it is recomputed, in the
     // expression of armour_p1_planes_kernel, instead of read -- 8 B less per plane and row
@@ -346,6 +393,21 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
         //    max_id defaults to plane 0 (RT/CollisionChecking.cu:262): its normal if it is live (then it is slot 0 of
         //    wave 0), zero if it was skipped (best = -2 matches no slot).
         const double x0 = xs[0], x1 = xs[1], x2 = xs[2];
+        if (EX) {  // what the raw 16-B registers of this wave hold (see the loads above)
+            if (ll_wave) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const int e = 3 * i;  // components e, e + 1, e + 2 of the 18 consecutive normal components
+                    a0[i] = (e & 1) ? raw[e >> 1].y : raw[e >> 1].x;
+                    a1[i] = ((e + 1) & 1) ? raw[(e + 1) >> 1].y : raw[(e + 1) >> 1].x;
+                    a2[i] = ((e + 2) & 1) ? raw[(e + 2) >> 1].y : raw[(e + 2) >> 1].x;
+                    dl[i] = (i & 1) ? raw[9 + (i >> 1)].y : raw[9 + (i >> 1)].x;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { a0[i] = raw[2 * i].x; a1[i] = raw[2 * i].y; a2[i] = raw[2 * i + 1].x; dl[i] = raw[2 * i + 1].y; }
+            }
+        }
         if (DFC) {
 #pragma unroll
             for (int i = 0; i < PPW; i++) dd[i] = a0[i] * oc0 + a1[i] * oc1 + a2[i] * oc2;

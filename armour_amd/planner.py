@@ -497,24 +497,28 @@ class ArmourNLP:
         return out
 
     def effective_bytes(self):
-        """Bytes ONE fused evaluation of all B problems moves by the layout it actually reads (tables built by P1; p2_tiles.h
-        collision_block with the compact link x link normals, p1_reach.hip planes_of_group): per collision row and live plane
-        below 21 the normal and delta (32 B), per live plane from 21 on delta alone (8 B), plus d (8 B per live plane) for the
-        batches of < 8 problems that read it instead of recomputing it; the compact normals once per (link, time step); the
-        obstacle centres; the link / torque PZ tables with their counts, centres and radii; k in, g and the dense Jacobian out.
-        Unlike algorithmic_bytes() -- defined by the reference's formulation, 1440 B per row -- a fraction of the HBM peak computed
-        from this number cannot exceed 1."""
+        """Bytes ONE fused evaluation of all B problems moves by the layout it actually reads (tables built by P1; common.h
+        armour_plane_index, p2_tiles.h collision_block, p1_reach.hip planes_of_group), counted in whole 128-B lines: rows are
+        padded to a multiple of 16, so per collision row and live plane below 21 the pairs {Ax,Ay} and {Az,delta} (32 B), per
+        PAIR of link x link planes with a live member the pair of deltas (16 B), plus d (8 B per live plane) for the launches
+        that read it instead of recomputing it (fewer than 8 problems and fewer than 32 768 rows); the compact normals as the
+        three lines of each (link, time step) record; the obstacle centres; the link / torque PZ tables with their counts,
+        centres and radii; k in, g and the dense Jacobian out.  Unlike algorithmic_bytes() -- defined by the reference's
+        formulation, 1440 B per row -- a fraction of the HBM peak computed from this number cannot exceed 1."""
         ts = self.table_sizes()
         JT, Q, nT = self.J * self.T, self.J * self.T * self.O, self.n * self.T
-        dfc = self.B >= 8                       # armour_make_tables (api.hip)
+        Qs = (Q + 15) // 16 * 16
+        dfc = self.B >= 8 or self.B * Q >= 32768    # p1_reach.hip store_d / armour_make_tables (api.hip)
+        line = lambda nbytes: (nbytes + 127) // 128 * 128
         total = 0
         for sk in self.plane_skip():
             live = [p for p in range(36) if not (int(sk) >> p) & 1]
             lo, hi = sum(1 for p in live if p < 21), sum(1 for p in live if p >= 21)
-            per_row = 32 * lo + 8 * hi + (0 if dfc else 8 * (lo + hi))
-            total += Q * per_row + JT * hi * 24 + (24 * self.O if dfc else 0)
+            hi_pairs = len({(p - 21) >> 1 for p in live if p >= 21})
+            per_row = 32 * lo + 16 * hi_pairs + (0 if dfc else 8 * (lo + hi))
+            total += Qs * per_row + (JT * 384 if hi else 0) + (line(24 * self.O) if dfc else 0)
         total += 32 * ts["sum_link"] + 16 * ts["sum_torque"] + self.B * (JT * 52 + nT * 20)
-        total += self.B * (8 * self.m * (1 + self.n) + 8 * self.n)
+        total += self.B * (line(8 * self.m * (1 + self.n)) + line(8 * self.n))
         return total
 
     def algorithmic_bytes(self):
