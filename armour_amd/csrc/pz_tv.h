@@ -251,13 +251,26 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                 wp0 = clock64();
             }
 #endif
+            // The products of PB terms first, as straight-line code without a branch in it -- each is a chain of dependent fp64 operations
+            // (18 cycles apiece for the one wave of its SIMD), independent of the other terms' -- and only then the serial part: the run
+            // logic, the sums in generation order, the verdicts.  (Round 3's walk formed a term's product inside its guarded block, so
+            // that nothing overlapped: 702 of a raw term's 1200 cycles.)  Same operations on the same operands in the same order per sum.
+            constexpr int PB = U % 4 == 0 ? 4 : U % 3 == 0 ? 3 : U % 2 == 0 ? 2 : 1;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (l0 + u < n) {
-                    const uint64_t key = readlane_u64(key_v, l0 + u);
-                    if (have && key != cur) { pol.close(cur); have = false; }
-                    pol.add(regs[u], !have);
-                    have = true; cur = key;
+            for (int u0 = 0; u0 < U; u0 += PB) {
+                typename P::Prod pr[PB];
+                pol.template prod_batch<PB>(&regs[u0], pr);   // (written term-innermost: the compiler keeps source order, a term after a term otherwise)
+#pragma unroll
+                for (int v = 0; v < PB; v++) pr[v].pin();   // (formed HERE: not sunk into the guarded blocks below)
+#pragma unroll
+                for (int v = 0; v < PB; v++) {
+                    const int u = u0 + v;
+                    if (l0 + u < n) {
+                        const uint64_t key = readlane_u64(key_v, l0 + u);
+                        if (have && key != cur) { pol.close(cur); have = false; }
+                        pol.accum(regs[u], pr[v], !have);
+                        have = true; cur = key;
+                    }
                 }
             }
 #ifdef TV_PROFILE_FULL
@@ -352,8 +365,10 @@ struct MulCtx {
             for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
         }
     }
-    __device__ inline void add(const Regs& r, bool first) {
-        double c[SH::SZ], ca[SH::ASZ], cb[SH::BSZ];
+    // the term's coefficient product: pure (no state of the walk), so that the walk can form several terms' products at once
+    struct Prod { double c[SH::SZ]; __device__ inline void pin() { for (int e = 0; e < SH::SZ; e++) __asm__ volatile("" : "+v"(c[e])); } };
+    __device__ inline void prod(const Regs& r, Prod& p) const {
+        double ca[SH::ASZ], cb[SH::BSZ];
         if constexpr (STAGE == 1) {
             const LDS_AS double* pa = stage + (size_t)r.i * SH::ASZ * WAVE + lane;
 #pragma unroll
@@ -370,11 +385,61 @@ struct MulCtx {
 #pragma unroll
             for (int e = 0; e < SH::BSZ; e++) cb[e] = r.cb[e];
         }
-        SH::mul(ca, cb, c);
+        SH::mul(ca, cb, p.c);
+    }
+    // PB terms' products with the term index INNERMOST in every loop: the staged rows of all PB terms are requested first, and every step of
+    // the dot products is taken for all PB terms before the next -- PB x rows independent chains in flight instead of one term's after the
+    // other's (per element exactly SH::mul's operations in SH::mul's order)
+    template <int PB>
+    __device__ inline void prod_batch(const Regs* r, Prod* p) const {
+        double ca[PB][SH::ASZ], cb[PB][SH::BSZ];
+#pragma unroll
+        for (int v = 0; v < PB; v++) {
+            if constexpr (STAGE == 1) {
+                const LDS_AS double* pa = stage + (size_t)r[v].i * SH::ASZ * WAVE + lane;
+#pragma unroll
+                for (int e = 0; e < SH::ASZ; e++) ca[v][e] = pa[e * WAVE];
+            } else {
+#pragma unroll
+                for (int e = 0; e < SH::ASZ; e++) ca[v][e] = r[v].ca[e];
+            }
+            if constexpr (STAGE == 2) {
+                const LDS_AS double* pb = stage + (size_t)r[v].j * SH::BSZ * WAVE + lane;
+#pragma unroll
+                for (int e = 0; e < SH::BSZ; e++) cb[v][e] = pb[e * WAVE];
+            } else {
+#pragma unroll
+                for (int e = 0; e < SH::BSZ; e++) cb[v][e] = r[v].cb[e];
+            }
+        }
+        if constexpr (SH::a11) {
+#pragma unroll
+            for (int e = 0; e < SH::BSZ; e++)
+#pragma unroll
+                for (int v = 0; v < PB; v++) p[v].c[e] = ca[v][0] * cb[v][e];
+        } else {
+            constexpr int AR = SH::OR_, BC = SH::OC, AC = SH::ASZ / SH::OR_;
+#pragma unroll
+            for (int rr = 0; rr < AR; rr++)
+#pragma unroll
+                for (int cc = 0; cc < BC; cc++) {
+                    double sm[PB];
+#pragma unroll
+                    for (int v = 0; v < PB; v++) sm[v] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < AC; k++)
+#pragma unroll
+                        for (int v = 0; v < PB; v++) sm[v] += ca[v][rr * AC + k] * cb[v][k * BC + cc];
+#pragma unroll
+                    for (int v = 0; v < PB; v++) p[v].c[rr * BC + cc] = sm[v];
+                }
+        }
+    }
+    __device__ inline void accum(const Regs&, const Prod& p, bool first) {
         // (selects on the wave-uniform `first`, not a branch: every branch of the walk ends in a block of register moves that merges
         //  the accumulators of its two sides -- about forty per raw term before this form)
 #pragma unroll
-        for (int e = 0; e < SH::SZ; e++) { const double sum = acc[e] + c[e]; acc[e] = first ? c[e] : sum; }
+        for (int e = 0; e < SH::SZ; e++) { const double sum = acc[e] + p.c[e]; acc[e] = first ? p.c[e] : sum; }
     }
     __device__ inline void close(uint64_t key) {
         bool small;
@@ -569,7 +634,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
                 for (int u = 0; u < kUc; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
 #pragma unroll
                 for (int u = 0; u < kUc; u++)
-                    if (l0 + u < n) { cx.add(regs[u], true); cx.close(readlane_u64(key_v, l0 + u)); }
+                    if (l0 + u < n) { typename MulCtx<SH, 0>::Prod pr; cx.prod(regs[u], pr); cx.accum(regs[u], pr, true); cx.close(readlane_u64(key_v, l0 + u)); }
             }
         }
 #pragma unroll
@@ -670,20 +735,39 @@ struct CrossCtx {
             for (int e = 0; e < 3; e++) r.cb[e] = p[e * WAVE];
         }
     }
-    __device__ inline void add(const Regs& r, bool first) {
+    struct Prod { double p6[6]; __device__ inline void pin() { for (int e = 0; e < 6; e++) __asm__ volatile("" : "+v"(p6[e])); } };
+    __device__ inline void prod(const Regs& r, Prod& p) const {
         double ca[3], cb[3];
 #pragma unroll
         for (int e = 0; e < 3; e++) {
             if constexpr (STAGE == 1) ca[e] = stage[((size_t)r.i * 3 + e) * WAVE + lane]; else ca[e] = r.ca[e];
             if constexpr (STAGE == 2) cb[e] = stage[((size_t)r.j * 3 + e) * WAVE + lane]; else cb[e] = r.cb[e];
         }
-        double p6[6];
-        p6[0] = ca[1] * cb[2]; p6[1] = ca[2] * cb[1];
-        p6[2] = ca[2] * cb[0]; p6[3] = ca[0] * cb[2];
-        p6[4] = ca[0] * cb[1]; p6[5] = ca[1] * cb[0];
-        // (selects on the wave-uniform `first`: see MulCtx::add)
+        p.p6[0] = ca[1] * cb[2]; p.p6[1] = ca[2] * cb[1];
+        p.p6[2] = ca[2] * cb[0]; p.p6[3] = ca[0] * cb[2];
+        p.p6[4] = ca[0] * cb[1]; p.p6[5] = ca[1] * cb[0];
+    }
+    template <int PB>
+    __device__ inline void prod_batch(const Regs* r, Prod* p) const {   // (the staged rows of all PB terms first: see MulCtx::prod_batch)
+        double ca[PB][3], cb[PB][3];
 #pragma unroll
-        for (int e = 0; e < 6; e++) { const double sum = acc[e] + p6[e]; acc[e] = first ? p6[e] : sum; }
+        for (int v = 0; v < PB; v++)
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                if constexpr (STAGE == 1) ca[v][e] = stage[((size_t)r[v].i * 3 + e) * WAVE + lane]; else ca[v][e] = r[v].ca[e];
+                if constexpr (STAGE == 2) cb[v][e] = stage[((size_t)r[v].j * 3 + e) * WAVE + lane]; else cb[v][e] = r[v].cb[e];
+            }
+#pragma unroll
+        for (int v = 0; v < PB; v++) {
+            p[v].p6[0] = ca[v][1] * cb[v][2]; p[v].p6[1] = ca[v][2] * cb[v][1];
+            p[v].p6[2] = ca[v][2] * cb[v][0]; p[v].p6[3] = ca[v][0] * cb[v][2];
+            p[v].p6[4] = ca[v][0] * cb[v][1]; p[v].p6[5] = ca[v][1] * cb[v][0];
+        }
+    }
+    __device__ inline void accum(const Regs&, const Prod& p, bool first) {
+        // (selects on the wave-uniform `first`: see MulCtx::accum)
+#pragma unroll
+        for (int e = 0; e < 6; e++) { const double sum = acc[e] + p.p6[e]; acc[e] = first ? p.p6[e] : sum; }
     }
     __device__ inline void close(uint64_t key) {
         // first stage for everybody: a product below the threshold goes to its product's radius.  In the common case that is all
@@ -890,11 +974,19 @@ struct LinCtx {
 #pragma unroll
         for (int e = 0; e < SZ; e++) r.x[e] = src[e * step];
     }
-    // scale * embed(source entry)
-    __device__ inline void term(const Regs& r, double* c) {
+    // scale * embed(source entry): pure -- the walk forms several terms' at once (walk_sorted).  XK: the pruned amounts of the constant
+    // cross product's two stages come back in x1 / x2 and join xr1 / xr2 in accum(), i.e. in the operand's key order as before.
+    struct Prod {
+        double c[SZ], x1[XK >= 0 ? 3 : 1], x2[XK >= 0 ? 3 : 1];
+        __device__ inline void pin() { for (int e = 0; e < SZ; e++) __asm__ volatile("" : "+v"(c[e])); }
+    };
+    __device__ inline void prod(const Regs& r, Prod& p) const {
         const int k = r.k;
+        double* c = p.c;
         if constexpr (XK >= 0) {
             static_assert(SZ == 3, "a constant cross product is a 3x1 source");
+#pragma unroll
+            for (int q = 0; q < 3; q++) { p.x1[q] = 0.0; p.x2[q] = 0.0; }
             if (k == XK) {   // (wave-uniform) cross_const's arithmetic on this term, in its order
                 const double x0 = r.x[0], x1 = r.x[1], x2 = r.x[2];
                 const double xa[3] = {x1, x2, x0}, xb[3] = {x2, x0, x1};
@@ -905,13 +997,13 @@ struct LinCtx {
                     double v = xsA[q] * xa[q];
                     v += xsB[q] * xb[q];
                     const bool small = fabs(v) <= thr;
-                    xr1[q] += small ? fabs(v) : 0.0;
+                    p.x1[q] = small ? fabs(v) : 0.0;
                     rr[q] = small ? 0.0 : v;
                     anyc = anyc || !small;
                 }
                 const bool keep = anyc && !(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] <= thr_sq) && active;
 #pragma unroll
-                for (int q = 0; q < 3; q++) { xr2[q] += (anyc && !keep) ? fabs(rr[q]) : 0.0; c[q] = s[XK].scale * (keep ? rr[q] : 0.0); }
+                for (int q = 0; q < 3; q++) { p.x2[q] = (anyc && !keep) ? fabs(rr[q]) : 0.0; c[q] = s[XK].scale * (keep ? rr[q] : 0.0); }
                 return;
             }
         }
@@ -919,14 +1011,10 @@ struct LinCtx {
         double scale = s[0].scale;
 #pragma unroll
         for (int q = 1; q < NS; q++) { const bool me = (k == q); comp = me ? s[q].comp : comp; scale = me ? s[q].scale : scale; }
-        if (comp < 0) {
+        // (no branch on the wave-uniform comp: an embedded 1x1 source has its one row in every x[e] -- load() reads it SZ times --
+        //  so entry comp is scale * x[0] either way)
 #pragma unroll
-            for (int e = 0; e < SZ; e++) c[e] = scale * r.x[e];
-        } else {
-            const double x = scale * r.x[0];
-#pragma unroll
-            for (int e = 0; e < SZ; e++) c[e] = (e == comp) ? x : 0.0;
-        }
+        for (int e = 0; e < SZ; e++) { const double x = scale * r.x[e]; c[e] = (comp < 0 || e == comp) ? x : 0.0; }
     }
     __device__ inline bool is_small() const {
         if constexpr (SZ == 1) return fabs(acc[0]) <= thr;
@@ -956,10 +1044,18 @@ struct LinCtx {
     // absent -- what is accumulated is tested.  Between two tests without a new member the sum does not change, so of the stages
     // (last, rk) that have no member of this key only the FIRST can prune (a sum it keeps passes the later ones unchanged, a sum it
     // drops is gone): one evaluation where the first version of this walk did NS - 1, identical results.
-    __device__ inline void add(const Regs& r, bool first) {
-        double c[SZ];
-        term(r, c);
+    template <int PB>
+    __device__ inline void prod_batch(const Regs* r, Prod* p) const {   // (one multiplication deep: nothing to interleave)
+#pragma unroll
+        for (int v = 0; v < PB; v++) prod(r[v], p[v]);
+    }
+    __device__ inline void accum(const Regs& r, const Prod& p, bool first) {
+        const double* c = p.c;
         const int rk = r.k;
+        if constexpr (XK >= 0) {   // (zeros from every other source's terms: adding 0.0 to a non-negative sum changes nothing)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { xr1[q] += p.x1[q]; xr2[q] += p.x2[q]; }
+        }
         if constexpr (CHAIN) {
             const int kf = last + 1 > 1 ? last + 1 : 1;
             if (!first && kf < rk) stage_at(kf);   // (wave-uniform condition; `first`: nothing accumulated yet)
