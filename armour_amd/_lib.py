@@ -66,6 +66,36 @@ class ArmourViolation(C.Structure):
 
 OPT_P1_BUILD = 1   # ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
 OPT_P1_WORK_MEMORY_MB = 2   # ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's work memory, MiB (0: none)
+# the other per-handle options of include/armour_hip.h (launch shapes: bit-identical keys / coefficients / centres for every value)
+OPT_P1_KEEP_WORK_MEMORY = 3
+OPT_P1_STEP_WAVES = 101
+OPT_P1_STEP_FREE = 102
+OPT_P1_STEP_SPLIT_FK = 103
+OPT_P1_STEP_AUX3 = 104
+OPT_P1_MAX_WAVES_PER_CU = 105
+OPT_P1_TWO_PASS = 106
+OPT_P1_TV_MIN_GROUPS = 110
+OPT_P1_TV_WAVES = 111
+OPT_P1_TV_FREE = 112
+OPT_P1_TV_SPLIT_FK = 113
+OPT_P1_TV_DEDICATED = 114
+OPT_P1_TV_HELP_SHIFT = 115
+OPT_P1_TV_HELPERS = 116
+OPT_P1_TV_HELP_MIN = 117
+OPT_P1_TV_HELP_N = 118
+OPT_P1_TV_AUX3 = 119
+OPT_P1_FULL_PLANES = 120
+OPT_P2_EX = 130
+OPT_STEPS_GRAPH_MIN = 131
+OPT_PINNED_MODE = 132
+OPT_SOLVE_SUB_TILES = 140
+OPT_SOLVE_DEVICE = 141
+OPT_SOLVE_CUT_TILES = 142
+OPT_SOLVE_BLOCKS = 143
+OPT_SOLVE_SUB_BATCH = 144
+OPT_SOLVE_ROW_CAP = 145
+OPT_SOLVE_HARD_CAP_S = 146
+OPT_SOLVE_WAVES_PER_SIMD = 147
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -76,10 +106,10 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_get_plane_skip", "armour_set_option", "armour_eval_violations_device", "armour_eval_violations",
+    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_eval_violations_device", "armour_eval_violations",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
-    "armour_batch_get_build_ms",
+    "armour_batch_get_build_ms", "armour_batch_get_build_info",
 ]
 
 _lib = None
@@ -171,6 +201,9 @@ def load():
                                            C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]
     L.armour_get_plane_skip.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.armour_set_option.argtypes = [vp, C.c_int32, C.c_double]
+    L.armour_get_option.argtypes = [vp, C.c_int32, dp]
+    L.armour_device_memory.argtypes = [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.armour_controller_set_kernel.argtypes = [C.c_int32]
     L.armour_eval_violations_device.argtypes = [vp, vp, vp, vp]
     L.armour_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
     L.armour_batch_partition.argtypes = [C.c_int32, C.c_int32, ip]
@@ -185,6 +218,7 @@ def load():
     L.armour_batch_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
     L.armour_batch_solve.argtypes = [vp, C.POINTER(ArmourSolveOptions), C.POINTER(ArmourSolveResult)]
     L.armour_batch_get_build_ms.argtypes = [vp, dp, dp]
+    L.armour_batch_get_build_info.argtypes = [vp, ip]
     _lib = L
     return L
 

@@ -130,6 +130,7 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.tq_count = h->d_tq_count; tb.tq_center = h->d_tq_center; tb.tq_indep = h->d_tq_indep;
     tb.tq_keys = h->d_tq_keys; tb.tq_coeff = h->d_tq_coeff;
     tb.planes = h->d_planes; tb.planes_ll = h->d_planes_ll; tb.ll_shared = h->ll_shared;
+    tb.ex_allowed = h->tune(ARMOUR_OPT_P2_EX);
     // recomputing d = A.c in the kernel trades 8 B per plane and row for 5 flops: pays once the launch is bandwidth-bound
     // (measured: -25 % at B = 128, O = 50; +1 % at B = 1)
     // (a lean table of >= 8 problems has no d column at all: p1_reach.hip)
@@ -139,6 +140,33 @@ P2Tables armour_make_tables(const ArmourPlanner* h) {
     tb.duration = h->params.duration;
     return tb;
 }
+
+// ---- per-handle launch-shape options (include/armour_hip.h: ARMOUR_OPT_FIRST_TUNING .. ARMOUR_OPT_LAST_TUNING) ----
+namespace {
+struct TuningSpec { int option; double def, lo, hi; };
+// default and accepted range of every option (an option id without an entry is unknown)
+const TuningSpec kTuning[] = {
+    {ARMOUR_OPT_P1_STEP_WAVES, 0, 0, 4}, {ARMOUR_OPT_P1_STEP_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_SPLIT_FK, -1, -1, 1}, {ARMOUR_OPT_P1_STEP_AUX3, 1, 0, 1},
+    {ARMOUR_OPT_P1_MAX_WAVES_PER_CU, 4, 1, 8}, {ARMOUR_OPT_P1_TWO_PASS, 1, 0, 1},
+    {ARMOUR_OPT_P1_TV_MIN_GROUPS, 36, 1, 1e6}, {ARMOUR_OPT_P1_TV_WAVES, 0, 0, 8}, {ARMOUR_OPT_P1_TV_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_TV_SPLIT_FK, -1, -1, 1},
+    {ARMOUR_OPT_P1_TV_DEDICATED, 1, 0, 1}, {ARMOUR_OPT_P1_TV_HELP_SHIFT, 0, 0, 3}, {ARMOUR_OPT_P1_TV_HELPERS, 1, 0, 31}, {ARMOUR_OPT_P1_TV_HELP_MIN, 192, 1, 1e6},
+    {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},
+    {ARMOUR_OPT_P2_EX, 1, 0, 1}, {ARMOUR_OPT_STEPS_GRAPH_MIN, 2, 0, 1e6}, {ARMOUR_OPT_PINNED_MODE, 0, 0, 2},
+    {ARMOUR_OPT_SOLVE_SUB_TILES, 48, 1, 1e6}, {ARMOUR_OPT_SOLVE_DEVICE, 1, 0, 1}, {ARMOUR_OPT_SOLVE_CUT_TILES, 156, 1, 1e6}, {ARMOUR_OPT_SOLVE_BLOCKS, 0, 0, 1e6},
+    {ARMOUR_OPT_SOLVE_SUB_BATCH, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_ROW_CAP, 0, 0, 1e7}, {ARMOUR_OPT_SOLVE_HARD_CAP_S, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_WAVES_PER_SIMD, 0, 0, 2},
+};
+const TuningSpec* tuning_spec(int option) {
+    for (const TuningSpec& t : kTuning) if (t.option == option) return &t;
+    return nullptr;
+}
+}  // namespace
+void armour_tuning_defaults(double* tuning) {
+    for (int o = ARMOUR_OPT_FIRST_TUNING; o <= ARMOUR_OPT_LAST_TUNING; o++) tuning[o - ARMOUR_OPT_FIRST_TUNING] = 0.0;
+    for (const TuningSpec& t : kTuning) tuning[t.option - ARMOUR_OPT_FIRST_TUNING] = t.def;
+}
+// tracing: the only environment variables the library reads besides the worker's ARMOUR_WORKER_PARENT; neither changes a result
+bool armour_trace_p1() { static const bool on = getenv("ARMOUR_P1_TRACE") != nullptr; return on; }
+bool armour_trace_solve() { static const bool on = getenv("ARMOUR_SOLVE_TIMING") != nullptr; return on; }
 
 extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* params, const ArmourLimits* limits,
                              int32_t device, ArmourPlanner** out) {
@@ -170,6 +198,7 @@ extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* param
     if (!h) { armour_set_error("out of host memory"); return ARMOUR_EINVAL; }
     h->robot = *robot;
     h->params = *params;
+    armour_tuning_defaults(h->tuning);
     ArmourLimits lim;
     memset(&lim, 0, sizeof(lim));
     if (limits) lim = *limits;
@@ -280,7 +309,7 @@ int armour_refresh_table_stats(ArmourPlanner* h) {
     h->sum_link = sl; h->sum_torque = st; h->max_link = ml; h->max_torque = mt;
     h->h_plane_skip.assign((size_t)h->B, 0ull);
     if (h->O > 0) HIPCHK(hipMemcpy(h->h_plane_skip.data(), h->d_plane_skip, (size_t)h->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (h->O > 0 && getenv("ARMOUR_P1_TRACE")) {   // development: which planes the collision rows never need (p1_reach.hip, armour_p1_planes_kernel)
+    if (h->O > 0 && armour_trace_p1()) {   // development: which planes the collision rows never need (p1_reach.hip, armour_p1_planes_kernel)
         unsigned long long all_and = ~0ull, all_or = 0ull;
         for (unsigned long long v : h->h_plane_skip) { all_and &= v; all_or |= v; }
         fprintf(stderr, "[P1 planes] plane_skip of %d problem(s): AND 0x%09llx OR 0x%09llx\n", h->B, all_and & ((1ull << ARMOUR_NPLANES) - 1ull), all_or & ((1ull << ARMOUR_NPLANES) - 1ull));
@@ -557,15 +586,15 @@ static int steps_graph(ArmourPlanner* h, const double* d_k, int steps, double* d
     return ARMOUR_OK;
 }
 
-static bool steps_use_graph(int steps) {
-    static const int min_steps = [] { const char* e = getenv("ARMOUR_STEPS_GRAPH"); return e ? atoi(e) : 2; }();  // development switch: 0 = never
+static bool steps_use_graph(const ArmourPlanner* h, int steps) {
+    const int min_steps = h->tune(ARMOUR_OPT_STEPS_GRAPH_MIN);   // (0 = never)
     return min_steps > 0 && steps >= min_steps;
 }
 
 extern "C" int armour_prepare_steps(ArmourPlanner* h, const double* d_k, int32_t steps, double* d_g, double* d_jac) {
     NEED_READY(h);
     if (!d_k || steps < 0) { armour_set_error("bad argument"); return ARMOUR_EINVAL; }
-    if (!steps_use_graph(steps)) return ARMOUR_OK;
+    if (!steps_use_graph(h, steps)) return ARMOUR_OK;
     hipGraphExec_t exec;
     return steps_graph(h, d_k, steps, d_g, d_jac, &exec);
 }
@@ -578,7 +607,7 @@ extern "C" int armour_eval_g_jac_device_steps(ArmourPlanner* h, const double* d_
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // a graph only if armour_prepare_steps built one for exactly these arguments: a caller that slides its pointers
     // from call to call would otherwise pay a capture + instantiate every time
-    if (steps_use_graph(steps))
+    if (steps_use_graph(h, steps))
         for (auto& g : h->step_graphs)
             if (g.d_k == d_k && g.steps == steps && g.d_g == d_g && g.d_jac == d_jac) {
                 g.last_use = ++h->graph_clock;
@@ -617,11 +646,11 @@ extern "C" int armour_eval_g_jac(ArmourPlanner* h, const double* k, double* g, d
     const P2Tables tb = armour_make_tables(h);
     // Buffers from armour_alloc_pinned.  Default (mode 0): the copies below run as true asynchronous DMA transfers (k in, g / jac out)
     // ordered with the launch on the handle's stream -- 2 x 8 m (1 + n) bytes cross PCIe once, in two large transfers.
-    // ARMOUR_PINNED_MODE=1 is the round-2 form: the kernel reads k from and writes g / jac to host memory itself (zero copy).  It
+    // ARMOUR_OPT_PINNED_MODE = 1 is the round-2 form: the kernel reads k from and writes g / jac to host memory itself (zero copy).  It
     // measured 39-43 us per call on some boxes and ~0.9 ms on freshly started ones (BENCH_r02.json, profiles/r03_pinned_probe.txt:
     // every block's k read and every row tile's stores become individual PCIe transactions whose cost depends on how the host
     // mapping is set up), and once did not return at all, so it is no longer chosen by default.  Mode 2: only k is read in place.
-    static const int pinned_mode = [] { const char* e = getenv("ARMOUR_PINNED_MODE"); return e ? atoi(e) : 0; }();
+    const int pinned_mode = h->tune(ARMOUR_OPT_PINNED_MODE);
     const bool all_pinned = in_pinned(k, bn * sizeof(double)) && in_pinned(g, bm * sizeof(double)) && in_pinned(jac, bm * h->n * sizeof(double));
     if (all_pinned && pinned_mode == 1) {
         int rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), k, g, jac, h->stream);
@@ -691,7 +720,35 @@ extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value)
     if (!h) { armour_set_error("null handle"); return ARMOUR_EINVAL; }
     if (option == ARMOUR_OPT_P1_BUILD && (value == 0.0 || value == 1.0 || value == 2.0)) { h->opt_p1_build = (int)value; return ARMOUR_OK; }
     if (option == ARMOUR_OPT_P1_WORK_MEMORY_MB && value >= 0.0 && value <= 1e9) { h->opt_p1_work_mb = value; return ARMOUR_OK; }
+    if (option == ARMOUR_OPT_P1_KEEP_WORK_MEMORY && (value == 0.0 || value == 1.0)) { h->opt_p1_keep_work = (int)value; return ARMOUR_OK; }
+    if (const TuningSpec* t = tuning_spec(option)) {
+        if (value >= t->lo && value <= t->hi && (option == ARMOUR_OPT_SOLVE_HARD_CAP_S || value == (double)(long long)value)) {
+            h->tuning[option - ARMOUR_OPT_FIRST_TUNING] = value;
+            return ARMOUR_OK;
+        }
+    }
     armour_set_error("armour_set_option: unknown option %d or bad value %g", option, value);
+    return ARMOUR_EINVAL;
+}
+
+extern "C" int armour_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); armour_set_error("armour_device_memory: no such device %d", device); return ARMOUR_EDEVICE; }
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_option(ArmourPlanner* h, int32_t option, double* value) {
+    if (!h || !value) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    if (option == ARMOUR_OPT_P1_BUILD) { *value = h->opt_p1_build; return ARMOUR_OK; }
+    if (option == ARMOUR_OPT_P1_WORK_MEMORY_MB) { *value = h->opt_p1_work_mb; return ARMOUR_OK; }
+    if (option == ARMOUR_OPT_P1_KEEP_WORK_MEMORY) { *value = h->opt_p1_keep_work; return ARMOUR_OK; }
+    if (tuning_spec(option)) { *value = h->tuning[option - ARMOUR_OPT_FIRST_TUNING]; return ARMOUR_OK; }
+    armour_set_error("armour_get_option: unknown option %d", option);
     return ARMOUR_EINVAL;
 }
 

@@ -87,6 +87,7 @@ struct P2Tables {
     const double* obs_center;   // [B][3][O] obstacle centres; when non-null P2 computes d = A.c itself instead of reading it (tables built by P1)
     const double* planes_ll;    // [B][J*T][48], see armour_plane_ll_index; used when ll_shared != 0
     int ll_shared;
+    int ex_allowed;  // ARMOUR_OPT_P2_EX of the handle the tables belong to
     int mode;  // ARMOUR_MODE_*: which trajectory the joint-limit rows belong to
     const unsigned long long* plane_skip;  // [B] bit p set: plane p is degenerate or an exact +-duplicate of an earlier plane in EVERY row of the problem
     const double* bez;          // [B][3][n] : q0, Tqd0, TTqdd0  (ARMTD mode: q0, qd0, k_range)
@@ -132,6 +133,11 @@ struct ArmourPlanner {
     bool stats_fresh = false;       // armour_p1_build has read the table statistics back itself (armour_refresh_table_stats has nothing to do)
     int opt_p1_build = 0;           // ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
     double opt_p1_work_mb = 0;      // ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's arena, MiB (0: none)
+    int opt_p1_keep_work = 0;       // ARMOUR_OPT_P1_KEEP_WORK_MEMORY: keep the time-vectorised build's arena between builds
+    // launch-shape options ARMOUR_OPT_FIRST_TUNING .. ARMOUR_OPT_LAST_TUNING (include/armour_hip.h), indexed by option - FIRST; defaults: armour_tuning_defaults
+    double tuning[ARMOUR_OPT_LAST_TUNING - ARMOUR_OPT_FIRST_TUNING + 1];
+    int tune(int option) const { return (int)tuning[option - ARMOUR_OPT_FIRST_TUNING]; }
+    double tune_f(int option) const { return tuning[option - ARMOUR_OPT_FIRST_TUNING]; }
     ArmourViolation* d_viol = nullptr; size_t viol_cap = 0;   // [B] records of armour_eval_violations
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
@@ -178,6 +184,11 @@ struct ArmourPlanner {
     std::vector<StepsGraph> step_graphs;
     unsigned long long graph_clock = 0;
 };
+
+// api.hip: the options' defaults / accepted ranges; the one place that reads the tracing variables of the environment
+void armour_tuning_defaults(double* tuning);
+bool armour_trace_p1();      // ARMOUR_P1_TRACE
+bool armour_trace_solve();   // ARMOUR_SOLVE_TIMING
 
 // p2_eval.hip
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,

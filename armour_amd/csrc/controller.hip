@@ -5,6 +5,7 @@
 // for B states at a time: one thread per state, everything in registers / thread-local memory.  The model preparation
 // (model file -> CoM frames -> interval model, robot_models.cpp:124-255) is host arithmetic done once per call from
 // the ArmourRobot constants; the per-state arithmetic is controller_core.h.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -259,6 +260,13 @@ constexpr size_t kStagedDoubles = (size_t)1 << 20;  // calls up to this many inp
 }  // namespace
 
 // C ABI: see include/armour_hip.h.  Host pointers; B states of n = robot->num_factors joints each, row-major [B][n].
+static std::atomic<int> g_ctl_kernel{-1};
+extern "C" int armour_controller_set_kernel(int32_t which) {
+    if (which < -1 || which > 1) { armour_set_error("armour_controller_set_kernel: -1 (automatic), 0 or 1"); return ARMOUR_EINVAL; }
+    g_ctl_kernel.store(which, std::memory_order_relaxed);
+    return ARMOUR_OK;
+}
+
 extern "C" int armour_robust_controller(const ArmourRobot* robot, double model_uncertainty, const double* Kr, double alpha, double V_max,
                                         double r_norm_threshold, int32_t B, const double* q, const double* qd, const double* q_des,
                                         const double* qd_des, const double* qdd_des, double* u, double* tau, double* v) {
@@ -316,7 +324,7 @@ extern "C" int armour_robust_controller(const ArmourRobot* robot, double model_u
     }
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(double), c.stream));
     // few states: four waves per 16 states (latency); many: one lane per state (throughput) -- bit-identical results
-    static const int split_env = [] { const char* e = getenv("ARMOUR_CTL_SPLIT"); return e ? atoi(e) : -1; }();   // development override: 0 never, 1 always
+    const int split_env = g_ctl_kernel.load(std::memory_order_relaxed);   // armour_controller_set_kernel: -1 automatic, 0 never, 1 always
     const bool split = split_env >= 0 ? split_env != 0 : B <= kSplitMaxStates;
     if (split)
         hipLaunchKernelGGL(armour_controller_split_kernel, dim3((B + kSplitStates - 1) / kSplitStates), dim3(256), 0, c.stream, c.d_args, B, d_in,

@@ -1598,6 +1598,19 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
 // Held for the two calls only -- the kernels of different handles still run concurrently on their own streams.
 static std::mutex g_p1_launch_mu;
 
+// Work slots of the time-vectorised build: ONE arena per device, shared by every handle of the process (round 4).  A build holds the
+// device's arena -- and its mutex -- from before its launch until the kernel has finished (the build is synchronous, and a launch of
+// one block per compute unit leaves no room for another handle's beside it anyway), so two handles that build batches at the same
+// time need the 111.6 MiB per block once, not twice; and a build releases the arena at its end unless its handle asked to keep it
+// (ARMOUR_OPT_P1_KEEP_WORK_MEMORY): a handle between builds holds its tables only.
+struct TvArenaPool {
+    std::mutex mu;
+    unsigned char* ptr = nullptr;
+    size_t bytes = 0;
+};
+constexpr int kMaxPoolDevices = 64;
+TvArenaPool g_tv_pool[kMaxPoolDevices];
+
 struct P1Work {
     unsigned char* arena = nullptr;
     size_t arena_total = 0;
@@ -1607,7 +1620,6 @@ struct P1Work {
     double* d_torque_radius = nullptr; size_t tr_cap = 0;
     double* d_obstacles = nullptr; size_t obs_cap = 0;
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
-    unsigned char* tv_arena = nullptr; size_t tv_arena_total = 0;
     unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1616,6 +1628,11 @@ struct P1Work {
 
 void armour_p1_free(ArmourPlanner* h) {
     P1Work* wk = (P1Work*)h->p1;
+    if (h->opt_p1_keep_work) {   // a handle that kept the device's work slots gives them back with itself
+        TvArenaPool& pool = g_tv_pool[h->device % kMaxPoolDevices];
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (pool.ptr) { (void)hipSetDevice(h->device); (void)hipFree(pool.ptr); pool.ptr = nullptr; pool.bytes = 0; }
+    }
     if (!wk) return;
     if (wk->arena) (void)hipFree(wk->arena);
     if (wk->d_status) (void)hipFree(wk->d_status);
@@ -1624,7 +1641,6 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
     if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
-    if (wk->tv_arena) (void)hipFree(wk->tv_arena);
     if (wk->ev0) (void)hipEventDestroy(wk->ev0);
     if (wk->ev1) (void)hipEventDestroy(wk->ev1);
     delete wk;
@@ -1740,7 +1756,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     auto lds_bytes = [&](int cap, int nw = 1) {
         return (size_t)(nw == 4 ? 3 : nw) * p1_wave_lds(cap, cap) + (nw == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : nw == kRoles ? L3 : L4));
     };
-    static const int max_waves_env = [] { const char* e = getenv("ARMOUR_P1_MAX_WAVES_PER_CU"); return e ? atoi(e) : 4 * P1_WAVES_PER_SIMD; }();  // development override
+    const int max_waves_env = std::min(h->tune(ARMOUR_OPT_P1_MAX_WAVES_PER_CU), 4 * P1_WAVES_PER_SIMD);
     auto waves_per_cu = [&](int cap) { return std::max(1, std::min(max_waves_env, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };
     float total_ms = 0;
     h->build_info[0] = h->build_info[1] = h->build_info[2] = h->build_info[3] = 0;
@@ -1750,11 +1766,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     auto launch = [&](int cap, const int* d_items, int n_items, bool collect) -> int {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
-        static const int nw_env = [] { const char* e = getenv("ARMOUR_P1_WAVES"); return e ? atoi(e) : 0; }();  // development override
+        const int nw_env = h->tune(ARMOUR_OPT_P1_STEP_WAVES);   // (0: automatic)
         // (round 3) ... FOUR waves when the block's LDS holds the fourth wave's small sort buffers as well: the forward kinematics,
         // the omega recursion and the constant cross products of the linear acceleration leave the three recursion waves for a wave
         // of their own (run_rnea_free, the choreography of the time-vectorised kernel's four-wave blocks) and no item is issued twice
-        static const int free_env0 = [] { const char* e = getenv("ARMOUR_P1_FREE"); return e ? atoi(e) : 1; }();
+        const int free_env0 = h->tune(ARMOUR_OPT_P1_STEP_FREE);
         const bool fits4 = free_env0 && lds_bytes(cap, 4) <= (size_t)160 * 1024;
         // Four-wave blocks take an item in 1.17 ms, one per CU at a time; one-wave blocks in 2.7 ms, waves_per_cu of them per CU.  With more
         // items than CUs the blocks loop, and what decides is the number of rounds either shape needs (measured, B problems of 100 steps,
@@ -1776,7 +1792,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (smem > (size_t)160 * 1024) { armour_set_error("raw_terms=%d does not fit the 160 KiB LDS", cap); return ARMOUR_EINVAL; }
         const int per_cu = multi ? 1 : waves_per_cu(cap);
         // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
-        static const int split_env = [] { const char* e = getenv("ARMOUR_P1_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
+        const int split_env = h->tune(ARMOUR_OPT_P1_STEP_SPLIT_FK);   // (-1: automatic)
         const bool split = split_env >= 0 ? (split_env != 0 && multi) : (multi && 2 * n_items <= prop.multiProcessorCount);
         const int fk_items = split ? n_items : 0;
         const int waves = std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
@@ -1791,7 +1807,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
         cf.capW = h->lim.work_monomials; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
         cf.arena_bytes = L.total; cf.arena = wk->arena;
-        static const int free_env = [] { const char* e = getenv("ARMOUR_P1_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
+        const int free_env = h->tune(ARMOUR_OPT_P1_STEP_FREE);   // (0 = a barrier per joint)
         cf.free_running = free_env;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
@@ -1802,7 +1818,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
         cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
         cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
-        static const int aux3_env = [] { const char* e = getenv("ARMOUR_P1_AUX3"); return e ? atoi(e) : 1; }();   // development switch
+        const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
@@ -1835,7 +1851,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
-        if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+        if (armour_trace_p1()) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
         return ARMOUR_OK;
     };
     auto other_errors = [&]() -> int {
@@ -1857,15 +1873,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // operator done once per group.  Batches only: a single problem has two groups, i.e. two waves, and is faster step by step
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
-    static const int tv_env = [] { const char* e = getenv("ARMOUR_P1_TV"); return e ? atoi(e) : -1; }();  // development override: 0 never, 1 always
-    static const int tv_min_groups = [] { const char* e = getenv("ARMOUR_P1_TV_MIN_GROUPS"); return e ? atoi(e) : 36; }();  // below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
+    const int tv_min_groups = h->tune(ARMOUR_OPT_P1_TV_MIN_GROUPS);  // default 36: below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
     const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 30 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
-    // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels; the environment switch is development only)
+    // (ARMOUR_OPT_P1_BUILD, include/armour_hip.h: a handle can be held to one of the two kernels)
     const bool want_tv = h->opt_p1_build == 1 ? false : h->opt_p1_build == 2 ? true
-                         : tv_env >= 0 ? tv_env != 0 : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 5 / 3 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
+                         : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 5 / 3 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
     if (want_tv) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
         const int capTv = h->lim.work_monomials;
@@ -1874,14 +1889,26 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // (b) one wave per group with sort buffers of 4096 entries (the union raw-term counts seen are <= 2.4 k), several waves per
         // CU, the forward kinematics of every group as a work item of its own while slots are free; (c) the same with 8192 entries.
         // A product that overflows the sort buffers sends the launch to the next shape; any other flag to the per-step path.
-        static const int tv_free_env = [] { const char* e = getenv("ARMOUR_P1_TV_FREE"); return e ? atoi(e) : 1; }();  // development switch: 0 = a barrier per joint
-        static const int tv_nw_env = [] { const char* e = getenv("ARMOUR_P1_TV_WAVES"); return e ? atoi(e) : 0; }();  // development override: 1 | 3 | 4
-        static const int tv_split_env = [] { const char* e = getenv("ARMOUR_P1_TV_SPLIT_FK"); return e ? atoi(e) : -1; }();  // development override
-        static const int tv_ded_env = [] { const char* e = getenv("ARMOUR_P1_TV_DEDICATED"); return e ? atoi(e) : 1; }();  // development switch: 0 = no eight-wave blocks
-        static const int tv_shift_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_SHIFT"); return e ? atoi(e) : 0; }();
+        const int tv_free_env = h->tune(ARMOUR_OPT_P1_TV_FREE);          // (0 = a barrier per joint)
+        const int tv_nw_env = h->tune(ARMOUR_OPT_P1_TV_WAVES);            // (0 automatic | 1 | 3 | 4 | 8)
+        const int tv_split_env = h->tune(ARMOUR_OPT_P1_TV_SPLIT_FK);      // (-1 automatic)
+        const int tv_ded_env = h->tune(ARMOUR_OPT_P1_TV_DEDICATED);       // (0 = no eight-wave blocks)
+        const int tv_shift_env = h->tune(ARMOUR_OPT_P1_TV_HELP_SHIFT);
         struct Shape { int nw, cap; };
         // (8: four role waves + four dedicated helper waves, two waves per SIMD -- only in a build whose operators fit 256 registers)
         const Shape shapes[5] = {{8, 4096}, {4, 4096}, {kRoles, 4096}, {1, 4096}, {1, 8192}};
+        TvArenaPool& pool = g_tv_pool[h->device % kMaxPoolDevices];
+        std::unique_lock<std::mutex> pool_lk(pool.mu);   // held until the last launch of this build has finished
+        // Released at the end of the build unless this handle keeps it -- on every way out: success, an error return, and when the build falls
+        // through to the per-step kernel (a cap below one block, a capacity flag): nothing of the time-vectorised build outlives it then.
+        struct PoolRelease {
+            TvArenaPool& p; bool keep;
+            ~PoolRelease() { if (p.ptr && !keep) { (void)hipFree(p.ptr); p.ptr = nullptr; p.bytes = 0; } }
+        } pool_release{pool, h->opt_p1_keep_work != 0};
+        if (pool.ptr && h->opt_p1_work_mb > 0 && pool.bytes > (size_t)(h->opt_p1_work_mb * 1048576.0)) {   // a kept arena larger than this handle's cap: give it back first
+            (void)hipFree(pool.ptr);
+            pool.ptr = nullptr; pool.bytes = 0;
+        }
         for (int si = 0; si < 5 && !built; si++) {
             const int nw_launch = shapes[si].nw, cap = shapes[si].cap;
             if (nw_launch == 8 && (!kTvDedicatedHelpers || !tv_ded_env || !tv_free_env)) continue;
@@ -1913,21 +1940,17 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                 if (max_blocks < 1.0) continue;   // (not even one block of this shape: the next shape, in the end the per-step kernel)
                 blocks = (int)std::min((double)blocks, max_blocks);
             }
-            if (wk->tv_arena && h->opt_p1_work_mb > 0 && wk->tv_arena_total > (size_t)(h->opt_p1_work_mb * 1048576.0)) {   // the cap was lowered: give the surplus back
-                (void)hipFree(wk->tv_arena);
-                wk->tv_arena = nullptr; wk->tv_arena_total = 0;
-            }
-            if ((size_t)blocks * TL.total > wk->tv_arena_total) {
-                if (wk->tv_arena) (void)hipFree(wk->tv_arena);
-                wk->tv_arena = nullptr; wk->tv_arena_total = 0;
-                if (hipMalloc((void**)&wk->tv_arena, (size_t)blocks * TL.total) != hipSuccess) { (void)hipGetLastError(); break; }
-                wk->tv_arena_total = (size_t)blocks * TL.total;
+            if ((size_t)blocks * TL.total > pool.bytes) {
+                if (pool.ptr) (void)hipFree(pool.ptr);
+                pool.ptr = nullptr; pool.bytes = 0;
+                if (hipMalloc((void**)&pool.ptr, (size_t)blocks * TL.total) != hipSuccess) { (void)hipGetLastError(); pool.ptr = nullptr; break; }
+                pool.bytes = (size_t)blocks * TL.total;
             }
             P1Cfg cf;
             memset(&cf, 0, sizeof(cf));
             cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
             cf.capW = capTv; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
-            cf.arena_bytes = TL.total; cf.arena = wk->tv_arena;
+            cf.arena_bytes = TL.total; cf.arena = pool.ptr;
             cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
             cf.bez = h->d_bez;
             cf.mode = h->mode; cf.jrs = h->d_jrs;
@@ -1937,12 +1960,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
-            static const int tv_help_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELPERS"); return e ? atoi(e) : 1; }();  // development switch: 0 = every walk on its own wave
+            const int tv_help_env = h->tune(ARMOUR_OPT_P1_TV_HELPERS);   // (0 = every walk on its own wave)
             cf.tv_walk_helpers = tv_help_env;
-            static const int tv_help_min_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_MIN"); return e ? atoi(e) : 192; }();
-            static const int tv_help_n_env = [] { const char* e = getenv("ARMOUR_P1_TV_HELP_N"); return e ? atoi(e) : 1; }();
+            const int tv_help_min_env = h->tune(ARMOUR_OPT_P1_TV_HELP_MIN);
+            const int tv_help_n_env = h->tune(ARMOUR_OPT_P1_TV_HELP_N);
             cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env; cf.tv_help_shift = tv_shift_env;
-            static const int tv_aux3_env = [] { const char* e = getenv("ARMOUR_P1_TV_AUX3"); return e ? atoi(e) : 1; }();   // development switch
+            const int tv_aux3_env = h->tune(ARMOUR_OPT_P1_TV_AUX3);
             cf.tv_aux_on_fk_wave = tv_aux3_env;
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
@@ -1967,16 +1990,17 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
             h->build_info[0] = ARMOUR_P1_KERNEL_TIME_VECTORISED; h->build_info[1] = nw_launch; h->build_info[2] = cap; h->build_info[3]++;
-            if (getenv("ARMOUR_P1_TRACE")) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }
+        // (pool_release, at the end of this scope: every launch above has been waited for)
     }
     const int kFirstPassCap = 2048;
     const int* d_items = nullptr;
     int n_items = built ? 0 : B * T;
     // (the second pass costs at least one item's latency, ~4 ms: worth it from about 16 items per CU)
-    static const int two_pass_env = [] { const char* e = getenv("ARMOUR_P1_TWO_PASS"); return e ? atoi(e) : 1; }();  // development switch
+    const int two_pass_env = h->tune(ARMOUR_OPT_P1_TWO_PASS);
     if (!built && two_pass_env && cap_raw > kFirstPassCap && waves_per_cu(kFirstPassCap) > waves_per_cu(cap_raw) && B * T >= 16 * prop.multiProcessorCount) {
         if ((rc = launch(kFirstPassCap, nullptr, B * T, true)) != ARMOUR_OK) return rc;
         if ((rc = other_errors()) != ARMOUR_OK) return rc;
@@ -2010,9 +2034,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         unsigned long long* d_pre_part = wk->d_skip_part + part_words;
         unsigned long long* d_pre = d_pre_part + pre_words;
         unsigned long long* d_live = d_pre + B;
-        // The table holds what the fused evaluation reads and nothing else (planes_of_group): ARMOUR_P1_FULL_PLANES=1 (development) builds
+        // The table holds what the fused evaluation reads and nothing else (planes_of_group): ARMOUR_OPT_P1_FULL_PLANES = 1 builds
         // the full one.  d = A.c is stored for the small launches that read it; batches of >= 8 problems or >= 32 768 rows recompute it (armour_make_tables).
-        static const int full_env = [] { const char* e = getenv("ARMOUR_P1_FULL_PLANES"); return e ? atoi(e) : 0; }();
+        const int full_env = h->tune(ARMOUR_OPT_P1_FULL_PLANES);
         const bool lean = !full_env;
         // (round 4, one box, interleaved: configs[4] -- one problem, 90 000 rows, a 60 MB table -- 13.1 us with d recomputed against 15.8 stored;
         //  configs[1] -- 14 000 rows, L2-resident -- 5.05 against 5.02: the launch that streams its table from beyond L2 wants the fewer bytes)
@@ -2069,7 +2093,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         h->sum_link = sl; h->sum_torque = st2; h->max_link = ml; h->max_torque = mt;
         h->h_plane_skip.assign((size_t)B, 0ull);
         if (O > 0) memcpy(h->h_plane_skip.data(), rb + off_ps, (size_t)B * sizeof(unsigned long long));
-        h->stats_fresh = !getenv("ARMOUR_P1_TRACE");   // (the trace line of armour_refresh_table_stats wants its own pass)
+        h->stats_fresh = !armour_trace_p1();   // (the trace line of armour_refresh_table_stats wants its own pass)
     } else {
         HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, n_lg * sizeof(double), hipMemcpyDeviceToHost));

@@ -119,9 +119,8 @@ int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsig
     // every problem of the launch has at most 24 live planes (6 per wave): use the 6-slot kernels
     bool six = h_skip != nullptr;
     for (int b = 0; six && b < tb.B; b++) six = __builtin_popcountll(~h_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull)) <= 24;
-    // ... exactly 24 (6 per wave) and the blocks slice in one pass: the EX kernels (development switch ARMOUR_P2_EX=0 turns them off)
-    static const bool ex_on = [] { const char* e = getenv("ARMOUR_P2_EX"); return !e || atoi(e) != 0; }();
-    bool exact = six && ex_on && lp.max_pairs <= lp.pair_chunk;
+    // ... exactly 24 (6 per wave) and the blocks slice in one pass: the EX kernels (ARMOUR_OPT_P2_EX = 0 turns them off)
+    bool exact = six && tb.ex_allowed && lp.max_pairs <= lp.pair_chunk;
     for (int b = 0; exact && b < tb.B; b++) exact = armour_p2_ex_layout_ok(h_skip[b]);
     *lp_out = lp; *smem_out = smem; *dfc_out = dfc; *six_out = six; *exact_out = exact;
     return ARMOUR_OK;

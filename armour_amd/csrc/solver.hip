@@ -317,7 +317,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     const int B = h->B, n = h->n, m = h->m;
     const P2Tables tb = armour_make_tables(h);
     SolvePlan plan;
-    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, &plan);
+    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan);
     if (rc != ARMOUR_OK) return rc;
     if (plan.capacity < 1) return 0;
     // A block walks its tiles one after the other (~4 us each), so what a phase costs is the tiles PER BLOCK, and the co-resident
@@ -326,23 +326,21 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     // form's 30).  Now such a batch is cut into SUB-BATCHES launched back to back on the handle's stream -- each a persistent
     // cooperative launch of its own over problems [b0, b0 + Bs) of the same tables, with enough blocks per problem for about
     // `sub_tiles` tiles per block; iterates and results do not depend on the cut (a problem's blocks see only that problem).
-    static const int sub_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_SUB_TILES"); return e ? std::max(1, atoi(e)) : 48; }();   // tiles per block aimed at (swept on B = 64 ... 256, O = 20 ... 50: profiles/r03_solve_subtiles.txt)
-    static const int force_dev = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
+    const int sub_tiles = std::max(1, h->tune(ARMOUR_OPT_SOLVE_SUB_TILES));   // default 48: tiles per block aimed at (swept on B = 64 ... 256, O = 20 ... 50: profiles/r03_solve_subtiles.txt)
     // When to cut (profiles/r03_solve_subtiles.txt, swept with candidate buffers large enough never to overflow): one launch is best or within
     // 3 % up to ~154 tiles per block (B = 128 at O = 20 / 30 / 40: 10.2 / 15.0 / 13.3 ms; B = 256 at O = 20: 19.7 against 24.9 cut); at 159
     // (B = 128, O = 50) the cut wins, 14.3 against 18.7 ms.  The threshold sits between those two measurements.
-    static const int cut_tiles = [] { const char* e = getenv("ARMOUR_SOLVE_CUT_TILES"); return e ? std::max(1, atoi(e)) : 156; }();
+    const int cut_tiles = std::max(1, h->tune(ARMOUR_OPT_SOLVE_CUT_TILES));   // default 156
     int Bs = B;
     if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > cut_tiles) {
         const int nb_want = std::min(plan.n_tiles, (plan.n_tiles + sub_tiles - 1) / sub_tiles);
         Bs = std::max(1, std::min(B, plan.capacity / std::max(1, nb_want)));
-        if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, &plan)) != ARMOUR_OK) return rc;
+        if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan)) != ARMOUR_OK) return rc;
         Bs = std::max(1, std::min(Bs, plan.capacity));
     }
-    (void)force_dev;
     int nb = std::min(std::min(plan.n_tiles, plan.capacity / Bs), 1024);
-    if (const char* e = getenv("ARMOUR_SOLVE_BLOCKS")) nb = std::max(1, std::min(nb, atoi(e)));  // development / tests
-    if (const char* e = getenv("ARMOUR_SOLVE_SUB_BATCH")) Bs = std::max(1, std::min(Bs, atoi(e)));  // development / tests: force the cut
+    if (h->tune(ARMOUR_OPT_SOLVE_BLOCKS) > 0) nb = std::max(1, std::min(nb, h->tune(ARMOUR_OPT_SOLVE_BLOCKS)));          // tuning / tests
+    if (h->tune(ARMOUR_OPT_SOLVE_SUB_BATCH) > 0) Bs = std::max(1, std::min(Bs, h->tune(ARMOUR_OPT_SOLVE_SUB_BATCH)));    // tuning / tests: force the cut
     const int n_launch = (B + Bs - 1) / Bs;
     if ((rc = armour_upload_bounds(h)) != ARMOUR_OK) return rc;
     // rows a block owns: at most ceil(n_tiles / nb) tiles of <= 64 rows, two candidates per row
@@ -351,7 +349,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     //  block overflowed 1024 rows per block on two of four world seeds -- 25 ms instead of 10; the buffers are 72 B per row)
     int cap_blk = std::min(2 * tiles_per_block * 64, 4096);
     int cap_rows = std::min(2 * m, 16384);
-    if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) { cap_blk = std::max(1, std::min(cap_blk, atoi(e))); }  // tests: force the overflow fallback
+    if (h->tune(ARMOUR_OPT_SOLVE_ROW_CAP) > 0) cap_blk = std::max(1, std::min(cap_blk, h->tune(ARMOUR_OPT_SOLVE_ROW_CAP)));  // tests: force the overflow fallback
     SolveDeviceWork& w = h->solve_dev;
     // everything the host hands the kernel sits in ONE device block, filled by ONE copy from its page-locked mirror: the per-problem
     // control words, the goals, the argument block (three copies and a fill ahead of the launch cost ~10 us of a 150 us solve)
@@ -398,11 +396,11 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         a.budget_ticks = left_ms > 0 ? (long long)(left_ms * plan.ticks_per_ms) : 0;
     }
     // no wait of the persistent kernel outlasts the budget by more than a second (10 s without a budget: 60 iterations of a large batch
-    // stay far below); the host's own poll gives up a little later.  ARMOUR_SOLVE_HARD_CAP_S: development / tests.
-    static const double hard_cap_s = [] { const char* e = getenv("ARMOUR_SOLVE_HARD_CAP_S"); return e ? atof(e) : 0.0; }();
+    // stay far below); the host's own poll gives up a little later.  ARMOUR_OPT_SOLVE_HARD_CAP_S: tuning / tests.
+    const double hard_cap_s = h->tune_f(ARMOUR_OPT_SOLVE_HARD_CAP_S);
     const double hard_s = hard_cap_s > 0 ? hard_cap_s : (a.budget_ticks >= 0 ? a.budget_ticks / plan.ticks_per_ms * 1e-3 + 1.0 : 10.0);
     a.hard_ticks = std::max<long long>(1, (long long)(hard_s * 1e3 * plan.ticks_per_ms));
-    const bool timing = getenv("ARMOUR_SOLVE_TIMING") != nullptr;
+    const bool timing = armour_trace_solve();
     long long* hstamps = timing ? reinterpret_cast<long long*>(armour_handle_pinned(h, 0, (size_t)B * 64 * sizeof(long long) + (size_t)B * n * sizeof(double))) : nullptr;
     if (hstamps) memset(hstamps, 0, (size_t)B * 64 * sizeof(long long));
     a.stamps = hstamps;
@@ -450,11 +448,11 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const int B = h->B, n = h->n, m = h->m;
     {
         // The device-resident form for batches, the host-driven form below for up to four problems (force_host_qp: > 0 host form, < 0 device form
-        // whatever the batch; ARMOUR_SOLVE_DEVICE=0|2: never / always the device form -- development).  Both produce the same iterates.  Why four:
+        // whatever the batch; ARMOUR_OPT_SOLVE_DEVICE = 0: never the device form).  Both produce the same iterates.  Why four:
         // the leader wavefront takes 6 us per QP step where a host core takes 0.3, and problems that end infeasible take hundreds of steps; on
         // random worlds (O = 20) the host form is faster in 36 of 36 batches of 1-3 problems (0.22 against 0.44 ms for one), even at 4, and the
         // persistent kernel in 33 of 36 from 6 on (profiles/r03_solve_small_batches.txt).  It also remains the fallback.
-        static const int dev_env = [] { const char* e = getenv("ARMOUR_SOLVE_DEVICE"); return e ? atoi(e) : 1; }();
+        const int dev_env = h->tune(ARMOUR_OPT_SOLVE_DEVICE);
         constexpr int kDeviceFormMinBatch = 5;
         const bool want_device = opt.force_host_qp > 0.0 ? false : opt.force_host_qp < 0.0 ? true : dev_env == 0 ? false : dev_env >= 2 ? true : B >= kDeviceFormMinBatch;
         if (want_device) {
@@ -486,7 +484,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const int nseg = (m + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
     // rows a segment may hand back (its slice of the page-locked buffer): everything if the batch is small
     int cap_rows = (int)std::max<size_t>(64, std::min<size_t>(2 * kScanRowsPerBlock, ((size_t)128 << 20) / ((size_t)B * nseg * sizeof(SolveRow))));
-    if (const char* e = getenv("ARMOUR_SOLVE_ROW_CAP")) cap_rows = std::max(1, atoi(e));  // development / tests: force the overflow fallback
+    if (h->tune(ARMOUR_OPT_SOLVE_ROW_CAP) > 0) cap_rows = std::max(1, h->tune(ARMOUR_OPT_SOLVE_ROW_CAP));  // tests: force the overflow fallback
     long long* hviol_seg = reinterpret_cast<long long*>(armour_handle_pinned(h, 3, (size_t)B * nseg * sizeof(long long)));
     int* hcount = reinterpret_cast<int*>(armour_handle_pinned(h, 4, (size_t)B * nseg * sizeof(int)));
     SolveRow* hrows = reinterpret_cast<SolveRow*>(armour_handle_pinned(h, 5, (size_t)B * nseg * cap_rows * sizeof(SolveRow)));
@@ -702,7 +700,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
         feas[b] = bad == 0 ? 1 : 0;
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (getenv("ARMOUR_SOLVE_TIMING")) fprintf(stderr, "[armour_solve] B=%d total %.3f ms: evaluations+scan %.3f ms, QP %.3f ms, rows of problem 0, segment 0: %d (cap %d, %d segments)\n", B, ms, t_eval, t_qp, hcount[0], cap_rows, nseg);
+    if (armour_trace_solve()) fprintf(stderr, "[armour_solve] B=%d total %.3f ms: evaluations+scan %.3f ms, QP %.3f ms, rows of problem 0, segment 0: %d (cap %d, %d segments)\n", B, ms, t_eval, t_qp, hcount[0], cap_rows, nseg);
     for (int b = 0; b < B; b++) {
         ArmourSolveResult& r = results[b];
         memset(&r, 0, sizeof(r));

@@ -59,6 +59,6 @@ struct SolvePlan {
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, p2::P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out);
 // b_launch: problems per launch the occupancy choice is made for (the whole batch, or a sub-batch of it)
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, SolvePlan* plan);
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan);
 // d_args: the SolveArgs in device memory (the kernel reads them through the pointer)
 int armour_solve_device_launch(const SolveArgs* d_args, int nb, const SolvePlan& plan, int B, hipStream_t stream);

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host side
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, SolvePlan* plan) {
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan) {
     P2Launch lp;
     size_t smem = 0;
     bool dfc, six, exact;
@@ -868,7 +868,7 @@ int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torqu
     // one block per CU (the 512-register build) while that still leaves a block at most 24 tiles to walk; otherwise two per CU
     const void* fn1 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 1> : six ? (const void*)armour_solve_kernel<true, 6, 1> : (const void*)armour_solve_kernel<true, 9, 1>;
     const void* fn2 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 2> : six ? (const void*)armour_solve_kernel<true, 6, 2> : (const void*)armour_solve_kernel<true, 9, 2>;
-    static const int wps_env = [] { const char* e = getenv("ARMOUR_SOLVE_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();  // development override
+    const int wps_env = waves_per_simd;   // ARMOUR_OPT_SOLVE_WAVES_PER_SIMD (0: automatic)
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn1, P2_BLOCK, smem));
     const int cap1 = per_cu * prop.multiProcessorCount;

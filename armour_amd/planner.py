@@ -187,6 +187,14 @@ class ArmourBatchNLP:
         check(self.L.armour_batch_get_build_ms(self.h, C.byref(v), per))
         return v.value
 
+    def build_info(self):
+        """armour_batch_get_build_info: per slot, as ArmourNLP.build_info() (None for a slot without problems)."""
+        out = (C.c_int32 * (4 * len(self.devices)))()
+        check(self.L.armour_batch_get_build_info(self.h, out))
+        kn = {0: None, 1: "per_step", 2: "time_vectorised"}
+        return [None if out[4 * d] == 0 else {"kernel": kn[out[4 * d]], "waves": out[4 * d + 1], "sort_entries": out[4 * d + 2], "launches": out[4 * d + 3]}
+                for d in range(len(self.devices))]
+
 
 class ArmourNLP:
     """B independent planning problems on one MI355X (B = 1 is the reference's use)."""

@@ -90,13 +90,68 @@ void armour_free_pinned(void* p);
  * and independent of the batch mates and of the batch size.  A caller that needs bit-identical tables for the same problem across
  * batch sizes (or across the ranks of a sharded batch, whose shard sizes differ) sets option 1 (or 2) on every handle. */
 #define ARMOUR_OPT_P1_BUILD 1
-/* ARMOUR_OPT_P1_WORK_MEMORY_MB caps the device memory the time-vectorised build keeps for its work slots, in MiB (0 = no cap, the
- * default: one block of ~112 MiB per compute unit while the batch has that many groups of time steps, 28.6 GiB on a 256-CU device,
- * held until armour_destroy).  With a cap the build runs on fewer blocks, which loop over the groups -- same tables bit for bit, the
- * build time grows with the rounds (a batch of 128 problems on half the blocks: about twice) -- so that several handles, or other
- * tenants of the device, fit beside it.  A cap below one block's slots sends batches to the step-by-step kernel (a few GiB at most). */
+/* ARMOUR_OPT_P1_WORK_MEMORY_MB caps the device memory the time-vectorised build takes for its work slots, in MiB (0 = no cap, the
+ * default: one block of ~112 MiB per compute unit while the batch has that many groups of time steps, 28.6 GiB for a batch of 128
+ * problems on a 256-CU device).  With a cap the build runs on fewer blocks, which loop over the groups -- same tables bit for bit,
+ * the build time grows with the rounds (a batch of 128 problems on half the blocks: about twice).  A cap below one block's slots
+ * sends batches to the step-by-step kernel (a few GiB at most).
+ * The work slots are ONE arena per device, shared by all handles of the process and held by a build only while it runs: two handles
+ * building batches at the same time take turns on it (the kernel fills the device anyway), so they need it once, not twice. */
 #define ARMOUR_OPT_P1_WORK_MEMORY_MB 2
+/* ARMOUR_OPT_P1_KEEP_WORK_MEMORY (0 | 1, default 0): 0 releases the device's work slots at the end of every armour_set_problems* of
+ * this handle -- between builds a handle holds its tables only; 1 leaves them allocated for the next build on that device (of any
+ * handle) and until this handle is destroyed: a caller that rebuilds large batches every planning cycle saves the allocation
+ * (measured: DESIGN.md 4.2b). */
+#define ARMOUR_OPT_P1_KEEP_WORK_MEMORY 3
+
+/* ---- launch-shape options (round 4: these were environment variables read once per process; two handles of one process can now
+ * differ, and no stray variable changes a result).  Every one of them selects HOW the same operator sequence is laid out on the
+ * device, never which operators run on which operands.  TOLERANCE CONTRACT of the whole group: monomial keys, coefficients and
+ * centres of every table are bit-identical for every value; options marked (r) may change the ORDER in which pruned amounts are
+ * added into the independent radii (<= 1e-12 on every table and output, as ARMOUR_OPT_P1_BUILD above); unmarked options leave
+ * every bit alone.  Defaults are what bench.py and the tests measure; the values are tuning / test knobs. */
+/* per-step reach-set kernel (p1_reach.hip: armour_p1_chain_kernel) */
+#define ARMOUR_OPT_P1_STEP_WAVES 101          /* 0 automatic (default) | 1 | 3 | 4 wavefronts per (problem, time step) block */
+#define ARMOUR_OPT_P1_STEP_FREE 102           /* 1 (default) free-running role waves | 0 a block barrier per joint */
+#define ARMOUR_OPT_P1_STEP_SPLIT_FK 103       /* -1 automatic (default) | 0 | 1: forward kinematics as work items of their own */
+#define ARMOUR_OPT_P1_STEP_AUX3 104           /* 1 (default) | 0: the w_aux recursion on the fourth wave of four-wave blocks */
+#define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..4 (default 4): one-wave blocks resident per compute unit */
+#define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
+/* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
+#define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 36: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
+#define ARMOUR_OPT_P1_TV_WAVES 111            /* 0 automatic (default) | 1 | 3 | 4 | 8 wavefronts per block (r: 4 and 8 share walks between waves) */
+#define ARMOUR_OPT_P1_TV_FREE 112             /* 1 (default) | 0: free-running role waves | a block barrier per joint */
+#define ARMOUR_OPT_P1_TV_SPLIT_FK 113         /* -1 automatic (default) | 0 | 1 */
+#define ARMOUR_OPT_P1_TV_DEDICATED 114        /* 1 (default) | 0: eight-wave blocks may be chosen (development builds with two waves per SIMD only) */
+#define ARMOUR_OPT_P1_TV_HELP_SHIFT 115       /* 0..3 (default 0): which helper wave serves which role wave in eight-wave blocks */
+#define ARMOUR_OPT_P1_TV_HELPERS 116          /* (r) 0 every walk on its own wave | 1 (default) shared walks, the owner keeps 16/32 | 2..31: it keeps value/32 */
+#define ARMOUR_OPT_P1_TV_HELP_MIN 117         /* (r) default 192: walks with fewer sorted terms stay on one wave */
+#define ARMOUR_OPT_P1_TV_HELP_N 118           /* (r) 1 (default) | 0: the n-recursion shares its walks as well */
+#define ARMOUR_OPT_P1_TV_AUX3 119             /* 1 (default) | 0: as ARMOUR_OPT_P1_STEP_AUX3 */
+#define ARMOUR_OPT_P1_FULL_PLANES 120         /* 0 (default) the lean half-space table | 1 every plane and component resident (armour_get_hyperplanes builds it on demand otherwise) */
+/* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
+#define ARMOUR_OPT_P2_EX 130                  /* 1 (default) | 0: the fixed-load-count kernels for problems with exactly 24 live planes */
+#define ARMOUR_OPT_STEPS_GRAPH_MIN 131        /* default 2: armour_eval_g_jac_device_steps submits >= this many steps as one graph; 0 never */
+#define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
+/* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
+#define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */
+#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default) | 0: the device-resident form may be chosen */
+#define ARMOUR_OPT_SOLVE_CUT_TILES 142        /* default 156: a batch whose blocks would walk more tiles each is cut */
+#define ARMOUR_OPT_SOLVE_BLOCKS 143           /* 0 (default: as many as fit) | n: at most n blocks per problem */
+#define ARMOUR_OPT_SOLVE_SUB_BATCH 144        /* 0 (default: by tiles) | n: sub-batches of at most n problems */
+#define ARMOUR_OPT_SOLVE_ROW_CAP 145          /* 0 (default) | n: candidate-row buffers of n rows (tests: forces the overflow path) */
+#define ARMOUR_OPT_SOLVE_HARD_CAP_S 146       /* 0 (default: from the time budget / iteration limit) | seconds: wall-clock cap of one persistent launch */
+#define ARMOUR_OPT_SOLVE_WAVES_PER_SIMD 147   /* 0 automatic (default) | 1 | 2: register build of the persistent kernel */
+#define ARMOUR_OPT_FIRST_TUNING 101
+#define ARMOUR_OPT_LAST_TUNING 147
+/* bytes of device memory free / in all on `device` as the runtime reports them (hipMemGetInfo): what a caller sizes
+ * ARMOUR_OPT_P1_WORK_MEMORY_MB against; either pointer may be NULL */
+int armour_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
 int armour_set_option(ArmourPlanner* h, int32_t option, double value);
+/* armour_get_option: the current value of an option of this handle (status ARMOUR_EINVAL for an unknown option) */
+int armour_get_option(ArmourPlanner* h, int32_t option, double* value);
+/* Environment variables the library still reads (none of them changes a result): ARMOUR_P1_TRACE, ARMOUR_SOLVE_TIMING (one line of
+ * timings per call on stderr), ARMOUR_WORKER_PARENT (armour_worker: exit with the parent process). */
 
 /* ---- P1: reach-set build, once per planning iteration ---- */
 /* Replaces RT/armour_main.cu:36-216 (parse armour.in, JRS, FK, RNEA x2, torque radius, half-space tables)
@@ -201,6 +256,9 @@ int armour_batch_eval_violations(ArmourBatch* bt, const double* k, ArmourViolati
 /* declared after ArmourSolveOptions below: armour_batch_solve */
 /* ms of the slowest slot's last reach-set build (device time); per_slot may be NULL or [n_slots] */
 int armour_batch_get_build_ms(ArmourBatch* bt, double* max_ms, double* per_slot);
+/* armour_get_build_info of every slot: info[4 * slot + 0..3] (zeros for a slot without problems).  All slots of a problem set are built
+ * by ONE kernel: with ARMOUR_OPT_P1_BUILD left automatic the one the smallest shard would take. */
+int armour_batch_get_build_info(ArmourBatch* bt, int32_t* info /* [n_slots][4] */);
 
 /* ---- caller side of the path: the trajectory the planner hands to the controller ---- */
 /* uarmtd_planner.desired_trajectory, traj_type 'bernstein' (KSI/uarmtd_planner.m:846-925, with
@@ -223,6 +281,10 @@ int armour_desired_trajectory(int32_t n, const double* q0, const double* qd0, co
 int armour_robust_controller(const ArmourRobot* robot, double model_uncertainty, const double* Kr, double alpha, double V_max,
                              double r_norm_threshold, int32_t B, const double* q, const double* qd, const double* q_des,
                              const double* qd_des, const double* qdd_des, double* u, double* tau, double* v);
+/* Which of the controller's two kernels a call uses (the entry has no handle, so this is per process; bit-identical results
+ * either way, tests/test_controller.py): -1 (default) the four-wave latency kernel up to 4096 states and one lane per state
+ * beyond, 0 always one lane per state, 1 always the latency kernel. */
+int armour_controller_set_kernel(int32_t which);
 
 /* ---- NLP solve of the planning iteration ---- */
 /* Replaces IpoptApplication::OptimizeTNLP + armtd_NLP::finalize_solution (RT/armour_main.cu:237-304,

@@ -106,3 +106,24 @@ def test_latency_and_throughput_kernels_agree_bit_for_bit():
         for a, b in zip(few, bulk):
             assert np.array_equal(np.asarray(a).reshape(hi - lo, 7), b[lo:hi])
     assert not bulk[2][70].any()
+
+
+@pytest.mark.gpu
+def test_controller_kernel_choice_is_an_api_call_and_changes_no_bit():
+    """armour_controller_set_kernel (round 4: it was the environment variable ARMOUR_CTL_SPLIT): the same 300 states through the one-lane-per-state
+    kernel (0), the four-wave latency kernel (1) and the automatic choice (-1) -- identical outputs; values outside -1..1 are refused."""
+    from armour_amd import _lib
+    from armour_amd.controller import kinova_controller
+    L = _lib.load()
+    q, qd, q_des, qd_des, qdd_des = _states(23, 300)
+    got = []
+    try:
+        for which in (0, 1, -1):
+            _lib.check(L.armour_controller_set_kernel(which))
+            got.append(kinova_controller(KR, ALPHA, V_MAX, R_THR, q, qd, q_des, qd_des, qdd_des, eps=0.03))
+        assert L.armour_controller_set_kernel(2) < 0
+    finally:
+        L.armour_controller_set_kernel(-1)
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert np.array_equal(a, b)

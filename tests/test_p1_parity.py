@@ -303,13 +303,20 @@ def test_more_work_items_than_resident_waves():
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
 
 
-def _two_pass_build_body():
+def test_two_pass_build_of_large_batches():
+    """The per-step kernel, from 16 items per CU on, first runs every (problem, time step) item with 2048-entry sort buffers
+    (four waves per CU) and rebuilds only the items that overflowed them with the full buffers: the tables must equal those
+    of single-problem handles (one pass, full buffers) bit for bit, including for a fast initial state whose products are
+    the ones that overflow.  A batch of this size is built time-vectorised by default (pz_tv.h): the batch's handle is held to
+    the per-step kernel by ARMOUR_OPT_P1_BUILD = 1 (round 4: a handle option; an environment switch read once per process before)."""
+    from armour_amd import _lib
     from armour_amd.planner import ArmourNLP
     from armour_amd.worlds import random_batch, random_k
     T, O, B = 100, 1, 42
     bp = random_batch(500, B, O)
     bp["qd0"][5] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])   # fast start: the largest PZs
-    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    nlp = ArmourNLP(T=T).set_option(_lib.OPT_P1_BUILD, 1).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    assert nlp.build_info()["kernel"] == "per_step" and nlp.build_info()["launches"] >= 2
     ks = random_k(9, B)
     g, jac = nlp.eval_g_jac(ks)
     for b in (0, 5, 23, 41):
@@ -318,19 +325,8 @@ def _two_pass_build_body():
         assert np.array_equal(g[b], g1[0]) and np.array_equal(jac[b], j1[0])
         assert np.array_equal(nlp.torque_radius()[b], one.torque_radius()[0])
         assert np.array_equal(nlp.link_generators()[b], one.link_generators()[0])
-
-
-def test_two_pass_build_of_large_batches():
-    """The per-step kernel, from 16 items per CU on, first runs every (problem, time step) item with 2048-entry sort buffers
-    (four waves per CU) and rebuilds only the items that overflowed them with the full buffers: the tables must equal those
-    of single-problem handles (one pass, full buffers) bit for bit, including for a fast initial state whose products are
-    the ones that overflow.  A batch of this size is built time-vectorised by default (pz_tv.h), so the check runs in a
-    process of its own with ARMOUR_P1_TV=0 (the switch is read once per process)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._two_pass_build_body(); print('two-pass ok')" % (root, os.path.join(root, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ARMOUR_P1_TV="0"), cwd=root, capture_output=True, text=True, timeout=280)
-    assert r.returncode == 0 and "two-pass ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        one.close()
+    nlp.close()
 
 
 def test_batch_built_time_vectorised_against_single_problem_handles():
@@ -480,16 +476,19 @@ def test_builds_are_reproducible_from_launch_to_launch(B, O):
             assert np.array_equal(a, b)
 
 
-def _tables_digest_body(B, dump=None):
-    """Prints a digest of everything a reach-set build leaves behind (run in a process of its own: the launch-shape switches
-    are read once per process).  dump: also save the arrays to this .npz (exact part and radii separately)."""
+def _tables_digest(B, options):
+    """Digest of everything a reach-set build leaves behind, for a handle with the given launch-shape options
+    ({option id: value}); returns (sha256 hex, exact arrays, radii arrays)."""
     import hashlib
     from armour_amd.planner import ArmourNLP
     from armour_amd.worlds import random_batch, random_k
     T, O = 100, 3
     bp = random_batch(900, B, O)
     bp["qd0"][B - 1] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
-    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    nlp = ArmourNLP(T=T)
+    for opt, val in options.items():
+        nlp.set_option(opt, val)
+    nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
     h = hashlib.sha256()
     g, jac = nlp.eval_g_jac(random_k(4, B))
     for a in (g, jac, nlp.torque_radius(), nlp.link_generators()):
@@ -504,55 +503,80 @@ def _tables_digest_body(B, dump=None):
                         h.update(np.ascontiguousarray(a).tobytes())
                     exact += [cen.ravel(), keys.astype(np.float64).ravel(), co.ravel()]
                     radii.append(ind.ravel())
-    print("digest", h.hexdigest())
-    if dump:
-        np.savez(dump, exact=np.concatenate(exact), radii=np.concatenate(radii))
+    info = nlp.build_info()
+    nlp.close()
+    return h.hexdigest(), np.concatenate(exact), np.concatenate(radii), info
+
+
+def _shape(**kw):
+    """{ARMOUR_OPT_* id: value} from short names: build, step_waves, step_free, step_split_fk, tv_waves, tv_free, tv_helpers."""
+    from armour_amd import _lib
+    names = {"build": _lib.OPT_P1_BUILD, "step_waves": _lib.OPT_P1_STEP_WAVES, "step_free": _lib.OPT_P1_STEP_FREE, "step_split_fk": _lib.OPT_P1_STEP_SPLIT_FK,
+             "tv_waves": _lib.OPT_P1_TV_WAVES, "tv_free": _lib.OPT_P1_TV_FREE, "tv_helpers": _lib.OPT_P1_TV_HELPERS}
+    return {names[k]: v for k, v in kw.items()}
 
 
 @pytest.mark.parametrize("B,settings", [
-    (1, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1"),
-         dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1", ARMOUR_P1_SPLIT_FK="0")]),
-    (2, [dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="1"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_FREE="0"), dict(ARMOUR_P1_TV="0", ARMOUR_P1_WAVES="1")]),
-    (3, [dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_HELPERS="0"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="1"),
-         dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_FREE="0"), dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="3", ARMOUR_P1_TV_FREE="0")]),
+    (1, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1), dict(build=1, step_free=1, step_split_fk=0)]),
+    (2, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1)]),
+    (3, [dict(build=2, tv_waves=4, tv_helpers=0), dict(build=2, tv_waves=3), dict(build=2, tv_waves=1), dict(build=2, tv_waves=4, tv_free=0), dict(build=2, tv_waves=3, tv_free=0)]),
 ], ids=["per-step, one problem", "per-step, two problems", "time-vectorised"])
 def test_wave_choreographies_leave_identical_tables(B, settings):
     """Which wave of a block computes what -- one wave playing every role, three roles with a barrier per joint, three or four
     free-running waves with the angular velocity, the torque tables and the helper products dealt out among them
     (p1_free.inc.h) -- must not show in the result: every shape runs the same operators on the same operands.  The digest of
-    g, jac, torque radii, link generators and sampled link / torque PZs is equal across the shapes of one kernel, bit for bit."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._tables_digest_body(%d)" % (root, os.path.join(root, "tests"), B)
-    digests = []
-    for env in settings:
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=120)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("digest ")]
-        assert r.returncode == 0 and lines, (env, r.stdout[-1500:] + r.stderr[-1500:])
-        digests.append(lines[-1])
+    g, jac, torque radii, link generators and sampled link / torque PZs is equal across the shapes of one kernel, bit for bit.
+    Round 4: the shapes are per-handle options (include/armour_hip.h, ARMOUR_OPT_P1_*), so all of them run in THIS process, one
+    handle each -- they were environment variables read once per process, and every shape needed a process of its own."""
+    digests, shapes = [], []
+    for kw in settings:
+        d, _, _, info = _tables_digest(B, _shape(**kw))
+        digests.append(d); shapes.append((info["kernel"], info["waves"]))
     assert len(set(digests)) == 1, list(zip(settings, digests))
+    assert len(set(shapes)) > 1, shapes   # (the options did select different launch shapes)
 
 
-def test_walk_helpers_only_reorder_the_sums_of_the_radii(tmp_path):
+def test_walk_helpers_only_reorder_the_sums_of_the_radii():
     """Round 3: in the backward pass of a four-wave time-vectorised block the two idle waves each walk the upper part of the
     f- / n-recursion's sorted raw terms (pz_tv.h "One walk on two waves").  Against the same build with every walk on its own wave:
     centres, monomial keys and coefficients equal bit for bit; the independent radii -- and torque radius, link generators, g, jac
     through them -- differ by the rounding of two partial sums instead of one running sum, <= 1e-12.  And the shared walk is
-    deterministic: two runs give the same bits."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    deterministic: two handles give the same bits.  (Two handles of one process with different ARMOUR_OPT_P1_TV_HELPERS.)"""
     out = {}
-    for tag, env in (("off", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4", ARMOUR_P1_TV_HELPERS="0")), ("on", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4")),
-                     ("on2", dict(ARMOUR_P1_TV="1", ARMOUR_P1_TV_WAVES="4"))):
-        f = str(tmp_path / (tag + ".npz"))
-        code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_p1_parity as t; t._tables_digest_body(3, %r)" % (root, os.path.join(root, "tests"), f)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0, (env, r.stdout[-1500:] + r.stderr[-1500:])
-        out[tag] = dict(np.load(f))
+    for tag, kw in (("off", dict(build=2, tv_waves=4, tv_helpers=0)), ("on", dict(build=2, tv_waves=4)), ("on2", dict(build=2, tv_waves=4))):
+        _, exact, radii, _ = _tables_digest(3, _shape(**kw))
+        out[tag] = {"exact": exact, "radii": radii}
     assert np.array_equal(out["on"]["exact"], out["off"]["exact"])
     assert np.abs(out["on"]["radii"] - out["off"]["radii"]).max() <= 1e-12
     assert not np.array_equal(out["on"]["radii"], out["off"]["radii"])        # (the helpers did take part)
     assert np.array_equal(out["on"]["radii"], out["on2"]["radii"]) and np.array_equal(out["on"]["exact"], out["on2"]["exact"])
+
+
+def test_two_handles_with_different_options_in_one_process():
+    """A stray setting of one handle must not reach another: two handles alive at the same time, one held to the per-step kernel with one-wave
+    blocks, one to the time-vectorised kernel, built alternately -- each keeps reporting its own kernel, and each reproduces its own tables."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    bp = random_batch(77, 4, 2)
+    a = ArmourNLP(T=100).set_option(_lib.OPT_P1_BUILD, 1).set_option(_lib.OPT_P1_STEP_WAVES, 1)
+    b = ArmourNLP(T=100).set_option(_lib.OPT_P1_BUILD, 2)
+    seen = {}
+    for rnd in range(2):
+        for name, nlp in (("a", a), ("b", b)):
+            nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+            info = nlp.build_info()
+            assert info["kernel"] == ("per_step" if name == "a" else "time_vectorised") and (info["waves"] == 1 if name == "a" else info["waves"] >= 3), (name, info)
+            tabs = (nlp.torque_radius().copy(), nlp.link_generators().copy())
+            if name in seen:
+                assert all(np.array_equal(x, y) for x, y in zip(tabs, seen[name]))
+            seen[name] = tabs
+    assert np.abs(seen["a"][0] - seen["b"][0]).max() <= 1e-12 and np.abs(seen["a"][1] - seen["b"][1]).max() <= 1e-12
+    with pytest.raises(Exception):
+        a.set_option(_lib.OPT_P1_TV_WAVES, 5.5)   # not an integer
+    with pytest.raises(Exception):
+        a.set_option(999, 1)
+    a.close(); b.close()
 
 
 def _exact_plane_skip(gens, obstacles):

@@ -82,18 +82,19 @@ def test_device_resident_solve_equals_the_host_driven_one(seed, O, T, B, monkeyp
         assert _same_solution(a, c), (a, c)
     for a, c in zip(host, nlp.solve()):      # ... and whatever the automatic choice is, the same again
         assert _same_solution(a, c), (a, c)
-    for blocks in ("1", "5", "64"):
-        monkeypatch.setenv("ARMOUR_SOLVE_BLOCKS", blocks)
+    from armour_amd import _lib
+    for blocks in (1, 5, 64):   # (ARMOUR_OPT_SOLVE_BLOCKS: a handle option since round 4)
+        nlp.set_option(_lib.OPT_SOLVE_BLOCKS, blocks)
         for a, c in zip(host, nlp.solve(device_qp=True)):
             assert _same_solution(a, c), (blocks, a, c)
-    monkeypatch.delenv("ARMOUR_SOLVE_BLOCKS")
+    nlp.set_option(_lib.OPT_SOLVE_BLOCKS, 0)
     # a batch cut into sub-batches launched back to back (round 3: what large batches with many obstacles do by themselves)
     if B > 1:
-        for sub in ("1", "2"):
-            monkeypatch.setenv("ARMOUR_SOLVE_SUB_BATCH", sub)
+        for sub in (1, 2):
+            nlp.set_option(_lib.OPT_SOLVE_SUB_BATCH, sub)
             for a, c in zip(host, nlp.solve(device_qp=True)):
                 assert _same_solution(a, c), ("sub-batch", sub, a, c)
-        monkeypatch.delenv("ARMOUR_SOLVE_SUB_BATCH")
+        nlp.set_option(_lib.OPT_SOLVE_SUB_BATCH, 0)
     # tighter tolerance / more iterations: longer iterate sequences
     for a, c in zip(nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True), nlp.solve(tolerance=1e-7, max_iterations=100, device_qp=True)):
         assert _same_solution(a, c), (a, c)
@@ -150,8 +151,8 @@ def test_row_buffer_overflow_falls_back_to_whole_linearisation(monkeypatch):
     T, O, B = 20, 4, 3
     bp = random_batch(30, B, O)
     ref = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
-    monkeypatch.setenv("ARMOUR_SOLVE_ROW_CAP", "2")
-    small = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
+    from armour_amd import _lib
+    small = ArmourNLP(T=T).set_option(_lib.OPT_SOLVE_ROW_CAP, 2).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]).solve()
     for a, c in zip(ref, small):
         assert np.array_equal(a["k_opt"], c["k_opt"]) and a["feasible"] == c["feasible"] and a["iterations"] == c["iterations"]
         assert abs(a["max_violation"] - c["max_violation"]) <= 1e-12 * max(1.0, a["max_violation"])
