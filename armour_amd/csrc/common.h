@@ -133,7 +133,7 @@ struct ArmourPlanner {
     bool stats_fresh = false;       // armour_p1_build has read the table statistics back itself (armour_refresh_table_stats has nothing to do)
     int opt_p1_build = 0;           // ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
     double opt_p1_work_mb = 0;      // ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's arena, MiB (0: none)
-    int opt_p1_keep_work = 0;       // ARMOUR_OPT_P1_KEEP_WORK_MEMORY: keep the time-vectorised build's arena between builds
+    int opt_p1_keep_work = 1;       // ARMOUR_OPT_P1_KEEP_WORK_MEMORY: 1 the device's shared work arena stays allocated between builds, 0 this handle's builds release it
     // launch-shape options ARMOUR_OPT_FIRST_TUNING .. ARMOUR_OPT_LAST_TUNING (include/armour_hip.h), indexed by option - FIRST; defaults: armour_tuning_defaults
     double tuning[ARMOUR_OPT_LAST_TUNING - ARMOUR_OPT_FIRST_TUNING + 1];
     int tune(int option) const { return (int)tuning[option - ARMOUR_OPT_FIRST_TUNING]; }

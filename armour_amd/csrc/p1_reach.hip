@@ -1601,12 +1601,15 @@ static std::mutex g_p1_launch_mu;
 // Work slots of the time-vectorised build: ONE arena per device, shared by every handle of the process (round 4).  A build holds the
 // device's arena -- and its mutex -- from before its launch until the kernel has finished (the build is synchronous, and a launch of
 // one block per compute unit leaves no room for another handle's beside it anyway), so two handles that build batches at the same
-// time need the 111.6 MiB per block once, not twice; and a build releases the arena at its end unless its handle asked to keep it
-// (ARMOUR_OPT_P1_KEEP_WORK_MEMORY): a handle between builds holds its tables only.
+// time need the 111.6 MiB per block once, not twice.  The arena stays allocated between builds and goes with the device's last handle;
+// ARMOUR_OPT_P1_KEEP_WORK_MEMORY = 0 releases it at the end of every build of that handle instead.  (Why keeping is the default --
+// measured, tools/gpu_p1_wall.py: releasing and re-allocating 28.6 GiB costs 0.6 ms of a 128-problem build's 10.4 ms as a rule, and 3.5 - 4.4 s
+// twice in twelve builds, when the runtime has to get the memory back from the driver.)
 struct TvArenaPool {
     std::mutex mu;
     unsigned char* ptr = nullptr;
     size_t bytes = 0;
+    int users = 0;   // live handles of the device that have built something: the last one to go frees the arena
 };
 constexpr int kMaxPoolDevices = 64;
 TvArenaPool g_tv_pool[kMaxPoolDevices];
@@ -1628,12 +1631,15 @@ struct P1Work {
 
 void armour_p1_free(ArmourPlanner* h) {
     P1Work* wk = (P1Work*)h->p1;
-    if (h->opt_p1_keep_work) {   // a handle that kept the device's work slots gives them back with itself
+    if (!wk) return;
+    {   // the device's last handle takes the shared work slots with it
         TvArenaPool& pool = g_tv_pool[h->device % kMaxPoolDevices];
         std::lock_guard<std::mutex> lk(pool.mu);
-        if (pool.ptr) { (void)hipSetDevice(h->device); (void)hipFree(pool.ptr); pool.ptr = nullptr; pool.bytes = 0; }
+        if (--pool.users <= 0) {
+            pool.users = 0;
+            if (pool.ptr) { (void)hipSetDevice(h->device); (void)hipFree(pool.ptr); pool.ptr = nullptr; pool.bytes = 0; }
+        }
     }
-    if (!wk) return;
     if (wk->arena) (void)hipFree(wk->arena);
     if (wk->d_status) (void)hipFree(wk->d_status);
     if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
@@ -1733,6 +1739,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (!h->p1) {
         P1Work* nw = new P1Work();
         h->p1 = nw;
+        { TvArenaPool& pool = g_tv_pool[h->device % kMaxPoolDevices]; std::lock_guard<std::mutex> lk(pool.mu); pool.users++; }
         HIPCHK(hipMalloc((void**)&nw->d_status, (ST_WORDS + 64) * sizeof(unsigned)));
         HIPCHK(hipEventCreate(&nw->ev0));
         HIPCHK(hipEventCreate(&nw->ev1));
@@ -1899,8 +1906,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const Shape shapes[5] = {{8, 4096}, {4, 4096}, {kRoles, 4096}, {1, 4096}, {1, 8192}};
         TvArenaPool& pool = g_tv_pool[h->device % kMaxPoolDevices];
         std::unique_lock<std::mutex> pool_lk(pool.mu);   // held until the last launch of this build has finished
-        // Released at the end of the build unless this handle keeps it -- on every way out: success, an error return, and when the build falls
-        // through to the per-step kernel (a cap below one block, a capacity flag): nothing of the time-vectorised build outlives it then.
+        // ARMOUR_OPT_P1_KEEP_WORK_MEMORY = 0: released at the end of the build -- on every way out: success, an error return, and when the build
+        // falls through to the per-step kernel (a cap below one block, a capacity flag): nothing of the time-vectorised build outlives it then.
         struct PoolRelease {
             TvArenaPool& p; bool keep;
             ~PoolRelease() { if (p.ptr && !keep) { (void)hipFree(p.ptr); p.ptr = nullptr; p.bytes = 0; } }

@@ -90,10 +90,11 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     ks = random_k(seed, 64)
     # thread count: the reference's default of 32 (NUM_THREADS, RT/Parameters.h:35), all cores and a few in between
     # (T = 100 time steps bound the useful parallelism, and a shared host punishes oversubscription); keep the fastest
-    best_t, best_rate = 0, 0.0
-    for th in sorted({min(c, max_threads()) for c in (16, 32, 64, 128, max_threads())}):
+    best_t, best_rate, sweep = 0, 0.0, {}
+    for th in sorted({min(c, max_threads()) for c in (1, 16, 32, 64, 128, max_threads())}):
         o.time_eval(ks, 3, threads=th)  # warm-up
         rate = 16 / o.time_eval(ks, 16, threads=th)
+        sweep[str(th)] = rate
         if rate > best_rate:
             best_t, best_rate = th, rate
     reps = int(max(20, min(20000, budget_s * best_rate)))
@@ -107,8 +108,12 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
             ob = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"], threads=th)
             ms.append(ob.build_ms)
         p1[str(th)] = min(ms)
+    host = host_description()
     return {
         "value": reps / secs, "unit": "iters/s", "cores": best_t, "kind": "port",
+        "cores_note": "`cores` = the OpenMP threads of the fastest setting of the sweep (what `value` was measured with), not the box's core count: see host",
+        "host": host, "cpu_model": host["cpu_model"], "physical_cores": host["physical_cores"], "logical_cpus": host["logical_cpus"],
+        "thread_sweep_iters_per_s": sweep,
         "sample": f"{reps} fused eval_g+eval_jac_g of 1 world (seed {seed}, O={O}, T={T}) at 64 cycling k points, "
                   f"OpenMP over time steps as RT/NLPclass.cu:304,376",
         "p1_build_ms_by_threads": p1, "p1_build_ms": min(p1.values()),
@@ -116,13 +121,38 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     }
 
 
-def measured_traffic(B, O, T):
+def host_description():
+    """CPU model, sockets, physical cores and logical CPUs of this box (from /proc/cpuinfo; the CPU baseline is timed on them) and the
+    CPUs this process may run on."""
+    model, phys, logical, sockets = None, set(), 0, set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip(); sockets.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip(); phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "sockets": len(sockets) or None, "physical_cores": len(phys) or None, "logical_cpus": logical or os.cpu_count(),
+            "cpus_usable_by_this_process": usable}
+
+
+def measured_traffic(B, O, T, name=None):
     """HBM bytes per P2 launch from the newest committed rocprofv3 PMC passes of this same configuration
     (profiles/r*_bench_{headline,configs2}_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
     MI355X_MICROARCH.md), with the file, the commit and the date the profile was taken at -- the number is read from a
     committed file, not measured in this run, so the line says which build it belongs to.  None when no profile of this
     configuration exists."""
-    name = {(1, 20, 100): "headline", (128, 50, 100): "configs2"}.get((B, O, T))
+    name = name or {(1, 20, 100): "headline", (128, 50, 100): "configs2"}.get((B, O, T))
     if name is None:
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{name}_pmc.json")), reverse=True):
@@ -203,7 +233,7 @@ class Timed:
         return worst
 
 
-def summarise(nlp, wall, ev, K, world, extra=None):
+def summarise(nlp, wall, ev, K, world, extra=None, traffic_name=None):
     """Three byte counts per launch, each divided by the HIP-event launch time:
       algorithmic  the reference formulation's bytes (1440 B per collision row + PZ tables + outputs) -- the yardstick
                    `roofline.achieved` is defined on; the kernel may legitimately move fewer (planes never needed are not stored)
@@ -214,9 +244,9 @@ def summarise(nlp, wall, ev, K, world, extra=None):
     launch_us = med_ev * 1e6 / K
     achieved = b_alg / (launch_us * 1e-6) / 1e9
     eff = b_eff / (launch_us * 1e-6) / 1e9
-    tr = measured_traffic(nlp.B, nlp.O, nlp.T)
+    tr = measured_traffic(nlp.B, nlp.O, nlp.T, traffic_name)
     out = {"problem_evals_per_s": world * nlp.B * K / med_wall, "ms_per_step": med_wall * 1e3 / K, "launch_us": launch_us,
-           "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": achieved, "algorithmic_equivalent_frac": achieved / HBM_PEAK_GBS,
            "effective_bytes_per_launch": b_eff, "effective_GBps": eff, "frac_effective": eff / HBM_PEAK_GBS,
            "traffic": tr, "frac_by_traffic": (tr["bytes"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tr else None,
            "repeats": len(wall), "wall_ms_min_med_max": [min(wall) * 1e3, med_wall * 1e3, max(wall) * 1e3],
@@ -276,7 +306,7 @@ def fetch_config(device, dev, T, K, R, check):
         spot = {"max_abs_dg": dg, "max_abs_djac": dj, "oracle_build_ms": o.build_ms}
     out = summarise(nlp, wall, ev, K, 1, {"robot": "fetch (CMP/FetchInfo.h), last link +-50 % mass / inertia", "links": nlp.J, "obstacles": O,
                                           "constraints_m": nlp.m, "p1_set_problems_ms": nlp.build_ms, "oracle_spot_check": spot,
-                                          "table_sizes": nlp.table_sizes()})
+                                          "table_sizes": nlp.table_sizes()}, traffic_name="configs4")
     nlp.close()
     return out
 
@@ -426,7 +456,14 @@ def main():
             "timing": {"repeats": R, "statistic": "median of the max-over-ranks wall time of K steps (barrier + synchronize on both sides)",
                        "wall_ms_min_med_max": s["wall_ms_min_med_max"]},
             "roofline": {"bound": "hbm", "achieved": s["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": s["frac_of_hbm_peak"], "traffic": s["traffic"]["bytes"] if s["traffic"] else None,
+                         "frac": s["algorithmic_equivalent_frac"], "traffic": s["traffic"]["bytes"] if s["traffic"] else None,
+                         "achieved_definition": "ALGORITHMIC bytes of the reference formulation (SURVEY.md 8d: 1440 B per collision row + PZ tables + outputs) / mean launch time "
+                                                "by HIP events -- an EQUIVALENT rate: the kernel reads a lean table (480 B per row), so this figure is not the bandwidth "
+                                                "moved and may exceed the peak on a large batch; bytes actually moved: achieved_by_traffic_GBps / frac_by_traffic (rocprofv3 "
+                                                "counters of the committed profile) and effective_GBps / frac_effective (the live layout's bytes)",
+                         "algorithmic_equivalent_GBps": s["achieved_GBps"],
+                         "achieved_by_traffic_GBps": (s["traffic"]["bytes"] / (s["launch_us"] * 1e-6) / 1e9) if s["traffic"] else None,
+                         "effective_GBps": s["effective_GBps"],
                          "traffic_source": s["traffic"], "frac_by_traffic": s["frac_by_traffic"],
                          "effective_bytes_per_launch": s["effective_bytes_per_launch"], "frac_effective": s["frac_effective"],
                          "kernel": nlp.L.armour_p2_kernel_name().decode(), "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],

@@ -98,10 +98,10 @@ void armour_free_pinned(void* p);
  * The work slots are ONE arena per device, shared by all handles of the process and held by a build only while it runs: two handles
  * building batches at the same time take turns on it (the kernel fills the device anyway), so they need it once, not twice. */
 #define ARMOUR_OPT_P1_WORK_MEMORY_MB 2
-/* ARMOUR_OPT_P1_KEEP_WORK_MEMORY (0 | 1, default 0): 0 releases the device's work slots at the end of every armour_set_problems* of
- * this handle -- between builds a handle holds its tables only; 1 leaves them allocated for the next build on that device (of any
- * handle) and until this handle is destroyed: a caller that rebuilds large batches every planning cycle saves the allocation
- * (measured: DESIGN.md 4.2b). */
+/* ARMOUR_OPT_P1_KEEP_WORK_MEMORY (0 | 1, default 1): 1 leaves the device's shared work slots allocated between builds (they go with the
+ * device's last handle); 0 releases them at the end of every armour_set_problems* of this handle, so that between builds the process
+ * holds tables only.  Releasing costs the next large build its allocation: 0.6 ms of a 128-problem build's 10.4 ms as a rule, but
+ * seconds now and then, when the runtime has to get 28.6 GiB back from the driver (measured) -- hence the default. */
 #define ARMOUR_OPT_P1_KEEP_WORK_MEMORY 3
 
 /* ---- launch-shape options (round 4: these were environment variables read once per process; two handles of one process can now

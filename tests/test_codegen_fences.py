@@ -1,0 +1,105 @@
+"""The two code-generation hazards of rounds 1-3 and the fences that hold them.
+
+Neither mechanism could be isolated (no <= 200-line reproduction fails on the GPU box: tools/micro/divloop_dpp.hip runs correctly at every
+occupancy, and the controller's faulting form left an unreadable dump), so both are held by fences, and the fences are under test:
+
+  * reach-set operators (round 1: a memory fault under interprocedural register allocation; round 2: wrong tables with two waves per SIMD):
+    the shipped object is built with -enable-ipra=false and pinned to one wave per SIMD, `make` fails otherwise (tools/check_p1_occupancy.py),
+    and HERE the same source with every LDS / arena index of the product merge and of the reduce passes range-checked (-DDBG_BOUNDS,
+    armour_amd/lib/libarmour_hip_checked.so) runs a fuzz set in every launch shape: no check fires (a firing check fails the build call with
+    flag 128) and the tables equal the shipped library's bit for bit;
+  * controller kernels (round 3: a memory-aperture violation when the interval RNEA's halves were functions of their own): `make` fails
+    unless controller.o holds exactly the two kernels, each with a static stack (tools/check_controller_codegen.py); HERE the check is run on
+    the remarks of the object that was shipped, and on a doctored copy that it must reject.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECKED = os.path.join(ROOT, "armour_amd", "lib", "libarmour_hip_checked.so")
+
+_FUZZ = r'''
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+from armour_amd import _lib
+from armour_amd.planner import ArmourNLP
+from armour_amd.worlds import random_batch
+print("library", _lib.LIB_PATH, flush=True)
+cases = [(1, 3, {}), (1, 3, {_lib.OPT_P1_STEP_WAVES: 1}), (1, 3, {_lib.OPT_P1_STEP_WAVES: 3}), (2, 2, {_lib.OPT_P1_STEP_FREE: 0}),
+         (6, 2, {_lib.OPT_P1_BUILD: 1}), (20, 1, {_lib.OPT_P1_BUILD: 1, _lib.OPT_P1_STEP_WAVES: 1}),
+         (6, 2, {_lib.OPT_P1_BUILD: 2}), (20, 1, {_lib.OPT_P1_BUILD: 2, _lib.OPT_P1_TV_WAVES: 3}), (24, 1, {_lib.OPT_P1_BUILD: 2, _lib.OPT_P1_TV_WAVES: 1})]
+for seed in range(%d):
+    for B, O, opts in cases:
+        bp = random_batch(3000 + 17 * seed + B, B, O)
+        if seed %% 2:   # fast starts: the largest products
+            bp["qd0"][B - 1] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
+        nlp = ArmourNLP(T=100)
+        for o, v in opts.items():
+            nlp.set_option(o, v)
+        nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])   # raises if a range check fired (flag 128)
+        h = hashlib.sha1(np.ascontiguousarray(nlp.torque_radius()).tobytes() + np.ascontiguousarray(nlp.link_generators()).tobytes())
+        for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
+            for i in range(cnt):
+                for t in (0, 41, 99):
+                    for a in nlp.pz(which, i, t, b=B - 1):
+                        h.update(np.ascontiguousarray(a).tobytes())
+        info = nlp.build_info()
+        print("case", seed, B, sorted(opts.items()), info["kernel"], info["waves"], h.hexdigest(), flush=True)
+        nlp.close()
+print("fuzz done", flush=True)
+'''
+
+
+def _run(lib, seeds):
+    env = dict(os.environ)
+    if lib:
+        env["ARMOUR_HIP_LIB"] = lib          # (the library path is the one thing the environment still selects)
+    else:
+        env.pop("ARMOUR_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", _FUZZ % (ROOT, seeds)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return [line for line in r.stdout.splitlines() if line.startswith("case ")], r.stdout.splitlines()[0]
+
+
+@pytest.mark.gpu
+def test_range_checked_operators_run_the_fuzz_set_clean_and_agree_with_the_shipped_library():
+    assert os.path.exists(CHECKED), "build it: make -C armour_amd/csrc checked (part of `make all`)"
+    checked, lib_line = _run(CHECKED, 4)
+    assert "libarmour_hip_checked.so" in lib_line
+    shipped, lib_line2 = _run(None, 4)
+    assert lib_line2.endswith("libarmour_hip.so")
+    assert len(checked) == 36 and checked == shipped
+
+
+def test_checked_library_exports_the_whole_abi():
+    """CPU: the range-checked library is a full libarmour_hip (same objects but p1_reach.o) -- every symbol of include/armour_hip.h."""
+    import ctypes as C
+    from armour_amd import _lib
+    if not os.path.exists(CHECKED):
+        pytest.skip("libarmour_hip_checked.so not built (make -C armour_amd/csrc)")
+    L = C.CDLL(CHECKED)
+    for name in _lib.EXPORTS:
+        assert hasattr(L, name), name
+
+
+def test_controller_codegen_check_accepts_the_shipped_object_and_rejects_a_callee(tmp_path):
+    """CPU: tools/check_controller_codegen.py on the remarks `make` kept of the shipped controller.o (exactly two kernels, static stacks), and
+    on a copy with a third function / a dynamic stack, which it must refuse."""
+    remarks = os.path.join(ROOT, "armour_amd", "lib", "controller.resources.txt")
+    if not os.path.exists(remarks):
+        pytest.skip("no build remarks (make -C armour_amd/csrc)")
+    tool = os.path.join(ROOT, "tools", "check_controller_codegen.py")
+    ok = subprocess.run([sys.executable, tool, remarks], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    text = open(remarks).read()
+    extra = tmp_path / "extra.txt"
+    extra.write_text(text + "\ncontroller_core.h:1:1: remark: Function Name: _ZN3ctl13interval_rneaEv [-Rpass-analysis=kernel-resource-usage]\n"
+                            "controller_core.h:1:1: remark:     ScratchSize [bytes/lane]: 512 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert subprocess.run([sys.executable, tool, str(extra)], capture_output=True, text=True).returncode == 1
+    dyn = tmp_path / "dyn.txt"
+    dyn.write_text(text.replace("Dynamic Stack: False", "Dynamic Stack: True", 1))
+    assert subprocess.run([sys.executable, tool, str(dyn)], capture_output=True, text=True).returncode == 1
