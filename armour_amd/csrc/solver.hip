@@ -361,15 +361,17 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     // the blocks' flag words: zero before a launch.  Every block clears its own word when it leaves the kernel, so a fill is only
     // needed when the array is new (or grew)
     {
-        const size_t need = (size_t)B * nb * sizeof(BlockWord);
+        // (sized for ONE sub-batch: the launches of a cut batch run one after the other on the stream and index these buffers by
+        //  b - b0, so a batch of 1024 problems holds the candidate rows of the <= Bs it solves at a time -- ADVICE round 3)
+        const size_t need = (size_t)Bs * nb * sizeof(BlockWord);
         const size_t had = w.word_cap;
         if ((rc = grow_dev(&w.blk_word, &w.word_cap, need)) != ARMOUR_OK) return rc;
         if (w.word_cap != had || !w.words_clean) HIPCHK(hipMemsetAsync(w.blk_word, 0, w.word_cap, h->stream));
         w.words_clean = 0;   // until this launch has been seen to end
     }
-    if ((rc = grow_dev(&w.blk_rows, &w.blk_rows_cap, (size_t)B * nb * cap_blk * sizeof(SolveRow))) != ARMOUR_OK) return rc;
-    if ((rc = grow_dev(&w.qp_rows, &w.qp_rows_cap, (size_t)B * cap_rows * sizeof(SolveRow))) != ARMOUR_OK) return rc;
-    if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)B * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.blk_rows, &w.blk_rows_cap, (size_t)Bs * nb * cap_blk * sizeof(SolveRow))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.qp_rows, &w.qp_rows_cap, (size_t)Bs * cap_rows * sizeof(SolveRow))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)Bs * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
     ArmourSolveResult* hres = reinterpret_cast<ArmourSolveResult*>(armour_handle_pinned(h, 1, (size_t)B * sizeof(ArmourSolveResult)));
     unsigned char* hblock = reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 2, block_bytes));
     if (!hres || !hblock) return ARMOUR_EDEVICE;
@@ -395,10 +397,11 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         const double left_ms = (opt.max_wall_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3 / n_launch;
         a.budget_ticks = left_ms > 0 ? (long long)(left_ms * plan.ticks_per_ms) : 0;
     }
-    // no wait of the persistent kernel outlasts the budget by more than a second (10 s without a budget: 60 iterations of a large batch
-    // stay far below); the host's own poll gives up a little later.  ARMOUR_OPT_SOLVE_HARD_CAP_S: tuning / tests.
+    // no wait of the persistent kernel outlasts the budget by more than a second (without a budget: from the iteration limit and the tiles per block, below); the host's own poll gives up a little later.  ARMOUR_OPT_SOLVE_HARD_CAP_S: tuning / tests.
     const double hard_cap_s = h->tune_f(ARMOUR_OPT_SOLVE_HARD_CAP_S);
-    const double hard_s = hard_cap_s > 0 ? hard_cap_s : (a.budget_ticks >= 0 ? a.budget_ticks / plan.ticks_per_ms * 1e-3 + 1.0 : 10.0);
+    // without a budget: 50 x what max_iterations iterations of (1 + max_line_search) evaluations cost at ~4 us per row tile of a block, at least 5 s
+    const double no_budget_s = std::max(5.0, 1.0 + 50.0 * (double)std::max(1, opt.max_iterations) * (1.0 + std::max(0, opt.max_line_search)) * tiles_per_block * 4e-6);
+    const double hard_s = hard_cap_s > 0 ? hard_cap_s : (a.budget_ticks >= 0 ? a.budget_ticks / plan.ticks_per_ms * 1e-3 + 1.0 : no_budget_s);
     a.hard_ticks = std::max<long long>(1, (long long)(hard_s * 1e3 * plan.ticks_per_ms));
     const bool timing = armour_trace_solve();
     long long* hstamps = timing ? reinterpret_cast<long long*>(armour_handle_pinned(h, 0, (size_t)B * 64 * sizeof(long long) + (size_t)B * n * sizeof(double))) : nullptr;

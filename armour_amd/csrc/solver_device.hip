@@ -526,7 +526,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
 // gather the candidate rows of all blocks of the group, in block (= row) order, into the problem's contiguous buffer
 __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, SolveRow* cand) {
     const int tid = threadIdx.x, nb = a.nb;
-    const BlockWord* bw = a.blk_word + (size_t)b * nb;
+    const BlockWord* bw = a.blk_word + (size_t)(b - a.b0) * nb;
     // exclusive prefix sum of the block counts (nb <= 1024)
     int mine[4], tot = 0;
 #pragma unroll
@@ -563,7 +563,7 @@ __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, S
             const int mid = (lo + hi + 1) >> 1;
             if (L.scan[mid] <= c) lo = mid; else hi = mid - 1;
         }
-        cand[c] = ld_coh_row(a.blk_rows + ((size_t)b * nb + lo) * a.cap_blk + (c - L.scan[lo]));
+        cand[c] = ld_coh_row(a.blk_rows + ((size_t)(b - a.b0) * nb + lo) * a.cap_blk + (c - L.scan[lo]));
     }
     if (tid == 0) L.ncand = total;
     __threadfence_block();
@@ -722,9 +722,9 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     int role, r0, r1, rdummy;
     tile_info(a, t0, role, r0, rdummy);
     tile_info(a, t1 - 1, role, rdummy, r1);
-    SolveRow* my_rows = a.blk_rows + ((size_t)b * a.nb + jb) * a.cap_blk;
-    SolveRow* cand = a.qp_rows + (size_t)b * a.cap_rows;
-    unsigned char* is_active = a.flags + (size_t)b * 2 * (a.cap_rows + 2 * NV);
+    SolveRow* my_rows = a.blk_rows + ((size_t)(b - a.b0) * a.nb + jb) * a.cap_blk;
+    SolveRow* cand = a.qp_rows + (size_t)(b - a.b0) * a.cap_rows;
+    unsigned char* is_active = a.flags + (size_t)(b - a.b0) * 2 * (a.cap_rows + 2 * NV);
     unsigned char* excluded = is_active + (a.cap_rows + 2 * NV);
     double* g = a.g + (size_t)b * m;
     double* jac = a.jac + (size_t)b * m * n;
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         __syncthreads();
         const int cmd = s_cmd;
         if (cmd == CMD_DONE) {   // leave the flag word as the next launch expects it (nobody polls it any more: the leader has finished)
-            if (tid == 0) st_coh(&a.blk_word[(size_t)b * a.nb + jb].flag, 0u);
+            if (tid == 0) st_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + jb].flag, 0u);
             break;
         }
         if (tid < NV) s_x[tid] = tid < n ? ld_coh(&c->x[tid]) : 0.0;   // the phase's point, into LDS: the tile code reads it from there
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         long long vfx = 0;
         int cnt = 0, bad = 0;
         scan_rows<3>(a, b, r0, r1, my_rows, a.cap_blk, scan_sh, vfx, cnt, bad);
-        BlockWord* mine = a.blk_word + (size_t)b * a.nb + jb;
+        BlockWord* mine = a.blk_word + (size_t)(b - a.b0) * a.nb + jb;
         if (tid == 0) { st_coh(&mine->viol, vfx); st_coh(&mine->bad, bad); st_coh(&mine->count, cnt); }
         // ---- group barrier: a flag per block (199 atomics on one counter cost ~10 us per phase; 199 separate words cost nothing).
         //      Every lane's coherent stores (candidate rows, the words above) have completed before the flag is written.
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         for (unsigned spins = 0;; spins++) {   // the leader's 256 lanes poll the group's flags, four each
             int all = 1;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb && ld_coh(&a.blk_word[(size_t)b * a.nb + j2].flag) < phase) all = 0; }
+            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb && ld_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + j2].flag) < phase) all = 0; }
             if (__syncthreads_and(all)) break;
             if ((spins & 255u) == 255u && __syncthreads_or(wall_clock64() - t_block > a.hard_ticks ? 1 : 0)) { group_lost = true; break; }
         }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
                 a.out[b].status = -1;
                 wait_my_memory_ops();
                 st_coh(&c->go, phase * 8u + (unsigned)CMD_DONE);
-                st_coh(&a.blk_word[(size_t)b * a.nb + jb].flag, 0u);
+                st_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + jb].flag, 0u);
             }
             break;
         }
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
             long long v = 0;
             int bd = 0;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb) { v += ld_coh(&a.blk_word[(size_t)b * a.nb + j2].viol); bd += ld_coh(&a.blk_word[(size_t)b * a.nb + j2].bad); } }
+            for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb) { v += ld_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + j2].viol); bd += ld_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + j2].bad); } }
             scan_sh.red[tid] = v; scan_sh.redi[tid] = bd;
             __syncthreads();
             for (int s2 = 128; s2 > 0; s2 >>= 1) {
