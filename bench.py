@@ -180,6 +180,8 @@ class Timed:
         self.stream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: HIP events on the null stream do not bracket the launches
         # the K timed launches go out as one instantiated graph (a chain of K kernel nodes), built before the timed region
         nlp.prepare_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr())
+        if W > 0:
+            nlp.prepare_steps(self.ks.data_ptr(), W, self.d_g.data_ptr(), self.d_jac.data_ptr())   # (the warm-up steps in front of every timed interval)
 
     def barrier(self):
         if self.use_dist:
@@ -191,23 +193,33 @@ class Timed:
         from armour_amd.sharding import reduce_max_elapsed
         torch, nlp, K, W = self.torch, self.nlp, self.K, self.W
         sh = self.stream.cuda_stream
-        if W > 0:
-            nlp.eval_g_jac_device_steps(self.ks.data_ptr(), W, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
         wall, ev = [], []
+        # Every timed interval is preceded by the W untimed warm-up steps (a 20-step interval is 0.1 ms: after the idle time between two
+        # intervals its first launches found cold caches), and the interval is measured twice over -- once by the wall clock with nothing but
+        # the K launches between the two barrier + synchronize brackets (`value`, `ms_per_step`), once more bracketed by HIP events on the
+        # launch stream (the roofline's launch duration): the two event records cost a 20-step interval 5 % when they sat inside the wall-clock
+        # bracket.  Same K steps, same k points, same graph both times.
         for _ in range(repeats):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.barrier()
-            t0 = time.perf_counter()
-            e0.record(self.stream)
-            nlp.eval_g_jac_device_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
-            e1.record(self.stream)
-            while not self.stream.query():   # poll the stream: a sleeping synchronize adds its wake-up latency to a 0.1 ms interval
-                pass
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-            self.barrier()
-            wall.append(reduce_max_elapsed(elapsed, device=self.dev if self.use_dist else None))
-            ev.append(reduce_max_elapsed(e0.elapsed_time(e1) * 1e-3, device=self.dev if self.use_dist else None))
+            for timed_by_events in (False, True):
+                if W > 0:
+                    nlp.eval_g_jac_device_steps(self.ks.data_ptr(), W, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.barrier()
+                t0 = time.perf_counter()
+                if timed_by_events:
+                    e0.record(self.stream)
+                nlp.eval_g_jac_device_steps(self.ks[W:].data_ptr(), K, self.d_g.data_ptr(), self.d_jac.data_ptr(), sh)
+                if timed_by_events:
+                    e1.record(self.stream)
+                while not self.stream.query():   # poll the stream: a sleeping synchronize adds its wake-up latency to a 0.1 ms interval
+                    pass
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t0
+                self.barrier()
+                if timed_by_events:
+                    ev.append(reduce_max_elapsed(e0.elapsed_time(e1) * 1e-3, device=self.dev if self.use_dist else None))
+                else:
+                    wall.append(reduce_max_elapsed(elapsed, device=self.dev if self.use_dist else None))
         return wall, ev
 
     def check(self, oracle_problems=None, tol_g=1e-9, tol_j=1e-8):
