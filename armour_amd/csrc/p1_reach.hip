@@ -1672,9 +1672,6 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     const int J = h->J, n = h->n;
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
-#ifdef PZW_HASH_PRODUCTS
-    if (cap_raw == 4096) cap_raw = 8192;  // one wave, one operator: the default limits get a block (80 KB) whose lists also hold products that prune nothing, as the operator tests feed them
-#endif
     const Layout L = make_layout(J, n, h->lim.work_monomials, 1);
     const size_t ci_doubles = (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3;
     const size_t smem = p1_wave_lds(cap_raw, cap_raw) + p1_shared_lds(ci_doubles);

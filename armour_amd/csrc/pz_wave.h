@@ -976,7 +976,8 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
     WSYNC();
 }
 
-#ifndef PZW_HASH_PRODUCTS  /* the shipped product: sort ALL raw terms.  -DPZW_HASH_PRODUCTS: the hash-classified product of pz_hash.h (experimental, see its header) */
+// The product sorts ALL raw terms.  (Rounds 2-3 carried a second, hash-classified product behind a build flag -- unique keys decided without
+// the sort; measured slower on the chip and never shipped.  It is kept as a text, docs/experiments/pz_hash.h.txt, not as source.)
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w_, const PZ& out_, const View& a_, const View& b_) {
     PZW_WAVE_LOCAL(w, w_)
@@ -1189,9 +1190,6 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
     WSYNC();
     PROF_CALL_END(N_in)
 }
-#else
-#include "pz_hash.h"
-#endif  // PZW_HASH_PRODUCTS
 
 // Cross product of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167):
 //     out[c] = sA[c] * a[cA[c]] + sB[c] * a[cB[c]],  c = 0..2.
