@@ -7,10 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ARMOUR_HIP_LIB") or os.path.join(_HERE, "lib", "libarmour_hip.so")  # env override: A/B builds
+# ARMOUR_KEY128=1 selects the second ABI of include/armour_types.h for the whole process: libarmour_hip_k128.so (128-bit monomial keys, 8 factors)
+KEY128 = os.environ.get("ARMOUR_KEY128", "0") not in ("", "0")
+LIB_PATH = os.environ.get("ARMOUR_HIP_LIB") or os.path.join(_HERE, "lib", "libarmour_hip_k128.so" if KEY128 else "libarmour_hip.so")  # env override: A/B builds
 
-MAXJ = 9   # ARMOUR_MAX_JOINTS
-MAXF = 7   # ARMOUR_MAX_FACTORS
+MAXJ = 9                    # ARMOUR_MAX_JOINTS
+MAXF = 8 if KEY128 else 7   # ARMOUR_MAX_FACTORS (checked against armour_abi_max_factors() of the library that was loaded)
 
 OK, EINVAL, EDEVICE, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
 
@@ -106,7 +108,7 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_eval_violations_device", "armour_eval_violations",
+    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
     "armour_batch_get_build_ms", "armour_batch_get_build_info",
@@ -151,6 +153,8 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU path.")
     _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
+    if hasattr(L, "armour_abi_max_factors") and L.armour_abi_max_factors() != MAXF:
+        raise RuntimeError(f"{LIB_PATH} is built for {L.armour_abi_max_factors()} factors, this process mirrors its structs for {MAXF} (ARMOUR_KEY128)")
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     vp = C.c_void_p
     L.armour_robot_kinova_gen3_no_gripper.argtypes = [C.POINTER(ArmourRobot)]

@@ -731,6 +731,8 @@ extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value)
     return ARMOUR_EINVAL;
 }
 
+extern "C" int armour_abi_max_factors(void) { return ARMOUR_MAX_FACTORS; }
+
 extern "C" int armour_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); armour_set_error("armour_device_memory: no such device %d", device); return ARMOUR_EDEVICE; }

@@ -87,7 +87,7 @@ struct P1Cfg {
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
-__host__ __device__ inline size_t slot_bytes(int cap, int sz) { return align64((size_t)cap * 8) + align64((size_t)cap * sz * 8) + align64((size_t)sz * 8) * 2; }
+__host__ __device__ inline size_t slot_bytes(int cap, int sz) { return align64((size_t)cap * sizeof(pzkey_t)) + align64((size_t)cap * sz * 8) + align64((size_t)sz * 8) * 2; }
 
 // arena = work V | work S | work M | small M | small V | small S
 struct Layout {
@@ -119,8 +119,8 @@ __host__ __device__ inline Layout make_layout(int J, int n, int capW, int nroles
 __device__ inline PZ mk_slot(GLB_AS unsigned char* base, size_t off, int index, int cap, int sz, int id0, LDS_AS double* ci) {
     GLB_AS unsigned char* p = base + off + (size_t)index * slot_bytes(cap, sz);
     PZ z;
-    z.keys = (GLB_AS uint64_t*)p;
-    z.coef = (GLB_AS double*)(p + align64((size_t)cap * 8));
+    z.keys = (GLB_AS pzkey_t*)p;
+    z.coef = (GLB_AS double*)(p + align64((size_t)cap * sizeof(pzkey_t)));
     z.cen = ci + (size_t)index * 3 * sz;
     z.ind = z.cen + sz;
     z.ind2 = z.ind + sz;
@@ -503,7 +503,7 @@ __device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js
     const P1Cfg& cf = *c.cf;
     const Wave& w = c.w;
     const int n = c.n, ax = cf.rb.axes[i];
-    const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);   // kk < kc < ks: the sorted order
+    const pzkey_t kk = pzkey_bit(2 * i), kc = pzkey_bit(5 * n + 2 * i), ks = pzkey_bit(7 * n + 2 * i);   // kk < kc < ks: the sorted order
     double cen[9], m0[9], m1[9], m2[9], t2[9];
     make_rotation(cen, js.cos_c, js.sin_c, ax, false);
     make_rotation(m0, js.cos_k, 0.0, ax, true);
@@ -578,7 +578,7 @@ __device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js
     }
 }
 // PZsparse(centre, {k: a, e: b}) of a velocity / acceleration polynomial (:176-243), simplify()
-__device__ inline void jrs_scalar_direct(Chain& c, const PZ& out, double cen, uint64_t k0, double a, uint64_t k1, double b) {
+__device__ inline void jrs_scalar_direct(Chain& c, const PZ& out, double cen, pzkey_t k0, double a, pzkey_t k1, double b) {
     const Wave& w = c.w;
     const double va = 1.0 * a, vb = 1.0 * b;
     const bool ka = !norm1_le(va, w.thr), kb = !norm1_le(vb, w.thr);
@@ -607,9 +607,9 @@ __device__ inline void jrs_linkbox_direct(Chain& c, int i) {
         out.ind[0] = i0 + 0.0; out.ind[1] = i1 + 0.0; out.ind[2] = i2 + 0.0;
         out.ind2[0] = i0 + 0.0; out.ind2[1] = i1 + 0.0; out.ind2[2] = i2 + 0.0;
         int pos = 0;
-        if (k0) { out.keys[pos] = 1ull << (2 * n); out.coef[(size_t)pos * 3] = 1.0 * g0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
-        if (k1) { out.keys[pos] = 1ull << (3 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 1.0 * g1; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
-        if (k2) { out.keys[pos] = 1ull << (4 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 1.0 * g2; pos++; }
+        if (k0) { out.keys[pos] = pzkey_bit(2 * n); out.coef[(size_t)pos * 3] = 1.0 * g0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
+        if (k1) { out.keys[pos] = pzkey_bit(3 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 1.0 * g1; out.coef[(size_t)pos * 3 + 2] = 0.0; pos++; }
+        if (k2) { out.keys[pos] = pzkey_bit(4 * n); out.coef[(size_t)pos * 3] = 0.0; out.coef[(size_t)pos * 3 + 1] = 0.0; out.coef[(size_t)pos * 3 + 2] = 1.0 * g2; pos++; }
         c.w.cnt[out.id] = pos;
     }
 }
@@ -660,7 +660,7 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
         if (!c.is(role)) continue;
         const bool actuated = i < n && cf.rb.axes[i] != 0;
         JrsScalars js;
-        const uint64_t kk = 1ull << (2 * i);
+        const pzkey_t kk = pzkey_bit(2 * i);
         js.cos_c = bcast(js_l.cos_c, i); js.cos_k = bcast(js_l.cos_k, i); js.cos_e = bcast(js_l.cos_e, i);
         js.sin_c = bcast(js_l.sin_c, i); js.sin_k = bcast(js_l.sin_k, i); js.sin_e = bcast(js_l.sin_e, i);
         js.qd_c = bcast(js_l.qd_c, i); js.qd_k = bcast(js_l.qd_k, i); js.qd_e = bcast(js_l.qd_e, i); js.qda_e = bcast(js_l.qda_e, i);
@@ -680,9 +680,9 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
         if (!kin_only) {
             // qd_des, qda_des, qdda_des (:176-243)
             if (actuated) {
-                jrs_scalar_direct(c, c.qd(i), js.qd_c, kk, js.qd_k, 1ull << (2 * n + i), js.qd_e);
-                jrs_scalar_direct(c, c.qda(i), js.qd_c, kk, js.qd_k, 1ull << (3 * n + i), js.qda_e);
-                jrs_scalar_direct(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, 1ull << (4 * n + i), js.qdd_e);
+                jrs_scalar_direct(c, c.qd(i), js.qd_c, kk, js.qd_k, pzkey_bit(2 * n + i), js.qd_e);
+                jrs_scalar_direct(c, c.qda(i), js.qd_c, kk, js.qd_k, pzkey_bit(3 * n + i), js.qda_e);
+                jrs_scalar_direct(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, pzkey_bit(4 * n + i), js.qdd_e);
             }
             jrs_mass_inertia_direct(c, i);   // radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
         }
@@ -703,7 +703,7 @@ __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int 
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, cnt = w.cnt[p.id];
-    const uint64_t kmax = 1ull << (2 * n), lmax = 1ull << (5 * n), kmask = kmax - 1;
+    const pzkey_t kmax = pzkey_bit(2 * n), lmax = pzkey_bit(5 * n), kmask = kmax - 1;
     const size_t idx = ((size_t)b * c.J + l) * cf.T + t;
     double* gens = cf.link_gens + (((size_t)b * cf.T + t) * c.J + l) * 18;
     if (w.lane < 18) gens[w.lane] = 0.0;
@@ -714,7 +714,7 @@ __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int 
         const int m = base + w.lane;
         bool isk = false, isg = false;
         if (m < cnt) {
-            const uint64_t key = p.keys[m];
+            const pzkey_t key = p.keys[m];
             isk = key < kmax;
             isg = !isk && key < lmax && (key & kmask) == 0;
             if (isk) {
@@ -936,7 +936,7 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t, in
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, T = cf.T;
-    const uint64_t kmax = 1ull << (2 * n);
+    const pzkey_t kmax = pzkey_bit(2 * n);
     Itv rho = {0.0, 0.0};
     double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
     for (int j = 0; j < n; j++) {
@@ -960,7 +960,7 @@ __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t, in
             const int m = base + w.lane;
             bool isk = false;
             if (m < cnt) {
-                const uint64_t key = p.keys[m];
+                const pzkey_t key = p.keys[m];
                 isk = key < kmax;
                 if (isk) {
                     if (m < cf.capT) { cf.tq_keys[idx * cf.capT + m] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + m] = p.coef[m]; }
@@ -1032,7 +1032,7 @@ constexpr bool kTvDedicatedHelpers = P1_TV_WAVES_PER_SIMD > 1;
 // One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
 // NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
-__host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * 8 + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * sizeof(pzkey_t) + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
 
 template <int NW>
@@ -1050,9 +1050,9 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     const bool fk_bufs = NW == 4 && c.wid == 3;
     const int my_cap_key = fk_bufs ? kFkCapKey : cf.capKey, my_cap_raw = fk_bufs ? kFkCapRaw : cf.capRaw;
     LDS_AS unsigned char* mine = lds + (size_t)c.wid * p1_wave_lds(cf.capKey, cf.capRaw);
-    c.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
-    c.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
+    c.w.skey = (LDS_AS pzkey_t*)mine;
+    c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * sizeof(pzkey_t));
+    c.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * sizeof(pzkey_t) + (size_t)my_cap_raw * 2);
     LDS_AS unsigned char* shared = lds + (size_t)(NW == 4 ? 3 : NW) * p1_wave_lds(cf.capKey, cf.capRaw) + (NW == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
@@ -1531,9 +1531,9 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     c.arena = (GLB_AS unsigned char*)cf.arena;
     LDS_AS unsigned char* lds = (LDS_AS unsigned char*)smem;
     c.nw = 1; c.wid = 0; c.role = 0;
-    c.w.skey = (LDS_AS uint64_t*)lds;
-    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * 8);
-    c.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * 8 + (size_t)cf.capRaw * 2);
+    c.w.skey = (LDS_AS pzkey_t*)lds;
+    c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * sizeof(pzkey_t));
+    c.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * sizeof(pzkey_t) + (size_t)cf.capRaw * 2);
     LDS_AS unsigned char* shared = lds + p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
         // 3x3 operands: the first in a work slot, the second in a small (<= 8 monomials) slot like a joint rotation
         in[o] = a.sz[o] == 9 ? (o == 0 ? c.M(0) : c.JM(0)) : a.sz[o] == 3 ? c.allocV() : c.allocS();
         const int n = a.cnt[o], sz = a.sz[o];
-        for (int m = threadIdx.x; m < n; m += WAVE) in[o].keys[m] = a.keys[o][m];
+        for (int m = threadIdx.x; m < n; m += WAVE) in[o].keys[m] = (pzkey_t)a.keys[o][m];
         for (int m = threadIdx.x; m < n * sz; m += WAVE) in[o].coef[m] = a.coef[o][m];
         if (threadIdx.x < sz) { in[o].cen[threadIdx.x] = a.cen[o][threadIdx.x]; in[o].ind[threadIdx.x] = a.ind[o][threadIdx.x]; in[o].ind2[threadIdx.x] = a.ind2[o][threadIdx.x]; }
         if (threadIdx.x == 0) c.w.cnt[in[o].id] = n;
@@ -1585,7 +1585,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
         for (int i = 0; i < PR_WORDS && 32 + i < 64; i++) a.out_misc[32 + i] = (double)w.prof[i];
 #endif
     }
-    for (int m = threadIdx.x; m < n && m < a.out_cap; m += WAVE) a.out_keys[m] = out.keys[m];
+    for (int m = threadIdx.x; m < n && m < a.out_cap; m += WAVE) a.out_keys[m] = (uint64_t)out.keys[m];   // (a 128-bit key build hands back the low word: the operator tests run on the 64-bit build)
     for (int m = threadIdx.x; m < n * sz && m < a.out_cap * sz; m += WAVE) a.out_coef[m] = out.coef[m];
     if (threadIdx.x == 0) {
         a.out_misc[0] = n; a.out_misc[1] = sz; a.out_misc[2] = w.lstat[ST_ERR];

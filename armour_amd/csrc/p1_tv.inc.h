@@ -17,7 +17,7 @@ constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22
 constexpr int kTvPart4First[4] = {0, 8, 23, 43}, kTvPart4Count[4] = {8, 15, 20, 20};   // (the forward-kinematics wave also owns w_aux and R_t w_aux: p1_free.inc.h, aux3)
 
 // (one spare key and one spare row block beyond `cap`)
-__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * 8) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
+__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * sizeof(pzkey_t)) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
 
 struct TLayout {
     int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (one per wave); npools: parts of the 3x1 pool (1, 3 or 4)
@@ -50,8 +50,8 @@ __host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwav
 __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index, int cap, int sz, int id0) {
     GLB_AS unsigned char* p = base + off + (size_t)index * tv_slot_bytes(cap, sz);
     TPZ z;
-    z.keys = (GLB_AS uint64_t*)p;
-    z.hdr = (GLB_AS double*)(p + align64((size_t)(cap + 1) * 8));
+    z.keys = (GLB_AS pzkey_t*)p;
+    z.hdr = (GLB_AS double*)(p + align64((size_t)(cap + 1) * sizeof(pzkey_t)));
     z.coef = z.hdr + (size_t)4 * sz * 64;
     z.sz = sz; z.cap = cap; z.id = id0 + index;
     return z;
@@ -99,8 +99,8 @@ struct TChain {
     __device__ TPZ H(int i) const {   // helper wave i's scratch slot (no entry in the count table: only its keys, rows and partial-sum rows are used)
         GLB_AS unsigned char* p = arena + L.offH + (size_t)i * tv_helper_slot_bytes(capW);
         TPZ z;
-        z.keys = (GLB_AS uint64_t*)p;
-        z.hdr = (GLB_AS double*)(p + align64((size_t)(capW + 1) * 8));
+        z.keys = (GLB_AS pzkey_t*)p;
+        z.hdr = (GLB_AS double*)(p + align64((size_t)(capW + 1) * sizeof(pzkey_t)));
         z.coef = z.hdr + (size_t)16 * 64;
         z.sz = 3; z.cap = capW; z.id = 0;
         return z;
@@ -249,7 +249,7 @@ struct TChain {
 // (a key stays while any lane keeps it; a lane that pruned it stores 0 and has |.| in its radius).  Same tables bit for bit as through the
 // operators (launch digests, tools/gpu_p1_repeat_stress.py), without their round trips through the arena: a dozen per joint.
 template <int SZ>
-__device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, uint64_t key, const double* v) {
+__device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, pzkey_t key, const double* v) {
     if (lane == 0) out.keys[pos] = key;
 #pragma unroll
     for (int e = 0; e < SZ; e++) out.coef[((size_t)pos * SZ + e) * 64 + lane] = v[e];
@@ -267,7 +267,7 @@ __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars
     const int lane = c.w.w.lane, n = c.n, ax = cf.rb.axes[i];
     const double thr_sq = c.w.w.thr_sq;
     const bool active = c.w.active;
-    const uint64_t kk = 1ull << (2 * i), kc = 1ull << (5 * n + 2 * i), ks = 1ull << (7 * n + 2 * i);   // kk < kc < ks: the sorted order
+    const pzkey_t kk = pzkey_bit(2 * i), kc = pzkey_bit(5 * n + 2 * i), ks = pzkey_bit(7 * n + 2 * i);   // kk < kc < ks: the sorted order
     double cen[9], m0[9], m1[9], m2[9], t2[9];
     make_rotation(cen, js.cos_c, js.sin_c, ax, false);
     make_rotation(m0, js.cos_k, 0.0, ax, true);
@@ -339,7 +339,7 @@ __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars
     if (lane == 0) { c.w.w.cnt[R.id] = pos; if (with_rt) c.w.w.cnt[Rt.id] = pos; }
 }
 // PZsparse(centre, {k: a, e: b}) of a velocity / acceleration polynomial, simplify()
-__device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double cen, uint64_t key0, double a, uint64_t key1, double b) {
+__device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double cen, pzkey_t key0, double a, pzkey_t key1, double b) {
     const int lane = c.w.w.lane;
     const double thr = c.w.w.thr;
     const bool active = c.w.active;
@@ -400,7 +400,7 @@ __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
     for (int j = 0; j < 3; j++)
         if (ex2[j]) {
             const double v[3] = {j == 0 ? x[0] : 0.0, j == 1 ? x[1] : 0.0, j == 2 ? x[2] : 0.0};
-            jrs_put_row<3>(out, pos, lane, 1ull << ((j + 2) * n), v);
+            jrs_put_row<3>(out, pos, lane, pzkey_bit((j + 2) * n), v);
             pos++;
         }
     if (lane == 0) c.w.w.cnt[out.id] = pos;
@@ -420,12 +420,12 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
         if (i < n && cf.rb.axes[i] != 0) {
             const JrsScalars js = cf.mode == ARMOUR_MODE_ARMTD ? armtd_jrs_scalars(cf, bz[i], b, i, t_lane)   // (CMP/Trajectory.cu:29-61: offline tables)
                                                                : jrs_scalars(cf, bz[i], bz[n + i], bz[2 * n + i], i, t_lane);
-            const uint64_t kk = 1ull << (2 * i);
+            const pzkey_t kk = pzkey_bit(2 * i);
             jrs_rotation_direct_tv(c, i, js, rp, !kin_only);
             if (!kin_only) {
-                jrs_scalar_direct_tv(c, c.qd(i), js.qd_c, kk, js.qd_k, 1ull << (2 * n + i), js.qd_e);
-                jrs_scalar_direct_tv(c, c.qda(i), js.qd_c, kk, js.qd_k, 1ull << (3 * n + i), js.qda_e);
-                jrs_scalar_direct_tv(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, 1ull << (4 * n + i), js.qdd_e);
+                jrs_scalar_direct_tv(c, c.qd(i), js.qd_c, kk, js.qd_k, pzkey_bit(2 * n + i), js.qd_e);
+                jrs_scalar_direct_tv(c, c.qda(i), js.qd_c, kk, js.qd_k, pzkey_bit(3 * n + i), js.qda_e);
+                jrs_scalar_direct_tv(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, pzkey_bit(4 * n + i), js.qdd_e);
             }
         } else {
             tv::set_const(c.w, c.R(i), rp, nullptr);
@@ -464,7 +464,7 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
     TW& t = c.w;
     const int lane = t.w.lane;
     const int n = c.n, cnt = tv::uni(t.w.cnt[p.id]);
-    const uint64_t kmax = 1ull << (2 * n), lmax = 1ull << (5 * n), kmask = kmax - 1;
+    const pzkey_t kmax = pzkey_bit(2 * n), lmax = pzkey_bit(5 * n), kmask = kmax - 1;
     const size_t idx = ((size_t)b * c.J + l) * cf.T + t_lane;
     double* gens = cf.link_gens + (((size_t)b * cf.T + t_lane) * c.J + l) * 18;
     double g[18];
@@ -473,7 +473,7 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
     int nk = 0, ng = 0;
     const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
     for (int m0 = 0; m0 < cnt; m0 += 64) {
-        const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
+        const pzkey_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
         const int nn = min(64, cnt - m0);
         constexpr int kU = 8;   // monomials whose three rows are in flight together
         for (int q0 = 0; q0 < nn; q0 += kU) {
@@ -486,7 +486,7 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
 #pragma unroll
             for (int u = 0; u < kU; u++) {
                 if (q0 + u >= nn) break;
-                const uint64_t key = tv::readlane_u64(key_v, q0 + u);
+                const pzkey_t key = pzkey_readlane(key_v, q0 + u);
                 const double x = xs[u][0], y = xs[u][1], z = xs[u][2];
                 const bool has = t.active && (x != 0.0 || y != 0.0 || z != 0.0);
                 const bool isk = key < kmax;                               // (the class of a monomial is wave-uniform)
@@ -536,7 +536,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
     TW& t = c.w;
     const int lane = t.w.lane;
     const int n = c.n, T = cf.T;
-    const uint64_t kmax = 1ull << (2 * n);
+    const pzkey_t kmax = pzkey_bit(2 * n);
     Itv rho = {0.0, 0.0};
     double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
     for (int j = 0; j < n; j++) {
@@ -554,7 +554,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
         int nk = 0;
         const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
         for (int m0 = 0; m0 < cnt; m0 += 64) {
-            const uint64_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
+            const pzkey_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
             const int nn = min(64, cnt - m0);
             constexpr int kU = 16;   // coefficient rows in flight
             for (int q0 = 0; q0 < nn; q0 += kU) {
@@ -564,7 +564,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     if (q0 + u >= nn) break;
-                    const uint64_t key = tv::readlane_u64(key_v, q0 + u);
+                    const pzkey_t key = pzkey_readlane(key_v, q0 + u);
                     const double x = xs[u];
                     if (key < kmax) {   // (wave-uniform)
                         if (t.active && x != 0.0) {
@@ -595,7 +595,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 }
 
 // LDS: NW x { sort buffers skey[cap] | sidx[cap] | status | staging rows for a product's short operand } | count table | mailbox
-__host__ __device__ inline size_t tv_lds_fixed(int cap_key, int cap_raw) { return ((size_t)cap_key * 8 + (size_t)cap_raw * 2 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tv_lds_fixed(int cap_key, int cap_raw) { return ((size_t)cap_key * sizeof(pzkey_t) + (size_t)cap_raw * 2 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t tv_lds_fixed(int cap) { return tv_lds_fixed(cap, cap); }
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 __host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kTvMbWords) * sizeof(int) + 15) & ~(size_t)15; }
@@ -641,9 +641,9 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
     const int lw = min(c.wid, 3);   // (a helper wave has no buffers of its own: the address below is not used)
     const int stage_before = NP == 1 ? 0 : (lw > 0 ? cf.tv_stage_rows_other : 0) + (lw > 1 ? cf.tv_stage_rows : 0) + (lw > 2 ? cf.tv_stage_rows_other : 0);
     LDS_AS unsigned char* mine = lds + (size_t)lw * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
-    c.w.w.skey = (LDS_AS uint64_t*)mine;
-    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * 8);
-    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * 8 + (size_t)my_cap_raw * 2);
+    c.w.w.skey = (LDS_AS pzkey_t*)mine;
+    c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * sizeof(pzkey_t));
+    c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * sizeof(pzkey_t) + (size_t)my_cap_raw * 2);
     c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap_key, my_cap_raw));
     c.w.stage_rows = my_stage;
     LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NP) - tv_lds_shared();

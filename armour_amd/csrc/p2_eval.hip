@@ -108,10 +108,10 @@ int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsig
     lp.magic_O = div_magic(tb.O > 0 ? tb.O : 1); lp.magic_pp3 = div_magic(3 * lp.strideL);
     if (tb.Q >= (1 << 20)) { armour_set_error("more than 2^20 collision rows per problem"); return ARMOUR_ECAPACITY; }
     if (lp.strideL * 3 > P2_BLOCK * P2_TASK_ROUNDS) { armour_set_error("link PZ with %d monomials exceeds the P2 kernel's %d", lp.strideL, P2_BLOCK * P2_TASK_ROUNDS / 3); return ARMOUR_ECAPACITY; }
-    lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / 24), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
+    lp.pair_chunk = std::max(1, std::min(std::min(lp.max_pairs, P2_BLOCK / P2_SL), (P2_BLOCK * P2_TASK_ROUNDS) / (lp.strideL * 3)));
     if (lp.strideT > 32 * P2_TQ_ROUNDS) { armour_set_error("torque PZ with %d monomials exceeds the P2 kernel's %d", lp.strideT, 32 * P2_TQ_ROUNDS); return ARMOUR_ECAPACITY; }
-    const size_t col = ((size_t)lp.max_pairs * 24 + (size_t)lp.pair_chunk * lp.strideL * 24 + 4 * 64 * 4 + 64 * ARMOUR_MAX_FACTORS) * sizeof(double) + 4 * 64 * sizeof(int);
-    const size_t tq = (size_t)P2_TQ_ROWS * lp.strideT * 8 * sizeof(double);
+    const size_t col = ((size_t)lp.max_pairs * P2_SL + (size_t)lp.pair_chunk * lp.strideL * P2_SL + 4 * 64 * 4 + 64 * ARMOUR_MAX_FACTORS) * sizeof(double) + 4 * 64 * sizeof(int);
+    const size_t tq = (size_t)P2_TQ_ROWS * lp.strideT * P2_TQW * sizeof(double);
     const size_t lim = (size_t)2 * ARMOUR_MAX_FACTORS * 8 * sizeof(double);
     const size_t smem = 2 * sizeof(KPow) + std::max(std::max(col, tq), lim);
     if (smem > 64 * 1024) { armour_set_error("P2 kernel needs %zu B of LDS (link/torque monomial counts too large)", smem); return ARMOUR_ECAPACITY; }

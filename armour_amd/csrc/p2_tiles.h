@@ -19,6 +19,8 @@
 #define P2_TASK_ROUNDS 2   // (monomial, axis) slicing tasks a thread preloads per LDS pass
 #define P2_TQ_ROWS 8      // torque rows per block (32 monomial lanes each)
 #define P2_TQ_ROUNDS 4    // monomials per lane of a torque row (strideT <= 128)
+#define P2_SL (3 * (1 + ARMOUR_MAX_FACTORS))   // doubles of one sliced link monomial / one sliced link PZ: x[3], dx[ARMOUR_MAX_FACTORS][3] (24; 27 in the 8-factor build)
+#define P2_TQW (1 + ARMOUR_MAX_FACTORS)        // doubles of one sliced torque monomial: value and ARMOUR_MAX_FACTORS partials (8; 9)
 
 #ifndef P2_DFC_WAVES
 #define P2_DFC_WAVES 3
@@ -151,7 +153,7 @@ struct PassRegs {
 // 3 % slower; the same plus a fixed 9 plane slots per wave, so that the slicing overlaps the planes in flight, 15 % slower.)
 __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, int lt_first, int p0, int pc, PassRegs& pr) {
     const int tid = threadIdx.x;
-    const int per_pair = lp.strideL * 24, per_pair3 = lp.strideL * 3;
+    const int per_pair = lp.strideL * P2_SL, per_pair3 = lp.strideL * 3;
     const int ntask = pc * per_pair3;
 #pragma unroll
     for (int r = 0; r < P2_TASK_ROUNDS; r++) {
@@ -161,7 +163,7 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
             const int pi = fast_div(task, lp.magic_pp3), rem = task - pi * per_pair3, mo = rem / 3, e = rem - mo * 3;
             const size_t idx = (size_t)b * tb.J * tb.T + (lt_first + p0 + pi);
             pr.tcnt[r] = tb.link_count[idx] - mo;  // > 0: live monomial
-            pr.tdst[r] = pi * per_pair + mo * 24 + e;
+            pr.tdst[r] = pi * per_pair + mo * P2_SL + e;
             if (mo < tb.capL) {
                 pr.tkey[r] = tb.link_keys[idx * tb.capL + mo];
                 pr.tco[r] = tb.link_coeff[(idx * tb.capL + mo) * 3 + e];
@@ -169,8 +171,8 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
         }
     }
     pr.rc_cen = 0.0; pr.rc_ind = 0.0; pr.rc_cnt = 0;
-    if (tid < pc * 24) {
-        const int pi = tid / 24, c = tid - pi * 24, e = c % 3;
+    if (tid < pc * P2_SL) {
+        const int pi = tid / P2_SL, c = tid - pi * P2_SL, e = c % 3;
         const size_t idx = (size_t)b * tb.J * tb.T + (lt_first + p0 + pi);
         pr.rc_cnt = min(tb.link_count[idx], lp.strideL);
         if (c < 3) { pr.rc_cen = tb.link_center[idx * 3 + e]; pr.rc_ind = tb.link_indep[idx * 3 + e]; }
@@ -186,7 +188,7 @@ __device__ inline void load_pass(const P2Tables& tb, const P2Launch& lp, int b, 
 // after them can stay in flight while these are waited for (vmcnt counts in order and takes an immediate).
 __device__ inline void load_pass_uncond(const P2Tables& tb, const P2Launch& lp, int b, int lt_first, int pc, PassRegs& pr) {
     const int tid = threadIdx.x;
-    const int per_pair = lp.strideL * 24, per_pair3 = lp.strideL * 3;
+    const int per_pair = lp.strideL * P2_SL, per_pair3 = lp.strideL * 3;
     const int ntask = pc * per_pair3;
     const size_t idx0 = (size_t)b * tb.J * tb.T + lt_first;
 #pragma unroll
@@ -201,12 +203,12 @@ __device__ inline void load_pass_uncond(const P2Tables& tb, const P2Launch& lp, 
         pr.tkey[r] = tb.link_keys[idx * tb.capL + moc];
         pr.tco[r] = tb.link_coeff[(idx * tb.capL + moc) * 3 + e];
         pr.tcnt[r] = cnt - (valid ? mo : (1 << 20));  // > 0: live monomial (cnt <= capL, so a clamped mo is never live)
-        pr.tdst[r] = pi * per_pair + mo * 24 + e;
+        pr.tdst[r] = pi * per_pair + mo * P2_SL + e;
     }
-    const int tc = tid < pc * 24 ? tid : 0;
-    const int pi = tc / 24, c = tc - pi * 24, e = c % 3;
+    const int tc = tid < pc * P2_SL ? tid : 0;
+    const int pi = tc / P2_SL, c = tc - pi * P2_SL, e = c % 3;
     const size_t idx = idx0 + pi;
-    pr.rc_cnt = min(tb.link_count[idx], lp.strideL);  // used by threads < pc*24 only
+    pr.rc_cnt = min(tb.link_count[idx], lp.strideL);  // used by threads < pc*P2_SL only
     pr.rc_cen = tb.link_center[idx * 3 + e];            // used for the value column (c < 3) only
     pr.rc_ind = tb.link_indep[idx * 3 + e];
 }
@@ -239,9 +241,9 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
     const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
 #endif
     // ------------------------------------------------------------------ collision rows
-    double* sx = lds;                                               // [max_pairs][24]: x[3], dx[7][3]
-    double* terms = sx + (size_t)lp.max_pairs * 24;                 // [pair_chunk][strideL][24]
-    double* part = terms + (size_t)lp.pair_chunk * lp.strideL * 24; // [4][64][4] partial scans
+    double* sx = lds;                                               // [max_pairs][P2_SL]: x[3], dx[ARMOUR_MAX_FACTORS][3]
+    double* terms = sx + (size_t)lp.max_pairs * P2_SL;                 // [pair_chunk][strideL][P2_SL]
+    double* part = terms + (size_t)lp.pair_chunk * lp.strideL * P2_SL; // [4][64][4] partial scans
     int* pneg = reinterpret_cast<int*>(part + 4 * 64 * 4);          // [4][64]
     double* stage = part + 4 * 64 * 4 + 4 * 64 / 2;                 // [64][n] Jacobian staging tile
 
@@ -345,9 +347,9 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
     //    scan the planes.  The link-PZ table entries do not depend on k: when one pass covers all pairs they are
     //    loaded once, before the k-power table of the first point is waited for, so the fresh k (an HBM miss), the
     //    PZ tables (L2) and the planes are all in flight together.
-    const int per_pair = lp.strideL * 24;
+    const int per_pair = lp.strideL * P2_SL;
     if (MULTI && single_pass) load_pass(tb, lp, b, lt_first, 0, npairs, pr);
-    const double* xs = sx + (q_lt - lt_first) * 24;
+    const double* xs = sx + (q_lt - lt_first) * P2_SL;
     for (int s = 0; s < nsteps; s++) {
         KPow& kp = kp2[s & 1];
         const double k_cur = k_next;
@@ -363,7 +365,7 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
 #pragma unroll
             for (int r = 0; r < P2_TASK_ROUNDS; r++) {
                 if (pr.tcnt[r] > 0) {
-                    double o8[8];
+                    double o8[P2_TQW];
                     mono_all<WANT_J>(kp, pr.tkey[r], pr.tco[r], n, o8);
                     double* dst = terms + pr.tdst[r];
                     dst[0] = o8[0];
@@ -376,14 +378,14 @@ __device__ __forceinline__ void collision_block(const P2Tables& tb, const P2Laun
             if (EX) lds_barrier(); else __syncthreads();
             P2_STAMP(3);
             // ordered sum over monomials (the reference's accumulation order, RT/PZsparse.cu:420,470-472)
-            if (tid < pc * 24) {
-                const int pi = tid / 24, c = tid - pi * 24, out = c / 3, e2 = c - out * 3;
+            if (tid < pc * P2_SL) {
+                const int pi = tid / P2_SL, c = tid - pi * P2_SL, out = c / 3, e2 = c - out * 3;
                 double acc = (!EX || out == 0) ? pr.rc_cen : 0.0;  // (the unconditional loader fills rc_cen for every column)
                 const double* tp = terms + (size_t)pi * per_pair + c;
 #pragma unroll 4
-                for (int mo = 0; mo < pr.rc_cnt; mo++) acc += tp[mo * 24];
+                for (int mo = 0; mo < pr.rc_cnt; mo++) acc += tp[mo * P2_SL];
                 if (out == 0) acc = interval_center(acc, pr.rc_ind);
-                sx[(p0 + pi) * 24 + (out == 0 ? e2 : 3 + (out - 1) * 3 + e2)] = acc;
+                sx[(p0 + pi) * P2_SL + (out == 0 ? e2 : 3 + (out - 1) * 3 + e2)] = acc;
             }
             if (EX) lds_barrier(); else __syncthreads();
         }
@@ -509,7 +511,7 @@ __device__ __forceinline__ void torque_block(const P2Tables& tb, const P2Launch&
     double k_next = k_first;
     (void)lane; (void)wv; (void)T; (void)O; (void)Q; (void)m; (void)kp2; (void)lds; (void)g0; (void)jac0; (void)nsteps; (void)k_next;
     // ------------------------------------------------------------------ torque rows (row = t*n + j)
-    double* terms = lds;  // [P2_TQ_ROWS][strideT][8]
+    double* terms = lds;  // [P2_TQ_ROWS][strideT][P2_TQW]
     const int r = tid >> 5, ml = tid & 31;
     const int row = (role - lp.nbc) * P2_TQ_ROWS + r;
     const bool live = row < n * T;
@@ -543,8 +545,8 @@ __device__ __forceinline__ void torque_block(const P2Tables& tb, const P2Launch&
             for (int rr = 0; rr < P2_TQ_ROUNDS; rr++) {
                 const int mo = ml + rr * 32;
                 if (mo < cnt) {
-                    double* tp = terms + ((size_t)r * lp.strideT + mo) * 8;
-                    double o8[8];
+                    double* tp = terms + ((size_t)r * lp.strideT + mo) * P2_TQW;
+                    double o8[P2_TQW];
                     mono_all<WANT_J>(kp, tkey[rr], tco[rr], n, o8);
                     tp[0] = o8[0];
                     if (WANT_J) {
@@ -556,18 +558,18 @@ __device__ __forceinline__ void torque_block(const P2Tables& tb, const P2Launch&
         }
         __syncthreads();
         if (live && ml <= n) {
-            const double* tp = terms + (size_t)r * lp.strideT * 8 + ml;
+            const double* tp = terms + (size_t)r * lp.strideT * P2_TQW + ml;
             if (ml == 0) {
                 if (WANT_G) {
                     double cen = cen0;
 #pragma unroll 4
-                    for (int mo = 0; mo < cnt; mo++) cen += tp[mo * 8];
+                    for (int mo = 0; mo < cnt; mo++) cen += tp[mo * P2_TQW];
                     g[row] = interval_center(cen, ind0);
                 }
             } else if (WANT_J) {
                 double gr = 0.0;
 #pragma unroll 4
-                for (int mo = 0; mo < cnt; mo++) gr += tp[mo * 8];
+                for (int mo = 0; mo < cnt; mo++) gr += tp[mo * P2_TQW];
                 jac[(size_t)row * n + (ml - 1)] = gr;
             }
         }

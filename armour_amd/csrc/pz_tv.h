@@ -35,13 +35,13 @@ using pzw::Wave;
 #endif
 
 struct TPZ {
-    GLB_AS uint64_t* keys;
+    GLB_AS pzkey_t* keys;
     GLB_AS double* coef;  // [cap][sz][64]
     GLB_AS double* hdr;   // [4][sz][64]: indep, indep2, asum, centre
     int sz, cap, id;
 };
 struct TView {
-    const GLB_AS uint64_t* keys;
+    const GLB_AS pzkey_t* keys;
     const GLB_AS double* coef;
     const GLB_AS double* hdr;
     int cnt, stride, off, sz;  // stride = rows per monomial of the underlying PZ, off = first row of this view, sz = rows of the view
@@ -147,7 +147,7 @@ __device__ inline void st_hdr(const TPZ& p, int which, int e, int lane, double x
 // Result writer: keys by lane 0, coefficient rows by every lane (0 where the lane pruned the term), asum on the way.
 template <int SZ>
 struct Out {
-    GLB_AS uint64_t* keys;
+    GLB_AS pzkey_t* keys;
     GLB_AS double* coef;
     int cap, n, lane;
     double asum[SZ];
@@ -156,7 +156,7 @@ struct Out {
 #pragma unroll
         for (int e = 0; e < SZ; e++) asum[e] = 0.0;
     }
-    __device__ inline void emit(uint64_t key, const double* v) {
+    __device__ inline void emit(pzkey_t key, const double* v) {
         // no branches here (each one costs the walk a block of register moves behind it): a term beyond the capacity lands in the
         // slot's spare row block (tv_slot_bytes) -- finish() flags the overflow -- and every lane stores the wave-uniform key
         const int at = n < cap ? n : cap;
@@ -203,7 +203,7 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
 // `idxat(p)` = its generation index; `P` supplies
 //     struct Regs;  void load(int idx, Regs&)   -- issue the row loads of one raw term (idx is wave-uniform)
 //     void add(const Regs&, bool first)          -- accumulate it (first: start a new sum)
-//     void close(uint64_t key)                   -- the run of equal keys is complete: verdict + emit
+//     void close(pzkey_t key)                   -- the run of equal keys is complete: verdict + emit
 // Loads run U terms ahead of their use.
 #ifdef TV_PROFILE_FULL
 __device__ long long g_tvprof[8];  // [0] load phase, [1] process phase, [2] chunk prologue, [3] batches
@@ -215,13 +215,13 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
     // bookkeeping around each update: measured 230 instructions per raw term).  One readfirstlane makes the walk scalar.
     const int N = uni(N_), N0 = uni(N0_);   // the sorted terms [N0, N): a part of a walk shared with a helper wave starts at N0 > 0
     bool have = false;
-    uint64_t cur = 0;
+    pzkey_t cur = 0;
     for (int base = N0; base < N; base += WAVE) {
 #ifdef TV_PROFILE_FULL
         long long wp0 = clock64();
 #endif
         const int p = base + lane;
-        const uint64_t key_v = p < N ? keyat(p) : 0ull;
+        const pzkey_t key_v = p < N ? keyat(p) : 0ull;
         const int idx_v = p < N ? idxat(p) : 0;
         const int n = min(WAVE, N - base);
         // what a term's loads need -- which source, where its rows start -- is worked out for the chunk's 64 terms at once, one term per
@@ -266,7 +266,7 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
                 for (int v = 0; v < PB; v++) {
                     const int u = u0 + v;
                     if (l0 + u < n) {
-                        const uint64_t key = readlane_u64(key_v, l0 + u);
+                        const pzkey_t key = pzkey_readlane(key_v, l0 + u);
                         if (have && key != cur) { pol.close(cur); have = false; }
                         pol.accum(regs[u], pr[v], !have);
                         have = true; cur = key;
@@ -441,7 +441,7 @@ struct MulCtx {
 #pragma unroll
         for (int e = 0; e < SH::SZ; e++) { const double sum = acc[e] + p.c[e]; acc[e] = first ? p.c[e] : sum; }
     }
-    __device__ inline void close(uint64_t key) {
+    __device__ inline void close(pzkey_t key) {
         bool small;
         if constexpr (SH::SZ == 1) small = fabs(acc[0]) <= thr;
         else {
@@ -625,7 +625,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         MulCtx<SH, 0> cx;
         mul_ctx_init(cx, t, a, b, &o);
         for (int m0 = 0; m0 < b.cnt; m0 += WAVE) {
-            const uint64_t key_v = m0 + lane < b.cnt ? b.keys[m0 + lane] : 0ull;
+            const pzkey_t key_v = m0 + lane < b.cnt ? b.keys[m0 + lane] : 0ull;
             const int n = min(WAVE, b.cnt - m0);
             constexpr int kUc = SH::ASZ + SH::BSZ > 12 ? 4 : 8;
             for (int l0 = 0; l0 < n; l0 += kUc) {
@@ -634,7 +634,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
                 for (int u = 0; u < kUc; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
 #pragma unroll
                 for (int u = 0; u < kUc; u++)
-                    if (l0 + u < n) { typename MulCtx<SH, 0>::Prod pr; cx.prod(regs[u], pr); cx.accum(regs[u], pr, true); cx.close(readlane_u64(key_v, l0 + u)); }
+                    if (l0 + u < n) { typename MulCtx<SH, 0>::Prod pr; cx.prod(regs[u], pr); cx.accum(regs[u], pr, true); cx.close(pzkey_readlane(key_v, l0 + u)); }
             }
         }
 #pragma unroll
@@ -769,7 +769,7 @@ struct CrossCtx {
 #pragma unroll
         for (int e = 0; e < 6; e++) { const double sum = acc[e] + p.p6[e]; acc[e] = first ? p.p6[e] : sum; }
     }
-    __device__ inline void close(uint64_t key) {
+    __device__ inline void close(pzkey_t key) {
         // first stage for everybody: a product below the threshold goes to its product's radius.  In the common case that is all
         // six of them in every lane, and then nothing else happens (no difference, no stack entry)
         bool h[6], anyh = false;
@@ -1068,7 +1068,7 @@ struct LinCtx {
         }
         last = rk;
     }
-    __device__ inline void close(uint64_t key) {
+    __device__ inline void close(pzkey_t key) {
         if constexpr (CHAIN) {
             const int kf = last + 1 > 1 ? last + 1 : 1;
             if (kf < NS) stage_at(kf);
@@ -1236,7 +1236,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
     const double thr = t.w.thr, thr_sq = t.w.thr_sq;
     const bool active = t.active;
     for (int m0 = m_lo; m0 < m_hi; m0 += WAVE) {
-        const uint64_t key_v = m0 + lane < m_hi ? a.keys[m0 + lane] : 0ull;
+        const pzkey_t key_v = m0 + lane < m_hi ? a.keys[m0 + lane] : 0ull;
         const int n = min(WAVE, m_hi - m0);
         for (int l0 = 0; l0 < n; l0 += 16) {
             double x[16][3];
@@ -1266,7 +1266,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
                     const bool keep = anyc && !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
 #pragma unroll
                     for (int c = 0; c < 3; c++) { ra2[c] += (anyc && !keep) ? fabs(r[c]) : 0.0; r[c] = keep ? r[c] : 0.0; }
-                    if (__ballot(keep) != 0ull) o.emit(readlane_u64(key_v, l0 + u), r);
+                    if (__ballot(keep) != 0ull) o.emit(pzkey_readlane(key_v, l0 + u), r);
                 }
             }
         }
@@ -1392,7 +1392,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     const int S = uni(ch[HJ_S]), N = uni(ch[HJ_N]);
     const bool indirect = uni(ch[HJ_INDIRECT]) != 0;
     Wave sw = t.w;   // the PRIMARY's sorted terms
-    sw.skey = (LDS_AS uint64_t*)(uintptr_t)(unsigned)uni(ch[HJ_SKEY]);
+    sw.skey = (LDS_AS pzkey_t*)(uintptr_t)(unsigned)uni(ch[HJ_SKEY]);
     sw.sidx = (LDS_AS uint16_t*)(uintptr_t)(unsigned)uni(ch[HJ_SIDX]);
     const LDS_AS double* stage = (const LDS_AS double*)(uintptr_t)(unsigned)uni(ch[HJ_STAGE]);
     Out<3> o;
@@ -1443,7 +1443,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     } else {   // HK_CROSS_CONST: monomials [S, N) of the operand
         LDS_AS int* sg = ch + HJ_SEG0 + HJ_SEG_WORDS;
         TView a = hj_seg_view(ch, 0, 3);
-        a.keys = lds_ld_ptr<const GLB_AS uint64_t>(&sg[0]);
+        a.keys = lds_ld_ptr<const GLB_AS pzkey_t>(&sg[0]);
         double sA[3], sB[3];
         int cA[3], cB[3];
 #pragma unroll
@@ -1462,7 +1462,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     // ... and once the primary has finished its part: our rows behind its n0
     hj_wait(t, &ch[HJ_N0SEQ], t.hseq);
     const int n0 = uni(ch[HJ_N0]), cap = uni(ch[HJ_OUT_CAP]);
-    GLB_AS uint64_t* ok = lds_ld_ptr<GLB_AS uint64_t>(&ch[HJ_OUT_KEYS]);
+    GLB_AS pzkey_t* ok = lds_ld_ptr<GLB_AS pzkey_t>(&ch[HJ_OUT_KEYS]);
     GLB_AS double* oc = lds_ld_ptr<GLB_AS double>(&ch[HJ_OUT_COEF]);
     const int room = cap - n0 > 0 ? cap - n0 : 0, ncopy = nh < room ? nh : room;   // (an overflow of the result is flagged by the primary's finish())
     for (int m = lane; m < ncopy; m += WAVE) ok[n0 + m] = tmp.keys[m];

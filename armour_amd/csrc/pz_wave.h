@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pz_key.h"
+
 // Synchronisation INSIDE an operator is wave-local: every operator runs on one 64-lane wave, whose LDS and memory
 // operations execute in order, so draining the wave's outstanding loads / stores / LDS traffic is all that the lanes
 // need to see each other's data.  (With one wave per block this is what __syncthreads() amounted to; written this way
@@ -69,7 +71,7 @@ enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_
 
 // A PZ slot (all fields wave-uniform).  id indexes the per-wave LDS count table.
 struct PZ {
-    GLB_AS uint64_t* keys;
+    GLB_AS pzkey_t* keys;
     GLB_AS double* coef;  // [cap][sz]
     LDS_AS double* cen;   // [sz]
     LDS_AS double* ind;   // [sz] independent (interval) radius, nominal inertial parameters
@@ -79,7 +81,7 @@ struct PZ {
 
 // Read view of a PZ or of one entry of it (RT/PZsparse.cu:678-697 operator()(r,c) without the copy).
 struct View {
-    const GLB_AS uint64_t* keys;
+    const GLB_AS pzkey_t* keys;
     const GLB_AS double* coef;
     const LDS_AS double* cen;
     const LDS_AS double* ind;
@@ -88,7 +90,7 @@ struct View {
 };
 
 struct Wave {
-    LDS_AS uint64_t* skey;   // LDS [cap_key]: raw keys (bitonic / linear-combination merge) or the operands' key lists (product merge)
+    LDS_AS pzkey_t* skey;   // LDS [cap_key]: raw keys (bitonic / linear-combination merge) or the operands' key lists (product merge)
     LDS_AS uint16_t* sidx;   // LDS [cap_raw]: sorted permutation of the raw terms
     LDS_AS int* cnt;         // LDS per-slot monomial counts
     int cap_raw, cap_key;
@@ -188,7 +190,7 @@ __device__ inline void bitonic_sort(const Wave& w, int P) {
             // (the pairs of one pass are disjoint); the loop is LDS-latency bound otherwise
             for (int t0 = w.lane; t0 < half; t0 += 4 * WAVE) {
                 int ii[4], ll[4];
-                uint64_t ka[4], kb[4];
+                pzkey_t ka[4], kb[4];
                 uint16_t ia[4], ib[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -212,7 +214,7 @@ __device__ inline void bitonic_sort(const Wave& w, int P) {
 }
 
 // number of a[0..n) strictly below t / not above t (a ascending, in LDS)
-__device__ inline int lower_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t t) {
+__device__ inline int lower_bound_lds(const LDS_AS pzkey_t* a, int n, pzkey_t t) {
     int lo = 0, len = n;
     while (len > 0) {
         const int half = len >> 1;
@@ -220,7 +222,7 @@ __device__ inline int lower_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t 
     }
     return lo;
 }
-__device__ inline int upper_bound_lds(const LDS_AS uint64_t* a, int n, uint64_t t) {
+__device__ inline int upper_bound_lds(const LDS_AS pzkey_t* a, int n, pzkey_t t) {
     int lo = 0, len = n;
     while (len > 0) {
         const int half = len >> 1;
@@ -248,11 +250,10 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             // (Eval::kCountMax: up to a full wave for products, whose merge has per-level fixed costs; a handful of terms
             // for sums, whose one-search merge is cheaper than ~200 cycles per broadcast step from there on)
             PROF_T0
-            const uint64_t key = w.lane < N ? ev.key(w.lane) : ~0ull;
-            const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+            const pzkey_t key = w.lane < N ? ev.key(w.lane) : PZKEY_MAX;
             int rank = 0;
             for (int l = 0; l < N; l++) {
-                const uint64_t kl = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)khi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)klo, l);
+                const pzkey_t kl = pzkey_readlane(key, l);
                 rank += (kl < key || (kl == key && l < w.lane)) ? 1 : 0;
             }
             if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
@@ -265,7 +266,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             {
                 int bad = 0;
                 for (int p = w.lane; p < N; p += WAVE) {
-                    const uint64_t kp = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
+                    const pzkey_t kp = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
                     if (p > 0 && (indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) > kp) bad = 1;
                     if (p > 0 && (indirect ? ev.key_lds(w, w.sidx[p - 1]) : w.skey[p - 1]) == kp && w.sidx[p - 1] > w.sidx[p]) bad |= 4;
                     if (kp != ev.key(w.sidx[p])) bad |= 2;
@@ -284,7 +285,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             const int P = next_pow2(N);
             { PROF_T0
             for (int p = w.lane; p < P; p += WAVE) {
-                w.skey[p] = p < N ? ev.key(p) : ~0ull;
+                w.skey[p] = p < N ? ev.key(p) : PZKEY_MAX;
                 w.sidx[p] = (uint16_t)p;
             }
             WSYNC();
@@ -299,7 +300,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
 
 // Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
 // and write the result to `out` (RT/PZsparse.cu:284-350).  base_ind / base_ind2 = independent parts before pruning.
-// Eval: uint64_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
+// Eval: pzkey_t key(int idx) const; void coef(int idx, double* c /*[SZ]*/) const.
 template <int SZ, class Eval>
 __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
     int emitted = 0;
@@ -313,7 +314,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
         for (int base = 0; base < N; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false;
-            uint64_t key = 0;
+            pzkey_t key = 0;
             double acc[SZ];
 #ifdef P1_PROFILE
             long long e_t = clock64();
@@ -417,9 +418,9 @@ struct LinEval {
     }
     // (a source picked by a per-lane index is picked with selects: `s[k]` with a run-time k puts the whole array into scratch
     //  memory, and every access becomes a memory round trip)
-    __device__ inline uint64_t key(int idx) const {
+    __device__ inline pzkey_t key(int idx) const {
         const int k = seg_of(idx);
-        const GLB_AS uint64_t* keys = s[0].v.keys;
+        const GLB_AS pzkey_t* keys = s[0].v.keys;
         int first = off[0];
 #pragma unroll
         for (int q = 1; q < NS; q++) { const bool me = (k == q); keys = me ? s[q].v.keys : keys; first = me ? off[q] : first; }
@@ -452,7 +453,7 @@ struct LinEval {
         WSYNC();
         for (int idx = w.lane; idx < N; idx += WAVE) {
             const int k = seg_of(idx);
-            const uint64_t ky = w.skey[idx];
+            const pzkey_t ky = w.skey[idx];
             int first = off[0];
 #pragma unroll
             for (int q = 1; q < NS; q++) first = (k == q) ? off[q] : first;
@@ -460,7 +461,7 @@ struct LinEval {
 #pragma unroll
             for (int k2 = 0; k2 < NS; k2++) {
                 if (k2 == k) continue;
-                const LDS_AS uint64_t* run = w.skey + off[k2];
+                const LDS_AS pzkey_t* run = w.skey + off[k2];
                 const int len = off[k2 + 1] - off[k2];
                 rank += (k2 < k) ? upper_bound_lds(run, len, ky) : lower_bound_lds(run, len, ky);
             }
@@ -470,7 +471,7 @@ struct LinEval {
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_LINMERGE)
         return true;
     }
-    __device__ inline uint64_t key_lds(const Wave& w, int idx) const { return w.skey[idx]; }
+    __device__ inline pzkey_t key_lds(const Wave& w, int idx) const { return w.skey[idx]; }
     __device__ inline void coef(int idx, double* c) const {
         const int k = seg_of(idx);
         const GLB_AS double* cf = s[0].v.coef;
@@ -604,7 +605,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
         for (int base = 0; base < N; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false, pruned = false;
-            uint64_t key = 0;
+            pzkey_t key = 0;
             double acc[SZ];
 #pragma unroll
             for (int e = 0; e < SZ; e++) acc[e] = 0.0;
@@ -717,7 +718,7 @@ struct MulEval {
         i = (int)(((unsigned long long)t * mb1_magic) >> 32);  // a division by a run-time value is ~30 instructions, per term
         j = t - i * mb1;
     }
-    __device__ inline uint64_t key(int idx) const {
+    __device__ inline pzkey_t key(int idx) const {
         int i, j;
         split(idx, i, j);
         return (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);  // plain u64 add (RT/PZsparse.cu:938-940)
@@ -768,7 +769,7 @@ struct MulEval {
         int levels = 0;
         while ((1 << levels) < nr) levels++;
         int cur = levels & 1;  // the last level writes buffer 0 = (skey, sidx) as the reduce pass expects them
-        LDS_AS uint64_t* kb[2] = {w.skey, w.skey + N};
+        LDS_AS pzkey_t* kb[2] = {w.skey, w.skey + N};
         LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
         // t / d1 by multiplication: exact while t * d1 < 2^32 (both are below 2^13 here)
         const unsigned long long magic = magic_u32(d1);
@@ -787,13 +788,13 @@ struct MulEval {
             const int rl = d1 << lv;  // run r of this level holds the positions q with q + 1 in [r*rl, (r+1)*rl)
             int top = 1;
             while (top * 2 <= rl) top *= 2;
-            const LDS_AS uint64_t* K = kb[cur];
+            const LDS_AS pzkey_t* K = kb[cur];
             const LDS_AS uint16_t* V = vb[cur];
-            LDS_AS uint64_t* Ko = kb[cur ^ 1];
+            LDS_AS pzkey_t* Ko = kb[cur ^ 1];
             LDS_AS uint16_t* Vo = vb[cur ^ 1];
             for (int p0 = w.lane; p0 < N; p0 += WAVE * U) {
                 int ss[U], len[U], cnt[U], dst[U];
-                uint64_t tg[U], ky[U];
+                pzkey_t tg[U], ky[U];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -808,12 +809,12 @@ struct MulEval {
                     ss[u] = len[u] > 0 ? sb : 0;
                     ky[u] = K[BIDX(w, pc, N, 1)];
                     // count the sibling's keys below ky -- and its equal key too if the sibling's term goes first on a tie
-                    tg[u] = ky[u] + (uint64_t)(((r & 1) != 0) == by_a);
+                    tg[u] = ky[u] + (pzkey_t)(((r & 1) != 0) == by_a ? 1 : 0);
                     cnt[u] = 0;
                     dst[u] = min(s0, sb) + (pc - s0);
                 }
                 for (int step = top; step > 0; step >>= 1) {
-                    uint64_t v[U];
+                    pzkey_t v[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) v[u] = K[BIDX(w, ss[u] + max(min(cnt[u] + step, len[u]), 1) - 1, N, 2)];
 #pragma unroll
@@ -847,22 +848,22 @@ struct MulEval {
         return false;
 #endif
         PROF_T0
-        const GLB_AS uint64_t* lk = a_short ? b.keys : a.keys;
-        const GLB_AS uint64_t* sk = a_short ? a.keys : b.keys;
+        const GLB_AS pzkey_t* lk = a_short ? b.keys : a.keys;
+        const GLB_AS pzkey_t* sk = a_short ? a.keys : b.keys;
         for (int t = w.lane; t < nl; t += WAVE) w.skey[t] = t ? lk[t - 1] : 0ull;
         if (w.lane < ns) w.skey[nl + w.lane] = w.lane ? sk[w.lane - 1] : 0ull;
         WSYNC();
-        const LDS_AS uint64_t* L = w.skey;
-        const LDS_AS uint64_t* S = w.skey + nl;
+        const LDS_AS pzkey_t* L = w.skey;
+        const LDS_AS pzkey_t* S = w.skey + nl;
         for (int idx = w.lane; idx < N; idx += WAVE) {
             int i, j;
             split(idx, i, j);
             const int r = a_short ? i : j, pos = a_short ? j : i;
-            const uint64_t ky = S[r] + L[pos];
+            const pzkey_t ky = S[r] + L[pos];
             int rank = pos - 1;  // the (centre, centre) term sorts first and is not a monomial
             for (int r2 = 0; r2 < ns; r2++) {
                 if (r2 == r || ky < S[r2]) continue;
-                const uint64_t tgt = ky - S[r2];
+                const pzkey_t tgt = ky - S[r2];
                 rank += (r2 < r) ? upper_bound_lds(L, nl, tgt) : lower_bound_lds(L, nl, tgt);
             }
             w.sidx[rank] = (uint16_t)idx;
@@ -871,7 +872,7 @@ struct MulEval {
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
         return true;
     }
-    __device__ inline uint64_t key_lds(const Wave& w, int idx) const {
+    __device__ inline pzkey_t key_lds(const Wave& w, int idx) const {
         int i, j;
         split(idx, i, j);
         const bool a_short = a.cnt <= b.cnt;
@@ -937,7 +938,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
     for (int base = 0; base < N; base += WAVE) {
         const int p = base + w.lane;
         bool keep = false, pruned = false;
-        uint64_t key = 0;
+        pzkey_t key = 0;
         double acc[SZ];
         if (p < N) {
             key = ev.key(p);
@@ -1093,7 +1094,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
         for (int base = 0; base < N; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false;
-            uint64_t key = 0;
+            pzkey_t key = 0;
             double u[3] = {0.0, 0.0, 0.0};
             if (p < N) {
                 key = indirect ? ev.key_lds(w, w.sidx[p]) : w.skey[p];
@@ -1215,7 +1216,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a
         const int m = base + w.lane;
         bool keep = false;
         double r[3] = {0, 0, 0};
-        uint64_t key = 0;
+        pzkey_t key = 0;
         if (m < a.cnt) {
             key = a.keys[m];
             const GLB_AS double* x = a.coef + (size_t)m * a.stride + a.off;

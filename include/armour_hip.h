@@ -147,6 +147,9 @@ void armour_free_pinned(void* p);
 /* bytes of device memory free / in all on `device` as the runtime reports them (hipMemGetInfo): what a caller sizes
  * ARMOUR_OPT_P1_WORK_MEMORY_MB against; either pointer may be NULL */
 int armour_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
+/* ARMOUR_MAX_FACTORS this library was built with: 7 (the shipped library: the reference's 64-bit monomial key, RT/PZsparse.h:8-21) or 8
+ * (libarmour_hip_k128.so: 128-bit keys; every struct of armour_types.h that holds per-factor arrays is laid out for 8 there) */
+int armour_abi_max_factors(void);
 int armour_set_option(ArmourPlanner* h, int32_t option, double value);
 /* armour_get_option: the current value of an option of this handle (status ARMOUR_EINVAL for an unknown option) */
 int armour_get_option(ArmourPlanner* h, int32_t option, double* value);

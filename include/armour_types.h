@@ -22,7 +22,15 @@ extern "C" {
 #endif
 
 #define ARMOUR_MAX_JOINTS 9   /* links incl. fixed joints at the end of the chain (RT/KinovaInfo.h: 8; CMP/FetchInfo.h: 9) */
-#define ARMOUR_MAX_FACTORS 7  /* 9 bits of monomial key per factor: 7 factors fill a u64 (RT/PZsparse.h:8-21) */
+/* 9 bits of monomial key per factor: 7 factors fill the reference's u64 key (RT/PZsparse.h:8-21), and that is what the shipped
+ * library is built for.  A build with -DARMOUR_KEY128 (make -C armour_amd/csrc k128: libarmour_hip_k128.so; make -C oracle k128) carries
+ * 128-bit monomial keys -- the same field order, LSB first, 9 bits per factor -- and holds 8 factors (BASELINE configs[4]'s "8-DOF");
+ * every array below grows with ARMOUR_MAX_FACTORS, so the two builds are two ABIs: armour_abi_max_factors() tells a loader which. */
+#if defined(ARMOUR_KEY128)
+#define ARMOUR_MAX_FACTORS 8
+#else
+#define ARMOUR_MAX_FACTORS 7
+#endif
 #define ARMOUR_OBS_DOUBLES 12 /* one obstacle = column-major Z=[c g1 g2 g3] (KSI/uarmtd_planner.m:178) */
 #define ARMOUR_NUM_PLANES 36  /* C(9,2) generator pairs of a buffered obstacle (RT/CollisionChecking.h:6-7) */
 

@@ -126,10 +126,10 @@ struct Problem {
     ArmourParams pr;
     ArmourUltimateBound ub;
     int T, J, n, O = 0;
-    double q0[7], qd0[7], qdd0[7], q_des[7], Tqd0[7], TTqdd0[7];
+    double q0[ARMOUR_MAX_FACTORS], qd0[ARMOUR_MAX_FACTORS], qdd0[ARMOUR_MAX_FACTORS], q_des[ARMOUR_MAX_FACTORS], Tqd0[ARMOUR_MAX_FACTORS], TTqdd0[ARMOUR_MAX_FACTORS];
     std::vector<double> obstacles; /* O*12 */
     /* Bezier k-independent extrema (RT/Trajectory.cu:36-58) */
-    double qx1[7], qx2[7], qm1[7], qm2[7], vx1[7], vx2[7], vm1[7], vm2[7], ax1[7], ax2[7], am1[7], am2[7];
+    double qx1[ARMOUR_MAX_FACTORS], qx2[ARMOUR_MAX_FACTORS], qm1[ARMOUR_MAX_FACTORS], qm2[ARMOUR_MAX_FACTORS], vx1[ARMOUR_MAX_FACTORS], vx2[ARMOUR_MAX_FACTORS], vm1[ARMOUR_MAX_FACTORS], vm2[ARMOUR_MAX_FACTORS], ax1[ARMOUR_MAX_FACTORS], ax2[ARMOUR_MAX_FACTORS], am1[ARMOUR_MAX_FACTORS], am2[ARMOUR_MAX_FACTORS];
     /* JRS PZs, index [i*T + t] */
     std::vector<PZ> R, R_t, qd_des, qda_des, qdda_des;
     std::vector<PZ> links, u_nom, u_nom_int;
@@ -141,7 +141,7 @@ struct Problem {
     /* ARMTD comparison mode (CMP/ = kinova_planner_realtime_armtd_comparison): constant-acceleration curve, offline JRS tables */
     bool armtd = false;
     std::vector<double> jrs; /* [n][6][T]: c,g,r of cos then of sin (CMP/armtd_main.cu:76-96) */
-    double k_range_a[7];     /* per-joint k_range read with the tables (:97) */
+    double k_range_a[ARMOUR_MAX_FACTORS];     /* per-joint k_range read with the tables (:97) */
 };
 
 /* RT/Trajectory.cu:15-61 */
@@ -200,14 +200,14 @@ static void make_poly_zono(Problem& P, Ctx& cx, int s_ind) {
         cos_c += getCenter(cos_rad);
         cos_rad = cos_rad - getCenter(cos_rad);
         const double cos_coeff[2] = {-kd_c * kr * std::sin(q_c), getRadius(cos_rad)};
-        const uint64_t cos_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_cosqe(i)};
+        const okey_t cos_keys[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_cosqe(i)};
         /* 1.b sin(q_des) (:120-127) */
         double sin_c = std::sin(q_c);
         Interval sin_rad = q_rad * std::cos(q_c) - (0.5 * isin(q_c + kint + q_rad)) * sqr(q_rad + kint);
         sin_c += getCenter(sin_rad);
         sin_rad = sin_rad - getCenter(sin_rad);
         const double sin_coeff[2] = {kd_c * kr * std::cos(q_c), getRadius(sin_rad)};
-        const uint64_t sin_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_sinqe(i)};
+        const okey_t sin_keys[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_sinqe(i)};
 
         PZ Ri = pz_rpy(P.rb.rots[3 * i], P.rb.rots[3 * i + 1], P.rb.rots[3 * i + 2]);
         if (P.rb.axes[i] != 0)
@@ -228,10 +228,10 @@ static void make_poly_zono(Problem& P, Ctx& cx, int s_ind) {
         const double qd_c = (ki_lb + ki_ub) * 0.5;
         {
             const double co[2] = {kd_c, kd_r + ki_r + P.ub.qde};
-            const uint64_t ke[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_qde(i)};
+            const okey_t ke[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_qde(i)};
             P.qd_des[i * T + s_ind] = pz_scalar_poly(cx, qd_c, co, ke, 2);
             const double co2[2] = {kd_c, kd_r + ki_r + P.ub.qdae};
-            const uint64_t ke2[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_qdae(i)};
+            const okey_t ke2[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_qdae(i)};
             P.qda_des[i * T + s_ind] = pz_scalar_poly(cx, qd_c, co2, ke2, 2);
         }
         /* Part 3: qdd_des (:189-243) */
@@ -251,7 +251,7 @@ static void make_poly_zono(Problem& P, Ctx& cx, int s_ind) {
         const double qdd_c = (ki_lb + ki_ub) * 0.5;
         {
             const double co[2] = {kd_c, kd_r + ki_r + P.ub.qddae};
-            const uint64_t ke[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_qddae(i)};
+            const okey_t ke[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_qddae(i)};
             P.qdda_des[i * T + s_ind] = pz_scalar_poly(cx, qdd_c, co, ke, 2);
         }
     }
@@ -275,13 +275,13 @@ static void make_poly_zono_armtd(Problem& P, Ctx& cx, int t_ind) {
         cos_coeff[0] = cos_q0 * g_cos[t_ind] - sin_q0 * g_sin[t_ind];
         cos_coeff[1] = std::fabs(cos_q0) * r_cos[t_ind] + std::fabs(sin_q0) * r_sin[t_ind];
         cos_coeff[1] *= 4.0;
-        const uint64_t cos_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_cosqe(i)};
+        const okey_t cos_keys[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_cosqe(i)};
         const double sin_c = cos_q0 * c_sin[t_ind] + sin_q0 * c_cos[t_ind];
         double sin_coeff[2];
         sin_coeff[0] = cos_q0 * g_sin[t_ind] + sin_q0 * g_cos[t_ind];
         sin_coeff[1] = std::fabs(cos_q0) * r_sin[t_ind] + std::fabs(sin_q0) * r_cos[t_ind];
         sin_coeff[1] *= 4.0;
-        const uint64_t sin_keys[2] = {(uint64_t)1 << kl.shift_k(i), (uint64_t)1 << kl.shift_sinqe(i)};
+        const okey_t sin_keys[2] = {(okey_t)1 << kl.shift_k(i), (okey_t)1 << kl.shift_sinqe(i)};
         PZ Ri = pz_rpy(P.rb.rots[3 * i], P.rb.rots[3 * i + 1], P.rb.rots[3 * i + 2]);
         if (P.rb.axes[i] != 0)
             Ri = mul(cx, Ri, pz_rotation(cx, cos_c, cos_coeff, cos_keys, 2, sin_c, sin_coeff, sin_keys, 2, P.rb.axes[i]));
@@ -353,7 +353,7 @@ static void armtd_state_extremum(const Problem& P, const double* k, double* extr
 static PZ make_link_box(Problem& P, Ctx& cx, int i) {
     PZ comp[3];
     for (int j = 0; j < 3; j++) {
-        const uint64_t key = (uint64_t)1 << (j == 0 ? cx.kl.shift_qde(0) : j == 1 ? cx.kl.shift_qdae(0) : cx.kl.shift_qddae(0));
+        const okey_t key = (okey_t)1 << (j == 0 ? cx.kl.shift_qde(0) : j == 1 ? cx.kl.shift_qdae(0) : cx.kl.shift_qddae(0));
         const double g = P.rb.link_zonotope_generators[3 * i + j];
         comp[j] = pz_scalar_poly(cx, P.rb.link_zonotope_center[3 * i + j], &g, &key, 1);
     }
@@ -787,7 +787,7 @@ void oracle_pz_get(void* h, int which, int i, int t, double* center, double* ind
     const int n = p.sz();
     for (int e = 0; e < n; e++) { center[e] = p.center[e]; indep[e] = p.indep[e]; }
     for (size_t m = 0; m < p.poly.size(); m++) {
-        keys[m] = p.poly[m].key;
+        keys[m] = (uint64_t)p.poly[m].key;   /* (tables returned here hold k-only monomials: below 2^(2n)) */
         for (int e = 0; e < n; e++) coeffs[m * n + e] = p.poly[m].c[e];
     }
 }
@@ -847,7 +847,7 @@ int oracle_pz_op(int op, int nops, const int* sz, const int* cnt, const uint64_t
     const int n = (int)out.poly.size(), osz = out.sz();
     if (n > out_cap) return -1;
     for (int m = 0; m < n; m++) {
-        out_keys[m] = out.poly[m].key;
+        out_keys[m] = (uint64_t)out.poly[m].key;
         for (int e = 0; e < osz; e++) out_coef[(size_t)m * osz + e] = out.poly[m].c[e];
     }
     out_misc[0] = n; out_misc[1] = osz; out_misc[2] = cx.st.min_margin;
@@ -856,5 +856,6 @@ int oracle_pz_op(int op, int nops, const int* sz, const int* cnt, const uint64_t
 }
 double oracle_min_margin(void* h) { return ((Problem*)h)->st.min_margin; }
 int oracle_max_threads(void) { return omp_get_max_threads(); }
+int oracle_abi_max_factors(void) { return ARMOUR_MAX_FACTORS; }   /* 7: u64 keys; 8: the -DARMOUR_KEY128 build */
 
 }  // extern "C"

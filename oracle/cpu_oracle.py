@@ -10,10 +10,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# ARMOUR_KEY128=1 in the environment selects the second ABI of include/armour_types.h for the whole process -- 128-bit monomial keys, room for
+# 8 factors: liboracle_k128.so here, libarmour_hip_k128.so in armour_amd/_lib.py (tests/test_key128.py runs in a process of its own)
+KEY128 = os.environ.get("ARMOUR_KEY128", "0") not in ("", "0")
+_LIB_PATH = os.path.join(_HERE, "liboracle_k128.so" if KEY128 else "liboracle.so")
 
-MAXJ = 9   # ARMOUR_MAX_JOINTS
-MAXF = 7   # ARMOUR_MAX_FACTORS
+MAXJ = 9                    # ARMOUR_MAX_JOINTS
+MAXF = 8 if KEY128 else 7   # ARMOUR_MAX_FACTORS
 
 
 class ArmourRobot(C.Structure):
@@ -87,6 +90,7 @@ def lib():
                                    dp, dp, dp, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_uint64), dp, dp]
         L.oracle_min_margin.argtypes = [C.c_void_p]
         L.oracle_min_margin.restype = C.c_double
+        assert L.oracle_abi_max_factors() == MAXF, "oracle library and struct mirrors disagree on ARMOUR_MAX_FACTORS"
         _lib = L
     return _lib
 

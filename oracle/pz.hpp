@@ -29,6 +29,14 @@
 
 namespace oracle {
 
+/* monomial key: the reference's u64 (RT/PZsparse.h:23-35); a -DARMOUR_KEY128 build widens it to 128 bits for an 8-factor arm, which the
+ * reference itself cannot represent -- same packing, same plain integer addition of keys (RT/PZsparse.cu:938-940) */
+#if defined(ARMOUR_KEY128)
+typedef unsigned __int128 okey_t;
+#else
+typedef uint64_t okey_t;
+#endif
+
 /* ---- key layout: RT/PZsparse.h:23-40 (MOVE_BIT_INC / DEGREE_MASK), generalised to n factors ---- */
 struct KeyLayout {
     int n = 7;
@@ -39,14 +47,14 @@ struct KeyLayout {
     int shift_qddae(int j) const { return 4 * n + j; }
     int shift_cosqe(int j) const { return 5 * n + 2 * j; }
     int shift_sinqe(int j) const { return 7 * n + 2 * j; }
-    uint64_t max_hash_dependent_k_only() const { return (uint64_t)1 << (2 * n); }       /* PZsparse.h:37 */
-    uint64_t max_hash_dependent_k_links_only() const { return (uint64_t)1 << (5 * n); } /* PZsparse.h:39 */
-    uint64_t dependent_k_mask() const { return max_hash_dependent_k_only() - 1; }       /* PZsparse.h:40 */
-    int k_degree(uint64_t key, int j) const { return (int)((key >> (2 * j)) & 3); }     /* PZsparse.cu:578-585 */
+    okey_t max_hash_dependent_k_only() const { return (okey_t)1 << (2 * n); }       /* PZsparse.h:37 */
+    okey_t max_hash_dependent_k_links_only() const { return (okey_t)1 << (5 * n); } /* PZsparse.h:39 */
+    okey_t dependent_k_mask() const { return max_hash_dependent_k_only() - 1; }       /* PZsparse.h:40 */
+    int k_degree(okey_t key, int j) const { return (int)((key >> (2 * j)) & 3); }     /* PZsparse.cu:578-585 */
 };
 
 struct Mono {
-    uint64_t key;
+    okey_t key;
     double c[9];
 };
 
@@ -114,7 +122,7 @@ inline void simplify(Ctx& cx, PZ& p) {
     size_t i = 0;
     while (i < p.poly.size()) {
         size_t j;
-        const uint64_t key = p.poly[i].key;
+        const okey_t key = p.poly[i].key;
         for (j = i + 1; j < p.poly.size(); j++) {
             if (p.poly[j].key != key) break;
             for (int e = 0; e < n; e++) p.poly[i].c[e] += p.poly[j].c[e];
@@ -136,7 +144,7 @@ inline void simplify(Ctx& cx, PZ& p) {
 }
 
 /* PZsparse.cu:120-136: 1x1 PZ from (center, coeffs, keys) */
-inline PZ pz_scalar_poly(Ctx& cx, double center, const double* coeff, const uint64_t* keys, int m) {
+inline PZ pz_scalar_poly(Ctx& cx, double center, const double* coeff, const okey_t* keys, int m) {
     PZ p(1, 1);
     p.center[0] = center;
     for (int i = 0; i < m; i++) {
@@ -180,8 +188,8 @@ inline void make_rotation(double* Rm, double cosE, double sinE, int axis, bool f
 }
 
 /* PZsparse.cu:179-205: 3x3 rotation PZ about `axis` from the cos / sin 1x1 polynomial data */
-inline PZ pz_rotation(Ctx& cx, double cos_c, const double* cos_coeff, const uint64_t* cos_keys, int cm,
-                      double sin_c, const double* sin_coeff, const uint64_t* sin_keys, int sm, int axis) {
+inline PZ pz_rotation(Ctx& cx, double cos_c, const double* cos_coeff, const okey_t* cos_keys, int cm,
+                      double sin_c, const double* sin_coeff, const okey_t* sin_keys, int sm, int axis) {
     PZ p(3, 3);
     make_rotation(p.center, cos_c, sin_c, axis, false);
     for (int i = 0; i < cm; i++) {
@@ -242,7 +250,7 @@ inline void slice_value(const Ctx& cx, const PZ& p, const double* factor, double
     for (const Mono& it : p.poly) {
         double t[9];
         for (int e = 0; e < n; e++) t[e] = it.c[e];
-        if (it.key < ((uint64_t)1 << (2 * cx.kl.n))) {
+        if (it.key < ((okey_t)1 << (2 * cx.kl.n))) {
             for (int j = 0; j < cx.kl.n; j++) {
                 const double pw = std::pow(factor[j], (double)cx.kl.k_degree(it.key, j));
                 for (int e = 0; e < n; e++) t[e] *= pw;
@@ -265,7 +273,7 @@ inline void slice_gradient(const Ctx& cx, const PZ& p, const double* factor, dou
     const int n = p.sz(), nf = cx.kl.n;
     for (int i = 0; i < nf * n; i++) grad_out[i] = 0;
     for (const Mono& it : p.poly) {
-        if (it.key <= ((uint64_t)1 << (2 * nf))) { /* "<=" as in PZsparse.cu:447,488,527 */
+        if (it.key <= ((okey_t)1 << (2 * nf))) { /* "<=" as in PZsparse.cu:447,488,527 */
             double t[ARMOUR_MAX_FACTORS][9];
             for (int k = 0; k < nf; k++) for (int e = 0; e < n; e++) t[k][e] = it.c[e];
             for (int j = 0; j < nf; j++) {
