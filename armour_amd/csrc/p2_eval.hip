@@ -37,6 +37,10 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
                                                                   double* __restrict__ g_all, double* __restrict__ jac_all,
                                                                   P2Launch lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (Round 4, measured and dropped: an XCD-aware mapping -- linear workgroup l runs on XCD l % 8; give each XCD a CONTIGUOUS range of the
+    //  (problem, row block) pairs so that neighbouring blocks, which share their (link, time step) records, share an L2 -- configs[2]
+    //  539 us against 500: what a block streams is 30 KB of its own rows and 3 KB of shared records, and eight XCDs that each walk one
+    //  contiguous stretch of the table concentrate on fewer HBM channels at a time, like the tiled table layout of round 2.)
     const int b = blockIdx.y, role = blockIdx.x;
     const int n = tb.n, m = tb.m;   // (read together: one scalar load of the kernel argument block instead of two dependent ones)
     const double* k0 = k_all + (size_t)b * n;

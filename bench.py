@@ -40,6 +40,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "planning iters/s (eval_g+jac) Kinova 7-DOF, 100 timesteps × 20 obstacles"
+OPTIONS = []   # --set-option ID=VALUE (development: A/B of a per-handle option, include/armour_hip.h), applied to every handle this run creates
+
+
+def _opts(nlp):
+    for opt, val in OPTIONS:
+        nlp.set_option(opt, val)
+    return nlp
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -275,7 +282,7 @@ def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle
     from armour_amd.worlds import random_batch, random_problem
     seeds = shard_seeds(1000, world * B, rank, world)
     probs = random_batch(seeds[0], len(seeds), O)
-    nlp = ArmourNLP(T=T, device=device).set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
+    nlp = _opts(ArmourNLP(T=T, device=device)).set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
     tm = Timed(nlp, dev, 77 + rank, K, 4, use_dist)
     wall, ev = tm.run(R)
     # output check: finite, device entry == host entry, two problems against the CPU oracle (rank 0; the oracle is the checker)
@@ -299,7 +306,7 @@ def fetch_config(device, dev, T, K, R, check):
     from armour_amd.worlds import random_fetch_problem
     O = 100
     p = random_fetch_problem(11, O)
-    nlp = ArmourNLP(robot=fetch_robot(0.5), params=default_params(T), device=device)
+    nlp = _opts(ArmourNLP(robot=fetch_robot(0.5), params=default_params(T), device=device))
     nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
     nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])   # (the second build: code objects loaded)
     tm = Timed(nlp, dev, 311, K, 4, False)
@@ -371,8 +378,11 @@ def main():
     ap.add_argument("--no-sync-probe", action="store_true",
                     help="for runs under rocprofv3: no synchronous host-pointer calls at all (they add PCIe-bound launches of the same "
                          "kernel to the trace), i.e. skip the host-entry check and the sync-latency probe")
+    ap.add_argument("--set-option", action="append", default=[], metavar="ID=VALUE", help="development: armour_set_option on every handle (A/B runs)")
     ap.add_argument("--dry-run", action="store_true", help="development / tests: launcher + rendezvous + reduction on CPU (gloo), no GPU work")
     args = ap.parse_args()
+    for kv in args.set_option:
+        OPTIONS.append((int(kv.split("=")[0]), float(kv.split("=")[1])))
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # the parent: no torch, no HIP
@@ -406,7 +416,7 @@ def main():
     # independent worlds per rank (block partition of world*B seeds, armour_amd/sharding.py); no data-path collective
     seeds = shard_seeds(0, world * B, rank, world)
     probs = random_batch(seeds[0], len(seeds), O)
-    nlp = ArmourNLP(T=T, device=local_rank)
+    nlp = _opts(ArmourNLP(T=T, device=local_rank))
     nlp.set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])  # loads the code objects
     t0 = time.time()
     nlp.set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])

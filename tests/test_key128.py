@@ -101,6 +101,11 @@ def _body():
         dg, dj = np.abs(g[b] - g_ref).max(), np.abs(jac[b] - jac_ref).max()
         assert dg <= 1e-9 and dj <= 1e-8, (name, dg, dj)
         print(f"{name}: {info}, build {nlp.build_ms:.2f} ms, |dg| {dg:.2e} |djac| {dj:.2e}, table sizes {nlp.table_sizes()}", flush=True)
+        if name == "time_vectorised":   # the NLP solve with 8 variables: the host-driven and the device-resident form give the same iterates
+            host, dev = nlp.solve(host_qp=True), nlp.solve(device_qp=True)
+            for a, c in zip(host, dev):
+                assert np.array_equal(a["k_opt"], c["k_opt"]) and a["feasible"] == c["feasible"] and a["iterations"] == c["iterations"] and len(a["k_opt"]) == 8
+            print(f"solve (8 variables): feasible {host[0]['feasible']}, {host[0]['iterations']} iterations, k_opt {np.round(host[0]['k_opt'], 4)}", flush=True)
         built[name] = tabs
         nlp.close()
     for (c1, r1, k1, co1), (c2, r2, k2, co2) in zip(built["per_step"], built["time_vectorised"]):
