@@ -206,8 +206,64 @@ __device__ inline bool verdict(double thr, double thr_sq, bool active, double* a
 //     void close(pzkey_t key)                   -- the run of equal keys is complete: verdict + emit
 // Loads run U terms ahead of their use.
 #ifdef TV_PROFILE_FULL
-__device__ long long g_tvprof[8];  // [0] load phase, [1] process phase, [2] chunk prologue, [3] batches
+__device__ long long g_tvprof[8];  // (round 3's in-walk stamps: load phase, process phase, chunk prologue, batches -- no longer filled: the walk is pipelined)
 #endif
+#ifndef TV_WALK_PIPELINE
+#define TV_WALK_PIPELINE 1   // development: 0 = round 3's form (a batch of U terms is loaded, waited for and processed before the next is asked for)
+#endif
+// the serial part of a batch of HB terms whose loads have been issued: products (PB at a time, term-innermost), then run logic, sums, verdicts
+template <int HB, class P>
+__device__ inline void walk_consume(P& pol, const typename P::Regs* regs, pzkey_t key_v, int l0, int n, bool& have, pzkey_t& cur) {
+    // The products of PB terms first, as straight-line code without a branch in it -- each is a chain of dependent fp64 operations
+    // (18 cycles apiece for the one wave of its SIMD), independent of the other terms' -- and only then the serial part: the run
+    // logic, the sums in generation order, the verdicts.  (Round 3's walk formed a term's product inside its guarded block, so
+    // that nothing overlapped.)  Same operations on the same operands in the same order per sum.
+    constexpr int PB = HB % 4 == 0 ? 4 : HB % 3 == 0 ? 3 : HB % 2 == 0 ? 2 : 1;
+#pragma unroll
+    for (int u0 = 0; u0 < HB; u0 += PB) {
+        typename P::Prod pr[PB];
+        pol.template prod_batch<PB>(&regs[u0], pr);   // (written term-innermost: the compiler keeps source order, a term after a term otherwise)
+#pragma unroll
+        for (int v = 0; v < PB; v++) pr[v].pin();   // (formed HERE: not sunk into the guarded blocks below)
+#pragma unroll
+        for (int v = 0; v < PB; v++) {
+            const int u = u0 + v;
+            if (l0 + u < n) {
+                const pzkey_t key = pzkey_readlane(key_v, l0 + u);
+                if (have && key != cur) { pol.close(cur); have = false; }
+                pol.accum(regs[u], pr[v], !have);
+                have = true; cur = key;
+            }
+        }
+    }
+}
+// a chunk of <= 64 sorted terms, one per lane: key, generation index, load descriptor (pol.describe)
+template <class P>
+struct WalkChunk {
+    pzkey_t key_v;
+    int idx_v, n;
+    typename P::Desc dv;
+};
+template <class P, class KeyAt, class IdxAt>
+__device__ inline WalkChunk<P> walk_chunk(const P& pol, int lane, int base, int N, const KeyAt& keyat, const IdxAt& idxat) {
+    WalkChunk<P> c;
+    const int p = base + lane;
+    const bool in = p < N;
+    c.key_v = in ? keyat(p) : 0ull;
+    c.idx_v = in ? idxat(p) : 0;
+    c.n = min(WAVE, N - base);
+    // what a term's loads need -- which source, where its rows start -- is worked out for the chunk's 64 terms at once, one term per
+    // lane on the vector unit, and the serial loop picks a term's descriptor out with a few v_readlane instead of redoing
+    // the source selection with scalar selects per term (measured on lincomb<3, 4>: 35 of the ~110 instructions per raw term)
+    c.dv = pol.describe(c.idx_v);
+    return c;
+}
+// the loads of terms [l0, l0 + HB) of a chunk (clamped to its last term: unconditional, so that the number of loads in flight is static)
+template <int HB, class P>
+__device__ inline void walk_issue(const P& pol, const WalkChunk<P>& c, int l0, typename P::Regs* r) {
+#pragma unroll
+    for (int u = 0; u < HB; u++) { const int l = min(l0 + u, c.n - 1); pol.load(c.dv, l, __builtin_amdgcn_readlane(c.idx_v, l), r[u]); }
+}
 template <int U, class P, class KeyAt, class IdxAt>
 __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const IdxAt& idxat, P& pol, int N0_ = 0) {
     // N arrives from the sorter as a value the compiler must assume differs between lanes; as a loop bound it would put the
@@ -216,66 +272,47 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
     const int N = uni(N_), N0 = uni(N0_);   // the sorted terms [N0, N): a part of a walk shared with a helper wave starts at N0 > 0
     bool have = false;
     pzkey_t cur = 0;
-    for (int base = N0; base < N; base += WAVE) {
-#ifdef TV_PROFILE_FULL
-        long long wp0 = clock64();
-#endif
-        const int p = base + lane;
-        const pzkey_t key_v = p < N ? keyat(p) : 0ull;
-        const int idx_v = p < N ? idxat(p) : 0;
-        const int n = min(WAVE, N - base);
-        // what a term's loads need -- which source, where its rows start -- is worked out for the chunk's 64 terms at once, one term per
-        // lane on the vector unit, and the serial loop below picks a term's descriptor out with a few v_readlane instead of redoing
-        // the source selection with scalar selects per term (measured on lincomb<3, 4>: 35 of the ~110 instructions per raw term)
-        const typename P::Desc dv = pol.describe(idx_v);
-#ifdef TV_PROFILE_FULL
-        { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd((unsigned long long*)&g_tvprof[2], (unsigned long long)(x - wp0)); wp0 = x; }
-#endif
-        for (int l0 = 0; l0 < n; l0 += U) {
-            typename P::Regs regs[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int l = min(l0 + u, n - 1);
-                pol.load(dv, l, __builtin_amdgcn_readlane(idx_v, l), regs[u]);
-            }
-#ifdef TV_PROFILE_FULL
-            {   // (profile build only: the wait for the row loads on its own, and the counters' own traffic drained before the process phase is timed)
-                const long long x0 = clock64();
-                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const long long x1 = clock64();
-                if (lane == 0 && blockIdx.x == 0) {
-                    atomicAdd((unsigned long long*)&g_tvprof[0], (unsigned long long)(x0 - wp0)); atomicAdd((unsigned long long*)&g_tvprof[4], (unsigned long long)(x1 - x0));
-                    atomicAdd((unsigned long long*)&g_tvprof[3], 1ull); atomicAdd((unsigned long long*)&g_tvprof[5], (unsigned long long)min(U, n - l0));
+    if (N0 >= N) return;
+    if constexpr (TV_WALK_PIPELINE && U % 2 == 0) {
+        // Two half-batches in flight alternately (round 4): while one half's terms are processed the other half's rows are on their
+        // way -- round 3 asked for U terms' rows, waited for them, processed them, and only then asked for the next U: a walk waits
+        // for rows, and during the processing nothing was in flight.  The same registers as before (U terms' rows);
+        // every load is unconditional with a clamped term index, so that the compiler's vmcnt for a half is the exact number of
+        // loads issued after it.  The pipeline runs ACROSS the 64-term chunks: the next chunk's keys and descriptors are worked out
+        // while the current chunk's first loads are in flight, and the half that follows a chunk's last half is the next chunk's first
+        // (picked with selects on the wave-uniform condition -- a branch would make the load count path-dependent).
+        constexpr int HB = U / 2;
+        typename P::Regs ra[HB], rb[HB];
+        WalkChunk<P> c = walk_chunk(pol, lane, N0, N, keyat, idxat);
+        walk_issue<HB>(pol, c, 0, ra);
+        for (int base = N0; base < N; base += WAVE) {
+            const bool more = base + WAVE < N;
+            WalkChunk<P> nx = c;
+            if (more) nx = walk_chunk(pol, lane, base + WAVE, N, keyat, idxat);   // (wave-uniform; no row load inside)
+            for (int l0 = 0; l0 < c.n; l0 += U) {
+                walk_issue<HB>(pol, c, l0 + HB, rb);
+                walk_consume<HB>(pol, ra, c.key_v, l0, c.n, have, cur);
+                {   // the next first half: this chunk's, or -- behind its last half -- the next chunk's
+                    const bool here = l0 + U < c.n;
+                    WalkChunk<P> w2;
+                    w2.n = here ? c.n : nx.n;
+                    w2.idx_v = here ? c.idx_v : nx.idx_v;
+                    w2.key_v = 0;
+                    w2.dv = P::select_desc(here, c.dv, nx.dv);
+                    walk_issue<HB>(pol, w2, here ? l0 + U : 0, ra);
                 }
-                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wp0 = clock64();
+                walk_consume<HB>(pol, rb, c.key_v, l0 + HB, c.n, have, cur);
             }
-#endif
-            // The products of PB terms first, as straight-line code without a branch in it -- each is a chain of dependent fp64 operations
-            // (18 cycles apiece for the one wave of its SIMD), independent of the other terms' -- and only then the serial part: the run
-            // logic, the sums in generation order, the verdicts.  (Round 3's walk formed a term's product inside its guarded block, so
-            // that nothing overlapped: 702 of a raw term's 1200 cycles.)  Same operations on the same operands in the same order per sum.
-            constexpr int PB = U % 4 == 0 ? 4 : U % 3 == 0 ? 3 : U % 2 == 0 ? 2 : 1;
-#pragma unroll
-            for (int u0 = 0; u0 < U; u0 += PB) {
-                typename P::Prod pr[PB];
-                pol.template prod_batch<PB>(&regs[u0], pr);   // (written term-innermost: the compiler keeps source order, a term after a term otherwise)
-#pragma unroll
-                for (int v = 0; v < PB; v++) pr[v].pin();   // (formed HERE: not sunk into the guarded blocks below)
-#pragma unroll
-                for (int v = 0; v < PB; v++) {
-                    const int u = u0 + v;
-                    if (l0 + u < n) {
-                        const pzkey_t key = pzkey_readlane(key_v, l0 + u);
-                        if (have && key != cur) { pol.close(cur); have = false; }
-                        pol.accum(regs[u], pr[v], !have);
-                        have = true; cur = key;
-                    }
-                }
+            c = nx;
+        }
+    } else {
+        for (int base = N0; base < N; base += WAVE) {
+            const WalkChunk<P> c = walk_chunk(pol, lane, base, N, keyat, idxat);
+            for (int l0 = 0; l0 < c.n; l0 += U) {
+                typename P::Regs regs[U];
+                walk_issue<U>(pol, c, l0, regs);
+                walk_consume<U>(pol, regs, c.key_v, l0, c.n, have, cur);
             }
-#ifdef TV_PROFILE_FULL
-            { const long long x = clock64(); if (lane == 0 && blockIdx.x == 0) atomicAdd((unsigned long long*)&g_tvprof[1], (unsigned long long)(x - wp0)); wp0 = x; }
-#endif
         }
     }
     if (have) pol.close(cur);
@@ -323,6 +360,11 @@ struct MulCtx {
     // worked out for 64 terms at once on the vector unit; per term the serial loop then needs a few v_readlane instead of a chain of
     // twenty dependent scalar instructions (split by magic multiply, 64-bit address arithmetic) in front of every term's loads
     struct Desc { unsigned alo, ahi, blo, bhi; int i, j; };
+    __device__ static inline Desc select_desc(bool first, const Desc& x, const Desc& y) {   // (wave-uniform condition: selects, no branch)
+        Desc d;
+        d.alo = first ? x.alo : y.alo; d.ahi = first ? x.ahi : y.ahi; d.blo = first ? x.blo : y.blo; d.bhi = first ? x.bhi : y.bhi; d.i = first ? x.i : y.i; d.j = first ? x.j : y.j;
+        return d;
+    }
     __device__ inline Desc describe(int idx_lane) const {
         Desc d;
         const int t = idx_lane + 1;
@@ -710,6 +752,11 @@ struct CrossCtx {
     struct Regs { double ca[STAGE == 1 ? 1 : 3], cb[STAGE == 2 ? 1 : 3]; int i, j; };
     static constexpr int kU = STAGE == 0 ? 8 : 16;
     struct Desc { unsigned alo, ahi, blo, bhi; int i, j; };   // (see MulCtx::Desc)
+    __device__ static inline Desc select_desc(bool first, const Desc& x, const Desc& y) {
+        Desc d;
+        d.alo = first ? x.alo : y.alo; d.ahi = first ? x.ahi : y.ahi; d.blo = first ? x.blo : y.blo; d.bhi = first ? x.bhi : y.bhi; d.i = first ? x.i : y.i; d.j = first ? x.j : y.j;
+        return d;
+    }
     __device__ inline Desc describe(int idx_lane) const {
         Desc d;
         const int t = idx_lane + 1;
@@ -949,6 +996,11 @@ struct LinCtx {
     }
     // per-lane descriptors of the chunk's terms (lane l describes the chunk's l-th term): source, byte address of its first row, row step
     struct Desc { int k; unsigned lo, hi; int step; };
+    __device__ static inline Desc select_desc(bool first, const Desc& x, const Desc& y) {
+        Desc d;
+        d.k = first ? x.k : y.k; d.lo = first ? x.lo : y.lo; d.hi = first ? x.hi : y.hi; d.step = first ? x.step : y.step;
+        return d;
+    }
     __device__ inline Desc describe(int idx_lane) const {
         Desc d;
         d.k = seg_of(idx_lane);
