@@ -668,17 +668,40 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         if (t.hch != nullptr && AR == 3 && AC == 3 && BR == 3 && BC == 1) hj_post_none(t);
         MulCtx<SH, 0> cx;
         mul_ctx_init(cx, t, a, b, &o);
-        for (int m0 = 0; m0 < b.cnt; m0 += WAVE) {
-            const pzkey_t key_v = m0 + lane < b.cnt ? b.keys[m0 + lane] : 0ull;
-            const int n = min(WAVE, b.cnt - m0);
-            constexpr int kUc = SH::ASZ + SH::BSZ > 12 ? 4 : 8;
-            for (int l0 = 0; l0 < n; l0 += kUc) {
-                typename MulCtx<SH, 0>::Regs regs[kUc];
+        // b's rows are walked in their own order (contiguous), two half-batches in flight alternately as in walk_sorted; the left operand is its
+        // centre alone -- `ca`, loaded once above: round 3 fetched its rows again with every term (L1 hits, but 9 of a term's 12 row loads for an
+        // inertia matrix).  Per term the same product and the same verdict in the same order.
+        constexpr int HBc = SH::BSZ > 3 ? 2 : 4;
+        double xa[HBc][SH::BSZ], xb[HBc][SH::BSZ];
+        const int nb_ = b.cnt;
+        auto issue_c = [&](double (*x)[SH::BSZ], int m) {
 #pragma unroll
-                for (int u = 0; u < kUc; u++) cx.load(m0 + min(l0 + u, n - 1), regs[u]);  // idx = m: (i, j) = (0, m + 1)
+            for (int u = 0; u < HBc; u++) {
+                const int mm = min(m + u, nb_ - 1);
 #pragma unroll
-                for (int u = 0; u < kUc; u++)
-                    if (l0 + u < n) { typename MulCtx<SH, 0>::Prod pr; cx.prod(regs[u], pr); cx.accum(regs[u], pr, true); cx.close(pzkey_readlane(key_v, l0 + u)); }
+                for (int e = 0; e < SH::BSZ; e++) x[u][e] = ld_coef(b, mm, e, lane);
+            }
+        };
+        auto consume_c = [&](double (*x)[SH::BSZ], int m, pzkey_t key_v, int m0) {
+            typename MulCtx<SH, 0>::Prod pr[HBc];
+#pragma unroll
+            for (int u = 0; u < HBc; u++) SH::mul(ca, x[u], pr[u].c);
+#pragma unroll
+            for (int u = 0; u < HBc; u++) pr[u].pin();
+            typename MulCtx<SH, 0>::Regs dummy;
+#pragma unroll
+            for (int u = 0; u < HBc; u++)
+                if (m + u < nb_) { cx.accum(dummy, pr[u], true); cx.close(pzkey_readlane(key_v, m + u - m0)); }
+        };
+        if (nb_ > 0) issue_c(xa, 0);
+        for (int m0 = 0; m0 < nb_; m0 += WAVE) {
+            const pzkey_t key_v = m0 + lane < nb_ ? b.keys[m0 + lane] : 0ull;
+            const int n = min(WAVE, nb_ - m0);
+            for (int l0 = 0; l0 < n; l0 += 2 * HBc) {
+                issue_c(xb, m0 + l0 + HBc);
+                consume_c(xa, m0 + l0, key_v, m0);
+                issue_c(xa, m0 + l0 + 2 * HBc);
+                consume_c(xb, m0 + l0 + HBc, key_v, m0);
             }
         }
 #pragma unroll
@@ -1289,40 +1312,50 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
     const int lane = t.w.lane;
     const double thr = t.w.thr, thr_sq = t.w.thr_sq;
     const bool active = t.active;
+    // (a's rows in their own order, two half-batches of eight monomials in flight alternately: see walk_sorted)
+    double xa[8][3], xb[8][3];
+    auto issue_c = [&](double (*x)[3], int m) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int mm = min(m + u, m_hi - 1);
+#pragma unroll
+            for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, mm, q, lane);
+        }
+    };
+    auto consume_c = [&](double (*x)[3], int m, pzkey_t key_v, int m0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (m + u < m_hi) {
+                double r[3];
+                bool anyc = false;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double xa_ = 0, xb_ = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { if (q == cA[c]) xa_ = x[u][q]; if (q == cB[c]) xb_ = x[u][q]; }
+                    double v = sA[c] * xa_;
+                    v += sB[c] * xb_;
+                    const bool small = fabs(v) <= thr;
+                    ra1[c] += small ? fabs(v) : 0.0;
+                    r[c] = small ? 0.0 : v;
+                    anyc = anyc || !small;
+                }
+                const bool keep = anyc && !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { ra2[c] += (anyc && !keep) ? fabs(r[c]) : 0.0; r[c] = keep ? r[c] : 0.0; }
+                if (__ballot(keep) != 0ull) o.emit(pzkey_readlane(key_v, m + u - m0), r);
+            }
+        }
+    };
+    if (m_lo < m_hi) issue_c(xa, m_lo);
     for (int m0 = m_lo; m0 < m_hi; m0 += WAVE) {
         const pzkey_t key_v = m0 + lane < m_hi ? a.keys[m0 + lane] : 0ull;
         const int n = min(WAVE, m_hi - m0);
         for (int l0 = 0; l0 < n; l0 += 16) {
-            double x[16][3];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int m = m0 + min(l0 + u, n - 1);
-#pragma unroll
-                for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, m, q, lane);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                if (l0 + u < n) {
-                    double r[3];
-                    bool anyc = false;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        double xa = 0, xb = 0;
-#pragma unroll
-                        for (int q = 0; q < 3; q++) { if (q == cA[c]) xa = x[u][q]; if (q == cB[c]) xb = x[u][q]; }
-                        double v = sA[c] * xa;
-                        v += sB[c] * xb;
-                        const bool small = fabs(v) <= thr;
-                        ra1[c] += small ? fabs(v) : 0.0;
-                        r[c] = small ? 0.0 : v;
-                        anyc = anyc || !small;
-                    }
-                    const bool keep = anyc && !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) { ra2[c] += (anyc && !keep) ? fabs(r[c]) : 0.0; r[c] = keep ? r[c] : 0.0; }
-                    if (__ballot(keep) != 0ull) o.emit(pzkey_readlane(key_v, l0 + u), r);
-                }
-            }
+            issue_c(xb, m0 + l0 + 8);
+            consume_c(xa, m0 + l0, key_v, m0);
+            issue_c(xa, m0 + l0 + 16);
+            consume_c(xb, m0 + l0 + 8, key_v, m0);
         }
     }
 }
