@@ -284,9 +284,12 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
         } else {
             const int P = next_pow2(N);
             { PROF_T0
-            for (int p = w.lane; p < P; p += WAVE) {
-                w.skey[p] = p < N ? ev.key(p) : PZKEY_MAX;
-                w.sidx[p] = (uint16_t)p;
+            for (int p0 = w.lane; p0 < P; p0 += 4 * WAVE) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
+                pzkey_t kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) kk[u] = ev.key(min(p0 + u * WAVE, N - 1));
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int p = p0 + u * WAVE; if (p < P) { w.skey[p] = p < N ? kk[u] : PZKEY_MAX; w.sidx[p] = (uint16_t)p; } }
             }
             WSYNC();
             PROF_ADD(PR_FILL) }
@@ -449,7 +452,13 @@ struct LinEval {
         return false;
 #endif
         PROF_T0
-        for (int idx = w.lane; idx < N; idx += WAVE) w.skey[idx] = key(idx);
+        for (int i0 = w.lane; i0 < N; i0 += 4 * WAVE) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
+            pzkey_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kk[u] = key(min(i0 + u * WAVE, N - 1));
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + u * WAVE < N) w.skey[i0 + u * WAVE] = kk[u];
+        }
         WSYNC();
         for (int idx = w.lane; idx < N; idx += WAVE) {
             const int k = seg_of(idx);
@@ -773,13 +782,30 @@ struct MulEval {
         LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
         // t / d1 by multiplication: exact while t * d1 < 2^32 (both are below 2^13 here)
         const unsigned long long magic = magic_u32(d1);
+        // (the raw keys come from the operands' key lists in global memory: four terms per lane and pass, all eight loads issued before the
+        //  first sum -- one term per pass made every pass a load latency of its own, ~20 of them for a 1500-term product; round 4)
+        constexpr int KF = 4;
         if (by_a) {
-            for (int idx = w.lane; idx < N; idx += WAVE) { kb[cur][idx] = key(idx); vb[cur][idx] = (uint16_t)idx; }
+            for (int i0 = w.lane; i0 < N; i0 += KF * WAVE) {
+                pzkey_t kk[KF];
+#pragma unroll
+                for (int u = 0; u < KF; u++) kk[u] = key(min(i0 + u * WAVE, N - 1));
+#pragma unroll
+                for (int u = 0; u < KF; u++) { const int idx = i0 + u * WAVE; if (idx < N) { kb[cur][idx] = kk[u]; vb[cur][idx] = (uint16_t)idx; } }
+            }
         } else {
-            for (int q = w.lane; q < N; q += WAVE) {  // position q of the b-major layout holds the pair (i, j): q + 1 = j * na1 + i
-                const int j = (int)(((unsigned long long)(q + 1) * magic) >> 32), i = q + 1 - j * na1;
-                kb[cur][q] = (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);
-                vb[cur][q] = (uint16_t)(i * mb1 + j - 1);
+            for (int q0 = w.lane; q0 < N; q0 += KF * WAVE) {  // position q of the b-major layout holds the pair (i, j): q + 1 = j * na1 + i
+                pzkey_t kk[KF];
+                int gi[KF];
+#pragma unroll
+                for (int u = 0; u < KF; u++) {
+                    const int q = min(q0 + u * WAVE, N - 1);
+                    const int j = (int)(((unsigned long long)(q + 1) * magic) >> 32), i = q + 1 - j * na1;
+                    kk[u] = (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);
+                    gi[u] = i * mb1 + j - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < KF; u++) { const int q = q0 + u * WAVE; if (q < N) { kb[cur][q] = kk[u]; vb[cur][q] = (uint16_t)gi[u]; } }
             }
         }
         WSYNC();
