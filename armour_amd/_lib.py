@@ -76,6 +76,7 @@ OPT_P1_STEP_SPLIT_FK = 103
 OPT_P1_STEP_AUX3 = 104
 OPT_P1_MAX_WAVES_PER_CU = 105
 OPT_P1_TWO_PASS = 106
+OPT_P1_STEP_PAIRS = 107
 OPT_P1_TV_MIN_GROUPS = 110
 OPT_P1_TV_WAVES = 111
 OPT_P1_TV_FREE = 112

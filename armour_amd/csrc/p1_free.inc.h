@@ -70,6 +70,101 @@ __device__ inline void t3_post(CH& c, int word, const typename CH::PZT& p) { if 
 template <class CH>
 __device__ inline typename CH::PZT t3_take(const CH& c, int word) { return c.V(t3_ld(&c.mb[word])); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The backward pass of a four-wave block of the PER-STEP kernel with two waves on every operator of the two recursions (round 4).
+// A time step's backward pass is two chains of operators, each waiting for the one before -- f = R f + F on wave 1, n = ((N + R n) +
+// com x F) + p x (R f) on wave 0 -- and in the per-step kernel an operator's lanes are its TERMS: 200 .. 1900 raw terms on 64 lanes,
+// while waves 2 and 3 have nothing of their own left (release-build stamps of the slowest step of a Kinova build: 3.6 of the step's
+// 5.9 M cycles are this pass, and waves 2 / 3 wait for 3.8 / 4.0 M of them).  So for this pass wave 2 becomes the second half of wave 1
+// and wave 3 the second half of wave 0: both halves of a pair run the SAME role code -- allocations included, so that they agree on
+// every slot -- and the operators stride their passes over the raw terms by 128 lanes (pz_wave.h: psync(), pair_split(), pair_finish()).
+// What is not worth sharing runs on one half while the other does something else or waits: the constant cross products com x F (wave 0)
+// and p x (R f) (wave 3, as before) side by side, the 1x1 torque sums on wave 0.
+// Every bit of every result is that of the one-wave operators (pz_wave.h: a reduce pass adds its pruned amounts as the same two partial
+// sums whichever waves work on it); ARMOUR_OPT_P1_STEP_PAIRS = 0 keeps the idle waves idle.
+template <class CH>
+__device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail) {
+    typedef typename CH::PZT TPZ;
+    const P1Cfg& cf = *c.cf;
+    auto& w = c.w;
+    const int J = c.J;
+    LDS_AS int* px = c.mb + kHelpBase;             // the words of the two walk-helper channels, which this chain does not use
+    LDS_AS int* fvx = px + 2 * pzw::PW_WORDS;      // allocator state of waves 0 / 1 for their second halves
+    static_assert(2 * pzw::PW_WORDS + 4 <= 2 * tv::HJ_WORDS, "pair words");
+    if (threadIdx.x < 2 * pzw::PW_WORDS) px[threadIdx.x] = 0;
+    if (c.wid <= 1 && w_lane0(c)) { fvx[2 * c.wid] = (int)(unsigned)(c.freeV & 0xffffffffull); fvx[2 * c.wid + 1] = (int)(unsigned)(c.freeV >> 32); }
+    c.bar();   // (A2)
+    const int first = (c.wid == 1 || c.wid == 2) ? 1 : 0;   // pairs: waves 1 + 2 (f), waves 0 + 3 (n)
+    const unsigned long long saved = c.freeV, pf = c.part_mask(first);
+    if (c.wid >= 2) {   // the second half allocates what the first allocates: it starts from the first's state of the first's part of the pool
+        const unsigned long long fv = (unsigned long long)(unsigned)t3_ld(&fvx[2 * first]) | ((unsigned long long)(unsigned)t3_ld(&fvx[2 * first + 1]) << 32);
+        c.freeV = (c.freeV & ~pf) | (fv & pf);
+    }
+    c.pair_begin(first, px + (first == 1 ? 0 : pzw::PW_WORDS));
+    const bool h0 = w.half == 0;
+    if (first == 1) {
+        c.role = 1;
+        TPZ f = c.allocV();
+        if (h0) set_const(w, f, nullptr, nullptr);
+        psync(w);
+        for (int i = J - 1; i >= 0; i--) {
+            const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i);
+            TPZ a2 = c.mulMV(Rn, f);
+            if (h0) { t3_post(c, T3_A2 + i, a2); t3_signal(c, T3_B1, J - i); }
+            TPZ f2 = c.add(a2, Fi); c.freeVs(f);
+            f = f2;
+        }
+        c.freeVs(f);
+    } else {
+        c.role = 0;
+        TPZ nn = c.allocV();
+        if (h0) set_const(w, nn, nullptr, nullptr);
+        psync(w);
+        for (int i = J - 1; i >= 0; i--) {
+            const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
+            TPZ a1 = c.mulMV(Rn, nn);
+            TPZ c1;
+            if (h0) c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);   // (an operator of this wave alone: no sort buffers)
+            else {
+                c1 = c.allocV();   // (the slot the first half has just taken)
+                c.role = 3;
+                t3_wait(c, T3_B1, J - i);
+                TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
+                t3_post(c, T3_C2 + i, c2);
+                c.role = 0;
+            }
+            psync(w);
+            const TPZ c2 = t3_take(c, T3_C2 + i);
+            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c1); c.freeVs(nn);  // ((N + a1) + c1) + c2
+            nn = n2;
+            if (cf.rb.axes[i] != 0) {
+                if (h0) {
+                    const auto st = c.solo_begin();
+                    const int ax = abs(cf.rb.axes[i]) - 1;
+                    u[i] = c.comb3(elem(w, n2, ax), 1.0, view(w, c.qdda(i)), cf.rb.armature[i], view(w, c.qd(i)), cf.rb.damping[i]);
+                    if (w_lane0(c)) c.mb[T3_U + i] = u[i].id - c.L.idS;
+                    c.solo_end(st);
+                }
+                psync(w);   // the pair's sort buffers are free again
+            }
+        }
+        c.freeVs(nn);
+    }
+    c.pair_end();
+    if (c.wid == 2) c.freeV = saved;
+    if (c.wid == 3) { const unsigned long long own = c.part_mask(3); c.freeV = (c.freeV & own) | (saved & ~own); }
+    c.role = c.wid;
+    c.bar();   // (B) both recursions are through
+    if (c.wid == 1) {
+        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_A2 + i));
+        for (int i = J - n_tail; i < J; i++) c.freeVs(t3_take(c, T3_N + i));
+    } else if (c.wid == 3) {
+        for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_C2 + i));
+    } else if (c.wid == 2) {
+        for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
+    }
+}
+
 template <class CH>
 __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, int t_lane) {
     typedef typename CH::PZT TPZ;
@@ -317,6 +412,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // The f-recursion (wave 1) is the chain everything hangs on: R f, then f = R f + F.  The cross product p x (R f) that the
     // n-recursion needs is a side product of it and goes to a wave that has nothing to do in this pass (wave 3, or wave 2).
     const int helper = fk_wave ? 3 : 2;
+    if constexpr (CH::kPairs) {
+        if (fk_wave && cf.step_pairs != 0) { run_backward_pairs(c, u, n_tail); return; }
+    }
     if (c.wid == 1) {
         c.role = 1;
         TPZ f = c.allocV();

@@ -84,6 +84,7 @@ struct P1Cfg {
     int tv_aux_on_fk_wave;  // four-wave blocks: the w_aux recursion runs on the forward-kinematics wave (p1_free.inc.h)
     int tv_help_shift;    // eight-wave blocks: role wave p's helper is wave 4 + (p + shift) % 4
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
+    int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -291,6 +292,7 @@ struct Chain {
     typedef PZ PZT;
     static constexpr bool kWalkHelpers = false;   // (the time-vectorised chain has them: p1_tv.inc.h)
     static constexpr bool kFusedCross = false;    // (likewise)
+    static constexpr bool kPairs = true;          // run_rnea_free: two waves per operator in the backward pass of a four-wave block
     Wave w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -346,6 +348,23 @@ struct Chain {
     __device__ PZ qdda(int i) const { return JS(2 * n + i); }
     __device__ PZ mass(int i) const { return JS(3 * n + i); }
     __device__ PZ rawS(int role, int i) const { return JS(3 * n + J + 4 * scratch(role) + i); }  // i = 0..3
+
+    // ---- two waves on one operator (pz_wave.h psync()): this wave becomes one half of the pair led by wave `first`, whose sort buffers both use
+    LDS_AS pzkey_t* peer_skey; LDS_AS uint16_t* peer_sidx;   // the sort buffers of the wave this one would join (waves 2 / 3 of four: waves 1 / 0), full size
+    LDS_AS pzkey_t* own_skey; LDS_AS uint16_t* own_sidx; int own_cap_raw, own_cap_key;
+    __device__ void pair_begin(int first, LDS_AS int* words) {
+        own_skey = w.skey; own_sidx = w.sidx; own_cap_raw = w.cap_raw; own_cap_key = w.cap_key;
+        w.half = wid == first ? 0 : 1; w.nl = 2 * WAVE; w.lane2 = w.lane + WAVE * w.half; w.pair = words;
+        if (w.half) { w.skey = peer_skey; w.sidx = peer_sidx; w.cap_raw = cf->capRaw; w.cap_key = cf->capKey; }
+    }
+    __device__ void pair_end() { w.skey = own_skey; w.sidx = own_sidx; w.cap_raw = own_cap_raw; w.cap_key = own_cap_key; solo(w); }
+    // an operator of this wave alone in the middle of a pair's work (its sort buffers are the pair's: the other half must be kept off them, psync() after)
+    struct PairState { int lane2, nl, half; LDS_AS int* pair; };
+    __device__ PairState solo_begin() { PairState st{w.lane2, w.nl, w.half, w.pair}; solo(w); return st; }
+    __device__ void solo_end(const PairState& st) { w.lane2 = st.lane2; w.nl = st.nl; w.half = st.half; w.pair = st.pair; }
+    __device__ unsigned long long part_mask(int r) const {
+        return L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[r]) - 1ull) << kPartFirst[r] : ((1ull << kPart4Count[r]) - 1ull) << kPart4First[r];
+    }
 
     int role = 0;  // the role the code being executed belongs to: selects the part of the 3x1 pool allocV() draws from
     __device__ PZ allocV() {
@@ -1068,6 +1087,12 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     c.w.thr = cf.pr.simplify_threshold;
     c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x & 63;
+    solo(c.w);
+    {   // (four-wave blocks: wave 2 may join wave 1's operators, wave 3 wave 0's -- run_rnea_free)
+        const int peer = c.wid == 2 ? 1 : 0;
+        LDS_AS unsigned char* pb = lds + (size_t)peer * p1_wave_lds(cf.capKey, cf.capRaw);
+        c.peer_skey = (LDS_AS pzkey_t*)pb; c.peer_sidx = (LDS_AS uint16_t*)(pb + (size_t)cf.capKey * sizeof(pzkey_t));
+    }
     if (c.w.lane < ST_WORDS) c.w.lstat[c.w.lane] = 0;
     for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
         const bool fk_only = it0 >= cf.n_items || cf.mode == ARMOUR_MODE_ARMTD;
@@ -1542,6 +1567,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     c.w.thr = cf.pr.simplify_threshold;
     c.w.thr_sq = sq_threshold(c.w.thr);
     c.w.lane = threadIdx.x;
+    solo(c.w);
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
     c.freeV = (1ull << c.L.nV) - 1ull; c.freeS = (1u << kNS) - 1u;
     for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
@@ -1824,6 +1850,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
         const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
+        cf.step_pairs = h->tune(ARMOUR_OPT_P1_STEP_PAIRS);
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));

@@ -61,6 +61,7 @@ __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index
 struct TChain {
     typedef TPZ PZT;
     static constexpr bool kWalkHelpers = true;   // pz_tv.h "One walk on two waves"; used by run_rnea_free in four-wave blocks
+    static constexpr bool kPairs = false;        // (the per-step chain's two-waves-per-operator backward pass; this chain shares its walks instead)
     static constexpr bool kFusedCross = true;    // run_rnea_free: (a + cross(w, b)) + c with the constant cross product taken inside the sum's walk (sum3x)
     TW w;
     const P1Cfg* cf;
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
     c.w.w.thr = cf.pr.simplify_threshold;
     c.w.w.thr_sq = pzw::sq_threshold(c.w.w.thr);
     c.w.w.lane = threadIdx.x & 63;
+    pzw::solo(c.w.w);
     const int lane = c.w.w.lane;
     if constexpr (NW == 8) {
         // channel p: role wave p -> helper wave NP + (p + shift) % NP (which SIMD a wave lands on is the dispatcher's choice; the shift is a tuning knob)

@@ -57,7 +57,7 @@ enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS
 #define PROF_CALL_T0
 #define PROF_CALL_END(N)
 #endif
-enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8, ERR_DBG_BOUNDS = 128 };
+enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8, ERR_PAIR = 32, ERR_DBG_BOUNDS = 128 };
 // -DDBG_BOUNDS (root-cause tooling, tools/gpu_fault_hunt.py): every LDS / arena index of the product merge and of the reduce
 // pass is range-checked BEFORE the access; a violation is recorded (flag 128, lstat[3] = code * 2^20 + the offending value's
 // low 20 bits, first one wins) and the index clamped to 0, so that a genuine out-of-range index shows up as a report
@@ -101,7 +101,13 @@ struct Wave {
 #endif
     LDS_AS int* lstat;       // LDS [ST_WORDS]: error bits / max raw terms / max monomials of this wave (flushed once per launch)
     int lane;
+    // Two waves on one operator (psync() below; the backward pass of the per-step kernel's four-wave blocks, p1_free.inc.h): the operators
+    // that support it stride their term loops by `nl` cooperating lanes from `lane2`; skey / sidx are then the FIRST wave's buffers on both.
+    int lane2, nl, half;     // lane2 = lane + WAVE * half; nl = WAVE (one wave, the rule) or 2 * WAVE; half = 0 | 1
+    LDS_AS int* pair;        // LDS words of the pair (PW_*), nullptr for a wave on its own
 };
+enum { PW_BAR = 0, PW_BROKEN = 1, PW_E0 = 2, PW_E1 = 3, PW_DBL = 8, PW_DBL_PER_HALF = 10, PW_WORDS = PW_DBL + 1 + 2 * PW_DBL_PER_HALF };
+__device__ inline void solo(Wave& w) { w.lane2 = w.lane; w.nl = 64; w.half = 0; w.pair = nullptr; }
 
 // Arguments of the (non-inlined) operators arrive by reference, i.e. as pointers into the caller's stack frame: every `w.field`,
 // `a.cnt`, `out.keys` inside a loop is a flat load the compiler may not hoist across the loop's stores, and a count read that way
@@ -115,7 +121,30 @@ __device__ inline void uni_caps(struct Wave& w);
 #else
 #define PZW_WAVE_LOCAL(w, w_) Wave w = w_; uni_caps(w);
 #endif
-__device__ inline void uni_caps(Wave& w) { w.cap_raw = uni_i(w.cap_raw); w.cap_key = uni_i(w.cap_key); }
+__device__ inline void uni_caps(Wave& w) { w.cap_raw = uni_i(w.cap_raw); w.cap_key = uni_i(w.cap_key); w.nl = uni_i(w.nl); w.half = uni_i(w.half); }
+// Barrier of the lanes that work on one operator: the wave's own memory traffic drained (WSYNC) and, for a pair of waves, both of them here.
+// The counter only grows: a wave that finds it even is the first of its round and waits for the next even value, one that finds it odd
+// completes the round.  (A wave cannot be a whole round ahead: it needs the other one's arrival to leave the round it is in.)  A wait that
+// never ends -- the two waves disagreeing about the number of barriers, which would be a bug -- is cut off, flagged, and disables the
+// pair's barriers for the rest of the launch instead of hanging the chip.
+__device__ inline void psync(const Wave& w) {
+    WSYNC();
+    if (w.nl == WAVE) return;
+    if (__hip_atomic_load(&w.pair[PW_BROKEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+    int old = 0;
+    if (w.lane == 0) old = __hip_atomic_fetch_add(&w.pair[PW_BAR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    const int target = (old | 1) + 1;
+    int spins = 0;
+    while (__hip_atomic_load(&w.pair[PW_BAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) {
+            if (w.lane == 0) { w.lstat[ST_ERR] |= ERR_PAIR; __hip_atomic_store(&w.pair[PW_BROKEN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
 __device__ inline PZ uni_pz(const PZ& p) { PZ u = p; u.cap = uni_i(p.cap); u.id = uni_i(p.id); return u; }
 __device__ inline View view(const Wave& w, const PZ& p) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, 0, p.sz}; }
 __device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.keys, p.coef, p.cen, p.ind, p.ind2, w.cnt[p.id], p.sz, r, 1}; }
@@ -250,14 +279,16 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             // (Eval::kCountMax: up to a full wave for products, whose merge has per-level fixed costs; a handful of terms
             // for sums, whose one-search merge is cheaper than ~200 cycles per broadcast step from there on)
             PROF_T0
-            const pzkey_t key = w.lane < N ? ev.key(w.lane) : PZKEY_MAX;
-            int rank = 0;
-            for (int l = 0; l < N; l++) {
-                const pzkey_t kl = pzkey_readlane(key, l);
-                rank += (kl < key || (kl == key && l < w.lane)) ? 1 : 0;
+            if (w.half == 0) {   // (a pair: the first wave alone)
+                const pzkey_t key = w.lane < N ? ev.key(w.lane) : PZKEY_MAX;
+                int rank = 0;
+                for (int l = 0; l < N; l++) {
+                    const pzkey_t kl = pzkey_readlane(key, l);
+                    rank += (kl < key || (kl == key && l < w.lane)) ? 1 : 0;
+                }
+                if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
             }
-            if (w.lane < N) { w.skey[rank] = key; w.sidx[rank] = (uint16_t)w.lane; }
-            WSYNC();
+            psync(w);
             PROF_ADD(PR_SORT) PROF_ADD(PR_S_RANK)
         } else if (ev.try_merge(w, N, indirect)) {
             // the operands' sorted runs were merged: either skey / sidx hold the sorted keys and the permutation like the
@@ -283,6 +314,7 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
 #endif
         } else {
             const int P = next_pow2(N);
+            if (w.half == 0) {   // (a pair: the first wave alone -- the network is the path of last resort)
             { PROF_T0
             for (int p0 = w.lane; p0 < P; p0 += 4 * WAVE) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
                 pzkey_t kk[4];
@@ -296,9 +328,95 @@ __device__ inline int sort_terms(Wave& w, int N, const Eval& ev, bool& indirect)
             { PROF_T0
             bitonic_sort(w, P);
             PROF_ADD(PR_SORT) PROF_ADD(PR_S_BITONIC) }
+            }
+            psync(w);
         }
     }
     return N;
+}
+
+// ---- a pair of waves on one reduce pass (Wave::nl == 2 * WAVE) ------------------------------------------------------------------------
+// The sorted terms are reduced in chunks of 64 (one per lane); a chunk never depends on another one's registers -- a run of equal keys that
+// crosses a chunk's end is finished by its head lane from memory, and the lanes of the next chunk that continue it do nothing.  So the first
+// wave takes the lower half of the chunks and the second the upper half, at the same time.  What the single wave carries from chunk to chunk
+// is the number of monomials emitted so far: the second wave starts at the number of RUN HEADS below its first chunk (an upper bound of what
+// the first wave will emit: counted from the keys alone), and once both are through it moves its rows down behind the first wave's
+// (pair_finish).  And the pruned amounts: a reduce pass -- on one wave or two -- adds those of the chunks below reduce_mid(N) and those of
+// the chunks from there on as TWO sums per lane, reduces each over the lanes and adds the two results; which wave works on a chunk does
+// not enter.  So every bit of a result -- keys, coefficients, centres and radii -- is the same whether one wave or a pair produced it.
+// (Round 4 changed this order for the single wave too, from one running sum: the per-step kernel's radii moved by a few 1e-16 against
+// round 3's, inside the 1e-11 its parity with the CPU oracle is stated to.)
+__device__ inline int reduce_mid(int N) { const int C = (N + WAVE - 1) / WAVE; return min(((C + 1) / 2) * WAVE, N); }
+template <class KeyAt>
+__device__ inline void pair_split(const Wave& w, int N, int cap, const KeyAt& keyat, int& b0, int& b1, int& pos0) {
+    const int mid = reduce_mid(N);
+    // run heads below and above the split (both waves count both: the keys are in LDS).  The second wave's rows start at `lo`, so lo + hi
+    // rows must fit the slot; a result that close to the slot's capacity is left to the first wave alone (as a wave on its own would do it).
+    int lo = 0, hi = 0;
+    for (int base = 0; base < N; base += WAVE) {
+        const int p = base + w.lane;
+        const bool head = p < N && ((p == 0) || (keyat(p - 1) != keyat(p)));
+        const int n = __popcll(__ballot(head));
+        if (base < mid) lo += n; else hi += n;
+    }
+    const bool split = lo + hi <= cap;
+    if (w.half == 0) { b0 = 0; b1 = split ? mid : N; pos0 = 0; }
+    else { b0 = split ? mid : N; b1 = N; pos0 = split ? lo : 0; }
+}
+__device__ inline LDS_AS double* pair_doubles(const Wave& w) {
+    LDS_AS int* q = w.pair + PW_DBL;
+    if (((unsigned)(size_t)q & 4u) != 0u) q += 1;   // (8-byte aligned)
+    return (LDS_AS double*)q;
+}
+// In: this wave's rows are out[pos0 .. emitted); rb[NR][SZ] = its sums (over its lanes) of the pruned amounts of the upper chunks.  Out, on
+// both waves: emitted = the result's monomial count; on the first wave rb = its own + the second's (one of the two is 0: a chunk is one
+// wave's); the second wave's rows sit behind the first's.  (The caller's closing psync() makes the moved rows and the header words visible.)
+template <int SZ, int NR>
+__device__ inline void pair_finish(const Wave& w, const PZ& out, int& emitted, int pos0, double (*rb)[SZ]) {
+    static_assert(NR * SZ <= PW_DBL_PER_HALF, "pair exchange area");
+    LDS_AS double* xd = pair_doubles(w);
+    if (w.lane == 0) {
+        w.pair[PW_E0 + w.half] = emitted - pos0;
+        if (w.half == 1) {
+            w.pair[PW_E1 + 1] = pos0;
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int e = 0; e < SZ; e++) xd[r * SZ + e] = rb[r][e];
+        }
+    }
+    psync(w);
+    const int e0 = uni_i(w.pair[PW_E0]), e1 = uni_i(w.pair[PW_E1]), p1 = uni_i(w.pair[PW_E1 + 1]);
+    if (w.half == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int e = 0; e < SZ; e++) rb[r][e] = rb[r][e] + xd[r * SZ + e];
+    }
+    if (w.half == 1 && e1 > 0 && p1 != e0) {   // (the first wave pruned something: p1 > e0)
+        for (int r0 = 0; r0 < e1; r0 += 2 * WAVE) {
+            pzkey_t kk[2];
+            double cc[2][SZ];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int r = min(r0 + u * WAVE + w.lane, e1 - 1), src = p1 + r;
+                kk[u] = out.keys[src];
+#pragma unroll
+                for (int e = 0; e < SZ; e++) cc[u][e] = out.coef[(size_t)src * SZ + e];
+            }
+            WSYNC();   // every row of this step is in registers before one of them is overwritten (the rows move DOWN: a step never writes a later step's sources)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int r = r0 + u * WAVE + w.lane;
+                if (r < e1) {
+                    out.keys[e0 + r] = kk[u];
+#pragma unroll
+                    for (int e = 0; e < SZ; e++) out.coef[(size_t)(e0 + r) * SZ + e] = cc[u][e];
+                }
+            }
+        }
+    }
+    emitted = e0 + e1;
 }
 
 // Sort the N raw terms described by `ev`, sum equal keys, prune small coefficients into the independent part
@@ -308,13 +426,23 @@ template <int SZ, class Eval>
 __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ& out, const double* base_ind, const double* base_ind2) {
     int emitted = 0;
     bool any_pruned = false, indirect = false;
-    double ra[SZ];
+    double ra[SZ], rb[SZ];   // pruned amounts of the chunks below / from reduce_mid(N) on
 #pragma unroll
-    for (int e = 0; e < SZ; e++) ra[e] = 0.0;
+    for (int e = 0; e < SZ; e++) { ra[e] = 0.0; rb[e] = 0.0; }
     N = uni_i(sort_terms(w, N, ev, indirect));
+    const bool paired = w.nl != WAVE;
+    int pos0 = 0;
     if (N > 0) {
         PROF_T0
-        for (int base = 0; base < N; base += WAVE) {
+        int b0 = 0, b1 = N;
+        const int mid = reduce_mid(N);
+        if (paired) {
+            if (indirect) pair_split(w, N, out.cap, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, b0, b1, pos0);
+            else pair_split(w, N, out.cap, [&](int p) { return w.skey[p]; }, b0, b1, pos0);
+            b0 = uni_i(b0); b1 = uni_i(b1); pos0 = uni_i(pos0);
+            emitted = pos0;
+        }
+        for (int base = b0; base < b1; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false;
             pzkey_t key = 0;
@@ -363,8 +491,9 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             if (head) {
                 keep = !norm_le<SZ>(acc, w);
                 if (!keep) {
+                    const bool upper = base >= mid;   // (wave-uniform; + 0.0 leaves a sum of absolute values as it is)
 #pragma unroll
-                    for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
+                    for (int e = 0; e < SZ; e++) { const double v = fabs(acc[e]); ra[e] += upper ? 0.0 : v; rb[e] += upper ? v : 0.0; }
                 }
             }
             E_LAP(PR_E_PRUNE)
@@ -383,18 +512,19 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
         }
         PROF_ADD(PR_EMIT)
     }
-    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
     if (any_pruned) {
 #pragma unroll
-        for (int e = 0; e < SZ; e++) ra[e] = wave_sum(ra[e]);
+        for (int e = 0; e < SZ; e++) { ra[e] = wave_sum(ra[e]); rb[e] = wave_sum(rb[e]); }
     }
-    if (w.lane == 0) {
+    if (paired && N > 0) pair_finish<SZ, 1>(w, out, emitted, pos0, (double (*)[SZ])rb);
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (w.lane2 == 0) {
 #pragma unroll
-        for (int e = 0; e < SZ; e++) { out.ind[e] = base_ind[e] + ra[e]; out.ind2[e] = base_ind2[e] + ra[e]; }
+        for (int e = 0; e < SZ; e++) { const double r = ra[e] + rb[e]; out.ind[e] = base_ind[e] + r; out.ind2[e] = base_ind2[e] + r; }
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    WSYNC();
+    psync(w);
 }
 #undef E_LAP
 
@@ -452,15 +582,16 @@ struct LinEval {
         return false;
 #endif
         PROF_T0
-        for (int i0 = w.lane; i0 < N; i0 += 4 * WAVE) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
+        const int nl = w.nl;   // (cooperating lanes: one wave's, or a pair's)
+        for (int i0 = w.lane2; i0 < N; i0 += 4 * nl) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
             pzkey_t kk[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) kk[u] = key(min(i0 + u * WAVE, N - 1));
+            for (int u = 0; u < 4; u++) kk[u] = key(min(i0 + u * nl, N - 1));
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (i0 + u * WAVE < N) w.skey[i0 + u * WAVE] = kk[u];
+            for (int u = 0; u < 4; u++) if (i0 + u * nl < N) w.skey[i0 + u * nl] = kk[u];
         }
-        WSYNC();
-        for (int idx = w.lane; idx < N; idx += WAVE) {
+        psync(w);
+        for (int idx = w.lane2; idx < N; idx += nl) {
             const int k = seg_of(idx);
             const pzkey_t ky = w.skey[idx];
             int first = off[0];
@@ -476,7 +607,7 @@ struct LinEval {
             }
             w.sidx[rank] = (uint16_t)idx;
         }
-        WSYNC();
+        psync(w);
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_LINMERGE)
         return true;
     }
@@ -546,8 +677,8 @@ __device__ PZW_NOINLINE void lincomb(Wave& w_, const PZ& out_, const Seg* segs) 
         }
     }
     ev.off[NS] = N;
-    WSYNC();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
-    if (w.lane == 0) {
+    psync(w);  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
+    if (w.lane2 == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
     }
@@ -596,22 +727,32 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
     }
     ev.off[NS] = N;
     [[maybe_unused]] const int N_in = N;
-    WSYNC();  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
-    if (w.lane == 0) {
+    psync(w);  // all lanes have read the sources' centre / indep before `out` (possibly aliasing) is written
+    if (w.lane2 == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) out.cen[e] = cen[e];
     }
     int emitted = 0;
     bool any_pruned = false, indirect = false;
-    double ra[NS][SZ];  // ra[k]: pruned at stage k (k >= 1)
+    double ra[NS][SZ], rb[NS][SZ];  // ra[k] / rb[k]: pruned at stage k (k >= 1) in the chunks below / from reduce_mid(N) on
 #pragma unroll
     for (int k = 0; k < NS; k++)
 #pragma unroll
-        for (int e = 0; e < SZ; e++) ra[k][e] = 0.0;
+        for (int e = 0; e < SZ; e++) { ra[k][e] = 0.0; rb[k][e] = 0.0; }
     N = uni_i(sort_terms(w, N, ev, indirect));
+    const bool paired = w.nl != WAVE;   // (two waves on this pass: see pair_split)
+    int pos0 = 0;
     if (N > 0) {
         PROF_T0
-        for (int base = 0; base < N; base += WAVE) {
+        int b0 = 0, b1 = N;
+        const int mid = reduce_mid(N);
+        if (paired) {
+            if (indirect) pair_split(w, N, out.cap, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, b0, b1, pos0);
+            else pair_split(w, N, out.cap, [&](int p) { return w.skey[p]; }, b0, b1, pos0);
+            b0 = uni_i(b0); b1 = uni_i(b1); pos0 = uni_i(pos0);
+            emitted = pos0;
+        }
+        for (int base = b0; base < b1; base += WAVE) {
             const int p = base + w.lane;
             bool head = false, keep = false, pruned = false;
             pzkey_t key = 0;
@@ -638,8 +779,9 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
                     }
                     if (k >= 1 && present) {  // simplify() of stage k
                         if (norm_le<SZ>(acc, w)) {
+                            const bool upper = base >= mid;
 #pragma unroll
-                            for (int e = 0; e < SZ; e++) ra[k][e] += fabs(acc[e]);
+                            for (int e = 0; e < SZ; e++) { const double v = fabs(acc[e]); ra[k][e] += upper ? 0.0 : v; rb[k][e] += upper ? v : 0.0; }
                             present = false;
                             pruned = true;
                         }
@@ -661,14 +803,21 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
         }
         PROF_ADD(PR_EMIT)
     }
-    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
     if (any_pruned) {
 #pragma unroll
         for (int k = 1; k < NS; k++)
 #pragma unroll
-            for (int e = 0; e < SZ; e++) ra[k][e] = wave_sum(ra[k][e]);
+            for (int e = 0; e < SZ; e++) { ra[k][e] = wave_sum(ra[k][e]); rb[k][e] = wave_sum(rb[k][e]); }
     }
-    if (w.lane == 0) {
+    if constexpr ((NS - 1) * SZ <= PW_DBL_PER_HALF) {
+        if (paired && N > 0) pair_finish<SZ, NS - 1>(w, out, emitted, pos0, &rb[1]);
+    }
+#pragma unroll
+    for (int k = 1; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < SZ; e++) ra[k][e] = ra[k][e] + rb[k][e];
+    if (emitted > out.cap) { flag(w, ERR_SLOT_OVERFLOW); emitted = out.cap; }
+    if (w.lane2 == 0) {
 #pragma unroll
         for (int e = 0; e < SZ; e++) {
             // stage 1: (i0 + i1) + pruned; stage k: (previous * 1.0 + ik) + pruned  -- as lincomb over two sources each time
@@ -680,7 +829,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    WSYNC();
+    psync(w);
     PROF_CALL_END(N_in)
 }
 
@@ -785,30 +934,31 @@ struct MulEval {
         // (the raw keys come from the operands' key lists in global memory: four terms per lane and pass, all eight loads issued before the
         //  first sum -- one term per pass made every pass a load latency of its own, ~20 of them for a 1500-term product; round 4)
         constexpr int KF = 4;
+        const int nl = w.nl;   // (cooperating lanes: one wave's, or a pair's -- every pass below is a loop over independent positions)
         if (by_a) {
-            for (int i0 = w.lane; i0 < N; i0 += KF * WAVE) {
+            for (int i0 = w.lane2; i0 < N; i0 += KF * nl) {
                 pzkey_t kk[KF];
 #pragma unroll
-                for (int u = 0; u < KF; u++) kk[u] = key(min(i0 + u * WAVE, N - 1));
+                for (int u = 0; u < KF; u++) kk[u] = key(min(i0 + u * nl, N - 1));
 #pragma unroll
-                for (int u = 0; u < KF; u++) { const int idx = i0 + u * WAVE; if (idx < N) { kb[cur][idx] = kk[u]; vb[cur][idx] = (uint16_t)idx; } }
+                for (int u = 0; u < KF; u++) { const int idx = i0 + u * nl; if (idx < N) { kb[cur][idx] = kk[u]; vb[cur][idx] = (uint16_t)idx; } }
             }
         } else {
-            for (int q0 = w.lane; q0 < N; q0 += KF * WAVE) {  // position q of the b-major layout holds the pair (i, j): q + 1 = j * na1 + i
+            for (int q0 = w.lane2; q0 < N; q0 += KF * nl) {  // position q of the b-major layout holds the pair (i, j): q + 1 = j * na1 + i
                 pzkey_t kk[KF];
                 int gi[KF];
 #pragma unroll
                 for (int u = 0; u < KF; u++) {
-                    const int q = min(q0 + u * WAVE, N - 1);
+                    const int q = min(q0 + u * nl, N - 1);
                     const int j = (int)(((unsigned long long)(q + 1) * magic) >> 32), i = q + 1 - j * na1;
                     kk[u] = (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);
                     gi[u] = i * mb1 + j - 1;
                 }
 #pragma unroll
-                for (int u = 0; u < KF; u++) { const int q = q0 + u * WAVE; if (q < N) { kb[cur][q] = kk[u]; vb[cur][q] = (uint16_t)gi[u]; } }
+                for (int u = 0; u < KF; u++) { const int q = q0 + u * nl; if (q < N) { kb[cur][q] = kk[u]; vb[cur][q] = (uint16_t)gi[u]; } }
             }
         }
-        WSYNC();
+        psync(w);
         constexpr int U = 8;
         for (int lv = 0; lv < levels; lv++) {
             const int rl = d1 << lv;  // run r of this level holds the positions q with q + 1 in [r*rl, (r+1)*rl)
@@ -818,13 +968,13 @@ struct MulEval {
             const LDS_AS uint16_t* V = vb[cur];
             LDS_AS pzkey_t* Ko = kb[cur ^ 1];
             LDS_AS uint16_t* Vo = vb[cur ^ 1];
-            for (int p0 = w.lane; p0 < N; p0 += WAVE * U) {
+            for (int p0 = w.lane2; p0 < N; p0 += nl * U) {
                 int ss[U], len[U], cnt[U], dst[U];
                 pzkey_t tg[U], ky[U];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const int p = p0 + WAVE * u;
+                    const int p = p0 + nl * u;
                     ok[u] = p < N;
                     const int pc = ok[u] ? p : 0;
                     const int r = (int)(((unsigned long long)(pc + 1) * magic) >> 32) >> lv;
@@ -859,9 +1009,9 @@ struct MulEval {
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    if (ok[u]) { const int o__ = BIDX(w, dst[u] + cnt[u], N, 3); Ko[o__] = ky[u]; Vo[o__] = V[BIDX(w, p0 + WAVE * u, N, 4)]; }
+                    if (ok[u]) { const int o__ = BIDX(w, dst[u] + cnt[u], N, 3); Ko[o__] = ky[u]; Vo[o__] = V[BIDX(w, p0 + nl * u, N, 4)]; }
             }
-            WSYNC();
+            psync(w);
             cur ^= 1;
         }
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
@@ -876,12 +1026,12 @@ struct MulEval {
         PROF_T0
         const GLB_AS pzkey_t* lk = a_short ? b.keys : a.keys;
         const GLB_AS pzkey_t* sk = a_short ? a.keys : b.keys;
-        for (int t = w.lane; t < nl; t += WAVE) w.skey[t] = t ? lk[t - 1] : 0ull;
-        if (w.lane < ns) w.skey[nl + w.lane] = w.lane ? sk[w.lane - 1] : 0ull;
-        WSYNC();
+        for (int t = w.lane2; t < nl; t += w.nl) w.skey[t] = t ? lk[t - 1] : 0ull;
+        if (w.lane2 < ns) w.skey[nl + w.lane2] = w.lane2 ? sk[w.lane2 - 1] : 0ull;
+        psync(w);
         const LDS_AS pzkey_t* L = w.skey;
         const LDS_AS pzkey_t* S = w.skey + nl;
-        for (int idx = w.lane; idx < N; idx += WAVE) {
+        for (int idx = w.lane2; idx < N; idx += w.nl) {
             int i, j;
             split(idx, i, j);
             const int r = a_short ? i : j, pos = a_short ? j : i;
@@ -894,7 +1044,7 @@ struct MulEval {
             }
             w.sidx[rank] = (uint16_t)idx;
         }
-        WSYNC();
+        psync(w);
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
         return true;
     }
@@ -1040,13 +1190,15 @@ __device__ PZW_NOINLINE void mul(Wave& w_, const PZ& out_, const View& a_, const
     SH::mul(ia2, ib2, ii);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) base2[e] = ii[e] + (t2[e] + t3[e]);
-    WSYNC();
-    if (w.lane == 0) {
+    psync(w);
+    if (w.lane2 == 0) {
 #pragma unroll
         for (int e = 0; e < SH::SZ; e++) out.cen[e] = cen[e];
     }
-    if (a.cnt == 0) emit_presorted<SH::SZ>(w, N, ev, out, base, base2);  // constant left operand: b's keys, in b's order
-    else sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
+    if (a.cnt == 0) {   // constant left operand: b's keys, in b's order  (a pair: the first wave alone)
+        if (w.half == 0) emit_presorted<SH::SZ>(w, N, ev, out, base, base2);
+        psync(w);
+    } else sort_reduce_emit<SH::SZ>(w, N, ev, out, base, base2);
     PROF_CALL_END(N)
 }
 
@@ -1214,7 +1366,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
-    WSYNC();
+    psync(w);
     PROF_CALL_END(N_in)
 }
 

@@ -117,6 +117,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_STEP_AUX3 104           /* 1 (default) | 0: the w_aux recursion on the fourth wave of four-wave blocks */
 #define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..4 (default 4): one-wave blocks resident per compute unit */
 #define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
+#define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
 #define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 36: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
 #define ARMOUR_OPT_P1_TV_WAVES 111            /* 0 automatic (default) | 1 | 3 | 4 | 8 wavefronts per block (r: 4 and 8 share walks between waves) */
