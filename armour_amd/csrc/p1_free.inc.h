@@ -16,7 +16,8 @@
 // operands as run_rnea: bit-identical tables.
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
        T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS, T3_NA = T3_X2 + ARMOUR_MAX_JOINTS,
-       T3_CNT = T3_NA + ARMOUR_MAX_JOINTS, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
+       T3_X3 = T3_NA + ARMOUR_MAX_JOINTS,   // w x (w_aux x com) of a late link, built by a wave that is through with its recursion (tail_cross)
+       T3_CNT = T3_X3 + ARMOUR_MAX_JOINTS + 1, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_C3P, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 // LDS mailbox of run_rnea / run_rnea_free, followed by the two walk-helper channels of the time-vectorised four-wave blocks
 // (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
 constexpr int kHelpBase = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;
@@ -188,7 +189,28 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // needs the state alone before it waits for the linear acceleration.  (Each of the three alone changes nothing: the pass ends with
     // F of the last link, which needs the last linear acceleration.)
     // (at most K + 1 of them: the states the tail reads must still be alive when the recursion ends -- it gives state k back K joints later)
-    const int n_tail = J >= 5 ? 4 : J >= 4 ? 3 : 0;   // (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
+    const int n_tail_max = J >= 5 ? 4 : J >= 4 ? 3 : 0;
+    const int n_tail = fk_wave && cf.tail_cross >= 100 ? min(cf.tail_cross / 100 - 1, n_tail_max) : n_tail_max;   // (development: 100 * (n + 1) in cf.tail_cross holds the tail to n links)   (three waves: the F / N wave, which also carries omega there, is the last to finish the forward pass as well)
+    // Round 4: the F / N wave is still the last one through the forward pass (per-step kernel, slowest step of a lone problem: the four waves are
+    // through after 0.89 / 1.26 / 1.30 / 1.48 M cycles; time-vectorised blocks of a 128-problem batch: 9.5 / 8.1 / 9.2 / 10.1 M).  Of what it does for a
+    // link, w x (w_aux x com) needs neither the linear acceleration nor anything of the F / N wave's own: for the last `tc_links` links (whose
+    // states are still alive when the recursions end) a wave that is through with its recursion builds it -- wave `tc_wave` = 3 (the fourth
+    // wave, when it has no forward kinematics to do) or 1 (the angular wave, before its tail moments) -- and the F / N wave takes it from the
+    // mailbox.  Same operators on the same operands: same bits.  (cf.tail_cross: 0 off | links | 10 + links: on wave 1)
+    const int tc_opt = cf.tail_cross % 100;
+    const int tc_wave = fk_wave && aux3 && tc_opt > 0 ? (tc_opt >= 10 ? 1 : 3) : -1;
+    const int tc_links = tc_wave < 0 ? 0 : min(tc_opt % 10, K + 1);
+    auto tail_cross = [&]() {   // (the wave that owns them frees them behind barrier (A))
+        for (int s = J - tc_links + 1; s <= J; s++) {
+            if (tc_wave == 1) t3_wait(c, T3_CA, s);   // (w_s, w_aux_s are the fourth wave's)
+            const TPZ wv = t3_take(c, T3_ST + 3 * s), waux = t3_take(c, T3_ST + 3 * s + 2);
+            TPZ c2 = c.crossPzMat(waux, &cf.rb.com[3 * (s - 1)]);
+            TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+            t3_post(c, T3_X3 + s, c3);
+            t3_signal(c, T3_C3P, s);
+        }
+    };
+    auto tail_cross_free = [&]() { for (int s = J - tc_links + 1; s <= J; s++) c.freeVs(t3_take(c, T3_X3 + s)); };
     if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
     // walk helpers (four-wave blocks of the time-vectorised kernel, backward pass): both channels start empty, every wave's job count at 0
     bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
@@ -269,6 +291,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (!aux3) t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
             t3_signal(c, T3_C1, s + 1);
         }
+        if (tc_wave == 1) tail_cross();   // (first: the F / N wave is waiting for these)
         for (int s = J; s > J - n_tail; s--) {   // N = I * wdot + cross(w_aux, I * w) of link s - 1
             t3_wait(c, T3_CA, s);
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
@@ -280,6 +303,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             t3_post(c, T3_N + s - 1, N);
         }
         c.prof_forward_done(); c.bar();   // (A) the forward pass is over everywhere
+        if (tc_wave == 1) tail_cross_free();
         for (int k = freed; k <= J; k++)
             for (int e = 1; e < (aux3 ? 2 : 3); e++) c.freeVs(t3_take(c, T3_ST + 3 * k + e));
         if (wave_w == 1) for (int k = freed_w1; k <= J; k++) c.freeVs(t3_take(c, T3_ST + 3 * k));
@@ -360,9 +384,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             }
             if (!aux3 && w3_fk) fk_step(c, fk, s, b, t_lane);
         }
+        if (tc_wave == 3) tail_cross();
         if (aux3 && w3_fk) for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);   // (behind the recursions the other waves wait for)
         if (w3_fk) c.freeVs(fk.T);
         c.prof_forward_done(); c.bar();   // (A)
+        if (tc_wave == 3) tail_cross_free();
         for (int k = freed_w; k <= J; k++) { c.freeVs(t3_take(c, T3_ST + 3 * k)); if (aux3) c.freeVs(t3_take(c, T3_ST + 3 * k + 2)); }
         if (aux3) for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_NA + k));
         for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
@@ -390,14 +416,16 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                     const double* cm = &cf.rb.com[3 * (s - 1)];
                     TPZ c1 = wdot;
                     if constexpr (!fused_cross) c1 = c.crossPzMat(wdot, cm);
-                    TPZ c2 = c.crossPzMat(waux, cm);
-                    TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                    const bool from_tail = s > J - tc_links;   // w x (w_aux x com) comes from a wave that is through with its recursion
+                    TPZ c3;
+                    if (from_tail) { t3_wait(c, T3_C3P, s); c3 = t3_take(c, T3_X3 + s); }
+                    else { TPZ c2 = c.crossPzMat(waux, cm); c3 = c.crossPzPz(wv, c2); c.freeVs(c2); }
                     t3_wait(c, T3_C0, s);
                     const TPZ lacc = t3_take(c, T3_LA + s);
                     TPZ s2;
                     if constexpr (fused_cross) s2 = c.sum3x(lacc, wdot, cm, c3);   // (lacc + wdot x com) + c3
                     else { s2 = c.sum3(lacc, c1, c3); c.freeVs(c1); }
-                    c.freeVs(c3);
+                    if (!from_tail) c.freeVs(c3);
                     TPZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
                     t3_post(c, T3_F + s - 1, F);
                 }

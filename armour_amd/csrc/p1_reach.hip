@@ -84,6 +84,7 @@ struct P1Cfg {
     int tv_aux_on_fk_wave;  // four-wave blocks: the w_aux recursion runs on the forward-kinematics wave (p1_free.inc.h)
     int tv_help_shift;    // eight-wave blocks: role wave p's helper is wave 4 + (p + shift) % 4
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
+    int tail_cross;       // four-wave blocks: w x (w_aux x com) of the last links on a wave that is through with its recursion (p1_free.inc.h): 0 off | links | 10 + links (on wave 1)
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
 };
 
@@ -1851,6 +1852,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
         cf.step_pairs = h->tune(ARMOUR_OPT_P1_STEP_PAIRS);
+        cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
@@ -1998,6 +2000,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tv_help_min = tv_help_min_env; cf.tv_help_n = tv_help_n_env; cf.tv_help_shift = tv_shift_env;
             const int tv_aux3_env = h->tune(ARMOUR_OPT_P1_TV_AUX3);
             cf.tv_aux_on_fk_wave = tv_aux3_env;
+            cf.tail_cross = h->tune(ARMOUR_OPT_P1_TV_TAIL_CROSS);
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {

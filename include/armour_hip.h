@@ -117,6 +117,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_STEP_AUX3 104           /* 1 (default) | 0: the w_aux recursion on the fourth wave of four-wave blocks */
 #define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..4 (default 4): one-wave blocks resident per compute unit */
 #define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
+#define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
 #define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
 #define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 36: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
@@ -129,6 +130,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_TV_HELP_MIN 117         /* (r) default 192: walks with fewer sorted terms stay on one wave */
 #define ARMOUR_OPT_P1_TV_HELP_N 118           /* (r) 1 (default) | 0: the n-recursion shares its walks as well */
 #define ARMOUR_OPT_P1_TV_AUX3 119             /* 1 (default) | 0: as ARMOUR_OPT_P1_STEP_AUX3 */
+#define ARMOUR_OPT_P1_TV_TAIL_CROSS 121       /* as ARMOUR_OPT_P1_STEP_TAIL_CROSS, for the four-wave blocks of the time-vectorised kernel */
 #define ARMOUR_OPT_P1_FULL_PLANES 120         /* 0 (default) the lean half-space table | 1 every plane and component resident (armour_get_hyperplanes builds it on demand otherwise) */
 /* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
 #define ARMOUR_OPT_P2_EX 130                  /* 1 (default) | 0: the fixed-load-count kernels for problems with exactly 24 live planes */
