@@ -1906,7 +1906,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // operator done once per group.  Batches only: a single problem has two groups, i.e. two waves, and is faster step by step
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
-    const int tv_min_groups = h->tune(ARMOUR_OPT_P1_TV_MIN_GROUPS);  // default 36: below this the per-step kernel is faster (re-measured in round 3 with the shared walks: 8.53 against 8.26 ms at B = 16, T = 100 -- the per-step kernel steps up with every 768 items -- and 6.2 against 7.9 at B = 14; profiles/r03_p1_breakeven.txt)
+    const int tv_min_groups = h->tune(ARMOUR_OPT_P1_TV_MIN_GROUPS);  // default 31: below this the per-step kernel is faster (re-measured at the end of round 4, B problems of 100 steps, per-step against time-vectorised: 14: 5.84 / 6.35 ms, 16: 7.49 / 6.64 -- the per-step kernel steps up with every 768 items -- 18: 8.04 / 6.66; round 3: 36, profiles/r03_p1_breakeven.txt)
     const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 30 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in

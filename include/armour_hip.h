@@ -80,7 +80,7 @@ void armour_free_pinned(void* p);
 /* ---- per-handle options ---- */
 /* ARMOUR_OPT_P1_BUILD selects the reach-set build kernel of armour_set_problems* (value 0, 1 or 2):
  *   0  automatic (default): one wavefront per (problem, time step) for small batches, the time-vectorised kernel (one wavefront per
- *      50-64 time steps of a problem) from B*T >= 1800 on;
+ *      50-64 time steps of a problem) from B*T >= 1550 on;
  *   1  always per time step;   2  always time-vectorised.
  * TOLERANCE CONTRACT.  Both kernels run the reference's operator sequence on the same operands and produce identical monomial keys,
  * coefficients and centres bit for bit; they add the pruned amounts of simplify() (RT/PZsparse.cu:327-341) into the independent
@@ -120,7 +120,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
 #define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
-#define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 36: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
+#define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 31: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
 #define ARMOUR_OPT_P1_TV_WAVES 111            /* 0 automatic (default) | 1 | 3 | 4 | 8 wavefronts per block (r: 4 and 8 share walks between waves) */
 #define ARMOUR_OPT_P1_TV_FREE 112             /* 1 (default) | 0: free-running role waves | a block barrier per joint */
 #define ARMOUR_OPT_P1_TV_SPLIT_FK 113         /* -1 automatic (default) | 0 | 1 */
