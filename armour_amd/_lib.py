@@ -77,6 +77,7 @@ OPT_P1_STEP_AUX3 = 104
 OPT_P1_MAX_WAVES_PER_CU = 105
 OPT_P1_TWO_PASS = 106
 OPT_P1_STEP_PAIRS = 107
+OPT_P1_STEP_QUEUE = 109
 OPT_P1_STEP_TAIL_CROSS = 108
 OPT_P1_TV_TAIL_CROSS = 121
 OPT_P1_TV_MIN_GROUPS = 110

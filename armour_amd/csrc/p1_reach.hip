@@ -85,6 +85,8 @@ struct P1Cfg {
     int tv_help_shift;    // eight-wave blocks: role wave p's helper is wave 4 + (p + shift) % 4
     int tv_walk_helpers;  // four-wave blocks: the idle waves of the backward pass walk part of the recursions' operators (pz_tv.h); 0 off, 1 on, n > 1: the primary keeps n / 32 of the terms
     int tail_cross;       // four-wave blocks: w x (w_aux x com) of the last links on a wave that is through with its recursion (p1_free.inc.h): 0 off | links | 10 + links (on wave 1)
+    unsigned* queue;      // per-step kernel: the blocks draw their items from this counter (nullptr: block k takes items k, k + blocks, ...)
+    int queue_order;      // 1: the late time steps of every problem first (they are the expensive ones) | 2: in index order | 3: the early steps first
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
 };
 
@@ -1095,9 +1097,29 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.peer_skey = (LDS_AS pzkey_t*)pb; c.peer_sidx = (LDS_AS uint16_t*)(pb + (size_t)cf.capKey * sizeof(pzkey_t));
     }
     if (c.w.lane < ST_WORDS) c.w.lstat[c.w.lane] = 0;
-    for (int it0 = blockIdx.x; it0 < cf.n_items + cf.fk_items; it0 += gridDim.x) {
+    // Which block builds which item (round 4).  Round 3 dealt them out by index -- block k took items k, k + blocks, ... -- and an item's cost
+    // grows with its time step: three problems, 300 items on 256 CUs, took two full rounds, the second for 44 items.  When there are more items than
+    // blocks the blocks now draw from a counter, and the order of the draw puts the late (expensive) steps of every problem first -- longest-
+    // processing-time-first on identical machines.  Measured (four-wave blocks, B problems of 100 steps): B = 3 2.12 -> 1.94 ms, 4 2.34 -> 2.09,
+    // 8 4.15 -> 3.98, 12 5.57 -> 5.18, 16 7.50 -> 7.10 -- less than the spread of the instrumented build's item costs (0.4 .. 1.0) promised: in the
+    // release build the cheapest items are no cheaper than 0.9 of the slowest.  An item's result does not depend on who builds it or when.
+    LDS_AS int* qword = c.mb + kMbWords - 1;   // (the last word of the walk-helper channels this chain does not use; pairs: the first 2 * PW_WORDS + 4)
+    int it0 = blockIdx.x;
+    for (;;) {
+        if (cf.queue) {
+            __syncthreads();   // everybody is through with the previous item, and has read its index
+            if (threadIdx.x == 0) *qword = (int)atomicAdd(cf.queue, 1u);
+            __syncthreads();
+            it0 = __builtin_amdgcn_readfirstlane(*qword);
+        }
+        if (it0 >= cf.n_items + cf.fk_items) break;
         const bool fk_only = it0 >= cf.n_items || cf.mode == ARMOUR_MODE_ARMTD;
-        const int it = it0 >= cf.n_items ? it0 - cf.n_items : it0;
+        int it = it0 >= cf.n_items ? it0 - cf.n_items : it0;
+        if (cf.queue && !cf.items && cf.queue_order != 2) {   // position in the draw -> item: time steps from the last (order 1) or the first (3), every problem's in turn
+            const int nb = cf.n_items / cf.T;   // (all problems, all steps: n_items = B * T)
+            const int tq = it / nb, bq = it - tq * nb;
+            it = bq * cf.T + (cf.queue_order == 1 ? cf.T - 1 - tq : tq);
+        }
         const int item = cf.items ? cf.items[it] : it;
         const int b = item / cf.T, t = item - b * cf.T;
         const int err_before = c.w.lstat[ST_ERR];  // (the retry list is only used with NW = 1)
@@ -1159,6 +1181,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         if (c.w.lane == 0 && t == 60 && !fk_only) printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
         c.bar_wait = 0;
 #endif
+        if (!cf.queue) it0 += gridDim.x;
     }
 #ifdef P1_PROFILE
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1852,6 +1875,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
         cf.step_pairs = h->tune(ARMOUR_OPT_P1_STEP_PAIRS);
+        cf.queue_order = h->tune(ARMOUR_OPT_P1_STEP_QUEUE);
+        cf.queue = cf.queue_order != 0 && n_items + fk_items > waves ? wk->d_status + ST_WORDS + 60 : nullptr;   // (with a block per item there is nothing to draw: B = 1 1.044 against 1.069 ms.  The word: one of the status block that the profile counters of development builds do not reach)
+        if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));

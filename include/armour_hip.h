@@ -118,6 +118,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..4 (default 4): one-wave blocks resident per compute unit */
 #define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
 #define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
+#define ARMOUR_OPT_P1_STEP_QUEUE 109          /* 1 (default): the blocks draw their items from a counter, every problem's late time steps first | 2, 3: in index order, early steps first | 0: block k builds items k, k + blocks, ... */
 #define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
 #define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 31: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */

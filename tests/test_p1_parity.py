@@ -513,7 +513,7 @@ def _shape(**kw):
     from armour_amd import _lib
     names = {"build": _lib.OPT_P1_BUILD, "step_waves": _lib.OPT_P1_STEP_WAVES, "step_free": _lib.OPT_P1_STEP_FREE, "step_split_fk": _lib.OPT_P1_STEP_SPLIT_FK,
              "tv_waves": _lib.OPT_P1_TV_WAVES, "tv_free": _lib.OPT_P1_TV_FREE, "tv_helpers": _lib.OPT_P1_TV_HELPERS,
-             "step_pairs": _lib.OPT_P1_STEP_PAIRS, "step_tail_cross": _lib.OPT_P1_STEP_TAIL_CROSS, "tv_tail_cross": _lib.OPT_P1_TV_TAIL_CROSS}
+             "step_queue": _lib.OPT_P1_STEP_QUEUE, "step_pairs": _lib.OPT_P1_STEP_PAIRS, "step_tail_cross": _lib.OPT_P1_STEP_TAIL_CROSS, "tv_tail_cross": _lib.OPT_P1_TV_TAIL_CROSS}
     return {names[k]: v for k, v in kw.items()}
 
 
@@ -521,9 +521,10 @@ def _shape(**kw):
     (1, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1), dict(build=1, step_free=1, step_split_fk=0),
          dict(build=1, step_pairs=0), dict(build=1, step_tail_cross=12)]),
     (2, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1), dict(build=1, step_pairs=0)]),
+    (3, [dict(build=1, step_waves=4, step_queue=0), dict(build=1, step_waves=4), dict(build=1, step_waves=4, step_queue=3), dict(build=1, step_waves=1, step_queue=2)]),
     (3, [dict(build=2, tv_waves=4, tv_helpers=0), dict(build=2, tv_waves=3), dict(build=2, tv_waves=1), dict(build=2, tv_waves=4, tv_free=0), dict(build=2, tv_waves=3, tv_free=0),
          dict(build=2, tv_waves=4, tv_helpers=0, tv_tail_cross=0), dict(build=2, tv_waves=4, tv_helpers=0, tv_tail_cross=13)]),
-], ids=["per-step, one problem", "per-step, two problems", "time-vectorised"])
+], ids=["per-step, one problem", "per-step, two problems", "per-step, three problems: more items than blocks", "time-vectorised"])
 def test_wave_choreographies_leave_identical_tables(B, settings):
     """Which wave of a block computes what -- one wave playing every role, three roles with a barrier per joint, three or four
     free-running waves with the angular velocity, the torque tables and the helper products dealt out among them
@@ -532,6 +533,7 @@ def test_wave_choreographies_leave_identical_tables(B, settings):
     Round 4 adds two more ways of dealing the work out, with the same claim: two waves on every operator of the backward pass of a per-step
     four-wave block (ARMOUR_OPT_P1_STEP_PAIRS: a reduce pass adds its pruned amounts as the same two partial sums on one wave as on two), and
     w x (w_aux x com) of the last links built by a wave that is through with its recursion (ARMOUR_OPT_P1_*_TAIL_CROSS).
+    And which block builds which item (ARMOUR_OPT_P1_STEP_QUEUE: dealt out by index, or drawn from a counter in one of three orders).
     Round 4: the shapes are per-handle options (include/armour_hip.h, ARMOUR_OPT_P1_*), so all of them run in THIS process, one
     handle each -- they were environment variables read once per process, and every shape needed a process of its own."""
     digests, shapes = [], []
