@@ -77,7 +77,7 @@ struct TvFn {   // whole-call time of an operator, by kind (the kind may be set 
 #define TVP_FN(t, k)
 #define TVP_FN_KIND(k)
 #endif
-#ifdef TV_PROFILE_FULL
+#ifdef TV_PROFILE
 #define TVP_T0 const long long tvp0__ = clock64();
 #define TVP_T1 const long long tvp1__ = clock64();
 #define TVP_END(t, N, E, TY) { const long long tvp2__ = clock64(); (t).c_sort += tvp1__ - tvp0__; (t).c_walk += tvp2__ - tvp1__; (t).n_raw += (N); (t).n_calls += 1; (t).n_emit += (E); (t).c_type[TY] += tvp2__ - tvp1__; (t).n_type[TY] += (N); }
