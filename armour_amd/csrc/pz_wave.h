@@ -260,6 +260,34 @@ __device__ inline int upper_bound_lds(const LDS_AS pzkey_t* a, int n, pzkey_t t)
     return lo;
 }
 
+// Merge path (round 4): places [c, c9) of the merge of the two adjacent sorted runs [ps, am) and [am, pe) of (K, V), written to (Ko, Vo) at the same
+// places.  One search along the diagonal of the first place -- how many of the places before it the first run fills -- then a two-finger merge,
+// one key read per place.  Ties: the first run's key first (first_wins), or the second's.  (No key is PZKEY_MAX: a run that is through never wins.)
+__device__ inline void merge_span(const LDS_AS pzkey_t* K, const LDS_AS uint16_t* V, LDS_AS pzkey_t* Ko, LDS_AS uint16_t* Vo,
+                                  int ps, int am, int pe, int c, int c9, bool first_wins, int N) {
+    const int la = am - ps, lb = pe - am;
+    const int d0 = c - ps, d9 = c9 - ps;
+    int lo = max(0, d0 - lb), hi = min(d0, la);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const pzkey_t ka = K[ps + mid], kq = K[am + d0 - 1 - mid];
+        const bool first = first_wins ? (ka <= kq) : (ka < kq);   // does A[mid] go before B[d0 - 1 - mid]?
+        lo = first ? mid + 1 : lo; hi = first ? hi : mid;
+    }
+    int i = lo, j = d0 - lo;
+    pzkey_t ka = K[min(ps + i, N - 1)], kq = K[min(am + j, N - 1)];
+    ka = i < la ? ka : PZKEY_MAX; kq = j < lb ? kq : PZKEY_MAX;
+    for (int o = d0; o < d9; o++) {
+        const bool first = first_wins ? (ka <= kq) : (ka < kq);
+        const int src = first ? ps + i : am + j;
+        Ko[ps + o] = first ? ka : kq;
+        Vo[ps + o] = V[src];
+        i += first ? 1 : 0; j += first ? 0 : 1;
+        const pzkey_t nx = K[min(first ? ps + i : am + j, N - 1)];
+        if (first) ka = i < la ? nx : PZKEY_MAX; else kq = j < lb ? nx : PZKEY_MAX;
+    }
+}
+
 // Sort step shared by every operator: checks the LDS capacity, then leaves the N raw terms of `ev` ordered by
 // (key, generation index) -- sidx[p] = index of the p-th term; the p-th key is skey[p], or ev.key_lds(w, sidx[p]) when
 // `indirect` is returned (merge paths that keep the operands' key lists in skey).  Returns the N to process (0 on overflow).
@@ -583,6 +611,51 @@ struct LinEval {
 #endif
         PROF_T0
         const int nl = w.nl;   // (cooperating lanes: one wave's, or a pair's)
+#ifndef LIN_MERGE_BY_SEARCH
+        // Merge path (round 4): the NS sorted runs are merged pairwise in ceil(log2 NS) levels between the two halves of the sort buffers, as
+        // a product's runs are (MulEval::tree_merge) -- a lane fills consecutive places of a level with one diagonal search and a two-finger
+        // merge -- instead of NS - 1 binary searches for every term (-DLIN_MERGE_BY_SEARCH: that form, also taken when the buffers cannot
+        // hold two copies).  Ties go to the earlier run, which is generation order: the same order, and the keys come out sorted in skey.
+        if (2 * N <= w.cap_key && 2 * N <= w.cap_raw) {
+            constexpr int LV = NS <= 2 ? 1 : 2;   // (NS <= 4)
+            static_assert(NS <= 4, "merge levels");
+            indirect = false;
+            int cur = LV & 1;   // the last level writes buffer 0 = (skey, sidx) as the reduce pass expects them
+            LDS_AS pzkey_t* kb[2] = {w.skey, w.skey + N};
+            LDS_AS uint16_t* vb[2] = {w.sidx, w.sidx + N};
+            for (int i0 = w.lane2; i0 < N; i0 += 4 * nl) {   // (four keys per lane and pass in flight)
+                pzkey_t kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) kk[u] = key(min(i0 + u * nl, N - 1));
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int idx = i0 + u * nl; if (idx < N) { kb[cur][idx] = kk[u]; vb[cur][idx] = (uint16_t)idx; } }
+            }
+            psync(w);
+            const int E = ((N + nl - 1) / nl) | 1;
+#pragma unroll
+            for (int lv = 0; lv < LV; lv++) {
+                // level 0: runs (0, 1) and (2, 3); level 1: (01, 23).  With two runs: one level, one pair.
+                int bnd[5];   // pair p of this level: [bnd[2p], bnd[2p+1]) + [bnd[2p+1], bnd[2p+2])
+                if (NS <= 2 || lv == 1) { bnd[0] = 0; bnd[1] = NS <= 2 ? off[1] : off[2 < NS ? 2 : NS]; bnd[2] = N; bnd[3] = N; bnd[4] = N; }
+                else { bnd[0] = 0; bnd[1] = off[1]; bnd[2] = off[2]; bnd[3] = NS >= 4 ? off[3] : N; bnd[4] = N; }
+                const LDS_AS pzkey_t* K = kb[cur];
+                const LDS_AS uint16_t* V = vb[cur];
+                int c = w.lane2 * E;
+                const int cend = min(c + E, N);
+                while (c < cend) {
+                    const bool second = c >= bnd[2];
+                    const int ps = second ? bnd[2] : bnd[0], am = second ? bnd[3] : bnd[1], pe = second ? bnd[4] : bnd[2];
+                    const int c9 = min(cend, pe);
+                    merge_span(K, V, kb[cur ^ 1], vb[cur ^ 1], ps, am, pe, c, c9, true, N);
+                    c = c9;
+                }
+                psync(w);
+                cur ^= 1;
+            }
+            PROF_ADD(PR_SORT) PROF_ADD(PR_S_LINMERGE)
+            return true;
+        }
+#endif
         for (int i0 = w.lane2; i0 < N; i0 += 4 * nl) {   // (four keys per lane and pass in flight: see MulEval::tree_merge)
             pzkey_t kk[4];
 #pragma unroll
@@ -959,15 +1032,37 @@ struct MulEval {
             }
         }
         psync(w);
-        constexpr int U = 8;
+        [[maybe_unused]] constexpr int U = 8;
         for (int lv = 0; lv < levels; lv++) {
             const int rl = d1 << lv;  // run r of this level holds the positions q with q + 1 in [r*rl, (r+1)*rl)
-            int top = 1;
+            [[maybe_unused]] int top = 1;
             while (top * 2 <= rl) top *= 2;
             const LDS_AS pzkey_t* K = kb[cur];
             const LDS_AS uint16_t* V = vb[cur];
             LDS_AS pzkey_t* Ko = kb[cur ^ 1];
             LDS_AS uint16_t* Vo = vb[cur ^ 1];
+#ifndef TREE_MERGE_BY_SEARCH
+            // Merge path (round 4; -DTREE_MERGE_BY_SEARCH builds the rounds 2-3 form below, one binary search per element and level).  Every
+            // lane produces E CONSECUTIVE places of the level's output: one search along the diagonal of its first place -- how many of the
+            // places before it come from the pair's first run -- and then a serial two-finger merge of E elements, one key read per element.
+            // The search form spent 11 steps of ~8 instructions on every element at every level; this spends them once per lane and level.
+            // A product's sort was half of the operator (1603 raw terms: 67 k of 119 k cycles; a 40 x 40 cross product: 168 k of 240 k).
+            // Ties as before: between runs of a's terms the earlier run first, between runs of b's terms the later.  Same order, same bits.
+            {
+                const int pl = 2 * rl;                      // a pair of runs, in the q + 1 numbering
+                const int E = ((N + nl - 1) / nl) | 1;      // (odd: the lanes' places start an odd number of keys apart -- not all in one LDS bank)
+                int c = w.lane2 * E;
+                const int cend = min(c + E, N);
+                while (c < cend) {                          // (a lane's places may reach into the next pair)
+                    const int pr = (int)(((unsigned long long)(c + 1) * magic) >> 32) >> (lv + 1);
+                    const int ps = max(pr * pl - 1, 0);                  // the pair's first run: [ps, am), its second: [am, pe)
+                    const int am = min(pr * pl + rl - 1, N), pe = min((pr + 1) * pl - 1, N);
+                    const int c9 = min(cend, pe);                        // this lane's places of the pair: [c, c9)
+                    merge_span(K, V, Ko, Vo, ps, am, pe, c, c9, by_a, N);
+                    c = c9;
+                }
+            }
+#else
             for (int p0 = w.lane2; p0 < N; p0 += nl * U) {
                 int ss[U], len[U], cnt[U], dst[U];
                 pzkey_t tg[U], ky[U];
@@ -1011,6 +1106,7 @@ struct MulEval {
                 for (int u = 0; u < U; u++)
                     if (ok[u]) { const int o__ = BIDX(w, dst[u] + cnt[u], N, 3); Ko[o__] = ky[u]; Vo[o__] = V[BIDX(w, p0 + nl * u, N, 4)]; }
             }
+#endif
             psync(w);
             cur ^= 1;
         }
