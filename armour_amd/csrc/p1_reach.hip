@@ -1874,7 +1874,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
         const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
-        cf.step_pairs = h->tune(ARMOUR_OPT_P1_STEP_PAIRS);
+        cf.step_pairs = h->tune(ARMOUR_OPT_P1_STEP_PAIRS) == 2 || (h->tune(ARMOUR_OPT_P1_STEP_PAIRS) == 1 && n_items + fk_items <= waves);   // (1: with a block per item only -- after the merge-path sorts the pairs are worth 1 % to a lone problem and cost 2 % when the blocks loop: B = 4 1.95 against 1.99 ms, 8: 3.73 against 3.82; 2: always)
         cf.queue_order = h->tune(ARMOUR_OPT_P1_STEP_QUEUE);
         cf.queue = cf.queue_order != 0 && n_items + fk_items > waves ? wk->d_status + ST_WORDS + 60 : nullptr;   // (with a block per item there is nothing to draw: B = 1 1.044 against 1.069 ms.  The word: one of the status block that the profile counters of development builds do not reach)
         if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));

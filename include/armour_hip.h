@@ -119,7 +119,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
 #define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
 #define ARMOUR_OPT_P1_STEP_QUEUE 109          /* 1 (default): the blocks draw their items from a counter, every problem's late time steps first | 2, 3: in index order, early steps first | 0: block k builds items k, k + blocks, ... */
-#define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators */
+#define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0 | 2: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators (1: when every item has a block of its own; 2: always) */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
 #define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 31: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
 #define ARMOUR_OPT_P1_TV_WAVES 111            /* 0 automatic (default) | 1 | 3 | 4 | 8 wavefronts per block (r: 4 and 8 share walks between waves) */

@@ -521,7 +521,8 @@ def _shape(**kw):
     (1, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1), dict(build=1, step_free=1, step_split_fk=0),
          dict(build=1, step_pairs=0), dict(build=1, step_tail_cross=12)]),
     (2, [dict(build=1, step_free=1), dict(build=1, step_free=0), dict(build=1, step_waves=1), dict(build=1, step_pairs=0)]),
-    (3, [dict(build=1, step_waves=4, step_queue=0), dict(build=1, step_waves=4), dict(build=1, step_waves=4, step_queue=3), dict(build=1, step_waves=1, step_queue=2)]),
+    (3, [dict(build=1, step_waves=4, step_queue=0), dict(build=1, step_waves=4), dict(build=1, step_waves=4, step_queue=3), dict(build=1, step_waves=1, step_queue=2),
+         dict(build=1, step_waves=4, step_pairs=2)]),
     (3, [dict(build=2, tv_waves=4, tv_helpers=0), dict(build=2, tv_waves=3), dict(build=2, tv_waves=1), dict(build=2, tv_waves=4, tv_free=0), dict(build=2, tv_waves=3, tv_free=0),
          dict(build=2, tv_waves=4, tv_helpers=0, tv_tail_cross=0), dict(build=2, tv_waves=4, tv_helpers=0, tv_tail_cross=13)]),
 ], ids=["per-step, one problem", "per-step, two problems", "per-step, three problems: more items than blocks", "time-vectorised"])
