@@ -1836,7 +1836,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const bool multi = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
                            : nw_env ? nw_env >= 3
                            : collect ? false
-                           : fits4 ? 100 * r4 < 258 * r1
+                           : fits4 ? r4 <= 5 && 100 * r4 < 258 * r1   // (round 4, after the merge-path sorts and the item queue, B problems of 100 steps, four waves | one: 5: 2.22 | 2.66, 8: 3.73 | 3.76, 10: 4.03 | 4.46, 12: 4.83 | 4.94, 13: 5.63 | 5.04, 15: 5.90 | 5.28 -- from the sixth round on the one-wave blocks' throughput wins)
                                    : (n_items <= cus && lds_bytes(cap, kRoles) <= (size_t)160 * 1024);
         const bool four = multi && free_env0 && (nw_env ? nw_env == 4 : fits4);
         const bool three = multi && !four;
