@@ -263,29 +263,37 @@ __device__ inline int upper_bound_lds(const LDS_AS pzkey_t* a, int n, pzkey_t t)
 // Merge path (round 4): places [c, c9) of the merge of the two adjacent sorted runs [ps, am) and [am, pe) of (K, V), written to (Ko, Vo) at the same
 // places.  One search along the diagonal of the first place -- how many of the places before it the first run fills -- then a two-finger merge,
 // one key read per place.  Ties: the first run's key first (first_wins), or the second's.  (No key is PZKEY_MAX: a run that is through never wins.)
-__device__ inline void merge_span(const LDS_AS pzkey_t* K, const LDS_AS uint16_t* V, LDS_AS pzkey_t* Ko, LDS_AS uint16_t* Vo,
-                                  int ps, int am, int pe, int c, int c9, bool first_wins, int N) {
+template <bool FIRST_WINS>
+__device__ inline void merge_span_t(const LDS_AS pzkey_t* K, const LDS_AS uint16_t* V, LDS_AS pzkey_t* Ko, LDS_AS uint16_t* Vo,
+                                    int ps, int am, int pe, int c, int c9, int N) {
     const int la = am - ps, lb = pe - am;
-    const int d0 = c - ps, d9 = c9 - ps;
+    const int d0 = c - ps;
     int lo = max(0, d0 - lb), hi = min(d0, la);
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         const pzkey_t ka = K[ps + mid], kq = K[am + d0 - 1 - mid];
-        const bool first = first_wins ? (ka <= kq) : (ka < kq);   // does A[mid] go before B[d0 - 1 - mid]?
+        const bool first = FIRST_WINS ? (ka <= kq) : (ka < kq);   // does A[mid] go before B[d0 - 1 - mid]?
         lo = first ? mid + 1 : lo; hi = first ? hi : mid;
     }
-    int i = lo, j = d0 - lo;
-    pzkey_t ka = K[min(ps + i, N - 1)], kq = K[min(am + j, N - 1)];
-    ka = i < la ? ka : PZKEY_MAX; kq = j < lb ? kq : PZKEY_MAX;
-    for (int o = d0; o < d9; o++) {
-        const bool first = first_wins ? (ka <= kq) : (ka < kq);
-        const int src = first ? ps + i : am + j;
-        Ko[ps + o] = first ? ka : kq;
-        Vo[ps + o] = V[src];
-        i += first ? 1 : 0; j += first ? 0 : 1;
-        const pzkey_t nx = K[min(first ? ps + i : am + j, N - 1)];
-        if (first) ka = i < la ? nx : PZKEY_MAX; else kq = j < lb ? nx : PZKEY_MAX;
+    int pa = ps + lo, pb = am + d0 - lo;   // the two fingers
+    pzkey_t ka = K[min(pa, N - 1)], kq = K[min(pb, N - 1)];
+    ka = pa < am ? ka : PZKEY_MAX; kq = pb < pe ? kq : PZKEY_MAX;
+    for (int o = c; o < c9; o++) {
+        const bool first = FIRST_WINS ? (ka <= kq) : (ka < kq);
+        const int src = first ? pa : pb;
+        Ko[o] = first ? ka : kq;
+        Vo[o] = V[src];
+        const int nsrc = src + 1;   // the run that gave the key moves on
+        const pzkey_t nx = K[min(nsrc, N - 1)];
+        const pzkey_t nv = nsrc < (first ? am : pe) ? nx : PZKEY_MAX;
+        pa = first ? nsrc : pa; pb = first ? pb : nsrc;
+        ka = first ? nv : ka; kq = first ? kq : nv;
     }
+}
+__device__ inline void merge_span(const LDS_AS pzkey_t* K, const LDS_AS uint16_t* V, LDS_AS pzkey_t* Ko, LDS_AS uint16_t* Vo,
+                                  int ps, int am, int pe, int c, int c9, bool first_wins, int N) {
+    if (first_wins) merge_span_t<true>(K, V, Ko, Vo, ps, am, pe, c, c9, N);   // (wave-uniform)
+    else merge_span_t<false>(K, V, Ko, Vo, ps, am, pe, c, c9, N);
 }
 
 // Sort step shared by every operator: checks the LDS capacity, then leaves the N raw terms of `ev` ordered by
