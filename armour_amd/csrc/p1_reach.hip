@@ -1847,7 +1847,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int per_cu = multi ? 1 : waves_per_cu(cap);
         // with at least as many idle CUs as items, the forward kinematics of every item runs as an item of its own
         const int split_env = h->tune(ARMOUR_OPT_P1_STEP_SPLIT_FK);   // (-1: automatic)
-        const bool split = split_env >= 0 ? (split_env != 0 && multi) : (multi && 2 * n_items <= prop.multiProcessorCount);
+        const bool split = split_env >= 0 ? (split_env != 0 && multi) : (multi && n_items <= prop.multiProcessorCount);   // (round 4: also when the two kinds of items together are more than the blocks -- the blocks draw the RNEA items first and fill up with the forward kinematics: B = 2 1.095 -> 1.081 ms)
         const int fk_items = split ? n_items : 0;
         const int waves = std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
