@@ -91,6 +91,7 @@ OPT_P1_TV_HELP_MIN = 117
 OPT_P1_TV_HELP_N = 118
 OPT_P1_TV_AUX3 = 119
 OPT_P1_FULL_PLANES = 120
+OPT_P1_TV_ROW_WIDTH = 122   # 0 automatic | 50 | 64 doubles per row of the time-vectorised kernel's work slots
 OPT_P2_EX = 130
 OPT_STEPS_GRAPH_MIN = 131
 OPT_PINNED_MODE = 132

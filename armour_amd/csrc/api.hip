@@ -147,12 +147,12 @@ struct TuningSpec { int option; double def, lo, hi; };
 // default and accepted range of every option (an option id without an entry is unknown)
 const TuningSpec kTuning[] = {
     {ARMOUR_OPT_P1_STEP_WAVES, 0, 0, 4}, {ARMOUR_OPT_P1_STEP_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_SPLIT_FK, -1, -1, 1}, {ARMOUR_OPT_P1_STEP_AUX3, 1, 0, 1},
-    {ARMOUR_OPT_P1_MAX_WAVES_PER_CU, 4, 1, 8}, {ARMOUR_OPT_P1_TWO_PASS, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_PAIRS, 1, 0, 2}, {ARMOUR_OPT_P1_STEP_QUEUE, 1, 0, 3}, {ARMOUR_OPT_P1_STEP_TAIL_CROSS, 0, 0, 514}, {ARMOUR_OPT_P1_TV_TAIL_CROSS, 11, 0, 514},
+    {ARMOUR_OPT_P1_MAX_WAVES_PER_CU, 4, 1, 8}, {ARMOUR_OPT_P1_TWO_PASS, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_PAIRS, 1, 0, 2}, {ARMOUR_OPT_P1_STEP_QUEUE, 1, 0, 3}, {ARMOUR_OPT_P1_STEP_TAIL_CROSS, 0, 0, 514}, {ARMOUR_OPT_P1_TV_TAIL_CROSS, 11, 0, 514} /* (set_option refuses the values without a meaning) */,
     {ARMOUR_OPT_P1_TV_MIN_GROUPS, 31, 1, 1e6}, {ARMOUR_OPT_P1_TV_WAVES, 0, 0, 8}, {ARMOUR_OPT_P1_TV_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_TV_SPLIT_FK, -1, -1, 1},
     {ARMOUR_OPT_P1_TV_DEDICATED, 1, 0, 1}, {ARMOUR_OPT_P1_TV_HELP_SHIFT, 0, 0, 3}, {ARMOUR_OPT_P1_TV_HELPERS, 1, 0, 31}, {ARMOUR_OPT_P1_TV_HELP_MIN, 192, 1, 1e6},
-    {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},
+    {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_TV_ROW_WIDTH, 0, 0, 64}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},
     {ARMOUR_OPT_P2_EX, 1, 0, 1}, {ARMOUR_OPT_STEPS_GRAPH_MIN, 2, 0, 1e6}, {ARMOUR_OPT_PINNED_MODE, 0, 0, 2},
-    {ARMOUR_OPT_SOLVE_SUB_TILES, 48, 1, 1e6}, {ARMOUR_OPT_SOLVE_DEVICE, 1, 0, 1}, {ARMOUR_OPT_SOLVE_CUT_TILES, 156, 1, 1e6}, {ARMOUR_OPT_SOLVE_BLOCKS, 0, 0, 1e6},
+    {ARMOUR_OPT_SOLVE_SUB_TILES, 48, 1, 1e6}, {ARMOUR_OPT_SOLVE_DEVICE, 1, 0, 2}, {ARMOUR_OPT_SOLVE_CUT_TILES, 156, 1, 1e6}, {ARMOUR_OPT_SOLVE_BLOCKS, 0, 0, 1e6},
     {ARMOUR_OPT_SOLVE_SUB_BATCH, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_ROW_CAP, 0, 0, 1e7}, {ARMOUR_OPT_SOLVE_HARD_CAP_S, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_WAVES_PER_SIMD, 0, 0, 2},
 };
 const TuningSpec* tuning_spec(int option) {
@@ -722,7 +722,15 @@ extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value)
     if (option == ARMOUR_OPT_P1_WORK_MEMORY_MB && value >= 0.0 && value <= 1e9) { h->opt_p1_work_mb = value; return ARMOUR_OK; }
     if (option == ARMOUR_OPT_P1_KEEP_WORK_MEMORY && (value == 0.0 || value == 1.0)) { h->opt_p1_keep_work = (int)value; return ARMOUR_OK; }
     if (const TuningSpec* t = tuning_spec(option)) {
-        if (value >= t->lo && value <= t->hi && (option == ARMOUR_OPT_SOLVE_HARD_CAP_S || value == (double)(long long)value)) {
+        bool ok = value >= t->lo && value <= t->hi && (option == ARMOUR_OPT_SOLVE_HARD_CAP_S || value == (double)(long long)value);
+        if (ok && (option == ARMOUR_OPT_P1_STEP_TAIL_CROSS || option == ARMOUR_OPT_P1_TV_TAIL_CROSS)) {
+            // 0 off | 1..4 links on the fourth wave | 11..14 links on the angular wave; + 100 * (n + 1), n = 0..4: the development form
+            // that holds the tail moments to n links.  Anything else has no meaning and is refused.
+            const int v = (int)value, lo2 = v % 100, hi2 = v / 100;
+            ok = (lo2 <= 4 || (lo2 >= 10 && lo2 <= 14)) && hi2 <= 5;
+        }
+        if (ok && option == ARMOUR_OPT_P1_TV_ROW_WIDTH) ok = value == 0.0 || value == 50.0 || value == 64.0;
+        if (ok) {
             h->tuning[option - ARMOUR_OPT_FIRST_TUNING] = value;
             return ARMOUR_OK;
         }

@@ -188,7 +188,7 @@ extern "C" int armour_batch_set_problems(ArmourBatch* bt, int32_t B, int32_t O, 
         int smallest = B;
         for (int d = 0; d < G; d++)
             if (bt->first[d + 1] > bt->first[d]) smallest = std::min(smallest, bt->first[d + 1] - bt->first[d]);
-        double min_groups = 36.0;
+        double min_groups = 31.0;   // (= kTuning's default; the option always exists, this is only the value if the query failed)
         (void)armour_get_option(bt->slot[0], ARMOUR_OPT_P1_TV_MIN_GROUPS, &min_groups);
         const int build = (long long)smallest * bt->T >= 50ll * (long long)min_groups ? 2 : 1;
         for (ArmourPlanner* h : bt->slot) (void)armour_set_option(h, ARMOUR_OPT_P1_BUILD, build);

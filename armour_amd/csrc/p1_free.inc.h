@@ -199,7 +199,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // mailbox.  Same operators on the same operands: same bits.  (cf.tail_cross: 0 off | links | 10 + links: on wave 1)
     const int tc_opt = cf.tail_cross % 100;
     const int tc_wave = fk_wave && aux3 && tc_opt > 0 ? (tc_opt >= 10 ? 1 : 3) : -1;
-    const int tc_links = tc_wave < 0 ? 0 : min(tc_opt % 10, K + 1);
+    const int tc_links = tc_wave < 0 ? 0 : min(tc_opt % 10, min(K + 1, n_tail_max));   // (never more links than the tail may hold: a chain of J < 4 joints has none -- s = J - tc_links + 1 must stay >= 1)
     auto tail_cross = [&]() {   // (the wave that owns them frees them behind barrier (A))
         for (int s = J - tc_links + 1; s <= J; s++) {
             if (tc_wave == 1) t3_wait(c, T3_CA, s);   // (w_s, w_aux_s are the fourth wave's)

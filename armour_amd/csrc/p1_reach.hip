@@ -1051,6 +1051,7 @@ constexpr bool kTvDedicatedHelpers = P1_TV_WAVES_PER_SIMD > 1;
 
 #include "p1_tv.inc.h"
 
+#ifndef P1_TV_VARIANT   // (a variant unit -- p1_reach_tv50.hip -- holds the time-vectorised kernel alone)
 // One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
 // NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
@@ -1677,7 +1678,41 @@ struct P1Work {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+#endif  // P1_TV_VARIANT
 }  // namespace
+
+// ---- launch of THIS translation unit's time-vectorised kernel (rows of tv::GR doubles; pz_tv.h).  p1_reach.hip holds the 64-double rows,
+// p1_reach_tv50.hip the same source with rows of 50 (BASELINE's T = 100 makes groups of 50 time steps): armour_p1_build picks by group size.
+#ifndef P1_TV_LAUNCH
+#define P1_TV_LAUNCH armour_p1_tv_launch_g64
+#endif
+__attribute__((visibility("hidden"))) hipError_t P1_TV_LAUNCH(int nw_launch, int nw, int blocks, size_t smem, hipStream_t stream, const void* cfg) {
+    const P1Cfg& cf = *static_cast<const P1Cfg*>(cfg);
+    hipError_t e = hipSuccess;
+    if (nw_launch == 8) {
+        if constexpr (kTvDedicatedHelpers) {
+            if ((e = hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return e;
+            hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<8>, dim3(blocks), dim3(WAVE * 8), smem, stream, cf);
+        }
+    } else if (nw == 4) {
+        if ((e = hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return e;
+        hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, stream, cf);
+    } else if (nw == kRoles) {
+        if ((e = hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return e;
+        hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, stream, cf);
+    } else {
+        if ((e = hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return e;
+        hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, stream, cf);
+    }
+    return hipGetLastError();
+}
+
+#ifndef P1_TV_VARIANT
+__attribute__((visibility("hidden"))) hipError_t armour_p1_tv_launch_g50(int nw_launch, int nw, int blocks, size_t smem, hipStream_t stream, const void* cfg);   // p1_reach_tv50.hip
+#ifndef P1_TV_NARROW
+#define P1_TV_NARROW 50
+#endif
+constexpr int kTvNarrowRows = P1_TV_NARROW;   // the row width of that unit (its TV_GROW; development builds pass both)
 
 void armour_p1_free(ArmourPlanner* h) {
     P1Work* wk = (P1Work*)h->p1;
@@ -1914,6 +1949,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         return ARMOUR_OK;
     };
     auto other_errors = [&]() -> int {
+        if (st[ST_ERR] & (unsigned)ERR_PAIR) {   // not a capacity limit: two waves that share an operator lost each other (psync), their barriers went off
+            armour_set_error("reach-set build: a pair of waves lost its barrier (flags 0x%x) -- an internal synchronisation error, not a capacity limit; "
+                             "ARMOUR_OPT_P1_STEP_PAIRS = 0 builds without paired waves", st[ST_ERR]);
+            return ARMOUR_EDEVICE;
+        }
         if (st[ST_ERR] & ~(unsigned)ERR_RAW_OVERFLOW) {
             armour_set_error("[dbg word3=%u] reach-set build overflow (flags 0x%x: 2=work_monomials, 4=link/torque_monomials, 8=link generators); max raw terms %u, max monomials %u",
                              st[3], st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
@@ -1942,6 +1982,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                          : (long long)B * T >= 50ll * (armtd ? tv_min_groups * 5 / 3 : tv_min_groups);   // (comparison mode: 60 groups -- 2.97 against 2.59 ms at B = 32, 2.40 against 2.57 at B = 28)
     if (want_tv) {
         const int G = (T + 63) / 64, LG = (T + G - 1) / G, groups = B * G;
+        // rows of 50 doubles when a group's time steps fit them (T = 100: two groups of 50), of 64 otherwise (the reference's T = 128): pz_tv.h, TV_GROW
+        static_assert(tv::GR == 64, "this unit holds the kernel with full-width rows");
+        const int tv_rows_env = h->tune(ARMOUR_OPT_P1_TV_ROW_WIDTH);   // (0 automatic | 50 | 64)
+        const int gr_multi = (tv_rows_env == 64 || LG > kTvNarrowRows) ? 64 : kTvNarrowRows;
         const int capTv = h->lim.work_monomials;
         // Block shapes, in the order tried: (a) while there is at most one group per CU, three waves per group -- the roles of
         // run_rnea run concurrently, as in the per-step kernel's small launches: the latency of ONE chain is what such a batch pays;
@@ -1980,7 +2024,13 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             if (multi && (armtd || tv_nw_env == 1)) continue;
             if (multi && tv_nw_env > 1 && tv_nw_env != nw_launch) continue;
             if (!multi && tv_nw_env > 1 && si == 3) continue;
-            const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw, nhelp);
+            // The ONE-WAVE blocks stay on the 64-double rows: armour_p1_tv_kernel<1> with rows of 48, 50 or 56 doubles ends in a memory-aperture
+            // violation (or hangs) on the MI355X in every launch -- three- and four-wave blocks of the same unit, and the one-wave kernel of the same unit
+            // built with TV_GROW = 64, are fine and bit-identical (the fourth member of that family, the first with a deterministic recipe:
+            // tools/mkvariant2.sh + tools/dev/t24_probe.py, profiles/r05_tv_one_wave_narrow_rows.txt).  One-wave blocks build the comparison mode's
+            // batches and the shapes after a sort-buffer overflow; BASELINE's batches run four-wave blocks.
+            const int gr = multi ? gr_multi : 64;
+            const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw, nhelp, gr);
             // blocks per CU by LDS; the staging area takes what is left
             const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed_fk() : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();
             const int per_cu = multi ? 1 : std::max(1, std::min(4, (int)((size_t)160 * 1024 / (fixed + 24 * 1024))));
@@ -2031,17 +2081,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {
                 std::lock_guard<std::mutex> lk(g_p1_launch_mu);
-                if constexpr (kTvDedicatedHelpers) { if (nw_launch == 8) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); }
-                if (nw_launch == 8) {}
-                else if (nw == 4) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                else if (nw == kRoles) HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<kRoles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                else HIPCHK(hipFuncSetAttribute((const void*)tvchain::armour_p1_tv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                if constexpr (kTvDedicatedHelpers) { if (nw_launch == 8) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<8>, dim3(blocks), dim3(WAVE * 8), smem, h->stream, cf); }
-                if (nw_launch == 8) {}
-                else if (nw == 4) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<4>, dim3(blocks), dim3(WAVE * 4), smem, h->stream, cf);
-                else if (nw == kRoles) hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<kRoles>, dim3(blocks), dim3(WAVE * kRoles), smem, h->stream, cf);
-                else hipLaunchKernelGGL(tvchain::armour_p1_tv_kernel<1>, dim3(blocks), dim3(WAVE), smem, h->stream, cf);
-                HIPCHK(hipGetLastError());
+                HIPCHK(gr == 64 ? armour_p1_tv_launch_g64(nw_launch, nw, blocks, smem, h->stream, &cf) : armour_p1_tv_launch_g50(nw_launch, nw, blocks, smem, h->stream, &cf));
             }
             HIPCHK(hipEventRecord(wk->ev1, h->stream));
             HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -2050,7 +2090,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
             h->build_info[0] = ARMOUR_P1_KERNEL_TIME_VECTORISED; h->build_info[1] = nw_launch; h->build_info[2] = cap; h->build_info[3]++;
-            if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+            if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each, rows of %d), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, gr, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) built = true;
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }
@@ -2174,3 +2214,4 @@ int armour_p1_full_planes(ArmourPlanner* h, double* d_full) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return ARMOUR_OK;
 }
+#endif  // P1_TV_VARIANT

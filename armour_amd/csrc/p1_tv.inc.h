@@ -17,7 +17,8 @@ constexpr int kTvPartFirst[kRoles] = {0, 12, 34}, kTvPartCount[kRoles] = {12, 22
 constexpr int kTvPart4First[4] = {0, 8, 23, 43}, kTvPart4Count[4] = {8, 15, 20, 20};   // (the forward-kinematics wave also owns w_aux and R_t w_aux: p1_free.inc.h, aux3)
 
 // (one spare key and one spare row block beyond `cap`)
-__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz) { return align64((size_t)(cap + 1) * sizeof(pzkey_t)) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * 64 * sizeof(double); }
+// (gr: doubles per row -- tv::GR in the kernel; the host sizes the arena for the unit it is about to launch)
+__host__ __device__ inline size_t tv_slot_bytes(int cap, int sz, int gr = tv::GR) { return align64((size_t)(cap + 1) * sizeof(pzkey_t)) + ((size_t)(cap + 1) * sz + 4 * (size_t)sz) * gr * sizeof(double); }
 
 struct TLayout {
     int nJM, nJV, nJS, nV, nroles, npools;   // nroles: sets of JRS scratch slots (one per wave); npools: parts of the 3x1 pool (1, 3 or 4)
@@ -25,9 +26,9 @@ struct TLayout {
     int idV, idS, idM, idJM, idJV, idJS;
 };
 // scratch slot of a dedicated helper wave (pz_tv.h serve_loop): a 3x1 work slot with 16 partial-sum rows where the header rows are
-__host__ __device__ inline size_t tv_helper_slot_bytes(int cap) { return tv_slot_bytes(cap, 3) + (size_t)4 * 64 * sizeof(double); }
+__host__ __device__ inline size_t tv_helper_slot_bytes(int cap, int gr = tv::GR) { return tv_slot_bytes(cap, 3, gr) + (size_t)4 * gr * sizeof(double); }
 // nwaves: the waves that play roles (1, 3 or 4); nhelp: dedicated helper waves behind them (0, or 4 in an eight-wave block)
-__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves, int nhelp = 0) {
+__host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwaves, int nhelp = 0, int gr = tv::GR) {
     TLayout L;
     const int nroles = nwaves;   // (a four-wave block builds the JRS on all four waves)
     L.nroles = nroles; L.npools = nwaves;
@@ -36,13 +37,13 @@ __host__ __device__ inline TLayout make_tlayout(int J, int n, int capW, int nwav
     L.nJV = (J + 1) + J;                   // trans P_i, link boxes
     L.nJS = 3 * n + J + 4 * nroles;        // qd, qda, qdda; mass; per role: 4 raw temps
     L.offV = 0;
-    L.offS = L.offV + (size_t)L.nV * tv_slot_bytes(capW, 3);
-    L.offM = L.offS + (size_t)kTvNS * tv_slot_bytes(capW, 1);
-    L.offJM = L.offM + (size_t)kTvNM * tv_slot_bytes(capW, 9);
-    L.offJV = L.offJM + (size_t)L.nJM * tv_slot_bytes(kCapSmall, 9);
-    L.offJS = L.offJV + (size_t)L.nJV * tv_slot_bytes(kCapSmall, 3);
-    L.offH = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1));
-    L.total = align64(L.offH + (size_t)nhelp * tv_helper_slot_bytes(capW));
+    L.offS = L.offV + (size_t)L.nV * tv_slot_bytes(capW, 3, gr);
+    L.offM = L.offS + (size_t)kTvNS * tv_slot_bytes(capW, 1, gr);
+    L.offJM = L.offM + (size_t)kTvNM * tv_slot_bytes(capW, 9, gr);
+    L.offJV = L.offJM + (size_t)L.nJM * tv_slot_bytes(kCapSmall, 9, gr);
+    L.offJS = L.offJV + (size_t)L.nJV * tv_slot_bytes(kCapSmall, 3, gr);
+    L.offH = align64(L.offJS + (size_t)L.nJS * tv_slot_bytes(kCapSmall, 1, gr));
+    L.total = align64(L.offH + (size_t)nhelp * tv_helper_slot_bytes(capW, gr));
     L.idV = 0; L.idS = L.idV + L.nV; L.idM = L.idS + kTvNS; L.idJM = L.idM + kTvNM; L.idJV = L.idJM + L.nJM; L.idJS = L.idJV + L.nJV;
     return L;
 }
@@ -52,7 +53,7 @@ __device__ inline TPZ mk_tslot(GLB_AS unsigned char* base, size_t off, int index
     TPZ z;
     z.keys = (GLB_AS pzkey_t*)p;
     z.hdr = (GLB_AS double*)(p + align64((size_t)(cap + 1) * sizeof(pzkey_t)));
-    z.coef = z.hdr + (size_t)4 * sz * 64;
+    z.coef = z.hdr + (size_t)4 * sz * tv::GR;
     z.sz = sz; z.cap = cap; z.id = id0 + index;
     return z;
 }
@@ -102,7 +103,7 @@ struct TChain {
         TPZ z;
         z.keys = (GLB_AS pzkey_t*)p;
         z.hdr = (GLB_AS double*)(p + align64((size_t)(capW + 1) * sizeof(pzkey_t)));
-        z.coef = z.hdr + (size_t)16 * 64;
+        z.coef = z.hdr + (size_t)16 * tv::GR;
         z.sz = 3; z.cap = capW; z.id = 0;
         return z;
     }
@@ -155,15 +156,15 @@ struct TChain {
     // any lane keeps it (the norm of (0, x, 0) is |x|), asum over the rows kept.
     __device__ TPZ embedOneDim(const TPZ& a, int r) {
         TPZ o = allocV();
-        const int lane = w.w.lane, n = tv::uni(w.w.cnt[a.id]);
+        const int lane = w.w.lane, rl = w.rl, n = tv::uni(w.w.cnt[a.id]);
         const double thr_sq = w.w.thr_sq;
         const TView av = tv::view(w, a);
-        const double cen = 0.0 + 1.0 * tv::ld_hdr(av, tv::H_CEN, 0, lane);
-        const double ind = 0.0 + tv::ld_hdr(av, tv::H_IND, 0, lane) * 1.0, ind2 = 0.0 + tv::ld_hdr(av, tv::H_IND2, 0, lane) * 1.0;
+        const double cen = 0.0 + 1.0 * tv::ld_hdr(av, tv::H_CEN, 0, rl);
+        const double ind = 0.0 + tv::ld_hdr(av, tv::H_IND, 0, rl) * 1.0, ind2 = 0.0 + tv::ld_hdr(av, tv::H_IND2, 0, rl) * 1.0;
         double ra = 0.0, as = 0.0;
         int pos = 0;
         for (int m = 0; m < n; m++) {
-            const double x = 1.0 * a.coef[(size_t)m * 64 + lane];
+            const double x = 1.0 * a.coef[(size_t)m * tv::GR + rl];
             const bool small = x * x <= thr_sq;
             ra += small ? fabs(x) : 0.0;
             const bool keep = !small && w.active;
@@ -171,7 +172,7 @@ struct TChain {
                 const double v = keep ? x : 0.0;
                 if (lane == 0) o.keys[pos] = a.keys[m];
 #pragma unroll
-                for (int e = 0; e < 3; e++) o.coef[((size_t)pos * 3 + e) * 64 + lane] = (e == r) ? v : 0.0;
+                for (int e = 0; e < 3; e++) o.coef[((size_t)pos * 3 + e) * tv::GR + rl] = (e == r) ? v : 0.0;
                 as += fabs(v);
                 pos++;
             }
@@ -179,10 +180,10 @@ struct TChain {
 #pragma unroll
         for (int e = 0; e < 3; e++) {
             const bool me = e == r;
-            tv::st_hdr(o, tv::H_CEN, e, lane, me ? cen : 0.0);
-            tv::st_hdr(o, tv::H_IND, e, lane, me ? ind + ra : 0.0);
-            tv::st_hdr(o, tv::H_IND2, e, lane, me ? ind2 + ra : 0.0);
-            tv::st_hdr(o, tv::H_ASUM, e, lane, me ? as : 0.0);
+            tv::st_hdr(o, tv::H_CEN, e, rl, me ? cen : 0.0);
+            tv::st_hdr(o, tv::H_IND, e, rl, me ? ind + ra : 0.0);
+            tv::st_hdr(o, tv::H_IND2, e, rl, me ? ind2 + ra : 0.0);
+            tv::st_hdr(o, tv::H_ASUM, e, rl, me ? as : 0.0);
         }
         if (lane == 0) w.w.cnt[o.id] = pos;
         WSYNC();
@@ -250,10 +251,10 @@ struct TChain {
 // (a key stays while any lane keeps it; a lane that pruned it stores 0 and has |.| in its radius).  Same tables bit for bit as through the
 // operators (launch digests, tools/gpu_p1_repeat_stress.py), without their round trips through the arena: a dozen per joint.
 template <int SZ>
-__device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, pzkey_t key, const double* v) {
+__device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, int rl, pzkey_t key, const double* v) {   // (rl: the lane's place in a row)
     if (lane == 0) out.keys[pos] = key;
 #pragma unroll
-    for (int e = 0; e < SZ; e++) out.coef[((size_t)pos * SZ + e) * 64 + lane] = v[e];
+    for (int e = 0; e < SZ; e++) out.coef[((size_t)pos * SZ + e) * tv::GR + rl] = v[e];
 }
 __device__ inline bool jrs_small9(const double* m, double thr_sq) {
     double q = 0.0;
@@ -265,7 +266,7 @@ __device__ inline bool jrs_small9(const double* m, double thr_sq) {
 // R_i = R_rpy * it, and (with_rt) the transpose
 __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars& js, const double* rp, bool with_rt) {
     const P1Cfg& cf = *c.cf;
-    const int lane = c.w.w.lane, n = c.n, ax = cf.rb.axes[i];
+    const int lane = c.w.w.lane, rl = c.w.rl, n = c.n, ax = cf.rb.axes[i];
     const double thr_sq = c.w.w.thr_sq;
     const bool active = c.w.active;
     const pzkey_t kk = pzkey_bit(2 * i), kc = pzkey_bit(5 * n + 2 * i), ks = pzkey_bit(7 * n + 2 * i);   // kk < kc < ks: the sorted order
@@ -317,31 +318,31 @@ __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
             const int e = r * 3 + cc, et = cc * 3 + r;
-            tv::st_hdr(R, tv::H_CEN, e, lane, Rcen[e]); tv::st_hdr(R, tv::H_IND, e, lane, Rind[e]); tv::st_hdr(R, tv::H_IND2, e, lane, Rind[e]); tv::st_hdr(R, tv::H_ASUM, e, lane, asum[e]);
-            if (with_rt) { tv::st_hdr(Rt, tv::H_CEN, et, lane, Rcen[e]); tv::st_hdr(Rt, tv::H_IND, et, lane, Rind[e]); tv::st_hdr(Rt, tv::H_IND2, et, lane, Rind[e]); tv::st_hdr(Rt, tv::H_ASUM, et, lane, asum[e]); }
+            tv::st_hdr(R, tv::H_CEN, e, rl, Rcen[e]); tv::st_hdr(R, tv::H_IND, e, rl, Rind[e]); tv::st_hdr(R, tv::H_IND2, e, rl, Rind[e]); tv::st_hdr(R, tv::H_ASUM, e, rl, asum[e]);
+            if (with_rt) { tv::st_hdr(Rt, tv::H_CEN, et, rl, Rcen[e]); tv::st_hdr(Rt, tv::H_IND, et, rl, Rind[e]); tv::st_hdr(Rt, tv::H_IND2, et, rl, Rind[e]); tv::st_hdr(Rt, tv::H_ASUM, et, rl, asum[e]); }
         }
     int pos = 0;
     double tr[9];
     if (E0) {
-        jrs_put_row<9>(R, pos, lane, kk, a0);
-        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a0[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, kk, tr); }
+        jrs_put_row<9>(R, pos, lane, rl, kk, a0);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a0[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, rl, kk, tr); }
         pos++;
     }
     if (E1) {
-        jrs_put_row<9>(R, pos, lane, kc, a1);
-        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a1[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, kc, tr); }
+        jrs_put_row<9>(R, pos, lane, rl, kc, a1);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a1[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, rl, kc, tr); }
         pos++;
     }
     if (E2) {
-        jrs_put_row<9>(R, pos, lane, ks, a2);
-        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a2[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, ks, tr); }
+        jrs_put_row<9>(R, pos, lane, rl, ks, a2);
+        if (with_rt) { for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) tr[cc * 3 + r] = a2[r * 3 + cc]; jrs_put_row<9>(Rt, pos, lane, rl, ks, tr); }
         pos++;
     }
     if (lane == 0) { c.w.w.cnt[R.id] = pos; if (with_rt) c.w.w.cnt[Rt.id] = pos; }
 }
 // PZsparse(centre, {k: a, e: b}) of a velocity / acceleration polynomial, simplify()
 __device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double cen, pzkey_t key0, double a, pzkey_t key1, double b) {
-    const int lane = c.w.w.lane;
+    const int lane = c.w.w.lane, rl = c.w.rl;
     const double thr = c.w.w.thr;
     const bool active = c.w.active;
     double va = 1.0 * a, vb = 1.0 * b;
@@ -353,16 +354,16 @@ __device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double ce
     va = ka ? va : 0.0; vb = kb ? vb : 0.0;
     double as = 0.0;
     as += ea ? fabs(va) : 0.0; as += eb ? fabs(vb) : 0.0;
-    tv::st_hdr(out, tv::H_CEN, 0, lane, 1.0 * cen); tv::st_hdr(out, tv::H_IND, 0, lane, 0.0 + ra); tv::st_hdr(out, tv::H_IND2, 0, lane, 0.0 + ra); tv::st_hdr(out, tv::H_ASUM, 0, lane, as);
+    tv::st_hdr(out, tv::H_CEN, 0, rl, 1.0 * cen); tv::st_hdr(out, tv::H_IND, 0, rl, 0.0 + ra); tv::st_hdr(out, tv::H_IND2, 0, rl, 0.0 + ra); tv::st_hdr(out, tv::H_ASUM, 0, rl, as);
     int pos = 0;
-    if (ea) { jrs_put_row<1>(out, pos, lane, key0, &va); pos++; }
-    if (eb) { jrs_put_row<1>(out, pos, lane, key1, &vb); pos++; }
+    if (ea) { jrs_put_row<1>(out, pos, lane, rl, key0, &va); pos++; }
+    if (eb) { jrs_put_row<1>(out, pos, lane, rl, key1, &vb); pos++; }
     if (lane == 0) c.w.w.cnt[out.id] = pos;
 }
 // link box: three 1x1 PZs {centre_j, one generator on key field (j + 2) n}, each simplify()d, then stack()ed and simplify()d
 __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
     const P1Cfg& cf = *c.cf;
-    const int lane = c.w.w.lane, n = c.n;
+    const int lane = c.w.w.lane, rl = c.w.rl, n = c.n;
     const double thr = c.w.w.thr, thr_sq = c.w.w.thr_sq;
     const bool active = c.w.active;
     const TPZ out = c.linkbox(i);
@@ -393,15 +394,15 @@ __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
     for (int e = 0; e < 3; e++) {
         const double i0 = e == 0 ? ind1[0] * 1.0 : 0.0, i1 = e == 1 ? ind1[1] * 1.0 : 0.0, i2 = e == 2 ? ind1[2] * 1.0 : 0.0;
         const double r = ((i0 + i1) + i2) + ra[e];
-        tv::st_hdr(out, tv::H_CEN, e, lane, 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i + e]));
-        tv::st_hdr(out, tv::H_IND, e, lane, r); tv::st_hdr(out, tv::H_IND2, e, lane, r); tv::st_hdr(out, tv::H_ASUM, e, lane, as[e]);
+        tv::st_hdr(out, tv::H_CEN, e, rl, 0.0 + 1.0 * (1.0 * cf.rb.link_zonotope_center[3 * i + e]));
+        tv::st_hdr(out, tv::H_IND, e, rl, r); tv::st_hdr(out, tv::H_IND2, e, rl, r); tv::st_hdr(out, tv::H_ASUM, e, rl, as[e]);
     }
     int pos = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++)
         if (ex2[j]) {
             const double v[3] = {j == 0 ? x[0] : 0.0, j == 1 ? x[1] : 0.0, j == 2 ? x[2] : 0.0};
-            jrs_put_row<3>(out, pos, lane, pzkey_bit((j + 2) * n), v);
+            jrs_put_row<3>(out, pos, lane, rl, pzkey_bit((j + 2) * n), v);
             pos++;
         }
     if (lane == 0) c.w.w.cnt[out.id] = pos;
@@ -434,15 +435,15 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
         }
         tv::set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
         if (!kin_only) {   // mass and inertia: constants with a second radius (no local arrays behind set_const's pointers: they would live in scratch memory)
-            const int lane = c.w.w.lane;
+            const int lane = c.w.w.lane, rl = c.w.rl;
             const TPZ pm = c.mass(i), pi = c.inertia(i);
-            tv::st_hdr(pm, tv::H_CEN, 0, lane, cf.rb.mass[i]); tv::st_hdr(pm, tv::H_IND, 0, lane, 0.0);
-            tv::st_hdr(pm, tv::H_IND2, 0, lane, armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i])); tv::st_hdr(pm, tv::H_ASUM, 0, lane, 0.0);
+            tv::st_hdr(pm, tv::H_CEN, 0, rl, cf.rb.mass[i]); tv::st_hdr(pm, tv::H_IND, 0, rl, 0.0);
+            tv::st_hdr(pm, tv::H_IND2, 0, rl, armour_mass_uncertainty(&cf.rb, i) * fabs(cf.rb.mass[i])); tv::st_hdr(pm, tv::H_ASUM, 0, rl, 0.0);
             const double unc = armour_inertia_uncertainty(&cf.rb, i);
 #pragma unroll
             for (int e = 0; e < 9; e++) {
                 const double v = cf.rb.inertia[9 * i + e];
-                tv::st_hdr(pi, tv::H_CEN, e, lane, v); tv::st_hdr(pi, tv::H_IND, e, lane, 0.0); tv::st_hdr(pi, tv::H_IND2, e, lane, unc * fabs(v)); tv::st_hdr(pi, tv::H_ASUM, e, lane, 0.0);
+                tv::st_hdr(pi, tv::H_CEN, e, rl, v); tv::st_hdr(pi, tv::H_IND, e, rl, 0.0); tv::st_hdr(pi, tv::H_IND2, e, rl, unc * fabs(v)); tv::st_hdr(pi, tv::H_ASUM, e, rl, 0.0);
             }
             if (lane == 0) { c.w.w.cnt[pm.id] = 0; c.w.w.cnt[pi.id] = 0; }
         }
@@ -472,7 +473,7 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
     for (int i = 0; i < 18; i++) g[i] = 0.0;
     double ra[3] = {0, 0, 0};
     int nk = 0, ng = 0;
-    const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
+    const GLB_AS double* pc = tv::uni_ptr(p.coef) + t.rl;
     for (int m0 = 0; m0 < cnt; m0 += 64) {
         const pzkey_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
         const int nn = min(64, cnt - m0);
@@ -481,15 +482,15 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
             double xs[kU][3];
 #pragma unroll
             for (int u = 0; u < kU; u++) {
-                const GLB_AS double* pr = pc + (size_t)(m0 + min(q0 + u, nn - 1)) * 3 * 64;
-                xs[u][0] = pr[0]; xs[u][1] = pr[64]; xs[u][2] = pr[128];
+                const GLB_AS double* pr = pc + (size_t)(m0 + min(q0 + u, nn - 1)) * 3 * tv::GR;
+                xs[u][0] = pr[0]; xs[u][1] = pr[tv::GR]; xs[u][2] = pr[2 * tv::GR];
             }
 #pragma unroll
             for (int u = 0; u < kU; u++) {
                 if (q0 + u >= nn) break;
                 const pzkey_t key = pzkey_readlane(key_v, q0 + u);
                 const double x = xs[u][0], y = xs[u][1], z = xs[u][2];
-                const bool has = t.active && (x != 0.0 || y != 0.0 || z != 0.0);
+                const bool has = t.live && (x != 0.0 || y != 0.0 || z != 0.0);
                 const bool isk = key < kmax;                               // (the class of a monomial is wave-uniform)
                 const bool isg = !isk && key < lmax && (key & kmask) == 0;
                 if (isk) {
@@ -514,14 +515,14 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
             }
         }
     }
-    if (__ballot(t.active && ng > 3) != 0ull) pzw::flag(t.w, pzw::ERR_LINK_GENS);
-    if (__ballot(t.active && nk > cf.capL) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
-    if (t.active) {
+    if (__ballot(t.live && ng > 3) != 0ull) pzw::flag(t.w, pzw::ERR_LINK_GENS);
+    if (__ballot(t.live && nk > cf.capL) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
+    if (t.live) {
         if (nk > cf.capL) nk = cf.capL;
         cf.link_count[idx] = nk;
         for (int e = 0; e < 3; e++) {
-            const double r = p.hdr[((size_t)tv::H_IND * 3 + e) * 64 + lane] + ra[e];
-            cf.link_center[idx * 3 + e] = p.hdr[((size_t)tv::H_CEN * 3 + e) * 64 + lane];
+            const double r = p.hdr[((size_t)tv::H_IND * 3 + e) * tv::GR + lane] + ra[e];   // (inside `if (t.live)`: a lane with a step of its own, its place in a row is its lane)
+            cf.link_center[idx * 3 + e] = p.hdr[((size_t)tv::H_CEN * 3 + e) * tv::GR + lane];
             cf.link_indep[idx * 3 + e] = r;
             g[e * 6 + 3 + e] = r;
         }
@@ -542,7 +543,8 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
     double tr[ARMOUR_MAX_FACTORS], un_ind[ARMOUR_MAX_FACTORS];
     for (int j = 0; j < n; j++) {
         const TPZ& p = u_nom[j];
-        const double pcen = p.hdr[((size_t)tv::H_CEN) * 64 + lane], pind = p.hdr[((size_t)tv::H_IND) * 64 + lane], pind2 = p.hdr[((size_t)tv::H_IND2) * 64 + lane];
+        const int rl = t.rl;
+        const double pcen = p.hdr[((size_t)tv::H_CEN) * tv::GR + rl], pind = p.hdr[((size_t)tv::H_IND) * tv::GR + rl], pind2 = p.hdr[((size_t)tv::H_IND2) * tv::GR + rl];
         const double dcen = pcen - pcen;
         const double rad = pind2 + pind;
         const double lo = dcen - rad, hi = dcen + rad;
@@ -553,7 +555,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
         const size_t idx = ((size_t)b * n + j) * T + t_lane;
         double ra = 0.0;
         int nk = 0;
-        const GLB_AS double* pc = tv::uni_ptr(p.coef) + lane;
+        const GLB_AS double* pc = tv::uni_ptr(p.coef) + rl;
         for (int m0 = 0; m0 < cnt; m0 += 64) {
             const pzkey_t key_v = m0 + lane < cnt ? p.keys[m0 + lane] : 0ull;
             const int nn = min(64, cnt - m0);
@@ -561,27 +563,27 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
             for (int q0 = 0; q0 < nn; q0 += kU) {
                 double xs[kU];
 #pragma unroll
-                for (int u = 0; u < kU; u++) xs[u] = pc[(size_t)(m0 + min(q0 + u, nn - 1)) * 64];
+                for (int u = 0; u < kU; u++) xs[u] = pc[(size_t)(m0 + min(q0 + u, nn - 1)) * tv::GR];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     if (q0 + u >= nn) break;
                     const pzkey_t key = pzkey_readlane(key_v, q0 + u);
                     const double x = xs[u];
                     if (key < kmax) {   // (wave-uniform)
-                        if (t.active && x != 0.0) {
+                        if (t.live && x != 0.0) {
                             if (nk < cf.capT) { cf.tq_keys[idx * cf.capT + nk] = (uint32_t)key; cf.tq_coeff[idx * cf.capT + nk] = x; }
                             nk++;
                         }
                     } else {
-                        ra += t.active ? fabs(x) : 0.0;   // (x = 0 adds nothing)
+                        ra += t.live ? fabs(x) : 0.0;   // (x = 0 adds nothing)
                     }
                 }
             }
         }
-        if (__ballot(t.active && nk > cf.capT) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
+        if (__ballot(t.live && nk > cf.capT) != 0ull) pzw::flag(t.w, pzw::ERR_TABLE_OVERFLOW);
         if (nk > cf.capT) nk = cf.capT;
         const double ind = pind + ra;
-        if (t.active) { cf.tq_count[idx] = nk; cf.tq_center[idx] = pcen; cf.tq_indep[idx] = ind; }
+        if (t.live) { cf.tq_count[idx] = nk; cf.tq_center[idx] = pcen; cf.tq_indep[idx] = ind; }
         un_ind[j] = ind;
     }
     const double rho_hi = up(sqrt(rho.hi));
@@ -590,7 +592,7 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
         v += 0.5 * rho_hi;
         v += un_ind[j];
         v += cf.rb.friction[j];
-        if (t.active) cf.torque_radius[((size_t)b * n + j) * T + t_lane] = v;
+        if (t.live) cf.torque_radius[((size_t)b * n + j) * T + t_lane] = v;
     }
     WSYNC();
 }
@@ -675,8 +677,17 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
         const int b = it / groups_per_problem, g = it - b * groups_per_problem;
         const int t0 = g * lanes_per_group;
         const int nl = min(lanes_per_group, cf.T - t0);
-        c.w.active = lane < nl;
-        const int t_lane = t0 + min(lane, nl - 1);  // idle lanes shadow the group's last step; they never write
+        // a lane without a step of its own shadows step (lane mod nl) of the group in everything -- inputs, arithmetic -- and writes no final table; its
+        // place in a row is its own while the rows have one for it, the shadowed lane's otherwise (the same value to the same address, from two
+        // lanes; shadowing the LAST step put fifteen lanes on one address: B = 24 6.65 -> 6.84 ms) (pz_tv.h)
+        const int sl = lane % nl;
+#ifdef TV_FORCE_ROW_PLACES   // development: lanes beyond this share the shadowed lane's place although the rows are wider
+        constexpr int kRowPlaces = TV_FORCE_ROW_PLACES;
+#else
+        constexpr int kRowPlaces = tv::GR;
+#endif
+        c.w.active = true; c.w.live = lane < nl; c.w.rl = lane < kRowPlaces ? lane : sl;
+        const int t_lane = t0 + sl;
         if constexpr (NW == 8) {
             if (helper_wave) { tv::serve_loop(c.w, c.H(c.wid - NP)); continue; }   // until the primary's HK_EXIT at the end of the item
         }

@@ -50,7 +50,9 @@ enum { H_IND = 0, H_IND2 = 1, H_ASUM = 2, H_CEN = 3 };  // the centre rows come 
 
 struct TW {
     Wave w;        // sort buffers, thresholds, lane, per-wave status, LDS count table (pz_wave.h)
-    bool active;   // this lane's time step exists (t < T)
+    bool active;   // the lane takes part in the arithmetic: always, since round 5 (a lane without a step of its own shadows the group's last step)
+    bool live;     // this lane's time step exists and is its own (lane < the group's step count): the lanes that write the final tables
+    int rl;        // the lane's place in a row: the lane itself, or -- beyond the row's width GR -- the place of the lane it shadows
     LDS_AS double* stage;  // LDS staging area for the rows of a product's SHORT operand (stage_rows below)
     int stage_rows;        // its capacity in rows of 64 doubles
     // walk helper (below, "One walk on two waves"): the channel to a wave that has nothing of its own to do right now, or nullptr
@@ -88,6 +90,22 @@ struct TvFn {   // whole-call time of an operator, by kind (the kind may be set 
 #endif
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Rows in global memory.  A row holds one double per time step of the group, GR doubles apart from the next row: GR = 64 (a row = the wave's
+// 64 lanes, four 128-byte lines) or -- round 5 -- the group's own lane count rounded up to even (TV_GROW: T = 100 makes groups of 50 time steps,
+// rows of 400 bytes packed back to back).  The fabric moves whole 128-byte lines: with 512-byte rows of which 400 bytes are used, every fourth
+// line was fetched and written back for two lanes (tools/micro/row_gather.hip: 50 lanes of 64 cost a full row); packed, consecutive rows share
+// their lines, so a pass over an operand in its own order moves 3.125 lines a row instead of 4.
+// A lane without a time step of its own (lane >= the group's step count nl <= GR) SHADOWS step (lane mod nl) of its group: same inputs, same
+// arithmetic, hence the same values -- stored to a place of its own while the row has one (lane < GR), to the shadowed lane's place otherwise
+// (TW::rl; the same value to the same address from two lanes).  No lane is masked anywhere in the arithmetic, a shadow's votes in the ballots
+// repeat the shadowed step's, and only the final tables are written by the lanes that own a step (TW::live).  (Rounds 3-4 kept such lanes
+// inactive, with zeros in places of their own in every row.)  The rows staged in LDS keep the wave's stride.
+#ifndef TV_GROW
+#define TV_GROW 64
+#endif
+constexpr int GR = TV_GROW;
+static_assert(GR >= 2 && GR <= WAVE, "a row holds at most one element per lane");
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One walk on two waves.  The serial walk over the sorted raw terms is what an operator costs (the sort is 5 %), and in the
@@ -140,16 +158,17 @@ __device__ inline pzw::View kview(const TView& v) {  // what the sorters need: k
     return k;
 }
 // row e of monomial m / of header block `which` of a view, this lane's element
-__device__ inline double ld_coef(const TView& v, int m, int e, int lane) { return v.coef[((size_t)m * v.stride + v.off + e) * WAVE + lane]; }
-__device__ inline double ld_hdr(const TView& v, int which, int e, int lane) { return v.hdr[((size_t)which * v.stride + v.off + e) * WAVE + lane]; }
-__device__ inline void st_hdr(const TPZ& p, int which, int e, int lane, double x) { p.hdr[((size_t)which * p.sz + e) * WAVE + lane] = x; }
+// (`rl` = the lane's place in a row: TW::rl)
+__device__ inline double ld_coef(const TView& v, int m, int e, int rl) { return v.coef[((size_t)m * v.stride + v.off + e) * GR + rl]; }
+__device__ inline double ld_hdr(const TView& v, int which, int e, int rl) { return v.hdr[((size_t)which * v.stride + v.off + e) * GR + rl]; }
+__device__ inline void st_hdr(const TPZ& p, int which, int e, int rl, double x) { p.hdr[((size_t)which * p.sz + e) * GR + rl] = x; }
 
 // Result writer: keys by lane 0, coefficient rows by every lane (0 where the lane pruned the term), asum on the way.
 template <int SZ>
 struct Out {
     GLB_AS pzkey_t* keys;
     GLB_AS double* coef;
-    int cap, n, lane;
+    int cap, n, lane;   // lane: the lane's place in a row (TW::rl)
     double asum[SZ];
     __device__ inline void init(const TPZ& o, int lane_) {
         keys = uni_ptr(o.keys); coef = uni_ptr(o.coef); cap = uni(o.cap); n = 0; lane = lane_;
@@ -162,7 +181,7 @@ struct Out {
         const int at = n < cap ? n : cap;
         keys[at] = key;
 #pragma unroll
-        for (int e = 0; e < SZ; e++) coef[((size_t)at * SZ + e) * WAVE + lane] = v[e];
+        for (int e = 0; e < SZ; e++) coef[((size_t)at * SZ + e) * GR + lane] = v[e];
 #pragma unroll
         for (int e = 0; e < SZ; e++) asum[e] += fabs(v[e]);
         n++;
@@ -171,7 +190,7 @@ struct Out {
         if (n > cap) { pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW); n = cap; }
 #pragma unroll
         for (int e = 0; e < SZ; e++) st_hdr(o, H_ASUM, e, lane, asum[e]);
-        if (lane == 0) {
+        if (t.w.lane == 0) {
             t.w.cnt[o.id] = n;
             if (n > t.w.lstat[pzw::ST_MAX_OUT]) t.w.lstat[pzw::ST_MAX_OUT] = n;
         }
@@ -328,14 +347,15 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
 __device__ inline bool stage_fits(const TW& t, const TView& v) { return (v.cnt + 1) * v.sz <= t.stage_rows; }
 __device__ inline void stage_rows_of(const TW& t, const TView& v, int lane) {
     const int sz = v.sz;
-    for (int e = 0; e < sz; e++) t.stage[(size_t)e * WAVE + lane] = ld_hdr(v, H_CEN, e, lane);
+    const int rl = t.rl;
+    for (int e = 0; e < sz; e++) t.stage[(size_t)e * WAVE + lane] = ld_hdr(v, H_CEN, e, rl);
     const int rows = v.cnt * sz;
-    const GLB_AS double* src = v.coef + (size_t)v.off * WAVE + lane;  // (whole-PZ views: off = 0, stride = sz, rows are consecutive)
+    const GLB_AS double* src = v.coef + (size_t)v.off * GR + rl;  // (whole-PZ views: off = 0, stride = sz, rows are consecutive)
     LDS_AS double* dst = t.stage + (size_t)sz * WAVE + lane;
     for (int r0 = 0; r0 < rows; r0 += 16) {
         double x[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) x[u] = src[(size_t)min(r0 + u, rows - 1) * WAVE];
+        for (int u = 0; u < 16; u++) x[u] = src[(size_t)min(r0 + u, rows - 1) * GR];
 #pragma unroll
         for (int u = 0; u < 16; u++) if (r0 + u < rows) dst[(size_t)(r0 + u) * WAVE] = x[u];
     }
@@ -372,8 +392,8 @@ struct MulCtx {
         const int t = idx_lane + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
         d.i = i; d.j = j;
-        const uint64_t pa = (uint64_t)(a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE);   // i = 0: the centre rows, stored right before the coefficients
-        const uint64_t pb = (uint64_t)(b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * WAVE);
+        const uint64_t pa = (uint64_t)(a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * GR);   // i = 0: the centre rows, stored right before the coefficients
+        const uint64_t pb = (uint64_t)(b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * GR);
         d.alo = (unsigned)pa; d.ahi = (unsigned)(pa >> 32); d.blo = (unsigned)pb; d.bhi = (unsigned)(pb >> 32);
         return d;
     }
@@ -384,13 +404,13 @@ struct MulCtx {
             const uint64_t pa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.ahi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.alo, l);
             const GLB_AS double* p = (const GLB_AS double*)pa + lane;
 #pragma unroll
-            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = p[e * WAVE];
+            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = p[e * GR];
         }
         if constexpr (STAGE != 2) {
             const uint64_t pb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.bhi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.blo, l);
             const GLB_AS double* p = (const GLB_AS double*)pb + lane;
 #pragma unroll
-            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = p[e * WAVE];
+            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = p[e * GR];
         }
     }
     // (generation index known as a scalar: the ordered pass of a product with a constant left operand)
@@ -399,14 +419,14 @@ struct MulCtx {
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
         r.i = i; r.j = j;
         if constexpr (STAGE != 1) {
-            const GLB_AS double* pa = a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * WAVE + lane;
+            const GLB_AS double* pa = a.coef + ((ptrdiff_t)(i - 1) * a.stride + a.off) * GR + lane;
 #pragma unroll
-            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * WAVE];
+            for (int e = 0; e < SH::ASZ; e++) r.ca[e] = pa[e * GR];
         }
         if constexpr (STAGE != 2) {
-            const GLB_AS double* pb = b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * WAVE + lane;
+            const GLB_AS double* pb = b.coef + ((ptrdiff_t)(j - 1) * b.stride + b.off) * GR + lane;
 #pragma unroll
-            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * WAVE];
+            for (int e = 0; e < SH::BSZ; e++) r.cb[e] = pb[e * GR];
         }
     }
     // the term's coefficient product: pure (no state of the walk), so that the walk can form several terms' products at once
@@ -510,7 +530,7 @@ struct MulCtx {
 
 template <class SH, int STAGE>
 __device__ inline void mul_ctx_init(MulCtx<SH, STAGE>& cx, const TW& t, const TView& a, const TView& b, Out<SH::SZ>* o) {
-    cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.a = a; cx.b = b; cx.lane = t.rl; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);   // (cx.lane addresses rows, global and staged)
     cx.a.coef = uni_ptr(a.coef); cx.b.coef = uni_ptr(b.coef); cx.a.stride = uni(a.stride); cx.b.stride = uni(b.stride); cx.a.off = uni(a.off); cx.b.off = uni(b.off);
     cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = t.stage;
 #pragma unroll
@@ -526,20 +546,23 @@ __device__ inline void mul_walk(TW& t, const Wave& sw, const LDS_AS double* stag
     cx.stage = stage;
     const Wave& w = sw;
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     if (indirect) walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
     else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) rad[e] = cx.rad[e];
 }
 
-// rows [r_lo, r_hi) of a block of 64-double rows from src to dst (both already offset by the lane), 32 rows in flight
-__device__ inline void move_rows(const GLB_AS double* src, GLB_AS double* dst, int r_lo, int r_hi) {
+// rows [r_lo, r_hi) of a block of rows from src to dst (row 0 of each, WITHOUT the lane offset), 32 rows in flight
+__device__ inline void move_rows(const GLB_AS double* src0, GLB_AS double* dst0, int rl, int r_lo, int r_hi) {
+    const GLB_AS double* src = src0 + rl;
+    GLB_AS double* dst = dst0 + rl;
     for (int r0 = r_lo; r0 < r_hi; r0 += 32) {
         double x[32];
 #pragma unroll
-        for (int u = 0; u < 32; u++) x[u] = src[(size_t)min(r0 + u, r_hi - 1) * WAVE];
+        for (int u = 0; u < 32; u++) x[u] = src[(size_t)min(r0 + u, r_hi - 1) * GR];
 #pragma unroll
-        for (int u = 0; u < 32; u++) if (r0 + u < r_hi) dst[(size_t)(r0 + u) * WAVE] = x[u];
+        for (int u = 0; u < 32; u++) if (r0 + u < r_hi) dst[(size_t)(r0 + u) * GR] = x[u];
     }
 }
 
@@ -615,8 +638,8 @@ __device__ inline int hj_collect(TW& t, int n0, const GLB_AS double*& hdr, const
     hj_wait(t, &t.hch[HJ_WALKED], t.hseq);
     const int nh = uni(t.hch[HJ_NH]);
     const int room = out.cap - n0 > 0 ? out.cap - n0 : 0, ncopy = nh < room ? nh : room;
-    const GLB_AS double* src = lds_ld_ptr<const GLB_AS double>(&t.hch[HJ_TMP_COEF]) + t.w.lane;
-    move_rows(src, out.coef + (size_t)n0 * 3 * WAVE + t.w.lane, 0, (ncopy * 3) / 2);
+    const GLB_AS double* src = lds_ld_ptr<const GLB_AS double>(&t.hch[HJ_TMP_COEF]);
+    move_rows(src, out.coef + (size_t)n0 * 3 * GR, t.rl, 0, (ncopy * 3) / 2);
     hj_wait(t, &t.hch[HJ_DONE], t.hseq);
     hdr = lds_ld_ptr<const GLB_AS double>(&t.hch[HJ_HDR]);
     return nh;
@@ -627,6 +650,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     typedef pzw::MulShape<AR, AC, BR, BC> SH;
     constexpr int SZ = SH::SZ;
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     TView a = a_, b = b_;
     a.cnt = uni(a.cnt); b.cnt = uni(b.cnt);
     TVP_FN(t, a.cnt == 0 ? 1 : 0)
@@ -635,13 +659,13 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     double ca[SH::ASZ], cb[SH::BSZ], ia[SH::ASZ], ib[SH::BSZ], ia2[SH::ASZ], ib2[SH::BSZ], r2[SH::ASZ], r3[SH::BSZ];
 #pragma unroll
     for (int e = 0; e < SH::ASZ; e++) {
-        ca[e] = ld_hdr(a, H_CEN, e, lane); ia[e] = ld_hdr(a, H_IND, e, lane); ia2[e] = ld_hdr(a, H_IND2, e, lane);
-        r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, lane);
+        ca[e] = ld_hdr(a, H_CEN, e, rl); ia[e] = ld_hdr(a, H_IND, e, rl); ia2[e] = ld_hdr(a, H_IND2, e, rl);
+        r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, rl);
     }
 #pragma unroll
     for (int e = 0; e < SH::BSZ; e++) {
-        cb[e] = ld_hdr(b, H_CEN, e, lane); ib[e] = ld_hdr(b, H_IND, e, lane); ib2[e] = ld_hdr(b, H_IND2, e, lane);
-        r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, lane);
+        cb[e] = ld_hdr(b, H_CEN, e, rl); ib[e] = ld_hdr(b, H_IND, e, rl); ib2[e] = ld_hdr(b, H_IND2, e, rl);
+        r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, rl);
     }
     double t2[SZ], t3[SZ], ii[SZ], cen[SZ], base[SZ], base2[SZ];
     SH::mul(r2, ib, t2);
@@ -658,7 +682,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     WSYNC();
 
     Out<SZ> o;
-    o.init(out, lane);
+    o.init(out, rl);
     double rad[SZ];
 #pragma unroll
     for (int e = 0; e < SZ; e++) rad[e] = 0.0;
@@ -679,7 +703,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
             for (int u = 0; u < HBc; u++) {
                 const int mm = min(m + u, nb_ - 1);
 #pragma unroll
-                for (int e = 0; e < SH::BSZ; e++) x[u][e] = ld_coef(b, mm, e, lane);
+                for (int e = 0; e < SH::BSZ; e++) x[u][e] = ld_coef(b, mm, e, rl);
             }
         };
         auto consume_c = [&](double (*x)[SH::BSZ], int m, pzkey_t key_v, int m0) {
@@ -747,7 +771,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
                 const GLB_AS double* hdr;
                 const int nh = hj_collect(t, o.n, hdr, out);
 #pragma unroll
-                for (int e = 0; e < SZ; e++) { rad[e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane]; o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane]; }
+                for (int e = 0; e < SZ; e++) { rad[e] += hdr[((size_t)H_IND * SZ + e) * GR + rl]; o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * GR + rl]; }
                 o.n += nh;
             }
         }
@@ -755,9 +779,9 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
     }
 #pragma unroll
     for (int e = 0; e < SZ; e++) {
-        st_hdr(out, H_CEN, e, lane, cen[e]);
-        st_hdr(out, H_IND, e, lane, base[e] + rad[e]);
-        st_hdr(out, H_IND2, e, lane, base2[e] + rad[e]);
+        st_hdr(out, H_CEN, e, rl, cen[e]);
+        st_hdr(out, H_IND, e, rl, base[e] + rad[e]);
+        st_hdr(out, H_IND2, e, rl, base2[e] + rad[e]);
     }
     o.finish(t, out);
 }
@@ -787,7 +811,7 @@ struct CrossCtx {
         const int t = idx_lane + 1;
         const int i = (int)(((unsigned long long)t * mb1_magic) >> 32), j = t - i * mb1;
         d.i = i; d.j = j;
-        const uint64_t pa = (uint64_t)(a.coef + (ptrdiff_t)(i - 1) * 3 * WAVE), pb = (uint64_t)(b.coef + (ptrdiff_t)(j - 1) * 3 * WAVE);   // i, j = 0: the centre rows
+        const uint64_t pa = (uint64_t)(a.coef + (ptrdiff_t)(i - 1) * 3 * GR), pb = (uint64_t)(b.coef + (ptrdiff_t)(j - 1) * 3 * GR);   // i, j = 0: the centre rows
         d.alo = (unsigned)pa; d.ahi = (unsigned)(pa >> 32); d.blo = (unsigned)pb; d.bhi = (unsigned)(pb >> 32);
         return d;
     }
@@ -798,13 +822,13 @@ struct CrossCtx {
             const uint64_t pa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.ahi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.alo, l);
             const GLB_AS double* p = (const GLB_AS double*)pa + lane;
 #pragma unroll
-            for (int e = 0; e < 3; e++) r.ca[e] = p[e * WAVE];
+            for (int e = 0; e < 3; e++) r.ca[e] = p[e * GR];
         }
         if constexpr (STAGE != 2) {
             const uint64_t pb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)d.bhi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)d.blo, l);
             const GLB_AS double* p = (const GLB_AS double*)pb + lane;
 #pragma unroll
-            for (int e = 0; e < 3; e++) r.cb[e] = p[e * WAVE];
+            for (int e = 0; e < 3; e++) r.cb[e] = p[e * GR];
         }
     }
     struct Prod { double p6[6]; __device__ inline void pin() { for (int e = 0; e < 6; e++) __asm__ volatile("" : "+v"(p6[e])); } };
@@ -880,7 +904,7 @@ struct CrossCtx {
 template <int STAGE>
 __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* stage, int N0, int N, bool indirect, const pzw::MulEval<pzw::MulShape<1, 1, 1, 1>>& ev, const TView& a, const TView& b, Out<3>* o, double* rad) {
     CrossCtx<STAGE> cx;
-    cx.a = a; cx.b = b; cx.lane = t.w.lane; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
+    cx.a = a; cx.b = b; cx.lane = t.rl; cx.mb1 = b.cnt + 1; cx.mb1_magic = pzw::magic_u32(cx.mb1);
     cx.a.coef = uni_ptr(a.coef); cx.b.coef = uni_ptr(b.coef);
     cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = o; cx.stage = stage;
 #pragma unroll
@@ -889,6 +913,7 @@ __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* st
     for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
     const Wave& w = sw;
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     if (indirect) walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
     else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
@@ -899,6 +924,7 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     TVP_FN(t, 2)
     typedef pzw::MulShape<1, 1, 1, 1> SH;
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     TView a = a_, b = b_;
     a.cnt = uni(a.cnt); b.cnt = uni(b.cnt);
     int N = (a.cnt + 1) * (b.cnt + 1) - 1;
@@ -907,10 +933,10 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
         double ca[3], cb[3], ia[3], ib[3], ia2[3], ib2[3], r2[3], r3[3];
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            ca[e] = ld_hdr(a, H_CEN, e, lane); ia[e] = ld_hdr(a, H_IND, e, lane); ia2[e] = ld_hdr(a, H_IND2, e, lane);
-            r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, lane);
-            cb[e] = ld_hdr(b, H_CEN, e, lane); ib[e] = ld_hdr(b, H_IND, e, lane); ib2[e] = ld_hdr(b, H_IND2, e, lane);
-            r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, lane);
+            ca[e] = ld_hdr(a, H_CEN, e, rl); ia[e] = ld_hdr(a, H_IND, e, rl); ia2[e] = ld_hdr(a, H_IND2, e, rl);
+            r2[e] = fabs(ca[e]) + ld_hdr(a, H_ASUM, e, rl);
+            cb[e] = ld_hdr(b, H_CEN, e, rl); ib[e] = ld_hdr(b, H_IND, e, rl); ib2[e] = ld_hdr(b, H_IND2, e, rl);
+            r3[e] = fabs(cb[e]) + ld_hdr(b, H_ASUM, e, rl);
         }
         const int ia_[6] = {1, 2, 2, 0, 0, 1}, ib_[6] = {2, 1, 0, 2, 1, 0};
 #pragma unroll
@@ -923,7 +949,7 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     }
     WSYNC();
     Out<3> o;
-    o.init(out, lane);
+    o.init(out, rl);
     double rad[12];
     if (lane == 0 && N > t.w.lstat[pzw::ST_MAX_RAW]) t.w.lstat[pzw::ST_MAX_RAW] = N;
     pzw::MulEval<SH> ev;
@@ -958,9 +984,9 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
             const GLB_AS double* hdr;
             const int nh = hj_collect(t, o.n, hdr, out);
 #pragma unroll
-            for (int e = 0; e < 12; e++) rad[e] += hdr[(size_t)e * WAVE + lane];
+            for (int e = 0; e < 12; e++) rad[e] += hdr[(size_t)e * GR + rl];
 #pragma unroll
-            for (int e = 0; e < 3; e++) o.asum[e] += hdr[(size_t)(12 + e) * WAVE + lane];
+            for (int e = 0; e < 3; e++) o.asum[e] += hdr[(size_t)(12 + e) * GR + rl];
             o.n += nh;
         }
     }
@@ -970,9 +996,9 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
         const double i0 = baseP[2 * c] + rad[2 * c], i1 = baseP[2 * c + 1] + rad[2 * c + 1];
         const double j0 = base2P[2 * c] + rad[2 * c], j1 = base2P[2 * c + 1] + rad[2 * c + 1];
         const double ir = (i0 * 1.0 + i1 * 1.0) + rad[6 + c], jr = (j0 * 1.0 + j1 * 1.0) + rad[6 + c];
-        st_hdr(out, H_CEN, c, lane, 0.0 + (1.0 * cenP[2 * c] + -1.0 * cenP[2 * c + 1]));
-        st_hdr(out, H_IND, c, lane, (0.0 + ir) + rad[9 + c]);
-        st_hdr(out, H_IND2, c, lane, (0.0 + jr) + rad[9 + c]);
+        st_hdr(out, H_CEN, c, rl, 0.0 + (1.0 * cenP[2 * c] + -1.0 * cenP[2 * c + 1]));
+        st_hdr(out, H_IND, c, rl, (0.0 + ir) + rad[9 + c]);
+        st_hdr(out, H_IND2, c, rl, (0.0 + jr) + rad[9 + c]);
     }
     o.finish(t, out);
 }
@@ -1017,7 +1043,7 @@ struct LinCtx {
     const GLB_AS double* row0[NS];
     __device__ inline void prepare() {
 #pragma unroll
-        for (int k = 0; k < NS; k++) row0[k] = s[k].v.coef + ((ptrdiff_t)s[k].v.off - (ptrdiff_t)off[k] * s[k].v.stride) * WAVE;
+        for (int k = 0; k < NS; k++) row0[k] = s[k].v.coef + ((ptrdiff_t)s[k].v.off - (ptrdiff_t)off[k] * s[k].v.stride) * GR;
     }
     // per-lane descriptors of the chunk's terms (lane l describes the chunk's l-th term): source, byte address of its first row, row step
     struct Desc { int k; unsigned lo, hi; int step; };
@@ -1037,9 +1063,9 @@ struct LinCtx {
             base = me ? row0[q] : base;
             stride = me ? s[q].v.stride : stride; comp = me ? s[q].comp : comp;
         }
-        const uint64_t a = (uint64_t)(base + (ptrdiff_t)idx_lane * stride * WAVE);
+        const uint64_t a = (uint64_t)(base + (ptrdiff_t)idx_lane * stride * GR);
         d.lo = (unsigned)a; d.hi = (unsigned)(a >> 32);
-        d.step = comp < 0 ? WAVE : 0;
+        d.step = comp < 0 ? GR : 0;
         return d;
     }
     // Only the loads: what is loaded must not be touched here, or the wave would wait for it before issuing the next term's loads.
@@ -1169,6 +1195,7 @@ template <int SZ, int NS, bool CHAIN, int XK = -1>
 __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, const double* xb = nullptr) {
     TVP_FN(t, 3)
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     LinCtx<SZ, NS, CHAIN, XK> cx;
     pzw::LinEval<SZ, NS> ev;
     int N = 0;
@@ -1195,7 +1222,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
                 cx.xsA[0] = b2; cx.xsA[1] = b0; cx.xsA[2] = b1; cx.xsB[0] = -b1; cx.xsB[1] = -b2; cx.xsB[2] = -b0;
                 double x0[3], i0[3], j0[3];
 #pragma unroll
-                for (int q = 0; q < 3; q++) { x0[q] = ld_hdr(v, H_CEN, q, lane); i0[q] = ld_hdr(v, H_IND, q, lane); j0[q] = ld_hdr(v, H_IND2, q, lane); cx.xr1[q] = 0.0; cx.xr2[q] = 0.0; }
+                for (int q = 0; q < 3; q++) { x0[q] = ld_hdr(v, H_CEN, q, rl); i0[q] = ld_hdr(v, H_IND, q, rl); j0[q] = ld_hdr(v, H_IND2, q, rl); cx.xr1[q] = 0.0; cx.xr2[q] = 0.0; }
                 const int cA[3] = {1, 2, 0}, cB[3] = {2, 0, 1};
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -1208,24 +1235,24 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
         } else if (segs[k].comp < 0) {
 #pragma unroll
             for (int e = 0; e < SZ; e++) {
-                const double c = sc * ld_hdr(v, H_CEN, e, lane);
+                const double c = sc * ld_hdr(v, H_CEN, e, rl);
                 cen[e] = (k == 0) ? c : cen[e] + c;
-                indk[k][e] = ld_hdr(v, H_IND, e, lane) * asc; ind2k[k][e] = ld_hdr(v, H_IND2, e, lane) * asc;
+                indk[k][e] = ld_hdr(v, H_IND, e, rl) * asc; ind2k[k][e] = ld_hdr(v, H_IND2, e, rl) * asc;
             }
         } else {
-            const double c = sc * ld_hdr(v, H_CEN, 0, lane), i1 = ld_hdr(v, H_IND, 0, lane) * asc, i2 = ld_hdr(v, H_IND2, 0, lane) * asc;
+            const double c = sc * ld_hdr(v, H_CEN, 0, rl), i1 = ld_hdr(v, H_IND, 0, rl) * asc, i2 = ld_hdr(v, H_IND2, 0, rl) * asc;
 #pragma unroll
             for (int e = 0; e < SZ; e++)
                 if (e == segs[k].comp) { cen[e] = cen[e] + c; indk[k][e] = i1; ind2k[k][e] = i2; }
         }
     }
     cx.off[NS] = N; ev.off[NS] = N;
-    cx.lane = lane;
+    cx.lane = rl;
     cx.prepare();
     WSYNC();  // every lane has read the sources' header rows before `out` (possibly one of them) is written
     Out<SZ> o;
-    o.init(out, lane);
-    cx.lane = lane; cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
+    o.init(out, rl);
+    cx.lane = rl; cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o;
     cx.present = false; cx.last = -1;
 #pragma unroll
     for (int e = 0; e < SZ; e++) cx.acc[e] = 0.0;
@@ -1268,11 +1295,11 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
 #pragma unroll
             for (int e = 0; e < SZ; e++) {
                 if constexpr (CHAIN) {
-                    cx.ra[1][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
-                    cx.ra[2][e] += hdr[((size_t)H_IND2 * SZ + e) * WAVE + lane];
-                    if constexpr (NS == 4) cx.ra[3][e] += hdr[((size_t)H_CEN * SZ + e) * WAVE + lane];
-                } else cx.ra[0][e] += hdr[((size_t)H_IND * SZ + e) * WAVE + lane];
-                o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * WAVE + lane];
+                    cx.ra[1][e] += hdr[((size_t)H_IND * SZ + e) * GR + rl];
+                    cx.ra[2][e] += hdr[((size_t)H_IND2 * SZ + e) * GR + rl];
+                    if constexpr (NS == 4) cx.ra[3][e] += hdr[((size_t)H_CEN * SZ + e) * GR + rl];
+                } else cx.ra[0][e] += hdr[((size_t)H_IND * SZ + e) * GR + rl];
+                o.asum[e] += hdr[((size_t)H_ASUM * SZ + e) * GR + rl];
             }
             o.n += nh;
         }
@@ -1297,9 +1324,9 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
             for (int k = 1; k < NS; k++) { r = r + indk[k][e]; r2 = r2 + ind2k[k][e]; }
             r = r + cx.ra[0][e]; r2 = r2 + cx.ra[0][e];
         }
-        st_hdr(out, H_CEN, e, lane, cen[e]);
-        st_hdr(out, H_IND, e, lane, r);
-        st_hdr(out, H_IND2, e, lane, r2);
+        st_hdr(out, H_CEN, e, rl, cen[e]);
+        st_hdr(out, H_IND, e, rl, r);
+        st_hdr(out, H_IND2, e, rl, r2);
     }
     o.finish(t, out);
 }
@@ -1310,6 +1337,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
 // (monomials [m_lo, m_hi) of a: the whole list, or the part of it one of two waves takes)
 __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, int m_hi, const double* sA, const int* cA, const double* sB, const int* cB, Out<3>& o, double* ra1, double* ra2) {
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     const double thr = t.w.thr, thr_sq = t.w.thr_sq;
     const bool active = t.active;
     // (a's rows in their own order, two half-batches of eight monomials in flight alternately: see walk_sorted)
@@ -1319,7 +1347,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
         for (int u = 0; u < 8; u++) {
             const int mm = min(m + u, m_hi - 1);
 #pragma unroll
-            for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, mm, q, lane);
+            for (int q = 0; q < 3; q++) x[u][q] = ld_coef(a, mm, q, rl);
         }
     };
     auto consume_c = [&](double (*x)[3], int m, pzkey_t key_v, int m0) {
@@ -1362,12 +1390,13 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
 __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
     TVP_FN(t, 4)
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     TView a = a_;
     a.cnt = uni(a.cnt);
     double x0[3], cen[3], ind[3], ind2[3], ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
     double i0[3], j0[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) { x0[c] = ld_hdr(a, H_CEN, c, lane); i0[c] = ld_hdr(a, H_IND, c, lane); j0[c] = ld_hdr(a, H_IND2, c, lane); }
+    for (int c = 0; c < 3; c++) { x0[c] = ld_hdr(a, H_CEN, c, rl); i0[c] = ld_hdr(a, H_IND, c, rl); j0[c] = ld_hdr(a, H_IND2, c, rl); }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         double xa = 0, xb = 0, ia = 0, ib = 0, ja = 0, jb = 0;
@@ -1382,7 +1411,7 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
     }
     WSYNC();
     Out<3> o;
-    o.init(out, lane);
+    o.init(out, rl);
 #ifdef TV_PROFILE_FULL
     const long long cc0__ = clock64();
 #endif
@@ -1410,7 +1439,7 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
         const GLB_AS double* hdr;
         const int nh = hj_collect(t, o.n, hdr, out);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { ra1[c] += hdr[(size_t)c * WAVE + lane]; ra2[c] += hdr[(size_t)(3 + c) * WAVE + lane]; o.asum[c] += hdr[(size_t)(6 + c) * WAVE + lane]; }
+        for (int c = 0; c < 3; c++) { ra1[c] += hdr[(size_t)c * GR + rl]; ra2[c] += hdr[(size_t)(3 + c) * GR + rl]; o.asum[c] += hdr[(size_t)(6 + c) * GR + rl]; }
         o.n += nh;
     }
 #ifdef TV_PROFILE_FULL
@@ -1418,9 +1447,9 @@ __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, 
 #endif
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        st_hdr(out, H_CEN, c, lane, cen[c]);
-        st_hdr(out, H_IND, c, lane, (ind[c] + ra1[c]) + ra2[c]);
-        st_hdr(out, H_IND2, c, lane, (ind2[c] + ra1[c]) + ra2[c]);
+        st_hdr(out, H_CEN, c, rl, cen[c]);
+        st_hdr(out, H_IND, c, rl, (ind[c] + ra1[c]) + ra2[c]);
+        st_hdr(out, H_IND2, c, rl, (ind2[c] + ra1[c]) + ra2[c]);
     }
     o.finish(t, out);
 }
@@ -1442,6 +1471,7 @@ __device__ inline double hj_seg_double(LDS_AS int* p) { return __longlong_as_dou
 template <int NS, bool CHAIN>
 __device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int S, int N, bool indirect, Out<3>& o, double (&ra)[4][3]) {
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     LinCtx<3, NS, CHAIN> cx;
     pzw::LinEval<3, NS> ev;   // (key_lds reads the primary's key buffer only)
     int tot = 0;
@@ -1453,7 +1483,7 @@ __device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int 
         cx.off[k] = tot; tot += cx.s[k].v.cnt;
     }
     cx.off[NS] = tot;
-    cx.lane = lane; cx.prepare();
+    cx.lane = rl; cx.prepare();
     cx.thr = t.w.thr; cx.thr_sq = t.w.thr_sq; cx.active = t.active; cx.o = &o; cx.present = false; cx.last = -1;
 #pragma unroll
     for (int e = 0; e < 3; e++) cx.acc[e] = 0.0;
@@ -1472,6 +1502,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     TVP_FN(t, 5)
     LDS_AS int* ch = t.hch;
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     t.hseq++;
     hj_wait(t, &ch[HJ_SEQ], t.hseq);
     const int kind = uni(ch[HJ_KIND]);
@@ -1483,8 +1514,8 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     sw.sidx = (LDS_AS uint16_t*)(uintptr_t)(unsigned)uni(ch[HJ_SIDX]);
     const LDS_AS double* stage = (const LDS_AS double*)(uintptr_t)(unsigned)uni(ch[HJ_STAGE]);
     Out<3> o;
-    o.init(tmp, lane);
-    GLB_AS double* pp = tmp.hdr + lane;   // partial sums, row q at pp[q * WAVE]
+    o.init(tmp, rl);
+    GLB_AS double* pp = tmp.hdr + rl;   // partial sums, row q at pp[q * GR]
     if (kind == HK_MUL_3331_A_STAGED || kind == HK_MUL_3331_B_STAGED || kind == HK_MUL_3331_UNSTAGED) {
         typedef pzw::MulShape<3, 3, 3, 1> SH;
         const TView a = hj_seg_view(ch, 0, 9), b = hj_seg_view(ch, 1, 3);
@@ -1495,7 +1526,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
         else if (kind == HK_MUL_3331_B_STAGED) mul_walk<SH, 2>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
         else mul_walk<SH, 0>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
 #pragma unroll
-        for (int e = 0; e < 3; e++) { pp[(size_t)(H_IND * 3 + e) * WAVE] = rad[e]; pp[(size_t)(H_ASUM * 3 + e) * WAVE] = o.asum[e]; }
+        for (int e = 0; e < 3; e++) { pp[(size_t)(H_IND * 3 + e) * GR] = rad[e]; pp[(size_t)(H_ASUM * 3 + e) * GR] = o.asum[e]; }
     } else if (kind == HK_LIN2 || kind == HK_LIN3_CHAIN || kind == HK_LIN4_CHAIN) {
         double ra[4][3];
 #pragma unroll
@@ -1508,10 +1539,10 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
         // rows: [H_IND] = the unchained sum's pruned amounts or stage 1's, [H_IND2] = stage 2's, [H_CEN] = stage 3's
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            pp[(size_t)(H_IND * 3 + e) * WAVE] = kind == HK_LIN2 ? ra[0][e] : ra[1][e];
-            pp[(size_t)(H_IND2 * 3 + e) * WAVE] = ra[2][e];
-            pp[(size_t)(H_CEN * 3 + e) * WAVE] = ra[3][e];
-            pp[(size_t)(H_ASUM * 3 + e) * WAVE] = o.asum[e];
+            pp[(size_t)(H_IND * 3 + e) * GR] = kind == HK_LIN2 ? ra[0][e] : ra[1][e];
+            pp[(size_t)(H_IND2 * 3 + e) * GR] = ra[2][e];
+            pp[(size_t)(H_CEN * 3 + e) * GR] = ra[3][e];
+            pp[(size_t)(H_ASUM * 3 + e) * GR] = o.asum[e];
         }
     } else if (kind == HK_CROSS_A_STAGED || kind == HK_CROSS_B_STAGED || kind == HK_CROSS_UNSTAGED) {
         typedef pzw::MulShape<1, 1, 1, 1> SH;
@@ -1524,9 +1555,9 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
         else if (kind == HK_CROSS_B_STAGED) cross_walk<2>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
         else cross_walk<0>(t, sw, stage, S, N, indirect, ev, a, b, &o, rad);
 #pragma unroll
-        for (int e = 0; e < 12; e++) pp[(size_t)e * WAVE] = rad[e];
+        for (int e = 0; e < 12; e++) pp[(size_t)e * GR] = rad[e];
 #pragma unroll
-        for (int e = 0; e < 3; e++) pp[(size_t)(12 + e) * WAVE] = o.asum[e];
+        for (int e = 0; e < 3; e++) pp[(size_t)(12 + e) * GR] = o.asum[e];
     } else {   // HK_CROSS_CONST: monomials [S, N) of the operand
         LDS_AS int* sg = ch + HJ_SEG0 + HJ_SEG_WORDS;
         TView a = hj_seg_view(ch, 0, 3);
@@ -1540,7 +1571,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
         double ra1[3] = {0, 0, 0}, ra2[3] = {0, 0, 0};
         cross_const_range(t, a, S, N, sA, cA, sB, cB, o, ra1, ra2);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { pp[(size_t)c * WAVE] = ra1[c]; pp[(size_t)(3 + c) * WAVE] = ra2[c]; pp[(size_t)(6 + c) * WAVE] = o.asum[c]; }
+        for (int c = 0; c < 3; c++) { pp[(size_t)c * GR] = ra1[c]; pp[(size_t)(3 + c) * GR] = ra2[c]; pp[(size_t)(6 + c) * GR] = o.asum[c]; }
     }
     const int nh = uni(o.n < tmp.cap ? o.n : tmp.cap);
     if (o.n > tmp.cap) pzw::flag(t.w, pzw::ERR_SLOT_OVERFLOW);
@@ -1553,7 +1584,7 @@ __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     GLB_AS double* oc = lds_ld_ptr<GLB_AS double>(&ch[HJ_OUT_COEF]);
     const int room = cap - n0 > 0 ? cap - n0 : 0, ncopy = nh < room ? nh : room;   // (an overflow of the result is flagged by the primary's finish())
     for (int m = lane; m < ncopy; m += WAVE) ok[n0 + m] = tmp.keys[m];
-    move_rows(tmp.coef + lane, oc + (size_t)n0 * 3 * WAVE + lane, (ncopy * 3) / 2, ncopy * 3);   // (the primary moves the lower half)
+    move_rows(tmp.coef, oc + (size_t)n0 * 3 * GR, rl, (ncopy * 3) / 2, ncopy * 3);   // (the primary moves the lower half)
     hj_signal(t, &ch[HJ_DONE], t.hseq);
     return kind;
 }
@@ -1570,15 +1601,16 @@ __device__ inline void serve_loop(TW& t, const TPZ& tmp) {
 __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
     TVP_FN(t, 6)
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     const int n = uni(t.w.cnt[a.id]);
     for (int m = 0; m < n; m++)
 #pragma unroll
-        for (int e = 0; e < 9; e++) out.coef[((size_t)m * 9 + (e % 3) * 3 + e / 3) * WAVE + lane] = a.coef[((size_t)m * 9 + e) * WAVE + lane];
+        for (int e = 0; e < 9; e++) out.coef[((size_t)m * 9 + (e % 3) * 3 + e / 3) * GR + rl] = a.coef[((size_t)m * 9 + e) * GR + rl];
     for (int m = lane; m < n; m += WAVE) out.keys[m] = a.keys[m];
 #pragma unroll
     for (int h = 0; h < 4; h++)
 #pragma unroll
-        for (int e = 0; e < 9; e++) out.hdr[((size_t)h * 9 + (e % 3) * 3 + e / 3) * WAVE + lane] = a.hdr[((size_t)h * 9 + e) * WAVE + lane];
+        for (int e = 0; e < 9; e++) out.hdr[((size_t)h * 9 + (e % 3) * 3 + e / 3) * GR + rl] = a.hdr[((size_t)h * 9 + e) * GR + rl];
     if (lane == 0) t.w.cnt[out.id] = n;
     WSYNC();
 }
@@ -1587,11 +1619,12 @@ __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
 __device__ TV_NOINLINE void set_const(TW& t, const TPZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
     TVP_FN(t, 6)
     const int lane = t.w.lane;
+    const int rl = t.rl;   // (the lane's place in a row)
     for (int e = 0; e < out.sz; e++) {
-        st_hdr(out, H_CEN, e, lane, cen ? cen[e] : 0.0);
-        st_hdr(out, H_IND, e, lane, ind ? ind[e] : 0.0);
-        st_hdr(out, H_IND2, e, lane, ind2 ? ind2[e] : (ind ? ind[e] : 0.0));
-        st_hdr(out, H_ASUM, e, lane, 0.0);
+        st_hdr(out, H_CEN, e, rl, cen ? cen[e] : 0.0);
+        st_hdr(out, H_IND, e, rl, ind ? ind[e] : 0.0);
+        st_hdr(out, H_IND2, e, rl, ind2 ? ind2[e] : (ind ? ind[e] : 0.0));
+        st_hdr(out, H_ASUM, e, rl, 0.0);
     }
     if (lane == 0) t.w.cnt[out.id] = 0;
     WSYNC();

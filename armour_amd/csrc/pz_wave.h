@@ -890,9 +890,10 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
 #pragma unroll
             for (int e = 0; e < SZ; e++) { ra[k][e] = wave_sum(ra[k][e]); rb[k][e] = wave_sum(rb[k][e]); }
     }
-    if constexpr ((NS - 1) * SZ <= PW_DBL_PER_HALF) {
-        if (paired && N > 0) pair_finish<SZ, NS - 1>(w, out, emitted, pos0, &rb[1]);
-    }
+    // (pair_split has handed the upper chunks to the second wave by now: an instantiation whose partial radii do not fit the exchange area
+    //  must not compile, it would publish the first wave's half alone)
+    static_assert((NS - 1) * SZ <= PW_DBL_PER_HALF, "lincomb_chain: the pair's exchange area does not hold this instantiation's partial radii");
+    if (paired && N > 0) pair_finish<SZ, NS - 1>(w, out, emitted, pos0, &rb[1]);
 #pragma unroll
     for (int k = 1; k < NS; k++)
 #pragma unroll

@@ -115,7 +115,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_STEP_FREE 102           /* 1 (default) free-running role waves | 0 a block barrier per joint */
 #define ARMOUR_OPT_P1_STEP_SPLIT_FK 103       /* -1 automatic (default) | 0 | 1: forward kinematics as work items of their own */
 #define ARMOUR_OPT_P1_STEP_AUX3 104           /* 1 (default) | 0: the w_aux recursion on the fourth wave of four-wave blocks */
-#define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..4 (default 4): one-wave blocks resident per compute unit */
+#define ARMOUR_OPT_P1_MAX_WAVES_PER_CU 105    /* 1..8 (default 4): one-wave blocks resident per compute unit; the shipped kernels hold one wave per SIMD, so values above 4 act as 4 (they matter only in two-waves-per-SIMD development builds) */
 #define ARMOUR_OPT_P1_TWO_PASS 106            /* 1 (default) | 0: large batches first with 2048-entry sort buffers, overflowing items rebuilt alone */
 #define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
 #define ARMOUR_OPT_P1_STEP_QUEUE 109          /* 1 (default): the blocks draw their items from a counter, every problem's late time steps first | 2, 3: in index order, early steps first | 0: block k builds items k, k + blocks, ... */
@@ -132,6 +132,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_TV_HELP_N 118           /* (r) 1 (default) | 0: the n-recursion shares its walks as well */
 #define ARMOUR_OPT_P1_TV_AUX3 119             /* 1 (default) | 0: as ARMOUR_OPT_P1_STEP_AUX3 */
 #define ARMOUR_OPT_P1_TV_TAIL_CROSS 121       /* as ARMOUR_OPT_P1_STEP_TAIL_CROSS, for the four-wave blocks of the time-vectorised kernel */
+#define ARMOUR_OPT_P1_TV_ROW_WIDTH 122        /* 0 automatic (default) | 50 | 64: doubles per row of the kernel's work slots.  Automatic = 50 when a group of time steps fits (T = 100: two groups of 50; the rows are packed, -19 % of the build's L2-miss traffic), 64 otherwise; 50 with longer groups is refused.  Every bit of every table is the same for both. */
 #define ARMOUR_OPT_P1_FULL_PLANES 120         /* 0 (default) the lean half-space table | 1 every plane and component resident (armour_get_hyperplanes builds it on demand otherwise) */
 /* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
 #define ARMOUR_OPT_P2_EX 130                  /* 1 (default) | 0: the fixed-load-count kernels for problems with exactly 24 live planes */
@@ -139,7 +140,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
 /* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
 #define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */
-#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default) | 0: the device-resident form may be chosen */
+#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default): the device-resident form from 5 problems on | 0: never | 2: always */
 #define ARMOUR_OPT_SOLVE_CUT_TILES 142        /* default 156: a batch whose blocks would walk more tiles each is cut */
 #define ARMOUR_OPT_SOLVE_BLOCKS 143           /* 0 (default: as many as fit) | n: at most n blocks per problem */
 #define ARMOUR_OPT_SOLVE_SUB_BATCH 144        /* 0 (default: by tiles) | n: sub-batches of at most n problems */

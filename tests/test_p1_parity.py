@@ -476,28 +476,31 @@ def test_builds_are_reproducible_from_launch_to_launch(B, O):
             assert np.array_equal(a, b)
 
 
-def _tables_digest(B, options):
+def _tables_digest(B, options, T=100, robot=None):
     """Digest of everything a reach-set build leaves behind, for a handle with the given launch-shape options
     ({option id: value}); returns (sha256 hex, exact arrays, radii arrays)."""
     import hashlib
-    from armour_amd.planner import ArmourNLP
+    from armour_amd.planner import ArmourNLP, default_params
     from armour_amd.worlds import random_batch, random_k
-    T, O = 100, 3
+    O = 3
     bp = random_batch(900, B, O)
     bp["qd0"][B - 1] = 0.9 * np.array([1.3963, 1.3963, 1.3963, 1.3963, 1.2218, 1.2218, 1.2218])
-    nlp = ArmourNLP(T=T)
+    if robot is not None:   # a shorter chain: the first joints' states
+        for k in ("q0", "qd0", "qdd0", "q_des"):
+            bp[k] = np.ascontiguousarray(bp[k][:, :robot.num_factors])
+    nlp = ArmourNLP(T=T) if robot is None else ArmourNLP(robot=robot, params=default_params(T))
     for opt, val in options.items():
         nlp.set_option(opt, val)
     nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
     h = hashlib.sha256()
-    g, jac = nlp.eval_g_jac(random_k(4, B))
+    g, jac = nlp.eval_g_jac(random_k(4, B)[:, :nlp.n])
     for a in (g, jac, nlp.torque_radius(), nlp.link_generators()):
         h.update(np.ascontiguousarray(a).tobytes())
     exact, radii = [], [nlp.torque_radius().ravel(), nlp.link_generators().ravel(), g.ravel(), jac.ravel()]
     for b in (0, B - 1):
         for which, cnt in (("link", nlp.J), ("torque", nlp.n)):
             for i in range(cnt):
-                for t in (0, 37, 50, 99):
+                for t in sorted({0, 37 % T, T // 2, T - 1}):
                     cen, ind, keys, co = nlp.pz(which, i, t, b=b)
                     for a in (cen, ind, keys, co):
                         h.update(np.ascontiguousarray(a).tobytes())
@@ -543,6 +546,54 @@ def test_wave_choreographies_leave_identical_tables(B, settings):
         digests.append(d); shapes.append((info["kernel"], info["waves"]))
     assert len(set(digests)) == 1, list(zip(settings, digests))
     assert len(set(shapes)) > 1, shapes   # (the options did select different launch shapes)
+
+
+@pytest.mark.parametrize("T", [100, 90, 128, 40])
+def test_row_widths_leave_identical_tables(T):
+    """Round 5: the time-vectorised kernel exists twice -- rows of 64 doubles (p1_reach.hip) and packed rows of 50 (p1_reach_tv50.hip: T = 100
+    makes groups of 50 time steps) -- and armour_p1_build picks by the group size (ARMOUR_OPT_P1_TV_ROW_WIDTH holds a handle to 64).  A row's
+    width changes addresses, never a value or an order: every bit of every table is the same, in four-, three- and one-wave blocks (the one-wave
+    blocks are held to the wide rows: p1_reach.hip); for groups
+    that do not fill a row of 50 (T = 90: 45 steps; T = 40) -- lanes with a place in the rows but no step of their own shadow another step
+    (pz_tv.h) -- and with T = 128 (groups of 64: only the wide rows fit, asking for 50 is refused by falling back to 64)."""
+    from armour_amd import _lib
+    digests = []
+    for rows in (0, 64):
+        for waves in (4, 3, 1):
+            d, _, _, info = _tables_digest(3, {**_shape(build=2, tv_waves=waves, tv_helpers=0), _lib.OPT_P1_TV_ROW_WIDTH: rows}, T=T)
+            assert info["kernel"] == "time_vectorised", info
+            digests.append(d)
+    assert len(set(digests)) == 1, digests
+    # ... and both agree with the per-step kernel: exact parts bit for bit, radii to the build contract's 1e-12
+    _, ex_tv, rad_tv, _ = _tables_digest(3, _shape(build=2, tv_waves=4), T=T)
+    _, ex_ps, rad_ps, _ = _tables_digest(3, _shape(build=1), T=T)
+    assert np.array_equal(ex_tv, ex_ps)
+    assert np.abs(rad_tv - rad_ps).max() <= 1e-12
+
+
+def test_tail_cross_options_on_a_three_joint_chain():
+    """ARMOUR_OPT_P1_*_TAIL_CROSS moved w x (w_aux x com) of the last n links to another wave with n clamped to 4 but not to the
+    chain: on a robot of J < 4 joints the loop started at link J - n + 1 <= 0 and read states that are not the links'.  The tail is now held to
+    the links the tail moments may take (none for J < 4), and set_option refuses values without a meaning.  A three-joint chain (the first
+    three joints of the Kinova): every accepted value leaves the tables of the default bit for bit, in both kernels."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP, kinova_robot
+    rb = kinova_robot()
+    rb.num_joints = 3; rb.num_factors = 3
+    ref = {}
+    for build, opt in ((1, "step_tail_cross"), (2, "tv_tail_cross")):
+        for val in (0, 1, 4, 11, 14):
+            kw = dict(build=build, step_waves=4) if build == 1 else dict(build=2, tv_waves=4, tv_helpers=0)
+            kw[opt] = val
+            d, _, _, _ = _tables_digest(2, _shape(**kw), robot=rb)
+            ref.setdefault(build, d)
+            assert d == ref[build], (build, val)
+    nlp = ArmourNLP(T=100)
+    for bad in (5, 9, 15, 99, 600):
+        with pytest.raises(Exception):
+            nlp.set_option(_lib.OPT_P1_TV_TAIL_CROSS, bad)
+    nlp.set_option(_lib.OPT_P1_TV_TAIL_CROSS, 213)   # (the development form: 100 * (n + 1) + links)
+    nlp.close()
 
 
 def test_walk_helpers_only_reorder_the_sums_of_the_radii():

@@ -4,7 +4,9 @@ to ONE wave per SIMD.  Reads the compiler's -Rpass-analysis=kernel-resource-usag
 a chain / pzop / tv kernel reports Occupancy > 1 or holds <= 256 registers (VGPRs + AGPRs), i.e. when a second wave could be
 placed on its SIMD -- the configuration in which the operators gave wrong tables.
 
-    check_p1_occupancy.py <remarks file> [--allow-occupancy N]   (N > 1: development builds with -DP1_WAVES_PER_SIMD=N)
+    check_p1_occupancy.py <remarks file> [--allow-occupancy N] [--expect K]
+                          (N > 1: development builds with -DP1_WAVES_PER_SIMD=N; K: operator kernels the object must hold -- 7 in
+                           p1_reach.o, 3 in p1_reach_tv50.o, the time-vectorised kernel alone)
 """
 import re
 import sys
@@ -32,6 +34,9 @@ def main(argv):
     allow = 1
     if "--allow-occupancy" in argv:
         allow = int(argv[argv.index("--allow-occupancy") + 1])
+    expect = 7   # chain<1>, chain<3>, chain<4>, pzop, tv<1>, tv<3>, tv<4>
+    if "--expect" in argv:
+        expect = int(argv[argv.index("--expect") + 1])
     kernels = parse(open(argv[1]).read())
     seen, bad = 0, []
     for name, r in kernels.items():
@@ -42,8 +47,8 @@ def main(argv):
         regs = int(r.get("VGPRs", "0")) + int(r.get("AGPRs", "0"))
         if occ > allow or (allow == 1 and regs <= 256):
             bad.append(f"{name}: occupancy {occ}, {r.get('VGPRs')} VGPRs + {r.get('AGPRs')} AGPRs")
-    if seen < 7:   # chain<1>, chain<3>, chain<4>, pzop, tv<1>, tv<3>, tv<4>
-        print(f"check_p1_occupancy: only {seen} of the 7 operator kernels found in {argv[1]}", file=sys.stderr)
+    if seen < expect:
+        print(f"check_p1_occupancy: only {seen} of the {expect} operator kernels found in {argv[1]}", file=sys.stderr)
         return 2
     if bad:
         print("check_p1_occupancy: these kernels would share a SIMD with a second wave:\n  " + "\n  ".join(bad), file=sys.stderr)
