@@ -37,7 +37,7 @@ class ArmourRobot(C.Structure):
 
 class ArmourParams(C.Structure):
     _fields_ = [
-        ("num_time_steps", C.c_int32), ("reserved", C.c_int32),
+        ("num_time_steps", C.c_int32), ("input_constraints_off", C.c_int32),
         ("duration", C.c_double), ("k_range", C.c_double * MAXF),
         ("simplify_threshold", C.c_double), ("t_plan", C.c_double), ("cost_scale", C.c_double),
         ("collision_violation_threshold", C.c_double), ("torque_violation_threshold", C.c_double),

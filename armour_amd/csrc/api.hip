@@ -275,7 +275,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     if (rc != ARMOUR_OK) return rc;
     h->B = B; h->O = O; h->Q = h->J * h->T * O;
     h->mode = mode;
-    h->row0 = mode == ARMOUR_MODE_ARMTD ? 0 : h->n * h->T;  // CMP/NLPclass.cu:42-43: no torque rows
+    h->row0 = h->no_torque() ? 0 : h->n * h->T;  // CMP/NLPclass.cu:42-43, RT/NLPclass.cu:51-54 (TURN_OFF_INPUT_CONSTRAINTS): no torque rows, the collision rows first
     h->m = h->row0 + h->Q + 4 * h->n;
     h->d_jac = h->d_g + (size_t)B * h->m;   // directly behind this problem set's g (the allocation holds max_B * m_max * (1 + n) doubles)
     const size_t bn = (size_t)B * h->n;
@@ -456,7 +456,7 @@ extern "C" int armour_get_bounds(ArmourPlanner* h, double* x_l, double* x_u, dou
     for (int b = 0; b < h->B; b++) {
         double* gl = g_l + (size_t)b * h->m;
         double* gu = g_u + (size_t)b * h->m;
-        if (h->mode == ARMOUR_MODE_ARMOUR) {
+        if (!h->no_torque()) {   // RT/NLPclass.cu:117
             const double* tr = &h->h_torque_radius[(size_t)b * n * T];
             for (int t = 0; t < T; t++)
                 for (int j = 0; j < n; j++) {
@@ -678,7 +678,7 @@ extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t*
     for (int b = 0; b < h->B; b++) {
         const double* gb = g + (size_t)b * h->m;
         bool ok = true;
-        if (h->mode == ARMOUR_MODE_ARMOUR) {
+        if (!h->no_torque()) {   // RT/NLPclass.cu:453
             const double* tr = &h->h_torque_radius[(size_t)b * n * T];
             for (int t = 0; t < T && ok; t++)
                 for (int j = 0; j < n; j++) {
@@ -895,7 +895,7 @@ extern "C" int armour_get_pz(ArmourPlanner* h, int32_t b, int32_t which, int32_t
         armour_set_error("armour_get_pz: index out of range");
         return ARMOUR_EINVAL;
     }
-    if (which == 1 && h->mode == ARMOUR_MODE_ARMTD) {  // the comparison planner has no torque PZs: empty, centred at 0
+    if (which == 1 && h->no_torque()) {  // the comparison planner -- and ARMOUR without input constraints -- has no torque PZs: empty, centred at 0
         if (center) center[0] = center[1] = 0.0;
         return 0;
     }

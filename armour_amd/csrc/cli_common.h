@@ -36,7 +36,8 @@ namespace cli {
 struct Session {  // planner handles kept across iterations (one per mode and T)
     ArmourPlanner* armour = nullptr; int armour_T = 0;
     ArmourPlanner* armtd = nullptr; int armtd_T = 0;
-    ~Session() { if (armour) armour_destroy(armour); if (armtd) armour_destroy(armtd); }
+    ArmourPlanner* armour_nic = nullptr; int armour_nic_T = 0;   // ARMOUR without input constraints (TURN_OFF_INPUT_CONSTRAINTS, RT/Parameters.h:44)
+    ~Session() { if (armour) armour_destroy(armour); if (armtd) armour_destroy(armtd); if (armour_nic) armour_destroy(armour_nic); }
 };
 
 inline int fail(const std::string& out1, const char* what) {
@@ -52,9 +53,10 @@ inline int bad_input(const std::string& out1, const char* what) {
     return 1;
 }
 
-inline int get_handle(ArmourPlanner** h, int* have_T, int T, ArmourRobot* rb, ArmourParams* pr) {
+inline int get_handle(ArmourPlanner** h, int* have_T, int T, ArmourRobot* rb, ArmourParams* pr, bool input_constraints_off = false) {
     armour_robot_kinova_gen3_no_gripper(rb);
     armour_params_default(pr, T);
+    pr->input_constraints_off = input_constraints_off ? 1 : 0;
     if (*h && *have_T == T) return ARMOUR_OK;
     if (*h) { armour_destroy(*h); *h = nullptr; }
     const int rc = armour_create(rb, pr, nullptr, 0, h);
@@ -91,7 +93,8 @@ inline void write_common_outputs(const std::string& dir, const char* prefix, int
 // armour.in -> armour.out + 4 files (RT/armour_main.cu).  The clock starts before the input is parsed; creating the
 // planner handle (GPU context, allocations) is outside it when the handle already exists, as the reference keeps its
 // allocations outside its own clock (armour_main.cu:86-88).
-inline int iteration_armour(Session& s, const std::string& dir, int T) {
+// input_off: the reference built with TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44): no torque rows, no control-input-radius file (RT/armour_main.cu:355)
+inline int iteration_armour(Session& s, const std::string& dir, int T, bool input_off = false) {
     const std::string out1 = dir + "armour.out";
     { std::ofstream touch(out1); }  // "declare this first and make sure we always have a new output" (armour_main.cu:36)
     ArmourRobot rb;
@@ -111,10 +114,10 @@ inline int iteration_armour(Session& s, const std::string& dir, int T) {
     if (!in && nobs > 0) return bad_input(out1, "input file too short");
     {
         const auto c0 = std::chrono::steady_clock::now();
-        if (get_handle(&s.armour, &s.armour_T, T, &rb, &pr) != ARMOUR_OK) return fail(out1, "armour_create");
+        if (get_handle(input_off ? &s.armour_nic : &s.armour, input_off ? &s.armour_nic_T : &s.armour_T, T, &rb, &pr, input_off) != ARMOUR_OK) return fail(out1, "armour_create");
         t0 += std::chrono::steady_clock::now() - c0;  // creating the handle is outside the clock
     }
-    ArmourPlanner* h = s.armour;
+    ArmourPlanner* h = input_off ? s.armour_nic : s.armour;
 
     if (armour_set_problems(h, 1, nobs, q0.data(), qd0.data(), qdd0.data(), q_des.data(), obs.data()) != ARMOUR_OK) return fail(out1, "reach-set build");
     const double t_reach = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -139,7 +142,7 @@ inline int iteration_armour(Session& s, const std::string& dir, int T) {
     armour_get_link_generators(h, gens.data());
     armour_get_torque_radius(h, tr.data());
     write_common_outputs(dir, "armour", T, J, n, m, res, total_ms, g, cen, gens);
-    {
+    if (!input_off) {   // RT/armour_main.cu:355
         std::ofstream o(dir + "armour_control_input_radius.out");
         o << std::setprecision(10);
         for (int i = 0; i < T; i++) { for (int j = 0; j < n; j++) o << tr[(size_t)j * T + i] << ' '; o << '\n'; }
@@ -271,6 +274,7 @@ inline int serve(const std::string& dir, int T_armour, int T_armtd, double idle_
         if (sscanf(req, "%15s %d", kind, &T) >= 1) {
             if (!strcmp(kind, "quit")) { quit = true; code = 0; }
             else if (!strcmp(kind, "armour") && T >= 2) code = iteration_armour(s, dir, T);
+            else if (!strcmp(kind, "armour_nic") && T >= 2) code = iteration_armour(s, dir, T, true);
             else if (!strcmp(kind, "armtd") && T >= 2) code = iteration_armtd(s, dir, T);
         }
         char reply[32];
@@ -285,7 +289,7 @@ inline int serve(const std::string& dir, int T_armour, int T_armtd, double idle_
 
 // main() of the worker: `armour_worker armour|armtd [--serve] [--idle-seconds S] [buffer_dir] [T] [T_armtd]`
 inline int worker_main(int argc, char** argv) {
-    if (argc < 2 || (strcmp(argv[1], "armour") && strcmp(argv[1], "armtd"))) { fprintf(stderr, "usage: armour_worker armour|armtd [--serve] [buffer_dir] [T]\n"); return 2; }
+    if (argc < 2 || (strcmp(argv[1], "armour") && strcmp(argv[1], "armtd") && strcmp(argv[1], "armour_nic"))) { fprintf(stderr, "usage: armour_worker armour|armour_nic|armtd [--serve] [buffer_dir] [T]\n"); return 2; }
     // started by armour_main / armtd_main (planner_client.cpp): if that front end dies -- e.g. killed by its caller --
     // this process, which holds the GPU and the socket, gets SIGTERM instead of living on as an orphan
     // Only when a front end did start it (ARMOUR_WORKER_PARENT = its pid): a worker started directly -- `rocprofv3 -- armour_worker ...
@@ -296,7 +300,8 @@ inline int worker_main(int argc, char** argv) {
         if ((long long)getppid() != atoll(pp)) { fprintf(stderr, "        HIP & C++: the front end that started this worker is gone\n"); return 1; }
     }
     const char* kind = argv[1];
-    const bool is_armour = !strcmp(kind, "armour");
+    const bool is_nic = !strcmp(kind, "armour_nic");   // ARMOUR without input constraints
+    const bool is_armour = !strcmp(kind, "armour") || is_nic;
     bool want_serve = false;
     double idle_s = 0;
     std::vector<std::string> pos;
@@ -304,6 +309,7 @@ inline int worker_main(int argc, char** argv) {
         const std::string a = argv[i];
         if (a == "--serve") want_serve = true;
         else if (a == "--idle-seconds" && i + 1 < argc) idle_s = atof(argv[++i]);
+        else if (a == "--no-input-constraints") {}   // (the front end has turned it into the kind already)
         else pos.push_back(a);
     }
     const std::string dir = buffer_dir(pos.size() > 0 ? pos[0].c_str() : nullptr);
@@ -314,7 +320,7 @@ inline int worker_main(int argc, char** argv) {
         return serve(dir, is_armour ? T : 0, is_armour ? T2 : T, idle_s);
     }
     Session s;
-    return is_armour ? iteration_armour(s, dir, T) : iteration_armtd(s, dir, T);
+    return is_armour ? iteration_armour(s, dir, T, is_nic) : iteration_armtd(s, dir, T);
 }
 
 }  // namespace cli

@@ -58,6 +58,7 @@ struct P1Cfg {
     ArmourUltimateBound ub;
     const double* bez;  // [B][3][n]: q0, Tqd0, TTqdd0
     int mode;           // ARMOUR_MODE_*; ARMTD: cos/sin JRS from `jrs`, forward kinematics only (no RNEA, no torque tables)
+    int fk_only;        // forward kinematics only: ARMTD mode, or the ARMOUR trajectory without input constraints (RT/armour_main.cu:149-165)
     const double* jrs;  // ARMTD mode: [B][n][6][T] centre / k-generator / radius of cos(q - q0), then of sin(q - q0)
     // outputs
     int* link_count; double* link_center; double* link_indep; uint32_t* link_keys; double* link_coeff;
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             it0 = __builtin_amdgcn_readfirstlane(*qword);
         }
         if (it0 >= cf.n_items + cf.fk_items) break;
-        const bool fk_only = it0 >= cf.n_items || cf.mode == ARMOUR_MODE_ARMTD;
+        const bool fk_only = it0 >= cf.n_items || cf.fk_only != 0;
         int it = it0 >= cf.n_items ? it0 - cf.n_items : it0;
         if (cf.queue && !cf.items && cf.queue_order != 2) {   // position in the draw -> item: time steps from the last (order 1) or the first (3), every problem's in turn
             const int nb = cf.n_items / cf.T;   // (all problems, all steps: n_items = B * T)
@@ -1868,7 +1869,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // a round of four-wave items 1.0 ms, of one-wave items 2.6 ms -- B = 11 5.07 against 5.27, 16 7.16 against 7.70, 14 6.2 against 5.7)
         const int cus = prop.multiProcessorCount;
         const long long r4 = (n_items + cus - 1) / cus, r1 = (n_items + (long long)cus * waves_per_cu(cap) - 1) / ((long long)cus * waves_per_cu(cap));
-        const bool multi = h->mode == ARMOUR_MODE_ARMTD ? false  // forward kinematics only: a single role
+        const bool multi = h->no_torque() ? false  // forward kinematics only: a single role
                            : nw_env ? nw_env >= 3
                            : collect ? false
                            : fits4 ? r4 <= 5 && 100 * r4 < 258 * r1   // (round 4, after the merge-path sorts and the item queue, B problems of 100 steps, four waves | one: 5: 2.22 | 2.66, 8: 3.73 | 3.76, 10: 4.03 | 4.46, 12: 4.83 | 4.94, 13: 5.63 | 5.04, 15: 5.90 | 5.28 -- from the sixth round on the one-wave blocks' throughput wins)
@@ -1900,7 +1901,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.free_running = free_env;
         cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
         cf.bez = h->d_bez;
-        cf.mode = h->mode; cf.jrs = h->d_jrs;
+        cf.mode = h->mode; cf.fk_only = h->no_torque() ? 1 : 0; cf.jrs = h->d_jrs;
         cf.link_count = h->d_link_count; cf.link_center = h->d_link_center; cf.link_indep = h->d_link_indep;
         cf.link_keys = h->d_link_keys; cf.link_coeff = h->d_link_coeff;
         cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
@@ -1964,7 +1965,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // Batches with more items than three waves per CU hold run a first pass with 2048-entry sort buffers -- 32 KB of LDS
     // per wave, so FOUR waves per CU -- and list the few items that overflow them; those alone are rebuilt with the full
     // buffers.  Small batches gain nothing from the fourth wave and go straight to the full buffers.
-    if (h->mode == ARMOUR_MODE_ARMTD) {  // no torque tables in this mode: empty PZs, zero radius
+    if (h->no_torque()) {  // no torque tables in these modes: empty PZs, zero radius (RT/armour_main.cu:172-175: the radius stays zero)
         HIPCHK(hipMemsetAsync(h->d_tq_count, 0, (size_t)B * n * T * sizeof(int), h->stream));
         HIPCHK(hipMemsetAsync(wk->d_torque_radius, 0, (size_t)B * n * T * sizeof(double), h->stream));
     }
@@ -1973,7 +1974,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // (DESIGN.md 4.2).  Any capacity flag sends the whole batch down the per-step path below.
     bool built = false;
     const int tv_min_groups = h->tune(ARMOUR_OPT_P1_TV_MIN_GROUPS);  // default 31: below this the per-step kernel is faster (re-measured at the end of round 4, B problems of 100 steps, per-step against time-vectorised: 14: 5.84 / 6.35 ms, 16: 7.49 / 6.64 -- the per-step kernel steps up with every 768 items -- 18: 8.04 / 6.66; round 3: 36, profiles/r03_p1_breakeven.txt)
-    const bool armtd = h->mode == ARMOUR_MODE_ARMTD;  // comparison mode: forward kinematics only -- every item is a forward-kinematics item
+    const bool armtd = h->no_torque();  // comparison mode, or ARMOUR without input constraints: forward kinematics only -- every item is a forward-kinematics item
     // (its chain is a fifth of the RNEA chain: the per-step kernel stays ahead up to B = 30 there)
     // (the break-even is one of WORK: the per-step kernel's time grows with B * T, a chain's latency hardly depends on the lanes in
     //  use -- 64 problems of 20 time steps are faster step by step -- so the threshold counts groups of 50 time steps' worth of items)
@@ -2062,7 +2063,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.arena_bytes = TL.total; cf.arena = pool.ptr;
             cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
             cf.bez = h->d_bez;
-            cf.mode = h->mode; cf.jrs = h->d_jrs;
+            cf.mode = h->mode; cf.fk_only = h->no_torque() ? 1 : 0; cf.jrs = h->d_jrs;
             cf.link_count = h->d_link_count; cf.link_center = h->d_link_center; cf.link_indep = h->d_link_indep;
             cf.link_keys = h->d_link_keys; cf.link_coeff = h->d_link_coeff;
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;

@@ -102,7 +102,7 @@ int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsig
                    long long g_stride, long long j_stride, P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out) {
     P2Launch lp;
     lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
-    lp.nbt = tb.mode == ARMOUR_MODE_ARMTD ? 0 : (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;  // ARMTD mode has no torque rows
+    lp.nbt = tb.row0 == 0 ? 0 : (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;  // no torque rows in ARMTD mode and with TURN_OFF_INPUT_CONSTRAINTS (row0 = 0: the collision rows come first)
     lp.max_pairs = tb.O > 0 ? (P2_ROWS - 1) / tb.O + 2 : 1;
     lp.strideL = max_link > 0 ? max_link : 1;
     lp.strideT = max_torque > 0 ? max_torque : 1;

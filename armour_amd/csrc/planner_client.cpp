@@ -83,14 +83,20 @@ int main(int argc, char** argv) {
     std::string base = self.substr(self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/') + 1);
     const char* kind = base.rfind("armtd", 0) == 0 ? "armtd" : "armour";
     bool serve = false, quit = false;
+    // TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44) is a compile-time switch of the reference; here: `--no-input-constraints`, or -- for a MATLAB
+    // caller that cannot change the command line of uarmtd_planner.m:189 -- ARMOUR_TURN_OFF_INPUT_CONSTRAINTS=1 in the environment (setenv)
+    const char* nic_env = getenv("ARMOUR_TURN_OFF_INPUT_CONSTRAINTS");
+    bool nic = nic_env && nic_env[0] && strcmp(nic_env, "0") != 0;
     std::vector<const char*> pos;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--serve") serve = true;
         else if (a == "--quit") quit = true;
         else if (a == "--idle-seconds") i++;
+        else if (a == "--no-input-constraints") nic = true;
         else pos.push_back(argv[i]);
     }
+    if (nic && kind[3] == 'o') kind = "armour_nic";
     const std::string dir = cli::buffer_dir(pos.size() > 0 ? pos[0] : nullptr);
     int rc = 1;
     if (quit) return cli::try_resident(dir, "quit", 0, &rc) ? rc : 1;

@@ -140,6 +140,9 @@ struct Problem {
     double build_ms = 0;
     /* ARMTD comparison mode (CMP/ = kinova_planner_realtime_armtd_comparison): constant-acceleration curve, offline JRS tables */
     bool armtd = false;
+    /* TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44): the ARMOUR trajectory without the torque rows -- P1 runs JRS + forward kinematics only
+     * (RT/armour_main.cu:115,149-165,175), m = J T O + 4n with the collision rows first (RT/NLPclass.cu:46-54,117,289-301,361-373,453) */
+    bool no_torque() const { return armtd || pr.input_constraints_off != 0; }
     std::vector<double> jrs; /* [n][6][T]: c,g,r of cos then of sin (CMP/armtd_main.cu:76-96) */
     double k_range_a[ARMOUR_MAX_FACTORS];     /* per-joint k_range read with the tables (:97) */
 };
@@ -499,7 +502,7 @@ static void build(Problem& P, int num_threads) {
             for (int i = 0; i < J; i++) P.links[i * T + t] = link_box[i];
             fk(P, cx, t);
             for (int i = 0; i < J; i++) reduce_link_PZ(cx, P.links[i * T + t], &P.link_gens[(size_t)(t * J + i) * 18]);
-            if (P.armtd) continue; /* CMP/armtd_main.cu:141-156: forward kinematics only */
+            if (P.no_torque()) continue; /* CMP/armtd_main.cu:141-156, RT/armour_main.cu:149-165: forward kinematics only */
             rnea(P, cx, t, mass_nom, I_nom, P.u_nom);
             rnea(P, cx, t, mass_unc, I_unc, P.u_nom_int);
             for (int i = 0; i < n; i++) P.u_nom_int[i * T + t] = sub(cx, P.u_nom_int[i * T + t], P.u_nom[i * T + t]);
@@ -509,7 +512,7 @@ static void build(Problem& P, int num_threads) {
         P.st.merge(cx.st);
     }
     /* robust input bound, RT/armour_main.cu:172-205 */
-    for (int t = 0; t < T && !P.armtd; t++) {
+    for (int t = 0; t < T && !P.no_torque(); t++) {   /* (RT/armour_main.cu:175: the radius stays zero without input constraints) */
         Interval rho(0.0);
         for (int i = 0; i < n; i++) {
             double lo, hi;
@@ -608,11 +611,11 @@ static void eval_g_jac(Problem& P, const double* x, double* g, double* jac, int 
     if (num_threads > 0) omp_set_num_threads(num_threads);
     Ctx cx; cx.kl.n = n;
     /* ARMTD mode, CMP/NLPclass.cu:245-330: collision rows first, then the state-limit rows; no torque rows */
-    const size_t off_col = P.armtd ? 0 : (size_t)T * n, off_lim = off_col + (size_t)T * J * O;
+    const size_t off_col = P.no_torque() ? 0 : (size_t)T * n, off_lim = off_col + (size_t)T * J * O;   /* (RT/NLPclass.cu:289-301: the same order with TURN_OFF_INPUT_CONSTRAINTS) */
 #pragma omp parallel for schedule(dynamic)
     for (int t = 0; t < T; t++) {
         double cen[3], dcen[ARMOUR_MAX_FACTORS * 3];
-        for (int j = 0; j < n && !P.armtd; j++) {
+        for (int j = 0; j < n && !P.no_torque(); j++) {
             if (g) { double c; slice_value(cx, P.u_nom[j * T + t], x, &c, nullptr); g[t * n + j] = c; }
             if (jac) slice_gradient(cx, P.u_nom[j * T + t], x, &jac[(size_t)(t * n + j) * n]);
         }
@@ -708,7 +711,7 @@ int oracle_set_problem_armtd(void* h, const double* q0, const double* qd0, const
     build(P, num_threads);
     return 0;
 }
-int oracle_num_constraints(void* h) { Problem& P = *(Problem*)h; return (P.armtd ? 0 : P.n * P.T) + P.J * P.T * P.O + 4 * P.n; }
+int oracle_num_constraints(void* h) { Problem& P = *(Problem*)h; return (P.no_torque() ? 0 : P.n * P.T) + P.J * P.T * P.O + 4 * P.n; }   /* RT/NLPclass.cu:46-54 */
 double oracle_build_ms(void* h) { return ((Problem*)h)->build_ms; }
 
 void oracle_eval_g_jac(void* h, const double* k, double* g, double* jac, int num_threads) { eval_g_jac(*(Problem*)h, k, g, jac, num_threads); }
@@ -726,12 +729,12 @@ void oracle_get_bounds(void* h, double* x_l, double* x_u, double* g_l, double* g
     Problem& P = *(Problem*)h;
     const int T = P.T, J = P.J, n = P.n, O = P.O;
     for (int i = 0; i < n; i++) { x_l[i] = -1.0; x_u[i] = 1.0; }
-    for (int i = 0; i < T && !P.armtd; i++)
+    for (int i = 0; i < T && !P.no_torque(); i++)   /* RT/NLPclass.cu:117 */
         for (int j = 0; j < n; j++) {
             g_l[i * n + j] = -P.rb.torque_limits[j] + P.torque_radius[j * T + i];
             g_u[i * n + j] = P.rb.torque_limits[j] - P.torque_radius[j * T + i];
         }
-    size_t off = P.armtd ? 0 : (size_t)n * T; /* CMP/NLPclass.cu:73-140: the same rows without the torque block */
+    size_t off = P.no_torque() ? 0 : (size_t)n * T; /* CMP/NLPclass.cu:73-140: the same rows without the torque block */
     for (size_t i = off; i < off + (size_t)T * J * O; i++) { g_l[i] = -1e19; g_u[i] = 0; }
     off += (size_t)T * J * O;
     for (int rep = 0; rep < 2; rep++, off += n)
