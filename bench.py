@@ -100,8 +100,12 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     # (each setting of the sweep is timed for about a second: a burst of 16 evaluations -- 2 ms -- rated 64 threads at 8.4 k/s on a box
     #  where the sustained figure at that setting was 1.7 k/s; the host is shared, and what a wide team loses to preemption at its
     #  barriers does not show in a burst)
+    # (the thread counts come from the CPUs this process may run on -- taken BEFORE the sweep: oracle_max_threads() is omp_get_max_threads(),
+    #  which returns whatever the last omp_set_num_threads() of the sweep left behind -- round 4 timed P1 at {1, 16} instead of {1, 32, all})
+    host = host_description()
+    avail = int(host["cpus_usable_by_this_process"] or max_threads())
     best_t, best_rate, sweep = 0, 0.0, {}
-    for th in sorted({min(c, max_threads()) for c in (1, 16, 32, 64, 128, max_threads())}):
+    for th in sorted({min(c, avail) for c in (1, 16, 32, 64, 128, avail)}):
         o.time_eval(ks, 3, threads=th)  # warm-up
         burst = 16 / o.time_eval(ks, 16, threads=th)
         n = int(max(16, min(8000, burst * 1.0)))
@@ -117,13 +121,12 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     # the reach-set build (P1, RT/armour_main.cu:96-216: OpenMP over the time steps) as its own timed figure: the same world at
     # 1 thread, at the reference's 32 (NUM_THREADS, RT/Parameters.h:35) and at all cores; best of 2 builds each (1 at one thread)
     p1 = {}
-    for th in sorted({1, min(32, max_threads()), max_threads()}):
+    for th in sorted({1, min(32, avail), avail}):
         ms = []
         for _ in range(1 if th == 1 else 2):
             ob = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"], threads=th)
             ms.append(ob.build_ms)
         p1[str(th)] = min(ms)
-    host = host_description()
     return {
         "value": reps / secs, "unit": "iters/s", "cores": best_t, "kind": "port",
         "cores_note": "`cores` = the OpenMP threads of the fastest setting of the sweep (what `value` was measured with), not the box's core count: see host",
@@ -131,7 +134,7 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
         "thread_sweep_iters_per_s": sweep, "sample_parts_iters_per_s": [part / t for t in part_secs],
         "sample": f"{reps} fused eval_g+eval_jac_g of 1 world (seed {seed}, O={O}, T={T}) at 64 cycling k points, "
                   f"OpenMP over time steps as RT/NLPclass.cu:304,376",
-        "p1_build_ms_by_threads": p1, "p1_build_ms": min(p1.values()),
+        "p1_build_ms_by_threads": p1, "p1_build_ms": min(p1.values()), "p1_pair_products": int(o.stats()["mul_pairs"]),
         "p1_sample": f"reach-set build (JRS, FK, RNEA x2, torque radius, half-space tables) of the same world, ms, by OpenMP threads",
     }
 
@@ -180,14 +183,71 @@ def measured_traffic(B, O, T, name=None):
     return None
 
 
+def p1_traffic(tag):
+    """L2-miss traffic of every kernel of one reach-set build (bytes: 2 x FETCH_SIZE + WRITE_SIZE summed over the build's kernels) from the newest
+    committed profiles/r*_p1_cache.json -- read from a committed file, not measured in this run -- or None."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_p1_cache.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            ks = d["kernels"][tag]
+            return {"bytes": float(sum(k["hbm_bytes_per_dispatch"] for k in ks.values())),
+                    "reach_set_kernel_bytes": float(max(k["hbm_bytes_per_dispatch"] for k in ks.values())),
+                    "l2_hit_rate_reach_set_kernel": max(ks.values(), key=lambda k: k["hbm_bytes_per_dispatch"]).get("l2_hit_rate"),
+                    "profile": os.path.relpath(path, ROOT), "profile_commit": d.get("commit"), "profile_date": d.get("date")}
+        except Exception:
+            continue
+    return None
+
+
+def p1_accounting(device, T, O, p1_ms_b1, count_pairs):
+    """set_problems ms per problem and monomial-pair products per second -- the pairs (sum over all operator* calls of
+    (M_a + 1)(M_b + 1), RT/PZsparse.cu:864-994) counted by the CPU oracle on the same worlds (the oracle is the counter here, not the thing
+    timed) -- for one problem and for a batch of 128 (configs[3]'s shard), with the build's counter traffic and its fraction of the HBM peak."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch, random_problem
+    out = {}
+    B = 128
+    bp = random_batch(0, B, O)
+    nlp = _opts(ArmourNLP(T=T, device=device))
+    ms = []
+    for _ in range(4):
+        nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        ms.append(nlp.build_ms)
+    info = nlp.build_info()
+    nlp.close()
+    pairs = {1: None, B: None}
+    if count_pairs:
+        from oracle.cpu_oracle import Oracle
+        tot = 0
+        for b in range(B):
+            p = random_problem(b, O)
+            tot += Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"]).stats()["mul_pairs"]
+            if b == 0:
+                pairs[1] = tot
+        pairs[B] = tot
+    for tag, nb, build_ms in (("B=1", 1, p1_ms_b1), ("B=128", B, min(ms[1:]))):
+        tr = p1_traffic(tag)
+        e = {"problems": nb, "set_problems_ms": build_ms, "ms_per_problem": build_ms / nb, "pair_products": pairs[nb],
+             "pair_products_per_s": (pairs[nb] / (build_ms * 1e-3)) if pairs[nb] else None,
+             "traffic": tr, "frac_by_traffic": (tr["bytes"] / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
+        if nb == B:
+            e["kernel"] = info
+        out[tag] = e
+    out["note"] = ("set_problems_ms: HIP events around every kernel of the build (reach-set kernel + half-space kernels), best of the warm builds; "
+                   "pair_products: counted by the CPU oracle on the same worlds (seeds 0..B-1, O = %d); traffic: L2-miss bytes of the same kernels from the "
+                   "committed counter profile; no roofline is claimed for P1 beyond that fraction (irregular, latency-bound: DESIGN.md 4.2)" % O)
+    return out
+
+
 class Timed:
     """K fused evaluations of one handle's problems as one graph, timed R times.  Every interval is bracketed by
     barrier + synchronize on both sides and MAX-reduced over the ranks (armour_amd.sharding.reduce_max_elapsed)."""
 
-    def __init__(self, nlp, dev, seed, K, W, use_dist):
+    def __init__(self, nlp, dev, seed, K, W, use_dist, red_dev="same"):
         import torch
         from armour_amd.worlds import random_k
         self.torch, self.nlp, self.dev, self.K, self.W, self.use_dist = torch, nlp, dev, K, W, use_dist
+        self.red_dev = (dev if use_dist else None) if red_dev == "same" else red_dev
         B, n, m = nlp.B, nlp.n, nlp.m
         self.ks = torch.tensor(random_k(seed, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
         self.d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
@@ -232,9 +292,9 @@ class Timed:
                 elapsed = time.perf_counter() - t0
                 self.barrier()
                 if timed_by_events:
-                    ev.append(reduce_max_elapsed(e0.elapsed_time(e1) * 1e-3, device=self.dev if self.use_dist else None))
+                    ev.append(reduce_max_elapsed(e0.elapsed_time(e1) * 1e-3, device=self.red_dev))
                 else:
-                    wall.append(reduce_max_elapsed(elapsed, device=self.dev if self.use_dist else None))
+                    wall.append(reduce_max_elapsed(elapsed, device=self.red_dev))
         return wall, ev
 
     def check(self, oracle_problems=None, tol_g=1e-9, tol_j=1e-8):
@@ -283,7 +343,7 @@ def summarise(nlp, wall, ev, K, world, extra=None, traffic_name=None):
     return out
 
 
-def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle):
+def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle, red_dev="same"):
     """One more BASELINE config measured exactly like the headline (never `value`): B worlds per GPU at O obstacles."""
     from armour_amd.planner import ArmourNLP
     from armour_amd.sharding import shard_seeds
@@ -291,7 +351,7 @@ def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle
     seeds = shard_seeds(1000, world * B, rank, world)
     probs = random_batch(seeds[0], len(seeds), O)
     nlp = _opts(ArmourNLP(T=T, device=device)).set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
-    tm = Timed(nlp, dev, 77 + rank, K, 4, use_dist)
+    tm = Timed(nlp, dev, 77 + rank, K, 4, use_dist, red_dev)
     wall, ev = tm.run(R)
     # output check: finite, device entry == host entry, two problems against the CPU oracle (rank 0; the oracle is the checker)
     spot = None
@@ -388,6 +448,9 @@ def main():
                          "kernel to the trace), i.e. skip the host-entry check and the sync-latency probe")
     ap.add_argument("--set-option", action="append", default=[], metavar="ID=VALUE", help="development: armour_set_option on every handle (A/B runs)")
     ap.add_argument("--dry-run", action="store_true", help="development / tests: launcher + rendezvous + reduction on CPU (gloo), no GPU work")
+    ap.add_argument("--rank-devices", default="", metavar="D0,D1,...", help="development / tests: device ordinal of every rank (default: rank r on device r); "
+                    "several ranks on one device need --dist-backend gloo (RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the barrier and the MAX reduction (nccl = RCCL)")
     args = ap.parse_args()
     for kv in args.set_option:
         OPTIONS.append((int(kv.split("=")[0]), float(kv.split("=")[1])))
@@ -412,14 +475,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    if args.rank_devices:
+        local_rank = int(args.rank_devices.split(",")[rank])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ   # under a launcher even a single rank goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    red_dev = dev if (use_dist and args.dist_backend == "nccl") else None   # where the reduction's tensor lives (gloo: host memory)
     B, O, T, K, W, R = args.batch, args.obstacles, args.time_steps, args.steps, args.warmup, max(1, args.repeats)
     # independent worlds per rank (block partition of world*B seeds, armour_amd/sharding.py); no data-path collective
     seeds = shard_seeds(0, world * B, rank, world)
@@ -462,7 +531,7 @@ def main():
     probe_early = {}
     if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:   # development: where in this process does the page-locked call get slow?
         probe_early["after_set_parameters"] = sync_probe()
-    tm = Timed(nlp, dev, rank, K, W, use_dist)
+    tm = Timed(nlp, dev, rank, K, W, use_dist, red_dev)
     if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:
         probe_early["after_graph_built"] = sync_probe()
     wall, ev = tm.run(R)
@@ -471,18 +540,21 @@ def main():
     if not args.no_check and not args.no_sync_probe:
         tm.check()   # finite, and the synchronous host entry reproduces the device entry bit for bit
 
+    from armour_amd.sharding import gather_counts
+    counts = gather_counts(len(seeds), device=red_dev)   # what every rank built and evaluated (a collective: all ranks call it)
     out = None
     if rank == 0:
         s = summarise(nlp, wall, ev, K, world)
         cfg_id = 1 if (B, O, T) == (1, 20, 100) else 2 if (B, O, T) == (128, 50, 100) else 3 if (B, O, T) == (128, 20, 100) else "custom"
         out = {
-            "metric": METRIC, "value": s["problem_evals_per_s"], "unit": "iters/s", "n_gpus": world,
+            "metric": METRIC, "value": sum(counts) * K / statistics.median(wall), "unit": "iters/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": s["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Kinova Gen3 7-DOF, {O} obstacles, {T} time steps, {B} planning problem(s) per GPU "
                                    f"(BASELINE configs[{cfg_id}]), one fused eval_g+eval_jac_g launch per step at a fresh k",
                        "robot": "kinova_gen3_7dof_no_gripper", "batch_per_gpu": B, "obstacles": O, "time_steps": T,
-                       "constraints_m": m, "parallelism": f"independent worlds x{world}, no collective"},
+                       "constraints_m": m, "parallelism": f"independent worlds x{world}, no collective", "problems_per_rank": counts,
+                       "dist_backend": (args.dist_backend if use_dist else None), "rank_devices": args.rank_devices or None},
             "timing": {"repeats": R, "statistic": "median of the max-over-ranks wall time of K steps (barrier + synchronize on both sides)",
                        "wall_ms_min_med_max": s["wall_ms_min_med_max"]},
             "roofline": {"bound": "hbm", "achieved": s["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -553,14 +625,16 @@ def main():
         KX = max(4, min(K, 40))
         chk = None if args.no_check or args.no_sync_probe else True
         if world == 1:
-            oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk),
+            oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk, red_dev),
                   "configs[4]: Fetch, payload +-50 %, O=100, batch 1, T=100": fetch_config(local_rank, dev, T, max(KX, 20), R, chk is not None)}
         else:
             oc = {f"configs[3]: O=20, batch 128 per GPU ({128 * world} worlds over {world} GPUs), T=100":
-                  extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False)}
+                  extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False, red_dev)}
         if rank == 0:
             out["other_configs"] = oc
     if rank == 0:
+        if world == 1 and not args.headline_only and (B, O, T) == (1, 20, 100):
+            out["p1"] = p1_accounting(local_rank, T, O, p1_dev_ms, count_pairs=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, O, seed=0)
         print(json.dumps(out), flush=True)
