@@ -106,7 +106,7 @@ OPT_SOLVE_WAVES_PER_SIMD = 147
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_robot_fetch", "armour_params_default", "armour_create", "armour_destroy",
+    "armour_robot_kinova_gen3_no_gripper", "armour_robot_kinova_gen3_gripper", "armour_robot_fetch", "armour_robot_fetch8", "armour_params_default", "armour_create", "armour_destroy",
     "armour_last_error", "armour_device_available", "armour_alloc_pinned", "armour_free_pinned", "armour_set_problems", "armour_set_problems_armtd", "armour_get_sizes",
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_prepare_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
@@ -167,6 +167,8 @@ def load():
     L.armour_robot_kinova_gen3_gripper.argtypes = [C.POINTER(ArmourRobot)]
     L.armour_robot_fetch.argtypes = [C.POINTER(ArmourRobot)]
     L.armour_robot_fetch.restype = None
+    L.armour_robot_fetch8.argtypes = [C.POINTER(ArmourRobot)]
+    L.armour_robot_fetch8.restype = C.c_int
     L.armour_robot_kinova_gen3_gripper.restype = None
     L.armour_params_default.argtypes = [C.POINTER(ArmourParams), C.c_int32]
     L.armour_params_default.restype = None

@@ -27,6 +27,18 @@ extern "C" const char* armour_last_error(void) { return g_err; }
 extern "C" void armour_robot_kinova_gen3_no_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_no_gripper(robot); }
 extern "C" void armour_robot_kinova_gen3_gripper(ArmourRobot* robot) { armour_fill_kinova_gen3_gripper(robot); }
 extern "C" void armour_robot_fetch(ArmourRobot* robot) { armour_fill_fetch(robot); }
+// (an 8-factor robot: the 128-bit-key ABI fills it, the 64-bit one says why it cannot -- include/armour_robot_fetch.h)
+extern "C" int armour_robot_fetch8(ArmourRobot* robot) {
+#if ARMOUR_MAX_FACTORS >= 8
+    if (!robot) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    armour_fill_fetch8(robot);
+    return ARMOUR_OK;
+#else
+    (void)robot;
+    armour_set_error("armour_robot_fetch8: an 8-factor robot needs the 128-bit-key library (libarmour_hip_k128.so: armour_abi_max_factors() == 8)");
+    return ARMOUR_EINVAL;
+#endif
+}
 extern "C" void armour_params_default(ArmourParams* params, int32_t T) { armour_fill_default_params(params, T); }
 
 extern "C" int armour_device_available(void) {

@@ -177,6 +177,10 @@ struct ArmourPlanner {
     double* d_g = nullptr;
     double* d_jac = nullptr;
     double build_ms = 0;
+    // where the LAST build's search for a launch shape ended (a sort-buffer overflow sends a build to the next larger shape): the next build of this
+    // handle -- the same robot, a similar problem -- starts there instead of repeating the failed launches (8-factor arms on the halved key buffers of
+    // the 128-bit build: 4 launches, 67 ms, for a 25 ms build).  0 = from the beginning.
+    int p1_step_cap_hint = 0, p1_tv_shape_hint = 0;
     int build_info[4] = {0, 0, 0, 0};          // armour_get_build_info: kernel of the last reach-set build, waves per block, sort-buffer entries, launches
     int max_link = 0, max_torque = 0;          // largest monomial counts in the current tables (LDS sizing of P2)
     long long sum_link = 0, sum_torque = 0;

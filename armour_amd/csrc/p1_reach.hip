@@ -42,6 +42,13 @@ constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28
 // ... and of a 4-wave block (round 3: the forward kinematics, the omega recursion and the constant cross products on a wave of their own,
 // as the time-vectorised kernel's four-wave blocks have had since round 2: p1_tv.inc.h kTvPart4First)
 constexpr int kPart4First[4] = {0, 8, 23, 43}, kPart4Count[4] = {8, 15, 20, 20};   // (63 slots: the free mask is one 64-bit word, built as (1 << nV) - 1)
+// Sort-buffer KEY entries for `cap` raw terms.  A wave's LDS sort buffers are skey[cap_key] (monomial keys) + sidx[cap_raw] (permutation, 2 B each).
+// The 64-bit build gives both `cap` entries; with 128-bit keys (pz_key.h, -DARMOUR_KEY128) the same bytes hold half as many keys -- and the
+// sorters ask for cap_key and cap_raw separately (pz_wave.h sort_terms: the tree merge needs 2 N keys, the ranked merge the two operands' key
+// lists, the bitonic network next_pow2(N)), so a block keeps its shape -- four waves, one block per CU -- with HALF the key entries instead of
+// falling back to one-wave blocks (round 4: 7.2 ms for one 8-factor problem).  A product too long for them raises ERR_RAW_OVERFLOW as before.
+constexpr int kKeyDiv = (int)(sizeof(pzkey_t) / sizeof(uint64_t));
+__host__ __device__ constexpr int key_cap(int cap) { return cap / kKeyDiv; }
 constexpr int kFkCapKey = 1024, kFkCapRaw = 2048;   // sort buffers of that fourth wave: its products stay below 0.9 k raw terms; the ranked rotation x vector products of omega need room for the permutation only
 constexpr int kRoleN = 2;  // the role that computes (and later frees) the moments N_i (measured with it in role 0 / 1 / 2 and the forward kinematics split off: 2.06 / 2.01 / 1.95 ms)
 constexpr int kNVOneWave = 32;  // a 1-wave block plays the roles in turn: one pool, one set of scratch slots
@@ -1789,7 +1796,7 @@ int armour_p1_debug_pz_op(ArmourPlanner* h, int op, int nops, const int* sz, con
     P1Cfg cf;
     memset(&cf, 0, sizeof(cf));
     cf.B = 1; cf.T = h->T; cf.J = J; cf.n = n;
-    cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capKey = cap_raw; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+    cf.capW = h->lim.work_monomials; cf.capRaw = cap_raw; cf.capKey = cap_raw; /* (the one-operator test hook: full-width key buffers) */ cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
     cf.arena_bytes = L.total; cf.arena = arena;
     cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
     const PzOpArgs* d_args = (const PzOpArgs*)up(&a, sizeof(a));
@@ -1838,13 +1845,13 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     int cap_raw = 64;
-    while (cap_raw < h->lim.raw_terms) cap_raw <<= 1;
+    while (cap_raw < h->lim.raw_terms || cap_raw < h->p1_step_cap_hint) cap_raw <<= 1;   // (the hint: what the last build of this handle ended up with)
     if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
     const Layout L1 = make_layout(J, n, h->lim.work_monomials, 1), L3 = make_layout(J, n, h->lim.work_monomials, kRoles), L4 = make_layout(J, n, h->lim.work_monomials, 4);
     if (L4.idJS + L4.nJS > kMaxSlots) { armour_set_error("slot table too small"); return ARMOUR_EINVAL; }
     auto ci_doubles = [&](const Layout& L) { return (size_t)L.nV * 9 + kNS * 3 + kNM * 27 + (size_t)L.nJM * 27 + (size_t)L.nJV * 9 + (size_t)L.nJS * 3; };
     auto lds_bytes = [&](int cap, int nw = 1) {
-        return (size_t)(nw == 4 ? 3 : nw) * p1_wave_lds(cap, cap) + (nw == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : nw == kRoles ? L3 : L4));
+        return (size_t)(nw == 4 ? 3 : nw) * p1_wave_lds(key_cap(cap), cap) + (nw == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0) + p1_shared_lds(ci_doubles(nw == 1 ? L1 : nw == kRoles ? L3 : L4));
     };
     const int max_waves_env = std::min(h->tune(ARMOUR_OPT_P1_MAX_WAVES_PER_CU), 4 * P1_WAVES_PER_SIMD);
     auto waves_per_cu = [&](int cap) { return std::max(1, std::min(max_waves_env, (int)((size_t)160 * 1024 / lds_bytes(cap)))); };
@@ -1895,7 +1902,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         P1Cfg cf;
         memset(&cf, 0, sizeof(cf));
         cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
-        cf.capW = h->lim.work_monomials; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+        cf.capW = h->lim.work_monomials; cf.capRaw = cap; cf.capKey = key_cap(cap); cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
         cf.arena_bytes = L.total; cf.arena = wk->arena;
         const int free_env = h->tune(ARMOUR_OPT_P1_STEP_FREE);   // (0 = a barrier per joint)
         cf.free_running = free_env;
@@ -2013,7 +2020,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             (void)hipFree(pool.ptr);
             pool.ptr = nullptr; pool.bytes = 0;
         }
-        for (int si = 0; si < 5 && !built; si++) {
+        for (int si = tv_nw_env > 0 ? 0 : std::min(h->p1_tv_shape_hint, 4); si < 5 && !built; si++) {   // (a forced block shape searches from the beginning)
             const int nw_launch = shapes[si].nw, cap = shapes[si].cap;
             if (nw_launch == 8 && (!kTvDedicatedHelpers || !tv_ded_env || !tv_free_env)) continue;
             const int nw = nw_launch == 8 ? 4 : nw_launch;   // the waves that play roles
@@ -2059,7 +2066,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             P1Cfg cf;
             memset(&cf, 0, sizeof(cf));
             cf.B = B; cf.T = T; cf.J = J; cf.n = n; cf.O = O;
-            cf.capW = capTv; cf.capRaw = cap; cf.capKey = cap; cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
+            cf.capW = capTv; cf.capRaw = cap; cf.capKey = key_cap(cap); cf.capL = h->lim.link_monomials; cf.capT = h->lim.torque_monomials;
             cf.arena_bytes = TL.total; cf.arena = pool.ptr;
             cf.rb = h->robot; cf.pr = h->params; cf.ub = h->ub;
             cf.bez = h->d_bez;
@@ -2092,7 +2099,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             total_ms += ms;
             h->build_info[0] = ARMOUR_P1_KERNEL_TIME_VECTORISED; h->build_info[1] = nw_launch; h->build_info[2] = cap; h->build_info[3]++;
             if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each, rows of %d), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, gr, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
-            if (st[ST_ERR] == 0) built = true;
+            if (st[ST_ERR] == 0) { built = true; h->p1_tv_shape_hint = si; }
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape
         }
         // (pool_release, at the end of this scope: every launch above has been waited for)
@@ -2113,7 +2120,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     while (n_items > 0) {
         if ((rc = launch(cap_raw, d_items, n_items, false)) != ARMOUR_OK) return rc;
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
-            if (cap_raw < 16384) { cap_raw <<= 1; continue; }  // retry with larger LDS sort buffers
+            if (cap_raw < 16384) { cap_raw <<= 1; h->p1_step_cap_hint = cap_raw; continue; }  // retry with larger LDS sort buffers (and start there next time)
             armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
             return ARMOUR_ECAPACITY;
         }

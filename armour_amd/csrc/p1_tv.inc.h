@@ -599,12 +599,12 @@ __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t
 
 // LDS: NW x { sort buffers skey[cap] | sidx[cap] | status | staging rows for a product's short operand } | count table | mailbox
 __host__ __device__ inline size_t tv_lds_fixed(int cap_key, int cap_raw) { return ((size_t)cap_key * sizeof(pzkey_t) + (size_t)cap_raw * 2 + pzw::ST_WORDS * sizeof(int) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t tv_lds_fixed(int cap) { return tv_lds_fixed(cap, cap); }
+__host__ __device__ inline size_t tv_lds_fixed(int cap) { return tv_lds_fixed(key_cap(cap), cap); }   // (`cap` raw terms: p1_reach.hip key_cap)
 __host__ __device__ inline size_t tv_lds_wave(int cap, int stage_rows) { return tv_lds_fixed(cap) + (size_t)stage_rows * 64 * sizeof(double); }
 __host__ __device__ inline size_t tv_lds_shared() { return ((size_t)(kMaxSlots + kTvMbWords) * sizeof(int) + 15) & ~(size_t)15; }
 // sort buffers of the forward-kinematics wave of a four-wave block: its own products have <= 0.9 k raw terms; the omega recursion it also
 // carries has rotation x vector products, which are ranked (<= 4 runs over the vector's keys) and need room for the permutation only
-constexpr int kTvFkCap = 1024, kTvFkCapRaw = 2048;
+constexpr int kTvFkCap = key_cap(1024), kTvFkCapRaw = 2048;   // (128-bit keys: the same bytes, half the key entries -- so that four-wave blocks still fit the LDS; p1_reach.hip key_cap)
 __host__ __device__ inline size_t tv_lds_fixed_fk() { return tv_lds_fixed(kTvFkCap, kTvFkCapRaw); }
 __host__ __device__ inline size_t tv_lds_bytes(int cap, int stage_rows, int stage_rows_other, int nw) {
     const int nmain = nw == 4 ? 3 : nw;
@@ -639,17 +639,17 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
     // have a joint rotation (36 rows) as the short operand and which is the busiest role -- gets the larger staging area.
     const int my_stage = (NP == 1 || c.wid == 1) ? cf.tv_stage_rows : cf.tv_stage_rows_other;
     const bool fk_bufs = NP == 4 && c.wid == 3;
-    const int my_cap_key = fk_bufs ? kTvFkCap : cf.capKey, my_cap_raw = fk_bufs ? kTvFkCapRaw : cf.capKey;
+    const int my_cap_key = fk_bufs ? kTvFkCap : cf.capKey, my_cap_raw = fk_bufs ? kTvFkCapRaw : cf.capRaw;
     // waves 0..2: [sort buffers (cap) | status | staging]; wave 3 of a four-wave block: the same with the smaller buffers
     const int lw = min(c.wid, 3);   // (a helper wave has no buffers of its own: the address below is not used)
     const int stage_before = NP == 1 ? 0 : (lw > 0 ? cf.tv_stage_rows_other : 0) + (lw > 1 ? cf.tv_stage_rows : 0) + (lw > 2 ? cf.tv_stage_rows_other : 0);
-    LDS_AS unsigned char* mine = lds + (size_t)lw * tv_lds_fixed(cf.capKey) + (size_t)stage_before * 64 * sizeof(double);
+    LDS_AS unsigned char* mine = lds + (size_t)lw * tv_lds_fixed(cf.capRaw) + (size_t)stage_before * 64 * sizeof(double);
     c.w.w.skey = (LDS_AS pzkey_t*)mine;
     c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * sizeof(pzkey_t));
     c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * sizeof(pzkey_t) + (size_t)my_cap_raw * 2);
     c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap_key, my_cap_raw));
     c.w.stage_rows = my_stage;
-    LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capKey, cf.tv_stage_rows, cf.tv_stage_rows_other, NP) - tv_lds_shared();
+    LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capRaw, cf.tv_stage_rows, cf.tv_stage_rows_other, NP) - tv_lds_shared();
     c.w.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.w.cnt + kMaxSlots;
     c.w.w.cap_raw = my_cap_raw;

@@ -49,6 +49,17 @@ def fetch_robot(payload_mass_uncertainty=0.0):
     return r
 
 
+def fetch8_robot(payload_mass_uncertainty=0.0):
+    """"Fetch 8-DOF" of BASELINE configs[4]: the Fetch arm behind a torso yaw joint -- 9 links, 8 factors (include/armour_robot_fetch.h says what is
+    assumed; only the 128-bit-key library fills it: ARMOUR_KEY128=1).  payload_mass_uncertainty widens the last (gripper) link's intervals."""
+    r = ArmourRobot()
+    check(_lib.load().armour_robot_fetch8(C.byref(r)))
+    if payload_mass_uncertainty:
+        r.mass_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+        r.inertia_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+    return r
+
+
 def default_params(T=128):
     p = ArmourParams()
     _lib.load().armour_params_default(C.byref(p), T)

@@ -56,6 +56,17 @@ def random_fetch_problem(seed, num_obstacles):
                 obstacles=random_problem(seed, num_obstacles)["obstacles"])
 
 
+def random_fetch8_problem(seed, num_obstacles):
+    """One world for the 8-factor "Fetch 8-DOF" preset (include/armour_robot_fetch.h): the torso yaw inside its +-1 rad, the arm as
+    random_fetch_problem, `num_obstacles` random boxes."""
+    rng = np.random.default_rng(50_000 + seed)
+    p = random_fetch_problem(seed, num_obstacles)
+    q_t = rng.uniform(-0.7, 0.7)
+    return dict(q0=np.concatenate([[q_t], p["q0"]]), qd0=np.concatenate([[rng.uniform(-0.5, 0.5) * 0.5], p["qd0"]]),
+                qdd0=np.concatenate([[rng.uniform(-1, 1)], p["qdd0"]]), q_des=np.concatenate([[q_t + rng.uniform(-0.3, 0.3)], p["q_des"]]),
+                obstacles=p["obstacles"])
+
+
 def random_batch(first_seed, batch, num_obstacles):
     """`batch` worlds with seeds first_seed..first_seed+batch-1, stacked: q0 [B,7] ... obstacles [B,O,12]."""
     ps = [random_problem(first_seed + b, num_obstacles) for b in range(batch)]

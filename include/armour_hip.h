@@ -59,6 +59,10 @@ void armour_robot_kinova_gen3_gripper(ArmourRobot* robot);   /* RT/KinovaInfo.h:
 /* CMP/FetchInfo.h: 9 links (two fixed), 7 factors, joint axes {z,y,x,y,x,y,x}; link boxes and M_max are stand-ins
  * (include/armour_robot_fetch.h).  For payload-mass uncertainty set robot->mass_uncertainty_link[i] afterwards. */
 void armour_robot_fetch(ArmourRobot* robot);
+/* "Fetch 8-DOF" (BASELINE configs[4]): the arm above behind a torso yaw joint -- 9 links, 8 factors.  Filled by the 128-bit-key library only
+ * (libarmour_hip_k128.so, armour_abi_max_factors() == 8); the 64-bit-key library returns ARMOUR_EINVAL (its key holds seven factors, as the
+ * reference's: RT/PZsparse.h:8-21).  A derived preset, not reference data: include/armour_robot_fetch.h says what is assumed. */
+int armour_robot_fetch8(ArmourRobot* robot);
 void armour_params_default(ArmourParams* params, int32_t num_time_steps);
 
 /* ---- lifetime ---- */

@@ -69,4 +69,55 @@ static inline void armour_fill_fetch(ArmourRobot* r) {
     r->K = 5.0;
 }
 
+#if ARMOUR_MAX_FACTORS >= 8
+/*
+ * "Fetch 8-DOF" of BASELINE configs[4]: the arm above behind ONE MORE actuated joint -- eight trajectory parameters, 72 key bits: only in the
+ * 128-bit-key ABI (ARMOUR_MAX_FACTORS = 8; the reference's own key holds seven factors, RT/PZsparse.h:8-21, and cannot represent this robot).
+ * The Fetch's eighth degree of freedom is its torso LIFT, a prismatic joint; the reference's formulation has rotations only (RT/Dynamics.cu:69-81:
+ * every joint is a rotation about one of its frame's axes), so the eighth joint here is a torso YAW -- a revolute joint about the base z axis
+ * under the shoulder -- which loads the pipeline exactly as an eighth revolute joint does: one more factor in every monomial key, one more
+ * rotation in the forward kinematics of every link, one more step in both RNEA recursions.  NOT reference data (there is none): the torso link's
+ * mass / centre of mass / inertia are the Fetch URDF's torso_lift_link as recalled (10.78 kg), its limits and link box are stated stand-ins.
+ * Links: 0 torso (axis z) | 1..7 the arm's seven actuated links of armour_fill_fetch, frames unchanged relative to the base at torso angle 0 |
+ * 8 the fixed gripper link (FetchInfo.h's eighth link; its ninth -- a fixed 2.27 kg point mass in the same frame -- is dropped: 9 links is
+ * ARMOUR_MAX_JOINTS), the link whose mass / inertia uncertainty models the payload: mass_uncertainty_link[8].
+ */
+static inline void armour_fill_fetch8(ArmourRobot* r) {
+    ArmourRobot f;
+    armour_fill_fetch(&f);
+    memset(r, 0, sizeof(*r));
+    r->num_joints = 9;
+    r->num_factors = 8;
+    /* the torso */
+    r->axes[0] = 3;
+    r->mass[0] = 10.7796;
+    r->com[0] = -0.0013; r->com[1] = -0.0009; r->com[2] = 0.2935;
+    r->inertia[0] = 0.3354; r->inertia[2] = -0.0162; r->inertia[4] = 0.3354; r->inertia[5] = -0.0006; r->inertia[6] = -0.0162; r->inertia[7] = -0.0006; r->inertia[8] = 0.0954;
+    r->continuous[0] = 0;
+    r->state_limits_lb[0] = -1.0; r->state_limits_ub[0] = 1.0;
+    r->speed_limits[0] = 0.5;
+    r->torque_limits[0] = 150.0;
+    r->link_zonotope_center[2] = 0.363;                                                              /* a column between the base and the shoulder */
+    r->link_zonotope_generators[0] = 0.12; r->link_zonotope_generators[1] = 0.12; r->link_zonotope_generators[2] = 0.363;
+    /* links 1..8 = the arm's links 0..7; frame i + 1 of this chain = frame i of the arm (the torso frame coincides with the base) */
+    for (int i = 0; i < 8; i++) {
+        const int j = i + 1;
+        r->axes[j] = f.axes[i];
+        r->mass[j] = f.mass[i];
+        for (int e = 0; e < 3; e++) { r->trans[3 * j + e] = f.trans[3 * i + e]; r->com[3 * j + e] = f.com[3 * i + e]; r->rots[3 * j + e] = f.rots[3 * i + e]; }
+        for (int e = 0; e < 9; e++) r->inertia[9 * j + e] = f.inertia[9 * i + e];
+        for (int e = 0; e < 3; e++) { r->link_zonotope_center[3 * j + e] = f.link_zonotope_center[3 * i + e]; r->link_zonotope_generators[3 * j + e] = f.link_zonotope_generators[3 * i + e]; }
+        r->friction[j] = f.friction[i]; r->damping[j] = f.damping[i]; r->armature[j] = f.armature[i];
+    }
+    for (int e = 0; e < 3; e++) r->trans[3 * 9 + e] = f.trans[3 * 8 + e];
+    for (int i = 0; i < 7; i++) {
+        r->continuous[i + 1] = f.continuous[i];
+        r->state_limits_lb[i + 1] = f.state_limits_lb[i]; r->state_limits_ub[i + 1] = f.state_limits_ub[i];
+        r->speed_limits[i + 1] = f.speed_limits[i]; r->torque_limits[i + 1] = f.torque_limits[i];
+    }
+    r->mass_uncertainty = f.mass_uncertainty; r->inertia_uncertainty = f.inertia_uncertainty;
+    r->gravity = f.gravity; r->alpha = f.alpha; r->V_m = f.V_m; r->M_min = f.M_min; r->M_max = f.M_max; r->K = f.K;
+}
+#endif
+
 #endif

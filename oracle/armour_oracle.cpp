@@ -18,6 +18,7 @@
 #include <omp.h>
 
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -659,6 +660,42 @@ extern "C" {
 void oracle_fill_kinova(ArmourRobot* rb) { oracle_tables::fill_kinova_gen3_no_gripper(rb); }
 void oracle_fill_kinova_gripper(ArmourRobot* rb) { oracle_tables::fill_kinova_gen3_gripper(rb); }
 void oracle_fill_fetch(ArmourRobot* rb) { oracle_tables::fill_fetch(rb); }
+#if ARMOUR_MAX_FACTORS >= 8
+/* "Fetch 8-DOF": the Fetch arm (CMP/FetchInfo.h via the generated table) behind a torso yaw joint.  The derivation is restated here, not shared with
+ * the product's include/armour_robot_fetch.h (armour_fill_fetch8); tests/test_robot_constants.py holds the two byte for byte.  Stand-in values for
+ * the torso link: see that header -- the reference has no such robot (its key holds seven factors). */
+void oracle_fill_fetch8(ArmourRobot* r) {
+    ArmourRobot f;
+    oracle_tables::fill_fetch(&f);
+    std::memset(r, 0, sizeof(*r));
+    r->num_joints = 9; r->num_factors = 8;
+    const double torso_com[3] = {-0.0013, -0.0009, 0.2935};
+    const double torso_I[9] = {0.3354, 0, -0.0162, 0, 0.3354, -0.0006, -0.0162, -0.0006, 0.0954};
+    const double torso_box_c[3] = {0, 0, 0.363}, torso_box_g[3] = {0.12, 0.12, 0.363};
+    r->axes[0] = 3; r->mass[0] = 10.7796;
+    for (int e = 0; e < 3; e++) { r->com[e] = torso_com[e]; r->link_zonotope_center[e] = torso_box_c[e]; r->link_zonotope_generators[e] = torso_box_g[e]; }
+    for (int e = 0; e < 9; e++) r->inertia[e] = torso_I[e];
+    r->state_limits_lb[0] = -1.0; r->state_limits_ub[0] = 1.0; r->speed_limits[0] = 0.5; r->torque_limits[0] = 150.0;
+    for (int i = 0; i < 8; i++) {
+        const int j = i + 1;
+        r->axes[j] = f.axes[i]; r->mass[j] = f.mass[i];
+        r->friction[j] = f.friction[i]; r->damping[j] = f.damping[i]; r->armature[j] = f.armature[i];
+        for (int e = 0; e < 3; e++) {
+            r->trans[3 * j + e] = f.trans[3 * i + e]; r->rots[3 * j + e] = f.rots[3 * i + e]; r->com[3 * j + e] = f.com[3 * i + e];
+            r->link_zonotope_center[3 * j + e] = f.link_zonotope_center[3 * i + e]; r->link_zonotope_generators[3 * j + e] = f.link_zonotope_generators[3 * i + e];
+        }
+        for (int e = 0; e < 9; e++) r->inertia[9 * j + e] = f.inertia[9 * i + e];
+    }
+    for (int e = 0; e < 3; e++) r->trans[27 + e] = f.trans[24 + e];
+    for (int i = 0; i < 7; i++) {
+        r->continuous[i + 1] = f.continuous[i];
+        r->state_limits_lb[i + 1] = f.state_limits_lb[i]; r->state_limits_ub[i + 1] = f.state_limits_ub[i];
+        r->speed_limits[i + 1] = f.speed_limits[i]; r->torque_limits[i + 1] = f.torque_limits[i];
+    }
+    r->mass_uncertainty = f.mass_uncertainty; r->inertia_uncertainty = f.inertia_uncertainty;
+    r->gravity = f.gravity; r->alpha = f.alpha; r->V_m = f.V_m; r->M_min = f.M_min; r->M_max = f.M_max; r->K = f.K;
+}
+#endif
 void oracle_fill_default_params(ArmourParams* pr, int T) { oracle_tables::fill_default_params(pr, T); }
 
 /* The scalar Bezier helpers on their own (tests/test_ref_bezier.py checks them against the REFERENCE's functions compiled

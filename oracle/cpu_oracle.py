@@ -123,6 +123,16 @@ def fetch_robot(payload_mass_uncertainty=0.0):
     return r
 
 
+def fetch8_robot(payload_mass_uncertainty=0.0):
+    """The oracle's own derivation of the "Fetch 8-DOF" preset (armour_oracle.cpp: oracle_fill_fetch8; 128-bit-key build only)."""
+    r = ArmourRobot()
+    lib().oracle_fill_fetch8(C.byref(r))
+    if payload_mass_uncertainty:
+        r.mass_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+        r.inertia_uncertainty_link[r.num_joints - 1] = payload_mass_uncertainty
+    return r
+
+
 def default_params(T=128):
     p = ArmourParams()
     lib().oracle_fill_default_params(C.byref(p), T)

@@ -113,6 +113,62 @@ def _body():
     print("key128 ok", flush=True)
 
 
+def _body_fetch8():
+    """(runs with ARMOUR_KEY128=1)  BASELINE configs[4] as it reads -- "Fetch 8-DOF arm with payload-mass uncertainty, 100 obstacles": the Fetch arm
+    behind a torso yaw joint (include/armour_robot_fetch.h: 9 links, 8 factors, mixed axes), +-50 % mass / inertia on the gripper link, O = 100,
+    T = 100, m = 8 T + 9 T O + 32 = 90 832 rows.  Both reach-set kernels and the fused evaluation against the 128-bit oracle."""
+    sys.path.insert(0, ROOT)
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP, default_params, fetch8_robot
+    from armour_amd.worlds import random_fetch8_problem
+    from oracle import cpu_oracle as orc
+    T, O, n, J = 100, 100, 8, 9
+    p = random_fetch8_problem(11, O)
+    def params(mod):
+        pr = mod(T)
+        pr.k_range[7] = pr.k_range[6]
+        return pr
+    oracle = orc.Oracle(robot=orc.fetch8_robot(0.5), params=params(orc.default_params)).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert oracle.min_margin() > 1e-9
+    k = np.random.default_rng(3).uniform(-1, 1, n)
+    g_ref, jac_ref = oracle.eval_g_jac(k)
+    m = n * T + J * T * O + 4 * n
+    assert g_ref.shape == (m,)
+    built = {}
+    for name, build, B in (("per_step", 1, 1), ("time_vectorised", 2, 3)):
+        nlp = ArmourNLP(robot=fetch8_robot(0.5), params=params(default_params))
+        nlp.set_option(_lib.OPT_P1_BUILD, build)
+        rep = lambda a: np.repeat(np.asarray(a)[None], B, axis=0)
+        for _ in range(2):
+            nlp.set_parameters(rep(p["q0"]), rep(p["qd0"]), rep(p["qdd0"]), rep(p["q_des"]), rep(p["obstacles"]))
+        info = nlp.build_info()
+        assert info["kernel"] == name and info["waves"] >= 3, info   # (multi-wave blocks: half the key entries in the same LDS bytes, p1_reach.hip key_cap)
+        assert (nlp.n, nlp.J, nlp.m) == (n, J, m)
+        b = B - 1
+        assert np.abs(nlp.torque_radius()[b] - oracle.torque_radius()).max() <= 1e-10
+        assert np.abs(nlp.link_generators()[b] - oracle.link_generators()).max() <= 1e-10
+        tabs = []
+        for which, cnt in (("link", J), ("torque", n)):
+            for i in range(cnt):
+                for t in range(0, T, 9):
+                    c1, r1, k1, co1 = nlp.pz(which, i, t, b=b)
+                    c2, r2, k2, co2 = oracle.pz(which, i, t)
+                    assert np.array_equal(k1, k2), (name, which, i, t, len(k1), len(k2))
+                    assert np.abs(co1 - co2).max(initial=0.0) <= 1e-12 and np.abs(c1 - c2).max() <= 1e-12 and np.abs(r1 - r2).max() <= 1e-10
+                    tabs.append((c1, r1, k1, co1))
+        g, jac = nlp.eval_g_jac(rep(k))
+        dg, dj = np.abs(g[b] - g_ref).max(), np.abs(jac[b] - jac_ref).max()
+        assert dg <= 1e-9 and dj <= 1e-8, (name, dg, dj)
+        print(f"fetch8 {name}: {info}, build {nlp.build_ms:.2f} ms ({B} problem(s)), |dg| {dg:.2e} |djac| {dj:.2e}, table sizes {nlp.table_sizes()}", flush=True)
+        if name == "per_step":
+            assert nlp.build_ms <= 2.0, nlp.build_ms   # (round 4's verdict: one-wave blocks took 7.2 ms for one 8-factor problem)
+        built[name] = tabs
+        nlp.close()
+    for (c1, r1, k1, co1), (c2, r2, k2, co2) in zip(built["per_step"], built["time_vectorised"]):
+        assert np.array_equal(k1, k2) and np.array_equal(co1, co2) and np.array_equal(c1, c2) and np.abs(r1 - r2).max() <= 1e-12
+    print("fetch8 ok", flush=True)
+
+
 def _run(code):
     env = dict(os.environ, ARMOUR_KEY128="1")
     env.pop("ARMOUR_HIP_LIB", None)
@@ -124,6 +180,31 @@ def test_eight_factor_arm_with_128_bit_keys_matches_the_oracle():
     r = _run("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_key128 as t; t._body()" % (ROOT, os.path.join(ROOT, "tests")))
     assert r.returncode == 0 and "key128 ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     print(r.stdout)
+
+
+@pytest.mark.gpu
+def test_fetch_8dof_payload_100_obstacles_matches_the_oracle():
+    r = _run("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_key128 as t; t._body_fetch8()" % (ROOT, os.path.join(ROOT, "tests")))
+    assert r.returncode == 0 and "fetch8 ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    print(r.stdout)
+
+
+def test_fetch8_preset_is_the_same_in_product_and_oracle():
+    """CPU: the "Fetch 8-DOF" preset is derived twice -- include/armour_robot_fetch.h (armour_fill_fetch8) and oracle/armour_oracle.cpp
+    (oracle_fill_fetch8, from the oracle's own table of CMP/FetchInfo.h) -- and must agree byte for byte; the 64-bit-key library refuses it."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import ctypes as C\n"
+            "from armour_amd import planner\n"
+            "from oracle import cpu_oracle as orc\n"
+            "a, b = planner.fetch8_robot(0.5), orc.fetch8_robot(0.5)\n"
+            "assert C.sizeof(a) == C.sizeof(b) and bytes(a) == bytes(b)\n"
+            "assert (a.num_joints, a.num_factors, list(a.axes)) == (9, 8, [3, 3, 2, 1, 2, 1, 2, 1, 0]) and a.mass_uncertainty_link[8] == 0.5\n"
+            "print('preset ok')\n") % ROOT
+    r = _run(code)
+    assert r.returncode == 0 and "preset ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    from armour_amd import _lib, planner
+    with pytest.raises(_lib.ArmourError):
+        planner.fetch8_robot()
 
 
 def test_key128_libraries_load_and_export_the_abi():
