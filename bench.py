@@ -249,7 +249,7 @@ class Timed:
         self.torch, self.nlp, self.dev, self.K, self.W, self.use_dist = torch, nlp, dev, K, W, use_dist
         self.red_dev = (dev if use_dist else None) if red_dev == "same" else red_dev
         B, n, m = nlp.B, nlp.n, nlp.m
-        self.ks = torch.tensor(random_k(seed, (K + W) * B).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
+        self.ks = torch.tensor(random_k(seed, (K + W) * B, n=n).reshape(K + W, B, n), device=dev)  # a fresh k per step and problem
         self.d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
         self.d_jac = torch.empty((B, m, n), device=dev, dtype=torch.float64)
         self.stream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: HIP events on the null stream do not bracket the launches
@@ -398,6 +398,70 @@ def fetch_config(device, dev, T, K, R, check):
     return out
 
 
+def fetch8_child(args):
+    """BASELINE configs[4] as it reads -- "Fetch 8-DOF arm with payload-mass uncertainty, 100 obstacles" (never `value`): the Fetch arm behind a torso
+    yaw joint (include/armour_robot_fetch.h: 9 links, 8 factors), +-50 % mass / inertia on the gripper link, one planning problem, O = 100, T = 100.
+    Eight factors need the 128-bit-key ABI (the reference's key holds seven: RT/PZsparse.h:8-21), which is chosen per process: this function is the
+    body of a CHILD process started with ARMOUR_KEY128=1 (libarmour_hip_k128.so / liboracle_k128.so); it prints one JSON object."""
+    import numpy as np
+    import torch
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP, default_params, fetch8_robot
+    from armour_amd.worlds import random_fetch8_problem
+    assert _lib.MAXF == 8, "fetch8_child runs with ARMOUR_KEY128=1"
+    T, O, K, R = args.time_steps, 100, max(20, min(args.steps, 40)), max(1, args.repeats)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    p = random_fetch8_problem(11, O)
+
+    def params(mod):
+        pr = mod(T)
+        pr.k_range[7] = pr.k_range[6]
+        return pr
+    nlp = _opts(ArmourNLP(robot=fetch8_robot(0.5), params=params(default_params), device=0))
+    ms = []
+    for _ in range(4):
+        nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        ms.append(nlp.build_ms)
+    tm = Timed(nlp, dev, 311, K, 4, False)
+    wall, ev = tm.run(R)
+    spot = None
+    if not args.no_check:
+        from oracle import cpu_oracle as orc
+        o = orc.Oracle(robot=orc.fetch8_robot(0.5), params=params(orc.default_params)).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+        k_last = tm.ks[-1].cpu().numpy()
+        g_ref, jac_ref = o.eval_g_jac(k_last[0])
+        dg = float(np.abs(tm.d_g.cpu().numpy()[0] - g_ref).max())
+        dj = float(np.abs(tm.d_jac.cpu().numpy()[0] - jac_ref).max())
+        assert dg <= 1e-9 and dj <= 1e-8, (dg, dj)
+        spot = {"max_abs_dg": dg, "max_abs_djac": dj, "oracle_build_ms": o.build_ms, "oracle_pair_products": int(o.stats()["mul_pairs"])}
+    out = summarise(nlp, wall, ev, K, 1, {"robot": "fetch 8-DOF: torso yaw + the 7 arm joints of CMP/FetchInfo.h + gripper link with +-50 % mass / inertia (include/armour_robot_fetch.h)",
+                                          "key_bits": 128, "links": nlp.J, "factors": nlp.n, "obstacles": O, "constraints_m": nlp.m,
+                                          "p1_set_problems_ms": min(ms[1:]), "p1_kernel": nlp.build_info(), "oracle_spot_check": spot,
+                                          "table_sizes": nlp.table_sizes()}, traffic_name="configs4_8factor")
+    nlp.close()
+    print("FETCH8_JSON " + json.dumps(out), flush=True)
+
+
+def fetch8_config(args):
+    """Parent side: run fetch8_child in a process of its own (the ABI is per process) and return its JSON, or the reason there is none."""
+    env = dict(os.environ, ARMOUR_KEY128="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ARMOUR_HIP_LIB"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--fetch8-child", "--steps", str(args.steps), "--repeats", str(args.repeats), "--time-steps", str(args.time_steps)]
+    cmd += ["--no-check"] if (args.no_check or args.no_sync_probe) else []
+    for opt, val in OPTIONS:
+        cmd += ["--set-option", f"{opt}={val}"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        for line in r.stdout.splitlines():
+            if line.startswith("FETCH8_JSON "):
+                return json.loads(line[len("FETCH8_JSON "):])
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as e:   # (the headline must not depend on this extra)
+        return {"error": repr(e)}
+
+
 # ----------------------------------------------------------------------------------------------- dry run (CPU, gloo)
 def dry_run(args, rank, world):
     """Development / test mode: the launcher, the rendezvous (gloo) and the timing reduction of the real run with the GPU
@@ -448,6 +512,7 @@ def main():
                          "kernel to the trace), i.e. skip the host-entry check and the sync-latency probe")
     ap.add_argument("--set-option", action="append", default=[], metavar="ID=VALUE", help="development: armour_set_option on every handle (A/B runs)")
     ap.add_argument("--dry-run", action="store_true", help="development / tests: launcher + rendezvous + reduction on CPU (gloo), no GPU work")
+    ap.add_argument("--fetch8-child", action="store_true", help="internal: the body of the configs[4] 8-factor measurement (a process with ARMOUR_KEY128=1)")
     ap.add_argument("--rank-devices", default="", metavar="D0,D1,...", help="development / tests: device ordinal of every rank (default: rank r on device r); "
                     "several ranks on one device need --dist-backend gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the barrier and the MAX reduction (nccl = RCCL)")
@@ -455,6 +520,8 @@ def main():
     for kv in args.set_option:
         OPTIONS.append((int(kv.split("=")[0]), float(kv.split("=")[1])))
 
+    if args.fetch8_child:
+        return fetch8_child(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # the parent: no torch, no HIP
 
@@ -626,7 +693,8 @@ def main():
         chk = None if args.no_check or args.no_sync_probe else True
         if world == 1:
             oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk, red_dev),
-                  "configs[4]: Fetch, payload +-50 %, O=100, batch 1, T=100": fetch_config(local_rank, dev, T, max(KX, 20), R, chk is not None)}
+                  "configs[4]: Fetch, payload +-50 %, O=100, batch 1, T=100": fetch_config(local_rank, dev, T, max(KX, 20), R, chk is not None),
+                  "configs[4] 8-factor: Fetch 8-DOF (torso yaw + arm), payload +-50 %, O=100, batch 1, T=100, 128-bit keys": fetch8_config(args)}
         else:
             oc = {f"configs[3]: O=20, batch 128 per GPU ({128 * world} worlds over {world} GPUs), T=100":
                   extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False, red_dev)}
