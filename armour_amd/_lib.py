@@ -95,6 +95,7 @@ OPT_P1_TV_ROW_WIDTH = 122   # 0 automatic | 50 | 64 doubles per row of the time-
 OPT_P2_EX = 130
 OPT_STEPS_GRAPH_MIN = 131
 OPT_PINNED_MODE = 132
+OPT_CULL_ROWS = 133   # 1: armour_eval_violations* evaluate only the rows that can be violated for some k (armour_get_row_relevance)
 OPT_SOLVE_SUB_TILES = 140
 OPT_SOLVE_DEVICE = 141
 OPT_SOLVE_CUT_TILES = 142
@@ -113,7 +114,7 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations",
+    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
     "armour_batch_get_build_ms", "armour_batch_get_build_info",
@@ -217,6 +218,7 @@ def load():
     L.armour_controller_set_kernel.argtypes = [C.c_int32]
     L.armour_eval_violations_device.argtypes = [vp, vp, vp, vp]
     L.armour_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
+    L.armour_get_row_relevance.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.armour_batch_partition.argtypes = [C.c_int32, C.c_int32, ip]
     L.armour_batch_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams), C.POINTER(ArmourLimits), ip, C.c_int32, C.POINTER(vp)]
     L.armour_batch_destroy.argtypes = [vp]

@@ -163,7 +163,7 @@ const TuningSpec kTuning[] = {
     {ARMOUR_OPT_P1_TV_MIN_GROUPS, 31, 1, 1e6}, {ARMOUR_OPT_P1_TV_WAVES, 0, 0, 8}, {ARMOUR_OPT_P1_TV_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_TV_SPLIT_FK, -1, -1, 1},
     {ARMOUR_OPT_P1_TV_DEDICATED, 1, 0, 1}, {ARMOUR_OPT_P1_TV_HELP_SHIFT, 0, 0, 3}, {ARMOUR_OPT_P1_TV_HELPERS, 1, 0, 31}, {ARMOUR_OPT_P1_TV_HELP_MIN, 192, 1, 1e6},
     {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_TV_ROW_WIDTH, 0, 0, 64}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},
-    {ARMOUR_OPT_P2_EX, 1, 0, 1}, {ARMOUR_OPT_STEPS_GRAPH_MIN, 2, 0, 1e6}, {ARMOUR_OPT_PINNED_MODE, 0, 0, 2},
+    {ARMOUR_OPT_P2_EX, 1, 0, 1}, {ARMOUR_OPT_STEPS_GRAPH_MIN, 2, 0, 1e6}, {ARMOUR_OPT_PINNED_MODE, 0, 0, 2}, {ARMOUR_OPT_CULL_ROWS, 0, 0, 1},
     {ARMOUR_OPT_SOLVE_SUB_TILES, 48, 1, 1e6}, {ARMOUR_OPT_SOLVE_DEVICE, 1, 0, 2}, {ARMOUR_OPT_SOLVE_CUT_TILES, 156, 1, 1e6}, {ARMOUR_OPT_SOLVE_BLOCKS, 0, 0, 1e6},
     {ARMOUR_OPT_SOLVE_SUB_BATCH, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_ROW_CAP, 0, 0, 1e7}, {ARMOUR_OPT_SOLVE_HARD_CAP_S, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_WAVES_PER_SIMD, 0, 0, 2},
 };
@@ -251,6 +251,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     drop_step_graphs(h);
     for (int i = 0; i < 9; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds); dev_free(&h->d_viol);
+    armour_relevance_free(h);
     dev_free(&h->solve_dev.ctl); dev_free(&h->solve_dev.blk_word); dev_free(&h->solve_dev.blk_rows); dev_free(&h->solve_dev.qp_rows);
     dev_free(&h->solve_dev.flags);
     dev_free(&h->d_jrs);
@@ -280,6 +281,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     }
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
+    h->rel_fresh = false;
     h->bounds_on_device = false;
     h->stats_fresh = false;
     drop_step_graphs(h);  // they bake in the tables of the previous problem set
@@ -835,6 +837,7 @@ extern "C" int armour_eval_violations_device(ArmourPlanner* h, const double* d_k
     int rc = armour_upload_bounds(h);
     if (rc != ARMOUR_OK) return rc;
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (h->tune(ARMOUR_OPT_CULL_ROWS)) return armour_eval_violations_culled(h, d_k, d_out, st);   // the relevant rows only: relevance.hip
     const P2Tables tb = armour_make_tables(h);
     // g only (the Jacobian tile, 7/8 of the output bytes, is neither computed nor written), into the handle's own g buffer
     rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, h->d_g, nullptr, st);

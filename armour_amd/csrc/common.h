@@ -142,6 +142,18 @@ struct ArmourPlanner {
     int tune(int option) const { return (int)tuning[option - ARMOUR_OPT_FIRST_TUNING]; }
     double tune_f(int option) const { return tuning[option - ARMOUR_OPT_FIRST_TUNING]; }
     ArmourViolation* d_viol = nullptr; size_t viol_cap = 0;   // [B] records of armour_eval_violations
+    // row relevance of the current problem set (relevance.hip): the mask [B][m], the relevant collision rows of every problem in ascending
+    // order [B][Q] and their counts; built on first use (armour_get_row_relevance, the culled armour_eval_violations)
+    unsigned char* d_rel = nullptr; size_t rel_cap = 0;
+    int* d_rel_rows = nullptr; size_t rel_rows_cap = 0;
+    int* d_rel_count = nullptr; size_t rel_count_cap = 0;
+    double* d_rel_packed = nullptr; size_t rel_packed_cap = 0;       // the listed rows' plane entries, packed (relevance.hip)
+    long long* d_rel_pack_off = nullptr; size_t rel_pack_off_cap = 0;   // [B][2]: offset and row stride of every problem's block, in doubles
+    int* d_rel_rows_res = nullptr; size_t rel_rows_res_cap = 0;   // the same rows by (row index mod 256): what the culled row test iterates
+    std::vector<int> h_rel_count;
+    bool rel_fresh = false;
+    double rel_ms = 0;
+    int rel_max_count = 0;
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
     bool bounds_on_device = false;
@@ -199,7 +211,11 @@ bool armour_trace_solve();   // ARMOUR_SOLVE_TIMING
 
 // p2_eval.hip
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,
-                     int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0);
+                     int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0, bool skip_collision_blocks = false);
+// relevance.hip
+int armour_relevance_build(ArmourPlanner* h);
+void armour_relevance_free(ArmourPlanner* h);
+int armour_eval_violations_culled(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, hipStream_t st);
 int armour_refresh_table_stats(ArmourPlanner* h);
 // collision rows the feasibility re-check looks at (all Q in ARMOUR mode; the first (n-1)*T*O in ARMTD mode, CMP/NLPclass.cu:391-402)
 int armour_checked_collision_rows(const ArmourPlanner* h);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(P2_WPE
     //  (problem, row block) pairs so that neighbouring blocks, which share their (link, time step) records, share an L2 -- configs[2]
     //  539 us against 500: what a block streams is 30 KB of its own rows and 3 KB of shared records, and eight XCDs that each walk one
     //  contiguous stretch of the table concentrate on fewer HBM channels at a time, like the tiled table layout of round 2.)
-    const int b = blockIdx.y, role = blockIdx.x;
+    const int b = blockIdx.y, role = blockIdx.x + lp.role0;
     const int n = tb.n, m = tb.m;   // (read together: one scalar load of the kernel argument block instead of two dependent ones)
     const double* k0 = k_all + (size_t)b * n;
     double* g0 = WANT_G ? g_all + (size_t)b * m : nullptr;
@@ -101,6 +101,7 @@ bool armour_p2_ex_layout_ok(unsigned long long skip) {
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out) {
     P2Launch lp;
+    lp.role0 = 0;
     lp.nbc = (tb.Q + P2_ROWS - 1) / P2_ROWS;
     lp.nbt = tb.row0 == 0 ? 0 : (tb.n * tb.T + P2_TQ_ROWS - 1) / P2_TQ_ROWS;  // no torque rows in ARMTD mode and with TURN_OFF_INPUT_CONSTRAINTS (row0 = 0: the collision rows come first)
     lp.max_pairs = tb.O > 0 ? (P2_ROWS - 1) / tb.O + 2 : 1;
@@ -131,14 +132,15 @@ int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsig
 }
 
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac,
-                     hipStream_t stream, int steps, long long k_stride, long long g_stride, long long j_stride) {
+                     hipStream_t stream, int steps, long long k_stride, long long g_stride, long long j_stride, bool skip_collision_blocks) {
     if (!d_g && !d_jac) return ARMOUR_OK;
     P2Launch lp;
     size_t smem = 0;
     bool dfc, six, exact;
     const int rc = armour_p2_plan(tb, max_link, max_torque, h_skip, steps, k_stride, g_stride, j_stride, &lp, &smem, &dfc, &six, &exact);
     if (rc != ARMOUR_OK) return rc;
-    dim3 grid(lp.nbc + lp.nbt + 1, tb.B), block(P2_BLOCK);
+    if (skip_collision_blocks) lp.role0 = lp.nbc;   // the torque blocks and the limit block only
+    dim3 grid(lp.nbc + lp.nbt + 1 - lp.role0, tb.B), block(P2_BLOCK);
 #define P2_LAUNCH_M(G, J, M)                                                                                                                      \
     do {                                                                                                                                          \
         if (dfc && exact && !(M)) hipLaunchKernelGGL((armour_p2_eval_kernel<G, J, false, true, true, 6, true>), grid, block, smem, stream, tb, d_k, d_g, d_jac, lp);      \

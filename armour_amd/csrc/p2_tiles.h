@@ -126,6 +126,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct P2Launch {
     int nbc, nbt;       // collision / torque block counts
+    int role0;          // first block role of the launch: 0, or nbc for a launch without the collision blocks (relevance.hip: the culled row test)
     int max_pairs;      // (l,t) pairs a collision block can touch
     int strideL;        // monomial stride of the LDS term buffer for link PZs (>= max link count)
     int strideT;        // same for torque PZs

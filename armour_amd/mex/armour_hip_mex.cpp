@@ -16,6 +16,8 @@
 //   [g, jac]             = armour_hip_mex('eval', k)               g: m x 1, jac: n x m (gradient of row i in column i)
 //   [h, heq, grad_h, grad_heq] = armour_hip_mex('constraints', k)  the fmincon `nonlcon` shape of KSI/uarmtd_planner.m:776-796:
 //                    h <= 0 feasible, grad_h n x numel(h); rows g - g_u first, then g_l - g of the two-sided rows
+//   [h, heq, grad_h, grad_heq] = armour_hip_mex('constraints', k, 'pruned')   the same with the rows that can be violated for some k only: the pruned
+//                    list of KSI/uarmtd_planner.m:577-583,628-690, computed on the device (armour_get_row_relevance); rel = armour_hip_mex('relevance')
 //   [x_l, x_u, g_l, g_u] = armour_hip_mex('bounds')
 //   [f, grad_f]          = armour_hip_mex('cost', k)
 //   [k_opt, feasible, info] = armour_hip_mex('solve')              info = [cost; iterations; evaluations; status; ms]
@@ -188,34 +190,49 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         chk(armour_eval_g_jac(g_h, mxGetPr(prhs[1]), mxGetPr(plhs[0]), mxGetPr(jac)));
         if (nlhs > 1) plhs[1] = jac; else mxDestroyArray(jac);
     } else if (!strcmp(cmd, "constraints")) {
-        need(nrhs == 2 && (int)mxGetNumberOfElements(prhs[1]) == n, "constraints needs k (n x 1)");
+        need((nrhs == 2 || nrhs == 3) && (int)mxGetNumberOfElements(prhs[1]) == n, "constraints needs k (n x 1) [, 'pruned']");
+        // ('constraints', k, 'pruned'): only the rows that can be violated for some k -- the list KSI/uarmtd_planner.m:577-583,628-690 builds by hand
+        // (armour_get_row_relevance; the same rows at every k of a problem, so fmincon sees a fixed constraint count)
+        bool pruned = false;
+        if (nrhs == 3) { char opt[16] = ""; need(!mxGetString(prhs[2], opt, sizeof(opt)) && !strcmp(opt, "pruned"), "the only option of constraints is 'pruned'"); pruned = true; }
+        unsigned char* keep = nullptr;
+        if (pruned) { keep = (unsigned char*)mxMalloc((size_t)m); chk(armour_get_row_relevance(g_h, keep, nullptr, nullptr)); }
         mxArray* g = col(m);
         mxArray* jac = mxCreateNumericMatrix(n, m, mxDOUBLE_CLASS, mxREAL);
         mxArray* b[4] = {col(n), col(n), col(m), col(m)};
         chk(armour_eval_g_jac(g_h, mxGetPr(prhs[1]), mxGetPr(g), mxGetPr(jac)));
         chk(armour_get_bounds(g_h, mxGetPr(b[0]), mxGetPr(b[1]), mxGetPr(b[2]), mxGetPr(b[3])));
         const double *gv = mxGetPr(g), *jv = mxGetPr(jac), *gl = mxGetPr(b[2]), *gu = mxGetPr(b[3]);
-        int two = 0;
-        for (int i = 0; i < m; i++) two += gl[i] > -1e18;  // collision rows are one-sided (g_l = -1e19, RT/NLPclass.cu:131-140)
-        mxArray* h = col(m + two);
-        mxArray* gh = mxCreateNumericMatrix(n, m + two, mxDOUBLE_CLASS, mxREAL);
+        int two = 0, kept = 0;
+        for (int i = 0; i < m; i++) { if (keep && !keep[i]) continue; kept++; two += gl[i] > -1e18; }  // collision rows are one-sided (g_l = -1e19, RT/NLPclass.cu:131-140)
+        mxArray* h = col(kept + two);
+        mxArray* gh = mxCreateNumericMatrix(n, kept + two, mxDOUBLE_CLASS, mxREAL);
         double *hv = mxGetPr(h), *ghv = mxGetPr(gh);
-        int r = m;
-        for (int i = 0; i < m; i++) {
-            hv[i] = gv[i] - gu[i];
-            for (int j = 0; j < n; j++) ghv[(size_t)i * n + j] = jv[(size_t)i * n + j];
-            if (gl[i] > -1e18) {
-                hv[r] = gl[i] - gv[i];
-                for (int j = 0; j < n; j++) ghv[(size_t)r * n + j] = -jv[(size_t)i * n + j];
+        int r = kept, u = 0;
+        for (int i0 = 0; i0 < m; i0++) {
+            if (keep && !keep[i0]) continue;
+            const int i = u++;   // position among the kept rows; i0: the row of g
+            hv[i] = gv[i0] - gu[i0];
+            for (int j = 0; j < n; j++) ghv[(size_t)i * n + j] = jv[(size_t)i0 * n + j];
+            if (gl[i0] > -1e18) {
+                hv[r] = gl[i0] - gv[i0];
+                for (int j = 0; j < n; j++) ghv[(size_t)r * n + j] = -jv[(size_t)i0 * n + j];
                 r++;
             }
         }
+        if (keep) mxFree(keep);
         mxDestroyArray(g); mxDestroyArray(jac);
         for (int i = 0; i < 4; i++) mxDestroyArray(b[i]);
         plhs[0] = h;
         if (nlhs > 1) plhs[1] = mxCreateDoubleMatrix(0, 0, mxREAL);   // heq = []
         if (nlhs > 2) plhs[2] = gh; else mxDestroyArray(gh);
         if (nlhs > 3) plhs[3] = mxCreateDoubleMatrix(n, 0, mxREAL);   // grad_heq: n x 0
+    } else if (!strcmp(cmd, "relevance")) {   // rel = armour_hip_mex('relevance'): m x 1, 1 = the row can be violated for some k (armour_get_row_relevance)
+        unsigned char* keep = (unsigned char*)mxMalloc((size_t)m);
+        chk(armour_get_row_relevance(g_h, keep, nullptr, nullptr));
+        plhs[0] = col(m);
+        for (int i = 0; i < m; i++) mxGetPr(plhs[0])[i] = keep[i] ? 1.0 : 0.0;
+        mxFree(keep);
     } else if (!strcmp(cmd, "bounds")) {
         mxArray* o[4] = {col(n), col(n), col(m), col(m)};
         chk(armour_get_bounds(g_h, mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3])));

@@ -400,6 +400,15 @@ class ArmourNLP:
         check(self.L.armour_eval_violations(self.h, _dp(self._k(x)), out))
         return [_violation_dict(v) for v in out]
 
+    def row_relevance(self):
+        """(relevant [B, m] bool, relevant collision rows per problem [B], device ms of the test) -- armour_get_row_relevance: the pruned
+        constraint list of KSI/uarmtd_planner.m:577-583,628-690 (a row marked False cannot be violated for any k in [-1, 1]^n)."""
+        rel = np.zeros((self.B, self.m), dtype=np.uint8)
+        cnt = np.zeros(self.B, dtype=np.int32)
+        ms = C.c_double()
+        check(self.L.armour_get_row_relevance(self.h, rel.ctypes.data_as(C.POINTER(C.c_uint8)), cnt.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)))
+        return rel.astype(bool), cnt, ms.value
+
     def eval_violations_device(self, d_k, d_out, stream=0):
         """Asynchronous: d_k [B][n] doubles, d_out [B] ArmourViolation records (32 B each), device pointers (ints)."""
         check(self.L.armour_eval_violations_device(self.h, d_k, d_out, stream))

@@ -141,6 +141,7 @@ void armour_free_pinned(void* p);
 /* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
 #define ARMOUR_OPT_P2_EX 130                  /* 1 (default) | 0: the fixed-load-count kernels for problems with exactly 24 live planes */
 #define ARMOUR_OPT_STEPS_GRAPH_MIN 131        /* default 2: armour_eval_g_jac_device_steps submits >= this many steps as one graph; 0 never */
+#define ARMOUR_OPT_CULL_ROWS 133              /* 0 (default) | 1: armour_eval_violations* evaluate the rows that can be violated for some k only (armour_get_row_relevance): same L1 violation, counts and verdict bit for bit; `worst` is the full evaluation's whenever a row is violated */
 #define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
 /* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
 #define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */
@@ -244,6 +245,15 @@ typedef struct ArmourViolation {
 int armour_eval_violations_device(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream);
 /* host pointers, synchronous: 56 B in and 32 B out per problem instead of 8 m (1 + n) bytes */
 int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourViolation* out);
+/* Row relevance of the current problem set -- the pruned constraint list of the reference's MATLAB path (KSI/uarmtd_planner.m:577-583: an
+ * obstacle constraint is kept only if the forward occupancy can reach the buffered obstacle; :628-690: an input / limit constraint only if
+ * `~(interval(...).sup < 0)`), which its C++ path does not have (RT/NLPclass.cu:272-396 evaluates every row at every iterate).
+ * relevant[B][m] (row order of armour_eval_g_jac): 0 = the row cannot be violated for ANY k in [-1,1]^n -- a plane of its buffered obstacle
+ * separates the whole family of sliced link centres (collision rows), the sliced torque's interval stays inside the bounds (torque rows) --
+ * 1 otherwise; the 4n joint-limit rows are always 1.  Sound (a 0 is never violated: 1e-9 margin on the test), not tight.  On random worlds
+ * about 2 % of the collision rows are 1.  n_relevant_collision_rows [B] and ms (device time of the test) may be NULL; so may `relevant`.
+ * Computed once per problem set, on the device (relevance.hip).  ARMOUR_OPT_CULL_ROWS = 1 makes armour_eval_violations* use it. */
+int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int32_t* n_relevant_collision_rows, double* ms);
 
 /* ---- in-process multi-device batch ---- */
 /* One caller thread (MATLAB / MEX, a Python host) drives several GPUs: an ArmourBatch owns one ArmourPlanner per entry of `devices`

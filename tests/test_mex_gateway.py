@@ -127,6 +127,14 @@ def test_every_command_against_the_ctypes_binding(mexlib, sample_problem):
     h, heq, grad_h, grad_heq = mex(4, "constraints", k)
     rh, rheq, rgh, rgheq = nlp.eval_constraint(k)
     assert np.array_equal(h[:, 0], rh) and np.array_equal(grad_h, rgh) and heq.size == 0 and grad_heq.shape == (n, 0)
+    # ... and with the pruned list (KSI/uarmtd_planner.m:577-583,628-690: only rows that can be violated for some k): the kept rows of the full list
+    rel = mex(1, "relevance")[0][:, 0].astype(bool)
+    rrel, _, _ = nlp.row_relevance()
+    assert np.array_equal(rel, rrel[0]) and rel[-4 * n:].all() and rel.sum() < 0.5 * m
+    hp, _, ghp, _ = mex(4, "constraints", k, "pruned")
+    two = rgl[0] > -1e18                                  # rows with a lower bound come a second time, behind the m upper-bound rows
+    keep = np.concatenate([rel, rel[two]])
+    assert np.array_equal(hp[:, 0], rh[keep]) and np.array_equal(ghp, rgh[:, keep])
     # whole NLP
     k_opt, feas, info = mex(3, "solve")
     sol = nlp.solve()[0]

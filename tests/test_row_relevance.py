@@ -1,0 +1,63 @@
+"""Device-side row relevance -- the pruned constraint list of the reference's MATLAB path (KSI/uarmtd_planner.m:577-583, 628-690: a constraint
+is kept only if it can be violated), which its C++ path lacks (RT/NLPclass.cu:272-396 evaluates every row every time).  relevance.hip."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _nlp(B, O, T=100, seed=40):
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    bp = random_batch(seed, B, O)
+    return ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"]), bp
+
+
+@pytest.mark.parametrize("B,O", [(1, 20), (6, 50), (3, 0)])
+def test_the_mask_contains_every_row_that_is_ever_violated(B, O):
+    """Soundness: over 1 000 sampled k (uniform in the box, plus its corners' neighbourhood) no row the mask drops is ever > 0 (collision rows)
+    or outside its bounds (torque rows); and the mask is not trivial: most collision rows are dropped, the 4n limit rows are always kept."""
+    from armour_amd.worlds import random_k
+    nlp, _ = _nlp(B, O)
+    rel, cnt, ms = nlp.row_relevance()
+    n, T, J = nlp.n, nlp.T, nlp.J
+    Q = J * T * O
+    assert rel.shape == (B, nlp.m) and rel[:, n * T + Q:].all()
+    assert (rel[:, n * T:n * T + Q].sum(1) == cnt).all()
+    if O:
+        assert 0 < cnt.max() and cnt.mean() < 0.25 * Q, (cnt, Q)
+    xl, xu, gl, gu = nlp.get_bounds_info()
+    ever = np.zeros((B, nlp.m), bool)
+    rng = np.random.default_rng(5)
+    for it in range(1000 // 8):
+        ks = random_k(it, B * 8).reshape(8, B, n)
+        ks[0] = np.sign(ks[0]) * (1.0 - 0.05 * rng.random((B, n)))   # near the corners of the box
+        for k in ks:
+            g = nlp.eval_g(k)
+            ever |= (g > gu) | (g < gl)
+    assert not (ever & ~rel).any(), np.argwhere(ever & ~rel)[:5]
+    print(f"B={B} O={O}: relevant collision rows {cnt.tolist()} of {Q}; rows ever violated {ever.sum(1).tolist()}; test {ms:.3f} ms")
+    nlp.close()
+
+
+@pytest.mark.parametrize("B,O", [(1, 20), (8, 50), (2, 0)])
+def test_culled_violation_records_equal_the_full_ones(B, O):
+    """ARMOUR_OPT_CULL_ROWS = 1: armour_eval_violations over the relevant rows only -- L1 violation, rows violated, rows outside the slacks and the
+    verdict are the full evaluation's bit for bit at every tested k (an unlisted row adds exactly 0); `worst` and its row whenever any row is
+    violated.  Includes k = 0, feasible-looking and badly infeasible points."""
+    from armour_amd import _lib
+    from armour_amd.worlds import random_k
+    nlp, bp = _nlp(B, O, seed=90)
+    from armour_amd.planner import ArmourNLP
+    culled = ArmourNLP(T=100).set_option(_lib.OPT_CULL_ROWS, 1).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    some_violation = False
+    for it in range(12):
+        k = np.zeros((B, nlp.n)) if it == 0 else random_k(100 + it, B) * (1.0 if it % 2 else 0.2)
+        full, cul = nlp.eval_violations(k), culled.eval_violations(k)
+        for a, c in zip(full, cul):
+            assert a["l1_violation"] == c["l1_violation"] and a["n_violated"] == c["n_violated"] and a["n_outside_slack"] == c["n_outside_slack"] and a["feasible"] == c["feasible"]
+            if a["n_violated"] > 0:
+                some_violation = True
+                assert a["worst"] == c["worst"] and a["worst_row"] == c["worst_row"]
+    assert some_violation
+    nlp.close(); culled.close()
