@@ -168,6 +168,7 @@ __device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail
 
 template <class CH>
 __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, int t_lane) {
+    PZ_KEEP_RETURN_ADDRESS();
     typedef typename CH::PZT TPZ;
     const P1Cfg& cf = *c.cf;
     auto& w = c.w;

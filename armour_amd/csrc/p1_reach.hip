@@ -213,6 +213,7 @@ struct JrsScalars {
 };
 
 __device__ PZW_NOINLINE JrsScalars jrs_scalars(const P1Cfg& cf, double q0, double a, double b, int i, int s_ind) {
+    PZ_KEEP_RETURN_ADDRESS();
     JrsScalars o;
     const double ds = 1.0 / cf.T, D = cf.pr.duration, kr = cf.pr.k_range[i];
     const double s_lb = s_ind * ds, s_ub = (s_ind + 1) * ds;
@@ -501,6 +502,7 @@ struct Chain {
 // ARMTD comparison mode, CMP/Trajectory.cu:29-61: cos / sin of the offline JRS (tabulated for q0 = 0) rotated by the
 // joint's initial angle; the radius term is scaled by 4 as the reference does.
 __device__ PZW_NOINLINE JrsScalars armtd_jrs_scalars(const P1Cfg& cf, double q0, int b, int i, int t) {
+    PZ_KEEP_RETURN_ADDRESS();
     const int T = cf.T;
     const double* tb = cf.jrs + ((size_t)b * cf.n + i) * 6 * T + t;
     const double cc = tb[0], gc = tb[T], rc = tb[2 * T], cs = tb[3 * T], gs = tb[4 * T], rs = tb[5 * T];
@@ -666,6 +668,7 @@ __device__ inline void jrs_mass_inertia_direct(Chain& c, int i) {
 // as an item of its own no link boxes.
 // The caller follows with a block barrier.
 __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
+    PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
@@ -730,6 +733,7 @@ __device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
 
 // RT/PZsparse.cu:370-402 reduce_link_PZ + write of the final link table entry
 __device__ PZW_NOINLINE void emit_link(Chain& c, const PZ& p, int b, int l, int t) {
+    PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, cnt = w.cnt[p.id];
@@ -787,6 +791,7 @@ template <class PZT> struct FkStateT { PZT R, Rn, T; };
 typedef FkStateT<PZ> FkState;
 template <class CH>
 __device__ PZW_NOINLINE void fk_begin(CH& c, FkStateT<typename CH::PZT>& f) {
+    PZ_KEEP_RETURN_ADDRESS();
     f.R = c.M(0); f.Rn = c.M(1);
     double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     set_const(c.w, f.R, id, nullptr);
@@ -795,6 +800,7 @@ __device__ PZW_NOINLINE void fk_begin(CH& c, FkStateT<typename CH::PZT>& f) {
 }
 template <class CH>
 __device__ PZW_NOINLINE void fk_step(CH& c, FkStateT<typename CH::PZT>& f, int i, int b, int t) {
+    PZ_KEEP_RETURN_ADDRESS();
     typedef typename CH::PZT PZ;
     auto& w = c.w;
     PZ tp = c.mulMV(f.R, c.Ptr(i));
@@ -824,6 +830,7 @@ __device__ PZW_NOINLINE void fk_step(CH& c, FkStateT<typename CH::PZT>& f, int i
 enum { MB_WV = 0, MB_WDOT, MB_WAUX, MB_LACC, MB_F, MB_N = MB_F + ARMOUR_MAX_JOINTS, MB_A2 = MB_N + ARMOUR_MAX_JOINTS, MB_C2, MB_FF, MB_NN, MB_WORDS };
 template <class CH>
 __device__ PZW_NOINLINE void run_rnea(CH& c, typename CH::PZT* u, int b, int t) {
+    PZ_KEEP_RETURN_ADDRESS();
     typedef typename CH::PZT PZ;
     const P1Cfg& cf = *c.cf;
     auto& w = c.w;
@@ -963,6 +970,7 @@ __device__ PZW_NOINLINE void run_rnea(CH& c, typename CH::PZT* u, int b, int t) 
 // (part / parts: the waves of a free-running block share the joints' tables -- joint j on wave j % parts -- after the last barrier of the RNEA;
 //  the radii every table entry needs are a few LDS reads, which every wave does for itself)
 __device__ PZW_NOINLINE void finish_torque(Chain& c, PZ* u_nom, int b, int t, int part = 0, int parts = 1) {
+    PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     Wave& w = c.w;
     const int n = c.n, T = cf.T;
@@ -2032,12 +2040,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             if (multi && (armtd || tv_nw_env == 1)) continue;
             if (multi && tv_nw_env > 1 && tv_nw_env != nw_launch) continue;
             if (!multi && tv_nw_env > 1 && si == 3) continue;
-            // The ONE-WAVE blocks stay on the 64-double rows: armour_p1_tv_kernel<1> with rows of 48, 50 or 56 doubles ends in a memory-aperture
-            // violation (or hangs) on the MI355X in every launch -- three- and four-wave blocks of the same unit, and the one-wave kernel of the same unit
-            // built with TV_GROW = 64, are fine and bit-identical (the fourth member of that family, the first with a deterministic recipe:
-            // tools/mkvariant2.sh + tools/dev/t24_probe.py, profiles/r05_tv_one_wave_narrow_rows.txt).  One-wave blocks build the comparison mode's
-            // batches and the shapes after a sort-buffer overflow; BASELINE's batches run four-wave blocks.
-            const int gr = multi ? gr_multi : 64;
+            // (Until the return-address guard of pz_wave.h -- PZ_KEEP_RETURN_ADDRESS -- the ONE-WAVE blocks had to stay on the 64-double rows: their
+            //  kernel ended in a memory-aperture violation with narrower rows, in every launch.  tv::mul<3,3,3,3> -- whose staged-operand walks only the
+            //  one-wave blocks' large staging area reaches -- is 150 KB long in the narrow-row unit, the compiler relaxed two of its branches through
+            //  s[30:31] without saving the return address, and the function returned into its own middle: DESIGN.md 7, profiles/r05_tv_one_wave_narrow_rows.txt.)
+            const int gr = gr_multi;
             const tvchain::TLayout TL = tvchain::make_tlayout(J, n, capTv, nw, nhelp, gr);
             // blocks per CU by LDS; the staging area takes what is left
             const size_t fixed = (nw == 4 ? 3 * tvchain::tv_lds_fixed(cap) + tvchain::tv_lds_fixed_fk() : (size_t)nw * tvchain::tv_lds_fixed(cap)) + tvchain::tv_lds_shared();

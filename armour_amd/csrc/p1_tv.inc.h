@@ -411,6 +411,7 @@ __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
 // JRS of this lane's time interval + the constant PZs (see build_jrs above for the per-step form and the citations).
 // Joint i is built by wave i % (number of waves) with that wave's scratch slots; the caller follows with a block barrier.
 __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_only) {
+    PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
@@ -461,6 +462,7 @@ __device__ TV_NOINLINE void build_jrs_tv(TChain& c, int b, int t_lane, bool kin_
 // on its key alone (wave-uniform); whether a lane HAS the monomial is whether its coefficient vector is non-zero.
 // (Found by fk_step through its chain argument; `t_lane` is this lane's time step.)
 __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int t_lane) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(c.w, 7)
     const P1Cfg& cf = *c.cf;
     TW& t = c.w;
@@ -534,6 +536,7 @@ __device__ TV_NOINLINE void emit_link(TChain& c, const TPZ& p, int b, int l, int
 // disturbance, reduce(u_nom), robust-input radius (RT/armour_main.cu:133-141,172-205), per lane; see finish_torque above
 // The tables of joint j are written by wave (j mod nshare) of the `nshare` waves that call this (all with the same u_nom).
 __device__ TV_NOINLINE void finish_torque_tv(TChain& c, TPZ* u_nom, int b, int t_lane, int share_id, int nshare) {
+    PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     TW& t = c.w;
     const int lane = t.w.lane;

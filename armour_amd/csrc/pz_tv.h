@@ -346,10 +346,10 @@ __device__ inline void walk_sorted(int lane, int N_, const KeyAt& keyat, const I
 // rows to fetch per raw term, so four times as many terms can be in flight in the same registers.
 __device__ inline bool stage_fits(const TW& t, const TView& v) { return (v.cnt + 1) * v.sz <= t.stage_rows; }
 __device__ inline void stage_rows_of(const TW& t, const TView& v, int lane) {
-    const int sz = v.sz;
+    const int sz = uni(v.sz);
     const int rl = t.rl;
     for (int e = 0; e < sz; e++) t.stage[(size_t)e * WAVE + lane] = ld_hdr(v, H_CEN, e, rl);
-    const int rows = v.cnt * sz;
+    const int rows = uni(v.cnt * sz);   // (a scalar bound: the guarded stores below are scalar branches, not sixteen exec masks)
     const GLB_AS double* src = v.coef + (size_t)v.off * GR + rl;  // (whole-PZ views: off = 0, stride = sz, rows are consecutive)
     LDS_AS double* dst = t.stage + (size_t)sz * WAVE + lane;
     for (int r0 = 0; r0 < rows; r0 += 16) {
@@ -647,6 +647,7 @@ __device__ inline int hj_collect(TW& t, int n0, const GLB_AS double*& hdr, const
 
 template <int AR, int AC, int BR, int BC>
 __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
+    PZ_KEEP_RETURN_ADDRESS();
     typedef pzw::MulShape<AR, AC, BR, BC> SH;
     constexpr int SZ = SH::SZ;
     const int lane = t.w.lane;
@@ -741,8 +742,10 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         const bool a_short = a.cnt <= b.cnt;
         const bool can_a = a.off == 0 && a.sz == a.stride && stage_fits(t, a), can_b = b.off == 0 && b.sz == b.stride && stage_fits(t, b);
         constexpr bool kSplittable = (AR == 3 && AC == 3 && BR == 3 && BC == 1);   // rotation x vector: the products of the backward recursions
-        const bool stage_a = (a_short && can_a) || (!can_b && can_a);
-        const int stage = stage_a ? 1 : can_b ? 2 : 0;
+        // (wave-uniform in fact -- every lane holds the same counts and the same view -- and made so for the compiler, which otherwise builds the
+        //  three walks as exec-masked branches of each other)
+        const bool stage_a = uni(((a_short && can_a) || (!can_b && can_a)) ? 1 : 0) != 0;
+        const int stage = uni(stage_a ? 1 : can_b ? 2 : 0);
         bool shared = false;
         if constexpr (kSplittable) {
             if (t.hch != nullptr) {
@@ -921,6 +924,7 @@ __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* st
 }
 
 __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 2)
     typedef pzw::MulShape<1, 1, 1, 1> SH;
     const int lane = t.w.lane;
@@ -962,7 +966,7 @@ __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, c
     {
         const bool a_short = a.cnt <= b.cnt;
         const bool can_a = stage_fits(t, a), can_b = stage_fits(t, b);
-        const int stage = ((a_short && can_a) || (!can_b && can_a)) ? 1 : can_b ? 2 : 0;
+        const int stage = uni(((a_short && can_a) || (!can_b && can_a)) ? 1 : can_b ? 2 : 0);   // (wave-uniform, and made so for the compiler: see mul)
         if (stage == 1) stage_rows_of(t, a, lane); else if (stage == 2) stage_rows_of(t, b, lane);
         // a dedicated helper walks the upper part of the sorted terms (whole-PZ 3x1 operands)
         const bool shared = t.hch != nullptr && t.hded && N >= t.hmin;
@@ -1193,6 +1197,7 @@ struct LinCtx {
 // xb (XK >= 0): the constant vector b of the cross product source XK stands for
 template <int SZ, int NS, bool CHAIN, int XK = -1>
 __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, const double* xb = nullptr) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 3)
     const int lane = t.w.lane;
     const int rl = t.rl;   // (the lane's place in a row)
@@ -1388,6 +1393,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
     }
 }
 __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 4)
     const int lane = t.w.lane;
     const int rl = t.rl;   // (the lane's place in a row)
@@ -1499,6 +1505,7 @@ __device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int 
         for (int e = 0; e < 3; e++) ra[k][e] = cx.ra[k][e];
 }
 __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 5)
     LDS_AS int* ch = t.hch;
     const int lane = t.w.lane;
@@ -1599,6 +1606,7 @@ __device__ inline void serve_loop(TW& t, const TPZ& tmp) {
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066): keys unchanged, no simplify
 __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 6)
     const int lane = t.w.lane;
     const int rl = t.rl;   // (the lane's place in a row)
@@ -1617,6 +1625,7 @@ __device__ TV_NOINLINE void transpose33(TW& t, const TPZ& out, const TPZ& a) {
 
 // constant PZ: the same centre / radii in every lane (RT/PZsparse.cu:66-98); ind2 == nullptr: equal to ind
 __device__ TV_NOINLINE void set_const(TW& t, const TPZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
+    PZ_KEEP_RETURN_ADDRESS();
     TVP_FN(t, 6)
     const int lane = t.w.lane;
     const int rl = t.rl;   // (the lane's place in a row)

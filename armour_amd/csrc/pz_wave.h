@@ -28,6 +28,15 @@
 // need to see each other's data.  (With one wave per block this is what __syncthreads() amounted to; written this way
 // the operators can also run in blocks whose waves work on different operators at the same time.)
 #define WSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+// FIRST STATEMENT OF EVERY NON-INLINED DEVICE FUNCTION.  The operator functions are large (tv::mul<3,3,3,3>: 24 000 instructions, 150 KB), and a
+// branch across more than 128 KB is relaxed by the compiler (ROCm 7.2 clang) into s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64 on a
+// SCAVENGED scalar pair -- for which it takes s[30:31], the RETURN ADDRESS of a function that makes no calls, without saving it: once such a
+// branch has been taken the function "returns" into its own middle and runs on with whatever the registers hold.  That is the mechanism
+// behind the memory-aperture violations of rounds 1-5 (profiles/r05_tv_one_wave_narrow_rows.txt: found with rocgdb on the one-wave kernel with
+// narrow rows, whose mul<3,3,3,3> is the first shipped function to cross the limit).  Declaring s30 / s31 clobbered at the entry makes the
+// compiler keep the return address elsewhere (a lane of a VGPR, as in functions that call), so that the scavenged pair is free to use.
+// tools/check_long_branches.py verifies on every P1 object that no function relaxes a branch through an unsaved s[30:31].
+#define PZ_KEEP_RETURN_ADDRESS() asm volatile("; return address kept out of s[30:31] (pz_wave.h)" ::: "s30", "s31")
 
 namespace pzw {
 
@@ -726,6 +735,7 @@ __device__ inline void coef_static(const LinEval<SZ, NS>& ev, int k, int idx, do
 
 template <int SZ, int NS>
 __device__ PZW_NOINLINE void lincomb(Wave& w_, const PZ& out_, const Seg* segs) {
+    PZ_KEEP_RETURN_ADDRESS();
     PZW_WAVE_LOCAL(w, w_)
     const PZ out = uni_pz(out_);
     PROF_CALL_T0
@@ -774,6 +784,7 @@ __device__ PZW_NOINLINE void lincomb(Wave& w_, const PZ& out_, const Seg* segs) 
 // intermediate PZ would have lost it.  Centre and radii are accumulated in the composed order.  NS = 2 is lincomb.
 template <int SZ, int NS>
 __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* segs) {
+    PZ_KEEP_RETURN_ADDRESS();
     PZW_WAVE_LOCAL(w, w_)
     const PZ out = uni_pz(out_);
     PROF_CALL_T0
@@ -1262,12 +1273,10 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
 // the sort; measured slower on the chip and never shipped.  It is kept as a text, docs/experiments/pz_hash.h.txt, not as source.)
 template <int AR, int AC, int BR, int BC>
 __device__ PZW_NOINLINE void mul(Wave& w_, const PZ& out_, const View& a_, const View& b_) {
+    PZ_KEEP_RETURN_ADDRESS();
     PZW_WAVE_LOCAL(w, w_)
     const PZ out = uni_pz(out_);
     const View a = uni_view(a_), b = uni_view(b_);
-#ifdef H1_FORCE_RA_SAVE  /* root-cause tooling: make this function save its return address on the stack, as the select form does */
-    asm volatile("; return address clobbered on purpose" ::: "s30", "s31");
-#endif
     PROF_CALL_T0
     typedef MulShape<AR, AC, BR, BC> SH;
     MulEval<SH> ev;
@@ -1341,6 +1350,7 @@ struct CrossEval : MulEval<MulShape<1, 1, 1, 1>> {
 };
 
 __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_, const View& b_) {
+    PZ_KEEP_RETURN_ADDRESS();
     PZW_WAVE_LOCAL(w, w_)
     const PZ out = uni_pz(out_);
     const View a = uni_view(a_), b = uni_view(b_);
@@ -1483,6 +1493,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
 // Because the key list never changes, the whole thing is one ordered pass over a's monomials: no sort.
 __device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a_, const double* sA, const int* cA,
                                    const double* sB, const int* cB) {
+    PZ_KEEP_RETURN_ADDRESS();
     PZW_WAVE_LOCAL(w, w_)
     const PZ out = uni_pz(out_);
     const View a = uni_view(a_);
@@ -1542,6 +1553,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a
 
 // out = a^T for 3x3 (RT/PZsparse.cu:1050-1066); keys unchanged, no simplify.
 __device__ PZW_NOINLINE void transpose33(Wave& w, const PZ& out, const PZ& a) {
+    PZ_KEEP_RETURN_ADDRESS();
     const int n = w.cnt[a.id];
     for (int t = w.lane; t < n * 9; t += WAVE) {
         const int m = t / 9, e = t - m * 9, r = e / 3, c = e - r * 3;
@@ -1561,6 +1573,7 @@ __device__ PZW_NOINLINE void transpose33(Wave& w, const PZ& out, const PZ& a) {
 // constant PZ (centre + independent radius, no monomials): RT/PZsparse.cu:66-98
 // ind2 == nullptr: the second radius equals the first (everything except the mass / inertia PZs)
 __device__ PZW_NOINLINE void set_const(Wave& w, const PZ& out, const double* cen, const double* ind, const double* ind2 = nullptr) {
+    PZ_KEEP_RETURN_ADDRESS();
     if (w.lane < out.sz) {
         out.cen[w.lane] = cen ? cen[w.lane] : 0.0;
         out.ind[w.lane] = ind ? ind[w.lane] : 0.0;

@@ -553,7 +553,7 @@ def test_row_widths_leave_identical_tables(T):
     """Round 5: the time-vectorised kernel exists twice -- rows of 64 doubles (p1_reach.hip) and packed rows of 50 (p1_reach_tv50.hip: T = 100
     makes groups of 50 time steps) -- and armour_p1_build picks by the group size (ARMOUR_OPT_P1_TV_ROW_WIDTH holds a handle to 64).  A row's
     width changes addresses, never a value or an order: every bit of every table is the same, in four-, three- and one-wave blocks (the one-wave
-    blocks are held to the wide rows: p1_reach.hip); for groups
+    kernel with narrow rows is the configuration that faulted in every launch until the return-address guard of pz_wave.h: DESIGN.md 7); for groups
     that do not fill a row of 50 (T = 90: 45 steps; T = 40) -- lanes with a place in the rows but no step of their own shadow another step
     (pz_tv.h) -- and with T = 128 (groups of 64: only the wide rows fit, asking for 50 is refused by falling back to 64)."""
     from armour_amd import _lib

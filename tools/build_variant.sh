@@ -9,5 +9,5 @@ src=/tmp/var_$name
 cd $src/armour_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -mllvm -enable-ipra=false "$@" -c p1_reach.hip -o $src/p1_reach.o
 L=/root/repo/armour_amd/lib
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,-rpath,/opt/rocm/lib -o $L/libarmour_hip_$name.so $L/api.o $L/p2_eval.o $src/p1_reach.o $L/solver.o $L/solver_device.o $L/controller.o $L/batch.o -lpthread
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,-rpath,/opt/rocm/lib -o $L/libarmour_hip_$name.so $L/api.o $L/p2_eval.o $src/p1_reach.o $L/solver.o $L/solver_device.o $L/controller.o $L/batch.o $L/relevance.o -lpthread
 echo built $L/libarmour_hip_$name.so
