@@ -1,7 +1,7 @@
 """Shader-clock cost of single PZ operators on the device (armour_debug_pz_op reports the operator's own cycles):
 cycles against raw terms for the operators the RNEA chain is made of.  Development tool.
 
-    python tools/gpu_pzop_cost.py
+    python tools/dev/gpu_pzop_cost.py
 """
 import os
 import sys

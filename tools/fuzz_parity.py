@@ -2,7 +2,7 @@
 table values, g and jac at random k -- with the worst deviations and the smallest prune margin seen.  Development /
 evidence tool (tests/ holds the fixed cases); the numbers quoted in DESIGN.md section 2 come from here.
 
-    python tools/gpu_fuzz_parity.py [N=48] [first_seed=5000]
+    python tools/fuzz_parity.py [N=48] [first_seed=5000]
 """
 import os
 import sys

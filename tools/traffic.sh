@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: L2-miss traffic of the reach-set build kernels for one or more libraries:  tools/gpu_p1_traffic.sh B lib [lib...]   (lib: 'tree' or the <name> of
+# dev: L2-miss traffic of the reach-set build kernels for one or more libraries:  tools/traffic.sh B lib [lib...]   (lib: 'tree' or the <name> of
 # armour_amd/lib/libarmour_hip_<name>.so).  One counter per rocprofv3 pass (FETCH_SIZE, WRITE_SIZE, TCC hit / miss), each under its own timeout;
 # a 'library' of the form opt:ID=VALUE[;ID=VALUE] is the tree's library with those per-handle options.
 # prints, per library, the mean per dispatch of the chain / tv kernel and 2 x FETCH_SIZE + WRITE_SIZE in bytes (MI355X_MICROARCH.md, HBM section).
@@ -11,11 +11,11 @@ OUT=$R/gpurun_out/p1_traffic
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 for lib in "$@"; do
-  unset P1_ONCE_OPTS
-  case "$lib" in opt:*) export P1_ONCE_OPTS="${lib#opt:}"; unset ARMOUR_HIP_LIB;; tree) unset ARMOUR_HIP_LIB;; *) export ARMOUR_HIP_LIB=$R/armour_amd/lib/libarmour_hip_$lib.so;; esac
+  OPTS=""
+  case "$lib" in opt:*) OPTS="$(echo ${lib#opt:} | tr ";" " ")"; unset ARMOUR_HIP_LIB;; tree) unset ARMOUR_HIP_LIB;; *) export ARMOUR_HIP_LIB=$R/armour_amd/lib/libarmour_hip_$lib.so;; esac
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     n=$(echo $c | cut -d' ' -f1)
-    timeout -k 10 180 rocprofv3 --pmc $c --output-format csv -d $OUT/${lib}_$n -- python3 $R/tools/p1_once.py $B > $OUT/${lib}_$n.log 2>&1 || echo "pass $lib $n failed"
+    timeout -k 10 180 rocprofv3 --pmc $c --output-format csv -d $OUT/${lib}_$n -- python3 $R/tools/workload.py p1 $B $OPTS > $OUT/${lib}_$n.log 2>&1 || echo "pass $lib $n failed"
   done
 done
 cd $R
