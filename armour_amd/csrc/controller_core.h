@@ -21,10 +21,19 @@ namespace ctl {
 // The halves of the RNEA go into their caller whole, with their getter / putter.  (As functions of their own they reached the kernel's frame --
 // the kinematics store, the lambdas' captures -- through generic pointers, and both kernels built that way ended in a memory-aperture violation
 // on the MI355X; inlined, no generic pointer into a frame is left.)
-#ifdef CTL_NO_FLATTEN   // (development: the halves as functions of their own, to reproduce the fault described above)
+// ROOT CAUSE (round 5, profiles/r05_codegen_hazards.txt): as functions of their own the interval rnea_dynamics is > 128 KB of code, the compiler
+// relaxes four of its branches through s[30:31] WITHOUT saving the return address held there, and the function returns into its own middle
+// (pz_wave.h PZ_KEEP_RETURN_ADDRESS; tools/check_long_branches.py reports exactly these two functions in a -DCTL_NO_FLATTEN object).  With the
+// return address declared clobbered at the entry (CTL_KEEP_RETURN_ADDRESS below) the non-inlined build runs and gives the same outputs.
+#ifdef CTL_NO_FLATTEN   // (development: the halves as functions of their own; add -DCTL_NO_RETURN_ADDRESS_GUARD for the faulting form of round 3)
 #define CTL_FLATTEN
 #else
 #define CTL_FLATTEN __attribute__((always_inline))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CTL_NO_FLATTEN) && !defined(CTL_NO_RETURN_ADDRESS_GUARD)
+#define CTL_KEEP_RETURN_ADDRESS() asm volatile("; return address kept out of s[30:31]" ::: "s30", "s31")
+#else
+#define CTL_KEEP_RETURN_ADDRESS()
 #endif
 
 struct Itv { double lo, hi; };
@@ -162,6 +171,7 @@ struct Model {
 // Operation for operation the code of the one-function form: results are unchanged to the bit.
 template <class S, class Put>
 CTL_HD CTL_FLATTEN void rnea_kinematics(const Model<S>& md, const double* q, Put put) {
+    CTL_KEEP_RETURN_ADDRESS();
     Xf<S> Xbw = md.XTree[0];
     for (int i = 0; i < md.n; i++) {
         if (i > 0) Xbw = apply(Xbw, md.XTree[i]);
@@ -173,6 +183,7 @@ CTL_HD CTL_FLATTEN void rnea_kinematics(const Model<S>& md, const double* q, Put
 template <class S, class Get>
 CTL_HD CTL_FLATTEN void rnea_dynamics(const Model<S>& md, Get get, const double* qd, const double* qda, const double* qdd, bool apply_friction, bool apply_gravity,
                           S* tau) {
+    CTL_KEEP_RETURN_ADDRESS();
     const int n = md.n;
     Tw<S> neg_g{vzero<S>(), vzero<S>()};
     if (apply_gravity) neg_g = -md.gravity;
@@ -213,16 +224,19 @@ template <class S> struct KinStore {   // the kinematics of one state in the cal
 };
 template <class S>
 CTL_HD CTL_FLATTEN void rnea_kinematics(const Model<S>& md, const double* q, KinStore<S>& k) {
+    CTL_KEEP_RETURN_ADDRESS();
     rnea_kinematics(md, q, [&](int i, const Xf<S>& Xli, const Tw<S>& Sb) { k.Xli[i] = Xli; k.Sb[i] = Sb; });
 }
 template <class S>
 CTL_HD CTL_FLATTEN void rnea_dynamics(const Model<S>& md, const KinStore<S>& k, const double* qd, const double* qda, const double* qdd, bool apply_friction,
                           bool apply_gravity, S* tau) {
+    CTL_KEEP_RETURN_ADDRESS();
     rnea_dynamics(md, [&](int i, Xf<S>& Xli, Tw<S>& Sb) { Xli = k.Xli[i]; Sb = k.Sb[i]; }, qd, qda, qdd, apply_friction, apply_gravity, tau);
 }
 template <class S>
 CTL_HD CTL_FLATTEN void pass_rnea(const Model<S>& md, const double* q, const double* qd, const double* qda, const double* qdd, bool apply_friction,
                       bool apply_gravity, S* tau) {
+    CTL_KEEP_RETURN_ADDRESS();
     KinStore<S> k;
     rnea_kinematics(md, q, k);
     rnea_dynamics(md, k, qd, qda, qdd, apply_friction, apply_gravity, tau);
@@ -241,6 +255,7 @@ CTL_HD double clamp_angle(double x) {  // robust_controller.hpp:11-16
 // prepare: modified reference velocity / acceleration and the tracking error r (:70-83); returns |r|
 CTL_HD CTL_FLATTEN double robust_prepare(int n, const double* Kr, const double* q, const double* q_d, const double* qd, const double* qd_d, const double* qd_dd,
                              double* qa_d, double* qa_dd, double* r) {
+    CTL_KEEP_RETURN_ADDRESS();
     for (int i = 0; i < n; i++) {
         const double q_diff = clamp_angle(qd[i] - q[i]);
         qa_d[i] = qd_d[i] + Kr[i] * q_diff;
@@ -255,6 +270,7 @@ CTL_HD CTL_FLATTEN double robust_prepare(int n, const double* Kr, const double* 
 // Returns false if the nominal torque leaves the interval torque (the reference throws).  u = tau = u_nominal - v.
 CTL_HD CTL_FLATTEN bool robust_combine(int n, double alpha, double V_max, double r_norm_threshold, const double* r, double r_norm, const double* u_nominal,
                            const Itv* u_int, const Itv* Mr, double* u, double* v_out) {
+    CTL_KEEP_RETURN_ADDRESS();
     bool ok = true;
     double bound_sq = 0.0;
     for (int i = 0; i < n; i++) {
@@ -277,6 +293,7 @@ CTL_HD CTL_FLATTEN bool robust_combine(int n, double alpha, double V_max, double
 CTL_HD CTL_FLATTEN bool robust_update(const Model<double>& md, const Model<Itv>& imd, const double* Kr, double alpha, double V_max, double r_norm_threshold,
                           const double* q, const double* q_d, const double* qd, const double* qd_d, const double* qd_dd, double* u, double* u_nominal,
                           double* v_out) {
+    CTL_KEEP_RETURN_ADDRESS();
     const int n = md.n;
     double qa_d[ARMOUR_MAX_FACTORS], qa_dd[ARMOUR_MAX_FACTORS], r[ARMOUR_MAX_FACTORS], zero[ARMOUR_MAX_FACTORS];
     const double r_norm = robust_prepare(n, Kr, q, q_d, qd, qd_d, qd_dd, qa_d, qa_dd, r);

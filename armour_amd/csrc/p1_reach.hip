@@ -523,7 +523,7 @@ __device__ PZW_NOINLINE JrsScalars armtd_jrs_scalars(const P1Cfg& cf, double q0,
 // in advance.  Built through the operators (a raw slot, lincomb's simplify(), the constant-left product, transpose33) each of them is a chain of
 // round trips through the arena: ~135 k cycles per joint, 0.2 M of a time step's 2.4 M.  Here every lane evaluates the same few expressions in
 // registers -- exactly the operators' arithmetic, in their order, including the order in which the wave reduction adds the pruned amounts of
-// lanes 0..3 -- and lane 0 writes the finished slots.  Same tables bit for bit (the launch digests of tools/gpu_p1_repeat_stress.py are those
+// lanes 0..3 -- and lane 0 writes the finished slots.  Same tables bit for bit (the launch digests of tools/ab.py --reps are those
 // of the operator form).
 __device__ inline double quad_sum(double r0, double r1, double r2, double r3) { return (r0 + r1) + (r2 + r3); }   // wave_sum() of four lanes
 // (No register array below is indexed by a run-time value -- the first version kept the surviving terms in arrays indexed by their count, which
@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
 #ifdef P1_PROFILE
     for (int i = 0; i < PR_WORDS; i++) c.w.prof[i] = 0;
 #endif
-    const long long cyc0 = clock64();  // shader-clock cycles of the operator alone, reported in out_misc[30] (tools/gpu_pzop_cost.py)
+    const long long cyc0 = clock64();  // shader-clock cycles of the operator alone, reported in out_misc[30] (tools/dev/gpu_pzop_cost.py)
     switch (a.op) {
         case 0: out = c.mulMV(in[0], in[1]); break;
         case 1: out = c.M(1); mul<3, 3, 3, 3>(w, out, view(w, in[0]), view(w, in[1])); break;
@@ -1670,7 +1670,7 @@ static std::mutex g_p1_launch_mu;
 // one block per compute unit leaves no room for another handle's beside it anyway), so two handles that build batches at the same
 // time need the 111.6 MiB per block once, not twice.  The arena stays allocated between builds and goes with the device's last handle;
 // ARMOUR_OPT_P1_KEEP_WORK_MEMORY = 0 releases it at the end of every build of that handle instead.  (Why keeping is the default --
-// measured, tools/gpu_p1_wall.py: releasing and re-allocating 28.6 GiB costs 0.6 ms of a 128-problem build's 10.4 ms as a rule, and 3.5 - 4.4 s
+// measured, tools/dev/gpu_p1_wall.py: releasing and re-allocating 28.6 GiB costs 0.6 ms of a 128-problem build's 10.4 ms as a rule, and 3.5 - 4.4 s
 // twice in twelve builds, when the runtime has to get the memory back from the driver.)
 struct TvArenaPool {
     std::mutex mu;

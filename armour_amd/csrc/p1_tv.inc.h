@@ -249,7 +249,7 @@ struct TChain {
 // Every lane evaluates the operators' arithmetic for ITS time step in registers, in their order -- lincomb<SZ,1>'s simplify() of the raw terms,
 // the constant-left product's, transpose33's copies, the stack's -- and writes its rows; which rows exist is the wave's vote, as in the walks
 // (a key stays while any lane keeps it; a lane that pruned it stores 0 and has |.| in its radius).  Same tables bit for bit as through the
-// operators (launch digests, tools/gpu_p1_repeat_stress.py), without their round trips through the arena: a dozen per joint.
+// operators (launch digests, tools/ab.py --reps), without their round trips through the arena: a dozen per joint.
 template <int SZ>
 __device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, int rl, pzkey_t key, const double* v) {   // (rl: the lane's place in a row)
     if (lane == 0) out.keys[pos] = key;

@@ -36,7 +36,11 @@
 // narrow rows, whose mul<3,3,3,3> is the first shipped function to cross the limit).  Declaring s30 / s31 clobbered at the entry makes the
 // compiler keep the return address elsewhere (a lane of a VGPR, as in functions that call), so that the scavenged pair is free to use.
 // tools/check_long_branches.py verifies on every P1 object that no function relaxes a branch through an unsaved s[30:31].
+#ifdef PZ_NO_RETURN_ADDRESS_GUARD   // (forensic builds only: the objects of rounds 1-4 as they were, for tools/check_long_branches.py to look at)
+#define PZ_KEEP_RETURN_ADDRESS()
+#else
 #define PZ_KEEP_RETURN_ADDRESS() asm volatile("; return address kept out of s[30:31] (pz_wave.h)" ::: "s30", "s31")
+#endif
 
 namespace pzw {
 
@@ -67,7 +71,7 @@ enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS
 #define PROF_CALL_END(N)
 #endif
 enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8, ERR_PAIR = 32, ERR_DBG_BOUNDS = 128 };
-// -DDBG_BOUNDS (root-cause tooling, tools/gpu_fault_hunt.py): every LDS / arena index of the product merge and of the reduce
+// -DDBG_BOUNDS (root-cause tooling, tools/dev/gpu_fault_hunt.py): every LDS / arena index of the product merge and of the reduce
 // pass is range-checked BEFORE the access; a violation is recorded (flag 128, lstat[3] = code * 2^20 + the offending value's
 // low 20 bits, first one wins) and the index clamped to 0, so that a genuine out-of-range index shows up as a report
 // instead of a memory fault.
@@ -160,7 +164,7 @@ __device__ inline View elem(const Wave& w, const PZ& p, int r) { return View{p.k
 
 // Sum over the 64 lanes, returned in every lane.  Data-parallel-primitive moves inside the VALU (quad permutes, row
 // mirrors, row broadcasts) instead of six rounds of cross-lane shuffles through the LDS crossbar, which cost ~3 k cycles
-// per product operator in abs_sum alone (tools/gpu_pzop_cost.py).  Fixed summation tree: the same result in every launch shape.
+// per product operator in abs_sum alone (tools/dev/gpu_pzop_cost.py).  Fixed summation tree: the same result in every launch shape.
 #ifdef NO_DPP  /* development: the same data movement through ds_bpermute instead of DPP moves */
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_take(double v) {
@@ -1004,7 +1008,7 @@ struct MulEval {
     // buffers: an element's place in the merged pair is its offset in its own run plus the number of the sibling run's
     // elements that go before it -- ONE binary search per element and level (ties: the earlier run first, which is
     // generation order), log2(#runs) levels.  Against the bitonic network this replaces (72 % of a 40 x 40 cross product,
-    // tools/gpu_pzop_cost.py) that is ~50 search steps per element instead of 66 compare-exchange stages, and against the
+    // tools/dev/gpu_pzop_cost.py) that is ~50 search steps per element instead of 66 compare-exchange stages, and against the
     // one-search-per-run ranking below it is log2 instead of linear in the number of runs.  Eight elements per lane are
     // searched together, branch-free with a wave-uniform step count, so that their LDS reads overlap.
     // The runs are taken along the SHORTER operand (fewer runs = fewer levels): a's terms when a is the shorter one -- the
