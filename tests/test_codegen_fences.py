@@ -75,6 +75,19 @@ def test_range_checked_operators_run_the_fuzz_set_clean_and_agree_with_the_shipp
     assert len(checked) == 36 and checked == shipped
 
 
+@pytest.mark.gpu
+def test_two_waves_per_simd_build_reproduces_the_shipped_tables():
+    """The round-2 hazard (wrong tables every second launch with two waves per SIMD) as a regression test: `make -C armour_amd/csrc occ2`
+    builds the shipped source at occupancy 2; the per-step kernel is forced, 12 fresh handles per batch size build the same worlds, and
+    every digest (tables, g, Jacobian) must equal the shipped library's (tools/ab.py; profiles/r05_codegen_hazards.txt)."""
+    occ2 = os.path.join(ROOT, "armour_amd", "lib", "libarmour_hip_occ2.so")
+    if not os.path.exists(occ2):
+        pytest.skip("libarmour_hip_occ2.so not built (make -C armour_amd/csrc occ2)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab.py"), "tree@1=1", "occ2@1=1", "--rounds", "1", "--reps", "12", "--", "16", "64", "128"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "digests identical across variants, rounds and repeats: True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_checked_library_exports_the_whole_abi():
     """CPU: the range-checked library is a full libarmour_hip (same objects but p1_reach.o) -- every symbol of include/armour_hip.h."""
     import ctypes as C
