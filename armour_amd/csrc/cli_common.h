@@ -36,7 +36,7 @@ namespace cli {
 struct Session {  // planner handles kept across iterations (one per mode and T)
     ArmourPlanner* armour = nullptr; int armour_T = 0;
     ArmourPlanner* armtd = nullptr; int armtd_T = 0;
-    ArmourPlanner* armour_nic = nullptr; int armour_nic_T = 0;   // ARMOUR without input constraints (TURN_OFF_INPUT_CONSTRAINTS, RT/Parameters.h:44)
+    ArmourPlanner* armour_nic = nullptr; int armour_nic_T = 0;   // ARMOUR without input constraints (TURN_OFF_INPUT_CONSTRAINTS, RT/Parameters.h:46-47)
     ~Session() { if (armour) armour_destroy(armour); if (armtd) armour_destroy(armtd); if (armour_nic) armour_destroy(armour_nic); }
 };
 
@@ -93,7 +93,7 @@ inline void write_common_outputs(const std::string& dir, const char* prefix, int
 // armour.in -> armour.out + 4 files (RT/armour_main.cu).  The clock starts before the input is parsed; creating the
 // planner handle (GPU context, allocations) is outside it when the handle already exists, as the reference keeps its
 // allocations outside its own clock (armour_main.cu:86-88).
-// input_off: the reference built with TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44): no torque rows, no control-input-radius file (RT/armour_main.cu:355)
+// input_off: the reference built with TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47): no torque rows, no control-input-radius file (RT/armour_main.cu:355)
 inline int iteration_armour(Session& s, const std::string& dir, int T, bool input_off = false) {
     const std::string out1 = dir + "armour.out";
     { std::ofstream touch(out1); }  // "declare this first and make sure we always have a new output" (armour_main.cu:36)

@@ -124,7 +124,7 @@ struct ArmourPlanner {
     bool ready = false;
     int mode = ARMOUR_MODE_ARMOUR;
     // no torque rows, forward kinematics only: the comparison planner (CMP/), or the ARMOUR trajectory with TURN_OFF_INPUT_CONSTRAINTS
-    // (ArmourParams.input_constraints_off: RT/Parameters.h:44, RT/armour_main.cu:115,149-165, RT/NLPclass.cu:46-54)
+    // (ArmourParams.input_constraints_off: RT/Parameters.h:46-47, RT/armour_main.cu:115,149-165, RT/NLPclass.cu:46-54)
     bool no_torque() const { return mode == ARMOUR_MODE_ARMTD || params.input_constraints_off != 0; }
     int row0 = 0;                   // rows before the collision block (n*T torque rows, or 0 in ARMTD mode)
     std::vector<double> h_krange;   // ARMTD mode: [B][n] acceleration range of each problem's JRS tables

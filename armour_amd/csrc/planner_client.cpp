@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
     std::string base = self.substr(self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/') + 1);
     const char* kind = base.rfind("armtd", 0) == 0 ? "armtd" : "armour";
     bool serve = false, quit = false;
-    // TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44) is a compile-time switch of the reference; here: `--no-input-constraints`, or -- for a MATLAB
+    // TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47) is a compile-time switch of the reference; here: `--no-input-constraints`, or -- for a MATLAB
     // caller that cannot change the command line of uarmtd_planner.m:189 -- ARMOUR_TURN_OFF_INPUT_CONSTRAINTS=1 in the environment (setenv)
     const char* nic_env = getenv("ARMOUR_TURN_OFF_INPUT_CONSTRAINTS");
     bool nic = nic_env && nic_env[0] && strcmp(nic_env, "0") != 0;

@@ -71,7 +71,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         ArmourParams& pr = g_pr;
         armour_robot_kinova_gen3_no_gripper(&rb);
         armour_params_default(&pr, (int)mxGetScalar(prhs[1]));
-        // armour_hip_mex('create', T, turn_off_input_constraints): the reference's compile-time switch TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44)
+        // armour_hip_mex('create', T, turn_off_input_constraints): the reference's compile-time switch TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47)
         if (nrhs >= 3) pr.input_constraints_off = mxGetScalar(prhs[2]) != 0.0 ? 1 : 0;
         if (g_h) { armour_destroy(g_h); g_h = nullptr; }
         chk(armour_create(&rb, &pr, nullptr, 0, &g_h));

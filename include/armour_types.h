@@ -77,7 +77,7 @@ ARMOUR_HD static inline double armour_inertia_uncertainty(const ArmourRobot* r, 
 
 typedef struct ArmourParams {
     int32_t num_time_steps;                 /* NUM_TIME_STEPS, must be even (RT/Parameters.h:16) */
-    int32_t input_constraints_off;          /* TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44), 0 = false (the default): non-zero plans the same Bezier
+    int32_t input_constraints_off;          /* TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47), 0 = false (the default): non-zero plans the same Bezier
                                              * trajectory without the torque rows -- the reach-set build stops after the forward kinematics
                                              * (RT/armour_main.cu:115,149-165,175), m = J T O + 4n, collision rows first (RT/NLPclass.cu:46-54,117,289-301,
                                              * 361-373,453), the torque-radius file is not written (RT/armour_main.cu:355).  (This field was `reserved`.) */

@@ -141,7 +141,7 @@ struct Problem {
     double build_ms = 0;
     /* ARMTD comparison mode (CMP/ = kinova_planner_realtime_armtd_comparison): constant-acceleration curve, offline JRS tables */
     bool armtd = false;
-    /* TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44): the ARMOUR trajectory without the torque rows -- P1 runs JRS + forward kinematics only
+    /* TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47): the ARMOUR trajectory without the torque rows -- P1 runs JRS + forward kinematics only
      * (RT/armour_main.cu:115,149-165,175), m = J T O + 4n with the collision rows first (RT/NLPclass.cu:46-54,117,289-301,361-373,453) */
     bool no_torque() const { return armtd || pr.input_constraints_off != 0; }
     std::vector<double> jrs; /* [n][6][T]: c,g,r of cos then of sin (CMP/armtd_main.cu:76-96) */

@@ -1,4 +1,4 @@
-"""TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:44): the ARMOUR (Bezier) trajectory planned without the torque rows.
+"""TURN_OFF_INPUT_CONSTRAINTS (RT/Parameters.h:46-47): the ARMOUR (Bezier) trajectory planned without the torque rows.
 
 The reference switches at compile time: the reach-set build stops after the forward kinematics (RT/armour_main.cu:115,149-165), the
 torque radius stays zero (:172-175) and its file is not written (:355); m = J T O + 4n with the collision rows FIRST

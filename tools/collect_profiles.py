@@ -20,7 +20,8 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
 KERNELS = ("armour_p2_eval_kernel", "armour_p1_chain_kernel", "armour_p1_tv_kernel", "armour_p1_planes_kernel", "armour_p1_plane_class_kernel",
            "armour_p1_plane_sample_kernel", "armour_solve_kernel", "armour_solve_scan_kernel")
-STAMP = {"commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+# (the newest commit that touched what was measured: re-running this script after a documentation commit does not move the stamp)
+STAMP = {"commit": subprocess.run(["git", "log", "-1", "--format=%h", "--", "armour_amd", "include", "bench.py", "tools/workload.py"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
          "date": datetime.date.today().isoformat()}
 
 
@@ -110,5 +111,8 @@ for B in (1, 128):
         print(f"P1 B={B} {kern}: HBM bytes per dispatch {e['hbm_bytes_per_dispatch']:.3e}, L2 hit rate {e.get('l2_hit_rate', float('nan')):.3f}, dispatches {e['dispatches']}")
     print(f"P1 B={B} SQ:", sq[f"B={B}"]["kernel"], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sq[f"B={B}"]["derived"].items()})
 shutil.copy(newest(os.path.join(SRC, "cull_trace", "**", "*kernel_stats.csv")), os.path.join(DST, TAG + "_cull_configs2_kernel_stats.csv"))
+with open(os.path.join(DST, TAG + "_cull_configs2.txt"), "w") as f:   # (what the workload itself timed with HIP events, under the kernel trace)
+    f.write(f"# python3 tools/workload.py cull 128 50 under rocprofv3 --kernel-trace --stats, commit {STAMP['commit']}, {STAMP['date']}\n")
+    f.write("".join(l for l in open(os.path.join(SRC, "cull_trace.log")) if l.startswith(("full:", "culled:", "records identical"))))
 for f in (TAG + "_bench_headline", TAG + "_bench_configs2", TAG + "_solve", TAG + "_p1_B1", TAG + "_p1_B128"):
     print("==", f); print("".join(open(os.path.join(DST, f + "_kernel_stats.csv")).readlines()[:6]))
