@@ -104,6 +104,7 @@ OPT_SOLVE_SUB_BATCH = 144
 OPT_SOLVE_ROW_CAP = 145
 OPT_SOLVE_HARD_CAP_S = 146
 OPT_SOLVE_WAVES_PER_SIMD = 147
+OPT_SOLVE_CULL = 148   # -1 automatic | 0 | 1: the device-resident solve walks only the rows that can ever be QP candidates (same iterates)
 
 # every symbol include/armour_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -114,7 +115,7 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance",
+    "armour_get_plane_skip", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance", "armour_get_solver_rows",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
     "armour_batch_get_build_ms", "armour_batch_get_build_info",
@@ -219,6 +220,7 @@ def load():
     L.armour_eval_violations_device.argtypes = [vp, vp, vp, vp]
     L.armour_eval_violations.argtypes = [vp, dp, C.POINTER(ArmourViolation)]
     L.armour_get_row_relevance.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.armour_get_solver_rows.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.armour_batch_partition.argtypes = [C.c_int32, C.c_int32, ip]
     L.armour_batch_create.argtypes = [C.POINTER(ArmourRobot), C.POINTER(ArmourParams), C.POINTER(ArmourLimits), ip, C.c_int32, C.POINTER(vp)]
     L.armour_batch_destroy.argtypes = [vp]

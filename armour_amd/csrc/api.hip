@@ -165,7 +165,7 @@ const TuningSpec kTuning[] = {
     {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_TV_ROW_WIDTH, 0, 0, 64}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},
     {ARMOUR_OPT_P2_EX, 1, 0, 1}, {ARMOUR_OPT_STEPS_GRAPH_MIN, 2, 0, 1e6}, {ARMOUR_OPT_PINNED_MODE, 0, 0, 2}, {ARMOUR_OPT_CULL_ROWS, 0, 0, 1},
     {ARMOUR_OPT_SOLVE_SUB_TILES, 48, 1, 1e6}, {ARMOUR_OPT_SOLVE_DEVICE, 1, 0, 2}, {ARMOUR_OPT_SOLVE_CUT_TILES, 156, 1, 1e6}, {ARMOUR_OPT_SOLVE_BLOCKS, 0, 0, 1e6},
-    {ARMOUR_OPT_SOLVE_SUB_BATCH, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_ROW_CAP, 0, 0, 1e7}, {ARMOUR_OPT_SOLVE_HARD_CAP_S, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_WAVES_PER_SIMD, 0, 0, 2},
+    {ARMOUR_OPT_SOLVE_SUB_BATCH, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_ROW_CAP, 0, 0, 1e7}, {ARMOUR_OPT_SOLVE_HARD_CAP_S, 0, 0, 1e6}, {ARMOUR_OPT_SOLVE_WAVES_PER_SIMD, 0, 0, 2}, {ARMOUR_OPT_SOLVE_CULL, -1, -1, 1},
 };
 const TuningSpec* tuning_spec(int option) {
     for (const TuningSpec& t : kTuning) if (t.option == option) return &t;
@@ -281,7 +281,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     }
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
-    h->rel_fresh = false;
+    h->rel_fresh = false; h->rel2_fresh = false;
     h->bounds_on_device = false;
     h->stats_fresh = false;
     drop_step_graphs(h);  // they bake in the tables of the previous problem set

@@ -151,6 +151,17 @@ struct ArmourPlanner {
     long long* d_rel_pack_off = nullptr; size_t rel_pack_off_cap = 0;   // [B][2]: offset and row stride of every problem's block, in doubles
     int* d_rel_rows_res = nullptr; size_t rel_rows_res_cap = 0;   // the same rows by (row index mod 256): what the culled row test iterates
     std::vector<int> h_rel_count;
+    // the solver's mask (rows that can pass armour_solve's candidate filter for some k), its row list, packed entries and torque tile list
+    unsigned char* d_rel2 = nullptr; size_t rel2_cap = 0;
+    int* d_rel2_rows = nullptr; size_t rel2_rows_cap = 0;
+    int* d_rel2_count = nullptr; size_t rel2_count_cap = 0;        // [B] listed collision rows | [B] listed torque tiles
+    double* d_rel2_packed = nullptr; size_t rel2_packed_cap = 0;
+    long long* d_rel2_pack_off = nullptr; size_t rel2_pack_off_cap = 0;
+    int* d_rel2_tq_tiles = nullptr; size_t rel2_tq_tiles_cap = 0;  // [B][rel2_tq_cap]
+    std::vector<int> h_rel2_count, h_rel2_tq_count;
+    bool rel2_fresh = false;
+    double rel2_ms = 0;
+    int rel2_max_count = 0, rel2_tq_cap = 0;
     bool rel_fresh = false;
     double rel_ms = 0;
     int rel_max_count = 0;
@@ -213,7 +224,7 @@ bool armour_trace_solve();   // ARMOUR_SOLVE_TIMING
 int armour_p2_launch(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, const double* d_k, double* d_g, double* d_jac, hipStream_t stream,
                      int steps = 1, long long k_stride = 0, long long g_stride = 0, long long j_stride = 0, bool skip_collision_blocks = false);
 // relevance.hip
-int armour_relevance_build(ArmourPlanner* h);
+int armour_relevance_build(ArmourPlanner* h, bool for_solver);   // (relevance.hip; for_solver: also the lists armour_solve's culled device form walks)
 void armour_relevance_free(ArmourPlanner* h);
 int armour_eval_violations_culled(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, hipStream_t st);
 int armour_refresh_table_stats(ArmourPlanner* h);

@@ -22,7 +22,7 @@
 // verdict are those of the full evaluation bit for bit (an unlisted row adds exactly 0).  armour_eval_g_jac* stays full (IPOPT parity).
 #include <vector>
 
-#include "p2_tiles.h"
+#include "p2_sparse.h"
 
 using namespace p2;
 
@@ -34,6 +34,8 @@ struct RelTables {
     P2Tables tb;
     const double* lo; const double* hi;   // [B][m] bounds (uploaded: armour_upload_bounds)
     unsigned char* rel;                   // [B][m]
+    unsigned char* rel2;                  // [B][m] the solver's mask: rows that can pass armour_solve's candidate filter for SOME k (a superset of rel), or null
+    int* tq_tiles; int* tq_count; int tq_cap;   // torque tiles (P2_TQ_ROWS rows each) holding a row of rel2, ascending: [B][tq_cap] | [B]
     int* rows; int* count;                // [B][Q] relevant collision rows in ascending order | [B]
     int* rows_res; int* count_res;        // the same rows by (row0 + q) mod 256, ascending within a class: [B][256][ceil(Q / 256)] | [B][256]
     // the half-space entries of the listed rows, PACKED: problem b's block starts at packed + pack_off[2 b] doubles and holds, for its j-th live
@@ -43,7 +45,6 @@ struct RelTables {
     double* packed; const long long* pack_off;
 };
 
-struct PlaneVals { double a0, a1, a2, dd, dl; };
 // plane p of row q as the fused evaluation sees it: normal from the table (link x link planes from the compact records when the table shares
 // them), delta from the table, d stored or recomputed from the obstacle centre -- the same choices as armour_p2_plan makes (dfc)
 __device__ inline PlaneVals load_plane(const P2Tables& tb, const double* pl0, const double* pll, int Q, int q, int p, bool dfc, double oc0, double oc1, double oc2) {
@@ -76,25 +77,48 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
     if (dfc) { const double* oc = tb.obs_center + (size_t)b * 3 * O + o; oc0 = oc[0]; oc1 = oc[O]; oc2 = oc[2 * (size_t)O]; }
     const unsigned long long live0 = ~tb.plane_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull);
     // first with the interval hull of the family (sum_i |A coef_i| <= |A| . r, r[e] = sum_i |coef_i[e]|: three products a plane) and out at the
-    // first plane that separates -- most rows are far from their obstacle; the tight sums only for the rows the hull leaves undecided
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-    for (int mo = 0; mo < cnt; mo++) { r0 += fabs(co[mo * 3]); r1 += fabs(co[mo * 3 + 1]); r2 += fabs(co[mo * 3 + 2]); }
-    bool separated = false;
-    for (unsigned long long live = live0; live && !separated; live &= live - 1ull) {
+    // first plane that separates -- most rows are far from their obstacle; the tight sums only for the rows the hull leaves undecided.
+    // The SOLVER's mask asks for more: armour_solve takes row i into its QP when g_i + 2 |J_i|_1 > u_i (solver_common.h row_upper_candidate).
+    // With a separating plane of margin L (one of its two values >= L for every k) g_i <= -L, and |J_i|_1 = |A_win . dx|_1 <= |rd|_2 for the
+    // unit normal of whichever plane wins, rd[e] = sum_i deg_i |coef_i[e]| (|d k^alpha / d k_j| <= alpha_j on the box): the row can never be a
+    // candidate when L >= 2 |rd|_2 - u_i + margin.
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, rd0 = 0.0, rd1 = 0.0, rd2 = 0.0;
+    {
+        const uint32_t* kk = tb.link_keys + idx * tb.capL;
+        for (int mo = 0; mo < cnt; mo++) {
+            const double f0 = fabs(co[mo * 3]), f1 = fabs(co[mo * 3 + 1]), f2 = fabs(co[mo * 3 + 2]);
+            uint32_t key = kk[mo];
+            int deg = 0;
+            for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) { deg += (int)(key & 3u); key >>= 2; }
+            r0 += f0; r1 += f1; r2 += f2;
+            rd0 += deg * f0; rd1 += deg * f1; rd2 += deg * f2;
+        }
+    }
+    const size_t row = (size_t)b * tb.m + tb.row0 + q;
+    const double ui = a.hi[row];
+    const bool lower_bounded = a.lo[row] > -1e18;   // (collision rows have no lower bound; if one had, it stays a solver row)
+    const double need2 = kRelMargin + 2.0 * sqrt(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) * (1.0 + 1e-9) - ui;
+    bool separated = false, sep2 = a.rel2 == nullptr;
+    for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
         const bool nz = (v.a0 != 0.0) | (v.a1 != 0.0) | (v.a2 != 0.0);
         const double s = fabs(v.a0 * c0 + v.a1 * c1 + v.a2 * c2 - v.dd);
         const double hh = fabs(v.a0) * r0 + fabs(v.a1) * r1 + fabs(v.a2) * r2;
-        separated = nz && s - hh * (1.0 + 1e-12) - v.dl >= kRelMargin;
+        const double L = s - hh * (1.0 + 1e-12) - v.dl;
+        separated |= nz && L >= kRelMargin;
+        sep2 |= nz && L >= need2;
     }
-    for (unsigned long long live = live0; live && !separated; live &= live - 1ull) {
+    for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
         const bool nz = (v.a0 != 0.0) | (v.a1 != 0.0) | (v.a2 != 0.0);
         const double s = fabs(v.a0 * c0 + v.a1 * c1 + v.a2 * c2 - v.dd);
         double h = 0.0;
         for (int mo = 0; mo < cnt; mo++) h += fabs(v.a0 * co[mo * 3] + v.a1 * co[mo * 3 + 1] + v.a2 * co[mo * 3 + 2]);
-        separated = nz && s - h * (1.0 + 1e-12) - v.dl >= kRelMargin;
+        const double L = s - h * (1.0 + 1e-12) - v.dl;
+        separated |= nz && L >= kRelMargin;
+        sep2 |= nz && L >= need2;
     }
+    if (a.rel2) a.rel2[row] = (sep2 && separated && !lower_bounded) ? 0 : 1;
     a.rel[(size_t)b * tb.m + tb.row0 + q] = separated ? 0 : 1;
 }
 
@@ -107,13 +131,24 @@ __global__ __launch_bounds__(256) void armour_rel_other_kernel(RelTables a) {
         const int t = r / tb.n, j = r - t * tb.n;
         const size_t idx = ((size_t)b * tb.n + j) * tb.T + t;
         const int cnt = min(tb.tq_count[idx], tb.capT);
-        double rad = 0.0;
-        for (int mo = 0; mo < cnt; mo++) rad += fabs(tb.tq_coeff[idx * tb.capT + mo]);
+        double rad = 0.0, radd = 0.0;   // sum |coef|, sum deg |coef| (>= |J_row|_1 on the box)
+        for (int mo = 0; mo < cnt; mo++) {
+            const double f = fabs(tb.tq_coeff[idx * tb.capT + mo]);
+            uint32_t key = tb.tq_keys[idx * tb.capT + mo];
+            int deg = 0;
+            for (int j2 = 0; j2 < ARMOUR_MAX_FACTORS; j2++) { deg += (int)(key & 3u); key >>= 2; }
+            rad += f; radd += deg * f;
+        }
         const double cen = tb.tq_center[idx];
         const double lo = a.lo[(size_t)b * tb.m + r], hi = a.hi[(size_t)b * tb.m + r];
-        a.rel[(size_t)b * tb.m + r] = (cen + rad >= hi - kRelMargin || cen - rad <= lo + kRelMargin) ? 1 : 0;
+        const bool relevant = cen + rad >= hi - kRelMargin || cen - rad <= lo + kRelMargin;
+        a.rel[(size_t)b * tb.m + r] = relevant ? 1 : 0;
+        // the solver's filter: g + 2 |J|_1 > u or g - 2 |J|_1 < l for some k (solver_common.h)
+        const double reach = (rad + 2.0 * radd) * (1.0 + 1e-9);
+        if (a.rel2) a.rel2[(size_t)b * tb.m + r] = (relevant || cen + reach >= hi - kRelMargin || cen - reach <= lo + kRelMargin) ? 1 : 0;
     } else if (r - nT < tb.m - lim0) {
         a.rel[(size_t)b * tb.m + lim0 + (r - nT)] = 1;
+        if (a.rel2) a.rel2[(size_t)b * tb.m + lim0 + (r - nT)] = 1;
     }
 }
 
@@ -128,7 +163,7 @@ __global__ __launch_bounds__(256) void armour_rel_list_kernel(RelTables a) {
     // most one of them per pass and thread tid appends to its class without a conflict, in ascending order (what the row test needs: it adds a
     // thread's rows in ascending order, as the full kernel does)
     const int per = (tb.Q + 255) / 256;
-    int* rres = a.rows_res + (size_t)b * 256 * per;
+    int* rres = a.rows_res ? a.rows_res + (size_t)b * 256 * per : nullptr;
     __shared__ int cres[256];   // entries per class so far
     cres[tid] = 0;
     __syncthreads();
@@ -136,7 +171,7 @@ __global__ __launch_bounds__(256) void armour_rel_list_kernel(RelTables a) {
     for (int q0 = 0; q0 < tb.Q; q0 += 256) {
         const int q = q0 + tid;
         const bool f = q < tb.Q && rel[q] != 0;
-        if (f) { const int c = (tb.row0 + q) & 255; rres[(size_t)c * per + cres[c]] = q; cres[c]++; }
+        if (f && a.rows_res) { const int c = (tb.row0 + q) & 255; rres[(size_t)c * per + cres[c]] = q; cres[c]++; }
         const unsigned long long bl = __ballot(f);
         if (lane == 0) wtot[wv] = __popcll(bl);
         __syncthreads();
@@ -147,7 +182,28 @@ __global__ __launch_bounds__(256) void armour_rel_list_kernel(RelTables a) {
         __syncthreads();
     }
     if (tid == 0) a.count[b] = base;
-    a.count_res[(size_t)b * 256 + tid] = cres[tid];
+    if (a.rows_res) a.count_res[(size_t)b * 256 + tid] = cres[tid];
+    // the torque tiles (P2_TQ_ROWS consecutive rows, the tiles of p2_tiles.h torque_block) that hold a row of the mask, ascending
+    if (a.tq_tiles) {
+        const unsigned char* relt = a.rel + (size_t)b * tb.m;
+        const int ntile = (tb.row0 + P2_TQ_ROWS - 1) / P2_TQ_ROWS;
+        int tbase = 0;
+        __syncthreads();
+        for (int t0 = 0; t0 < ntile; t0 += 256) {
+            const int t = t0 + tid;
+            bool f = false;
+            if (t < ntile) for (int r = t * P2_TQ_ROWS; r < min(tb.row0, (t + 1) * P2_TQ_ROWS); r++) f |= relt[r] != 0;
+            const unsigned long long bl = __ballot(f);
+            if (lane == 0) wtot[wv] = __popcll(bl);
+            __syncthreads();
+            int pos = tbase + __popcll(bl & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; w++) pos += wtot[w];
+            if (f) a.tq_tiles[(size_t)b * a.tq_cap + pos] = t;
+            tbase += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            __syncthreads();
+        }
+        if (tid == 0) a.tq_count[b] = tbase;
+    }
 }
 
 // ---- pack the listed rows' plane entries (once per problem set)
@@ -184,54 +240,8 @@ __global__ __launch_bounds__(64) void armour_sparse_collision_g_kernel(RelTables
     fill_kpow(kp, (int)threadIdx.x < tb.n ? k_all[(size_t)b * tb.n + threadIdx.x] : 0.0, tb.n);
     __syncthreads();
     if (i >= cntb) return;
-    const int Q = tb.Q, O = tb.O, JT = tb.J * tb.T, n = tb.n;
-    const int q = a.rows[(size_t)b * Q + i];
-    const int lt = q / O;
-    const size_t idx = (size_t)b * JT + lt;
-    const int cnt = min(tb.link_count[idx], tb.capL);
-    double x[3];
-    {   // the three axes together, four monomials' table entries requested before they are used (clamped index: a lane past its count adds nothing)
-        double acc0 = tb.link_center[idx * 3 + 0], acc1 = tb.link_center[idx * 3 + 1], acc2 = tb.link_center[idx * 3 + 2];
-        const uint32_t* kk = tb.link_keys + idx * tb.capL;
-        const double* cc = tb.link_coeff + idx * tb.capL * 3;
-        const int cmax = cnt > 0 ? cnt - 1 : 0;
-        for (int m0 = 0; m0 < cnt; m0 += 4) {
-            uint32_t key[4]; double c3[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int mo = min(m0 + u, cmax); key[u] = kk[mo]; c3[u][0] = cc[mo * 3]; c3[u][1] = cc[mo * 3 + 1]; c3[u][2] = cc[mo * 3 + 2]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (m0 + u < cnt) {   // (per lane; in monomial order, axis by axis the sums of the full evaluation)
-                    acc0 += mono_value(kp, key[u], c3[u][0], n); acc1 += mono_value(kp, key[u], c3[u][1], n); acc2 += mono_value(kp, key[u], c3[u][2], n);
-                }
-            }
-        }
-        x[0] = interval_center(acc0, tb.link_indep[idx * 3 + 0]); x[1] = interval_center(acc1, tb.link_indep[idx * 3 + 1]); x[2] = interval_center(acc2, tb.link_indep[idx * 3 + 2]);
-    }
-    // the packed entries of this row: plane j of the problem's live planes (ascending), six planes' values requested, then used
-    const double* src = a.packed + a.pack_off[2 * b] + i;
-    const size_t stride = (size_t)a.pack_off[2 * b + 1];
-    const int nlive = __popcll(~tb.plane_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull));
-    double max_elt = -100000000.0;
-    for (int j0 = 0; j0 < nlive; j0 += 6) {
-        PlaneVals v[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int j = min(j0 + u, nlive - 1);
-            v[u].a0 = src[(size_t)(j * 5 + 0) * stride]; v[u].a1 = src[(size_t)(j * 5 + 1) * stride]; v[u].a2 = src[(size_t)(j * 5 + 2) * stride];
-            v[u].dd = src[(size_t)(j * 5 + 3) * stride]; v[u].dl = src[(size_t)(j * 5 + 4) * stride];
-        }
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const bool nz = j0 + u < nlive && ((v[u].a0 != 0.0) | (v[u].a1 != 0.0) | (v[u].a2 != 0.0));
-            const double dot = v[u].a0 * x[0] + v[u].a1 * x[1] + v[u].a2 * x[2];
-            const double pos_res = nz ? dot - (v[u].dd + v[u].dl) : -100000000.0;
-            const double neg_res = nz ? -dot - (-v[u].dd + v[u].dl) : -100000000.0;
-            max_elt = pos_res > max_elt ? pos_res : max_elt;
-            max_elt = neg_res > max_elt ? neg_res : max_elt;
-        }
-    }
-    g_all[(size_t)b * tb.m + tb.row0 + q] = -max_elt;
+    const SparseList sl{a.rows, a.count, a.packed, a.pack_off};
+    sparse_collision_row<false>(tb, sl, b, i, kp, g_all + (size_t)b * tb.m, nullptr);
 }
 
 // ---- armour_violation_kernel (api.hip) over the torque rows, the LISTED collision rows and the limit rows.  Thread t takes the rows r with
@@ -309,70 +319,135 @@ void armour_relevance_free(ArmourPlanner* h) {
     if (h->d_rel_rows_res) (void)hipFree(h->d_rel_rows_res);
     if (h->d_rel_packed) (void)hipFree(h->d_rel_packed);
     if (h->d_rel_pack_off) (void)hipFree(h->d_rel_pack_off);
+    if (h->d_rel2) (void)hipFree(h->d_rel2);
+    if (h->d_rel2_rows) (void)hipFree(h->d_rel2_rows);
+    if (h->d_rel2_count) (void)hipFree(h->d_rel2_count);
+    if (h->d_rel2_packed) (void)hipFree(h->d_rel2_packed);
+    if (h->d_rel2_pack_off) (void)hipFree(h->d_rel2_pack_off);
+    if (h->d_rel2_tq_tiles) (void)hipFree(h->d_rel2_tq_tiles);
+    h->d_rel2 = nullptr; h->d_rel2_rows = nullptr; h->d_rel2_count = nullptr; h->d_rel2_packed = nullptr; h->d_rel2_pack_off = nullptr; h->d_rel2_tq_tiles = nullptr;
+    h->rel2_cap = h->rel2_rows_cap = h->rel2_count_cap = h->rel2_packed_cap = h->rel2_pack_off_cap = h->rel2_tq_tiles_cap = 0;
+    h->rel2_fresh = false;
     h->d_rel_packed = nullptr; h->d_rel_pack_off = nullptr; h->rel_packed_cap = h->rel_pack_off_cap = 0;
     h->d_rel = nullptr; h->d_rel_rows = nullptr; h->d_rel_count = nullptr; h->d_rel_rows_res = nullptr;
     h->rel_cap = h->rel_rows_cap = h->rel_count_cap = h->rel_rows_res_cap = 0;
     h->rel_fresh = false;
 }
 
-// mask + row lists of the current problem set (once per problem set: begin_problem_set clears rel_fresh)
-int armour_relevance_build(ArmourPlanner* h) {
-    if (h->rel_fresh) return ARMOUR_OK;
-    int rc = armour_upload_bounds(h);
-    if (rc != ARMOUR_OK) return rc;
-    const size_t B = (size_t)h->B;
-    if ((rc = rel_alloc(&h->d_rel, &h->rel_cap, B * h->m)) != ARMOUR_OK) return rc;
-    if ((rc = rel_alloc(&h->d_rel_rows, &h->rel_rows_cap, B * (size_t)std::max(h->Q, 1))) != ARMOUR_OK) return rc;
-    if ((rc = rel_alloc(&h->d_rel_count, &h->rel_count_cap, B * 257)) != ARMOUR_OK) return rc;   // [B] counts | [B][256] per residue class
-    if ((rc = rel_alloc(&h->d_rel_rows_res, &h->rel_rows_res_cap, B * 256 * (size_t)std::max((h->Q + 255) / 256, 1))) != ARMOUR_OK) return rc;
-    RelTables a;
-    a.tb = armour_make_tables(h);
-    a.lo = h->d_bounds; a.hi = h->d_bounds + B * h->m;
-    a.rel = h->d_rel; a.rows = h->d_rel_rows; a.count = h->d_rel_count; a.rows_res = h->d_rel_rows_res; a.count_res = h->d_rel_count + (size_t)h->B;
-    a.packed = nullptr; a.pack_off = nullptr;
-    const int dfc = a.tb.obs_center != nullptr && a.tb.ll_shared;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, h->stream));
-    if (h->Q > 0) hipLaunchKernelGGL(armour_rel_collision_kernel, dim3((h->Q + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
-    const int other = h->row0 + (h->m - h->row0 - h->Q);
-    hipLaunchKernelGGL(armour_rel_other_kernel, dim3((other + 255) / 256, h->B), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(armour_rel_list_kernel, dim3(h->B), dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, h->stream));
-    h->h_rel_count.resize(B);
-    HIPCHK(hipMemcpyAsync(h->h_rel_count.data(), h->d_rel_count, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    h->rel_ms = ms;
-    h->rel_max_count = 0;
-    for (int c : h->h_rel_count) h->rel_max_count = std::max(h->rel_max_count, c);
-    // the packed plane entries of the listed rows: offsets from the counts just read back
-    std::vector<long long> off(2 * B);
+// offsets of the packed plane entries of B row lists: [2 b] first double of problem b's block, [2 b + 1] its row stride; returns the total
+static long long pack_offsets(const ArmourPlanner* h, const std::vector<int>& count, std::vector<long long>& off) {
+    off.resize(2 * count.size());
     long long total = 0;
-    for (size_t b = 0; b < B; b++) {
-        const long long stride = (h->h_rel_count[b] + 15) & ~15;
+    for (size_t b = 0; b < count.size(); b++) {
+        const long long stride = (count[b] + 15) & ~15;
         const int nlive = __builtin_popcountll(~h->h_plane_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull));
         off[2 * b] = total; off[2 * b + 1] = stride;
         total += (long long)5 * nlive * stride;
     }
-    if ((rc = rel_alloc(&h->d_rel_packed, &h->rel_packed_cap, (size_t)std::max(total, 1ll))) != ARMOUR_OK) return rc;
-    if ((rc = rel_alloc(&h->d_rel_pack_off, &h->rel_pack_off_cap, 2 * B)) != ARMOUR_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_rel_pack_off, off.data(), 2 * B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    a.packed = h->d_rel_packed; a.pack_off = h->d_rel_pack_off;
-    if (h->rel_max_count > 0) hipLaunchKernelGGL(armour_rel_pack_kernel, dim3((h->rel_max_count + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));   // (`off` is read by the copy)
-    h->rel_fresh = true;
+    return total;
+}
+
+// mask + row lists of the current problem set (once per problem set: begin_problem_set clears rel_fresh / rel2_fresh).
+// for_solver: also the lists of the solver's mask (rows that can pass armour_solve's candidate filter), their packed plane entries and the
+// torque tiles that hold such a row -- what the culled device form of armour_solve walks (solver_device.hip).
+int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
+    if (h->rel_fresh && (!for_solver || h->rel2_fresh)) return ARMOUR_OK;
+    int rc = armour_upload_bounds(h);
+    if (rc != ARMOUR_OK) return rc;
+    const size_t B = (size_t)h->B;
+    RelTables a;
+    a.tb = armour_make_tables(h);
+    a.lo = h->d_bounds; a.hi = h->d_bounds + B * h->m;
+    const int dfc = a.tb.obs_center != nullptr && a.tb.ll_shared;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    if (!h->rel_fresh) {
+        if ((rc = rel_alloc(&h->d_rel, &h->rel_cap, B * h->m)) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel2, &h->rel2_cap, B * h->m)) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel_rows, &h->rel_rows_cap, B * (size_t)std::max(h->Q, 1))) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel_count, &h->rel_count_cap, B * 257)) != ARMOUR_OK) return rc;   // [B] counts | [B][256] per residue class
+        if ((rc = rel_alloc(&h->d_rel_rows_res, &h->rel_rows_res_cap, B * 256 * (size_t)std::max((h->Q + 255) / 256, 1))) != ARMOUR_OK) return rc;
+        a.rel = h->d_rel; a.rel2 = h->d_rel2; a.rows = h->d_rel_rows; a.count = h->d_rel_count; a.rows_res = h->d_rel_rows_res; a.count_res = h->d_rel_count + (size_t)h->B;
+        a.tq_tiles = nullptr; a.tq_count = nullptr; a.tq_cap = 0;
+        a.packed = nullptr; a.pack_off = nullptr;
+        HIPCHK(hipEventRecord(e0, h->stream));
+        if (h->Q > 0) hipLaunchKernelGGL(armour_rel_collision_kernel, dim3((h->Q + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
+        const int other = h->row0 + (h->m - h->row0 - h->Q);
+        hipLaunchKernelGGL(armour_rel_other_kernel, dim3((other + 255) / 256, h->B), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(armour_rel_list_kernel, dim3(h->B), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, h->stream));
+        h->h_rel_count.resize(B);
+        HIPCHK(hipMemcpyAsync(h->h_rel_count.data(), h->d_rel_count, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        h->rel_ms = ms;
+        h->rel_max_count = 0;
+        for (int c : h->h_rel_count) h->rel_max_count = std::max(h->rel_max_count, c);
+        // the packed plane entries of the listed rows: offsets from the counts just read back
+        std::vector<long long> off;
+        const long long total = pack_offsets(h, h->h_rel_count, off);
+        if ((rc = rel_alloc(&h->d_rel_packed, &h->rel_packed_cap, (size_t)std::max(total, 1ll))) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel_pack_off, &h->rel_pack_off_cap, 2 * B)) != ARMOUR_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_rel_pack_off, off.data(), 2 * B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        a.packed = h->d_rel_packed; a.pack_off = h->d_rel_pack_off;
+        if (h->rel_max_count > 0) hipLaunchKernelGGL(armour_rel_pack_kernel, dim3((h->rel_max_count + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));   // (`off` is read by the copy)
+        h->rel_fresh = true;
+    }
+    if (for_solver && !h->rel2_fresh) {
+        const int tq_cap = std::max(1, (h->row0 + P2_TQ_ROWS - 1) / P2_TQ_ROWS);
+        if ((rc = rel_alloc(&h->d_rel2_rows, &h->rel2_rows_cap, B * (size_t)std::max(h->Q, 1))) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel2_count, &h->rel2_count_cap, 2 * B)) != ARMOUR_OK) return rc;   // [B] listed collision rows | [B] listed torque tiles
+        if ((rc = rel_alloc(&h->d_rel2_tq_tiles, &h->rel2_tq_tiles_cap, B * (size_t)tq_cap)) != ARMOUR_OK) return rc;
+        a.rel = h->d_rel2; a.rel2 = nullptr; a.rows = h->d_rel2_rows; a.count = h->d_rel2_count; a.rows_res = nullptr; a.count_res = nullptr;
+        a.tq_tiles = h->d_rel2_tq_tiles; a.tq_count = h->d_rel2_count + B; a.tq_cap = tq_cap;
+        a.packed = nullptr; a.pack_off = nullptr;
+        HIPCHK(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(armour_rel_list_kernel, dim3(h->B), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        std::vector<int> cnt(2 * B);
+        HIPCHK(hipMemcpyAsync(cnt.data(), h->d_rel2_count, 2 * B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->h_rel2_count.assign(cnt.begin(), cnt.begin() + B);
+        h->h_rel2_tq_count.assign(cnt.begin() + B, cnt.end());
+        h->rel2_tq_cap = tq_cap;
+        h->rel2_max_count = 0;
+        for (int c : h->h_rel2_count) h->rel2_max_count = std::max(h->rel2_max_count, c);
+        std::vector<long long> off;
+        const long long total = pack_offsets(h, h->h_rel2_count, off);
+        if ((rc = rel_alloc(&h->d_rel2_packed, &h->rel2_packed_cap, (size_t)std::max(total, 1ll))) != ARMOUR_OK) return rc;
+        if ((rc = rel_alloc(&h->d_rel2_pack_off, &h->rel2_pack_off_cap, 2 * B)) != ARMOUR_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_rel2_pack_off, off.data(), 2 * B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        a.packed = h->d_rel2_packed; a.pack_off = h->d_rel2_pack_off;
+        if (h->rel2_max_count > 0) hipLaunchKernelGGL(armour_rel_pack_kernel, dim3((h->rel2_max_count + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        h->rel2_ms = ms;
+        h->rel2_fresh = true;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ARMOUR_OK;
+}
+
+// the solver's row lists of the current problem set as the persistent kernel takes them (solver.hip)
+int armour_solver_lists(ArmourPlanner* h, p2::SparseList* sl, const int** tq_tiles, const int** tq_count, int* tq_cap) {
+    const int rc = armour_relevance_build(h, true);
+    if (rc != ARMOUR_OK) return rc;
+    sl->rows = h->d_rel2_rows; sl->count = h->d_rel2_count; sl->packed = h->d_rel2_packed; sl->pack_off = h->d_rel2_pack_off;
+    *tq_tiles = h->d_rel2_tq_tiles; *tq_count = h->d_rel2_count + (size_t)h->B; *tq_cap = h->rel2_tq_cap;
     return ARMOUR_OK;
 }
 
 extern "C" int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int32_t* n_relevant_collision_rows, double* ms) {
     if (!h || !h->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
     HIPCHK(hipSetDevice(h->device));
-    const int rc = armour_relevance_build(h);
+    const int rc = armour_relevance_build(h, false);
     if (rc != ARMOUR_OK) return rc;
     if (relevant) HIPCHK(hipMemcpy(relevant, h->d_rel, (size_t)h->B * h->m, hipMemcpyDeviceToHost));
     if (n_relevant_collision_rows) for (int b = 0; b < h->B; b++) n_relevant_collision_rows[b] = h->h_rel_count[b];
@@ -380,10 +455,24 @@ extern "C" int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int
     return ARMOUR_OK;
 }
 
+extern "C" int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_tiles, double* ms) {
+    if (!h || !h->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
+    HIPCHK(hipSetDevice(h->device));
+    const int rc = armour_relevance_build(h, true);
+    if (rc != ARMOUR_OK) return rc;
+    if (solver_rows) HIPCHK(hipMemcpy(solver_rows, h->d_rel2, (size_t)h->B * h->m, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->B; b++) {
+        if (n_collision_rows) n_collision_rows[b] = h->h_rel2_count[b];
+        if (n_torque_tiles) n_torque_tiles[b] = h->h_rel2_tq_count[b];
+    }
+    if (ms) *ms = h->rel_ms + h->rel2_ms;
+    return ARMOUR_OK;
+}
+
 // the culled form of armour_eval_violations_device (api.hip): torque + limit blocks of the fused evaluation, the listed collision rows, the
 // row test over the same rows
 int armour_eval_violations_culled(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, hipStream_t st) {
-    int rc = armour_relevance_build(h);
+    int rc = armour_relevance_build(h, false);
     if (rc != ARMOUR_OK) return rc;
     const P2Tables tb = armour_make_tables(h);
     rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, h->d_g, nullptr, st, 1, 0, 0, 0, /*skip_collision_blocks=*/true);

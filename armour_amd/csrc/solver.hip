@@ -317,8 +317,21 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     const int B = h->B, n = h->n, m = h->m;
     const P2Tables tb = armour_make_tables(h);
     SolvePlan plan;
-    int rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan);
-    if (rc != ARMOUR_OK) return rc;
+    int rc;
+    // The culled form (ARMOUR_OPT_SOLVE_CULL; relevance.hip, solver_device.h): the kernel walks only the rows that can pass the candidate filter
+    // for some k.  Same iterates; the lists cost one pass over the half-space table per problem set (about one evaluation), so automatic = from
+    // kSolveCullMinRows collision rows in the batch on.
+    const int cull_opt = h->tune(ARMOUR_OPT_SOLVE_CULL);
+    constexpr long long kSolveCullMinRows = 40000;
+    const bool culled = h->Q > 0 && (cull_opt > 0 || (cull_opt < 0 && (long long)B * h->Q >= kSolveCullMinRows));
+    p2::SparseList sl = {nullptr, nullptr, nullptr, nullptr};
+    const int* tq_tiles = nullptr; const int* tq_count = nullptr;
+    int tq_cap = 0, n_tiles_culled = 0;
+    if (culled) {
+        if ((rc = armour_solver_lists(h, &sl, &tq_tiles, &tq_count, &tq_cap)) != ARMOUR_OK) return rc;
+        for (int b = 0; b < B; b++) n_tiles_culled = std::max(n_tiles_culled, h->h_rel2_tq_count[b] + (h->h_rel2_count[b] + P2_BLOCK - 1) / P2_BLOCK + 1);
+    }
+    if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan, n_tiles_culled)) != ARMOUR_OK) return rc;
     if (plan.capacity < 1) return 0;
     // A block walks its tiles one after the other (~4 us each), so what a phase costs is the tiles PER BLOCK, and the co-resident
     // grid has to be shared by the problems of a launch.  Round 2 ran the whole batch in one launch and fell back to the host form
@@ -335,7 +348,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     if (plan.capacity < B || (plan.n_tiles + std::max(1, plan.capacity / B) - 1) / std::max(1, plan.capacity / B) > cut_tiles) {
         const int nb_want = std::min(plan.n_tiles, (plan.n_tiles + sub_tiles - 1) / sub_tiles);
         Bs = std::max(1, std::min(B, plan.capacity / std::max(1, nb_want)));
-        if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan)) != ARMOUR_OK) return rc;
+        if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, Bs, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan, n_tiles_culled)) != ARMOUR_OK) return rc;
         Bs = std::max(1, std::min(Bs, plan.capacity));
     }
     int nb = std::min(std::min(plan.n_tiles, plan.capacity / Bs), 1024);
@@ -347,7 +360,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     const int tiles_per_block = (plan.n_tiles + nb - 1) / nb;
     // (an overflow of either sends the whole batch to the host-driven form, i.e. costs a second solve: B = 128 at O = 20 with 77 tiles per
     //  block overflowed 1024 rows per block on two of four world seeds -- 25 ms instead of 10; the buffers are 72 B per row)
-    int cap_blk = std::min(2 * tiles_per_block * 64, 4096);
+    int cap_blk = std::min(2 * tiles_per_block * (culled ? P2_BLOCK : 64), 4096);
     int cap_rows = std::min(2 * m, 16384);
     if (h->tune(ARMOUR_OPT_SOLVE_ROW_CAP) > 0) cap_blk = std::max(1, std::min(cap_blk, h->tune(ARMOUR_OPT_SOLVE_ROW_CAP)));  // tests: force the overflow fallback
     SolveDeviceWork& w = h->solve_dev;
@@ -383,6 +396,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     SolveArgs a;
     memset(&a, 0, sizeof(a));
     a.tb = tb; a.lp = plan.lp; a.nb = nb; a.n_tiles = plan.n_tiles; a.cap_blk = cap_blk; a.cap_rows = cap_rows;
+    a.culled = culled ? 1 : 0; a.sl = sl; a.tq_tiles = tq_tiles; a.tq_count = tq_count; a.tq_cap = tq_cap;
     a.lo = h->d_bounds; a.hi = h->d_bounds + (size_t)B * m; a.g = h->d_g; a.jac = h->d_jac;
     a.ctl = reinterpret_cast<SolveCtl*>(w.ctl); a.blk_word = reinterpret_cast<BlockWord*>(w.blk_word);
     a.blk_rows = reinterpret_cast<SolveRow*>(w.blk_rows); a.qp_rows = reinterpret_cast<SolveRow*>(w.qp_rows); a.flags = w.flags;
@@ -429,6 +443,8 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         if (hres[b].status < 0) { w.words_clean = 0; return 0; }   // candidate buffers too small for some problem, or a group lost a block: the host form redoes the solve
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (timing) {
+        if (culled) fprintf(stderr, "[armour_solve, device form] culled: at most %d listed tiles per problem (problem 0: %d of %d collision rows, %d of %d torque tiles), lists %.3f + %.3f ms\n",
+                            n_tiles_culled, h->h_rel2_count[0], h->Q, h->h_rel2_tq_count[0], plan.lp.nbt, h->rel_ms, h->rel2_ms);
         fprintf(stderr, "[armour_solve, device form] B=%d in %d launch(es) of <= %d problems: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, n_launch, Bs, nb, plan.n_tiles, ms,
                 std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
         for (int i = 0; i < 32 && (i < 2 || hstamps[i]); i++) fprintf(stderr, " %.1f", hstamps[i] / plan.ticks_per_ms * 1e3);

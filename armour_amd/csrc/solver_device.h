@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "p2_tiles.h"
+#include "p2_sparse.h"
 #include "solver_common.h"
 
 // per-problem control block in device memory: the group's barrier, the leader's command and the phase accumulators
@@ -23,6 +24,12 @@ struct SolveArgs {
     P2Tables tb;
     p2::P2Launch lp;
     int nb, n_tiles;               // blocks per problem; row tiles per problem
+    // culled != 0 (ARMOUR_OPT_SOLVE_CULL; relevance.hip): a problem's tiles are its LISTED torque tiles, then its listed collision rows in tiles of
+    // P2_BLOCK (one thread per row: p2_sparse.h), then the limit rows -- the rows that can pass the candidate filter for some k; every other row
+    // adds nothing to any quantity the solver reads (no violation, no candidate, inside the slacks), so the iterates are those of the full form
+    int culled;
+    p2::SparseList sl;
+    const int* tq_tiles; const int* tq_count; int tq_cap;   // [B][tq_cap] listed torque tiles, ascending | [B]
     int b0;                        // first problem of this launch: a batch too large to give every problem enough co-resident blocks runs as
                                    // several launches back to back, each over problems [b0, b0 + gridDim.x / nb) of the same tables
     int cap_blk, cap_rows;         // candidate rows a block / a problem may hand over
@@ -59,6 +66,9 @@ struct SolvePlan {
 int armour_p2_plan(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int steps, long long k_stride,
                    long long g_stride, long long j_stride, p2::P2Launch* lp_out, size_t* smem_out, bool* dfc_out, bool* six_out, bool* exact_out);
 // b_launch: problems per launch the occupancy choice is made for (the whole batch, or a sub-batch of it)
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan);
+// n_tiles_override > 0: the tiles a problem of the launch has at most (the culled form's count, from the row lists)
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan,
+                                 int n_tiles_override = 0);
+int armour_solver_lists(ArmourPlanner* h, p2::SparseList* sl, const int** tq_tiles, const int** tq_count, int* tq_cap);   // relevance.hip
 // d_args: the SolveArgs in device memory (the kernel reads them through the pointer)
 int armour_solve_device_launch(const SolveArgs* d_args, int nb, const SolvePlan& plan, int B, hipStream_t stream);

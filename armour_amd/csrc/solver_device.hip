@@ -182,6 +182,90 @@ __device__ inline void scan_rows(const SolveArgs& a, int b, int r0, int r1, Solv
     __syncthreads();
 }
 
+// The culled form's scan: the block's rows are those of its tiles [t0, t1) of the problem's LISTED tiles -- torque tiles (P2_TQ_ROWS rows each), then
+// tiles of P2_BLOCK listed collision rows, then the limit rows -- visited tile by tile in row order, one thread per row of a tile; the tests and the
+// compaction are scan_rows' (candidates of the block in ascending row order).
+struct TileSet { int ntq, nsp, cnt2; };   // listed torque tiles, sparse collision tiles, listed collision rows of the problem
+__device__ inline TileSet problem_tiles(const SolveArgs& a, int b) {
+    TileSet ts;
+    ts.ntq = a.tq_count[b]; ts.cnt2 = a.sl.count[b]; ts.nsp = (ts.cnt2 + P2_BLOCK - 1) / P2_BLOCK;
+    return ts;
+}
+// row of thread `tid` in listed tile t (or -1)
+__device__ inline int tile_row(const SolveArgs& a, int b, const TileSet& ts, int t, int tid) {
+    if (t < ts.ntq) {
+        const int r = a.tq_tiles[(size_t)b * a.tq_cap + t] * P2_TQ_ROWS + tid;
+        return tid < P2_TQ_ROWS && r < a.tb.row0 ? r : -1;
+    }
+    if (t < ts.ntq + ts.nsp) {
+        const int i = (t - ts.ntq) * P2_BLOCK + tid;
+        return i < ts.cnt2 ? a.tb.row0 + a.sl.rows[(size_t)b * a.tb.Q + i] : -1;
+    }
+    const int r = a.tb.row0 + a.tb.Q + tid;
+    return r < a.tb.m ? r : -1;
+}
+__device__ inline void scan_tiles(const SolveArgs& a, int b, const TileSet& ts, int t0, int t1, SolveRow* __restrict__ rows, int cap, ScanShared& sh,
+                                  long long& viol_out, int& count_out, int& bad_out) {
+    const int n = a.tb.n, m = a.tb.m, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* g = a.g + (size_t)b * m;
+    const double* jac = a.jac + (size_t)b * m * n;
+    const double* lo = a.lo + (size_t)b * m;
+    const double* hi = a.hi + (size_t)b * m;
+    const int n_unchecked = a.tb.Q - a.n_checked_collision;
+    int base = 0, bad = 0;
+    long long vsum = 0;
+    for (int t = t0; t < t1; t++) {
+        const int i = tile_row(a, b, ts, t, tid);
+        const bool in = i >= 0;
+        const double gi = in ? g[i] : 0.0, li = in ? lo[i] : -1e300, ui = in ? hi[i] : 1e300;
+        vsum += row_violation(gi, li, ui);
+        if (in) {
+            const int ic = i - a.tb.row0 - a.n_checked_collision;  // >= 0: behind the re-checked collision rows
+            const double slack = i < a.tb.row0 ? a.torque_slack : ic < 0 ? a.collision_slack : 0.0;
+            if ((ic < 0 || ic >= n_unchecked) && (gi < li - slack || gi > ui + slack)) bad++;
+        }
+        double J[NV], l1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) { J[j] = (in && j < n) ? jac[(size_t)i * n + j] : 0.0; l1 += fabs(J[j]); }
+        const bool fh = in && row_upper_candidate(gi, ui, l1);
+        const bool fl = in && row_lower_candidate(gi, li, l1);
+        const unsigned long long bh = __ballot(fh), bl = __ballot(fl);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) sh.wave_tot[wv] = __popcll(bh) + __popcll(bl);
+        __syncthreads();
+        int pos = base + __popcll(bh & below) + __popcll(bl & below);
+        for (int w2 = 0; w2 < wv; w2++) pos += sh.wave_tot[w2];
+        if (fh) {
+            if (pos < cap) {
+                SolveRow r; r.idx = i; r.side = 0; r.v = gi - ui;
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.a[j] = -J[j];
+                st_coh_row(rows + pos, r);
+            }
+            pos++;
+        }
+        if (fl && pos < cap) {
+            SolveRow r; r.idx = i; r.side = 1; r.v = li - gi;
+#pragma unroll
+            for (int j = 0; j < NV; j++) r.a[j] = J[j];
+            st_coh_row(rows + pos, r);
+        }
+        base += sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+        __syncthreads();
+    }
+    sh.red[tid] = vsum;
+    sh.redi[tid] = bad;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) { sh.red[tid] += sh.red[tid + s2]; sh.redi[tid] += sh.redi[tid + s2]; }
+        __syncthreads();
+    }
+    viol_out = sh.red[0];
+    bad_out = sh.redi[0];
+    count_out = base;
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ the leader
 constexpr int kFlagsInLds = 1024;   // QP rows whose active / excluded flags fit in LDS (more: the global byte arrays)
 struct Leader {
@@ -718,10 +802,16 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     const bool leader = jb == 0;
     const int n = a.tb.n, m = a.tb.m;
     SolveCtl* c = a.ctl + b;
-    const int t0 = (int)(((long long)jb * a.n_tiles) / a.nb), t1 = (int)(((long long)(jb + 1) * a.n_tiles) / a.nb);
-    int role, r0, r1, rdummy;
-    tile_info(a, t0, role, r0, rdummy);
-    tile_info(a, t1 - 1, role, rdummy, r1);
+    // (culled: the problem's own count of listed tiles; a block past the last tile evaluates and scans nothing and still keeps the group's barrier)
+    TileSet ts = {0, 0, 0};
+    int my_tiles = a.n_tiles;
+    if (a.culled) { ts = problem_tiles(a, b); my_tiles = ts.ntq + ts.nsp + 1; }
+    const int t0 = (int)(((long long)jb * my_tiles) / a.nb), t1 = (int)(((long long)(jb + 1) * my_tiles) / a.nb);
+    int role = 0, r0 = 0, r1 = 0, rdummy;
+    if (!a.culled) {
+        tile_info(a, t0, role, r0, rdummy);
+        tile_info(a, t1 - 1, role, rdummy, r1);
+    }
     SolveRow* my_rows = a.blk_rows + ((size_t)(b - a.b0) * a.nb + jb) * a.cap_blk;
     SolveRow* cand = a.qp_rows + (size_t)(b - a.b0) * a.cap_rows;
     unsigned char* is_active = a.flags + (size_t)(b - a.b0) * 2 * (a.cap_rows + 2 * NV);
@@ -774,8 +864,21 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         // ---- evaluate my tiles at x (the tile code of armour_eval_g_jac)
         const double kf = tid < n ? s_x[tid] : 0.0;
         for (int t = t0; t < t1; t++) {
-            int tr0, tr1;
-            tile_info(a, t, role, tr0, tr1);
+            if (a.culled) {
+                if (t >= ts.ntq && t < ts.ntq + ts.nsp) {   // P2_BLOCK listed collision rows, one per thread
+                    KPow& kp = *reinterpret_cast<KPow*>(smem_raw);
+                    fill_kpow(kp, kf, n);
+                    __syncthreads();
+                    const int i = (t - ts.ntq) * P2_BLOCK + tid;
+                    if (i < ts.cnt2) sparse_collision_row<true>(a.tb, a.sl, b, i, kp, g, jac);
+                    __syncthreads();
+                    continue;
+                }
+                role = t < ts.ntq ? a.lp.nbc + a.tq_tiles[(size_t)b * a.tq_cap + t] : a.lp.nbc + a.lp.nbt;
+            } else {
+                int tr0, tr1;
+                tile_info(a, t, role, tr0, tr1);
+            }
             if (role < a.lp.nbc) {
                 // d = A.c recomputed from the obstacle centres where the launch of armour_eval_g_jac does the same (batches of >= 8
                 // problems, whose tables hold no d column: api.hip armour_make_tables) -- the same rows bit for bit either way
@@ -793,7 +896,8 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         __syncthreads();
         long long vfx = 0;
         int cnt = 0, bad = 0;
-        scan_rows<3>(a, b, r0, r1, my_rows, a.cap_blk, scan_sh, vfx, cnt, bad);
+        if (a.culled) scan_tiles(a, b, ts, t0, t1, my_rows, a.cap_blk, scan_sh, vfx, cnt, bad);
+        else scan_rows<3>(a, b, r0, r1, my_rows, a.cap_blk, scan_sh, vfx, cnt, bad);
         BlockWord* mine = a.blk_word + (size_t)(b - a.b0) * a.nb + jb;
         if (tid == 0) { st_coh(&mine->viol, vfx); st_coh(&mine->bad, bad); st_coh(&mine->count, cnt); }
         // ---- group barrier: a flag per block (199 atomics on one counter cost ~10 us per phase; 199 separate words cost nothing).
@@ -852,14 +956,15 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host side
-int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan) {
+int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torque, const unsigned long long* h_skip, int device, int b_launch, int waves_per_simd, SolvePlan* plan,
+                                 int n_tiles_override) {
     P2Launch lp;
     size_t smem = 0;
     bool dfc, six, exact;
     int rc = armour_p2_plan(tb, max_link, max_torque, h_skip, 1, 0, 0, 0, &lp, &smem, &dfc, &six, &exact);
     if (rc != ARMOUR_OK) return rc;
     plan->lp = lp; plan->smem = smem; plan->six = six;
-    plan->n_tiles = lp.nbt + lp.nbc + 1;
+    plan->n_tiles = n_tiles_override > 0 ? n_tiles_override : lp.nbt + lp.nbc + 1;
     int coop = 0;
     HIPCHK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device));
     if (!coop) { plan->capacity = 0; return ARMOUR_OK; }

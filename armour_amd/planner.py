@@ -409,6 +409,16 @@ class ArmourNLP:
         check(self.L.armour_get_row_relevance(self.h, rel.ctypes.data_as(C.POINTER(C.c_uint8)), cnt.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)))
         return rel.astype(bool), cnt, ms.value
 
+    def solver_rows(self):
+        """(mask [B, m] bool, listed collision rows [B], listed torque tiles [B], device ms) -- armour_get_solver_rows: the rows that can pass
+        armour_solve's candidate filter for some k (what its culled device form walks)."""
+        mask = np.zeros((self.B, self.m), dtype=np.uint8)
+        cnt, tq = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        ms = C.c_double()
+        i32 = C.POINTER(C.c_int32)
+        check(self.L.armour_get_solver_rows(self.h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), cnt.ctypes.data_as(i32), tq.ctypes.data_as(i32), C.byref(ms)))
+        return mask.astype(bool), cnt, tq, ms.value
+
     def eval_violations_device(self, d_k, d_out, stream=0):
         """Asynchronous: d_k [B][n] doubles, d_out [B] ArmourViolation records (32 B each), device pointers (ints)."""
         check(self.L.armour_eval_violations_device(self.h, d_k, d_out, stream))

@@ -152,8 +152,11 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_SOLVE_ROW_CAP 145          /* 0 (default) | n: candidate-row buffers of n rows (tests: forces the overflow path) */
 #define ARMOUR_OPT_SOLVE_HARD_CAP_S 146       /* 0 (default: from the time budget / iteration limit) | seconds: wall-clock cap of one persistent launch */
 #define ARMOUR_OPT_SOLVE_WAVES_PER_SIMD 147   /* 0 automatic (default) | 1 | 2: register build of the persistent kernel */
+#define ARMOUR_OPT_SOLVE_CULL 148              /* -1 automatic (default: from 40 000 collision rows in the batch on) | 0 | 1: the device-resident form walks only the rows that can pass
+                                                * its candidate filter for some k (a second, wider mask than armour_get_row_relevance's: g_i + 2 |J_i|_1 can reach the bound); every
+                                                * other row adds nothing the solver reads, so iterates and results are those of the full form bit for bit */
 #define ARMOUR_OPT_FIRST_TUNING 101
-#define ARMOUR_OPT_LAST_TUNING 147
+#define ARMOUR_OPT_LAST_TUNING 148
 /* bytes of device memory free / in all on `device` as the runtime reports them (hipMemGetInfo): what a caller sizes
  * ARMOUR_OPT_P1_WORK_MEMORY_MB against; either pointer may be NULL */
 int armour_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
@@ -254,6 +257,11 @@ int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourViolation* o
  * about 2 % of the collision rows are 1.  n_relevant_collision_rows [B] and ms (device time of the test) may be NULL; so may `relevant`.
  * Computed once per problem set, on the device (relevance.hip).  ARMOUR_OPT_CULL_ROWS = 1 makes armour_eval_violations* use it. */
 int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int32_t* n_relevant_collision_rows, double* ms);
+/* The SOLVER's rows of the current problem set: solver_rows[B][m], 1 = the row can pass armour_solve's candidate filter for some k in [-1,1]^n
+ * (g_i + 2 |J_i|_1 > u_i or g_i - 2 |J_i|_1 < l_i: solver_common.h; the filter leaves out rows that cannot become active within the variables'
+ * box, and this mask the rows it leaves out at EVERY k) -- a superset of armour_get_row_relevance's mask; what the culled device form of armour_solve
+ * walks (ARMOUR_OPT_SOLVE_CULL).  n_collision_rows [B] and n_torque_tiles [B] (listed tiles of 8 torque rows) may be NULL; so may `solver_rows`. */
+int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_tiles, double* ms);
 
 /* ---- in-process multi-device batch ---- */
 /* One caller thread (MATLAB / MEX, a Python host) drives several GPUs: an ArmourBatch owns one ArmourPlanner per entry of `devices`

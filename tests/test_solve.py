@@ -100,6 +100,48 @@ def test_device_resident_solve_equals_the_host_driven_one(seed, O, T, B, monkeyp
         assert _same_solution(a, c), (a, c)
 
 
+@pytest.mark.parametrize("seed,O,T,B", [(8, 30, 100, 3), (5000, 50, 100, 12), (7, 12, 100, 1), (2, 0, 100, 2), (3, 3, 20, 1)])
+def test_culled_device_solve_equals_the_full_one(seed, O, T, B):
+    """ARMOUR_OPT_SOLVE_CULL: the persistent kernel walks only the rows that can pass its candidate filter for some k (relevance.hip: the
+    solver's mask; listed collision rows one per thread from their packed plane entries, listed torque tiles, the limit rows).  Every other
+    row adds nothing the solver reads, and a listed row's g / Jacobian are the fused evaluation's bit for bit -- so k_opt, cost, violation,
+    counts and verdict equal the full device form's and the host form's, for every block count and sub-batch cut."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    bp = random_batch(seed, B, O)
+    nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    host = nlp.solve(host_qp=True)
+    nlp.set_option(_lib.OPT_SOLVE_CULL, 0)
+    full = nlp.solve(device_qp=True)
+    nlp.set_option(_lib.OPT_SOLVE_CULL, 1)
+    for blocks in (0, 1, 3, 64):
+        nlp.set_option(_lib.OPT_SOLVE_BLOCKS, blocks)
+        for b, (h, f, c) in enumerate(zip(host, full, nlp.solve(device_qp=True))):
+            assert _same_solution(f, c) and _same_solution(h, c), (blocks, b, h, f, c)
+    nlp.set_option(_lib.OPT_SOLVE_BLOCKS, 0)
+    if B > 1:
+        nlp.set_option(_lib.OPT_SOLVE_SUB_BATCH, 2)
+        for f, c in zip(full, nlp.solve(device_qp=True)):
+            assert _same_solution(f, c), ("sub-batch", f, c)
+        nlp.set_option(_lib.OPT_SOLVE_SUB_BATCH, 0)
+    for a, c in zip(nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True), nlp.solve(tolerance=1e-7, max_iterations=100, device_qp=True)):
+        assert _same_solution(a, c), (a, c)
+    nlp.close()
+
+
+def test_culled_device_solve_in_armtd_mode():
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem, synthetic_offline_jrs
+    T = 100
+    p = random_problem(4, 8)
+    jrs, kr = synthetic_offline_jrs(p["qd0"], T=T)
+    nlp = ArmourNLP(T=T).set_option(_lib.OPT_SOLVE_CULL, 1).set_parameters_armtd(p["q0"], p["qd0"], p["q_des"], jrs, kr, p["obstacles"])
+    a, c = nlp.solve(host_qp=True)[0], nlp.solve(device_qp=True)[0]
+    assert _same_solution(a, c), (a, c)
+
+
 def test_device_resident_solve_in_armtd_mode():
     from armour_amd.planner import ArmourNLP
     from armour_amd.worlds import random_problem, synthetic_offline_jrs

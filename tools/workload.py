@@ -4,6 +4,7 @@
     python tools/workload.py c4 [K]                    BASELINE configs[4] (Fetch preset, payload +-50 %, O = 100): K fused evaluations x 3
     python tools/workload.py c4_8f [K]                 the 8-factor configs[4] (Fetch 8-DOF; needs ARMOUR_KEY128=1 in the environment)
     python tools/workload.py solve [N]                 the reference's sample problem solved N times by the device-resident armour_solve
+    python tools/workload.py solveb B O [id=value ...] armour_solve of B random worlds (seed 5000), best wall time of 5 per option set; prints the solver rows
     python tools/workload.py cull B O                  armour_eval_violations_device on every row, then on the relevant rows (ARMOUR_OPT_CULL_ROWS)
 `id=value` arguments are per-handle options (include/armour_hip.h).  The handles are closed before interpreter exit (under rocprofv3 a handle
 freed from the exit handlers crashed inside the tool library)."""
@@ -71,6 +72,36 @@ def main(argv):
         for _ in range(N):
             s = nlp.solve(device_qp=True)[0]   # (one problem would take the host-QP form by itself: the persistent kernel is what is profiled)
         print("solved", N, "times:", {k: s[k] for k in ("feasible", "iterations", "evaluations", "status")})
+    elif what == "solveb":
+        import time, gc
+        from armour_amd import _lib
+        from armour_amd.worlds import random_batch
+        B, O = int(args[0]), int(args[1])
+        bp = random_batch(5000, B, O)
+        nlp = _opts(ArmourNLP(T=100), args).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        ref = None
+        for cull in (0, 1, -1):
+            nlp.set_option(_lib.OPT_SOLVE_CULL, cull)
+            nlp.solve()
+            gc.collect(); gc.disable()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); res = nlp.solve(); ts.append(time.perf_counter() - t0)
+            gc.enable()
+            key = [(tuple(r["k_opt"]), r["feasible"], r["iterations"], r["evaluations"], r["status"]) for r in res]
+            ref = ref or key
+            print(f"B={B} O={O} ARMOUR_OPT_SOLVE_CULL={cull}: armour_solve best {min(ts) * 1e3:.3f} ms, median {sorted(ts)[2] * 1e3:.3f} ms; feasible {sum(r['feasible'] for r in res)}, "
+                  f"iterations max {max(r['iterations'] for r in res)}; same results as the full form: {key == ref}", flush=True)
+        # a FRESH problem set: what the first solve after armour_set_problems costs (the lists are built inside it)
+        for cull in (0, 1):
+            nlp.set_option(_lib.OPT_SOLVE_CULL, cull)
+            ts = []
+            for _ in range(3):
+                nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+                t0 = time.perf_counter(); nlp.solve(); ts.append(time.perf_counter() - t0)
+            print(f"   first solve after set_problems, cull={cull}: best {min(ts) * 1e3:.3f} ms", flush=True)
+        mask, cnt, tq, ms = nlp.solver_rows()
+        print(f"   solver rows: collision mean {cnt.mean():.0f} of {nlp.J * nlp.T * O} ({cnt.mean() / max(1, nlp.J * nlp.T * O):.3f}), torque tiles mean {tq.mean():.1f} of {(nlp.n * nlp.T + 7) // 8}; masks + lists {ms:.3f} ms")
     elif what == "cull":
         import torch
         from armour_amd import _lib
