@@ -82,7 +82,7 @@ struct QpResult {
 };
 
 // Goldfarb-Idnani for  min 1/2 x'Gx + g0'x  s.t.  a_i'x >= b_i,  G = diag(Gd) > 0.
-QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = 400) {
+QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = slv::kQpMaxSteps) {
     QpResult res;
     res.iterations = 0; res.feasible = true; res.max_mult = 0;
     double x[NV], invG[NV];
@@ -384,7 +384,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     }
     if ((rc = grow_dev(&w.blk_rows, &w.blk_rows_cap, (size_t)Bs * nb * cap_blk * sizeof(SolveRow))) != ARMOUR_OK) return rc;
     if ((rc = grow_dev(&w.qp_rows, &w.qp_rows_cap, (size_t)Bs * cap_rows * sizeof(SolveRow))) != ARMOUR_OK) return rc;
-    if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)Bs * 2 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;
+    if ((rc = grow_dev(&w.flags, &w.flags_cap, (size_t)Bs * 8 * (cap_rows + 2 * NV))) != ARMOUR_OK) return rc;   // (active / excluded) x the four QP attempts
     ArmourSolveResult* hres = reinterpret_cast<ArmourSolveResult*>(armour_handle_pinned(h, 1, (size_t)B * sizeof(ArmourSolveResult)));
     unsigned char* hblock = reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 2, block_bytes));
     if (!hres || !hblock) return ARMOUR_EDEVICE;
@@ -396,6 +396,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     SolveArgs a;
     memset(&a, 0, sizeof(a));
     a.tb = tb; a.lp = plan.lp; a.nb = nb; a.n_tiles = plan.n_tiles; a.cap_blk = cap_blk; a.cap_rows = cap_rows;
+    a.lds_rows = (int)(plan.smem / ((NV + 1) * sizeof(double)));
     a.culled = culled ? 1 : 0; a.sl = sl; a.tq_tiles = tq_tiles; a.tq_count = tq_count; a.tq_cap = tq_cap;
     a.lo = h->d_bounds; a.hi = h->d_bounds + (size_t)B * m; a.g = h->d_g; a.jac = h->d_jac;
     a.ctl = reinterpret_cast<SolveCtl*>(w.ctl); a.blk_word = reinterpret_cast<BlockWord*>(w.blk_word);
@@ -447,12 +448,21 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
                             n_tiles_culled, h->h_rel2_count[0], h->Q, h->h_rel2_tq_count[0], plan.lp.nbt, h->rel_ms, h->rel2_ms);
         fprintf(stderr, "[armour_solve, device form] B=%d in %d launch(es) of <= %d problems: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, n_launch, Bs, nb, plan.n_tiles, ms,
                 std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
-        for (int i = 0; i < 32 && (i < 2 || hstamps[i]); i++) fprintf(stderr, " %.1f", hstamps[i] / plan.ticks_per_ms * 1e3);
-        fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)", hstamps[32] / plan.ticks_per_ms * 1e3,
-                hstamps[33] / plan.ticks_per_ms * 1e3, hstamps[34] / plan.ticks_per_ms * 1e3, hstamps[40], hstamps[41]);
-        fprintf(stderr, " | QP parts of problem 0, all steps, us: row search %.1f, entering row %.1f, M + rhs %.1f, factor + solves %.1f, z + step lengths %.1f, update %.1f, closing barrier %.1f\n",
-                hstamps[44] / plan.ticks_per_ms * 1e3, hstamps[45] / plan.ticks_per_ms * 1e3, hstamps[46] / plan.ticks_per_ms * 1e3, hstamps[47] / plan.ticks_per_ms * 1e3,
-                hstamps[48] / plan.ticks_per_ms * 1e3, hstamps[49] / plan.ticks_per_ms * 1e3, hstamps[50] / plan.ticks_per_ms * 1e3);
+        int bs = 0;   // the problem whose group left last: what the launch waited for
+        for (int b = 1; b < B; b++) if (hres[b].time_ms > hres[bs].time_ms) bs = b;
+        for (int which = 0; which < 2; which++) {
+            const int b = which == 0 ? 0 : bs;
+            const long long* st = hstamps + (size_t)b * 64;
+            if (which == 1) fprintf(stderr, "\n   slowest problem %d: kernel %.3f ms, %d iterations, %d evaluations, status %d, %lld QP solves with %lld steps in all; phases in us:", b, hres[b].time_ms / plan.ticks_per_ms,
+                                    hres[b].iterations, hres[b].evaluations, hres[b].status, st[43], st[42]);
+            for (int i = 0; i < 32 && (i < 2 || st[i]); i++) fprintf(stderr, " %.1f", st[i] / plan.ticks_per_ms * 1e3);
+            fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)", st[32] / plan.ticks_per_ms * 1e3,
+                    st[33] / plan.ticks_per_ms * 1e3, st[34] / plan.ticks_per_ms * 1e3, st[40], st[41]);
+            fprintf(stderr, " | QP steps by attempt (sigma 0, 0.5, 0.9, 0.99), all solves: %lld %lld %lld %lld", st[44], st[45], st[46], st[47]);
+        }
+        long long longest_ok = 0, long_bad = 0, steps_all = 0;
+        for (int b = 0; b < B; b++) { const long long* st = hstamps + (size_t)b * 64; longest_ok = std::max(longest_ok, st[48]); long_bad += st[49]; steps_all += st[44] + st[45] + st[46] + st[47]; }
+        fprintf(stderr, "\n   all problems: %lld QP steps; longest attempt that ended feasible %lld steps; attempts of more than 60 steps that ended infeasible: %lld\n", steps_all, longest_ok, long_bad);
     }
     for (int b = 0; b < B; b++) { results[b] = hres[b]; results[b].time_ms = ms; }
     return 1;

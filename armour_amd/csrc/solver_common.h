@@ -36,6 +36,12 @@ __host__ __device__ inline long long row_violation(double gi, double li, double 
     return 0;
 }
 
+// Steps one QP attempt may take before it is given up as infeasible (and the next elastic attempt is tried).  An attempt that ends feasible takes
+// <= 18 steps on every problem tried (<= 8 variables: each step adds or drops one row); the attempts that run longer are cycling on degenerate
+// rows and never end feasible -- round 5 counted them over batches of 64 ... 256 random worlds, O = 10 ... 50: 0 ... 3 per batch, every one ran
+// into the limit, which was 400 until then.  Since the row culling a batch waits for its slowest leader, i.e. for exactly those attempts.
+constexpr int kQpMaxSteps = 100;
+
 // a row that cannot become active for any |d|_inf <= 2 is left out of the QP (l1 = sum_j |J_ij|)
 __host__ __device__ inline bool row_upper_candidate(double gi, double ui, double l1) { return ui < 1e18 && gi + 2.0 * l1 > ui; }
 __host__ __device__ inline bool row_lower_candidate(double gi, double li, double l1) { return li > -1e18 && gi - 2.0 * l1 < li; }

@@ -33,6 +33,7 @@ struct SolveArgs {
     int b0;                        // first problem of this launch: a batch too large to give every problem enough co-resident blocks runs as
                                    // several launches back to back, each over problems [b0, b0 + gridDim.x / nb) of the same tables
     int cap_blk, cap_rows;         // candidate rows a block / a problem may hand over
+    int lds_rows;                  // candidate rows the dynamic LDS holds during the leader's step (NV + 1 doubles each)
     const double* lo; const double* hi;   // bounds [B][m]
     double* g; double* jac;        // [B][m], [B][m][n]
     SolveCtl* ctl;                 // [B]

@@ -21,6 +21,7 @@
 // candidate rows in the same order: both forms produce the same iterates (tests/test_solve.py compares k_opt bit for bit).
 // Problems of a batch no longer run in lock step: each group proceeds, converges and leaves on its own.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -316,7 +317,7 @@ __device__ inline void qp_row(const SolveArgs& a, const Leader& L, const SolveRo
 //     numbers are those of the from-scratch factorisation the host form does at every step.
 template <int WPS>   // (one copy per compiled occupancy, see leader_step)
 __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const SolveRow* cand, unsigned char* is_active_g, unsigned char* excluded_g,
-                                       int max_iter = 400) {
+                                       int max_iter = kQpMaxSteps) {
     const int n = a.tb.n, tid = threadIdx.x;
     const int mrows = L.ncand + 2 * n;
     unsigned char* is_active = mrows <= kFlagsInLds ? L.act : is_active_g;
@@ -338,7 +339,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
     for (int j = 0; j < NV; j++) { qx[j] = j < n ? L.qx[j] : 0.0; u[j] = 0.0; }
     u[NV] = 0.0;
     int q = 0, cv = 0;
-    long long* qst = a.stamps && blockIdx.x == 0 ? a.stamps + 44 : nullptr;   // ARMOUR_SOLVE_TIMING: ticks per part of the QP step, summed over the steps
+    long long* qst = a.stamps ? a.stamps + (size_t)(blockIdx.x / a.nb + a.b0) * 64 + 44 : nullptr;   // ARMOUR_SOLVE_TIMING: ticks per part of the QP step, summed over the steps
     long long q_t = qst ? wall_clock64() : 0;
 #define QP_LAP(slot) if (qst && tid == 0) { const long long n__ = wall_clock64(); qst[slot] += n__ - q_t; q_t = n__; }
     for (;;) {
@@ -607,6 +608,323 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
     __syncthreads();
 }
 
+__device__ inline int ld_lds_int(const int* p) { return *reinterpret_cast<const volatile int*>(p); }
+// ---- the four elastic attempts of one QP side by side, one per wave ------------------------------------------------------------------
+// solver.hip tries sigma = 0, 0.5, 0.9, 0.99 one after the other and keeps the first attempt that is feasible; the attempts share nothing but
+// their input (each starts from the unconstrained minimiser with an empty active set), so here wave w runs attempt w on a state of its own
+// and the leader takes the lowest-numbered feasible one: the same numbers as the sequential form, in the time of the longest attempt that
+// matters instead of the sum (an infeasible problem pays all four at every SQP iteration -- after the row culling that was what a batch waited
+// for).  A wave that finishes feasible tells the attempts above it to stop.  Inside an attempt nothing crosses waves: the search for the most
+// violated row runs on the wave's 64 lanes (with at most 64 * kRegRows rows every lane keeps its rows in registers across the steps; more: it
+// reads them four at a time), the step is the lockstep code of solve_qp_device on the wave's own LDS state, and there is no block barrier
+// until all four are done.
+struct QpWave {
+    double qx[NV], An[NV][NV], np[NV], M[NV * NV], Lc[NV][NV], Lci[NV], rhs[NV];
+    double bp, max_mult;
+    int A[NV], q, qp_iter, feasible;
+    unsigned char act[kFlagsInLds], exc[kFlagsInLds];
+};
+struct QpShared {
+    QpWave w[4];
+    int first_ok;     // lowest attempt that has finished feasible so far (4: none)
+};
+__device__ inline double attempt_sigma(int attempt) { return attempt == 0 ? 0.0 : attempt == 1 ? 0.5 : attempt == 2 ? 0.9 : 0.99; }
+// QP row i of the attempt with elasticity sigma (qp_row with the attempt's own sigma)
+__device__ inline void qp_row_s(const SolveArgs& a, const Leader& L, const SolveRow* cand, int i, double sigma, double* arow, double& brow) {
+    if (i < L.ncand) {
+        const SolveRow& r = cand[i];
+#pragma unroll
+        for (int j = 0; j < NV; j++) arow[j] = r.a[j];
+        const double v = r.v;
+        brow = v - (v > 0 ? sigma * v : 0.0);
+    } else {
+        const int e = i - L.ncand, j = e >> 1;
+        const double sg = (e & 1) == 0 ? 1.0 : -1.0;
+#pragma unroll
+        for (int jj = 0; jj < NV; jj++) arow[jj] = jj == j ? sg : 0.0;
+        brow = (e & 1) == 0 ? -1.0 - L.x[j] : -(1.0 - L.x[j]);
+    }
+}
+template <int WPS>
+__device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShared& S, const SolveRow* cand, const double* lds_rows, unsigned char* flags_g, int max_iter = kQpMaxSteps) {
+    constexpr int kRegRows = WPS == 1 ? 4 : 2;   // rows a lane keeps in registers (the two-waves-per-SIMD build has 256 registers for everything)
+    const int n = a.tb.n, lane = threadIdx.x & 63, attempt = threadIdx.x >> 6;
+    QpWave& W = S.w[attempt];
+    const double sigma = attempt_sigma(attempt);
+    const int mrows = L.ncand + 2 * n;
+    unsigned char* is_active = mrows <= kFlagsInLds ? W.act : flags_g + (size_t)(2 * attempt) * (a.cap_rows + 2 * NV);
+    unsigned char* excluded = mrows <= kFlagsInLds ? W.exc : flags_g + (size_t)(2 * attempt + 1) * (a.cap_rows + 2 * NV);
+    for (int i = lane; i < mrows; i += 64) { is_active[i] = 0; excluded[i] = 0; }
+    const bool reg_rows = mrows <= 64 * kRegRows;
+    // a row of the QP: from the candidates staged in LDS (component-major: lanes read consecutive words) when they fit, from global memory otherwise
+    auto load_row = [&](int i, double* arow, double& brow) {
+        if (lds_rows && i < L.ncand) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) arow[j] = lds_rows[(size_t)j * a.lds_rows + i];
+            const double v = lds_rows[(size_t)NV * a.lds_rows + i];
+            brow = v - (v > 0 ? sigma * v : 0.0);
+        } else qp_row_s(a, L, cand, i, sigma, arow, brow);
+    };
+    double my_a[kRegRows][NV], my_b[kRegRows];
+#pragma unroll
+    for (int r = 0; r < kRegRows; r++) {
+        my_b[r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) my_a[r][j] = 0.0;
+        if (reg_rows && lane + 64 * r < mrows) load_row(lane + 64 * r, my_a[r], my_b[r]);
+    }
+    // the wave's QP state, the same values in all of its lanes: iterate, multipliers, active count, valid rows of the Cholesky factor
+    double qx[NV], u[NV + 1], ih[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) { ih[j] = L.invHd[j]; qx[j] = j < n ? -L.gradf[j] * ih[j] : 0.0; u[j] = 0.0; }
+    u[NV] = 0.0;
+    int q = 0, cv = 0, qp_iter = 0;
+    bool feasible = true, stop = false;
+    WAVE_LDS_SYNC();
+    while (!stop) {
+        if (ld_lds_int(&S.first_ok) < attempt) { feasible = false; break; }   // a lower attempt is feasible: this one is not needed
+        // most violated inactive row: smallest s = a_i'x - b_i below -1e-10, the first such row on ties
+        double best = -1e-10;
+        int bi = -1;
+        if (reg_rows) {
+#pragma unroll
+            for (int r = 0; r < kRegRows; r++) {
+                const int i = lane + 64 * r;
+                if (i < mrows && !is_active[i] && !excluded[i]) {
+                    double s = -my_b[r];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) if (j < n) s += my_a[r][j] * qx[j];
+                    if (s < best) { best = s; bi = i; }
+                }
+            }
+        } else {
+            for (int i0 = lane; i0 < mrows; i0 += 4 * 64) {   // four rows of a lane requested together (a row is 72 bytes of global memory)
+                double ar[4][NV], br[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) load_row(min(i0 + 64 * e, mrows - 1), ar[e], br[e]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = i0 + 64 * e;
+                    if (i < mrows && !is_active[i] && !excluded[i]) {
+                        double s = -br[e];
+#pragma unroll
+                        for (int j = 0; j < NV; j++) if (j < n) s += ar[e][j] * qx[j];
+                        if (s < best) { best = s; bi = i; }
+                    }
+                }
+            }
+        }
+        // lexicographic (value, index) minimum: the sequential scan keeps the FIRST row attaining the minimum
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
+        }
+        const int p = __builtin_amdgcn_readfirstlane(bi);
+        if (p < 0) break;
+        if (++qp_iter > max_iter) { feasible = false; break; }
+        // the entering row's normal and right-hand side, in every lane
+        double npr[NV], bp;
+        if (reg_rows) {
+            const int slot = p >> 6, src = p & 63;
+            double v[NV + 1];
+#pragma unroll
+            for (int j = 0; j <= NV; j++) v[j] = 0.0;
+#pragma unroll
+            for (int r = 0; r < kRegRows; r++) {
+                if (slot == r) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) v[j] = my_a[r][j];
+                    v[NV] = my_b[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j++) npr[j] = __shfl(v[j], src, 64);
+            bp = __shfl(v[NV], src, 64);
+        } else {
+            load_row(p, npr, bp);
+        }
+        if (lane < NV) W.np[lane] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) if (lane == j) W.np[j] = npr[j];
+        double up = 0.0;
+        bool added = false;
+        for (int guard = 0; guard < 4 * NV + 8 && !added; guard++) {
+            // r = N* np,  z = G^-1 (np - N r)
+            double rr[NV];
+#pragma unroll
+            for (int i = 0; i < NV; i++) rr[i] = 0.0;
+            WAVE_LDS_SYNC();
+            if (q > 0) {
+                if (lane < NV * NV) {
+                    const int i = lane / NV, k = lane - i * NV;
+                    if (i < q && k <= i) {
+                        double s = 0;
+#pragma unroll
+                        for (int j = 0; j < NV; j++) if (j < n) s += W.An[i][j] * W.An[k][j] * ih[j];
+                        W.M[i * NV + k] = s; W.M[k * NV + i] = s;
+                    }
+                } else if (lane < NV * NV + NV) {
+                    const int i = lane - NV * NV;
+                    if (i < q) {
+                        double s = 0;
+#pragma unroll
+                        for (int j = 0; j < NV; j++) if (j < n) s += W.An[i][j] * npr[j] * ih[j];
+                        W.rhs[i] = s;
+                    }
+                }
+                WAVE_LDS_SYNC();
+                // Cholesky M = Lc Lc' (spd_solve of solver.hip), rows [cv, q) new, in registers
+                double Lr[NV][NV], Li[NV];
+#pragma unroll
+                for (int i = 0; i < NV; i++) {
+                    Li[i] = i < cv ? W.Lci[i] : 0.0;
+#pragma unroll
+                    for (int k = 0; k <= i; k++) Lr[i][k] = i < cv ? W.Lc[i][k] : 0.0;
+                }
+                bool spd = true;
+#pragma unroll
+                for (int i = 0; i < NV; i++) {
+                    if (i >= cv && i < q && spd) {
+#pragma unroll
+                        for (int jj = 0; jj <= i; jj++) {
+                            if (spd) {
+                                double s = W.M[i * NV + jj];
+#pragma unroll
+                                for (int k = 0; k < jj; k++) s -= Lr[i][k] * Lr[jj][k];
+                                if (jj == i) {
+                                    if (s <= 1e-14 * fabs(W.M[i * NV + i]) || s <= 0) spd = false;
+                                    else { Lr[i][i] = sqrt(s); Li[i] = 1.0 / Lr[i][i]; }
+                                } else {
+                                    Lr[i][jj] = s * Li[jj];
+                                }
+                            }
+                        }
+                        if (spd) {
+#pragma unroll
+                            for (int k = 0; k <= i; k++) W.Lc[i][k] = Lr[i][k];
+                            W.Lci[i] = Li[i];
+                            cv = i + 1;
+                        }
+                    }
+                }
+                if (!spd) { if (lane == 0) excluded[p] = 1; break; }  // dependent active set: skip this row
+                double tt[NV];
+#pragma unroll
+                for (int i = 0; i < NV; i++) {
+                    tt[i] = 0.0;
+                    if (i < q) {
+                        double s = W.rhs[i];
+#pragma unroll
+                        for (int k = 0; k < i; k++) s -= Lr[i][k] * tt[k];
+                        tt[i] = s * Li[i];
+                    }
+                }
+#pragma unroll
+                for (int i = NV - 1; i >= 0; i--) {
+                    if (i < q) {
+                        double s = tt[i];
+#pragma unroll
+                        for (int k = i + 1; k < NV; k++) if (k < q) s -= Lr[k][i] * rr[k];
+                        rr[i] = s * Li[i];
+                    }
+                }
+            }
+            // z: lane j forms entry j (np_j - sum_i An[i][j] r_i in row order, times 1/Hd_j), then every lane takes all of them
+            double zmine = 0.0;
+            {
+                const int j = lane < NV ? lane : 0;
+                double s = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < NV; jj++) if (jj == j) s = npr[jj];
+#pragma unroll
+                for (int i = 0; i < NV; i++) if (i < q) s -= W.An[i][j] * rr[i];
+                double ihj = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < NV; jj++) if (jj == j) ihj = ih[jj];
+                zmine = s * ihj;
+            }
+            double z[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) z[j] = j < n ? __shfl(zmine, j, 64) : 0.0;
+            double zz = 0, znp = 0;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (j < n) { zz += z[j] * z[j]; znp += z[j] * npr[j]; }
+            // step lengths
+            double t1 = kInf;
+            int l = -1;
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                if (i < q && rr[i] > 1e-14) { const double ur = u[i] / rr[i]; if (ur < t1) { t1 = ur; l = i; } }
+            double sp = -bp;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (j < n) sp += npr[j] * qx[j];
+            double t2 = kInf;
+            if (zz > 1e-24 && znp > 1e-16) t2 = -sp / znp;
+            if (t2 < 0) t2 = 0;
+            const double t = t1 < t2 ? t1 : t2;
+            if (t >= kInf) { feasible = false; break; }
+            const bool dual_only = t2 >= kInf;
+            if (!dual_only) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) if (j < n) qx[j] += t * z[j];
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i++) if (i < q) u[i] -= t * rr[i];
+            up += t;
+            if (!dual_only && t == t2) {  // full step: the row becomes active
+                if (q >= n) { feasible = false; break; }
+#pragma unroll
+                for (int i = 0; i < NV; i++) if (i == q) u[i] = up;
+                if (lane < NV) W.An[q][lane] = W.np[lane];
+                if (lane == 0) { W.A[q] = p; is_active[p] = 1; }
+                q++;
+                added = true;
+            } else {        // dual step only, or a partial step: drop the blocking row (and try again)
+                if (lane == 0) is_active[W.A[l]] = 0;
+                WAVE_LDS_SYNC();
+                for (int i = l; i < q - 1; i++) {   // (rare; rows move up one by one, every lane a column)
+                    if (lane < NV) W.An[i][lane] = W.An[i + 1][lane];
+                    if (lane == 0) W.A[i] = W.A[i + 1];
+                    WAVE_LDS_SYNC();
+                }
+#pragma unroll
+                for (int i = 0; i < NV; i++) if (i >= l && i < q - 1) u[i] = u[i + 1];
+                q--;
+                if (cv > l) cv = l;
+            }
+        }
+        if (!feasible) break;
+        WAVE_LDS_SYNC();
+        if (!added && !excluded[p]) { WAVE_LDS_SYNC(); if (lane == 0) excluded[p] = 1; }  // could not make progress on this row
+        WAVE_LDS_SYNC();
+    }
+    // excluded rows that remain violated mean the linearisation is inconsistent
+    if (feasible) {
+        int viol = 0;
+        for (int i = lane; i < mrows; i += 64) {
+            if (!excluded[i]) continue;
+            double ar[NV], br;
+            load_row(i, ar, br);
+            double s = -br;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (j < n) s += ar[j] * qx[j];
+            if (s < -1e-7) viol = 1;
+        }
+        if (__ballot(viol != 0) != 0ull) feasible = false;
+    }
+    double mm = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) if (i < q && u[i] > mm) mm = u[i];
+    if (lane == 0) {
+        W.q = q; W.qp_iter = qp_iter; W.feasible = feasible ? 1 : 0; W.max_mult = mm;
+        if (feasible) atomicMin(&S.first_ok, attempt);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) if (lane == j) W.qx[j] = qx[j];
+}
+
 // gather the candidate rows of all blocks of the group, in block (= row) order, into the problem's contiguous buffer
 __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, SolveRow* cand) {
     const int tid = threadIdx.x, nb = a.nb;
@@ -665,8 +983,8 @@ __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, S
 // (WPS: one copy per compiled occupancy -- the compiler keeps this function out of line, and a copy shared by both kernel builds would be
 // compiled to the tighter register budget of the two)
 template <int WPS>
-__device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long long viol_fx, int bad, SolveRow* cand,
-                                  unsigned char* is_active, unsigned char* excluded, double* x_pub) {
+__device__ inline int leader_step(const SolveArgs& a, Leader& L, QpShared& QS, int b, long long viol_fx, int bad, SolveRow* cand,
+                                  unsigned char* flags_g, double* x_pub, double* lds_stage) {
     const int n = a.tb.n, tid = threadIdx.x;
     const double viol = viol_from_fixed(viol_fx);
 #define LSTAMP(k) do { if (a.stamps && tid == 0 && first) a.stamps[(size_t)b * 64 + 32 + (k)] = wall_clock64() - L.t_start; } while (0)
@@ -722,17 +1040,55 @@ __device__ inline int leader_step(const SolveArgs& a, Leader& L, int b, long lon
         }
         if (!finish) {
             LSTAMP(1);
-            // QP with the elastic retries of solver.hip (sigma = fraction of the violation a row may keep)
+            // QP with the elastic retries of solver.hip (sigma = fraction of the violation a row may keep): the four attempts side by side,
+            // one per wave, the lowest feasible one taken (solve_qp_wave)
+#ifdef SOLVE_QP_SEQUENTIAL   // (development: the attempts one after the other on the whole block, rounds 2-4)
             for (int attempt = 0; attempt < 4; attempt++) {
-                if (tid == 0) L.sigma = attempt == 0 ? 0.0 : attempt == 1 ? 0.5 : attempt == 2 ? 0.9 : 0.99;
+                if (tid == 0) L.sigma = attempt_sigma(attempt);
                 __syncthreads();
-                solve_qp_device<WPS>(a, L, cand, is_active, excluded);
+                solve_qp_device<WPS>(a, L, cand, flags_g, flags_g + (a.cap_rows + 2 * NV));
                 if (L.feasible) break;
                 __syncthreads();
             }
             __syncthreads();
+#else
+            if (tid == 0) {
+                QS.first_ok = 4;
+                for (int j = 0; j < NV; j++) L.invHd[j] = 1.0 / L.Hd[j];
+            }
+            // the candidates' normals and values once more in LDS (the tiles' scratch, idle during the leader's step), component-major: what the
+            // four attempts' searches read at every step -- from global memory a step of a 2 000-row QP waited ten load latencies
+            const double* staged = nullptr;
+            if (L.ncand > 64 * (WPS == 1 ? 4 : 2) - 2 * n && L.ncand <= a.lds_rows) {
+                for (int i = tid; i < L.ncand; i += 256) {
+                    const SolveRow& r = cand[i];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) lds_stage[(size_t)j * a.lds_rows + i] = r.a[j];
+                    lds_stage[(size_t)NV * a.lds_rows + i] = r.v;
+                }
+                staged = lds_stage;
+            }
+            __syncthreads();
+            solve_qp_wave<WPS>(a, L, QS, cand, staged, flags_g);
+            __syncthreads();
+            if (tid == 0) {
+                int k = 0;
+                while (k < 3 && !QS.w[k].feasible) k++;
+                const QpWave& W = QS.w[k];
+                for (int j = 0; j < NV; j++) L.qx[j] = W.qx[j];
+                L.max_mult = W.max_mult; L.feasible = W.feasible; L.sigma = attempt_sigma(k); L.qp_iter = W.qp_iter;
+                if (a.stamps) {
+                    for (int e = 0; e < 4; e++) {
+                        a.stamps[(size_t)b * 64 + 44 + e] += QS.w[e].qp_iter;   // steps per attempt, summed over the solves
+                        if (QS.w[e].feasible && QS.w[e].qp_iter > a.stamps[(size_t)b * 64 + 48]) a.stamps[(size_t)b * 64 + 48] = QS.w[e].qp_iter;   // longest attempt that ended feasible
+                        if (QS.w[e].qp_iter > 60 && !QS.w[e].feasible) a.stamps[(size_t)b * 64 + 49] += 1;   // attempts that ran long and ended infeasible
+                    }
+                }
+            }
+            __syncthreads();
+#endif
             LSTAMP(2);
-            if (tid == 0 && a.stamps && L.it == 0) { a.stamps[(size_t)b * 64 + 40] = L.qp_iter; a.stamps[(size_t)b * 64 + 41] = L.ncand; }
+            if (tid == 0 && a.stamps) { if (L.it == 0) { a.stamps[(size_t)b * 64 + 40] = L.qp_iter; a.stamps[(size_t)b * 64 + 41] = L.ncand; } a.stamps[(size_t)b * 64 + 42] += L.qp_iter; a.stamps[(size_t)b * 64 + 43] += 1; }
             if (tid == 0) {
                 if (!L.feasible) { L.status = 3; L.stop = 1; }
                 else {
@@ -794,6 +1150,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ ScanShared scan_sh;
     __shared__ Leader L;
+    __shared__ QpShared QS;
     __shared__ int s_cmd;
     __shared__ double s_x[NV];
     const int tid = threadIdx.x;
@@ -814,8 +1171,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     }
     SolveRow* my_rows = a.blk_rows + ((size_t)(b - a.b0) * a.nb + jb) * a.cap_blk;
     SolveRow* cand = a.qp_rows + (size_t)(b - a.b0) * a.cap_rows;
-    unsigned char* is_active = a.flags + (size_t)(b - a.b0) * 2 * (a.cap_rows + 2 * NV);
-    unsigned char* excluded = is_active + (a.cap_rows + 2 * NV);
+    unsigned char* flags_g = a.flags + (size_t)(b - a.b0) * 8 * (a.cap_rows + 2 * NV);   // active / excluded flags of the four QP attempts when they outgrow LDS
     double* g = a.g + (size_t)b * m;
     double* jac = a.jac + (size_t)b * m * n;
     if (leader && tid < 3 * NV) L.bz[tid] = tid < 3 * n ? a.tb.bez[(size_t)b * 3 * n + tid] : 0.0;
@@ -943,7 +1299,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
             __syncthreads();
         }
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1)] = wall_clock64() - L.t_start;      // barrier passed
-        const int next = leader_step<WPS>(a, L, b, viol_fx, nbad, cand, is_active, excluded, c->x);
+        const int next = leader_step<WPS>(a, L, QS, b, viol_fx, nbad, cand, flags_g, c->x, reinterpret_cast<double*>(smem_raw));
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1) + 1] = wall_clock64() - L.t_start;  // leader step done
         if (tid == 0) {
             wait_my_memory_ops();                          // x is at the memory side ...
@@ -974,16 +1330,29 @@ int armour_solve_device_capacity(const P2Tables& tb, int max_link, int max_torqu
     const void* fn1 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 1> : six ? (const void*)armour_solve_kernel<true, 6, 1> : (const void*)armour_solve_kernel<true, 9, 1>;
     const void* fn2 = !tb.ll_shared ? (const void*)armour_solve_kernel<false, 9, 2> : six ? (const void*)armour_solve_kernel<true, 6, 2> : (const void*)armour_solve_kernel<true, 9, 2>;
     const int wps_env = waves_per_simd;   // ARMOUR_OPT_SOLVE_WAVES_PER_SIMD (0: automatic)
+    // dynamic LDS: the tiles' scratch, and during the leader's step the staged candidate rows of the QP (8 (NV + 1) bytes a row): as much as the
+    // occupancy leaves -- one block per CU: 96 KB (1 365 rows), two: 40 KB (568 rows); the kernel holds 29 KB of its own
+    const size_t smem1 = std::max(smem, (size_t)96 * 1024), smem2 = std::max(smem, (size_t)40 * 1024);
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn1, P2_BLOCK, smem));
+    {   // (per kernel function and device, once: the attribute call is a driver round trip and a lone solve is 0.14 ms)
+        static std::atomic<unsigned long long> set1[3], set2[3];
+        const int which = !tb.ll_shared ? 0 : six ? 1 : 2;
+        const unsigned long long bit = 1ull << (device & 63);
+        if (smem1 > 96 * 1024 || !(set1[which].load() & bit)) { HIPCHK(hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1)); set1[which].fetch_or(bit); }
+        if (smem2 > 40 * 1024 || !(set2[which].load() & bit)) { HIPCHK(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)); set2[which].fetch_or(bit); }
+    }
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn1, P2_BLOCK, smem1));
     const int cap1 = per_cu * prop.multiProcessorCount;
     // (B = 16, O = 20: 16 blocks of 20 tiles per problem in the one-per-CU build: 0.83 ms; 32 blocks of 10 tiles in the other: 1.00 ms -- the
     //  leader's serial QP weighs more than the tiles; at B = 128 it is the other way round: 14.7 against 9.8 ms)
     const int blocks1 = cap1 / std::max(1, b_launch);
-    const bool one = wps_env ? wps_env == 1 : (blocks1 >= 1 && (plan->n_tiles + blocks1 - 1) / blocks1 <= 24);
+    // (the culled form's tiles are few and cheap -- what a phase costs there is the leader's QP: one block per CU whenever the batch fits;
+    //  B = 128, O = 50: 5.6 against 6.7 ms, B = 64, O = 20: 4.4 against 5.9)
+    const bool one = wps_env ? wps_env == 1 : (blocks1 >= 1 && (n_tiles_override > 0 || (plan->n_tiles + blocks1 - 1) / blocks1 <= 24));
     const void* fn = one ? fn1 : fn2;
     plan->fn = fn;
-    if (!one) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P2_BLOCK, smem));
+    plan->smem = one ? smem1 : smem2;
+    if (!one) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P2_BLOCK, smem2));
     plan->capacity = per_cu * prop.multiProcessorCount;
     int rate_khz = 0;
     HIPCHK(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device));
