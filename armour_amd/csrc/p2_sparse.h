@@ -104,4 +104,40 @@ __device__ inline void sparse_collision_row(const P2Tables& tb, const SparseList
     }
 }
 
+// Torque row `row` (= t * n + j) of problem b on ONE thread: the sums of p2_tiles.h's torque_block in its order -- every monomial's value and
+// partials by mono_all, the value summed from the centre in table order and centred on the interval (RT/PZsparse.cu:404-435), each partial summed
+// from 0 in table order (:454-472) -- so g and the Jacobian row are the fused evaluation's bit for bit.  For the culled solver: 256 listed rows
+// per pass instead of 8 rows per tile of 32 monomial lanes.
+__device__ inline void sparse_torque_row(const P2Tables& tb, int b, int row, int strideT, const KPow& kp, double* __restrict__ g, double* __restrict__ jac) {
+    const int n = tb.n, T = tb.T;
+    const int t = row / n, j = row - t * n;
+    const size_t idx = ((size_t)b * n + j) * T + t;
+    const int cnt = min(tb.tq_count[idx], strideT);
+    double cen = tb.tq_center[idx];
+    double gr[ARMOUR_MAX_FACTORS];
+#pragma unroll
+    for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) gr[kk] = 0.0;
+    const uint32_t* keys = tb.tq_keys + idx * tb.capT;
+    const double* co = tb.tq_coeff + idx * tb.capT;
+    const int cmax = cnt > 0 ? cnt - 1 : 0;
+    for (int m0 = 0; m0 < cnt; m0 += 4) {   // four monomials' table entries requested before they are used
+        uint32_t key[4]; double c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int mo = min(m0 + u, cmax); key[u] = keys[mo]; c[u] = co[mo]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (m0 + u < cnt) {
+                double o8[P2_TQW];
+                mono_all<true>(kp, key[u], c[u], n, o8);
+                cen += o8[0];
+#pragma unroll
+                for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) gr[kk] += o8[1 + kk];
+            }
+        }
+    }
+    g[row] = interval_center(cen, tb.tq_indep[idx]);
+#pragma unroll
+    for (int kk = 0; kk < ARMOUR_MAX_FACTORS; kk++) if (kk < n) jac[(size_t)row * n + kk] = gr[kk];
+}
+
 }  // namespace p2

@@ -35,7 +35,7 @@ struct RelTables {
     const double* lo; const double* hi;   // [B][m] bounds (uploaded: armour_upload_bounds)
     unsigned char* rel;                   // [B][m]
     unsigned char* rel2;                  // [B][m] the solver's mask: rows that can pass armour_solve's candidate filter for SOME k (a superset of rel), or null
-    int* tq_tiles; int* tq_count; int tq_cap;   // torque tiles (P2_TQ_ROWS rows each) holding a row of rel2, ascending: [B][tq_cap] | [B]
+    int* tq_tiles; int* tq_count; int tq_cap;   // the torque ROWS of the mask, ascending: [B][tq_cap] | [B]
     int* rows; int* count;                // [B][Q] relevant collision rows in ascending order | [B]
     int* rows_res; int* count_res;        // the same rows by (row0 + q) mod 256, ascending within a class: [B][256][ceil(Q / 256)] | [B][256]
     // the half-space entries of the listed rows, PACKED: problem b's block starts at packed + pack_off[2 b] doubles and holds, for its j-th live
@@ -183,22 +183,20 @@ __global__ __launch_bounds__(256) void armour_rel_list_kernel(RelTables a) {
     }
     if (tid == 0) a.count[b] = base;
     if (a.rows_res) a.count_res[(size_t)b * 256 + tid] = cres[tid];
-    // the torque tiles (P2_TQ_ROWS consecutive rows, the tiles of p2_tiles.h torque_block) that hold a row of the mask, ascending
+    // the torque rows of the mask, ascending
     if (a.tq_tiles) {
         const unsigned char* relt = a.rel + (size_t)b * tb.m;
-        const int ntile = (tb.row0 + P2_TQ_ROWS - 1) / P2_TQ_ROWS;
         int tbase = 0;
         __syncthreads();
-        for (int t0 = 0; t0 < ntile; t0 += 256) {
-            const int t = t0 + tid;
-            bool f = false;
-            if (t < ntile) for (int r = t * P2_TQ_ROWS; r < min(tb.row0, (t + 1) * P2_TQ_ROWS); r++) f |= relt[r] != 0;
+        for (int r0 = 0; r0 < tb.row0; r0 += 256) {
+            const int r = r0 + tid;
+            const bool f = r < tb.row0 && relt[r] != 0;
             const unsigned long long bl = __ballot(f);
             if (lane == 0) wtot[wv] = __popcll(bl);
             __syncthreads();
             int pos = tbase + __popcll(bl & ((1ull << lane) - 1ull));
             for (int w = 0; w < wv; w++) pos += wtot[w];
-            if (f) a.tq_tiles[(size_t)b * a.tq_cap + pos] = t;
+            if (f) a.tq_tiles[(size_t)b * a.tq_cap + pos] = r;
             tbase += wtot[0] + wtot[1] + wtot[2] + wtot[3];
             __syncthreads();
         }
@@ -349,7 +347,7 @@ static long long pack_offsets(const ArmourPlanner* h, const std::vector<int>& co
 
 // mask + row lists of the current problem set (once per problem set: begin_problem_set clears rel_fresh / rel2_fresh).
 // for_solver: also the lists of the solver's mask (rows that can pass armour_solve's candidate filter), their packed plane entries and the
-// torque tiles that hold such a row -- what the culled device form of armour_solve walks (solver_device.hip).
+// torque rows of the mask -- what the culled device form of armour_solve walks (solver_device.hip).
 int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
     if (h->rel_fresh && (!for_solver || h->rel2_fresh)) return ARMOUR_OK;
     int rc = armour_upload_bounds(h);
@@ -398,9 +396,9 @@ int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
         h->rel_fresh = true;
     }
     if (for_solver && !h->rel2_fresh) {
-        const int tq_cap = std::max(1, (h->row0 + P2_TQ_ROWS - 1) / P2_TQ_ROWS);
+        const int tq_cap = std::max(1, h->row0);
         if ((rc = rel_alloc(&h->d_rel2_rows, &h->rel2_rows_cap, B * (size_t)std::max(h->Q, 1))) != ARMOUR_OK) return rc;
-        if ((rc = rel_alloc(&h->d_rel2_count, &h->rel2_count_cap, 2 * B)) != ARMOUR_OK) return rc;   // [B] listed collision rows | [B] listed torque tiles
+        if ((rc = rel_alloc(&h->d_rel2_count, &h->rel2_count_cap, 2 * B)) != ARMOUR_OK) return rc;   // [B] listed collision rows | [B] listed torque rows
         if ((rc = rel_alloc(&h->d_rel2_tq_tiles, &h->rel2_tq_tiles_cap, B * (size_t)tq_cap)) != ARMOUR_OK) return rc;
         a.rel = h->d_rel2; a.rel2 = nullptr; a.rows = h->d_rel2_rows; a.count = h->d_rel2_count; a.rows_res = nullptr; a.count_res = nullptr;
         a.tq_tiles = h->d_rel2_tq_tiles; a.tq_count = h->d_rel2_count + B; a.tq_cap = tq_cap;
@@ -455,7 +453,7 @@ extern "C" int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int
     return ARMOUR_OK;
 }
 
-extern "C" int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_tiles, double* ms) {
+extern "C" int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_rows, double* ms) {
     if (!h || !h->ready) { armour_set_error("no problem set: call armour_set_problems first"); return ARMOUR_ESTATE; }
     HIPCHK(hipSetDevice(h->device));
     const int rc = armour_relevance_build(h, true);
@@ -463,7 +461,7 @@ extern "C" int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, in
     if (solver_rows) HIPCHK(hipMemcpy(solver_rows, h->d_rel2, (size_t)h->B * h->m, hipMemcpyDeviceToHost));
     for (int b = 0; b < h->B; b++) {
         if (n_collision_rows) n_collision_rows[b] = h->h_rel2_count[b];
-        if (n_torque_tiles) n_torque_tiles[b] = h->h_rel2_tq_count[b];
+        if (n_torque_rows) n_torque_rows[b] = h->h_rel2_tq_count[b];
     }
     if (ms) *ms = h->rel_ms + h->rel2_ms;
     return ARMOUR_OK;

@@ -329,7 +329,7 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     int tq_cap = 0, n_tiles_culled = 0;
     if (culled) {
         if ((rc = armour_solver_lists(h, &sl, &tq_tiles, &tq_count, &tq_cap)) != ARMOUR_OK) return rc;
-        for (int b = 0; b < B; b++) n_tiles_culled = std::max(n_tiles_culled, h->h_rel2_tq_count[b] + (h->h_rel2_count[b] + P2_BLOCK - 1) / P2_BLOCK + 1);
+        for (int b = 0; b < B; b++) n_tiles_culled = std::max(n_tiles_culled, (h->h_rel2_tq_count[b] + P2_BLOCK - 1) / P2_BLOCK + (h->h_rel2_count[b] + P2_BLOCK - 1) / P2_BLOCK + 1);
     }
     if ((rc = armour_solve_device_capacity(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), h->device, B, h->tune(ARMOUR_OPT_SOLVE_WAVES_PER_SIMD), &plan, n_tiles_culled)) != ARMOUR_OK) return rc;
     if (plan.capacity < 1) return 0;
@@ -444,8 +444,8 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
         if (hres[b].status < 0) { w.words_clean = 0; return 0; }   // candidate buffers too small for some problem, or a group lost a block: the host form redoes the solve
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (timing) {
-        if (culled) fprintf(stderr, "[armour_solve, device form] culled: at most %d listed tiles per problem (problem 0: %d of %d collision rows, %d of %d torque tiles), lists %.3f + %.3f ms\n",
-                            n_tiles_culled, h->h_rel2_count[0], h->Q, h->h_rel2_tq_count[0], plan.lp.nbt, h->rel_ms, h->rel2_ms);
+        if (culled) fprintf(stderr, "[armour_solve, device form] culled: at most %d listed tiles per problem (problem 0: %d of %d collision rows, %d of %d torque rows), lists %.3f + %.3f ms\n",
+                            n_tiles_culled, h->h_rel2_count[0], h->Q, h->h_rel2_tq_count[0], h->row0, h->rel_ms, h->rel2_ms);
         fprintf(stderr, "[armour_solve, device form] B=%d in %d launch(es) of <= %d problems: %d blocks per problem (%d tiles), %.3f ms wall (%.3f ms before the launch), kernel %.3f ms (problem 0); phases of problem 0 in us (barrier passed / leader done):", B, n_launch, Bs, nb, plan.n_tiles, ms,
                 std::chrono::duration<double, std::milli>(t_launch - t_begin).count(), hres[0].time_ms / plan.ticks_per_ms);
         int bs = 0;   // the problem whose group left last: what the launch waited for

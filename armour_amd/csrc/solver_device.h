@@ -24,12 +24,12 @@ struct SolveArgs {
     P2Tables tb;
     p2::P2Launch lp;
     int nb, n_tiles;               // blocks per problem; row tiles per problem
-    // culled != 0 (ARMOUR_OPT_SOLVE_CULL; relevance.hip): a problem's tiles are its LISTED torque tiles, then its listed collision rows in tiles of
+    // culled != 0 (ARMOUR_OPT_SOLVE_CULL; relevance.hip): a problem's tiles are its LISTED torque rows, then its listed collision rows, in tiles of
     // P2_BLOCK (one thread per row: p2_sparse.h), then the limit rows -- the rows that can pass the candidate filter for some k; every other row
     // adds nothing to any quantity the solver reads (no violation, no candidate, inside the slacks), so the iterates are those of the full form
     int culled;
     p2::SparseList sl;
-    const int* tq_tiles; const int* tq_count; int tq_cap;   // [B][tq_cap] listed torque tiles, ascending | [B]
+    const int* tq_tiles; const int* tq_count; int tq_cap;   // [B][tq_cap] listed torque rows, ascending | [B]
     int b0;                        // first problem of this launch: a batch too large to give every problem enough co-resident blocks runs as
                                    // several launches back to back, each over problems [b0, b0 + gridDim.x / nb) of the same tables
     int cap_blk, cap_rows;         // candidate rows a block / a problem may hand over

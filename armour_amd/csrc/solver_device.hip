@@ -183,20 +183,21 @@ __device__ inline void scan_rows(const SolveArgs& a, int b, int r0, int r1, Solv
     __syncthreads();
 }
 
-// The culled form's scan: the block's rows are those of its tiles [t0, t1) of the problem's LISTED tiles -- torque tiles (P2_TQ_ROWS rows each), then
+// The culled form's scan: the block's rows are those of its tiles [t0, t1) of the problem's LISTED rows -- tiles of P2_BLOCK listed torque rows, then
 // tiles of P2_BLOCK listed collision rows, then the limit rows -- visited tile by tile in row order, one thread per row of a tile; the tests and the
 // compaction are scan_rows' (candidates of the block in ascending row order).
-struct TileSet { int ntq, nsp, cnt2; };   // listed torque tiles, sparse collision tiles, listed collision rows of the problem
+struct TileSet { int ntq, nsp, cnt2, cntq; };   // tiles of listed torque rows, tiles of listed collision rows, listed collision rows, listed torque rows
 __device__ inline TileSet problem_tiles(const SolveArgs& a, int b) {
     TileSet ts;
-    ts.ntq = a.tq_count[b]; ts.cnt2 = a.sl.count[b]; ts.nsp = (ts.cnt2 + P2_BLOCK - 1) / P2_BLOCK;
+    ts.cntq = a.tq_count[b]; ts.ntq = (ts.cntq + P2_BLOCK - 1) / P2_BLOCK;
+    ts.cnt2 = a.sl.count[b]; ts.nsp = (ts.cnt2 + P2_BLOCK - 1) / P2_BLOCK;
     return ts;
 }
 // row of thread `tid` in listed tile t (or -1)
 __device__ inline int tile_row(const SolveArgs& a, int b, const TileSet& ts, int t, int tid) {
     if (t < ts.ntq) {
-        const int r = a.tq_tiles[(size_t)b * a.tq_cap + t] * P2_TQ_ROWS + tid;
-        return tid < P2_TQ_ROWS && r < a.tb.row0 ? r : -1;
+        const int i = t * P2_BLOCK + tid;
+        return i < ts.cntq ? a.tq_tiles[(size_t)b * a.tq_cap + i] : -1;
     }
     if (t < ts.ntq + ts.nsp) {
         const int i = (t - ts.ntq) * P2_BLOCK + tid;
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
     const int n = a.tb.n, m = a.tb.m;
     SolveCtl* c = a.ctl + b;
     // (culled: the problem's own count of listed tiles; a block past the last tile evaluates and scans nothing and still keeps the group's barrier)
-    TileSet ts = {0, 0, 0};
+    TileSet ts = {0, 0, 0, 0};
     int my_tiles = a.n_tiles;
     if (a.culled) { ts = problem_tiles(a, b); my_tiles = ts.ntq + ts.nsp + 1; }
     const int t0 = (int)(((long long)jb * my_tiles) / a.nb), t1 = (int)(((long long)(jb + 1) * my_tiles) / a.nb);
@@ -1221,16 +1222,21 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
         const double kf = tid < n ? s_x[tid] : 0.0;
         for (int t = t0; t < t1; t++) {
             if (a.culled) {
-                if (t >= ts.ntq && t < ts.ntq + ts.nsp) {   // P2_BLOCK listed collision rows, one per thread
+                if (t < ts.ntq + ts.nsp) {   // P2_BLOCK listed torque / collision rows, one per thread (p2_sparse.h)
                     KPow& kp = *reinterpret_cast<KPow*>(smem_raw);
                     fill_kpow(kp, kf, n);
                     __syncthreads();
-                    const int i = (t - ts.ntq) * P2_BLOCK + tid;
-                    if (i < ts.cnt2) sparse_collision_row<true>(a.tb, a.sl, b, i, kp, g, jac);
+                    if (t < ts.ntq) {
+                        const int i = t * P2_BLOCK + tid;
+                        if (i < ts.cntq) sparse_torque_row(a.tb, b, a.tq_tiles[(size_t)b * a.tq_cap + i], a.lp.strideT, kp, g, jac);
+                    } else {
+                        const int i = (t - ts.ntq) * P2_BLOCK + tid;
+                        if (i < ts.cnt2) sparse_collision_row<true>(a.tb, a.sl, b, i, kp, g, jac);
+                    }
                     __syncthreads();
                     continue;
                 }
-                role = t < ts.ntq ? a.lp.nbc + a.tq_tiles[(size_t)b * a.tq_cap + t] : a.lp.nbc + a.lp.nbt;
+                role = a.lp.nbc + a.lp.nbt;
             } else {
                 int tr0, tr1;
                 tile_info(a, t, role, tr0, tr1);

@@ -410,7 +410,7 @@ class ArmourNLP:
         return rel.astype(bool), cnt, ms.value
 
     def solver_rows(self):
-        """(mask [B, m] bool, listed collision rows [B], listed torque tiles [B], device ms) -- armour_get_solver_rows: the rows that can pass
+        """(mask [B, m] bool, listed collision rows [B], listed torque rows [B], device ms) -- armour_get_solver_rows: the rows that can pass
         armour_solve's candidate filter for some k (what its culled device form walks)."""
         mask = np.zeros((self.B, self.m), dtype=np.uint8)
         cnt, tq = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)

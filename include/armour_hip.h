@@ -260,8 +260,8 @@ int armour_get_row_relevance(ArmourPlanner* h, uint8_t* relevant, int32_t* n_rel
 /* The SOLVER's rows of the current problem set: solver_rows[B][m], 1 = the row can pass armour_solve's candidate filter for some k in [-1,1]^n
  * (g_i + 2 |J_i|_1 > u_i or g_i - 2 |J_i|_1 < l_i: solver_common.h; the filter leaves out rows that cannot become active within the variables'
  * box, and this mask the rows it leaves out at EVERY k) -- a superset of armour_get_row_relevance's mask; what the culled device form of armour_solve
- * walks (ARMOUR_OPT_SOLVE_CULL).  n_collision_rows [B] and n_torque_tiles [B] (listed tiles of 8 torque rows) may be NULL; so may `solver_rows`. */
-int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_tiles, double* ms);
+ * walks (ARMOUR_OPT_SOLVE_CULL).  n_collision_rows [B] and n_torque_rows [B] may be NULL; so may `solver_rows`. */
+int armour_get_solver_rows(ArmourPlanner* h, uint8_t* solver_rows, int32_t* n_collision_rows, int32_t* n_torque_rows, double* ms);
 
 /* ---- in-process multi-device batch ---- */
 /* One caller thread (MATLAB / MEX, a Python host) drives several GPUs: an ArmourBatch owns one ArmourPlanner per entry of `devices`

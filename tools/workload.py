@@ -101,7 +101,7 @@ def main(argv):
                 t0 = time.perf_counter(); nlp.solve(); ts.append(time.perf_counter() - t0)
             print(f"   first solve after set_problems, cull={cull}: best {min(ts) * 1e3:.3f} ms", flush=True)
         mask, cnt, tq, ms = nlp.solver_rows()
-        print(f"   solver rows: collision mean {cnt.mean():.0f} of {nlp.J * nlp.T * O} ({cnt.mean() / max(1, nlp.J * nlp.T * O):.3f}), torque tiles mean {tq.mean():.1f} of {(nlp.n * nlp.T + 7) // 8}; masks + lists {ms:.3f} ms")
+        print(f"   solver rows: collision mean {cnt.mean():.0f} of {nlp.J * nlp.T * O} ({cnt.mean() / max(1, nlp.J * nlp.T * O):.3f}), torque rows mean {tq.mean():.1f} of {nlp.n * nlp.T}; masks + lists {ms:.3f} ms")
     elif what == "cull":
         import torch
         from armour_amd import _lib
