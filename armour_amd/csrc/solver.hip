@@ -319,10 +319,10 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
     SolvePlan plan;
     int rc;
     // The culled form (ARMOUR_OPT_SOLVE_CULL; relevance.hip, solver_device.h): the kernel walks only the rows that can pass the candidate filter
-    // for some k.  Same iterates; the lists cost one pass over the half-space table per problem set (about one evaluation), so automatic = from
-    // kSolveCullMinRows collision rows in the batch on.
+    // for some k.  Same iterates; the lists cost one pass over the half-space table per problem set (about one evaluation) and 0.2 ms of host
+    // round trips, so automatic = from kSolveCullMinRows collision rows in the batch on.
     const int cull_opt = h->tune(ARMOUR_OPT_SOLVE_CULL);
-    constexpr long long kSolveCullMinRows = 40000;
+    constexpr long long kSolveCullMinRows = 150000;   // (first solve after armour_set_problems, lists included, O = 20: B = 8 1.43 against 1.44 ms, B = 16 1.61 against 1.98, B = 64 2.2 against 4.5)
     const bool culled = h->Q > 0 && (cull_opt > 0 || (cull_opt < 0 && (long long)B * h->Q >= kSolveCullMinRows));
     p2::SparseList sl = {nullptr, nullptr, nullptr, nullptr};
     const int* tq_tiles = nullptr; const int* tq_count = nullptr;
@@ -459,6 +459,8 @@ static int solve_on_device(ArmourPlanner* h, const ArmourSolveOptions& opt, Armo
             fprintf(stderr, " | first leader step: bookkeeping %.1f, candidates gathered %.1f, QP done %.1f us (%lld QP steps, %lld candidate rows)", st[32] / plan.ticks_per_ms * 1e3,
                     st[33] / plan.ticks_per_ms * 1e3, st[34] / plan.ticks_per_ms * 1e3, st[40], st[41]);
             fprintf(stderr, " | QP steps by attempt (sigma 0, 0.5, 0.9, 0.99), all solves: %lld %lld %lld %lld", st[44], st[45], st[46], st[47]);
+            fprintf(stderr, " | attempt 0, all steps, us: row search %.1f, entering row %.1f, M + rhs %.1f, factor + solves %.1f, z + step lengths %.1f, update %.1f",
+                    st[50] / plan.ticks_per_ms * 1e3, st[51] / plan.ticks_per_ms * 1e3, st[52] / plan.ticks_per_ms * 1e3, st[53] / plan.ticks_per_ms * 1e3, st[54] / plan.ticks_per_ms * 1e3, st[55] / plan.ticks_per_ms * 1e3);
         }
         long long longest_ok = 0, long_bad = 0, steps_all = 0;
         for (int b = 0; b < B; b++) { const long long* st = hstamps + (size_t)b * 64; longest_ok = std::max(longest_ok, st[48]); long_bad += st[49]; steps_all += st[44] + st[45] + st[46] + st[47]; }
@@ -476,13 +478,14 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, n = h->n, m = h->m;
     {
-        // The device-resident form for batches, the host-driven form below for up to four problems (force_host_qp: > 0 host form, < 0 device form
-        // whatever the batch; ARMOUR_OPT_SOLVE_DEVICE = 0: never the device form).  Both produce the same iterates.  Why four:
-        // the leader wavefront takes 6 us per QP step where a host core takes 0.3, and problems that end infeasible take hundreds of steps; on
-        // random worlds (O = 20) the host form is faster in 36 of 36 batches of 1-3 problems (0.22 against 0.44 ms for one), even at 4, and the
-        // persistent kernel in 33 of 36 from 6 on (profiles/r03_solve_small_batches.txt).  It also remains the fallback.
+        // The device-resident form from two problems on, the host-driven form below for a lone problem (force_host_qp: > 0 host form, < 0 device
+        // form whatever the batch; ARMOUR_OPT_SOLVE_DEVICE = 0: never the device form, 2: always).  Both produce the same iterates.  Rounds 3-4 drew
+        // the line at five: the leader ran the four elastic QP attempts of an infeasible linearisation one after the other at 6 us a step where a
+        // host core takes 0.3.  With the attempts side by side on the leader's four waves (round 5) the persistent kernel wins from B = 2 on
+        // (O = 20: 0.19 against 0.28 ms; B = 4, O = 10: 0.23 against 0.39; B = 6: 0.25 against 0.54) and ties for one problem (0.146 / 0.157
+        // against 0.131 / 0.155 ms at O = 10 / 20), where the host form stays.  It also remains the fallback.
         const int dev_env = h->tune(ARMOUR_OPT_SOLVE_DEVICE);
-        constexpr int kDeviceFormMinBatch = 5;
+        constexpr int kDeviceFormMinBatch = 2;
         const bool want_device = opt.force_host_qp > 0.0 ? false : opt.force_host_qp < 0.0 ? true : dev_env == 0 ? false : dev_env >= 2 ? true : B >= kDeviceFormMinBatch;
         if (want_device) {
             HIPCHK(hipSetDevice(h->device));

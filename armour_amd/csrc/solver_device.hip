@@ -681,6 +681,9 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
     u[NV] = 0.0;
     int q = 0, cv = 0, qp_iter = 0;
     bool feasible = true, stop = false;
+    long long* qst = a.stamps && attempt == 0 ? a.stamps + (size_t)(blockIdx.x / a.nb + a.b0) * 64 + 50 : nullptr;   // ARMOUR_SOLVE_TIMING: ticks per part of attempt 0's steps
+    long long q_t = qst ? wall_clock64() : 0;
+#define QPW_LAP(slot) if (qst && lane == 0) { const long long n__ = wall_clock64(); qst[slot] += n__ - q_t; q_t = n__; }
     WAVE_LDS_SYNC();
     while (!stop) {
         if (ld_lds_int(&S.first_ok) < attempt) { feasible = false; break; }   // a lower attempt is feasible: this one is not needed
@@ -723,6 +726,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
             if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
         }
         const int p = __builtin_amdgcn_readfirstlane(bi);
+        QPW_LAP(0)
         if (p < 0) break;
         if (++qp_iter > max_iter) { feasible = false; break; }
         // the entering row's normal and right-hand side, in every lane
@@ -751,6 +755,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
         for (int j = 0; j < NV; j++) if (lane == j) W.np[j] = npr[j];
         double up = 0.0;
         bool added = false;
+        QPW_LAP(1)
         for (int guard = 0; guard < 4 * NV + 8 && !added; guard++) {
             // r = N* np,  z = G^-1 (np - N r)
             double rr[NV];
@@ -776,6 +781,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
                     }
                 }
                 WAVE_LDS_SYNC();
+                QPW_LAP(2)
                 // Cholesky M = Lc Lc' (spd_solve of solver.hip), rows [cv, q) new, in registers
                 double Lr[NV][NV], Li[NV];
 #pragma unroll
@@ -832,6 +838,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
                     }
                 }
             }
+            QPW_LAP(3)
             // z: lane j forms entry j (np_j - sum_i An[i][j] r_i in row order, times 1/Hd_j), then every lane takes all of them
             double zmine = 0.0;
             {
@@ -866,6 +873,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
             if (t2 < 0) t2 = 0;
             const double t = t1 < t2 ? t1 : t2;
             if (t >= kInf) { feasible = false; break; }
+            QPW_LAP(4)
             const bool dual_only = t2 >= kInf;
             if (!dual_only) {
 #pragma unroll
@@ -896,6 +904,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
                 if (cv > l) cv = l;
             }
         }
+        QPW_LAP(5)
         if (!feasible) break;
         WAVE_LDS_SYNC();
         if (!added && !excluded[p]) { WAVE_LDS_SYNC(); if (lane == 0) excluded[p] = 1; }  // could not make progress on this row

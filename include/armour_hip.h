@@ -145,14 +145,14 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
 /* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
 #define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */
-#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default): the device-resident form from 5 problems on | 0: never | 2: always */
+#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default): the device-resident form from 2 problems on | 0: never | 2: always */
 #define ARMOUR_OPT_SOLVE_CUT_TILES 142        /* default 156: a batch whose blocks would walk more tiles each is cut */
 #define ARMOUR_OPT_SOLVE_BLOCKS 143           /* 0 (default: as many as fit) | n: at most n blocks per problem */
 #define ARMOUR_OPT_SOLVE_SUB_BATCH 144        /* 0 (default: by tiles) | n: sub-batches of at most n problems */
 #define ARMOUR_OPT_SOLVE_ROW_CAP 145          /* 0 (default) | n: candidate-row buffers of n rows (tests: forces the overflow path) */
 #define ARMOUR_OPT_SOLVE_HARD_CAP_S 146       /* 0 (default: from the time budget / iteration limit) | seconds: wall-clock cap of one persistent launch */
 #define ARMOUR_OPT_SOLVE_WAVES_PER_SIMD 147   /* 0 automatic (default) | 1 | 2: register build of the persistent kernel */
-#define ARMOUR_OPT_SOLVE_CULL 148              /* -1 automatic (default: from 40 000 collision rows in the batch on) | 0 | 1: the device-resident form walks only the rows that can pass
+#define ARMOUR_OPT_SOLVE_CULL 148              /* -1 automatic (default: from 150 000 collision rows in the batch on) | 0 | 1: the device-resident form walks only the rows that can pass
                                                 * its candidate filter for some k (a second, wider mask than armour_get_row_relevance's: g_i + 2 |J_i|_1 can reach the bound); every
                                                 * other row adds nothing the solver reads, so iterates and results are those of the full form bit for bit */
 #define ARMOUR_OPT_FIRST_TUNING 101
