@@ -360,6 +360,20 @@ def extra_config(device, dev, rank, world, use_dist, B, O, T, K, R, check_oracle
         spot = tm.check(picks)
     out = summarise(nlp, wall, ev, K, world, {"checked": "finite + device entry == host entry" + (" + oracle on problems 0 and B-1" if spot else ""),
                                                "oracle_spot_check": spot} if check_oracle is not None else {"checked": None})
+    if check_oracle is not None:
+        # the whole NLP solve of the same worlds (an extra, never `value`): the first solve after armour_set_problems -- which
+        # builds the solver's row lists inside it -- and a repeated one; wall clock around the synchronous call
+        nlp.set_parameters(probs["q0"], probs["qd0"], probs["qdd0"], probs["q_des"], probs["obstacles"])
+        t1 = time.perf_counter(); sols = nlp.solve(); first_ms = (time.perf_counter() - t1) * 1e3
+        rep = []
+        for _ in range(3):
+            t1 = time.perf_counter(); nlp.solve(); rep.append((time.perf_counter() - t1) * 1e3)
+        _, n_col, n_tq, lists_ms = nlp.solver_rows()
+        out["armour_solve"] = {"first_solve_ms": first_ms, "repeated_solve_ms": min(rep), "feasible": int(sum(int(s2["feasible"]) for s2 in sols)),
+                               "iterations_max": int(max(s2["iterations"] for s2 in sols)),
+                               "rows_walked": {"collision_mean": float(n_col.mean()), "collision_all": nlp.J * nlp.T * O, "torque_mean": float(n_tq.mean()), "torque_all": nlp.n * nlp.T,
+                                               "lists_ms": lists_ms},
+                               "note": "device-resident SQP on the rows that can pass its candidate filter for some k (ARMOUR_OPT_SOLVE_CULL automatic); same iterates as the full form"}
     nlp.close()
     return out
 
