@@ -109,6 +109,33 @@ __device__ inline double plan_dk(const SolveArgs& a, const double* bz, int i) {
     const double tp = a.t_plan;
     return a.tb.mode == ARMOUR_MODE_ARMTD ? cacc::q_plan_dk(bz[2 * a.tb.n + i]) : (tp * tp * tp) * (6 * tp * tp - 15 * tp + 10) * a.tb.k_range[i];
 }
+// Block-wide integer sums and scans with one barrier instead of a tree of eight: inside each wave by shuffles, the four wave results through LDS.
+// (Integer addition: any order gives the same number.)  `sh4` / `si4`: LDS arrays of >= 4 entries that nobody else is using.
+__device__ inline void block_sum(long long& v, int& i, long long* sh4, int* si4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); i += __shfl_xor(i, off, 64); }
+    __syncthreads();   // (the arrays may still be read from an earlier call)
+    if ((threadIdx.x & 63) == 0) { sh4[threadIdx.x >> 6] = v; si4[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    v = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    i = si4[0] + si4[1] + si4[2] + si4[3];
+}
+// exclusive prefix sum of one int per thread over the block (and the block total)
+__device__ inline int block_exclusive_scan(int v, int* si4, int& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    __syncthreads();
+    if (lane == 63) si4[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (w < wv) base += si4[w];
+    total = si4[0] + si4[1] + si4[2] + si4[3];
+    return base + inc - v;
+}
+
 // ------------------------------------------------------------------------------------------------ per-block scan
 // The block's rows after an evaluation: their L1 violation (fixed point), the candidate rows of the QP compacted in row order
 // into `rows`, and the number of rows outside [g_l - slack, g_u + slack] (finalize_solution).  The row tests are the host
@@ -170,15 +197,9 @@ __device__ inline void scan_rows(const SolveArgs& a, int b, int r0, int r1, Solv
             __syncthreads();
         }
     }
-    sh.red[tid] = vsum;
-    sh.redi[tid] = bad;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (tid < s2) { sh.red[tid] += sh.red[tid + s2]; sh.redi[tid] += sh.redi[tid + s2]; }
-        __syncthreads();
-    }
-    viol_out = sh.red[0];
-    bad_out = sh.redi[0];
+    block_sum(vsum, bad, sh.red, sh.redi);
+    viol_out = vsum;
+    bad_out = bad;
     count_out = base;
     __syncthreads();
 }
@@ -255,15 +276,9 @@ __device__ inline void scan_tiles(const SolveArgs& a, int b, const TileSet& ts, 
         base += sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
         __syncthreads();
     }
-    sh.red[tid] = vsum;
-    sh.redi[tid] = bad;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (tid < s2) { sh.red[tid] += sh.red[tid + s2]; sh.redi[tid] += sh.redi[tid + s2]; }
-        __syncthreads();
-    }
-    viol_out = sh.red[0];
-    bad_out = sh.redi[0];
+    block_sum(vsum, bad, sh.red, sh.redi);
+    viol_out = vsum;
+    bad_out = bad;
     count_out = base;
     __syncthreads();
 }
@@ -646,6 +661,32 @@ __device__ inline void qp_row_s(const SolveArgs& a, const Leader& L, const Solve
         brow = (e & 1) == 0 ? -1.0 - L.x[j] : -(1.0 - L.x[j]);
     }
 }
+// ---- wave-level exchanges without LDS: a value of a lane whose index is wave-uniform (v_readlane), and the lexicographic minimum of
+// (value, index) pairs over the wave by DPP moves (row shifts inside the rows of 16, then the two row broadcasts of gfx9: the total ends up in lane 63)
+__device__ inline double readlane_f64(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline void min_pair_dpp(double& best, int& bi) {
+    // a lane without a source lane (or masked off) gets its own value back: combining a pair with itself changes nothing
+    const int hi = __double2hiint(best), lo = __double2loint(best);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(ohi, olo);
+    if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
+}
+// the first row attaining the smallest value (the sequential scan's choice), as its index, in every lane
+__device__ inline int wave_argmin_first(double best, int bi) {
+    min_pair_dpp<0x111, 0xf>(best, bi);   // row_shr:1
+    min_pair_dpp<0x112, 0xf>(best, bi);   // row_shr:2
+    min_pair_dpp<0x114, 0xf>(best, bi);   // row_shr:4
+    min_pair_dpp<0x118, 0xf>(best, bi);   // row_shr:8   -> lane 15 of every row holds its row's minimum
+    min_pair_dpp<0x142, 0xa>(best, bi);   // row_bcast:15 into rows 1 and 3
+    min_pair_dpp<0x143, 0xc>(best, bi);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+    return __builtin_amdgcn_readlane(bi, 63);
+}
+
 template <int WPS>
 __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShared& S, const SolveRow* cand, const double* lds_rows, unsigned char* flags_g, int max_iter = kQpMaxSteps) {
     constexpr int kRegRows = WPS == 1 ? 4 : 2;   // rows a lane keeps in registers (the two-waves-per-SIMD build has 256 registers for everything)
@@ -681,6 +722,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
     u[NV] = 0.0;
     int q = 0, cv = 0, qp_iter = 0;
     bool feasible = true, stop = false;
+    unsigned act_bits = 0, exc_bits = 0;   // reg_rows: the active / excluded flags of this lane's rows (bit r: row lane + 64 r), instead of the LDS bytes
     long long* qst = a.stamps && attempt == 0 ? a.stamps + (size_t)(blockIdx.x / a.nb + a.b0) * 64 + 50 : nullptr;   // ARMOUR_SOLVE_TIMING: ticks per part of attempt 0's steps
     long long q_t = qst ? wall_clock64() : 0;
 #define QPW_LAP(slot) if (qst && lane == 0) { const long long n__ = wall_clock64(); qst[slot] += n__ - q_t; q_t = n__; }
@@ -694,7 +736,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
 #pragma unroll
             for (int r = 0; r < kRegRows; r++) {
                 const int i = lane + 64 * r;
-                if (i < mrows && !is_active[i] && !excluded[i]) {
+                if (i < mrows && !(((act_bits | exc_bits) >> r) & 1u)) {
                     double s = -my_b[r];
 #pragma unroll
                     for (int j = 0; j < NV; j++) if (j < n) s += my_a[r][j] * qx[j];
@@ -719,13 +761,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
             }
         }
         // lexicographic (value, index) minimum: the sequential scan keeps the FIRST row attaining the minimum
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (oi >= 0 && (bi < 0 || o < best || (o == best && oi < bi))) { best = o; bi = oi; }
-        }
-        const int p = __builtin_amdgcn_readfirstlane(bi);
+        const int p = wave_argmin_first(best, bi);
         QPW_LAP(0)
         if (p < 0) break;
         if (++qp_iter > max_iter) { feasible = false; break; }
@@ -745,8 +781,8 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NV; j++) npr[j] = __shfl(v[j], src, 64);
-            bp = __shfl(v[NV], src, 64);
+            for (int j = 0; j < NV; j++) npr[j] = readlane_f64(v[j], src);
+            bp = readlane_f64(v[NV], src);
         } else {
             load_row(p, npr, bp);
         }
@@ -816,7 +852,11 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
                         }
                     }
                 }
-                if (!spd) { if (lane == 0) excluded[p] = 1; break; }  // dependent active set: skip this row
+                if (!spd) {   // dependent active set: skip this row
+                    if (reg_rows) { if (lane == (p & 63)) exc_bits |= 1u << (p >> 6); }
+                    else if (lane == 0) excluded[p] = 1;
+                    break;
+                }
                 double tt[NV];
 #pragma unroll
                 for (int i = 0; i < NV; i++) {
@@ -855,7 +895,7 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
             }
             double z[NV];
 #pragma unroll
-            for (int j = 0; j < NV; j++) z[j] = j < n ? __shfl(zmine, j, 64) : 0.0;
+            for (int j = 0; j < NV; j++) z[j] = j < n ? readlane_f64(zmine, j) : 0.0;
             double zz = 0, znp = 0;
 #pragma unroll
             for (int j = 0; j < NV; j++) if (j < n) { zz += z[j] * z[j]; znp += z[j] * npr[j]; }
@@ -887,11 +927,17 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
 #pragma unroll
                 for (int i = 0; i < NV; i++) if (i == q) u[i] = up;
                 if (lane < NV) W.An[q][lane] = W.np[lane];
-                if (lane == 0) { W.A[q] = p; is_active[p] = 1; }
+                if (lane == 0) W.A[q] = p;
+                if (reg_rows) { if (lane == (p & 63)) act_bits |= 1u << (p >> 6); }
+                else if (lane == 0) is_active[p] = 1;
                 q++;
                 added = true;
             } else {        // dual step only, or a partial step: drop the blocking row (and try again)
-                if (lane == 0) is_active[W.A[l]] = 0;
+                {
+                    const int d = ld_lds_int(&W.A[l]);   // (written by lane 0 in an earlier step, fenced since)
+                    if (reg_rows) { if (lane == (d & 63)) act_bits &= ~(1u << (d >> 6)); }
+                    else if (lane == 0) is_active[d] = 0;
+                }
                 WAVE_LDS_SYNC();
                 for (int i = l; i < q - 1; i++) {   // (rare; rows move up one by one, every lane a column)
                     if (lane < NV) W.An[i][lane] = W.An[i + 1][lane];
@@ -907,14 +953,17 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
         QPW_LAP(5)
         if (!feasible) break;
         WAVE_LDS_SYNC();
-        if (!added && !excluded[p]) { WAVE_LDS_SYNC(); if (lane == 0) excluded[p] = 1; }  // could not make progress on this row
+        if (!added) {   // could not make progress on this row
+            if (reg_rows) { if (lane == (p & 63)) exc_bits |= 1u << (p >> 6); }
+            else if (!excluded[p]) { WAVE_LDS_SYNC(); if (lane == 0) excluded[p] = 1; }
+        }
         WAVE_LDS_SYNC();
     }
     // excluded rows that remain violated mean the linearisation is inconsistent
     if (feasible) {
         int viol = 0;
         for (int i = lane; i < mrows; i += 64) {
-            if (!excluded[i]) continue;
+            if (reg_rows ? !((exc_bits >> (i >> 6)) & 1u) : !excluded[i]) continue;
             double ar[NV], br;
             load_row(i, ar, br);
             double s = -br;
@@ -943,30 +992,14 @@ __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, S
     int mine[4], tot = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) { const int jb = tid * 4 + e; mine[e] = jb < nb ? ld_coh(&bw[jb].count) : 0; tot += mine[e]; }
-    L.ri[tid] = tot;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = tid >= off ? L.ri[tid - off] : 0;
-        __syncthreads();
-        L.ri[tid] += v;
-        __syncthreads();
-    }
-    int run = L.ri[tid] - tot;
-    const int total = L.ri[255];
+    int total;
+    int run = block_exclusive_scan(tot, L.ri, total);
 #pragma unroll
     for (int e = 0; e < 4; e++) { L.scan[tid * 4 + e] = run; run += mine[e]; }
-    __syncthreads();
     bool ok = total <= a.cap_rows;
 #pragma unroll
     for (int e = 0; e < 4; e++) if (tid * 4 + e < nb && mine[e] > a.cap_blk) ok = false;
-    L.ri[tid] = ok ? 0 : 1;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (tid < s2) L.ri[tid] |= L.ri[tid + s2];
-        __syncthreads();
-    }
-    const bool overflow = L.ri[0] != 0;
-    __syncthreads();
+    const bool overflow = __syncthreads_or(ok ? 0 : 1) != 0;   // (also: L.scan is written)
     if (overflow) return false;
     // candidate c of the problem lives in the slot of the block whose prefix range holds c
     for (int c = tid; c < total; c += 256) {
@@ -1124,7 +1157,7 @@ __device__ inline int leader_step(const SolveArgs& a, Leader& L, QpShared& QS, i
     }
     int next;
     if (L.stop == 3) {   // evaluate the trial point
-        if (tid == 0) for (int j = 0; j < n; j++) st_coh(x_pub + j, L.xt[j]);
+        if (tid < n) st_coh(x_pub + tid, L.xt[tid]);   // (one lane per component: seven stores in flight instead of one after the other)
         next = CMD_EVAL;
     } else {             // finished: finalize_solution (RT/NLPclass.cu:422-538) on the last evaluation of x
         if (tid == 0) {
@@ -1304,22 +1337,16 @@ __global__ __launch_bounds__(P2_BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, W
             int bd = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) { const int j2 = tid * 4 + e; if (j2 < a.nb) { v += ld_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + j2].viol); bd += ld_coh(&a.blk_word[(size_t)(b - a.b0) * a.nb + j2].bad); } }
-            scan_sh.red[tid] = v; scan_sh.redi[tid] = bd;
-            __syncthreads();
-            for (int s2 = 128; s2 > 0; s2 >>= 1) {
-                if (tid < s2) { scan_sh.red[tid] += scan_sh.red[tid + s2]; scan_sh.redi[tid] += scan_sh.redi[tid + s2]; }
-                __syncthreads();
-            }
-            viol_fx = scan_sh.red[0]; nbad = scan_sh.redi[0];
+            block_sum(v, bd, scan_sh.red, scan_sh.redi);
+            viol_fx = v; nbad = bd;
             __syncthreads();
         }
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1)] = wall_clock64() - L.t_start;      // barrier passed
         const int next = leader_step<WPS>(a, L, QS, b, viol_fx, nbad, cand, flags_g, c->x, reinterpret_cast<double*>(smem_raw));
         if (a.stamps && tid == 0 && phase <= 16) a.stamps[(size_t)b * 64 + 2 * (phase - 1) + 1] = wall_clock64() - L.t_start;  // leader step done
-        if (tid == 0) {
-            wait_my_memory_ops();                          // x is at the memory side ...
-            st_coh(&c->go, phase * 8u + (unsigned)next);   // ... before the release (phase and command in one word) is
-        }
+        wait_my_memory_ops();                              // every lane's stores of x are at the memory side ...
+        __syncthreads();
+        if (tid == 0) st_coh(&c->go, phase * 8u + (unsigned)next);   // ... before the release (phase and command in one word) is
         __syncthreads();
     }
 }
