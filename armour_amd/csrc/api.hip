@@ -252,6 +252,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     for (int i = 0; i < 9; i++) armour_free_pinned(h->solve_pin[i]);
     dev_free(&h->d_bounds); dev_free(&h->d_viol);
     armour_relevance_free(h);
+    if (h->d_tr_stage) (void)hipFree(h->d_tr_stage);
     dev_free(&h->solve_dev.ctl); dev_free(&h->solve_dev.blk_word); dev_free(&h->solve_dev.blk_rows); dev_free(&h->solve_dev.qp_rows);
     dev_free(&h->solve_dev.flags);
     dev_free(&h->d_jrs);
@@ -282,7 +283,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     HIPCHK(hipSetDevice(h->device));
     h->ready = false;
     h->rel_fresh = false; h->rel2_fresh = false;
-    h->bounds_on_device = false;
+    h->bounds_on_device = false; h->bounds_on_host = false;
     h->stats_fresh = false;
     drop_step_graphs(h);  // they bake in the tables of the previous problem set
     int rc = ensure_capacity(h, B, O);
@@ -717,15 +718,60 @@ extern "C" int armour_check_feasible(ArmourPlanner* h, const double* g, int32_t*
     return ARMOUR_OK;
 }
 
+// g_l / g_u of every problem on the device, the values of armour_get_bounds (RT/NLPclass.cu:87-165) expression for expression, filled by a kernel
+// from the torque radii (B n T doubles to upload instead of 2 B m: 73 MB at B = 128, O = 50 -- 3 ms of the first armour_solve after a build)
+namespace {
+struct BoundsArgs {
+    int n, T, m, row0, Q, no_torque;
+    double torque_limits[ARMOUR_MAX_FACTORS], lb[ARMOUR_MAX_FACTORS], ub[ARMOUR_MAX_FACTORS], speed[ARMOUR_MAX_FACTORS];
+    double qe, qde;
+    const double* tr;   // [B][n][T]
+    double* lo; double* hi;   // [B][m]
+};
+__global__ __launch_bounds__(256) void armour_bounds_kernel(BoundsArgs a) {
+    const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.m) return;
+    double l, u;
+    if (r < a.row0) {   // row t * n + j
+        const int t = r / a.n, j = r - t * a.n;
+        const double tr = a.tr[((size_t)b * a.n + j) * a.T + t];
+        l = -a.torque_limits[j] + tr; u = a.torque_limits[j] - tr;
+    } else if (r < a.row0 + a.Q) { l = -1e19; u = 0; }
+    else {
+        const int e = r - a.row0 - a.Q, rep = e / a.n, i = e - rep * a.n;
+        if (rep < 2) { l = a.lb[i] + a.qe; u = a.ub[i] - a.qe; }
+        else { l = -a.speed[i] + a.qde; u = a.speed[i] - a.qde; }
+    }
+    a.lo[(size_t)b * a.m + r] = l;
+    a.hi[(size_t)b * a.m + r] = u;
+}
+}  // namespace
+
 int armour_upload_bounds(ArmourPlanner* h) {
     if (h->bounds_on_device) return ARMOUR_OK;
     const size_t bm = (size_t)h->B * h->m;
-    h->h_gl.resize(bm); h->h_gu.resize(bm);
-    int rc = armour_get_bounds(h, nullptr, nullptr, h->h_gl.data(), h->h_gu.data());
-    if (rc != ARMOUR_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    BoundsArgs a;
+    a.n = h->n; a.T = h->T; a.m = h->m; a.row0 = h->row0; a.Q = h->Q; a.no_torque = h->no_torque() ? 1 : 0;
+    for (int j = 0; j < ARMOUR_MAX_FACTORS; j++) {
+        a.torque_limits[j] = h->robot.torque_limits[j]; a.lb[j] = h->robot.state_limits_lb[j]; a.ub[j] = h->robot.state_limits_ub[j]; a.speed[j] = h->robot.speed_limits[j];
+    }
+    a.qe = h->ub.qe; a.qde = h->ub.qde;
+    a.lo = h->d_bounds; a.hi = h->d_bounds + bm;
+    a.tr = nullptr;
+    if (!h->no_torque()) {
+        const size_t ntr = (size_t)h->B * h->n * h->T;
+        if (h->tr_stage_cap < ntr) {
+            if (h->d_tr_stage) (void)hipFree(h->d_tr_stage);
+            h->d_tr_stage = nullptr; h->tr_stage_cap = 0;
+            HIPCHK(hipMalloc((void**)&h->d_tr_stage, ntr * sizeof(double)));
+            h->tr_stage_cap = ntr;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_tr_stage, h->h_torque_radius.data(), ntr * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        a.tr = h->d_tr_stage;
+    }
+    hipLaunchKernelGGL(armour_bounds_kernel, dim3((h->m + 255) / 256, h->B), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // (h_torque_radius may change with the next problem set)
     h->bounds_on_device = true;
     return ARMOUR_OK;
 }

@@ -167,10 +167,11 @@ struct ArmourPlanner {
     int rel_max_count = 0;
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
-    bool bounds_on_device = false;
-    std::vector<double> h_gl, h_gu;  // host copy of the same bounds (valid while bounds_on_device)
+    bool bounds_on_device = false, bounds_on_host = false;
+    std::vector<double> h_gl, h_gu;  // host copy of the same bounds (valid while bounds_on_host: the host-driven solver form fills it)
     std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
     std::vector<double> h_torque_radius;              // [B][n][T]
+    double* d_tr_stage = nullptr; size_t tr_stage_cap = 0;   // the same on the device, for the kernel that fills the bounds (armour_upload_bounds)
     std::vector<double> h_link_gens;                  // [B][T][J][18]
     std::vector<unsigned long long> h_plane_skip;     // [B] host copy of d_plane_skip
     // device tables (sized for allocB x allocO)
@@ -234,7 +235,7 @@ int armour_checked_collision_rows(const ArmourPlanner* h);
 double* armour_handle_pinned(ArmourPlanner* h, int slot, size_t bytes);
 int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* d_centers, hipStream_t stream);
 P2Tables armour_make_tables(const ArmourPlanner* h);
-// g_l / g_u of the current problem set in h->d_bounds ([2][B][m]) and h->h_gl / h->h_gu; uploaded once per problem set (api.hip)
+// g_l / g_u of the current problem set in h->d_bounds ([2][B][m]): filled by a kernel once per problem set (api.hip)
 int armour_upload_bounds(ArmourPlanner* h);
 
 // p1_reach.hip

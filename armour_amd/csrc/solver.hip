@@ -504,13 +504,11 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     int rc = ARMOUR_OK;
     // g and jac stay on the device; a scan kernel hands back the L1 violation and the compacted candidate rows
     const size_t bm = (size_t)B * m;
-    if (!h->bounds_on_device) {  // once per problem set
+    if ((rc = armour_upload_bounds(h)) != ARMOUR_OK) return rc;   // (d_bounds: once per problem set, on the device)
+    if (!h->bounds_on_host) {  // this form's own host copy, once per problem set
         h->h_gl.resize(bm); h->h_gu.resize(bm);
         if ((rc = armour_get_bounds(h, xl.data(), xu.data(), h->h_gl.data(), h->h_gu.data())) != ARMOUR_OK) return rc;
-        HIPCHK(hipMemcpyAsync(h->d_bounds, h->h_gl.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_bounds + bm, h->h_gu.data(), bm * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->bounds_on_device = true;
+        h->bounds_on_host = true;
     } else if ((rc = armour_get_bounds(h, xl.data(), xu.data(), nullptr, nullptr)) != ARMOUR_OK) return rc;
     const std::vector<double>&gl = h->h_gl, &gu = h->h_gu;
     const int nseg = (m + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
