@@ -1023,10 +1023,10 @@ __device__ inline bool gather_candidates(const SolveArgs& a, Leader& L, int b, S
 // linearisation -- the host form evaluates the accepted point a second time, with identical results -- and the verdict of the
 // current point is always at hand: a solve that takes the full step needs one phase per SQP iteration, and none at the end.
 // `evals` counts what the host form would have evaluated, so both forms report the same numbers.
-// (WPS: one copy per compiled occupancy -- the compiler keeps this function out of line, and a copy shared by both kernel builds would be
-// compiled to the tighter register budget of the two)
+// (Forced inline since round 5: as a function of its own it saved and restored 169 callee-saved VGPRs through scratch memory at every call -- 338
+// scratch instructions per phase, 540 B of scratch per lane -- which was a tenth of a lone solve: sample problem 0.122 -> 0.116 ms.)
 template <int WPS>
-__device__ inline int leader_step(const SolveArgs& a, Leader& L, QpShared& QS, int b, long long viol_fx, int bad, SolveRow* cand,
+__device__ __forceinline__ int leader_step(const SolveArgs& a, Leader& L, QpShared& QS, int b, long long viol_fx, int bad, SolveRow* cand,
                                   unsigned char* flags_g, double* x_pub, double* lds_stage) {
     const int n = a.tb.n, tid = threadIdx.x;
     const double viol = viol_from_fixed(viol_fx);
