@@ -747,8 +747,8 @@ __global__ __launch_bounds__(256) void armour_bounds_kernel(BoundsArgs a) {
 }
 }  // namespace
 
-int armour_upload_bounds(ArmourPlanner* h) {
-    if (h->bounds_on_device) return ARMOUR_OK;
+// the kernel, queued on the handle's stream: d_tr = the torque radii [B][n][T] on the device (unused without torque rows)
+int armour_bounds_launch(ArmourPlanner* h, const double* d_tr) {
     const size_t bm = (size_t)h->B * h->m;
     BoundsArgs a;
     a.n = h->n; a.T = h->T; a.m = h->m; a.row0 = h->row0; a.Q = h->Q; a.no_torque = h->no_torque() ? 1 : 0;
@@ -757,7 +757,18 @@ int armour_upload_bounds(ArmourPlanner* h) {
     }
     a.qe = h->ub.qe; a.qde = h->ub.qde;
     a.lo = h->d_bounds; a.hi = h->d_bounds + bm;
-    a.tr = nullptr;
+    a.tr = d_tr;
+    hipLaunchKernelGGL(armour_bounds_kernel, dim3((h->m + 255) / 256, h->B), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    h->bounds_on_device = true;   // (for everything queued on the handle's stream after this)
+    return ARMOUR_OK;
+}
+
+// Lazy form, for problem sets whose tables came from the host (armour_set_tables): the reach-set build queues the kernel itself, behind its own
+// kernels, from the torque radii it has on the device (p1_reach.hip) -- no upload, no wait.
+int armour_upload_bounds(ArmourPlanner* h) {
+    if (h->bounds_on_device) return ARMOUR_OK;
+    const double* d_tr = nullptr;
     if (!h->no_torque()) {
         const size_t ntr = (size_t)h->B * h->n * h->T;
         if (h->tr_stage_cap < ntr) {
@@ -767,12 +778,11 @@ int armour_upload_bounds(ArmourPlanner* h) {
             h->tr_stage_cap = ntr;
         }
         HIPCHK(hipMemcpyAsync(h->d_tr_stage, h->h_torque_radius.data(), ntr * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        a.tr = h->d_tr_stage;
+        d_tr = h->d_tr_stage;
     }
-    hipLaunchKernelGGL(armour_bounds_kernel, dim3((h->m + 255) / 256, h->B), dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
+    const int rc = armour_bounds_launch(h, d_tr);
+    if (rc != ARMOUR_OK) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));   // (h_torque_radius may change with the next problem set)
-    h->bounds_on_device = true;
     return ARMOUR_OK;
 }
 

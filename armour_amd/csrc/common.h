@@ -237,6 +237,7 @@ int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* 
 P2Tables armour_make_tables(const ArmourPlanner* h);
 // g_l / g_u of the current problem set in h->d_bounds ([2][B][m]): filled by a kernel once per problem set (api.hip)
 int armour_upload_bounds(ArmourPlanner* h);
+int armour_bounds_launch(ArmourPlanner* h, const double* d_torque_radius);   // the same kernel queued on the handle's stream (the reach-set build calls it)
 
 // p1_reach.hip
 int armour_p1_build(ArmourPlanner* h, const double* obstacles);  // h->mode selects the ARMOUR or the ARMTD chain

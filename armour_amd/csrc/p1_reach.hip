@@ -2171,6 +2171,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
     }
+    // the constraint bounds of this problem set (torque limits -+ the radii just built, collision and joint-limit constants: RT/NLPclass.cu:87-165),
+    // filled on the device behind the build's kernels: the first armour_solve / armour_eval_violations of the set finds them there
+    if (h->d_bounds) { const int rcb = armour_bounds_launch(h, wk->d_torque_radius); if (rcb != ARMOUR_OK) return rcb; }
     // What the host keeps of a build -- torque radii, link generators, the monomial counts behind the table statistics, the plane masks -- comes
     // back through ONE page-locked block, queued behind the half-space kernels and waited for once (five blocking copies from pageable memory
     // and a wait of their own before: 0.1 ms of a lone problem's 1.2 ms call).  Large batches keep the plain copies.
