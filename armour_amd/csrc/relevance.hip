@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
     const size_t row = (size_t)b * tb.m + tb.row0 + q;
     const double ui = a.hi[row];
     const bool lower_bounded = a.lo[row] > -1e18;   // (collision rows have no lower bound; if one had, it stays a solver row)
-    const double need2 = kRelMargin + 2.0 * sqrt(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) * (1.0 + 1e-9) - ui;
+    // (the solver's points stay inside the box to 1e-7 -- every accepted QP step is verified against the variables' bounds, solver.hip -- so the
+    //  monomials are bounded by (1 + 1e-7)^3: the sums of the solver's mask carry a factor 1 + 1e-6 where the relevance mask's carry 1 + 1e-12)
+    const double need2 = kRelMargin + 2.0 * sqrt(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) * (1.0 + 1e-6) - ui;
     bool separated = false, sep2 = a.rel2 == nullptr;
     for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
         const double hh = fabs(v.a0) * r0 + fabs(v.a1) * r1 + fabs(v.a2) * r2;
         const double L = s - hh * (1.0 + 1e-12) - v.dl;
         separated |= nz && L >= kRelMargin;
-        sep2 |= nz && L >= need2;
+        sep2 |= nz && L - hh * 1e-6 >= need2;
     }
     for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
         for (int mo = 0; mo < cnt; mo++) h += fabs(v.a0 * co[mo * 3] + v.a1 * co[mo * 3 + 1] + v.a2 * co[mo * 3 + 2]);
         const double L = s - h * (1.0 + 1e-12) - v.dl;
         separated |= nz && L >= kRelMargin;
-        sep2 |= nz && L >= need2;
+        sep2 |= nz && L - h * 1e-6 >= need2;
     }
     if (a.rel2) a.rel2[row] = (sep2 && separated && !lower_bounded) ? 0 : 1;
     a.rel[(size_t)b * tb.m + tb.row0 + q] = separated ? 0 : 1;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void armour_rel_other_kernel(RelTables a) {
         const bool relevant = cen + rad >= hi - kRelMargin || cen - rad <= lo + kRelMargin;
         a.rel[(size_t)b * tb.m + r] = relevant ? 1 : 0;
         // the solver's filter: g + 2 |J|_1 > u or g - 2 |J|_1 < l for some k (solver_common.h)
-        const double reach = (rad + 2.0 * radd) * (1.0 + 1e-9);
+        const double reach = (rad + 2.0 * radd) * (1.0 + 1e-6);
         if (a.rel2) a.rel2[(size_t)b * tb.m + r] = (relevant || cen + reach >= hi - kRelMargin || cen - reach <= lo + kRelMargin) ? 1 : 0;
     } else if (r - nT < tb.m - lim0) {
         a.rel[(size_t)b * tb.m + lim0 + (r - nT)] = 1;
@@ -357,8 +359,12 @@ int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
     a.tb = armour_make_tables(h);
     a.lo = h->d_bounds; a.hi = h->d_bounds + B * h->m;
     const int dfc = a.tb.obs_center != nullptr && a.tb.ll_shared;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    struct Events {   // (destroyed on every way out)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     if (!h->rel_fresh) {
         if ((rc = rel_alloc(&h->d_rel, &h->rel_cap, B * h->m)) != ARMOUR_OK) return rc;
         if ((rc = rel_alloc(&h->d_rel2, &h->rel2_cap, B * h->m)) != ARMOUR_OK) return rc;
@@ -429,7 +435,6 @@ int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
         h->rel2_ms = ms;
         h->rel2_fresh = true;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ARMOUR_OK;
 }
 

@@ -172,9 +172,13 @@ QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<Q
     }
     for (int j = 0; j < n; j++) res.x[j] = x[j];
     for (int i = 0; i < q; i++) if (u[i] > res.max_mult) res.max_mult = u[i];
-    // excluded rows that remain violated mean the linearisation is inconsistent
+    // The result is VERIFIED against every row, active ones included.  Excluded rows that remain violated mean the linearisation is inconsistent;
+    // and an ACTIVE row can have drifted: with an ill-conditioned M = N'G^-1 N (cost Hessian entries four orders of magnitude apart, near-parallel
+    // collision normals) z is not exactly in the null space of the active normals, the rows that are "satisfied with equality" are no longer, and
+    // nothing above looks at them again.  Round 5 met a step that broke a variable's bound by 1.6 that way and was taken as feasible (a trajectory
+    // parameter of -2.56 in a box of +-1: tools/dev/solve_stress.py, profiles/r05_solve_batches.txt).  A result that fails the check is infeasible:
+    // the next elastic attempt, or the end of the solve -- so every accepted step keeps x + d inside the box to 1e-7.
     for (int i = 0; i < m && res.feasible; i++) {
-        if (!excluded[i]) continue;
         double s = -rows[i].b;
         for (int j = 0; j < n; j++) s += rows[i].a[j] * x[j];
         if (s < -1e-7) res.feasible = false;
@@ -653,6 +657,13 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                     qp = solve_qp(n, &Hd_all[(size_t)b * NV], s.gradf, rows);
                     if (qp.feasible) break;
                     sigma = attempt == 0 ? 0.5 : attempt == 1 ? 0.9 : 0.99;
+                }
+                if (armour_trace_solve() && B == 1) {
+                    fprintf(stderr, "[armour_solve, host form] iteration %d: QP %s at sigma %.2f after %d steps, %zu rows; x =", it, qp.feasible ? "feasible" : "INFEASIBLE", sigma, qp.iterations, rows.size());
+                    for (int j = 0; j < n; j++) fprintf(stderr, " %.6g", s.x[j]);
+                    fprintf(stderr, "; d =");
+                    for (int j = 0; j < n; j++) fprintf(stderr, " %.6g", qp.x[j]);
+                    fprintf(stderr, "; viol %.6g\n", s.viol);
                 }
                 if (!qp.feasible) { s.done = true; s.status = 3; continue; }
                 double dn = 0, gd = 0;

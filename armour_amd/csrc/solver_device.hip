@@ -606,8 +606,7 @@ __device__ inline void solve_qp_device(const SolveArgs& a, Leader& L, const Solv
     int viol = 0;
     if (L.feasible)
         for (int i = tid; i < mrows; i += 256) {
-            if (!excluded[i]) continue;
-            double ar[NV], br;
+            double ar[NV], br;   // (every row, active ones included)
             qp_row(a, L, cand, i, ar, br);
             double s = -br;
 #pragma unroll
@@ -959,12 +958,11 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
         }
         WAVE_LDS_SYNC();
     }
-    // excluded rows that remain violated mean the linearisation is inconsistent
+    // the result verified against every row: excluded rows that remain violated mean the linearisation is inconsistent, active rows may have drifted
     if (feasible) {
         int viol = 0;
         for (int i = lane; i < mrows; i += 64) {
-            if (reg_rows ? !((exc_bits >> (i >> 6)) & 1u) : !excluded[i]) continue;
-            double ar[NV], br;
+            double ar[NV], br;   // (every row, active ones included: solver.hip solve_qp, "The result is VERIFIED")
             load_row(i, ar, br);
             double s = -br;
 #pragma unroll
@@ -1157,6 +1155,15 @@ __device__ __forceinline__ int leader_step(const SolveArgs& a, Leader& L, QpShar
     }
     int next;
     if (L.stop == 3) {   // evaluate the trial point
+        // (the culled form's row lists hold for points inside the variables' box; every accepted QP step is verified against the bounds, so a trial
+        //  point outside it by more than 1e-6 cannot happen -- if it ever does, the problem goes back to the host form instead of being evaluated
+        //  on lists that do not cover the point)
+        const int outside = a.culled && tid < n && !(fabs(L.xt[tid]) <= 1.0 + 1e-6) ? 1 : 0;
+        if (__syncthreads_or(outside)) {
+            if (tid == 0) a.out[b].status = -1;
+            __syncthreads();
+            return CMD_DONE;
+        }
         if (tid < n) st_coh(x_pub + tid, L.xt[tid]);   // (one lane per component: seven stores in flight instead of one after the other)
         next = CMD_EVAL;
     } else {             // finished: finalize_solution (RT/NLPclass.cu:422-538) on the last evaluation of x

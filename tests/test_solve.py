@@ -130,6 +130,31 @@ def test_culled_device_solve_equals_the_full_one(seed, O, T, B):
     nlp.close()
 
 
+def test_accepted_steps_keep_the_trajectory_parameter_in_its_box():
+    """Round 5 (tools/dev/solve_stress.py): a QP result was taken as feasible although an ACTIVE row -- a variable's bound -- had drifted by 1.6
+    (ill-conditioned N'G^-1 N: the rows "satisfied with equality" are not looked at again), the SQP went to a trajectory parameter of -2.56 in a
+    box of +-1, and the culled form -- whose row lists hold inside the box -- and the full form parted.  solve_qp now verifies its result against
+    every row.  The world that showed it, and a sweep of batches: every k_opt inside the box, the three forms equal."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_batch
+    nlp = ArmourNLP(T=100)
+    cases = [(16, 3)] + [(s, O) for s in range(1, 25, 3) for O in (3, 20)]
+    for seed, O in cases:
+        B = 32
+        bp = random_batch(9000 + 31 * seed + O, B, O)
+        if seed % 3 == 1:
+            bp["q_des"] = bp["q0"] + 0.05 * (bp["q_des"] - bp["q0"])   # goals near the start: part of the problems feasible
+        nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        nlp.set_option(_lib.OPT_SOLVE_CULL, 1); cul = nlp.solve(device_qp=True)
+        nlp.set_option(_lib.OPT_SOLVE_CULL, 0); full = nlp.solve(device_qp=True)
+        host = nlp.solve(host_qp=True)
+        for b, (c, f, h) in enumerate(zip(cul, full, host)):
+            assert np.all(np.abs(c["k_opt"]) <= 1.0 + 1e-6), (seed, O, b, c["k_opt"])
+            assert _same_solution(c, f) and _same_solution(c, h), (seed, O, b, c, f, h)
+    nlp.close()
+
+
 def test_culled_device_solve_in_armtd_mode():
     from armour_amd import _lib
     from armour_amd.planner import ArmourNLP
