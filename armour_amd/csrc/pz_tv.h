@@ -546,7 +546,6 @@ __device__ inline void mul_walk(TW& t, const Wave& sw, const LDS_AS double* stag
     cx.stage = stage;
     const Wave& w = sw;
     const int lane = t.w.lane;
-    const int rl = t.rl;   // (the lane's place in a row)
     if (indirect) walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
     else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
@@ -916,7 +915,6 @@ __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* st
     for (int e = 0; e < 12; e++) cx.rad[e] = 0.0;
     const Wave& w = sw;
     const int lane = t.w.lane;
-    const int rl = t.rl;   // (the lane's place in a row)
     if (indirect) walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return ev.key_lds(w, w.sidx[p]); }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
     else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
