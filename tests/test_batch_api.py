@@ -122,6 +122,11 @@ def test_batch_over_device_slots_equals_one_handle(slots):
         assert np.array_equal(r1["k_opt"], r2["k_opt"]) and r1["feasible"] == r2["feasible"] and r1["status"] == r2["status"]
         assert r1["cost"] == r2["cost"] and r1["iterations"] == r2["iterations"]
     assert bt.build_ms > 0
+    # the row lists are per handle: culled row test and culled solve on every slot (round 5), same records and results
+    bt.set_option(_lib.OPT_CULL_ROWS, 1); bt.set_option(_lib.OPT_SOLVE_CULL, 1); bt.set_option(_lib.OPT_SOLVE_DEVICE, 2)
+    assert [(v["l1_violation"], v["n_violated"], v["feasible"]) for v in one.eval_violations(k)] == [(v["l1_violation"], v["n_violated"], v["feasible"]) for v in bt.eval_violations(k)]
+    for r1, r2 in zip(s1, bt.solve()):
+        assert np.array_equal(r1["k_opt"], r2["k_opt"]) and r1["feasible"] == r2["feasible"] and r1["status"] == r2["status"] and r1["cost"] == r2["cost"]
     # errors of a worker thread reach the caller: an out-of-range capacity on one slot's problems
     with pytest.raises(_lib.ArmourError):
         bad = bp["q0"].copy(); bad[B - 1, 0] = np.nan
