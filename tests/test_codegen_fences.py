@@ -1,16 +1,18 @@
-"""The two code-generation hazards of rounds 1-3 and the fences that hold them.
+"""The code-generation hazards of rounds 1-4 and what holds them (profiles/r05_codegen_hazards.txt).
 
-Neither mechanism could be isolated (no <= 200-line reproduction fails on the GPU box: tools/micro/divloop_dpp.hip runs correctly at every
-occupancy, and the controller's faulting form left an unreadable dump), so both are held by fences, and the fences are under test:
+Round 5 found the mechanism of the memory-aperture violations (the controller's non-inlined form of round 3, the time-vectorised kernel's one-wave
+blocks on narrow rows): ROCm 7.2's clang relaxes branches over more than 128 KB through s[30:31] -- the return address -- in functions that make no
+calls, without saving it.  Every non-inlined device function now keeps its return address elsewhere (pz_wave.h PZ_KEEP_RETURN_ADDRESS) and `make`
+runs tools/check_long_branches.py on every library it links.  Two hazards are still unexplained and stay fenced; the fences are under test here:
 
   * reach-set operators (round 1: a memory fault under interprocedural register allocation; round 2: wrong tables with two waves per SIMD):
-    the shipped object is built with -enable-ipra=false and pinned to one wave per SIMD, `make` fails otherwise (tools/check_p1_occupancy.py),
+    the shipped objects are built with -enable-ipra=false and pinned to one wave per SIMD, `make` fails otherwise (tools/check_p1_occupancy.py),
     and HERE the same source with every LDS / arena index of the product merge and of the reduce passes range-checked (-DDBG_BOUNDS,
     armour_amd/lib/libarmour_hip_checked.so) runs a fuzz set in every launch shape: no check fires (a firing check fails the build call with
-    flag 128) and the tables equal the shipped library's bit for bit;
-  * controller kernels (round 3: a memory-aperture violation when the interval RNEA's halves were functions of their own): `make` fails
-    unless controller.o holds exactly the two kernels, each with a static stack (tools/check_controller_codegen.py); HERE the check is run on
-    the remarks of the object that was shipped, and on a doctored copy that it must reject.
+    flag 128) and the tables equal the shipped library's bit for bit; the two-waves-per-SIMD build of today's source (`make occ2`) must
+    reproduce the shipped tables over 12 fresh handles per batch size;
+  * controller kernels: `make` fails unless controller.o holds exactly the two kernels, each with a static stack (tools/check_controller_codegen.py);
+    HERE the check is run on the remarks of the object that was shipped, and on a doctored copy that it must reject.
 """
 import os
 import subprocess
