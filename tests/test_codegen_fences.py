@@ -118,3 +118,38 @@ def test_controller_codegen_check_accepts_the_shipped_object_and_rejects_a_calle
     dyn = tmp_path / "dyn.txt"
     dyn.write_text(text.replace("Dynamic Stack: False", "Dynamic Stack: True", 1))
     assert subprocess.run([sys.executable, tool, str(dyn)], capture_output=True, text=True).returncode == 1
+
+
+def test_long_branch_check_on_listings_and_on_the_shipped_library():
+    """CPU: tools/check_long_branches.py, the build gate of DESIGN.md 7.  On listings: a leaf function that relaxes a branch through s[30:31]
+    without saving it is reported; the same function with the return address kept in a VGPR lane, a function that only CALLS through s[30:31]'s
+    neighbours, and one without relaxed branches are not.  On the shipped library: nothing to report."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_long_branches as clb
+    leaf = """
+0000000000001000 <leaf_without_a_saved_return_address>:
+\ts_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)
+\ts_cbranch_scc0 8
+\ts_getpc_b64 s[30:31]
+\ts_add_u32 s30, s30, 0x34f88
+\ts_addc_u32 s31, s31, 0
+\ts_setpc_b64 s[30:31]
+\tv_mov_b32_e32 v0, 0
+\ts_setpc_b64 s[30:31]
+"""
+    kept = leaf.replace("leaf_without_a_saved_return_address", "leaf_with_the_guard").replace("\ts_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)\n",
+                                                                                              "\ts_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)\n\tv_writelane_b32 v40, s30, 0\n\tv_writelane_b32 v40, s31, 1\n")
+    other = """
+0000000000003000 <calls_through_another_pair>:
+\ts_getpc_b64 s[16:17]
+\ts_add_u32 s16, s16, 0x100
+\ts_addc_u32 s17, s17, 0
+\ts_swappc_b64 s[30:31], s[16:17]
+\ts_setpc_b64 s[30:31]
+"""
+    bad, nfun, nlong = clb.scan(leaf + kept + other)
+    assert nfun == 3 and nlong == 2 and [b[0] for b in bad] == ["leaf_without_a_saved_return_address"], (bad, nfun, nlong)
+    lib = os.path.join(ROOT, "armour_amd", "lib", "libarmour_hip.so")
+    if os.path.exists(lib) and os.path.exists(clb.OBJDUMP):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_long_branches.py"), lib], capture_output=True, text=True)
+        assert r.returncode == 0 and "0 relaxed branch(es)" in r.stdout, r.stdout + r.stderr

@@ -37,6 +37,35 @@ def code_objects(path):
     return out
 
 
+def scan(dis):
+    """(functions that relax a branch through an unsaved s[30:31]: [(name, branches, lines)], functions seen, relaxed branches seen) of one
+    llvm-objdump -d listing"""
+    bad, nfun, nlong = [], 0, 0
+    name, body = None, []
+
+    def flush():
+        nonlocal nfun, nlong
+        if name is None:
+            return
+        nfun += 1
+        lb = sum(1 for l in body if re.match(r"\s*s_getpc_b64 s\[30:31\]", l))
+        if not lb:
+            return
+        nlong += lb
+        saved = any(re.match(r"\s*(v_writelane_b32 v\d+, s3[01],|s_mov_b64 s\[\d+:\d+\], s\[30:31\]|s_mov_b32 s\d+, s3[01]\b)", l) for l in body)
+        if not saved:
+            bad.append((name, lb, len(body)))
+    for l in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]{16} <(.+)>:", l)
+        if m:
+            flush()
+            name, body = m.group(1), []
+        else:
+            body.append(l)
+    flush()
+    return bad, nfun, nlong
+
+
 def check(path):
     bad, nfun, nlong = [], 0, 0
     for k, img in enumerate(code_objects(path)):
@@ -47,28 +76,8 @@ def check(path):
             dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", tmp], capture_output=True, text=True).stdout
         finally:
             os.unlink(tmp)
-        name, body = None, []
-
-        def flush():
-            nonlocal nfun, nlong
-            if name is None:
-                return
-            nfun += 1
-            lb = sum(1 for l in body if re.match(r"\s*s_getpc_b64 s\[30:31\]", l))
-            if not lb:
-                return
-            nlong += lb
-            saved = any(re.match(r"\s*(v_writelane_b32 v\d+, s3[01],|s_mov_b64 s\[\d+:\d+\], s\[30:31\]|s_mov_b32 s\d+, s3[01]\b)", l) for l in body)
-            if not saved:
-                bad.append((name, lb, len(body)))
-        for l in dis.split("\n"):
-            m = re.match(r"^[0-9a-f]{16} <(.+)>:", l)
-            if m:
-                flush()
-                name, body = m.group(1), []
-            else:
-                body.append(l)
-        flush()
+        b, nf, nl = scan(dis)
+        bad += b; nfun += nf; nlong += nl
     return bad, nfun, nlong
 
 
