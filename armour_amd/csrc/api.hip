@@ -284,6 +284,7 @@ static int begin_problem_set(ArmourPlanner* h, int B, int O, const double* q0, c
     h->ready = false;
     h->rel_fresh = false; h->rel2_fresh = false;
     h->bounds_on_device = false; h->bounds_on_host = false;
+    h->tables_from_host = false;
     h->stats_fresh = false;
     drop_step_graphs(h);  // they bake in the tables of the previous problem set
     int rc = ensure_capacity(h, B, O);
@@ -446,6 +447,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
     h->h_link_gens.assign((size_t)B * T * J * 18, 0.0);
     rc = armour_refresh_table_stats(h);
     if (rc != ARMOUR_OK) return rc;
+    h->tables_from_host = true;
     h->ready = true;
     return ARMOUR_OK;
 }
@@ -802,6 +804,7 @@ extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value)
         if (ok && option == ARMOUR_OPT_P1_TV_ROW_WIDTH) ok = value == 0.0 || value == 50.0 || value == 64.0;
         if (ok) {
             h->tuning[option - ARMOUR_OPT_FIRST_TUNING] = value;
+            h->p1_step_cap_hint = 0; h->p1_tv_shape_hint = 0;   // (an option may re-enable a block shape the hints had moved past)
             return ARMOUR_OK;
         }
     }
@@ -886,14 +889,15 @@ __global__ __launch_bounds__(256) void armour_violation_kernel(ViolArgs a) {
 }
 }  // namespace
 
-extern "C" int armour_eval_violations_device(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream) {
+// allow_cull = false: every row whatever ARMOUR_OPT_CULL_ROWS says (the host entry's second pass for a k outside the box)
+static int eval_violations_device_impl(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream, bool allow_cull) {
     NEED_READY(h);
     if (!d_k || !d_out) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     int rc = armour_upload_bounds(h);
     if (rc != ARMOUR_OK) return rc;
     const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    if (h->tune(ARMOUR_OPT_CULL_ROWS)) return armour_eval_violations_culled(h, d_k, d_out, st);   // the relevant rows only: relevance.hip
+    if (allow_cull && h->tune(ARMOUR_OPT_CULL_ROWS)) return armour_eval_violations_culled(h, d_k, d_out, st);   // the relevant rows only: relevance.hip
     const P2Tables tb = armour_make_tables(h);
     // g only (the Jacobian tile, 7/8 of the output bytes, is neither computed nor written), into the handle's own g buffer
     rc = armour_p2_launch(tb, h->max_link, h->max_torque, h->h_plane_skip.data(), d_k, h->d_g, nullptr, st);
@@ -905,6 +909,10 @@ extern "C" int armour_eval_violations_device(ArmourPlanner* h, const double* d_k
     hipLaunchKernelGGL(armour_violation_kernel, dim3(h->B), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return ARMOUR_OK;
+}
+
+extern "C" int armour_eval_violations_device(ArmourPlanner* h, const double* d_k, ArmourViolation* d_out, void* stream) {
+    return eval_violations_device_impl(h, d_k, d_out, stream, true);
 }
 
 extern "C" int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourViolation* out) {
@@ -924,7 +932,11 @@ extern "C" int armour_eval_violations(ArmourPlanner* h, const double* k, ArmourV
     if (!hk || !hv) return ARMOUR_EDEVICE;
     memcpy(hk, k, bn * sizeof(double));
     HIPCHK(hipMemcpyAsync(h->d_k, hk, bn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    int rc = armour_eval_violations_device(h, h->d_k, h->d_viol, h->stream);
+    // The relevant-rows form (ARMOUR_OPT_CULL_ROWS) holds for k inside [-1, 1]^n -- its mask says "never violated for a k of the box" (relevance.hip).
+    // A call with any component outside the box takes every row instead: the records then are the full evaluation's, as the header promises.
+    bool in_box = true;
+    for (size_t i = 0; i < bn && in_box; i++) in_box = fabs(k[i]) <= 1.0;
+    int rc = eval_violations_device_impl(h, h->d_k, h->d_viol, h->stream, in_box);
     if (rc != ARMOUR_OK) return rc;
     HIPCHK(hipMemcpyAsync(hv, h->d_viol, (size_t)h->B * sizeof(ArmourViolation), hipMemcpyDeviceToHost, h->stream));
     rc = spin_on_stream(h->stream);

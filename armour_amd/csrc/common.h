@@ -168,6 +168,7 @@ struct ArmourPlanner {
     SolveDeviceWork solve_dev;
     double* d_bounds = nullptr;      // [2][B][m] g_l, g_u for the solver's device-side scan (uploaded on the first solve of a problem set)
     bool bounds_on_device = false, bounds_on_host = false;
+    bool tables_from_host = false;   // armour_debug_load_tables: plane normals are the caller's, not necessarily unit vectors (relevance.hip)
     std::vector<double> h_gl, h_gu;  // host copy of the same bounds (valid while bounds_on_host: the host-driven solver form fills it)
     std::vector<double> h_q0, h_qd0, h_qdd0, h_qdes;  // [B][n]
     std::vector<double> h_torque_radius;              // [B][n][T]
@@ -205,6 +206,9 @@ struct ArmourPlanner {
     // handle -- the same robot, a similar problem -- starts there instead of repeating the failed launches (8-factor arms on the halved key buffers of
     // the 128-bit build: 4 launches, 67 ms, for a 25 ms build).  0 = from the beginning.
     int p1_step_cap_hint = 0, p1_tv_shape_hint = 0;
+    // the hints only ever grow inside a run of like builds: they are dropped when the problem set changes class (B, T or O), with every
+    // armour_set_option, and every 64th build (one hard problem must not pin a long-lived handle to larger buffers for good: ADVICE r5)
+    int p1_hint_B = 0, p1_hint_T = 0, p1_hint_O = 0, p1_hint_builds = 0;
     int build_info[4] = {0, 0, 0, 0};          // armour_get_build_info: kernel of the last reach-set build, waves per block, sort-buffer entries, launches
     int max_link = 0, max_torque = 0;          // largest monomial counts in the current tables (LDS sizing of P2)
     long long sum_link = 0, sum_torque = 0;

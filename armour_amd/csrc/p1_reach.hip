@@ -1852,6 +1852,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
 
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    if (h->p1_hint_B != B || h->p1_hint_T != T || h->p1_hint_O != O || ++h->p1_hint_builds >= 64) {
+        h->p1_step_cap_hint = 0; h->p1_tv_shape_hint = 0; h->p1_hint_builds = 0;
+        h->p1_hint_B = B; h->p1_hint_T = T; h->p1_hint_O = O;
+    }
     int cap_raw = 64;
     while (cap_raw < h->lim.raw_terms || cap_raw < h->p1_step_cap_hint) cap_raw <<= 1;   // (the hint: what the last build of this handle ended up with)
     if ((rc = grow(&wk->d_retry, &wk->retry_cap, (size_t)1 + (size_t)B * T)) != ARMOUR_OK) return rc;
@@ -2188,7 +2192,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMemcpyAsync(rb + off_tc, h->d_tq_count, n_tc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (O > 0) HIPCHK(hipMemcpyAsync(rb + off_ps, h->d_plane_skip, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     }
-    if (O > 0 || rb) HIPCHK(p1_wait_stream(h->stream));
+    // (unconditional: the bounds kernel above and the blocking copies below are ordered against h->stream -- a non-blocking stream -- by this
+    //  wait alone; with O == 0 and a batch beyond the page-locked block it used to be skipped: ADVICE r5)
+    HIPCHK(p1_wait_stream(h->stream));
     if (O > 0) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));

@@ -61,7 +61,12 @@ __device__ inline PlaneVals load_plane(const P2Tables& tb, const double* pl0, co
 }
 
 // ---- collision rows: one lane per row
-__global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, int dfc) {
+// (1 + 1e-6)^21 < 1 + kBoxSlack: a monomial of total degree <= 3 n = 21 at a point the persistent solver still evaluates on the lists (its guard
+// admits |x_j| <= 1 + 1e-6, solver_device.hip) against its bound on the box -- the factor the solver's mask inflates its sums by (the
+// per-factor degree 3 under-counted it)
+constexpr double kBoxSlack = 3e-5;
+
+__global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, int dfc, int any_normals) {
     const P2Tables& tb = a.tb;
     const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
     const int Q = tb.Q, O = tb.O, JT = tb.J * tb.T;
@@ -97,9 +102,17 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
     const size_t row = (size_t)b * tb.m + tb.row0 + q;
     const double ui = a.hi[row];
     const bool lower_bounded = a.lo[row] > -1e18;   // (collision rows have no lower bound; if one had, it stays a solver row)
-    // (the solver's points stay inside the box to 1e-7 -- every accepted QP step is verified against the variables' bounds, solver.hip -- so the
-    //  monomials are bounded by (1 + 1e-7)^3: the sums of the solver's mask carry a factor 1 + 1e-6 where the relevance mask's carry 1 + 1e-12)
-    const double need2 = kRelMargin + 2.0 * sqrt(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) * (1.0 + 1e-6) - ui;
+    // (the solver's points stay inside the box to 1e-7 -- every accepted QP step is verified against the variables' bounds, solver.hip -- and the
+    //  persistent kernel hands a point beyond 1 + 1e-6 back to the host form: the sums of the solver's mask carry a factor 1 + kBoxSlack where the
+    //  relevance mask's carry 1 + 1e-12.  |J_i|_1 <= |A_win|_2 |rd|_2: the build's normals are unit vectors; tables loaded from the host
+    //  (armour_debug_load_tables, `any_normals`) carry whatever the caller gave, so the bound takes each plane's own norm there.)
+    double amax = 1.0;   // the largest norm a winning normal can have
+    if (any_normals && a.rel2)
+        for (unsigned long long live = live0; live; live &= live - 1ull) {
+            const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
+            amax = fmax(amax, sqrt(v.a0 * v.a0 + v.a1 * v.a1 + v.a2 * v.a2) * (1.0 + 1e-12));
+        }
+    const double need2 = kRelMargin + 2.0 * sqrt(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) * amax * (1.0 + kBoxSlack) - ui;
     bool separated = false, sep2 = a.rel2 == nullptr;
     for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
         const double hh = fabs(v.a0) * r0 + fabs(v.a1) * r1 + fabs(v.a2) * r2;
         const double L = s - hh * (1.0 + 1e-12) - v.dl;
         separated |= nz && L >= kRelMargin;
-        sep2 |= nz && L - hh * 1e-6 >= need2;
+        sep2 |= nz && L - hh * kBoxSlack >= need2;
     }
     for (unsigned long long live = live0; live && !(separated && sep2); live &= live - 1ull) {
         const PlaneVals v = load_plane(tb, pl0, pll, Q, q, __builtin_ctzll(live), dfc != 0, oc0, oc1, oc2);
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(64) void armour_rel_collision_kernel(RelTables a, i
         for (int mo = 0; mo < cnt; mo++) h += fabs(v.a0 * co[mo * 3] + v.a1 * co[mo * 3 + 1] + v.a2 * co[mo * 3 + 2]);
         const double L = s - h * (1.0 + 1e-12) - v.dl;
         separated |= nz && L >= kRelMargin;
-        sep2 |= nz && L - h * 1e-6 >= need2;
+        sep2 |= nz && L - h * kBoxSlack >= need2;
     }
     if (a.rel2) a.rel2[row] = (sep2 && separated && !lower_bounded) ? 0 : 1;
     a.rel[(size_t)b * tb.m + tb.row0 + q] = separated ? 0 : 1;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256) void armour_rel_other_kernel(RelTables a) {
         const bool relevant = cen + rad >= hi - kRelMargin || cen - rad <= lo + kRelMargin;
         a.rel[(size_t)b * tb.m + r] = relevant ? 1 : 0;
         // the solver's filter: g + 2 |J|_1 > u or g - 2 |J|_1 < l for some k (solver_common.h)
-        const double reach = (rad + 2.0 * radd) * (1.0 + 1e-6);
+        const double reach = (rad + 2.0 * radd) * (1.0 + kBoxSlack);
         if (a.rel2) a.rel2[(size_t)b * tb.m + r] = (relevant || cen + reach >= hi - kRelMargin || cen - reach <= lo + kRelMargin) ? 1 : 0;
     } else if (r - nT < tb.m - lim0) {
         a.rel[(size_t)b * tb.m + lim0 + (r - nT)] = 1;
@@ -252,6 +265,7 @@ struct SparseViolArgs {
     double torque_slack, collision_slack;
     const double* g; const double* lo; const double* hi;
     const int* rows_res; const int* count_res;   // (by residue class of the row index: armour_rel_list_kernel)
+    const double* k; int n;                      // the point [B][n]: the lists hold for k inside the box only
     ArmourViolation* out;
 };
 __global__ __launch_bounds__(256) void armour_sparse_violation_kernel(SparseViolArgs a) {
@@ -296,6 +310,12 @@ __global__ __launch_bounds__(256) void armour_sparse_violation_kernel(SparseViol
         ArmourViolation o;
         o.l1_violation = s_l1[0]; o.worst = s_w[0]; o.worst_row = s_row[0]; o.n_violated = s_nv[0]; o.n_outside_slack = s_no[0];
         o.feasible = s_no[0] == 0 ? 1 : 0;
+        // The mask says "never violated for a k of [-1, 1]^n".  A point outside the box may violate an unlisted row, so its record cannot claim to be
+        // the full evaluation's: it is marked instead (feasible = -1, worst_row = -2; armour_hip.h) -- the host entry never gets here with such a point
+        // (it takes every row then), a device caller re-evaluates the problem with ARMOUR_OPT_CULL_ROWS = 0.
+        bool in_box = true;
+        for (int j = 0; j < a.n; j++) in_box = in_box && fabs(a.k[(size_t)b * a.n + j]) <= 1.0;
+        if (!in_box) { o.feasible = -1; o.worst_row = -2; }
         a.out[b] = o;
     }
 }
@@ -375,7 +395,7 @@ int armour_relevance_build(ArmourPlanner* h, bool for_solver) {
         a.tq_tiles = nullptr; a.tq_count = nullptr; a.tq_cap = 0;
         a.packed = nullptr; a.pack_off = nullptr;
         HIPCHK(hipEventRecord(e0, h->stream));
-        if (h->Q > 0) hipLaunchKernelGGL(armour_rel_collision_kernel, dim3((h->Q + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc);
+        if (h->Q > 0) hipLaunchKernelGGL(armour_rel_collision_kernel, dim3((h->Q + 63) / 64, h->B), dim3(64), 0, h->stream, a, dfc, h->tables_from_host ? 1 : 0);
         const int other = h->row0 + (h->m - h->row0 - h->Q);
         hipLaunchKernelGGL(armour_rel_other_kernel, dim3((other + 255) / 256, h->B), dim3(256), 0, h->stream, a);
         hipLaunchKernelGGL(armour_rel_list_kernel, dim3(h->B), dim3(256), 0, h->stream, a);
@@ -490,7 +510,7 @@ int armour_eval_violations_culled(ArmourPlanner* h, const double* d_k, ArmourVio
     SparseViolArgs v;
     v.m = h->m; v.row0 = h->row0; v.Q = h->Q; v.n_checked = armour_checked_collision_rows(h);
     v.torque_slack = h->params.torque_violation_threshold; v.collision_slack = h->params.collision_violation_threshold;
-    v.g = h->d_g; v.lo = a.lo; v.hi = a.hi; v.rows_res = a.rows_res; v.count_res = a.count_res; v.out = d_out;
+    v.g = h->d_g; v.lo = a.lo; v.hi = a.hi; v.rows_res = a.rows_res; v.count_res = a.count_res; v.k = d_k; v.n = h->n; v.out = d_out;
     hipLaunchKernelGGL(armour_sparse_violation_kernel, dim3(h->B), dim3(256), 0, st, v);
     HIPCHK(hipGetLastError());
     return ARMOUR_OK;

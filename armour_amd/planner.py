@@ -351,9 +351,14 @@ class ArmourNLP:
         check(self.L.armour_eval_g_jac(self.h, _dp(self._k(x)), None, _dp(jac)))
         return jac
 
-    def eval_g_jac(self, x, pinned=False):
-        """pinned=True returns views of page-locked buffers owned by this object (valid until the next call)."""
-        if pinned:
+    def eval_g_jac(self, x, pinned=False, out=None):
+        """pinned=True returns views of page-locked buffers owned by this object (valid until the next call); out=(g, jac) writes into the
+        caller's own C-contiguous float64 arrays (an IPOPT TNLP's `g` and `values`, reused call after call)."""
+        if out is not None:
+            k, (g, jac) = self._k(x), out
+            assert g.dtype == np.float64 and jac.dtype == np.float64 and g.flags.c_contiguous and jac.flags.c_contiguous
+            assert g.size == self.B * self.m and jac.size == self.B * self.m * self.n
+        elif pinned:
             k = self._pinned("k", (self.B, self.n)); k[...] = np.asarray(x, dtype=np.float64).reshape(self.B, self.n)
             # g and jac in ONE page-locked block, jac directly behind g: armour_eval_g_jac then brings both back in one transfer
             gj = self._pinned("gjac", (self.B * self.m * (1 + self.n),))

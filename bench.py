@@ -88,7 +88,33 @@ def launch_ranks(n_ranks, argv):
 
 
 # ----------------------------------------------------------------------------------------------- measurement pieces
+OMP_ENV = {"OMP_WAIT_POLICY": "passive", "OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}
+
+
 def cpu_baseline(T, O, seed, budget_s=12.0):
+    """Parent side: the oracle is timed in a process of its own, started with the OpenMP settings that serve it best (VERDICT r5 item 7:
+    waiting threads sleep instead of spinning, threads bound to neighbouring cores) -- libgomp reads them when it is loaded, and this
+    process loaded it with torch.  The child touches no GPU.  Falls back to timing in this process when the child cannot be started."""
+    env = dict(os.environ, **OMP_ENV)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--time-steps", str(T), "--obstacles", str(O)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE_JSON "):
+                d = json.loads(line[len("CPU_BASELINE_JSON "):])
+                d["openmp_environment"] = OMP_ENV
+                return d
+        err = (r.stderr or r.stdout)[-300:]
+    except Exception as e:
+        err = repr(e)
+    d = cpu_baseline_body(T, O, seed, budget_s)
+    d["openmp_environment"] = {"note": "timed in the bench process itself (default OpenMP settings): the child failed", "error": err}
+    return d
+
+
+def cpu_baseline_body(T, O, seed, budget_s=12.0):
     """Oracle (kind 'port') on the host cores: P2 evals/s on the same world, bounded to ~budget_s seconds."""
     from oracle.cpu_oracle import Oracle, max_threads
     from armour_amd.worlds import random_k, random_problem
@@ -105,7 +131,8 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     host = host_description()
     avail = int(host["cpus_usable_by_this_process"] or max_threads())
     best_t, best_rate, sweep = 0, 0.0, {}
-    for th in sorted({min(c, avail) for c in (1, 16, 32, 64, 128, avail)}):
+    phys = int(host["physical_cores"] or avail)
+    for th in sorted({min(c, avail) for c in (1, 8, 16, 32, 64, 128, phys, avail)}):
         o.time_eval(ks, 3, threads=th)  # warm-up
         burst = 16 / o.time_eval(ks, 16, threads=th)
         n = int(max(16, min(8000, burst * 1.0)))
@@ -121,7 +148,7 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     # the reach-set build (P1, RT/armour_main.cu:96-216: OpenMP over the time steps) as its own timed figure: the same world at
     # 1 thread, at the reference's 32 (NUM_THREADS, RT/Parameters.h:35) and at all cores; best of 2 builds each (1 at one thread)
     p1 = {}
-    for th in sorted({1, min(32, avail), avail}):
+    for th in sorted({1, min(32, avail), min(phys, avail), avail}):
         ms = []
         for _ in range(1 if th == 1 else 2):
             ob = Oracle(T=T).set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"], threads=th)
@@ -132,6 +159,7 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
         "cores_note": "`cores` = the OpenMP threads of the fastest setting of the sweep (what `value` was measured with), not the box's core count: see host",
         "host": host, "cpu_model": host["cpu_model"], "physical_cores": host["physical_cores"], "logical_cpus": host["logical_cpus"],
         "thread_sweep_iters_per_s": sweep, "sample_parts_iters_per_s": [part / t for t in part_secs],
+        "iters_per_s_at_all_physical_cores": sweep.get(str(min(phys, avail))), "iters_per_s_at_reference_32_threads": sweep.get(str(min(32, avail))),
         "sample": f"{reps} fused eval_g+eval_jac_g of 1 world (seed {seed}, O={O}, T={T}) at 64 cycling k points, "
                   f"OpenMP over time steps as RT/NLPclass.cu:304,376",
         "p1_build_ms_by_threads": p1, "p1_build_ms": min(p1.values()), "p1_pair_products": int(o.stats()["mul_pairs"]),
@@ -527,6 +555,7 @@ def main():
                          "kernel to the trace), i.e. skip the host-entry check and the sync-latency probe")
     ap.add_argument("--set-option", action="append", default=[], metavar="ID=VALUE", help="development: armour_set_option on every handle (A/B runs)")
     ap.add_argument("--dry-run", action="store_true", help="development / tests: launcher + rendezvous + reduction on CPU (gloo), no GPU work")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help="internal: the body of the cpu_baseline measurement (a process started with OMP_WAIT_POLICY=passive etc.; no GPU)")
     ap.add_argument("--fetch8-child", action="store_true", help="internal: the body of the configs[4] 8-factor measurement (a process with ARMOUR_KEY128=1)")
     ap.add_argument("--rank-devices", default="", metavar="D0,D1,...", help="development / tests: device ordinal of every rank (default: rank r on device r); "
                     "several ranks on one device need --dist-backend gloo (RCCL refuses two ranks on one GPU)")
@@ -535,6 +564,9 @@ def main():
     for kv in args.set_option:
         OPTIONS.append((int(kv.split("=")[0]), float(kv.split("=")[1])))
 
+    if args.cpu_baseline_child:
+        print("CPU_BASELINE_JSON " + json.dumps(cpu_baseline_body(args.time_steps, args.obstacles, seed=0)), flush=True)
+        return
     if args.fetch8_child:
         return fetch8_child(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -585,30 +617,36 @@ def main():
     n, m = nlp.n, nlp.m
 
     def sync_probe():
-        # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac)
-        k1 = np.full((B, n), 0.25)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            nlp.eval_g_jac(k1)
-        sync_us = (time.perf_counter() - t1) / 20 * 1e6
-        nlp.eval_g_jac(k1, pinned=True)        # allocates the page-locked buffers
-        tt = []
+        # synchronous single-call latency as an IPOPT host loop would see it (H2D k, launch, D2H g+jac); VERDICT r5 item 3: every leg
+        # with one untimed call first, the interpreter's garbage collector held off (a generation-2 pass of a process with torch loaded
+        # is ~40 ms: DESIGN.md section 5), per-call times, and median / mean / max / index of the slowest call in the line
         import gc
-        gc.collect(); gc.disable()             # (a generation-2 pass of this interpreter -- torch's modules are loaded -- is tens of ms: not the call's)
-        try:
-            for _ in range(50):
-                t1 = time.perf_counter()
-                nlp.eval_g_jac(k1, pinned=True)
-                tt.append((time.perf_counter() - t1) * 1e6)
-            tv = []
-            for _ in range(50):   # the reduced-output entry: k in, one 32-byte record per problem out
-                t1 = time.perf_counter()
-                nlp.eval_violations(k1)
-                tv.append((time.perf_counter() - t1) * 1e6)
-        finally:
-            gc.enable()
-        return {"pageable": sync_us, "pinned": statistics.median(tt), "violations": statistics.median(tv), "pinned_mean": sum(tt) / len(tt), "pinned_max": max(tt), "pinned_argmax": tt.index(max(tt)),
-                "note": "pinned = median of 50 calls with buffers from armour_alloc_pinned (k in, g | jac out as asynchronous DMA transfers on the handle's stream)"}
+        k1 = np.full((B, n), 0.25)
+
+        def leg(call, reps):
+            call()
+            tt = []
+            gc.collect(); gc.disable()
+            try:
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    call()
+                    tt.append((time.perf_counter() - t1) * 1e6)
+            finally:
+                gc.enable()
+            return tt
+
+        g_own, jac_own = np.zeros((B, m)), np.zeros((B, m, n))       # the caller's own arrays, reused: an IPOPT TNLP's `g` and `values`
+        tp = leg(lambda: nlp.eval_g_jac(k1, out=(g_own, jac_own)), 50)
+        tf = leg(lambda: nlp.eval_g_jac(k1), 20)                     # fresh numpy arrays per call (never-touched pages every time)
+        tt = leg(lambda: nlp.eval_g_jac(k1, pinned=True), 50)
+        tv = leg(lambda: nlp.eval_violations(k1), 50)                # the reduced-output entry: k in, one 32-byte record per problem out
+        return {"pageable": statistics.median(tp), "pageable_mean": sum(tp) / len(tp), "pageable_max": max(tp), "pageable_argmax": tp.index(max(tp)),
+                "pageable_fresh_arrays": statistics.median(tf), "pageable_fresh_arrays_mean": sum(tf) / len(tf), "pageable_fresh_arrays_max": max(tf),
+                "pinned": statistics.median(tt), "violations": statistics.median(tv), "pinned_mean": sum(tt) / len(tt), "pinned_max": max(tt), "pinned_argmax": tt.index(max(tt)),
+                "note": "medians of 50 calls after one untimed call, garbage collector held off; pageable = armour_eval_g_jac(h, x, g, values) on the caller's own "
+                        "reused arrays; pageable_fresh_arrays = new numpy arrays per call (20 calls); pinned = buffers from armour_alloc_pinned (k in, g | jac out as "
+                        "asynchronous DMA transfers on the handle's stream)"}
 
     probe_early = {}
     if os.environ.get("BENCH_PROBE_POINTS") and rank == 0:   # development: where in this process does the page-locked call get slow?

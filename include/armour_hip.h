@@ -141,7 +141,10 @@ void armour_free_pinned(void* p);
 /* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
 #define ARMOUR_OPT_P2_EX 130                  /* 1 (default) | 0: the fixed-load-count kernels for problems with exactly 24 live planes */
 #define ARMOUR_OPT_STEPS_GRAPH_MIN 131        /* default 2: armour_eval_g_jac_device_steps submits >= this many steps as one graph; 0 never */
-#define ARMOUR_OPT_CULL_ROWS 133              /* 0 (default) | 1: armour_eval_violations* evaluate the rows that can be violated for some k only (armour_get_row_relevance): same L1 violation, counts and verdict bit for bit; `worst` is the full evaluation's whenever a row is violated */
+#define ARMOUR_OPT_CULL_ROWS 133              /* 0 (default) | 1: armour_eval_violations* evaluate the rows that can be violated for some k only (armour_get_row_relevance): same L1 violation, counts and verdict bit for bit; `worst` is the full evaluation's whenever a row is violated.
+                                                * PRECONDITION: k inside [-1, 1]^n (the mask is a statement about the box).  armour_eval_violations (host k) takes every row when a component
+                                                * lies outside; armour_eval_violations_device cannot look at k on the host: the record of a problem whose k is outside the box comes back
+                                                * with feasible = -1 and worst_row = -2, and is to be re-evaluated with the option at 0 */
 #define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
 /* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
 #define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */

@@ -493,7 +493,9 @@ static void build(Problem& P, int num_threads) {
         I_unc[i] = pz_matrix_uncertain(3, 3, &P.rb.inertia[9 * i], armour_inertia_uncertainty(&P.rb, i));
         link_box[i] = make_link_box(P, cx0, i);
     }
-#pragma omp parallel
+    /* (a team wider than the T items only adds idle threads to every barrier: bench.py's sweep on a 256-thread host) */
+    const int team = std::max(1, std::min(omp_get_max_threads(), T));
+#pragma omp parallel num_threads(team)
     {
         Ctx cx; cx.kl.n = n; cx.threshold = P.pr.simplify_threshold;
 #pragma omp for schedule(dynamic, 1)
@@ -613,7 +615,8 @@ static void eval_g_jac(Problem& P, const double* x, double* g, double* jac, int 
     Ctx cx; cx.kl.n = n;
     /* ARMTD mode, CMP/NLPclass.cu:245-330: collision rows first, then the state-limit rows; no torque rows */
     const size_t off_col = P.no_torque() ? 0 : (size_t)T * n, off_lim = off_col + (size_t)T * J * O;   /* (RT/NLPclass.cu:289-301: the same order with TURN_OFF_INPUT_CONSTRAINTS) */
-#pragma omp parallel for schedule(dynamic)
+    const int team = std::max(1, std::min(omp_get_max_threads(), T));   /* never more threads than time steps (idle members of a wide team) */
+#pragma omp parallel for schedule(dynamic) num_threads(team)
     for (int t = 0; t < T; t++) {
         double cen[3], dcen[ARMOUR_MAX_FACTORS * 3];
         for (int j = 0; j < n && !P.no_torque(); j++) {

@@ -15,6 +15,7 @@ runs tools/check_long_branches.py on every library it links.  Two hazards are st
     HERE the check is run on the remarks of the object that was shipped, and on a doctored copy that it must reject.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -153,3 +154,17 @@ def test_long_branch_check_on_listings_and_on_the_shipped_library():
     if os.path.exists(lib) and os.path.exists(clb.OBJDUMP):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_long_branches.py"), lib], capture_output=True, text=True)
         assert r.returncode == 0 and "0 relaxed branch(es)" in r.stdout, r.stdout + r.stderr
+        nfun = int(re.search(r"(\d+) functions", r.stdout).group(1))
+        assert nfun >= 100, r.stdout        # ("0 functions, 0 relaxed branches" must not read as a pass)
+    # a file without device code, and a missing disassembler, are failures of the gate -- not passes
+    empty = os.path.join(ROOT, "tools", "check_long_branches.py")
+    r = subprocess.run([sys.executable, empty, empty], capture_output=True, text=True)
+    assert r.returncode != 0 and "NOTHING CHECKED" in r.stderr, r.stdout + r.stderr
+    if os.path.exists(lib):
+        saved = clb.OBJDUMP
+        try:
+            clb.OBJDUMP = "/nonexistent/llvm-objdump"
+            with pytest.raises(clb.NothingChecked):
+                clb.check(lib)
+        finally:
+            clb.OBJDUMP = saved

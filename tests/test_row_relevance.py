@@ -92,3 +92,38 @@ def test_the_solver_mask_contains_every_row_that_is_ever_a_qp_candidate(B, O):
     assert not (ever & ~mask).any(), np.argwhere(ever & ~mask)[:5]
     print(f"B={B} O={O}: solver rows {cnt.tolist()} of {Q} collision rows, torque rows {tq.tolist()} of {nT}; rows ever candidates (sampled) {ever[:, nT:nT + Q].sum(1).tolist()}; {ms:.3f} ms")
     nlp.close()
+
+
+def test_a_point_outside_the_box_is_not_answered_from_the_lists():
+    """the mask is a statement about k in [-1, 1]^n.  With ARMOUR_OPT_CULL_ROWS = 1 the host entry takes every row when a component of k
+    lies outside the box -- its records equal the full evaluation's bit for bit there too -- and the device entry marks such a problem's record
+    (feasible = -1, worst_row = -2) while the in-box problems of the same launch keep the full evaluation's records."""
+    import ctypes as C
+    import torch
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_k
+    B, O = 4, 20
+    nlp, bp = _nlp(B, O, seed=91)
+    culled = ArmourNLP(T=100).set_option(_lib.OPT_CULL_ROWS, 1).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+    k = random_k(300, B)
+    k[1, 2] = 1.7; k[3, 0] = -2.5          # problems 1 and 3 leave the box
+    full, cul = nlp.eval_violations(k), culled.eval_violations(k)
+    for a, c in zip(full, cul):
+        assert a == c, (a, c)
+    assert any(a["n_violated"] > 0 for a in full)
+    # the device entry
+    d_k = torch.tensor(k, device="cuda", dtype=torch.float64)
+    d_out = torch.zeros(B * C.sizeof(_lib.ArmourViolation), device="cuda", dtype=torch.uint8)
+    culled.eval_violations_device(d_k.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    rec = (_lib.ArmourViolation * B).from_buffer_copy(d_out.cpu().numpy().tobytes())
+    kin = k.copy(); kin[1, 2] = 0.7; kin[3, 0] = -0.5
+    full_in = nlp.eval_violations(kin)
+    for b in range(B):
+        if b in (1, 3):
+            assert rec[b].feasible == -1 and rec[b].worst_row == -2
+        else:
+            assert rec[b].feasible == full[b]["feasible"] and rec[b].l1_violation == full[b]["l1_violation"] and rec[b].n_violated == full[b]["n_violated"]
+            assert full_in[b]["l1_violation"] == full[b]["l1_violation"]      # (problems are independent)
+    nlp.close(); culled.close()

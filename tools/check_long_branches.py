@@ -66,25 +66,46 @@ def scan(dis):
     return bad, nfun, nlong
 
 
+class NothingChecked(Exception):
+    """The check could not look at any device code (a gate that passes when it has checked nothing is no gate)."""
+
+
 def check(path):
     bad, nfun, nlong = [], 0, 0
-    for k, img in enumerate(code_objects(path)):
+    imgs = code_objects(path)
+    if not imgs:
+        raise NothingChecked(f"{path}: no gfx950 code object found (missing file contents, or a compressed offload bundle)")
+    for k, img in enumerate(imgs):
         with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
             f.write(img)
             tmp = f.name
         try:
-            dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", tmp], capture_output=True, text=True).stdout
+            r = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", tmp], capture_output=True, text=True)
+        except OSError as e:
+            raise NothingChecked(f"{path}: cannot run {OBJDUMP}: {e}")
         finally:
             os.unlink(tmp)
-        b, nf, nl = scan(dis)
+        if r.returncode != 0:
+            raise NothingChecked(f"{path}: {OBJDUMP} failed on code object {k} (rc {r.returncode}): {r.stderr[-200:]}")
+        b, nf, nl = scan(r.stdout)
         bad += b; nfun += nf; nlong += nl
+    if nfun == 0:
+        raise NothingChecked(f"{path}: {len(imgs)} code object(s) disassembled to no function at all")
     return bad, nfun, nlong
 
 
 def main(argv):
     rc = 0
+    if len(argv) < 2:
+        print(__doc__, file=sys.stderr)
+        return 2
     for path in argv[1:]:
-        bad, nfun, nlong = check(path)
+        try:
+            bad, nfun, nlong = check(path)
+        except (NothingChecked, OSError) as e:
+            print(f"check_long_branches: NOTHING CHECKED: {e}", file=sys.stderr)
+            rc = 1
+            continue
         if bad:
             rc = 1
             for name, lb, n in bad:
