@@ -58,3 +58,31 @@ def oracle_tables(oracles, cap_l=32, cap_t=128):
             t["A"][b], t["d"][b], t["delta"][b] = A, d, delta
         t["torque_radius"][b] = o.torque_radius()
     return t
+
+
+def plane_pairs():
+    """(a, b) generator indices of the 36 half-space pairs, RT/CollisionChecking.cu:26-39."""
+    out, a, b = [], 0, 1
+    for _ in range(36):
+        out.append((a, b))
+        if b < 8:
+            b += 1
+        else:
+            a += 1
+            b = a + 1
+    return out
+
+
+def noise_planes(obstacle, link_gens, rel=1e-9):
+    """bool[36]: planes whose normal is rounding noise.  The reference normalises cross(g_a, g_b) whenever its norm is > 0
+    (RT/CollisionChecking.cu:177-189); for two generators that are parallel in exact arithmetic the computed cross product is
+    ~1e-20 instead of 0 and its DIRECTION is decided by the last bits of the generators -- any two correct implementations
+    differ there (found on the reference's hard scenario 3, where the arm starts at multiples of pi/4).  obstacle: [12]
+    column-major [c g1 g2 g3]; link_gens: [3][6]."""
+    G = np.concatenate([np.asarray(obstacle, dtype=np.float64).reshape(4, 3)[1:], np.asarray(link_gens, dtype=np.float64).T])
+    out = np.zeros(36, bool)
+    for p, (a, b) in enumerate(plane_pairs()):
+        c = np.cross(G[a], G[b])
+        nn = np.linalg.norm(G[a]) * np.linalg.norm(G[b])
+        out[p] = 0 < np.linalg.norm(c) <= rel * nn
+    return out

@@ -129,6 +129,44 @@ def _slsqp(o):
     return r, bool(np.all(g <= gu + 1e-6) and np.all(g >= gl - 1e-6))
 
 
+
+def _rows_differ_only_through_noise_planes(name, p, o, T, O, off, k, g_dev, g_ref):
+    """Rows `off` of a padded world differ from the oracle's.  Accepted only if (i) every one is a collision row whose arg-max
+    plane -- in the oracle's table or in the device's -- has a normal that is rounding noise (two generators parallel in exact
+    arithmetic: helpers.noise_planes), (ii) the device's FULL table, built on a handle of this world alone, agrees with the
+    oracle's on every other plane, and (iii) the device's row is the reference's row formula applied to the device's own table."""
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.scenes import pad_obstacles
+    from helpers import noise_planes
+    n = J = 7
+    obs = pad_obstacles(p["obstacles"], O)
+    one = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], obs)
+    A2, d2, dl2 = (a[0] for a in one.hyperplanes())
+    A, d, dl = o.hyperplanes()
+    gens = o.link_generators()
+    cen = o.slice_links(k)
+    for r in off:
+        q = r - n * T
+        assert 0 <= q < J * T * O, (name, r)
+        l, t, ob = q // (T * O), (q // O) % T, q % O
+        noise = noise_planes(obs[ob], gens[t, l])
+        assert noise.any(), (name, r)
+        ok = ~noise
+        assert np.abs(A[t, l, ob][ok] - A2[t, l, ob][ok]).max() <= C_TOL and np.abs(d[t, l, ob][ok] - d2[t, l, ob][ok]).max() <= C_TOL
+        assert np.abs(dl[t, l, ob][ok] - dl2[t, l, ob][ok]).max() <= C_TOL
+        vals = []
+        for (Ax, dx, dlx) in ((A[t, l, ob], d[t, l, ob], dl[t, l, ob]), (A2[t, l, ob], d2[t, l, ob], dl2[t, l, ob])):
+            v = Ax @ cen[t, l]
+            live = np.linalg.norm(Ax, axis=1) > 0
+            pos, neg = np.where(live, v - dx - dlx, -1e8), np.where(live, -v + dx - dlx, -1e8)
+            both = np.concatenate([pos, neg])
+            vals.append((-both.max(), int(np.argmax(both)) % 36))
+        assert noise[vals[0][1]] or noise[vals[1][1]], (name, r, vals)          # a noise plane decides the row in one of the two tables
+        assert abs(vals[0][0] - g_ref[r]) <= G_TOL and abs(vals[1][0] - g_dev[r]) <= G_TOL, (name, r, vals, g_ref[r], g_dev[r])
+    one.close()
+    return int(off.size)
+
+
 @pytest.mark.gpu
 def test_all_107_reference_worlds_as_one_batch():
     """Tables, g, Jacobian of every world against the live oracle; armour_solve of every world against SLSQP on the oracle's callbacks."""
@@ -150,7 +188,7 @@ def test_all_107_reference_worlds_as_one_batch():
     sols = nlp.solve(tolerance=1e-7, max_iterations=100)
     host = nlp.solve(tolerance=1e-7, max_iterations=100, host_qp=True)
     worst = dict(coef=0.0, radius=0.0, g=0.0, jac=0.0, k=0.0, cost=0.0)
-    n_feasible = n_ref_feasible = 0
+    n_feasible = n_ref_feasible = n_noise_rows = 0
     min_margin = np.inf
     for b, (name, p) in enumerate(ws):
         o = Oracle(T=T).set_problem(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
@@ -170,8 +208,13 @@ def test_all_107_reference_worlds_as_one_batch():
         worst["coef"] = max(worst["coef"], np.abs(gens[b] - o.link_generators()).max())
         for s in range(2):
             gr, jr = o.eval_g_jac(ks[s, b])
-            worst["g"] = max(worst["g"], np.abs(outs[s][0][b] - gr).max())
-            worst["jac"] = max(worst["jac"], np.abs(outs[s][1][b] - jr).max())
+            dg, dj = np.abs(outs[s][0][b] - gr), np.abs(outs[s][1][b] - jr).max(axis=1)
+            off = np.nonzero((dg > G_TOL) | (dj > J_TOL))[0]
+            if off.size:   # allowed only where the winning half-space is one whose normal is rounding noise (helpers.noise_planes)
+                n_noise_rows += _rows_differ_only_through_noise_planes(name, p, o, T, O, off, ks[s, b], outs[s][0][b], gr)
+                dg[off], dj[off] = 0.0, 0.0
+            worst["g"] = max(worst["g"], dg.max())
+            worst["jac"] = max(worst["jac"], dj.max())
         assert worst["coef"] <= C_TOL and worst["radius"] <= R_TOL and worst["g"] <= G_TOL and worst["jac"] <= J_TOL, (name, worst)
         # ---- the solve: the same verdict as an independent solver on the oracle's callbacks, and the same optimum
         sol = sols[b]
@@ -190,7 +233,9 @@ def test_all_107_reference_worlds_as_one_batch():
             worst["k"] = max(worst["k"], np.abs(sol["k_opt"] - ref.x).max())
             assert abs(sol["cost"] - ref.fun) <= 1e-6 * (1 + abs(ref.fun)), (name, sol, ref.fun)
             assert np.abs(sol["k_opt"] - ref.x).max() <= 1e-4, (name, sol["k_opt"], ref.x)    # (the cost is strictly convex in k: one optimum)
-    print(f"107 reference worlds: {n_feasible} feasible (independent solver: {n_ref_feasible}); worst deviations {worst}; smallest prune margin {min_margin:.3e}")
+    print(f"107 reference worlds: {n_feasible} feasible (independent solver: {n_ref_feasible}); worst deviations {worst}; smallest prune margin {min_margin:.3e}; "
+          f"{n_noise_rows} collision row(s) decided by a half-space whose normal is rounding noise")
+    assert n_noise_rows <= 16
     # ---- padding: worlds with their own obstacle count on handles of their own give the batch's optimum
     for b in (0, 55, 100, 104):
         p = ws[b][1]
