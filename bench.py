@@ -441,6 +441,97 @@ def fetch_config(device, dev, T, K, R, check):
     return out
 
 
+def reference_scenes_config(device, dev, T, check):
+    """The reference's own worlds as a workload (never `value`): first planning iteration of its 100 saved random scenes and 7 hard scenarios
+    (armour_amd/scenes.py; kinova_src/saved_worlds/random/*.csv, KSI/kinova_scenarios/get_kinova_scenario_info.m) -- reach-set build ms, fused
+    evaluation us, armour_solve ms, feasible count and SQP iterations of the 107 worlds as ONE batch (obstacle lists padded to 14 with a far box),
+    every world ALONE with its own obstacle count (one problem per call is what the reference runs), and the same figures on 107 synthetic
+    worlds of armour_amd/worlds.py at the same sizes."""
+    import numpy as np
+    import torch
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.scenes import as_batch, reference_worlds
+    from armour_amd.worlds import random_batch, random_k
+
+    def batch_figures(bp, spot_world=None):
+        B = bp["q0"].shape[0]
+        nlp = _opts(ArmourNLP(T=T, device=device))
+        for _ in range(2):
+            nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        n, m = nlp.n, nlp.m
+        st = torch.cuda.Stream()
+        d_k = torch.from_numpy(random_k(91, B)).to(dev)
+        d_g = torch.empty((B, m), device=dev, dtype=torch.float64)
+        d_j = torch.empty((B, m, n), device=dev, dtype=torch.float64)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(2):
+            if it:
+                e0.record(st)
+            for _ in range(20):
+                nlp.eval_g_jac_device(d_k.data_ptr(), d_g.data_ptr(), d_j.data_ptr(), st.cuda_stream)
+            if it:
+                e1.record(st)
+            st.synchronize()
+        eval_us = e0.elapsed_time(e1) * 1e3 / 20
+        spot = None
+        if spot_world is not None:
+            from oracle.cpu_oracle import Oracle
+            b = spot_world
+            o = Oracle(T=T).set_problem(bp["q0"][b], bp["qd0"][b], bp["qdd0"][b], bp["q_des"][b], bp["obstacles"][b])
+            gr, jr = o.eval_g_jac(d_k[b].cpu().numpy())
+            dg, dj = float(np.abs(d_g[b].cpu().numpy() - gr).max()), float(np.abs(d_j[b].cpu().numpy() - jr).max())
+            assert dg <= 1e-9 and dj <= 1e-8, (dg, dj)
+            spot = {"world": b, "max_abs_dg": dg, "max_abs_djac": dj}
+        nlp.solve()
+        nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
+        build_ms = nlp.build_ms
+        t1 = time.perf_counter(); sols = nlp.solve(); first_ms = (time.perf_counter() - t1) * 1e3
+        rep = []
+        for _ in range(3):
+            t1 = time.perf_counter(); nlp.solve(); rep.append((time.perf_counter() - t1) * 1e3)
+        out = {"problems": B, "obstacles": int(bp["obstacles"].shape[1]), "constraints_m": m, "reach_sets_ms": build_ms, "eval_us": eval_us,
+               "first_solve_ms": first_ms, "repeated_solve_ms": min(rep), "feasible": int(sum(int(s2["feasible"]) for s2 in sols)),
+               "sqp_iterations_sum": int(sum(s2["iterations"] for s2 in sols)), "sqp_iterations_max": int(max(s2["iterations"] for s2 in sols)),
+               "evaluations_sum": int(sum(s2["evaluations"] for s2 in sols)), "oracle_spot_check": spot}
+        nlp.close()
+        return out
+
+    def lone_figures(problems):
+        nlp = _opts(ArmourNLP(T=T, device=device))
+        build, host, devf, auto, feas, its = [], [], [], [], 0, []
+        for p in problems:
+            for _ in range(2):
+                nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+            build.append(nlp.build_ms)
+            for kind, acc in (("host", host), ("device", devf), ("auto", auto)):
+                best = 1e30
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    sols = nlp.solve(host_qp=(kind == "host"), device_qp=(kind == "device"))
+                    best = min(best, (time.perf_counter() - t1) * 1e3)
+                acc.append(best)
+            feas += int(sols[0]["feasible"]); its.append(int(sols[0]["iterations"]))
+        nlp.close()
+        med = statistics.median
+        return {"problems": len(problems), "reach_sets_ms_median": med(build), "reach_sets_ms_max": max(build),
+                "solve_ms_median": {"host_form": med(host), "device_form": med(devf), "automatic": med(auto)},
+                "solve_ms_max": {"host_form": max(host), "device_form": max(devf), "automatic": max(auto)},
+                "planning_iteration_ms_median": med([a + b for a, b in zip(build, auto)]), "feasible": feas, "sqp_iterations_median": med(its), "sqp_iterations_max": max(its)}
+
+    ws = reference_worlds()
+    bp = as_batch(ws)
+    B, O = bp["obstacles"].shape[:2]
+    syn = random_batch(7000, B, O)
+    return {"reference_worlds_one_batch": batch_figures(bp, spot_world=103 if check else None),
+            "reference_worlds_one_at_a_time": lone_figures([p for _, p in ws]),
+            "synthetic_worlds_one_batch": batch_figures(syn),
+            "synthetic_worlds_one_at_a_time": lone_figures([{k: syn[k][b] for k in ("q0", "qd0", "qdd0", "q_des", "obstacles")} for b in range(B)]),
+            "note": "107 worlds = 100 saved random scenes (5..14 boxes) + 7 hard scenarios (1..12 boxes), first planning iteration (arm at rest at `start`, "
+                    "q_des = the straight-line waypoint); the synthetic worlds are random_batch(7000, 107, 14) of armour_amd/worlds.py (random state and "
+                    "velocity, boxes anywhere in reach); solve times are wall clock around the synchronous call, best of three"}
+
+
 def fetch8_child(args):
     """BASELINE configs[4] as it reads -- "Fetch 8-DOF arm with payload-mass uncertainty, 100 obstacles" (never `value`): the Fetch arm behind a torso
     yaw joint (include/armour_robot_fetch.h: 9 links, 8 factors), +-50 % mass / inertia on the gripper link, one planning problem, O = 100, T = 100.
@@ -747,7 +838,8 @@ def main():
         if world == 1:
             oc = {"configs[2]: O=50, batch 128, T=100": extra_config(local_rank, dev, rank, world, use_dist, 128, 50, T, KX, R, chk, red_dev),
                   "configs[4]: Fetch, payload +-50 %, O=100, batch 1, T=100": fetch_config(local_rank, dev, T, max(KX, 20), R, chk is not None),
-                  "configs[4] 8-factor: Fetch 8-DOF (torso yaw + arm), payload +-50 %, O=100, batch 1, T=100, 128-bit keys": fetch8_config(args)}
+                  "configs[4] 8-factor: Fetch 8-DOF (torso yaw + arm), payload +-50 %, O=100, batch 1, T=100, 128-bit keys": fetch8_config(args),
+                  "reference scenes": reference_scenes_config(local_rank, dev, T, chk is not None)}
         else:
             oc = {f"configs[3]: O=20, batch 128 per GPU ({128 * world} worlds over {world} GPUs), T=100":
                   extra_config(local_rank, dev, rank, world, use_dist, 128, 20, T, KX, R, None if chk is None else False, red_dev)}
