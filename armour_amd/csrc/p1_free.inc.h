@@ -54,6 +54,7 @@ template <class CH>
 __device__ inline void t3_signal(CH& c, int word, int value) {
     WSYNC();   // this wave's stores (result rows, keys, LDS count table, mailbox) are done
     if (c.wave().lane == 0) __hip_atomic_store(&c.mb[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    c.prof_signal(word, value);
 }
 template <class CH>
 __device__ inline void t3_wait(CH& c, int word, int value) {

@@ -324,10 +324,14 @@ struct Chain {
     __device__ long long prof_clock() const { return clock64(); }
     __device__ void prof_waited(long long t0) { bar_wait += clock64() - t0; }
     __device__ void prof_forward_done() { fwd_done = clock64(); wait_fwd = bar_wait; }
+    // -DP1_STAMPS: when this wave raised which progress counter (word, value, cycles since the item began)
+    long long ph_item = 0; int n_log = 0; int log_word[48]; int log_val[48]; long long log_clk[48];
+    __device__ void prof_signal(int word, int value) { if (n_log < 48) { log_word[n_log] = word; log_val[n_log] = value; log_clk[n_log] = clock64() - ph_item; n_log++; } }
 #else
     __device__ long long prof_clock() const { return 0; }
     __device__ void prof_waited(long long) {}
     __device__ void prof_forward_done() {}
+    __device__ void prof_signal(int, int) {}
 #endif
 #if defined(P1_PROFILE) || defined(P1_STAMPS)
     mutable long long bar_wait = 0;
@@ -1147,6 +1151,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         __syncthreads();
 #if defined(P1_PROFILE) || defined(P1_STAMPS)
         const long long ph0 = clock64();
+        c.ph_item = ph0; c.n_log = 0;
 #endif
         build_jrs(c, b, t, fk_only);
         __syncthreads();
@@ -1195,7 +1200,11 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             printf("[P1 phases, wave 0] jrs %lld fk+rnea %lld torque %lld cycles\n", ph1 - ph0, ph3 - ph1, (long long)clock64() - ph3);
 #endif
 #if defined(P1_STAMPS) && !defined(P1_PROFILE)
-        if (c.w.lane == 0 && t == 60 && !fk_only) printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
+        if (c.w.lane == 0 && (t == 60 || t == cf.T - 1 || t == 0) && !fk_only) {
+            printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
+            if (t == cf.T - 1) for (int q = 0; q < c.n_log; q++) printf("[t=%d wave %d signal] word %d value %d at %lld\n", t, c.wid, c.log_word[q] - T3_CNT, c.log_val[q], c.log_clk[q]);
+        }
+        if (c.w.lane == 0 && t == cf.T - 1 && fk_only) printf("[t=%d fk item wave %d] %lld cycles\n", t, c.wid, (long long)clock64() - ph0);
         c.bar_wait = 0;
 #endif
         if (!cf.queue) it0 += gridDim.x;

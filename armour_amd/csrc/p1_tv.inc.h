@@ -81,10 +81,12 @@ struct TChain {
     __device__ long long prof_clock() const { return clock64(); }
     __device__ void prof_waited(long long t0) { w.c_wait += clock64() - t0; }
     __device__ void prof_forward_done() { w.c_fwd = clock64(); w.c_wait_fwd = w.c_wait; }
+    __device__ void prof_signal(int, int) {}
 #else
     __device__ long long prof_clock() const { return 0; }
     __device__ void prof_waited(long long) {}
     __device__ void prof_forward_done() {}
+    __device__ void prof_signal(int, int) {}
 #endif
     __device__ void bar() {   // (a dedicated helper joins every block barrier of its primary)
         if (w.hded) tv::hj_post_ctl(w, tv::HK_BAR);
