@@ -381,6 +381,7 @@ extern "C" int armour_debug_load_tables(ArmourPlanner* h, int32_t B, int32_t O, 
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
     h->build_ms = 0; h->build_info[0] = h->build_info[1] = h->build_info[2] = h->build_info[3] = 0;   // no reach-set kernel ran
+    h->h_prune_margin.clear();   // (no verdicts were taken here)
     const int J = h->J, T = h->T, n = h->n, capL = h->lim.link_monomials, capT = h->lim.torque_monomials;
     const size_t nl = (size_t)B * J * T, nt = (size_t)B * n * T;
     // centres arrive as [..][2][sz]: slot 0 = centre, slot 1 = independent radius
@@ -1060,6 +1061,14 @@ extern "C" int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip) {
     NEED_READY(h);
     if (!plane_skip) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
     for (int b = 0; b < h->B; b++) plane_skip[b] = (uint64_t)h->h_plane_skip[b] & ((1ull << ARMOUR_NPLANES) - 1ull);
+    return ARMOUR_OK;
+}
+
+extern "C" int armour_get_prune_margin(ArmourPlanner* h, double* margin) {
+    NEED_READY(h);
+    if (!margin) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    if ((int)h->h_prune_margin.size() != h->B) { armour_set_error("no reach-set build on this handle (tables loaded by armour_debug_load_tables carry no prune margin)"); return ARMOUR_ESTATE; }
+    for (int b = 0; b < h->B; b++) margin[b] = h->h_prune_margin[(size_t)b];
     return ARMOUR_OK;
 }
 

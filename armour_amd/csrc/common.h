@@ -175,6 +175,7 @@ struct ArmourPlanner {
     double* d_tr_stage = nullptr; size_t tr_stage_cap = 0;   // the same on the device, for the kernel that fills the bounds (armour_upload_bounds)
     std::vector<double> h_link_gens;                  // [B][T][J][18]
     std::vector<unsigned long long> h_plane_skip;     // [B] host copy of d_plane_skip
+    std::vector<double> h_prune_margin;               // [B] how close the last build's simplify() verdicts came to flipping (armour_get_prune_margin)
     // device tables (sized for allocB x allocO)
     int allocB = 0, allocO = 0;
     int* d_link_count = nullptr;

@@ -73,6 +73,7 @@ struct P1Cfg {
     double* link_gens;      // [B][T][J][18]
     double* torque_radius;  // [B][n][T]
     unsigned* status;
+    unsigned long long* margin;   // [B] or nullptr: per problem, (bits of +inf) - bits of the smallest |squared norm - thr_sq| of its simplify() verdicts (grows: atomicMax; pz_wave.h Wave::mg)
     // work list: items[0..n_items) are the (problem, time step) indices b*T + t to build (nullptr: all 0..n_items-1).
     // retry_list != nullptr: an item whose sort buffers overflowed is appended there (its error bits are dropped) for a
     // second launch with larger buffers, instead of failing the whole launch.
@@ -549,7 +550,7 @@ __device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js
 #pragma unroll
     for (int e = 0; e < 9; e++) m0[e] = 1.0 * m0[e] + 1.0 * t2[e];   // the two k terms, summed in generation order
     // simplify(): sorted positions 0 (k, head), 1 (k, member), 2 (e_c), 3 (e_s); a pruned term's |.| goes to the radius from its head's lane
-    const bool k0 = !norm_le<9>(m0, w), k1 = !norm_le<9>(m1, w), k2 = !norm_le<9>(m2, w);
+    const bool k0 = !norm_le_lds<9>(m0, w), k1 = !norm_le_lds<9>(m1, w), k2 = !norm_le_lds<9>(m2, w);   // (tracked: Wave::mg, the prune margin)
     double rind[9];
 #pragma unroll
     for (int e = 0; e < 9; e++) rind[e] = 0.0 + quad_sum(k0 ? 0.0 : fabs(m0[e]), 0.0, k1 ? 0.0 : fabs(m1[e]), k2 ? 0.0 : fabs(m2[e]));
@@ -563,7 +564,7 @@ __device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js
     SH::mul(rp, m0, a0);
     SH::mul(rp, m1, a1);
     SH::mul(rp, m2, a2);
-    const bool K0 = k0 && !norm_le<9>(a0, w), K1 = k1 && !norm_le<9>(a1, w), K2 = k2 && !norm_le<9>(a2, w);
+    const bool K0 = k0 && !norm_le_lds<9>(a0, w), K1 = k1 && !norm_le_lds<9>(a1, w), K2 = k2 && !norm_le_lds<9>(a2, w);
     // lanes of the product's reduction = places among rot's survivors
     const bool second_is_1 = k0 && k1, second_is_2 = (k0 != k1) && k2, third_is_2 = k0 && k1 && k2;
     double Rind[9];
@@ -617,7 +618,7 @@ __device__ inline void jrs_rotation_direct(Chain& c, int i, const JrsScalars& js
 __device__ inline void jrs_scalar_direct(Chain& c, const PZ& out, double cen, pzkey_t k0, double a, pzkey_t k1, double b) {
     const Wave& w = c.w;
     const double va = 1.0 * a, vb = 1.0 * b;
-    const bool ka = !norm1_le(va, w.thr), kb = !norm1_le(vb, w.thr);
+    const bool ka = !norm_le_lds<1>(&va, w), kb = !norm_le_lds<1>(&vb, w);
     const double ind = 0.0 + quad_sum(ka ? 0.0 : fabs(va), kb ? 0.0 : fabs(vb), 0.0, 0.0);
     if (w.lane == 0) {
         out.cen[0] = cen; out.ind[0] = ind; out.ind2[0] = ind;
@@ -634,7 +635,7 @@ __device__ inline void jrs_linkbox_direct(Chain& c, int i) {
     const Wave& w = c.w;
     const int n = c.n;
     const double g0 = 1.0 * cf.rb.link_zonotope_generators[3 * i], g1 = 1.0 * cf.rb.link_zonotope_generators[3 * i + 1], g2 = 1.0 * cf.rb.link_zonotope_generators[3 * i + 2];
-    const bool k0 = !norm1_le(g0, w.thr), k1 = !norm1_le(g1, w.thr), k2 = !norm1_le(g2, w.thr);
+    const bool k0 = !norm_le_lds<1>(&g0, w), k1 = !norm_le_lds<1>(&g1, w), k2 = !norm_le_lds<1>(&g2, w);
     if (w.lane == 0) {
         const PZ out = c.linkbox(i);
         const double i0 = 0.0 + (k0 ? 0.0 : 0.0 + quad_sum(fabs(g0), 0.0, 0.0, 0.0)) * 1.0, i1 = 0.0 + (k1 ? 0.0 : 0.0 + quad_sum(fabs(g1), 0.0, 0.0, 0.0)) * 1.0,
@@ -1075,7 +1076,9 @@ constexpr bool kTvDedicatedHelpers = P1_TV_WAVES_PER_SIMD > 1;
 // One block per (problem, time step) item.  NW = 1: one wave plays every role in turn (throughput: up to 4 items per CU).
 // NW = 3: the roles run concurrently on three waves, each with its own sort buffers (latency: small batches).
 // LDS: NW x { skey[capKey] u64, sidx[capRaw] u16, lstat[ST_WORDS] } | cnt[kMaxSlots] | mailbox | ci (centres / radii).
-__host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return (((size_t)cap_key * sizeof(pzkey_t) + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 15) & ~(size_t)15; }
+// (round 6: + the wave's prune-margin row, Wave::mg, behind the status words)
+__host__ __device__ inline size_t p1_wave_mg_off(int cap_key, int cap_raw) { return (((size_t)cap_key * sizeof(pzkey_t) + (size_t)cap_raw * 2 + ST_WORDS * sizeof(int)) + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t p1_wave_lds(int cap_key, int cap_raw) { return ((p1_wave_mg_off(cap_key, cap_raw) + WAVE * sizeof(double)) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t p1_shared_lds(size_t ci_doubles) { return (((size_t)(kMaxSlots + kMbWords) * sizeof(int)) + 15 & ~(size_t)15) + ci_doubles * sizeof(double); }
 
 template <int NW>
@@ -1096,6 +1099,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     c.w.skey = (LDS_AS pzkey_t*)mine;
     c.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * sizeof(pzkey_t));
     c.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * sizeof(pzkey_t) + (size_t)my_cap_raw * 2);
+    c.w.mg = cf.margin ? (LDS_AS double*)(mine + p1_wave_mg_off(my_cap_key, my_cap_raw)) : nullptr;
     LDS_AS unsigned char* shared = lds + (size_t)(NW == 4 ? 3 : NW) * p1_wave_lds(cf.capKey, cf.capRaw) + (NW == 4 ? p1_wave_lds(kFkCapKey, kFkCapRaw) : 0);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
@@ -1148,6 +1152,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.freeS = (1u << kNS) - 1u;
         c.role = 0;
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
+        margin_reset(c.w);
         __syncthreads();
 #if defined(P1_PROFILE) || defined(P1_STAMPS)
         const long long ph0 = clock64();
@@ -1183,6 +1188,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
                 finish_torque(c, u_nom, b, t, c.wid, NW);
             } else if (c.is(0)) finish_torque(c, u_nom, b, t);
         }
+        if (((c.w.lstat[ST_ERR] & ~err_before)) == 0) margin_item_end(c.w, cf.margin ? cf.margin + (size_t)b : nullptr);   // (not an item this wave flagged: it is built again -- here with larger buffers, or the whole launch, which then starts from cleared words)
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
             // this item needs larger sort buffers: hand it to the second launch and forget what it flagged
@@ -1609,6 +1615,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     c.w.skey = (LDS_AS pzkey_t*)lds;
     c.w.sidx = (LDS_AS uint16_t*)(lds + (size_t)cf.capKey * sizeof(pzkey_t));
     c.w.lstat = (LDS_AS int*)(lds + (size_t)cf.capKey * sizeof(pzkey_t) + (size_t)cf.capRaw * 2);
+    c.w.mg = (LDS_AS double*)(lds + p1_wave_mg_off(cf.capKey, cf.capRaw));
     LDS_AS unsigned char* shared = lds + p1_wave_lds(cf.capKey, cf.capRaw);
     c.w.cnt = (LDS_AS int*)shared;
     c.mb = c.w.cnt + kMaxSlots;
@@ -1619,6 +1626,7 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     c.w.lane = threadIdx.x;
     solo(c.w);
     if (threadIdx.x < ST_WORDS) c.w.lstat[threadIdx.x] = 0;
+    margin_reset(c.w);
     c.freeV = (1ull << c.L.nV) - 1ull; c.freeS = (1u << kNS) - 1u;
     for (int i = threadIdx.x; i < kMaxSlots; i += WAVE) c.w.cnt[i] = 0;
     __syncthreads();
@@ -1663,6 +1671,11 @@ __global__ __launch_bounds__(64) P1_OCC void armour_p1_pzop_kernel(P1Cfg cf, con
     }
     for (int m = threadIdx.x; m < n && m < a.out_cap; m += WAVE) a.out_keys[m] = (uint64_t)out.keys[m];   // (a 128-bit key build hands back the low word: the operator tests run on the 64-bit build)
     for (int m = threadIdx.x; m < n * sz && m < a.out_cap * sz; m += WAVE) a.out_coef[m] = out.coef[m];
+    {   // the operator's prune margin (pz_wave.h Wave::mg): the smallest |squared norm - thr_sq| over the lanes -> out_misc[60]; thr_sq -> [61]
+        double m = w.mg[threadIdx.x];
+        for (int k = 32; k >= 1; k >>= 1) m = fmin(m, __shfl_xor(m, k, WAVE));
+        if (threadIdx.x == 0) { a.out_misc[60] = m; a.out_misc[61] = w.thr_sq; }
+    }
     if (threadIdx.x == 0) {
         a.out_misc[0] = n; a.out_misc[1] = sz; a.out_misc[2] = w.lstat[ST_ERR];
         for (int e = 0; e < sz; e++) { a.out_misc[3 + e] = out.cen[e]; a.out_misc[12 + e] = out.ind[e]; a.out_misc[21 + e] = out.ind2[e]; }
@@ -1700,6 +1713,7 @@ struct P1Work {
     double* d_obstacles = nullptr; size_t obs_cap = 0;
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
     unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
+    unsigned long long* d_margin = nullptr; size_t margin_cap = 0;   // [B]: the prune margin word of every problem (P1Cfg::margin)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -1754,6 +1768,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_status) (void)hipFree(wk->d_status);
     if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
+    if (wk->d_margin) (void)hipFree(wk->d_margin);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
     if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
@@ -1842,6 +1857,26 @@ static hipError_t p1_wait_stream(hipStream_t st) {
     }
 }
 
+// Prune margin of every problem from the build's words (P1Cfg::margin): the smallest |s - thr_sq| over the squared norms s of every simplify()
+// verdict (RT/PZsparse.cu:305-316), as |norm - threshold| / threshold.  Which side of the threshold the nearest verdict fell on is not recorded (the
+// tracking is a subtraction and a minimum); the kept side's figure, sqrt(thr_sq + m) - thr, is the smaller of the two and differs from the other by a
+// relative O(margin): exact where it matters.  The oracle's min_margin() (oracle/pz.hpp:131) is the same minimum, zero norms left out there and
+// counted as a margin of 1 here.  1e300 for a problem without a verdict.
+static void armour_margin_from_words(ArmourPlanner* h, const unsigned long long* w) {
+    const double thr = h->params.simplify_threshold;
+    double S = thr * thr;   // sq_threshold() of pz_wave.h: the largest double whose root is <= thr
+    while (std::sqrt(std::nextafter(S, INFINITY)) <= thr) S = std::nextafter(S, INFINITY);
+    while (S > 0.0 && std::sqrt(S) > thr) S = std::nextafter(S, -INFINITY);
+    h->h_prune_margin.assign((size_t)h->B, 1e300);
+    for (int b = 0; b < h->B; b++) {
+        if (w[b] == 0) continue;
+        const unsigned long long bits = 0x7ff0000000000000ull - w[b];
+        double m;
+        memcpy(&m, &bits, 8);
+        h->h_prune_margin[(size_t)b] = std::fabs(std::sqrt(S + m) - thr) / thr;
+    }
+}
+
 int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if (!h->p1) {
         P1Work* nw = new P1Work();
@@ -1856,6 +1891,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     int rc;
     if ((rc = grow(&wk->d_link_gens, &wk->gens_cap, (size_t)B * T * J * 18)) != ARMOUR_OK) return rc;
     if ((rc = grow(&wk->d_torque_radius, &wk->tr_cap, (size_t)B * n * T)) != ARMOUR_OK) return rc;
+    if ((rc = grow(&wk->d_margin, &wk->margin_cap, (size_t)B)) != ARMOUR_OK) return rc;
     if ((rc = grow(&wk->d_obstacles, &wk->obs_cap, (size_t)B * O * 12)) != ARMOUR_OK) return rc;
     if (O > 0) HIPCHK(hipMemcpyAsync(wk->d_obstacles, obstacles, (size_t)B * O * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
 
@@ -1935,6 +1971,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
         cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
         cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
+        cf.margin = wk->d_margin;
+        if (!d_items) HIPCHK(hipMemsetAsync(wk->d_margin, 0, (size_t)B * sizeof(unsigned long long), h->stream));   // (a launch over ALL items starts the margins afresh; the second pass over a few overflowed items adds to them)
         cf.items = d_items; cf.n_items = n_items; cf.fk_items = fk_items;
         const int aux3_env = h->tune(ARMOUR_OPT_P1_STEP_AUX3);
         cf.tv_aux_on_fk_wave = aux3_env;   // (four-wave blocks: the w_aux recursion next to omega on the fourth wave)
@@ -2096,6 +2134,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             cf.tq_count = h->d_tq_count; cf.tq_center = h->d_tq_center; cf.tq_indep = h->d_tq_indep;
             cf.tq_keys = h->d_tq_keys; cf.tq_coeff = h->d_tq_coeff;
             cf.link_gens = wk->d_link_gens; cf.torque_radius = wk->d_torque_radius; cf.status = wk->d_status;
+            cf.margin = wk->d_margin;
+            HIPCHK(hipMemsetAsync(wk->d_margin, 0, (size_t)B * sizeof(unsigned long long), h->stream));
             cf.n_items = rnea_items; cf.fk_items = fk_items; cf.tv_groups = G; cf.tv_lanes = LG; cf.tv_cap = capTv; cf.tv_stage_rows = stage_rows; cf.tv_stage_rows_other = stage_other; cf.tv_free_running = tv_free_env;
             const int tv_help_env = h->tune(ARMOUR_OPT_P1_TV_HELPERS);   // (0 = every walk on its own wave)
             cf.tv_walk_helpers = tv_help_env;
@@ -2192,7 +2232,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // and a wait of their own before: 0.1 ms of a lone problem's 1.2 ms call).  Large batches keep the plain copies.
     const size_t n_tr = (size_t)B * n * T, n_lg = (size_t)B * T * J * 18, n_lc = (size_t)B * J * T, n_tc = (size_t)B * n * T;
     const size_t off_lg = n_tr * sizeof(double), off_lc = off_lg + n_lg * sizeof(double), off_tc = off_lc + n_lc * sizeof(int),
-                 off_ps = (off_tc + n_tc * sizeof(int) + 7) & ~(size_t)7, rb_bytes = off_ps + (size_t)B * sizeof(unsigned long long);
+                 off_ps = (off_tc + n_tc * sizeof(int) + 7) & ~(size_t)7, off_mg = off_ps + (size_t)B * sizeof(unsigned long long), rb_bytes = off_mg + (size_t)B * sizeof(unsigned long long);
     unsigned char* rb = rb_bytes <= ((size_t)4 << 20) ? reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 8, rb_bytes)) : nullptr;
     if (rb) {
         HIPCHK(hipMemcpyAsync(rb, wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2200,6 +2240,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMemcpyAsync(rb + off_lc, h->d_link_count, n_lc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(rb + off_tc, h->d_tq_count, n_tc * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (O > 0) HIPCHK(hipMemcpyAsync(rb + off_ps, h->d_plane_skip, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rb + off_mg, wk->d_margin, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     }
     // (unconditional: the bounds kernel above and the blocking copies below are ordered against h->stream -- a non-blocking stream -- by this
     //  wait alone; with O == 0 and a batch beyond the page-locked block it used to be skipped: ADVICE r5)
@@ -2227,7 +2268,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         h->h_plane_skip.assign((size_t)B, 0ull);
         if (O > 0) memcpy(h->h_plane_skip.data(), rb + off_ps, (size_t)B * sizeof(unsigned long long));
         h->stats_fresh = !armour_trace_p1();   // (the trace line of armour_refresh_table_stats wants its own pass)
+        armour_margin_from_words(h, reinterpret_cast<const unsigned long long*>(rb + off_mg));
     } else {
+        std::vector<unsigned long long> mw((size_t)B);
+        HIPCHK(hipMemcpy(mw.data(), wk->d_margin, mw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        armour_margin_from_words(h, mw.data());
         HIPCHK(hipMemcpy(h->h_torque_radius.data(), wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(h->h_link_gens.data(), wk->d_link_gens, n_lg * sizeof(double), hipMemcpyDeviceToHost));
     }

@@ -168,6 +168,7 @@ struct TChain {
         for (int m = 0; m < n; m++) {
             const double x = 1.0 * a.coef[(size_t)m * tv::GR + rl];
             const bool small = x * x <= thr_sq;
+            tv::mtrk(w.w.mabs, thr_sq, x * x);   // (prune margin: pz_tv.h)
             ra += small ? fabs(x) : 0.0;
             const bool keep = !small && w.active;
             if (__ballot(keep) != 0ull) {
@@ -258,11 +259,12 @@ __device__ inline void jrs_put_row(const TPZ& out, int pos, int lane, int rl, pz
 #pragma unroll
     for (int e = 0; e < SZ; e++) out.coef[((size_t)pos * SZ + e) * tv::GR + rl] = v[e];
 }
-__device__ inline bool jrs_small9(const double* m, double thr_sq) {
+__device__ inline bool jrs_small9(pzw::Wave& w, const double* m) {   // the verdict on a 3x3 term, tracked for the prune margin (pz_tv.h mtrk)
     double q = 0.0;
 #pragma unroll
     for (int e = 0; e < 9; e++) q += m[e] * m[e];
-    return q <= thr_sq;
+    tv::mtrk(w.mabs, w.thr_sq, q);
+    return q <= w.thr_sq;
 }
 // rotation about the joint axis from the cos / sin polynomials (four raw terms {k: cos_k, e_c: cos_e, k: sin_k, e_s: sin_e}, simplify()),
 // R_i = R_rpy * it, and (with_rt) the transpose
@@ -281,7 +283,7 @@ __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars
 #pragma unroll
     for (int e = 0; e < 9; e++) { cen[e] = 1.0 * cen[e]; m0[e] = 1.0 * m0[e] + 1.0 * t2[e]; m1[e] = 1.0 * m1[e]; m2[e] = 1.0 * m2[e]; }
     // simplify(), per lane; the pruned amounts join the lane's radius in key order
-    const bool d0 = jrs_small9(m0, thr_sq), d1 = jrs_small9(m1, thr_sq), d2 = jrs_small9(m2, thr_sq);
+    const bool d0 = jrs_small9(c.w.w, m0), d1 = jrs_small9(c.w.w, m1), d2 = jrs_small9(c.w.w, m2);
     const bool k0 = !d0 && active, k1 = !d1 && active, k2 = !d2 && active;
     const bool e0 = __ballot(k0) != 0ull, e1 = __ballot(k1) != 0ull, e2 = __ballot(k2) != 0ull;   // rows of rot that exist (wave-uniform)
     double rind[9];
@@ -302,7 +304,8 @@ __device__ inline void jrs_rotation_direct_tv(TChain& c, int i, const JrsScalars
     SH::mul(rp, m0, a0);
     SH::mul(rp, m1, a1);
     SH::mul(rp, m2, a2);
-    const bool K0 = e0 && !jrs_small9(a0, thr_sq) && active, K1 = e1 && !jrs_small9(a1, thr_sq) && active, K2 = e2 && !jrs_small9(a2, thr_sq) && active;
+    const bool s0 = jrs_small9(c.w.w, a0), s1 = jrs_small9(c.w.w, a1), s2 = jrs_small9(c.w.w, a2);   // (a row rot does not hold is zeros here: a zero norm is not tracked)
+    const bool K0 = e0 && !s0 && active, K1 = e1 && !s1 && active, K2 = e2 && !s2 && active;
     const bool E0 = __ballot(K0) != 0ull, E1 = __ballot(K1) != 0ull, E2 = __ballot(K2) != 0ull;
     const TPZ R = c.R(i), Rt = c.Rt(i);
     double Rind[9], asum[9];
@@ -349,6 +352,7 @@ __device__ inline void jrs_scalar_direct_tv(TChain& c, const TPZ& out, double ce
     const bool active = c.w.active;
     double va = 1.0 * a, vb = 1.0 * b;
     const bool da = fabs(va) <= thr, db = fabs(vb) <= thr;
+    tv::mtrk(c.w.w.mabs, c.w.w.thr_sq, va * va); tv::mtrk(c.w.w.mabs, c.w.w.thr_sq, vb * vb);
     const bool ka = !da && active, kb = !db && active;
     const bool ea = __ballot(ka) != 0ull, eb = __ballot(kb) != 0ull;
     double ra = 0.0;
@@ -375,6 +379,7 @@ __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
     for (int j = 0; j < 3; j++) {   // the 1x1 PZs
         const double g = 1.0 * cf.rb.link_zonotope_generators[3 * i + j];
         const bool d = fabs(g) <= thr, k = !d && active;
+        tv::mtrk(c.w.w.mabs, thr_sq, g * g);
         ex1[j] = __ballot(k) != 0ull;
         ind1[j] = 0.0 + (0.0 + (d ? fabs(g) : 0.0));
         x[j] = k ? g : 0.0;
@@ -386,6 +391,7 @@ __device__ inline void jrs_linkbox_direct_tv(TChain& c, int i) {
     for (int j = 0; j < 3; j++) {
         const double v = 1.0 * x[j];
         const bool d = ex1[j] && (0.0 + v * v + 0.0 * 0.0 <= thr_sq);   // (the norm of (0, v, 0): zeros add nothing)
+        tv::mtrk(c.w.w.mabs, thr_sq, 0.0 + v * v + 0.0 * 0.0);
         ra[j] += d ? fabs(v) : 0.0;
         k2[j] = ex1[j] && !d && active;
         ex2[j] = __ballot(k2[j]) != 0ull;
@@ -652,6 +658,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
     c.w.w.skey = (LDS_AS pzkey_t*)mine;
     c.w.w.sidx = (LDS_AS uint16_t*)(mine + (size_t)my_cap_key * sizeof(pzkey_t));
     c.w.w.lstat = (LDS_AS int*)(mine + (size_t)my_cap_key * sizeof(pzkey_t) + (size_t)my_cap_raw * 2);
+    c.w.w.mg = nullptr;   // (the time-vectorised walks keep the prune margin in registers: pz_tv.h mtrk)
     c.w.stage = (LDS_AS double*)(mine + tv_lds_fixed(my_cap_key, my_cap_raw));
     c.w.stage_rows = my_stage;
     LDS_AS unsigned char* shared = lds + tv_lds_bytes(cf.capRaw, cf.tv_stage_rows, cf.tv_stage_rows_other, NP) - tv_lds_shared();
@@ -693,8 +700,13 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
 #endif
         c.w.active = true; c.w.live = lane < nl; c.w.rl = lane < kRowPlaces ? lane : sl;
         const int t_lane = t0 + sl;
+        c.w.w.mabs = __builtin_inf();   // this item's prune margin (pz_tv.h mtrk; reduced over the lanes -- the group's time steps -- below)
         if constexpr (NW == 8) {
-            if (helper_wave) { tv::serve_loop(c.w, c.H(c.wid - NP)); continue; }   // until the primary's HK_EXIT at the end of the item
+            if (helper_wave) {   // until the primary's HK_EXIT at the end of the item
+                tv::serve_loop(c.w, c.H(c.wid - NP));
+                pzw::margin_reduce_store(c.w.w.mabs, lane, cf.margin ? cf.margin + (size_t)b : nullptr);
+                continue;
+            }
         }
         c.freeV = (1ull << c.L.nV) - 1ull;
         c.freeS = (1u << kTvNS) - 1u;
@@ -736,6 +748,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
             if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] rnea done at %lld, torque tables %lld cycles\n", it, c.wid, tvp_rnea - tvp_start, (long long)clock64() - tvp_rnea);
 #endif
         }
+        pzw::margin_reduce_store(c.w.w.mabs, lane, cf.margin ? cf.margin + (size_t)b : nullptr);
         c.bar();
         if constexpr (NW == 8) tv::hj_post_ctl(c.w, tv::HK_EXIT);
 #ifdef TV_PROFILE

@@ -198,6 +198,18 @@ struct Out {
     }
 };
 
+// ---- prune margin (round 6; pz_wave.h Wave::mabs): every per-lane verdict of simplify() leaves |s - thr_sq| of the squared norm s it was taken on
+// in its walk context (a subtraction and a minimum: nothing gated -- a lane without the monomial records thr_sq, a stage looking again at a dropped
+// sum records that sum again); when the context ends the minimum is folded into the wave's register (TW::w.mabs, which lives as long as the work
+// item), and the kernel reduces it over the lanes -- the group's time steps -- into the problem's word when the item ends (p1_tv.inc.h).
+__device__ inline void mtrk(double& m, double thr_sq, double s) {
+#ifndef PZW_NO_MARGIN   // (development: the build without the tracking, for its cost -- profiles/r06_prune_margin.txt)
+    m = fmin(m, fabs(s - thr_sq));
+#endif
+}
+template <class CX>
+__device__ inline void mfold(TW& t, const CX& cx) { t.w.mabs = fmin(t.w.mabs, cx.mabs); }
+
 // simplify()'s verdict on one finished sum, per lane (RT/PZsparse.cu:327-341): a pruned term goes to the lane's radius and
 // its coefficient becomes 0.  Returns whether this lane keeps the term.
 template <int SZ>
@@ -375,6 +387,7 @@ struct MulCtx {
     Out<SH::SZ>* o;
     const LDS_AS double* stage;
     double acc[SH::SZ], rad[SH::SZ];
+    double mabs = __builtin_inf();   // prune margin of this walk (mtrk / mfold)
     struct Regs { double ca[STAGE == 1 ? 1 : SH::ASZ], cb[STAGE == 2 ? 1 : SH::BSZ]; int i, j; };   // i, j: the staged operand's term index (rows in LDS)
     static constexpr int kRegDoubles = (STAGE == 1 ? 0 : SH::ASZ) + (STAGE == 2 ? 0 : SH::BSZ);
     static constexpr int kU = kRegDoubles <= 3 ? 16 : kRegDoubles <= 6 ? 8 : kRegDoubles <= 9 ? 6 : 4;  // terms whose row loads are in flight together
@@ -507,13 +520,12 @@ struct MulCtx {
     }
     __device__ inline void close(pzkey_t key) {
         bool small;
-        if constexpr (SH::SZ == 1) small = fabs(acc[0]) <= thr;
-        else {
-            double q = 0.0;
+        double q = 0.0;
 #pragma unroll
-            for (int e = 0; e < SH::SZ; e++) q += acc[e] * acc[e];
-            small = q <= thr_sq;
-        }
+        for (int e = 0; e < SH::SZ; e++) q += acc[e] * acc[e];
+        if constexpr (SH::SZ == 1) small = fabs(acc[0]) <= thr;
+        else small = q <= thr_sq;
+        mtrk(mabs, thr_sq, q);
         const bool keep = !small && active;
         // the pruned amount goes to the radius in every lane that does not keep the term (all of them, nine times in ten) ...
 #pragma unroll
@@ -550,6 +562,7 @@ __device__ inline void mul_walk(TW& t, const Wave& sw, const LDS_AS double* stag
     else walk_sorted<MulCtx<SH, STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
     for (int e = 0; e < SH::SZ; e++) rad[e] = cx.rad[e];
+    mfold(t, cx);
 }
 
 // rows [r_lo, r_hi) of a block of rows from src to dst (row 0 of each, WITHOUT the lane offset), 32 rows in flight
@@ -730,6 +743,7 @@ __device__ TV_NOINLINE void mul(TW& t, const TPZ& out, const TView& a_, const TV
         }
 #pragma unroll
         for (int e = 0; e < SZ; e++) rad[e] = cx.rad[e];
+        mfold(t, cx);
     } else {
         pzw::MulEval<SH> ev;
         ev.a = kview(a); ev.set_b(kview(b));
@@ -800,6 +814,7 @@ struct CrossCtx {
     Out<3>* o;
     const LDS_AS double* stage;
     double acc[6], rad[12];  // radii: 6 products | 3 differences | 3 stack
+    double mabs = __builtin_inf();   // prune margin of this walk (mtrk / mfold)
     struct Regs { double ca[STAGE == 1 ? 1 : 3], cb[STAGE == 2 ? 1 : 3]; int i, j; };
     static constexpr int kU = STAGE == 0 ? 8 : 16;
     struct Desc { unsigned alo, ahi, blo, bhi; int i, j; };   // (see MulCtx::Desc)
@@ -874,6 +889,7 @@ struct CrossCtx {
 #pragma unroll
         for (int e = 0; e < 6; e++) {
             h[e] = !(fabs(acc[e]) <= thr);
+            mtrk(mabs, thr_sq, acc[e] * acc[e]);
             rad[e] += h[e] ? 0.0 : fabs(acc[e]);
             anyh = anyh || h[e];
         }
@@ -889,12 +905,14 @@ struct CrossCtx {
             const double wv2 = wv + -1.0 * v1;
             wv = (h0 && h1) ? wv2 : wv;
             const bool any01 = h0 || h1, smallw = fabs(wv) <= thr;
+            mtrk(mabs, thr_sq, wv * wv);
             rad[6 + c] += (any01 && smallw) ? fabs(wv) : 0.0;
             const bool kc = any01 && !smallw;
             u[c] = kc ? wv : 0.0;
             anyc = anyc || kc;
         }
         const double s = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        mtrk(mabs, thr_sq, s);
         const bool keep = anyc && !(s <= thr_sq) && active;
 #pragma unroll
         for (int c = 0; c < 3; c++) { rad[9 + c] += (anyc && !keep) ? fabs(u[c]) : 0.0; u[c] = keep ? u[c] : 0.0; }
@@ -919,6 +937,7 @@ __device__ inline void cross_walk(TW& t, const Wave& sw, const LDS_AS double* st
     else walk_sorted<CrossCtx<STAGE>::kU>(lane, N, [&](int p) { return w.skey[p]; }, [&](int p) { return (int)w.sidx[p]; }, cx, N0);
 #pragma unroll
     for (int e = 0; e < 12; e++) rad[e] = cx.rad[e];
+    mfold(t, cx);
 }
 
 __device__ TV_NOINLINE void cross_pzpz(TW& t, const TPZ& out, const TView& a_, const TView& b_) {
@@ -1029,6 +1048,7 @@ struct LinCtx {
     bool active;
     Out<SZ>* o;
     double acc[SZ], ra[NS][SZ];
+    mutable double mabs = __builtin_inf();   // prune margin of this walk (mtrk / mfold)
     double xsA[XK >= 0 ? 3 : 1], xsB[XK >= 0 ? 3 : 1], xr1[XK >= 0 ? 3 : 1], xr2[XK >= 0 ? 3 : 1];   // XK >= 0: the constants and the two stages' pruned amounts
     bool present;   // per lane
     int last;       // source of the run's latest member (wave-uniform)
@@ -1102,11 +1122,14 @@ struct LinCtx {
                     double v = xsA[q] * xa[q];
                     v += xsB[q] * xb[q];
                     const bool small = fabs(v) <= thr;
+                    mtrk(mabs, thr_sq, v * v);
                     p.x1[q] = small ? fabs(v) : 0.0;
                     rr[q] = small ? 0.0 : v;
                     anyc = anyc || !small;
                 }
-                const bool keep = anyc && !(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] <= thr_sq) && active;
+                const double s3 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2];
+                mtrk(mabs, thr_sq, s3);
+                const bool keep = anyc && !(s3 <= thr_sq) && active;
 #pragma unroll
                 for (int q = 0; q < 3; q++) { p.x2[q] = (anyc && !keep) ? fabs(rr[q]) : 0.0; c[q] = s[XK].scale * (keep ? rr[q] : 0.0); }
                 return;
@@ -1121,19 +1144,20 @@ struct LinCtx {
 #pragma unroll
         for (int e = 0; e < SZ; e++) { const double x = scale * r.x[e]; c[e] = (comp < 0 || e == comp) ? x : 0.0; }
     }
-    __device__ inline bool is_small() const {
-        if constexpr (SZ == 1) return fabs(acc[0]) <= thr;
-        else {
-            double q = 0.0;
+    __device__ inline bool is_small() const {   // (a lane that holds no term holds zeros or a sum an earlier stage dropped: tracked again, harmlessly)
+        double q = 0.0;
 #pragma unroll
-            for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
-            return q <= thr_sq;
-        }
+        for (int e = 0; e < SZ; e++) q += acc[e] * acc[e];
+        bool small;
+        if constexpr (SZ == 1) small = fabs(acc[0]) <= thr; else small = q <= thr_sq;
+        mtrk(mabs, thr_sq, q);
+        return small;
     }
     // simplify() of stage k (1 <= k < NS, wave-uniform) on what has been accumulated so far: a lane whose sum is small drops it into that
     // stage's radius (selects, not branches on the per-lane verdict; the stage index is wave-uniform and picks the radius registers)
     __device__ inline void stage_at(int k) {
-        const bool drop = present && is_small();
+        const bool sm = is_small();   // (every lane: no branch on the per-lane `present`)
+        const bool drop = present && sm;
         double v[SZ];
 #pragma unroll
         for (int e = 0; e < SZ; e++) v[e] = drop ? fabs(acc[e]) : 0.0;
@@ -1179,7 +1203,8 @@ struct LinCtx {
             if (kf < NS) stage_at(kf);
         } else {
             // one simplify() at the end: pruned terms go to ra[0]
-            const bool drop = present && is_small();
+            const bool sm = is_small();
+            const bool drop = present && sm;
 #pragma unroll
             for (int e = 0; e < SZ; e++) ra[0][e] += drop ? fabs(acc[e]) : 0.0;
             present = present && !drop;
@@ -1308,6 +1333,7 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
         }
     }
     TVP_END(t, N, o.n, 2)
+    mfold(t, cx);
     if constexpr (XK >= 0) {   // (cross_const: ind = (ind + ra1) + ra2, then this sum's |scale|)
         const double asc = fabs(cx.s[XK].scale);
 #pragma unroll
@@ -1338,11 +1364,12 @@ __device__ TV_NOINLINE void lincomb(TW& t, const TPZ& out, const TSeg* segs, con
 // cross of a 3x1 PZ with a constant vector, either order (RT/PZsparse.cu:1118-1132, 1153-1167): out[c] = sA[c]*a[cA[c]] +
 // sB[c]*a[cB[c]]; the key list is a's, so one ordered pass (see pz_wave.h cross_const for the two simplify() stages)
 // (monomials [m_lo, m_hi) of a: the whole list, or the part of it one of two waves takes)
-__device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, int m_hi, const double* sA, const int* cA, const double* sB, const int* cB, Out<3>& o, double* ra1, double* ra2) {
+__device__ inline void cross_const_range(TW& t, const TView& a, int m_lo, int m_hi, const double* sA, const int* cA, const double* sB, const int* cB, Out<3>& o, double* ra1, double* ra2) {
     const int lane = t.w.lane;
     const int rl = t.rl;   // (the lane's place in a row)
     const double thr = t.w.thr, thr_sq = t.w.thr_sq;
     const bool active = t.active;
+    double mabs = __builtin_inf();   // prune margin of this pass (mtrk), folded into t.w below
     // (a's rows in their own order, two half-batches of eight monomials in flight alternately: see walk_sorted)
     double xa[8][3], xb[8][3];
     auto issue_c = [&](double (*x)[3], int m) {
@@ -1367,11 +1394,14 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
                     double v = sA[c] * xa_;
                     v += sB[c] * xb_;
                     const bool small = fabs(v) <= thr;
+                    mtrk(mabs, thr_sq, v * v);
                     ra1[c] += small ? fabs(v) : 0.0;
                     r[c] = small ? 0.0 : v;
                     anyc = anyc || !small;
                 }
-                const bool keep = anyc && !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= thr_sq) && active;
+                const double s3 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                mtrk(mabs, thr_sq, s3);
+                const bool keep = anyc && !(s3 <= thr_sq) && active;
 #pragma unroll
                 for (int c = 0; c < 3; c++) { ra2[c] += (anyc && !keep) ? fabs(r[c]) : 0.0; r[c] = keep ? r[c] : 0.0; }
                 if (__ballot(keep) != 0ull) o.emit(pzkey_readlane(key_v, m + u - m0), r);
@@ -1389,6 +1419,7 @@ __device__ inline void cross_const_range(const TW& t, const TView& a, int m_lo, 
             consume_c(xb, m0 + l0 + 8, key_v, m0);
         }
     }
+    t.w.mabs = fmin(t.w.mabs, mabs);
 }
 __device__ TV_NOINLINE void cross_const(TW& t, const TPZ& out, const TView& a_, const double* sA, const int* cA, const double* sB, const int* cB) {
     PZ_KEEP_RETURN_ADDRESS();
@@ -1501,6 +1532,7 @@ __device__ inline void serve_lincomb(TW& t, LDS_AS int* ch, const Wave& sw, int 
     for (int k = 0; k < NS; k++)
 #pragma unroll
         for (int e = 0; e < 3; e++) ra[k][e] = cx.ra[k][e];
+    mfold(t, cx);
 }
 __device__ TV_NOINLINE int serve_walk(TW& t, const TPZ& tmp) {
     PZ_KEEP_RETURN_ADDRESS();

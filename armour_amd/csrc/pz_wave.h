@@ -113,6 +113,15 @@ struct Wave {
     unsigned long long prof[PR_WORDS];  // per-wave counters (lane 0's copy is the one that counts)
 #endif
     LDS_AS int* lstat;       // LDS [ST_WORDS]: error bits / max raw terms / max monomials of this wave (flushed once per launch)
+    // Prune margin (round 6): how close a simplify() verdict of this wave came to flipping.  Per lane, in the squared domain of the norm test: the
+    // smallest |s - thr_sq| over the squared norms s the verdicts were taken on -- TWO instructions per verdict (a subtraction and a minimum with
+    // the |.| modifier), which is what the time-vectorised walks can afford (a select-based form that kept the pruned and the kept side apart cost
+    // the B = 128 build 5.5 %: profiles/r06_prune_margin.txt).  Nothing is gated: a verdict on an exact zero (a lane without the monomial) records
+    // thr_sq, i.e. a margin of 1; a stage that looks again at a sum an earlier stage dropped records that sum's distance a second time.
+    // The operators track in the register of their local copy (mtrack) and fold it into this wave's LDS row mg[WAVE] when they end (mflush); the
+    // kernel reduces the row per work item into the problem's word (margin_item_end).
+    double mabs;
+    LDS_AS double* mg;       // LDS [WAVE] (nullptr: not tracked)
     int lane;
     // Two waves on one operator (psync() below; the backward pass of the per-step kernel's four-wave blocks, p1_free.inc.h): the operators
     // that support it stride their term loops by `nl` cooperating lanes from `lane2`; skey / sidx are then the FIRST wave's buffers on both.
@@ -130,9 +139,9 @@ __device__ inline int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline View uni_view(const View& v) { View u = v; u.cnt = uni_i(v.cnt); u.stride = uni_i(v.stride); u.off = uni_i(v.off); return u; }
 __device__ inline void uni_caps(struct Wave& w);
 #ifdef P1_PROFILE
-#define PZW_WAVE_LOCAL(w, w_) Wave& w = w_;
+#define PZW_WAVE_LOCAL(w, w_) Wave& w = w_; w.mabs = __builtin_inf();
 #else
-#define PZW_WAVE_LOCAL(w, w_) Wave w = w_; uni_caps(w);
+#define PZW_WAVE_LOCAL(w, w_) Wave w = w_; uni_caps(w); w.mabs = __builtin_inf();
 #endif
 __device__ inline void uni_caps(Wave& w) { w.cap_raw = uni_i(w.cap_raw); w.cap_key = uni_i(w.cap_key); w.nl = uni_i(w.nl); w.half = uni_i(w.half); }
 // Barrier of the lanes that work on one operator: the wave's own memory traffic drained (WSYNC) and, for a pair of waves, both of them here.
@@ -218,6 +227,59 @@ __device__ inline bool norm_le(const double* acc, const Wave& w) {
 #pragma unroll
     for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
     return s <= w.thr_sq;
+}
+// ---- prune margin: the verdicts of simplify() with their distance to the threshold recorded (Wave::mabs) ----
+// s = the squared norm the verdict was taken on (1x1: v * v, whose root IS |v|)
+__device__ inline void mtrack(Wave& w, double s) {
+#ifndef PZW_NO_MARGIN   // (development: the build without the tracking, for its cost -- profiles/r06_prune_margin.txt)
+    w.mabs = fmin(w.mabs, fabs(s - w.thr_sq));
+#endif
+}
+__device__ inline bool norm1_le_t(Wave& w, double v) { mtrack(w, v * v); return fabs(v) <= w.thr; }
+template <int SZ>
+__device__ inline bool norm_le_t(const double* acc, Wave& w) {
+    if constexpr (SZ == 1) return norm1_le_t(w, acc[0]);
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+    mtrack(w, s);
+    return s <= w.thr_sq;
+}
+// fold this operator's tracker into the wave's LDS row (every lane its own place: no reduction here)
+__device__ inline void mflush(const Wave& w) {
+#ifdef PZW_NO_MARGIN
+    return;
+#endif
+    if (w.mg == nullptr) return;
+    w.mg[w.lane] = fmin(w.mg[w.lane], w.mabs);
+}
+// the same for a verdict taken outside the operators (the closed-form JRS of p1_reach.hip): straight into the row
+__device__ inline void mtrack_lds(const Wave& w, double s) {
+    if (w.mg == nullptr) return;
+    w.mg[w.lane] = fmin(w.mg[w.lane], fabs(s - w.thr_sq));
+}
+template <int SZ>
+__device__ inline bool norm_le_lds(const double* acc, const Wave& w) {   // norm_le() + mtrack_lds()
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < SZ; e++) s += acc[e] * acc[e];
+    mtrack_lds(w, s);
+    return SZ == 1 ? fabs(acc[0]) <= w.thr : s <= w.thr_sq;
+}
+// a work item's verdicts, reduced over the wave's lanes, into its problem's two words
+__device__ inline void margin_reset(const Wave& w) { if (w.mg) w.mg[w.lane] = __builtin_inf(); }
+// (m: a lane's smallest |squared norm - thr_sq|) -> the problem's word: (bits of +inf) - bits of the minimum over the lanes, by atomicMax, so that
+// a cleared word means "no verdict" (non-negative doubles order as their bits)
+__device__ inline void margin_reduce_store(double m, int lane, unsigned long long* dst) {
+    if (dst == nullptr) return;
+    unsigned long long v = 0x7ff0000000000000ull - (unsigned long long)__double_as_longlong(m);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { const unsigned long long v2 = __shfl_xor(v, k, WAVE); v = v2 > v ? v2 : v; }
+    if (lane == 0 && v) atomicMax(dst, v);
+}
+__device__ inline void margin_item_end(const Wave& w, unsigned long long* dst) {
+    if (w.mg == nullptr || dst == nullptr) return;
+    margin_reduce_store(w.mg[w.lane], w.lane, dst);
 }
 __device__ inline int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 
@@ -538,7 +600,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
             }
             E_LAP(PR_E_RUN)
             if (head) {
-                keep = !norm_le<SZ>(acc, w);
+                keep = !norm_le_t<SZ>(acc, w);
                 if (!keep) {
                     const bool upper = base >= mid;   // (wave-uniform; + 0.0 leaves a sum of absolute values as it is)
 #pragma unroll
@@ -573,6 +635,7 @@ __device__ inline void sort_reduce_emit(Wave& w, int N, const Eval& ev, const PZ
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
+    mflush(w);
     psync(w);
 }
 #undef E_LAP
@@ -874,7 +937,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
                         q++;
                     }
                     if (k >= 1 && present) {  // simplify() of stage k
-                        if (norm_le<SZ>(acc, w)) {
+                        if (norm_le_t<SZ>(acc, w)) {
                             const bool upper = base >= mid;
 #pragma unroll
                             for (int e = 0; e < SZ; e++) { const double v = fabs(acc[e]); ra[k][e] += upper ? 0.0 : v; rb[k][e] += upper ? v : 0.0; }
@@ -926,6 +989,7 @@ __device__ PZW_NOINLINE void lincomb_chain(Wave& w_, const PZ& out_, const Seg* 
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
+    mflush(w);
     psync(w);
     PROF_CALL_END(N_in)
 }
@@ -1239,7 +1303,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
         if (p < N) {
             key = ev.key(p);
             ev.coef(p, acc);
-            keep = !norm_le<SZ>(acc, w);
+            keep = !norm_le_t<SZ>(acc, w);
             if (!keep) {
 #pragma unroll
                 for (int e = 0; e < SZ; e++) ra[e] += fabs(acc[e]);
@@ -1270,6 +1334,7 @@ __device__ inline void emit_presorted(Wave& w, int N, const Eval& ev, const PZ& 
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
+    mflush(w);
     WSYNC();
 }
 
@@ -1426,14 +1491,14 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
                 for (int c = 0; c < 3; c++) {
                     // simplify() of each product: 1x1 norm
                     double v0 = acc[2 * c], v1 = acc[2 * c + 1];
-                    bool h0 = !norm1_le(v0, w.thr), h1 = !norm1_le(v1, w.thr);
+                    bool h0 = !norm1_le_t(w, v0), h1 = !norm1_le_t(w, v1);
                     if (!h0) { raP[2 * c] += fabs(v0); pruned = true; }
                     if (!h1) { raP[2 * c + 1] += fabs(v1); pruned = true; }
                     // simplify() of the difference 1.0*P0 + (-1.0)*P1 over the surviving terms
                     if (h0 || h1) {
                         double wv = h0 ? 1.0 * v0 : -1.0 * v1;
                         if (h0 && h1) wv += -1.0 * v1;
-                        if (norm1_le(wv, w.thr)) { raR[c] += fabs(wv); pruned = true; }
+                        if (norm1_le_t(w, wv)) { raR[c] += fabs(wv); pruned = true; }
                         else { u[c] = wv; anyc = true; }
                     }
                 }
@@ -1443,6 +1508,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
 #pragma unroll
                     for (int c = 0; c < 3; c++) s += u[c] * u[c];
                     keep = !(s <= w.thr_sq);
+                    mtrack(w, s);
                     if (!keep) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) raS[c] += fabs(u[c]);
@@ -1485,6 +1551,7 @@ __device__ PZW_NOINLINE void cross_pzpz(Wave& w_, const PZ& out_, const View& a_
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
+    mflush(w);
     psync(w);
     PROF_CALL_END(N_in)
 }
@@ -1524,11 +1591,13 @@ __device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a
             for (int c = 0; c < 3; c++) {
                 double v = sA[c] * x3[cA[c]];
                 v += sB[c] * x3[cB[c]];
-                if (norm1_le(v, w.thr)) { ra1[c] += fabs(v); any1 = true; v = 0.0; } else anyc = true;
+                if (norm1_le_t(w, v)) { ra1[c] += fabs(v); any1 = true; v = 0.0; } else anyc = true;
                 r[c] = v;
             }
             if (anyc) {
-                keep = !(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= w.thr_sq);
+                const double s3 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                keep = !(s3 <= w.thr_sq);
+                mtrack(w, s3);
                 if (!keep) { ra2[0] += fabs(r[0]); ra2[1] += fabs(r[1]); ra2[2] += fabs(r[2]); any2 = true; }
             }
         }
@@ -1552,6 +1621,7 @@ __device__ PZW_NOINLINE void cross_const(Wave& w_, const PZ& out_, const View& a
         w.cnt[out.id] = emitted;
         if (emitted > w.lstat[ST_MAX_OUT]) w.lstat[ST_MAX_OUT] = emitted;
     }
+    mflush(w);
     WSYNC();
 }
 

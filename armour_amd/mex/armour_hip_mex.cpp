@@ -9,7 +9,8 @@
 // the solver loop.
 //
 //   armour_hip_mex('create', T)                                    T = NUM_TIME_STEPS (RT/Parameters.h:17)
-//   armour_hip_mex('set_problem', q0, qd0, qdd0, q_des, Z)         Z = 12 x nObs, columns = obstacle zonotope Z(:)
+//   [margin] = armour_hip_mex('set_problem', q0, qd0, qdd0, q_des, Z)   Z = 12 x nObs, columns = obstacle zonotope Z(:); the optional output is the
+//                    build's prune margin (armour_get_prune_margin: how close a simplify() verdict came to flipping; also margin = armour_hip_mex('prune_margin'))
 //   armour_hip_mex('set_problem_armtd', q0, qd0, q_des, JRS, k_range, Z)   ARMTD comparison mode: JRS = T x 6 x 7
 //                    (per joint the columns c_cos g_cos r_cos c_sin g_sin r_sin that KSI/uarmtd_planner.m:277-312 writes
 //                    into armtd.in), k_range = 7 x 1; the commands below then follow CMP/NLPclass.cu
@@ -160,6 +161,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need(mxGetNumberOfElements(prhs[5]) % 12 == 0, "Z must be 12 x nObs");
         const int nObs = (int)(mxGetNumberOfElements(prhs[5]) / 12);
         chk(armour_set_problems(g_h, 1, nObs, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5])));
+        if (nlhs > 0) { plhs[0] = col(1); chk(armour_get_prune_margin(g_h, mxGetPr(plhs[0]))); }
         return;
     }
     if (!strcmp(cmd, "set_problem_armtd")) {
@@ -233,6 +235,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         plhs[0] = col(m);
         for (int i = 0; i < m; i++) mxGetPr(plhs[0])[i] = keep[i] ? 1.0 : 0.0;
         mxFree(keep);
+    } else if (!strcmp(cmd, "prune_margin")) {   // margin = armour_hip_mex('prune_margin'): min |norm - SIMPLIFY_THRESHOLD| / threshold over the last build's simplify() verdicts
+        plhs[0] = col(1);
+        chk(armour_get_prune_margin(g_h, mxGetPr(plhs[0])));
     } else if (!strcmp(cmd, "bounds")) {
         mxArray* o[4] = {col(n), col(n), col(m), col(m)};
         chk(armour_get_bounds(g_h, mxGetPr(o[0]), mxGetPr(o[1]), mxGetPr(o[2]), mxGetPr(o[3])));

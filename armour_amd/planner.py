@@ -473,7 +473,8 @@ class ArmourNLP:
                                         ok.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(oc), _dp(misc)))
         m, osz = int(misc[0]), int(misc[1])
         return dict(keys=ok[:m].copy(), coef=oc[:m * osz].reshape(m, osz).copy(), cen=misc[3:3 + osz].copy(), ind=misc[12:12 + osz].copy(),
-                    ind2=misc[21:21 + osz].copy(), flags=int(misc[2]), cycles=float(misc[30]), raw_terms=int(misc[31]), prof=misc[32:].copy())
+                    ind2=misc[21:21 + osz].copy(), flags=int(misc[2]), cycles=float(misc[30]), raw_terms=int(misc[31]), prof=misc[32:60].copy(),
+                    margin_sq=float(misc[60]), thr_sq=float(misc[61]))
 
     # ------------------------------------------------------------------ diagnostics / tables
     def torque_radius(self):
@@ -537,6 +538,13 @@ class ArmourNLP:
         """[B] uint64: bit p set = half-space p is never needed by any collision row of the problem (armour_get_plane_skip)."""
         out = np.zeros(self.B, dtype=np.uint64)
         check(self.L.armour_get_plane_skip(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def prune_margin(self):
+        """[B]: min |norm - SIMPLIFY_THRESHOLD| / threshold over every simplify() verdict of the last reach-set build (armour_get_prune_margin):
+        how close the build came to a prune flip.  The oracle's counterpart is Oracle.min_margin()."""
+        out = np.zeros(self.B)
+        check(self.L.armour_get_prune_margin(self.h, _dp(out)))
         return out
 
     def effective_bytes(self):

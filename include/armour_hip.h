@@ -378,6 +378,19 @@ int armour_get_hyperplanes(ArmourPlanner* h, double* A, double* d, double* delta
  * the table holds nothing for it and the fused evaluation does not read it.  With axis-aligned box obstacles 12 of the 36 planes.
  * For the byte accounting of bench.py (what one evaluation reads) and for tests. */
 int armour_get_plane_skip(ArmourPlanner* h, uint64_t* plane_skip);
+/* Prune margin of the last armour_set_problems*, per problem: margin[B] = the minimum over EVERY simplify() verdict of the build (RT/PZsparse.cu:305-316:
+ * a summed monomial whose Frobenius norm is <= SIMPLIFY_THRESHOLD moves into the independent part, else it stays) of |norm - threshold| / threshold,
+ * verdicts on an exactly zero norm left out -- how close the build came to a prune FLIP, where rounding of the last bits decides whether a monomial
+ * of norm ~5e-4 is kept as a monomial or folded into the radius: a legitimate change of g by up to that norm, and of the key sets.  Every stated
+ * tolerance of this library against the reference's arithmetic (tests/: identical key sets, 1e-11 on tables, 1e-9 / 1e-8 on g / jac) holds while no
+ * verdict came closer than ~1e-9; the reference cannot tell (it does not record it), the CPU oracle can (oracle_min_margin), and with
+ * this entry so can a production call: both reach-set kernels keep, per lane, the smallest distance of a verdict's squared norm to the squared
+ * threshold (two instructions per verdict) and reduce it per problem.  Two conventions differ from the oracle's figure, neither where it matters:
+ * which side of the threshold the nearest verdict fell on is not recorded and the kept side's figure is reported -- below the other side's by a
+ * relative O(margin) -- and a verdict on an exactly zero norm (a lane of the time-vectorised build without that monomial) counts with the margin
+ * sqrt(2) - 1, so 0.414 is the largest value reported while any exists.  1e300 for a problem without a verdict.  Cost: profiles/r06_prune_margin.txt.
+ * ARMOUR_ESTATE after armour_debug_load_tables. */
+int armour_get_prune_margin(ArmourPlanner* h, double* margin /* [B] */);
 /* ms spent in the last armour_set_problems (device time, hipEvent) */
 int armour_get_build_ms(ArmourPlanner* h, double* ms);
 /* how the last armour_set_problems built its tables: out4 = {kernel that produced them (ARMOUR_P1_KERNEL_*), waves per block of
@@ -399,7 +412,8 @@ const char* armour_p2_kernel_name(void);
  * Operand o: sz[o] in {1,3,9} entries per coefficient (row-major), cnt[o] monomials with keys[o][cnt] sorted unique and
  * coef[o][cnt][sz]; cen / ind / ind2 are [nops][9].  Result: out_keys[<=out_cap], out_coef[<=out_cap][sz],
  * out_misc[64] = {count, sz, error flags, cen[9], ind[9], ind2[9], [30] the operator's shader-clock cycles, [31] raw terms,
- * [32..] phase counters in -DP1_PROFILE builds}. */
+ * [32..] phase counters in -DP1_PROFILE builds, [60] the smallest |s - [61]| over the SQUARED norms s of the operator's simplify() verdicts,
+ * [61] the squared threshold they were compared with (+inf in [60]: no verdict; armour_get_prune_margin)}. */
 int armour_debug_pz_op(ArmourPlanner* h, int32_t op, int32_t nops, const int32_t* sz, const int32_t* cnt, const uint64_t* const* keys,
                        const double* const* coef, const double* cen, const double* ind, const double* ind2, const double* consts,
                        int32_t r, int32_t out_cap, uint64_t* out_keys, double* out_coef, double* out_misc);

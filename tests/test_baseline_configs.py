@@ -19,6 +19,8 @@ cases reach only in part.  Checked here, all through the C ABI:
 import numpy as np
 import pytest
 
+from test_pz_ops import margin_agrees
+
 pytestmark = pytest.mark.gpu
 
 C_TOL, R_TOL, G_TOL, J_TOL = 1e-11, 1e-10, 1e-9, 1e-8
@@ -59,6 +61,10 @@ def test_batch_of_128_worlds(O, first_seed):
     assert np.isfinite(g).all() and np.isfinite(jac).all()
     tr, gens = nlp.torque_radius(), nlp.link_generators()
     assert np.isfinite(tr).all() and (tr > 0).all() and np.isfinite(gens).all()
+    # the prune margin of EVERY world, from the device (armour_get_prune_margin): no simplify() verdict of the batch came within 1e-9 of flipping, which
+    # is what the tolerances below are conditional on -- until round 6 only the six sampled worlds could be asked, through the oracle
+    margins = nlp.prune_margin()
+    assert margins.shape == (B,) and (margins > 1e-9).all(), (margins.min(), int(margins.argmin()))
 
     # ---- device entries, all 128 worlds: one-point launch, graph of steps, multi-point launch == host entry
     dev = torch.device("cuda:0")
@@ -97,6 +103,7 @@ def test_batch_of_128_worlds(O, first_seed):
     for b in SAMPLE:
         o = _oracle(T, bp, b)
         _tables_equal_oracle(nlp, o, b)
+        assert margin_agrees(margins[b], o.min_margin()), (b, margins[b], o.min_margin())
         assert np.abs(tr[b] - o.torque_radius()).max() <= R_TOL
         assert np.abs(gens[b] - o.link_generators()).max() <= C_TOL
         for s, (gs, js) in enumerate(((g, jac), (g1, j1))):

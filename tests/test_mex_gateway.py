@@ -110,9 +110,11 @@ def test_every_command_against_the_ctypes_binding(mexlib, sample_problem):
     mex(0, "create", T)
     assert mexlib.mexh_is_locked() == 1
     Z = sp["obstacles"].T                                        # 12 x nObs, columns = Z(:) of each obstacle
-    mex(0, "set_problem", sp["q0"], sp["qd0"], sp["qdd0"], sp["q_des"], Z)
+    margin = mex(1, "set_problem", sp["q0"], sp["qd0"], sp["qdd0"], sp["q_des"], Z)[0]    # (optional output: the build's prune margin)
     nlp = ArmourNLP(T=T).set_parameters(sp["q0"], sp["qd0"], sp["qdd0"], sp["q_des"], sp["obstacles"])
     n, m = nlp.n, nlp.m
+    assert margin.shape == (1, 1) and margin[0, 0] == nlp.prune_margin()[0] and 1e-9 < margin[0, 0] < 0.4143
+    assert mex(1, "prune_margin")[0][0, 0] == margin[0, 0]
     k = PZ_TESTS_K
     g, jac = mex(2, "eval", k)
     g_ref, jac_ref = nlp.eval_g_jac(k)

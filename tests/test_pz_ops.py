@@ -87,6 +87,21 @@ def _compare(dev, ref, ctol=1e-13, itol=1e-12):
     assert np.abs(dev["ind"] - ref["ind"]).max() <= itol * max(1.0, np.abs(ref["ind"]).max())
 
 
+def _device_margin(out):
+    """|norm - threshold| / threshold of the operator's nearest verdict, from the squared-domain distance armour_debug_pz_op hands back, as
+    armour_get_prune_margin converts it (the kept side's figure); 1e300: no verdict."""
+    if not np.isfinite(out["margin_sq"]):
+        return 1e300
+    return abs(np.sqrt(out["thr_sq"] + out["margin_sq"]) - THR) / THR
+
+
+def margin_agrees(dev_margin, ref, tol=2e-10):
+    """The device's margin against the oracle's min_margin.  Equal when the nearest verdict kept its monomial; when it pruned it the device
+    reports the kept side's figure, sqrt(1 + 2r - r^2) - 1 = r - r^2 + ..., and a zero norm -- which the oracle leaves out -- counts as r = 1."""
+    r = min(ref, 1.0)
+    return np.sqrt(1.0 + 2.0 * r - r * r) - 1.0 - tol <= dev_margin <= ref + tol
+
+
 @pytest.fixture(scope="module")
 def dev():
     from armour_amd.planner import ArmourNLP
@@ -124,6 +139,9 @@ def test_device_operator_matches_oracle(dev, op, shapes, label):
             continue                                 # a coefficient within 1e-9 of the threshold: either verdict is legitimate
         out = dev.debug_pz_op(op, ops, consts=consts, r=r, out_cap=max(4096, len(ref["keys"]) + 8))
         _compare(out, ref)
+        # the prune margin the device recorded for this operator (armour_get_prune_margin is the minimum of these over a build) equals the
+        # oracle's: the same verdicts on the same sums, the one nearest to the threshold found by both
+        assert margin_agrees(_device_margin(out), ref["min_margin"]), (label, trial, _device_margin(out), ref["min_margin"])
         # second independent radius: same rule with ind2 in place of ind (fused nominal / interval RNEA)
         ops2 = [dict(o, ind2=o["ind"] * (1.5 + i)) for i, o in enumerate(ops)]
         ref2 = oracle_op(op, [dict(o, ind=o["ind2"]) for o in ops2], consts=consts, r=r)

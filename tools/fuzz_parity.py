@@ -22,6 +22,7 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 GRIPPER = len(sys.argv) > 4 and sys.argv[4] == "gripper"   # the 8-link arm (fixed gripper joint, RT/KinovaInfo.h)
 worst = dict(coef=0.0, cen=0.0, gens=0.0, radius=0.0, planes=0.0, g=0.0, jac=0.0)
 min_margin, key_mismatch, low_margin_cases = 1.0, 0, 0
+margin_mismatch, flagged = 0, []
 t_start = time.time()
 if GRIPPER:
     from armour_amd.planner import kinova_gripper_robot
@@ -45,6 +46,14 @@ for s in range(N):
         o = mk_oracle().set_problem(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
     m = o.min_margin()
     min_margin = min(min_margin, m)
+    md = float(nlp.prune_margin()[0])       # the device's own figure (armour_get_prune_margin): what a call without an oracle has
+    r = min(m, 1.0)
+    if not (np.sqrt(1.0 + 2.0 * r - r * r) - 1.0 - 2e-10 <= md <= m + 2e-10):
+        margin_mismatch += 1
+        print(f"seed {S0 + s}: device prune margin {md:.6e}, oracle {m:.6e}", flush=True)
+    if md < 1e-9:
+        flagged.append(S0 + s)
+        print(f"seed {S0 + s}: DEVICE prune margin {md:.3e} < 1e-9 (oracle {m:.3e}): a verdict of this build may flip", flush=True)
     bad_keys = 0
     for which, cnt in (("link", o.J), ("torque", o.n)):
         for i in range(cnt):
@@ -60,7 +69,7 @@ for s in range(N):
     if bad_keys:
         key_mismatch += 1
         low_margin_cases += m < 1e-9
-        print(f"seed {S0 + s}: {bad_keys} PZs with different key sets (oracle min_margin {m:.2e})", flush=True)
+        print(f"seed {S0 + s}: {bad_keys} PZs with different key sets (oracle min_margin {m:.2e}, device {md:.2e}; flagged by the device: {md < 1e-9})", flush=True)
         continue
     worst["gens"] = max(worst["gens"], np.abs(nlp.link_generators()[0] - o.link_generators()).max())
     if not armtd:
@@ -77,3 +86,4 @@ for s in range(N):
 print(f"{N} problems (seeds {S0}..{S0 + N - 1}, every third in ARMTD mode, O in {{0,1,3,10,20,40}}, T={T}{', 8-link arm with gripper' if GRIPPER else ''}) in {time.time() - t_start:.0f} s")
 print("worst absolute deviations device vs oracle:", {k: float(f"{v:.3g}") for k, v in worst.items()})
 print(f"smallest prune margin seen by the oracle: {min_margin:.3g}; problems with a key-set difference: {key_mismatch} (of which margin < 1e-9: {low_margin_cases})")
+print(f"device prune margin against the oracle's: {margin_mismatch} disagreement(s); seeds the DEVICE flags below 1e-9: {flagged if flagged else 'none'}")
