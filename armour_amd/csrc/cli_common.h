@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 
 #include <cerrno>
+#include <charconv>
 #include <chrono>
 #include <csignal>
 #include <sys/prctl.h>
@@ -26,6 +27,7 @@
 #include <fstream>
 #include <iomanip>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/armour_hip.h"
@@ -64,31 +66,64 @@ inline int get_handle(ArmourPlanner** h, int* have_T, int T, ArmourRobot* rb, Ar
     return rc;
 }
 
+// The output files (RT/armour_main.cu:312-372: `ofstream << setprecision(10)`, i.e. printf's %.10g; the constraints with precision 6).  Round 6: a
+// file is formatted into one buffer with std::to_chars (chars_format::general with a precision IS %g: the same bytes) and written with one
+// fwrite -- the iostream form spent 4 of a resident iteration's 6-7 ms of process wall on these ~36 000 numbers.
+struct OutFile {
+    std::vector<char> buf;
+    size_t len = 0;
+    explicit OutFile(size_t numbers) { buf.resize(numbers * 26 + 64); }   // (%.10g: at most sign + 1 + '.' + 9 + "e-308" = 17 characters, and a separator)
+    void num(double v, int precision) {
+        if (len + 40 > buf.size()) buf.resize(buf.size() * 2);
+        const auto r = std::to_chars(buf.data() + len, buf.data() + buf.size(), v, std::chars_format::general, precision);
+        len = (size_t)(r.ptr - buf.data());
+    }
+    void ch(char c) { if (len + 1 > buf.size()) buf.resize(buf.size() * 2); buf[len++] = c; }
+    void integer(int v) { const auto r = std::to_chars(buf.data() + len, buf.data() + buf.size(), v); len = (size_t)(r.ptr - buf.data()); }
+    bool write(const std::string& path) const {
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) return false;
+        const bool ok = fwrite(buf.data(), 1, len, f) == len;
+        return fclose(f) == 0 && ok;
+    }
+};
+
+// (`tr`: the torque radii [n][T] for armour_control_input_radius.out, or nullptr: RT/armour_main.cu:355 / the comparison planner has none)
+// The three large files -- 12 600 + 14 700 + 2 100 numbers at T = 100, O = 10 -- are formatted side by side on threads of their own; the small ones here.
 inline void write_common_outputs(const std::string& dir, const char* prefix, int T, int J, int n, int m, const ArmourSolveResult& res, double total_ms,
-                                 const std::vector<double>& g, const std::vector<double>& cen, const std::vector<double>& gens) {
+                                 const std::vector<double>& g, const std::vector<double>& cen, const std::vector<double>& gens, const double* tr = nullptr) {
+    std::thread radius([&] {
+        OutFile o((size_t)T * J * 18 + (size_t)T * J * 3);
+        for (int i = 0; i < T * J; i++) for (int k = 0; k < 3; k++) { for (int l = 0; l < 6; l++) { o.num(gens[(size_t)i * 18 + k * 6 + l], 10); o.ch(' '); } o.ch('\n'); }
+        o.write(dir + prefix + "_joint_position_radius.out");
+    });
+    std::thread constraints([&] {
+        OutFile o((size_t)m);
+        for (int i = 0; i < m; i++) { o.num(g[i], 6); o.ch('\n'); }
+        o.write(dir + prefix + "_constraints.out");
+    });
     {
-        std::ofstream o(dir + prefix + ".out");
-        o << std::setprecision(10);
-        if (res.feasible) for (int i = 0; i < n; i++) o << res.k_opt[i] << '\n';
-        else o << -1 << '\n';
-        o << total_ms;
+        OutFile o((size_t)T * J * 3 + (size_t)T * J);
+        for (int i = 0; i < T * J; i++) { for (int l = 0; l < 3; l++) { o.num(cen[(size_t)i * 3 + l], 10); o.ch(' '); } o.ch('\n'); }
+        o.write(dir + prefix + "_joint_position_center.out");
     }
-    {
-        std::ofstream o(dir + prefix + "_joint_position_center.out");
-        o << std::setprecision(10);
-        for (int i = 0; i < T * J; i++) { for (int l = 0; l < 3; l++) o << cen[(size_t)i * 3 + l] << ' '; o << '\n'; }
+    if (tr) {
+        OutFile o((size_t)T * n + (size_t)T);
+        for (int i = 0; i < T; i++) { for (int j = 0; j < n; j++) { o.num(tr[(size_t)j * T + i], 10); o.ch(' '); } o.ch('\n'); }
+        o.write(dir + prefix + "_control_input_radius.out");
     }
-    {
-        std::ofstream o(dir + prefix + "_joint_position_radius.out");
-        o << std::setprecision(10);
-        for (int i = 0; i < T * J; i++) for (int k = 0; k < 3; k++) { for (int l = 0; l < 6; l++) o << gens[(size_t)i * 18 + k * 6 + l] << ' '; o << '\n'; }
-    }
-    {
-        std::ofstream o(dir + prefix + "_constraints.out");
-        o << std::setprecision(6);
-        for (int i = 0; i < m; i++) o << g[i] << '\n';
+    radius.join();
+    constraints.join();
+    {   // last: the file the caller reads first (KSI/uarmtd_planner.m:209-219) exists once everything else does
+        OutFile o((size_t)n + 2);
+        if (res.feasible) for (int i = 0; i < n; i++) { o.num(res.k_opt[i], 10); o.ch('\n'); }
+        else { o.integer(-1); o.ch('\n'); }
+        o.num(total_ms, 10);
+        o.write(dir + prefix + ".out");
     }
 }
+// ARMOUR_CLI_TIMING=1: where an iteration's wall time went, one line on stdout (the resident planner's log)
+inline bool cli_timing() { static const bool on = [] { const char* e = getenv("ARMOUR_CLI_TIMING"); return e && e[0] && strcmp(e, "0") != 0; }(); return on; }
 
 // armour.in -> armour.out + 4 files (RT/armour_main.cu).  The clock starts before the input is parsed; creating the
 // planner handle (GPU context, allocations) is outside it when the handle already exists, as the reference keeps its
@@ -141,11 +176,13 @@ inline int iteration_armour(Session& s, const std::string& dir, int T, bool inpu
     armour_get_link_centers(h, res.k_opt, cen.data());
     armour_get_link_generators(h, gens.data());
     armour_get_torque_radius(h, tr.data());
-    write_common_outputs(dir, "armour", T, J, n, m, res, total_ms, g, cen, gens);
-    if (!input_off) {   // RT/armour_main.cu:355
-        std::ofstream o(dir + "armour_control_input_radius.out");
-        o << std::setprecision(10);
-        for (int i = 0; i < T; i++) { for (int j = 0; j < n; j++) o << tr[(size_t)j * T + i] << ' '; o << '\n'; }
+    const auto t_diag = std::chrono::steady_clock::now();
+    write_common_outputs(dir, "armour", T, J, n, m, res, total_ms, g, cen, gens, input_off ? nullptr : tr.data());   // (no control-input-radius file without input constraints: RT/armour_main.cu:355)
+    if (cli_timing()) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
+        printf("        HIP & C++: [timing] input + reach sets %.3f ms, solve %.3f ms, diagnostics (g at k_opt, link centres, generators, radii) %.3f ms, five output files %.3f ms\n",
+               t_reach * 1e3, total_ms - t_reach * 1e3, ms(t_diag - t0) - total_ms, ms(t_end - t_diag));
     }
     fflush(stdout);
     return 0;

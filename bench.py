@@ -98,6 +98,10 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
     env = dict(os.environ, **OMP_ENV)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS"):
         env.pop(k, None)
+    try:
+        env["BENCH_CPUS_USABLE"] = str(len(os.sched_getaffinity(0)))   # (this process's own mask: nothing here has bound its threads)
+    except AttributeError:
+        pass
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--time-steps", str(T), "--obstacles", str(O)]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -116,6 +120,11 @@ def cpu_baseline(T, O, seed, budget_s=12.0):
 
 def cpu_baseline_body(T, O, seed, budget_s=12.0):
     """Oracle (kind 'port') on the host cores: P2 evals/s on the same world, bounded to ~budget_s seconds."""
+    # the CPUs this process may run on, BEFORE libgomp is loaded: with OMP_PROC_BIND set, loading it binds this thread to its first place -- one
+    # core -- and the affinity mask read afterwards says 2 logical CPUs (round 6: the first run with the child's OpenMP settings swept {1, 2} threads)
+    host = host_description()
+    if os.environ.get("BENCH_CPUS_USABLE"):
+        host["cpus_usable_by_this_process"] = int(os.environ["BENCH_CPUS_USABLE"])
     from oracle.cpu_oracle import Oracle, max_threads
     from armour_amd.worlds import random_k, random_problem
     p = random_problem(seed, O)
@@ -128,7 +137,6 @@ def cpu_baseline_body(T, O, seed, budget_s=12.0):
     #  barriers does not show in a burst)
     # (the thread counts come from the CPUs this process may run on -- taken BEFORE the sweep: oracle_max_threads() is omp_get_max_threads(),
     #  which returns whatever the last omp_set_num_threads() of the sweep left behind -- round 4 timed P1 at {1, 16} instead of {1, 32, all})
-    host = host_description()
     avail = int(host["cpus_usable_by_this_process"] or max_threads())
     best_t, best_rate, sweep = 0, 0.0, {}
     phys = int(host["physical_cores"] or avail)

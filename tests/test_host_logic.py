@@ -259,3 +259,49 @@ def test_resident_planner_survives_thousands_of_iterations_and_dies_with_its_fro
     rp = fp.ResidentPlanner(tmp_path, 0, 0)
     rp.proc.send_signal(signal.SIGTERM)
     assert rp.proc.wait(timeout=30) == 0 and not os.path.exists(tmp_path / "armour.sock")
+
+
+def test_output_files_are_formatted_as_the_reference_formats_them(tmp_path):
+    """The five .out files are `ofstream << setprecision(10)` in the reference (RT/armour_main.cu:312-372; the constraints with precision 6).  The
+    worker formats them with std::to_chars into one buffer per file (cli_common.h OutFile): the same bytes as the iostream form, number for
+    number -- checked here on two million doubles of every magnitude, on the CPU."""
+    import subprocess
+    src = tmp_path / "fmt.cpp"
+    src.write_text(r'''
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iomanip>
+#include <random>
+#include <sstream>
+#include "cli_common.h"
+int main() {
+    std::mt19937_64 r(7);
+    int bad = 0;
+    for (int i = 0; i < 2000000; i++) {
+        const unsigned long long b = r();
+        double v;
+        if (i % 3 == 0) memcpy(&v, &b, 8);
+        else if (i % 3 == 1) v = (double)(long long)(b % 2000001) / (double)((b >> 32) % 100000 + 1) - 7.0;
+        else { v = std::ldexp((double)(b & 0xfffff) / 1048576.0, (int)((b >> 40) % 60) - 30); if (b & 1) v = -v; }
+        if (!std::isfinite(v)) continue;
+        for (int prec : {10, 6}) {
+            cli::OutFile o(1);
+            o.num(v, prec);
+            std::ostringstream ref;
+            ref << std::setprecision(prec) << v;
+            if (ref.str() != std::string(o.buf.data(), o.len)) bad++;
+        }
+    }
+    cli::OutFile o(4);
+    o.integer(-1); o.ch('\n'); o.num(0.5, 10); o.ch(' '); o.num(-1e-7, 10);
+    if (std::string(o.buf.data(), o.len) != "-1\n0.5 -1e-07") bad++;
+    printf("bad %d\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "fmt"
+    inc = os.path.join(ROOT, "armour_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "bad 0", out.stdout + out.stderr
