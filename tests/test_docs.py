@@ -17,6 +17,16 @@ def test_design_numbers_block_is_what_the_committed_profiles_say():
     assert m.group(1).strip() == out.stdout.strip(), "run: python tools/design_numbers.py --write"
 
 
+def test_readme_measured_paragraph_is_generated_from_the_committed_profiles():
+    """README.md's "Measured" paragraph was typed by hand until round 5 and went stale (VERDICT round 5, weak #3 / #11): it is a generated block now."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_numbers.py"), "--readme"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = open(os.path.join(ROOT, "README.md")).read()
+    m = re.search(r"<!-- measured:begin -->\n(.*?)\n<!-- measured:end -->", text, flags=re.S)
+    assert m, "README.md has no measured block"
+    assert m.group(1).strip() == out.stdout.strip(), "run: python tools/design_numbers.py --write"
+
+
 def test_every_tool_and_profile_the_current_documents_cite_exists():
     """README / DESIGN / INTEGRATION / tools/README name scripts and profile files; a renamed or deleted one must not stay cited.  (The notebooks
     under docs/ and the profiles themselves are history and cite scripts by the names they had.)"""
