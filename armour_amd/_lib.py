@@ -115,7 +115,7 @@ EXPORTS = [
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
     "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
-    "armour_get_plane_skip", "armour_get_prune_margin", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance", "armour_get_solver_rows",
+    "armour_get_plane_skip", "armour_get_prune_margin", "armour_batch_get_prune_margin", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance", "armour_get_solver_rows",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
     "armour_batch_get_sizes", "armour_batch_get_bounds", "armour_batch_eval_g_jac", "armour_batch_eval_violations", "armour_batch_solve",
     "armour_batch_get_build_ms", "armour_batch_get_build_info",
@@ -214,6 +214,7 @@ def load():
                                            C.c_int32, ip, dp, C.POINTER(C.c_uint64), dp, C.c_int32, dp, dp, dp, dp]
     L.armour_get_plane_skip.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.armour_get_prune_margin.argtypes = [vp, dp]
+    L.armour_batch_get_prune_margin.argtypes = [vp, dp]
     L.armour_set_option.argtypes = [vp, C.c_int32, C.c_double]
     L.armour_get_option.argtypes = [vp, C.c_int32, dp]
     L.armour_device_memory.argtypes = [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -266,6 +266,14 @@ extern "C" int armour_batch_get_build_info(ArmourBatch* bt, int32_t* info) {
     return ARMOUR_OK;
 }
 
+extern "C" int armour_batch_get_prune_margin(ArmourBatch* bt, double* margin) {
+    BATCH_READY(bt);
+    if (!margin) { armour_set_error("null argument"); return ARMOUR_EINVAL; }
+    for (size_t d = 0; d < bt->slot.size(); d++)
+        if (bt->first[d + 1] > bt->first[d]) { const int rc = armour_get_prune_margin(bt->slot[d], margin + bt->first[d]); if (rc != ARMOUR_OK) return rc; }
+    return ARMOUR_OK;
+}
+
 extern "C" int armour_batch_get_build_ms(ArmourBatch* bt, double* max_ms, double* per_slot) {
     BATCH_READY(bt);
     double mx = 0.0;

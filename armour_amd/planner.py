@@ -198,6 +198,12 @@ class ArmourBatchNLP:
         check(self.L.armour_batch_get_build_ms(self.h, C.byref(v), per))
         return v.value
 
+    def prune_margin(self):
+        """[B]: armour_batch_get_prune_margin -- every problem's prune margin, whichever slot built it (ArmourNLP.prune_margin)."""
+        out = np.zeros(self.B)
+        check(self.L.armour_batch_get_prune_margin(self.h, _dp(out)))
+        return out
+
     def build_info(self):
         """armour_batch_get_build_info: per slot, as ArmourNLP.build_info() (None for a slot without problems)."""
         out = (C.c_int32 * (4 * len(self.devices)))()

@@ -287,6 +287,8 @@ int armour_batch_get_bounds(ArmourBatch* bt, double* x_l, double* x_u, double* g
 int armour_batch_eval_g_jac(ArmourBatch* bt, const double* k, double* g, double* jac);             /* full outputs (parity path) */
 int armour_batch_eval_violations(ArmourBatch* bt, const double* k, ArmourViolation* out /* [B] */);  /* reduced outputs */
 /* declared after ArmourSolveOptions below: armour_batch_solve */
+/* armour_get_prune_margin of every problem of the batch: margin[B], problem-major like every other array */
+int armour_batch_get_prune_margin(ArmourBatch* bt, double* margin /* [B] */);
 /* ms of the slowest slot's last reach-set build (device time); per_slot may be NULL or [n_slots] */
 int armour_batch_get_build_ms(ArmourBatch* bt, double* max_ms, double* per_slot);
 /* armour_get_build_info of every slot: info[4 * slot + 0..3] (zeros for a slot without problems).  All slots of a problem set are built

@@ -122,6 +122,7 @@ def test_batch_over_device_slots_equals_one_handle(slots):
         assert np.array_equal(r1["k_opt"], r2["k_opt"]) and r1["feasible"] == r2["feasible"] and r1["status"] == r2["status"]
         assert r1["cost"] == r2["cost"] and r1["iterations"] == r2["iterations"]
     assert bt.build_ms > 0
+    assert np.array_equal(bt.prune_margin(), one.prune_margin())     # every problem's prune margin, whichever slot built it (both built step by step here)
     # the row lists are per handle: culled row test and culled solve on every slot (round 5), same records and results
     bt.set_option(_lib.OPT_CULL_ROWS, 1); bt.set_option(_lib.OPT_SOLVE_CULL, 1); bt.set_option(_lib.OPT_SOLVE_DEVICE, 2)
     assert [(v["l1_violation"], v["n_violated"], v["feasible"]) for v in one.eval_violations(k)] == [(v["l1_violation"], v["n_violated"], v["feasible"]) for v in bt.eval_violations(k)]
