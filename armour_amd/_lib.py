@@ -113,7 +113,7 @@ EXPORTS = [
     "armour_get_bounds", "armour_eval_f", "armour_eval_grad_f", "armour_eval_g_jac",
     "armour_eval_g_jac_device", "armour_eval_g_jac_device_steps", "armour_prepare_steps", "armour_eval_g_jac_device_multi", "armour_desired_trajectory", "armour_robust_controller", "armour_check_feasible", "armour_get_torque_radius",
     "armour_get_link_generators", "armour_get_link_centers", "armour_get_pz", "armour_get_table_sizes",
-    "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_pz_op",
+    "armour_solve_options_default", "armour_solve", "armour_debug_qp", "armour_debug_qp_box", "armour_debug_pz_op",
     "armour_get_hyperplanes", "armour_get_build_ms", "armour_get_build_info", "armour_p2_kernel_name", "armour_debug_load_tables",
     "armour_get_plane_skip", "armour_get_prune_margin", "armour_batch_get_prune_margin", "armour_set_option", "armour_get_option", "armour_controller_set_kernel", "armour_device_memory", "armour_abi_max_factors", "armour_eval_violations_device", "armour_eval_violations", "armour_get_row_relevance", "armour_get_solver_rows",
     "armour_batch_partition", "armour_batch_create", "armour_batch_destroy", "armour_batch_set_option", "armour_batch_set_problems",
@@ -199,6 +199,7 @@ def load():
     L.armour_solve_options_default.restype = None
     L.armour_solve.argtypes = [vp, C.POINTER(ArmourSolveOptions), C.POINTER(ArmourSolveResult)]
     L.armour_debug_qp.argtypes = [C.c_int32, dp, dp, C.c_int32, dp, dp, dp, dp, ip]
+    L.armour_debug_qp_box.argtypes = [C.c_int32, dp, dp, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, dp, ip, ip, dp]
     L.armour_debug_pz_op.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(dp), dp, dp, dp, dp,
                                      C.c_int32, C.c_int32, C.POINTER(C.c_uint64), dp, dp]
     L.armour_get_torque_radius.argtypes = [vp, dp]

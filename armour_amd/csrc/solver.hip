@@ -82,11 +82,29 @@ struct QpResult {
 };
 
 // Goldfarb-Idnani for  min 1/2 x'Gx + g0'x  s.t.  a_i'x >= b_i,  G = diag(Gd) > 0.
-QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = slv::kQpMaxSteps) {
+// box_rows = 2 n: the LAST 2 n rows are the variables' box, lower then upper bound of variable 0, 1, ... (what armour_solve appends); 0: no such promise.
+QpResult solve_qp(int n, const double* Gd, const double* g0, const std::vector<QpRow>& rows, int max_iter = slv::kQpMaxSteps, int box_rows = 0) {
     QpResult res;
     res.iterations = 0; res.feasible = true; res.max_mult = 0;
     double x[NV], invG[NV];
     for (int j = 0; j < n; j++) { invG[j] = 1.0 / Gd[j]; x[j] = -g0[j] * invG[j]; }
+    if (box_rows == 2 * n && (int)rows.size() >= box_rows) {   // the box-clipped minimiser first (solver_common.h)
+        const int m0 = (int)rows.size() - box_rows;
+        double lo[NV], hi[NV], d[NV];
+        for (int j = 0; j < n; j++) { lo[j] = rows[m0 + 2 * j].b; hi[j] = -rows[m0 + 2 * j + 1].b; }
+        const double mm = slv::box_clipped_step(n, Gd, invG, g0, lo, hi, d);
+        bool ok = true;
+        for (int i = 0; i < (int)rows.size() && ok; i++) {
+            double s = -rows[i].b;
+            for (int j = 0; j < n; j++) s += rows[i].a[j] * d[j];
+            if (s < -1e-7) ok = false;
+        }
+        if (ok) {
+            for (int j = 0; j < n; j++) res.x[j] = d[j];
+            res.max_mult = mm;
+            return res;
+        }
+    }
     int A[NV];       // active row ids
     double u[NV + 1];  // multipliers of the active rows (+ the entering one)
     int q = 0;
@@ -304,6 +322,28 @@ extern "C" int armour_debug_qp(int32_t n, const double* Gd, const double* g0, in
     return ARMOUR_OK;
 }
 
+// test hook: the QP as armour_solve poses it -- the rows above, then the variables' box x_lo <= x <= x_hi as 2 n trailing rows -- with (first_try = 1)
+// or without (0) the box-clipped first try of solver_common.h.  steps = active-set steps taken (0: the clipped point passed every row).
+extern "C" int armour_debug_qp_box(int32_t n, const double* Gd, const double* g0, int32_t m, const double* Amat, const double* lo, const double* hi,
+                                   const double* x_lo, const double* x_hi, int32_t first_try, double* x, int32_t* feasible, int32_t* steps, double* max_mult) {
+    if (n < 1 || n > NV || m < 0 || !x_lo || !x_hi) { armour_set_error("armour_debug_qp_box: bad argument"); return ARMOUR_EINVAL; }
+    std::vector<QpRow> rows;
+    for (int i = 0; i < m; i++) {
+        if (hi[i] < 1e18) { QpRow r; for (int j = 0; j < n; j++) r.a[j] = -Amat[i * n + j]; r.b = -hi[i]; rows.push_back(r); }
+        if (lo[i] > -1e18) { QpRow r; for (int j = 0; j < n; j++) r.a[j] = Amat[i * n + j]; r.b = lo[i]; rows.push_back(r); }
+    }
+    for (int j = 0; j < n; j++) {
+        QpRow r; memset(&r, 0, sizeof(r)); r.a[j] = 1.0; r.b = x_lo[j]; rows.push_back(r);
+        QpRow r2; memset(&r2, 0, sizeof(r2)); r2.a[j] = -1.0; r2.b = -x_hi[j]; rows.push_back(r2);
+    }
+    const QpResult q = solve_qp(n, Gd, g0, rows, slv::kQpMaxSteps, first_try ? 2 * n : 0);
+    for (int j = 0; j < n; j++) x[j] = q.x[j];
+    *feasible = q.feasible ? 1 : 0;
+    if (steps) *steps = q.iterations;
+    if (max_mult) *max_mult = q.max_mult;
+    return ARMOUR_OK;
+}
+
 // ---- the device-resident form (solver_device.hip): one persistent launch runs every problem's SQP to the end ----
 // Returns 1 when it produced the results, 0 when the caller must use the host form (no cooperative launch, batch larger than
 // the co-resident grid, or a problem's candidate rows outgrew the device buffers), < 0 on error.
@@ -482,14 +522,18 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, n = h->n, m = h->m;
     {
-        // The device-resident form from two problems on, the host-driven form below for a lone problem (force_host_qp: > 0 host form, < 0 device
+        // Until round 5: the device-resident form from two problems on, the host-driven form below for a lone problem (force_host_qp: > 0 host form, < 0 device
         // form whatever the batch; ARMOUR_OPT_SOLVE_DEVICE = 0: never the device form, 2: always).  Both produce the same iterates.  Rounds 3-4 drew
         // the line at five: the leader ran the four elastic QP attempts of an infeasible linearisation one after the other at 6 us a step where a
         // host core takes 0.3.  With the attempts side by side on the leader's four waves (round 5) the persistent kernel wins from B = 2 on
         // (O = 20: 0.19 against 0.28 ms; B = 4, O = 10: 0.23 against 0.39; B = 6: 0.25 against 0.54) and ties for one problem (0.146 / 0.157
-        // against 0.131 / 0.155 ms at O = 10 / 20), where the host form stays.  It also remains the fallback.
+        // against 0.131 / 0.155 ms at O = 10 / 20), where the host form stayed.  Round 6: with the box-clipped first try (solver_common.h) a QP of the
+        // reference's own worlds takes no active-set step, a lone problem's persistent kernel is 43-49 us instead of 118, and the device form wins for
+        // ONE problem as well -- 0.070 against 0.120 ms (medians of the reference's 107 worlds, one at a time); on random worlds, most of them
+        // infeasible with hundreds of QP steps, it loses 7 % (0.178 against 0.167 ms): the automatic choice is the device form for every batch size.
+        // The host form remains the fallback (and ARMOUR_OPT_SOLVE_DEVICE = 0 / force_host_qp > 0 hold a handle / a call to it).
         const int dev_env = h->tune(ARMOUR_OPT_SOLVE_DEVICE);
-        constexpr int kDeviceFormMinBatch = 2;
+        constexpr int kDeviceFormMinBatch = 1;
         const bool want_device = opt.force_host_qp > 0.0 ? false : opt.force_host_qp < 0.0 ? true : dev_env == 0 ? false : dev_env >= 2 ? true : B >= kDeviceFormMinBatch;
         if (want_device) {
             HIPCHK(hipSetDevice(h->device));
@@ -654,7 +698,7 @@ extern "C" int armour_solve(ArmourPlanner* h, const ArmourSolveOptions* opt_in, 
                         QpRow r; memset(&r, 0, sizeof(r)); r.a[j] = 1.0; r.b = xl[j] - s.x[j]; rows.push_back(r);
                         QpRow r2; memset(&r2, 0, sizeof(r2)); r2.a[j] = -1.0; r2.b = -(xu[j] - s.x[j]); rows.push_back(r2);
                     }
-                    qp = solve_qp(n, &Hd_all[(size_t)b * NV], s.gradf, rows);
+                    qp = solve_qp(n, &Hd_all[(size_t)b * NV], s.gradf, rows, slv::kQpMaxSteps, 2 * n);
                     if (qp.feasible) break;
                     sigma = attempt == 0 ? 0.5 : attempt == 1 ? 0.9 : 0.99;
                 }

@@ -726,6 +726,30 @@ __device__ inline void solve_qp_wave(const SolveArgs& a, const Leader& L, QpShar
     long long q_t = qst ? wall_clock64() : 0;
 #define QPW_LAP(slot) if (qst && lane == 0) { const long long n__ = wall_clock64(); qst[slot] += n__ - q_t; q_t = n__; }
     WAVE_LDS_SYNC();
+    {   // the box-clipped minimiser first (solver_common.h box_clipped_step: the host form's arithmetic), verified against every row like any result
+        double lo[NV], hi[NV], hd[NV], g0[NV], d[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) { lo[j] = -1.0 - L.x[j]; hi[j] = 1.0 - L.x[j]; hd[j] = L.Hd[j]; g0[j] = L.gradf[j]; d[j] = 0.0; }
+        const double mmc = box_clipped_step(n, hd, ih, g0, lo, hi, d);
+        int viol = 0;
+        for (int i = lane; i < mrows; i += 64) {
+            double ar[NV], br;
+            load_row(i, ar, br);
+            double s = -br;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (j < n) s += ar[j] * d[j];
+            if (s < -1e-7) viol = 1;
+        }
+        if (__ballot(viol != 0) == 0ull) {
+            if (lane == 0) {
+                W.q = 0; W.qp_iter = 0; W.feasible = 1; W.max_mult = mmc;
+                atomicMin(&S.first_ok, attempt);
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (lane == j) W.qx[j] = d[j];
+            return;
+        }
+    }
     while (!stop) {
         if (ld_lds_int(&S.first_ok) < attempt) { feasible = false; break; }   // a lower attempt is feasible: this one is not needed
         // most violated inactive row: smallest s = a_i'x - b_i below -1e-10, the first such row on ties
@@ -1083,7 +1107,7 @@ __device__ __forceinline__ int leader_step(const SolveArgs& a, Leader& L, QpShar
             LSTAMP(1);
             // QP with the elastic retries of solver.hip (sigma = fraction of the violation a row may keep): the four attempts side by side,
             // one per wave, the lowest feasible one taken (solve_qp_wave)
-#ifdef SOLVE_QP_SEQUENTIAL   // (development: the attempts one after the other on the whole block, rounds 2-4)
+#ifdef SOLVE_QP_SEQUENTIAL   // (development: the attempts one after the other on the whole block, rounds 2-4; WITHOUT round 6's box-clipped first try, so not the host form's iterates any more)
             for (int attempt = 0; attempt < 4; attempt++) {
                 if (tid == 0) L.sigma = attempt_sigma(attempt);
                 __syncthreads();

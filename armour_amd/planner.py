@@ -105,7 +105,7 @@ def _solve_options(L, max_iterations, tolerance, max_wall_time_s, host_qp, devic
         opt.max_wall_time_s = max_wall_time_s
     if host_qp:   # the host-driven form (one launch per evaluation, QPs on the host) whatever the batch size
         opt.force_host_qp = 1.0
-    elif device_qp:   # the persistent-kernel form whatever the batch size (automatic: from 2 problems on)
+    elif device_qp:   # the persistent-kernel form whatever the batch size (automatic since round 6, for every batch size)
         opt.force_host_qp = -1.0
     return opt
 
@@ -437,7 +437,7 @@ class ArmourNLP:
     def solve(self, max_iterations=None, tolerance=None, max_wall_time_s=None, host_qp=False, device_qp=False):
         """OptimizeTNLP + finalize_solution for all B problems (RT/armour_main.cu:237-304): returns a list of dicts
         (k_opt, cost, feasible, iterations, evaluations, status, time_ms).  host_qp / device_qp hold the solver to one of its two forms
-        (same iterates; automatic: the persistent kernel from 2 problems on)."""
+        (same iterates; automatic: the persistent kernel, for every batch size since round 6)."""
         opt = _solve_options(self.L, max_iterations, tolerance, max_wall_time_s, host_qp, device_qp)
         res = (_lib.ArmourSolveResult * self.B)()
         check(self.L.armour_solve(self.h, C.byref(opt), res))

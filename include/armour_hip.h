@@ -148,7 +148,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_PINNED_MODE 132            /* 0 (default) page-locked buffers through device staging + one DMA transfer | 1 the kernel reads / writes host memory itself */
 /* armour_solve (solver.hip, solver_device.hip): iterates are bit-identical for every value (tests/test_solve.py) */
 #define ARMOUR_OPT_SOLVE_SUB_TILES 140        /* default 48: row tiles per block aimed at when a batch is cut into sub-batches */
-#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default): the device-resident form from 2 problems on | 0: never | 2: always */
+#define ARMOUR_OPT_SOLVE_DEVICE 141           /* 1 (default): the device-resident form (round 6: for every batch size; until round 5 from 2 problems on) | 0: never | 2: always */
 #define ARMOUR_OPT_SOLVE_CUT_TILES 142        /* default 156: a batch whose blocks would walk more tiles each is cut */
 #define ARMOUR_OPT_SOLVE_BLOCKS 143           /* 0 (default: as many as fit) | n: at most n blocks per problem */
 #define ARMOUR_OPT_SOLVE_SUB_BATCH 144        /* 0 (default: by tiles) | n: sub-batches of at most n problems */
@@ -332,10 +332,10 @@ typedef struct ArmourSolveOptions {
     double tolerance;         /* step / violation tolerance (1e-4 = IPOPT_OPTIMIZATION_TOLERANCE, RT/Parameters.h:50) */
     double max_wall_time_s;   /* 0 = unlimited (reference: 0.5 s - t(P1) - 0.05 s, RT/armour_main.cu:227-229) */
     double force_host_qp;     /* which of the two forms of the solver runs -- both give the same iterates bit for bit:
-                               *   0 (default) automatic: batches of more than 4 problems run the whole SQP iterate in one persistent kernel, smaller ones
-                               *     keep the evaluations on the device and solve the 7-variable QPs on the host, one launch per evaluation (measured on
-                               *     random worlds: the host does a QP step in 0.3 us against 6 us on one wavefront, and infeasible problems take
-                               *     hundreds of them; the persistent kernel wins from 6 problems on);
+                               *   0 (default) automatic: the whole SQP iterate in one persistent kernel (since round 6 for a lone problem too: the QP's
+                               *     box-clipped first try -- armour_debug_qp_box -- settles the QPs of feasible problems without an active-set step, 0.07 ms
+                               *     per solve on the reference's worlds; the host-driven form -- evaluations on the device, one launch each, the 7-variable
+                               *     QPs on the host -- is 7 % faster on lone INFEASIBLE problems, which take hundreds of QP steps, and remains the fallback);
                                *   > 0: the host-QP form whatever the batch;   < 0: the persistent-kernel form whatever the batch. */
     double reserved[3];
 } ArmourSolveOptions;
@@ -355,6 +355,13 @@ int armour_batch_solve(ArmourBatch* bt, const ArmourSolveOptions* opt, ArmourSol
  * |bound| >= 1e18 = absent).  Host-only: runs without a GPU. */
 int armour_debug_qp(int32_t n, const double* Gd, const double* g0, int32_t m, const double* A, const double* lo,
                     const double* hi, double* x, int32_t* feasible);
+
+/* the same with the variables' box x_lo <= x <= x_hi appended as armour_solve appends it, and armour_solve's FIRST TRY (round 6): with a diagonal G the
+ * minimiser over the box alone is the unconstrained one clipped variable by variable; when that point satisfies every row it is the QP's solution and
+ * no active-set step is taken (steps = 0) -- on the reference's own worlds nearly every QP ends there.  first_try = 0: the active-set method alone.
+ * Host-only.  steps / max_mult may be NULL. */
+int armour_debug_qp_box(int32_t n, const double* Gd, const double* g0, int32_t m, const double* A, const double* lo, const double* hi,
+                        const double* x_lo, const double* x_hi, int32_t first_try, double* x, int32_t* feasible, int32_t* steps, double* max_mult);
 
 /* ---- diagnostics the reference writes to its 4 extra files (RT/armour_main.cu:329-372) ---- */
 /* torque_radius [B][n][T]   (armour_control_input_radius.out holds its transpose) */

@@ -77,7 +77,7 @@ def test_device_resident_solve_equals_the_host_driven_one(seed, O, T, B, monkeyp
     bp = random_batch(seed, B, O)
     nlp = ArmourNLP(T=T).set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
     host = nlp.solve(host_qp=True)
-    dev = nlp.solve(device_qp=True)          # (automatic: the persistent kernel from 2 problems on; asked for here)
+    dev = nlp.solve(device_qp=True)          # (the automatic choice since round 6; asked for here)
     for a, c in zip(host, dev):
         assert _same_solution(a, c), (a, c)
     for a, c in zip(host, nlp.solve()):      # ... and whatever the automatic choice is, the same again
