@@ -61,7 +61,10 @@ def first_iteration(start, goal, obstacles, lookahead):
 
 
 def saved_scene_files():
-    return sorted(glob.glob(os.path.join(SCENE_DIR, "scene_*.csv")))
+    files = sorted(glob.glob(os.path.join(SCENE_DIR, "scene_*.csv")))
+    if not files:
+        raise FileNotFoundError(f"the reference's saved scenes are fixtures of this repository's tests: none under {SCENE_DIR}")
+    return files
 
 
 def saved_scenes(lookahead=1.0):
