@@ -285,3 +285,31 @@ def test_device_against_the_scene_goldens(T):
         assert np.abs(jt[b][idx][rows] - gd[pre + "jac_kt"]).max() <= J_TOL
         assert abs(nlp.eval_f(np.tile(PZ_TESTS_K, (len(names), 1)))[b] - float(gd[pre + "f_kt"])) <= 1e-12
     nlp.close()
+
+
+REF_SCENARIOS = "/root/reference/kinova_src/kinova_simulator_interfaces/kinova_scenarios/get_kinova_scenario_info.m"
+REF_SCENES = "/root/reference/kinova_src/saved_worlds/random"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCENARIOS), reason="the reference checkout is only present in the build container")
+def test_fixtures_are_the_references_own_numbers():
+    """Where the reference checkout exists (this container, not the GPU box): the committed CSVs are byte for byte the reference's files, and start / goal of
+    every hard scenario in the JSON table are the (uncommented) MATLAB statements of get_kinova_scenario_info.m, read as text and evaluated."""
+    import re
+    from armour_amd.scenes import SCENE_DIR
+    names = sorted(f for f in os.listdir(REF_SCENES) if f.endswith(".csv"))
+    assert len(names) == 100
+    for f in names:
+        assert open(os.path.join(REF_SCENES, f), "rb").read() == open(os.path.join(SCENE_DIR, f), "rb").read(), f
+    text = open(REF_SCENARIOS).read()
+    with open(os.path.join(SCENE_DIR, "hard_scenarios.json")) as fh:
+        table = {s["scenario"]: s for s in json.load(fh)["scenarios"]}
+    blocks = re.split(r"\n\s*case (\d) %", text)
+    for k in range(1, len(blocks), 2):
+        case, body = int(blocks[k]), blocks[k + 1]
+        for field in ("start", "goal"):
+            m = [ln for ln in body.splitlines() if re.match(rf"\s*{field} = \[", ln)]     # (commented alternatives start with %)
+            vec = re.search(r"\[(.*?)\]", m[0]).group(1)
+            vals = [float(eval(x.strip(), {"pi": np.pi})) for x in re.split(r"[;,]", vec) if x.strip()]
+            assert np.allclose(vals, table[case][field], rtol=0, atol=1e-15), (case, field)
+    assert len(table) == 7
