@@ -250,6 +250,7 @@ def p1_accounting(device, T, O, p1_ms_b1, count_pairs):
         nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
         ms.append(nlp.build_ms)
     info = nlp.build_info()
+    margins = nlp.prune_margin()   # (armour_get_prune_margin: how close any simplify() verdict of each world's build came to flipping)
     nlp.close()
     pairs = {1: None, B: None}
     if count_pairs:
@@ -268,6 +269,8 @@ def p1_accounting(device, T, O, p1_ms_b1, count_pairs):
              "traffic": tr, "frac_by_traffic": (tr["bytes"] / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
         if nb == B:
             e["kernel"] = info
+            e["prune_margin"] = {"min": float(margins.min()), "world": int(margins.argmin()), "below_1e-9": int((margins < 1e-9).sum()),
+                                 "note": "smallest |norm - SIMPLIFY_THRESHOLD| / threshold over every simplify() verdict of the 128 builds, from the device (DESIGN.md 4.11): the parity tolerances hold while it stays above ~1e-9"}
         out[tag] = e
     out["note"] = ("set_problems_ms: HIP events around every kernel of the build (reach-set kernel + half-space kernels), best of the warm builds; "
                    "pair_products: counted by the CPU oracle on the same worlds (seeds 0..B-1, O = %d); traffic: L2-miss bytes of the same kernels from the "
