@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -178,6 +179,19 @@ void armour_tuning_defaults(double* tuning) {
 }
 // tracing: the only environment variables the library reads besides the worker's ARMOUR_WORKER_PARENT; neither changes a result
 bool armour_trace_p1() { static const bool on = getenv("ARMOUR_P1_TRACE") != nullptr; return on; }
+BuildStamps& armour_build_stamps() { static thread_local BuildStamps s; return s; }
+void armour_build_stamp(const char* name) {
+    if (!armour_trace_p1()) return;
+    BuildStamps& s = armour_build_stamps();
+    if (s.n < 12) { s.t[s.n] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); s.name[s.n] = name; s.n++; }
+}
+static void armour_build_stamps_print(const char* what) {
+    if (!armour_trace_p1()) return;
+    BuildStamps& s = armour_build_stamps();
+    fprintf(stderr, "[%s, host side, us]", what);
+    for (int i = 1; i < s.n; i++) fprintf(stderr, " %s %.1f", s.name[i], s.t[i] - s.t[i - 1]);
+    if (s.n > 1) fprintf(stderr, " | total %.1f\n", s.t[s.n - 1] - s.t[0]);
+}
 bool armour_trace_solve() { static const bool on = getenv("ARMOUR_SOLVE_TIMING") != nullptr; return on; }
 
 extern "C" int armour_create(const ArmourRobot* robot, const ArmourParams* params, const ArmourLimits* limits,
@@ -335,16 +349,22 @@ int armour_refresh_table_stats(ArmourPlanner* h) {
 
 extern "C" int armour_set_problems(ArmourPlanner* h, int32_t B, int32_t O, const double* q0, const double* qd0,
                                    const double* qdd0, const double* q_des, const double* obstacles) {
+    armour_build_stamps().n = 0;
+    armour_build_stamp("start");
     int rc = begin_problem_set(h, B, O, q0, qd0, qdd0, q_des);
     if (rc != ARMOUR_OK) return rc;
     if (O > 0 && !obstacles) { armour_set_error("obstacles is null but O=%d", O); return ARMOUR_EINVAL; }
     for (size_t i = 0; i < (size_t)B * O * 12; i++)
         if (!std::isfinite(obstacles[i])) { armour_set_error("non-finite obstacle entry %zu", i); return ARMOUR_EINVAL; }
+    armour_build_stamp("checks+bezier-upload");
     rc = armour_p1_build(h, obstacles);
     if (rc != ARMOUR_OK) return rc;
+    armour_build_stamp("copy-out");
     rc = armour_refresh_table_stats(h);
     if (rc != ARMOUR_OK) return rc;
     h->ready = true;
+    armour_build_stamp("table-stats");
+    armour_build_stamps_print("armour_set_problems");
     return ARMOUR_OK;
 }
 

@@ -242,6 +242,10 @@ int armour_p2_slice_links_launch(const P2Tables& tb, const double* d_k, double* 
 P2Tables armour_make_tables(const ArmourPlanner* h);
 // g_l / g_u of the current problem set in h->d_bounds ([2][B][m]): filled by a kernel once per problem set (api.hip)
 int armour_upload_bounds(ArmourPlanner* h);
+// ARMOUR_P1_TRACE: host-side stamps of one armour_set_problems* call (where its wall time goes beside the kernels), printed by the call when it returns
+struct BuildStamps { double t[12]; const char* name[12]; int n; };
+BuildStamps& armour_build_stamps();
+void armour_build_stamp(const char* name);
 int armour_bounds_launch(ArmourPlanner* h, const double* d_torque_radius);   // the same kernel queued on the handle's stream (the reach-set build calls it)
 
 // p1_reach.hip

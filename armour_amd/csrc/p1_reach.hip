@@ -1894,6 +1894,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     if ((rc = grow(&wk->d_margin, &wk->margin_cap, (size_t)B)) != ARMOUR_OK) return rc;
     if ((rc = grow(&wk->d_obstacles, &wk->obs_cap, (size_t)B * O * 12)) != ARMOUR_OK) return rc;
     if (O > 0) HIPCHK(hipMemcpyAsync(wk->d_obstacles, obstacles, (size_t)B * O * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    armour_build_stamp("buffers+obstacles");
 
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
@@ -1997,7 +1998,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+        armour_build_stamp("launch-queued");
         HIPCHK(p1_wait_stream(h->stream));
+        armour_build_stamp("reach-set-kernel-waited");
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
@@ -2244,7 +2247,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     }
     // (unconditional: the bounds kernel above and the blocking copies below are ordered against h->stream -- a non-blocking stream -- by this
     //  wait alone; with O == 0 and a batch beyond the page-locked block it used to be skipped: ADVICE r5)
+    armour_build_stamp("planes+bounds+readback-queued");
     HIPCHK(p1_wait_stream(h->stream));
+    armour_build_stamp("planes-waited");
     if (O > 0) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
