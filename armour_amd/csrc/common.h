@@ -207,6 +207,7 @@ struct ArmourPlanner {
     // handle -- the same robot, a similar problem -- starts there instead of repeating the failed launches (8-factor arms on the halved key buffers of
     // the 128-bit build: 4 launches, 67 ms, for a 25 ms build).  0 = from the beginning.
     int p1_step_cap_hint = 0, p1_tv_shape_hint = 0;
+    bool p1_two_cu_off = false;   // a two-CU build of this handle lost its helper blocks once (ERR_HELPER): one CU per time step from then on
     // the hints only ever grow inside a run of like builds: they are dropped when the problem set changes class (B, T or O), with every
     // armour_set_option, and every 64th build (one hard problem must not pin a long-lived handle to larger buffers for good: ADVICE r5)
     int p1_hint_B = 0, p1_hint_T = 0, p1_hint_O = 0, p1_hint_builds = 0;

@@ -167,6 +167,171 @@ __device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A time step on TWO compute units (round 6; per-step kernel, four-wave blocks, a lone problem: 2 T blocks on 256 CUs).
+// Of what a time step's forward pass computes, three families of products read nothing but the angular VELOCITY recursions -- w_s and w_aux_s,
+// which are cheap (a rotation times a short vector, plus one entry) -- and none of the angular or linear ACCELERATION:
+//     c3L_s = w_s x (w_aux_s x p_s)             the linear-acceleration step's cross product     (RT/Dynamics.cu:107-109)
+//     c3C_s = w_s x (w_aux_s x com_{s-1})       the same for the link's centre of mass, in F     (:125-127)
+//     crN_s = w_aux_s x (I_{s-1} w_s)           the gyroscopic half of the moment N              (:130-132)
+// -- 21 PZ x PZ cross products of up to 1 700 raw terms each, 0.4 M of the 1.2 M cycles every wave of the block spends in the forward pass.
+// A HELPER block on a second CU builds the JRS of the same time step, runs the two velocity recursions AGAIN (same operators on the same
+// operands: the same bits as the main block's own), builds the three families on three waves and the step's forward kinematics behind the
+// recursions on the fourth (the items of their own it used to be), and PUBLISHES each product; the main block takes them where it used to
+// compute them.  Data flows one way, helper -> main, and a published slot is never written again within the item, so there is no
+// acknowledgement, no allocator protocol, and the helper never waits for the main block.
+// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the product's rows are plain stores into
+// the helper's arena, drained by the producing wave (s_waitcnt vmcnt(0)); its header (count, slot, centre, radii: 80 bytes of the helper's LDS)
+// goes into a 128-byte record of the item's exchange area with sc1 stores, drained again, then the flag word (sc1, tagged with the launch's
+// epoch so that the area is never cleared).  The taking wave polls the flag with sc1 loads, invalidates its CU's L1 (agent-scope acquire:
+// a line of the helper's arena that straddles two slots may have been fetched before its second half was written), reads the record with
+// sc1 loads and makes a PZ whose rows point into the helper's arena and whose header is a slot of its own pool.  Plain stores are visible
+// to another CU through the L2 only on the SAME XCD: both blocks publish their XCC_ID at the start of the item, the main block decides --
+// same XCD: two CUs; different, or no sign of the helper: everything itself, as before -- and publishes the decision for the helper.  Block
+// b's helper is block helper0 + b with helper0 a multiple of 8 (blocks are dealt round-robin to the XCDs: observed, not promised -- hence the check).
+// A take that never sees its flag (cut off after ~0.1 s) raises ERR_HELPER; the host then builds again on one CU per step and keeps the handle there.
+enum { XK_C3L = 0, XK_C3C = 1, XK_CRN = 2, XK_KINDS = 3 };
+constexpr int kXchSlots = ARMOUR_MAX_JOINTS + 1;
+constexpr size_t kXchFlags = 128, kXchRecs = 256, kXchRecBytes = 128, kXchBytes = 4096;   // control line | flag words | records
+static_assert(XK_KINDS * kXchSlots * sizeof(unsigned) <= 128 && kXchRecs + XK_KINDS * kXchSlots * kXchRecBytes <= kXchBytes, "exchange area");
+__device__ inline unsigned xch_xcc() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return (v & 0xfu) + 1u; }
+__device__ inline void xch_st(GLB_AS unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned xch_ld(const GLB_AS unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class CH>
+__device__ inline void xch_hello(CH& c, bool helper) {   // before the JRS: who runs where
+    if (c.wid == 0 && w_lane0(c)) xch_st((GLB_AS unsigned*)c.xch + (helper ? 1 : 0), ((unsigned)c.xch_epoch << 8) | xch_xcc());
+}
+// every wave of the block (two block barriers inside): true = this item runs on two CUs
+template <class CH>
+__device__ inline bool xch_decide(CH& c, bool helper) {
+    LDS_AS int* word = c.mb + kMbWords - 2;
+    if (c.wid == 0) {
+        const GLB_AS unsigned* src = (const GLB_AS unsigned*)c.xch + (helper ? 2 : 1);
+        const unsigned ep = (unsigned)c.xch_epoch;
+        unsigned v = 0;
+        const int limit = helper ? (1 << 13) : (1 << 11);   // (~0.7 us per poll: the main block gives the helper ~1.5 ms to show up, the helper waits longer than that for the decision)
+        for (int spins = 0; spins < limit; spins++) { v = xch_ld(src); if ((v >> 8) == ep) break; __builtin_amdgcn_s_sleep(16); }
+        int mode = 2;
+        if ((v >> 8) == ep) mode = helper ? (int)(v & 0xffu) : ((v & 0xffu) == xch_xcc() ? 1 : 2);
+        if (!helper && w_lane0(c)) xch_st((GLB_AS unsigned*)c.xch + 2, (ep << 8) | (unsigned)mode);
+        if (w_lane0(c)) *word = mode;
+    }
+    c.bar();
+    const bool two = t3_ld(word) == 1;
+    c.bar();
+    return two;
+}
+template <class CH>
+__device__ inline void xch_publish(CH& c, int kind, int idx, const typename CH::PZT& p) {
+    auto& w = c.wave();
+    WSYNC();   // the product's rows have left this CU
+    GLB_AS unsigned long long* rec = (GLB_AS unsigned long long*)(c.xch + kXchRecs + (size_t)(kind * kXchSlots + idx) * kXchRecBytes);
+    if (w.lane < 10) {
+        unsigned long long v;
+        if (w.lane == 0) v = (unsigned long long)(unsigned)w.cnt[p.id] | ((unsigned long long)(unsigned)(p.id - c.L.idV) << 32);
+        else v = (unsigned long long)__double_as_longlong(p.cen[w.lane - 1]);   // centre | radius | second radius: nine doubles in a row (mk_slot)
+        __hip_atomic_store(rec + w.lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w.lane == 0) xch_st((GLB_AS unsigned*)(c.xch + kXchFlags) + kind * kXchSlots + idx, (unsigned)c.xch_epoch);
+    c.prof_signal(T3_CNT + 100 + 16 * kind + idx, 0);
+}
+template <class CH>
+__device__ inline typename CH::PZT xch_take(CH& c, int kind, int idx) {
+    typedef typename CH::PZT TPZ;
+    auto& w = c.wave();
+    LDS_AS int* broken = c.mb + kMbWords - 3;   // (one lost take: the others of this item do not wait again)
+    const GLB_AS unsigned* fl = (const GLB_AS unsigned*)(c.xch + kXchFlags) + kind * kXchSlots + idx;
+    const long long tw0 = c.prof_clock();
+    bool ok = t3_ld(broken) == 0;
+    if (ok) {
+        int spins = 0;
+        while (xch_ld(fl) != (unsigned)c.xch_epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 17)) { ok = false; break; }
+        }
+    }
+    c.prof_waited(tw0);
+    TPZ r = c.allocV();
+    if (!ok) {
+        flag(w, ERR_HELPER);
+        if (w.lane == 0) *broken = 1;
+        set_const(w, r, nullptr, nullptr);
+        return r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 holds nothing older than the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const GLB_AS unsigned long long* rec = (const GLB_AS unsigned long long*)(c.xch + kXchRecs + (size_t)(kind * kXchSlots + idx) * kXchRecBytes);
+    unsigned long long v = 0ull;
+    if (w.lane < 10) v = __hip_atomic_load(rec + w.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned lo0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull)), hi0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    int cnt = (int)lo0, slot = (int)hi0;
+    if (cnt < 0 || cnt > r.cap || slot < 0 || slot >= c.L.nV) { flag(w, ERR_HELPER); cnt = 0; slot = 0; }
+    const TPZ src = mk_slot(c.peer_arena, c.L.offV, slot, r.cap, 3, c.L.idV, c.ci);
+    r.keys = src.keys; r.coef = src.coef;
+    if (w.lane >= 1 && w.lane < 10) r.cen[w.lane - 1] = __longlong_as_double((long long)v);
+    if (w.lane == 0) w.cnt[r.id] = cnt;
+    WSYNC();
+    return r;
+}
+// The helper block's item: the two velocity recursions and the forward kinematics on wave 3, one family of products on each of the others.
+template <class CH>
+__device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publish) {
+    PZ_KEEP_RETURN_ADDRESS();
+    typedef typename CH::PZT TPZ;
+    const P1Cfg& cf = *c.cf;
+    auto& w = c.w;
+    const int J = c.J;
+    if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
+    if (c.wid == 3) {
+        c.role = 3;
+        TPZ wv = c.allocV(); set_const(w, wv, nullptr, nullptr); t3_post(c, T3_ST + 0, wv);
+        TPZ waux = c.allocV(); set_const(w, waux, nullptr, nullptr); t3_post(c, T3_ST + 2, waux);
+    }
+    c.bar();
+    if (c.wid == 3) {
+        c.role = 3;
+        if (publish) {
+            for (int s = 0; s < J; s++) {   // w_{s+1} = R_t w_s + qd_s, w_aux_{s+1} = R_t w_aux_s + qda_s: as the main block's fourth wave runs them (run_rnea_free)
+                const int ax = abs(cf.rb.axes[s]) - 1;
+                TPZ nw = c.mulMV(c.Rt(s), t3_take(c, T3_ST + 3 * s));
+                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
+                t3_post(c, T3_ST + 3 * (s + 1), nw);
+                TPZ na = c.mulMV(c.Rt(s), t3_take(c, T3_ST + 3 * s + 2));
+                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = t2; }
+                t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+                t3_signal(c, T3_CA, s + 1);
+            }
+        }
+        FkStateT<TPZ> fk;
+        fk_begin(c, fk);
+        for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);
+        c.freeVs(fk.T);
+    } else if (publish) {
+        c.role = c.wid;
+        const int s0 = c.wid == 0 ? 0 : 1, s1 = c.wid == 0 ? J - 1 : J;
+        for (int s = s0; s <= s1; s++) {
+            t3_wait(c, T3_CA, s);
+            const TPZ wv = t3_take(c, T3_ST + 3 * s), waux = t3_take(c, T3_ST + 3 * s + 2);
+            if (c.wid == 0) {
+                TPZ c2 = c.crossPzMat(waux, &cf.rb.trans[3 * s]);
+                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                xch_publish(c, XK_C3L, s, c3);
+            } else if (c.wid == 2) {
+                TPZ c2 = c.crossPzMat(waux, &cf.rb.com[3 * (s - 1)]);
+                TPZ c3 = c.crossPzPz(wv, c2); c.freeVs(c2);
+                xch_publish(c, XK_C3C, s - 1, c3);
+            } else {
+                TPZ t2 = c.mulMV(c.inertia(s - 1), wv);
+                TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+                xch_publish(c, XK_CRN, s - 1, cr);
+            }
+        }
+    }
+    c.prof_forward_done();
+    c.bar();
+}
+
 template <class CH>
 __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, int t_lane) {
     PZ_KEEP_RETURN_ADDRESS();
@@ -199,7 +364,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // states are still alive when the recursions end) a wave that is through with its recursion builds it -- wave `tc_wave` = 3 (the fourth
     // wave, when it has no forward kinematics to do) or 1 (the angular wave, before its tail moments) -- and the F / N wave takes it from the
     // mailbox.  Same operators on the same operands: same bits.  (cf.tail_cross: 0 off | links | 10 + links: on wave 1)
-    const int tc_opt = cf.tail_cross % 100;
+    // a time step on two CUs: the three families of velocity-only cross products come from the item's helper block (xch_take)
+    bool two = false;
+    if constexpr (CH::kTwoCu) two = c.two_cu;
+    auto take_x = [&](int kind, int idx) -> TPZ { if constexpr (CH::kTwoCu) return xch_take(c, kind, idx); else return TPZ(); };
+    const int tc_opt = two ? 0 : cf.tail_cross % 100;
     const int tc_wave = fk_wave && aux3 && tc_opt > 0 ? (tc_opt >= 10 ? 1 : 3) : -1;
     const int tc_links = tc_wave < 0 ? 0 : min(tc_opt % 10, min(K + 1, n_tail_max));   // (never more links than the tail may hold: a chain of J < 4 joints has none -- s = J - tc_links + 1 must stay >= 1)
     auto tail_cross = [&]() {   // (the wave that owns them frees them behind barrier (A))
@@ -299,8 +468,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
             const TPZ I = c.inertia(s - 1);
             TPZ t1 = c.mulMV(I, wdot);
-            TPZ t2 = c.mulMV(I, wv);
-            TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+            TPZ cr;
+            if (two) cr = take_x(XK_CRN, s - 1);
+            else { TPZ t2 = c.mulMV(I, wv); cr = c.crossPzPz(waux, t2); c.freeVs(t2); }
             TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
             t3_post(c, T3_N + s - 1, N);
         }
@@ -327,12 +497,12 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (fk_wave) {   // wdot x p, w_aux x p: from the forward-kinematics wave (wdot x p only where it is a PZ of its own)
                 t3_wait(c, T3_C3, s + 1);
                 if constexpr (!fused_cross) c1 = t3_take(c, T3_X1 + s);
-                c2 = t3_take(c, T3_X2 + s);
+                if (!two) c2 = t3_take(c, T3_X2 + s);
             } else {
                 if constexpr (!fused_cross) c1 = c.crossPzMat(wdot, tr);
                 c2 = c.crossPzMat(waux, tr);
             }
-            TPZ c3 = c.crossPzPz(wv, c2); if (!fk_wave) c.freeVs(c2);
+            TPZ c3 = two ? take_x(XK_C3L, s) : c.crossPzPz(wv, c2); if (!fk_wave) c.freeVs(c2);
             TPZ s2;
             if constexpr (fused_cross) s2 = c.sum3x(lacc, wdot, tr, c3);   // (lacc + wdot x p) + c3, the cross product inside the sum
             else { s2 = c.sum3(lacc, c1, c3); if (!fk_wave) c.freeVs(c1); }
@@ -371,12 +541,14 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 if (s >= 2) {
                     t3_wait(c, T3_C0, s - 1);
                     if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s - 2));
-                    c.freeVs(t3_take(c, T3_X2 + s - 2));
+                    if (!two) c.freeVs(t3_take(c, T3_X2 + s - 2));
                 }
                 if (!aux3) t3_wait(c, T3_C1, s);   // (w_aux_s is this wave's own otherwise)
                 const double* tr = &cf.rb.trans[3 * s];
-                TPZ x2 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 2), tr);
-                t3_post(c, T3_X2 + s, x2);
+                if (!two) {   // (w_aux x p only feeds w x (w_aux x p), which the helper block builds from its own recursion)
+                    TPZ x2 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 2), tr);
+                    t3_post(c, T3_X2 + s, x2);
+                }
                 if constexpr (!fused_cross) {   // wdot x p where it is a PZ of its own
                     if (aux3) t3_wait(c, T3_C1, s);
                     TPZ x1 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 1), tr);
@@ -393,7 +565,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         if (tc_wave == 3) tail_cross_free();
         for (int k = freed_w; k <= J; k++) { c.freeVs(t3_take(c, T3_ST + 3 * k)); if (aux3) c.freeVs(t3_take(c, T3_ST + 3 * k + 2)); }
         if (aux3) for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_NA + k));
-        for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); c.freeVs(t3_take(c, T3_X2 + s)); }
+        for (int s = J >= 2 ? J - 2 : 0; s < J; s++) { if constexpr (!fused_cross) c.freeVs(t3_take(c, T3_X1 + s)); if (!two) c.freeVs(t3_take(c, T3_X2 + s)); }
     } else {
         c.role = 2;
         FkStateT<TPZ> fk;
@@ -409,8 +581,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 if (s <= J - n_tail) {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
                     const TPZ I = c.inertia(s - 1);
                     TPZ t1 = c.mulMV(I, wdot);
-                    TPZ t2 = c.mulMV(I, wv);
-                    TPZ cr = c.crossPzPz(waux, t2); c.freeVs(t2);
+                    TPZ cr;
+                    if (two) cr = take_x(XK_CRN, s - 1);
+                    else { TPZ t2 = c.mulMV(I, wv); cr = c.crossPzPz(waux, t2); c.freeVs(t2); }
                     TPZ N = c.add(t1, cr); c.freeVs(t1); c.freeVs(cr);
                     t3_post(c, T3_N + s - 1, N);
                 }
@@ -421,6 +594,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                     const bool from_tail = s > J - tc_links;   // w x (w_aux x com) comes from a wave that is through with its recursion
                     TPZ c3;
                     if (from_tail) { t3_wait(c, T3_C3P, s); c3 = t3_take(c, T3_X3 + s); }
+                    else if (two) c3 = take_x(XK_C3C, s - 1);
                     else { TPZ c2 = c.crossPzMat(waux, cm); c3 = c.crossPzPz(wv, c2); c.freeVs(c2); }
                     t3_wait(c, T3_C0, s);
                     const TPZ lacc = t3_take(c, T3_LA + s);

@@ -42,6 +42,9 @@ constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28
 // ... and of a 4-wave block (round 3: the forward kinematics, the omega recursion and the constant cross products on a wave of their own,
 // as the time-vectorised kernel's four-wave blocks have had since round 2: p1_tv.inc.h kTvPart4First)
 constexpr int kPart4First[4] = {0, 8, 23, 43}, kPart4Count[4] = {8, 15, 20, 20};   // (63 slots: the free mask is one 64-bit word, built as (1 << nV) - 1)
+// ... and of the HELPER block of a time step on two CUs (p1_free.inc.h): J products + one temporary on each product wave; 2 (J + 1) states + the forward kinematics on the fourth
+constexpr int kPartHFirst[4] = {0, 10, 20, 30}, kPartHCount[4] = {10, 10, 10, 33};
+static_assert(ARMOUR_MAX_JOINTS + 1 <= 10 && 2 * (ARMOUR_MAX_JOINTS + 1) + 8 <= 33, "helper pool");
 // Sort-buffer KEY entries for `cap` raw terms.  A wave's LDS sort buffers are skey[cap_key] (monomial keys) + sidx[cap_raw] (permutation, 2 B each).
 // The 64-bit build gives both `cap` entries; with 128-bit keys (pz_key.h, -DARMOUR_KEY128) the same bytes hold half as many keys -- and the
 // sorters ask for cap_key and cap_raw separately (pz_wave.h sort_terms: the tree merge needs 2 N keys, the ranked merge the two operands' key
@@ -97,6 +100,9 @@ struct P1Cfg {
     unsigned* queue;      // per-step kernel: the blocks draw their items from this counter (nullptr: block k takes items k, k + blocks, ...)
     int queue_order;      // 1: the late time steps of every problem first (they are the expensive ones) | 2: in index order | 3: the early steps first
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
+    // a time step on two CUs (p1_free.inc.h): block b < n_items builds item b, block helper0 + b is its helper; xch: kXchBytes per item
+    int two_cu, helper0, xch_epoch;
+    unsigned char* xch;
 };
 
 __host__ __device__ inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -306,6 +312,11 @@ struct Chain {
     static constexpr bool kWalkHelpers = false;   // (the time-vectorised chain has them: p1_tv.inc.h)
     static constexpr bool kFusedCross = false;    // (likewise)
     static constexpr bool kPairs = true;          // run_rnea_free: two waves per operator in the backward pass of a four-wave block
+    static constexpr bool kTwoCu = true;          // a time step on two CUs (p1_free.inc.h)
+    bool helper = false, two_cu = false;          // this block is the helper of its item | this item runs on two CUs (decided per item: xch_decide)
+    GLB_AS unsigned char* xch = nullptr;          // the item's exchange area
+    GLB_AS unsigned char* peer_arena = nullptr;   // main block: the helper's arena
+    int xch_epoch = 0;
     Wave w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -380,15 +391,15 @@ struct Chain {
     __device__ PairState solo_begin() { PairState st{w.lane2, w.nl, w.half, w.pair}; solo(w); return st; }
     __device__ void solo_end(const PairState& st) { w.lane2 = st.lane2; w.nl = st.nl; w.half = st.half; w.pair = st.pair; }
     __device__ unsigned long long part_mask(int r) const {
+        if (helper) return ((1ull << kPartHCount[r]) - 1ull) << kPartHFirst[r];
         return L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[r]) - 1ull) << kPartFirst[r] : ((1ull << kPart4Count[r]) - 1ull) << kPart4First[r];
     }
 
     int role = 0;  // the role the code being executed belongs to: selects the part of the 3x1 pool allocV() draws from
     __device__ PZ allocV() {
-        const unsigned long long part = L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[role]) - 1ull) << kPartFirst[role]
-                                                                                   : ((1ull << kPart4Count[role]) - 1ull) << kPart4First[role];
+        const unsigned long long part = part_mask(role);
         const int i = __ffsll((long long)(freeV & part)) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 100 + role; return V(L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 100 + role; return V(helper ? kPartHFirst[role] : L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
         freeV &= ~(1ull << i);
         return V(i);
     }
@@ -672,12 +683,12 @@ __device__ inline void jrs_mass_inertia_direct(Chain& c, int i) {
 // read is not built: a chain that stops at the forward kinematics has no velocity polynomials, an RNEA item whose forward kinematics runs
 // as an item of its own no link boxes.
 // The caller follows with a block barrier.
-__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only) {
+__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only, bool with_boxes = false) {
     PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
-    const bool boxes = kin_only || cf.fk_items == 0;
+    const bool boxes = kin_only || cf.fk_items == 0 || with_boxes;   // (with_boxes: the helper block of a time step on two CUs -- velocity polynomials for its recursions AND link boxes for the forward kinematics)
     // The scalar work of a joint -- the trigonometry of its fixed rotation (14 k cycles) and jrs_scalars (19 k) -- is the same in all 64 lanes
     // of the per-step wave: lane i does it for joint i instead, all of this wave's joints at once, and the joint loop below reads lane i's
     // results.  Same functions on the same arguments: same bits.
@@ -1130,6 +1141,13 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     // release build the cheapest items are no cheaper than 0.9 of the slowest.  An item's result does not depend on who builds it or when.
     LDS_AS int* qword = c.mb + kMbWords - 1;   // (the last word of the walk-helper channels this chain does not use; pairs: the first 2 * PW_WORDS + 4)
     int it0 = blockIdx.x;
+    bool helper_block = false;   // a time step on two CUs (p1_free.inc.h): block helper0 + k is the helper of item k, the blocks between the two ranges have nothing to do
+    if constexpr (NW == 4) {
+        if (cf.two_cu) {
+            if ((int)blockIdx.x >= cf.helper0) { helper_block = true; it0 = (int)blockIdx.x - cf.helper0; }
+            else if ((int)blockIdx.x >= cf.n_items) it0 = cf.n_items + cf.fk_items;
+        }
+    }
     for (;;) {
         if (cf.queue) {
             __syncthreads();   // everybody is through with the previous item, and has read its index
@@ -1138,7 +1156,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             it0 = __builtin_amdgcn_readfirstlane(*qword);
         }
         if (it0 >= cf.n_items + cf.fk_items) break;
-        const bool fk_only = it0 >= cf.n_items || cf.fk_only != 0;
+        const bool fk_only = !helper_block && (it0 >= cf.n_items || cf.fk_only != 0);
         int it = it0 >= cf.n_items ? it0 - cf.n_items : it0;
         if (cf.queue && !cf.items && cf.queue_order != 2) {   // position in the draw -> item: time steps from the last (order 1) or the first (3), every problem's in turn
             const int nb = cf.n_items / cf.T;   // (all problems, all steps: n_items = B * T)
@@ -1153,18 +1171,33 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.role = 0;
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         margin_reset(c.w);
+        c.helper = helper_block; c.two_cu = false;
+        if constexpr (NW == 4) {
+            if (cf.two_cu) {
+                c.xch = (GLB_AS unsigned char*)cf.xch + (size_t)it0 * kXchBytes;
+                c.xch_epoch = cf.xch_epoch;
+                c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(cf.helper0 + it0) * cf.arena_bytes;
+                xch_hello(c, helper_block);
+                if (threadIdx.x == 0) c.mb[kMbWords - 3] = 0;   // (xch_take: no take of this item has been lost)
+            }
+        }
         __syncthreads();
 #if defined(P1_PROFILE) || defined(P1_STAMPS)
         const long long ph0 = clock64();
         c.ph_item = ph0; c.n_log = 0;
 #endif
-        build_jrs(c, b, t, fk_only);
+        build_jrs(c, b, t, fk_only, helper_block);
         __syncthreads();
+        if constexpr (NW == 4) {
+            if (cf.two_cu) c.two_cu = xch_decide(c, helper_block);   // same XCD as the other block of the item, and both alive: two CUs; otherwise this block does everything (the helper: the forward kinematics alone)
+        }
 #ifdef P1_PROFILE
         const long long ph1 = clock64();
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
-        if (fk_only) {
+        if (helper_block) {
+            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu);
+        } else if (fk_only) {
             // forward kinematics and the link tables, nothing else: the whole ARMTD chain (CMP/armtd_main.cu:141-156), or
             // the forward-kinematics half of a split ARMOUR item.  A single role: one wave works.
             if (c.is(2)) {
@@ -1182,7 +1215,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #ifdef P1_PROFILE
         const long long ph3 = clock64();
 #endif
-        if (!fk_only) {
+        if (!fk_only && !helper_block) {
             if (NW >= kRoles && cf.free_running) {   // every wave takes its share of the joints' tables (the 1x1 slots of u_nom: the mailbox, past the last barrier of the RNEA)
                 for (int j = 0; j < c.n; j++) u_nom[j] = c.S(t3_ld(&c.mb[T3_U + j]));
                 finish_torque(c, u_nom, b, t, c.wid, NW);
@@ -1207,8 +1240,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #endif
 #if defined(P1_STAMPS) && !defined(P1_PROFILE)
         if (c.w.lane == 0 && (t == 60 || t == cf.T - 1 || t == 0) && !fk_only) {
-            printf("[t=%d wave %d] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, c.wid, (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
-            if (t == cf.T - 1) for (int q = 0; q < c.n_log; q++) printf("[t=%d wave %d signal] word %d value %d at %lld\n", t, c.wid, c.log_word[q] - T3_CNT, c.log_val[q], c.log_clk[q]);
+            printf("[t=%d %swave %d%s] %lld cycles, %lld of them at barriers / mailbox waits (%lld in the forward pass); forward pass done at %lld\n", t, helper_block ? "helper " : "", c.wid, c.two_cu ? ", two CUs" : "", (long long)clock64() - ph0, c.bar_wait, c.wait_fwd, c.fwd_done - ph0);
+            if (t == cf.T - 1) for (int q = 0; q < c.n_log; q++) printf("[t=%d %swave %d signal] word %d value %d at %lld\n", t, helper_block ? "helper " : "", c.wid, c.log_word[q] - T3_CNT, c.log_val[q], c.log_clk[q]);
         }
         if (c.w.lane == 0 && t == cf.T - 1 && fk_only) printf("[t=%d fk item wave %d] %lld cycles\n", t, c.wid, (long long)clock64() - ph0);
         c.bar_wait = 0;
@@ -1714,6 +1747,7 @@ struct P1Work {
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
     unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
     unsigned long long* d_margin = nullptr; size_t margin_cap = 0;   // [B]: the prune margin word of every problem (P1Cfg::margin)
+    unsigned char* d_xch = nullptr; size_t xch_cap = 0; int xch_epoch = 0;   // a time step on two CUs: kXchBytes per item, flags tagged with the launch's epoch (cleared when allocated and when the epoch wraps)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -1769,6 +1803,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_link_gens) (void)hipFree(wk->d_link_gens);
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
     if (wk->d_margin) (void)hipFree(wk->d_margin);
+    if (wk->d_xch) (void)hipFree(wk->d_xch);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
     if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
@@ -1922,6 +1957,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
         const int nw_env = h->tune(ARMOUR_OPT_P1_STEP_WAVES);   // (0: automatic)
+        const int cf_two_cu_env = h->tune(ARMOUR_OPT_P1_STEP_TWO_CU);
         // (round 3) ... FOUR waves when the block's LDS holds the fourth wave's small sort buffers as well: the forward kinematics,
         // the omega recursion and the constant cross products of the linear acceleration leave the three recursion waves for a wave
         // of their own (run_rnea_free, the choreography of the time-vectorised kernel's four-wave blocks) and no item is issued twice
@@ -1950,7 +1986,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         const int split_env = h->tune(ARMOUR_OPT_P1_STEP_SPLIT_FK);   // (-1: automatic)
         const bool split = split_env >= 0 ? (split_env != 0 && multi) : (multi && n_items <= prop.multiProcessorCount);   // (round 4: also when the two kinds of items together are more than the blocks -- the blocks draw the RNEA items first and fill up with the forward kinematics: B = 2 1.095 -> 1.081 ms)
         const int fk_items = split ? n_items : 0;
-        const int waves = std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
+        // A time step on two CUs (p1_free.inc.h): every item gets a helper block on a CU of its own, which also runs the item's forward kinematics.
+        // Block k builds item k, block helper0 + k helps it; helper0 a multiple of 8 puts the two on one XCD (checked on the device, item by item).
+        const int helper0 = (n_items + 7) & ~7;
+        const bool two_cu = four && split && !collect && !d_items && cf_two_cu_env && !h->p1_two_cu_off && h->mode == ARMOUR_MODE_ARMOUR && helper0 + n_items <= prop.multiProcessorCount * per_cu;
+        const int waves = two_cu ? helper0 + n_items : std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
             wk->arena = nullptr;
@@ -1983,6 +2023,20 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
+        cf.two_cu = two_cu ? 1 : 0; cf.helper0 = helper0;
+        if (two_cu) {
+            const size_t need = (size_t)n_items * kXchBytes;
+            bool clear = false;
+            if (need > wk->xch_cap) {
+                if (wk->d_xch) (void)hipFree(wk->d_xch);
+                wk->d_xch = nullptr; wk->xch_cap = 0;
+                HIPCHK(hipMalloc((void**)&wk->d_xch, need));
+                wk->xch_cap = need; clear = true;
+            }
+            if (++wk->xch_epoch >= (1 << 23)) { wk->xch_epoch = 1; clear = true; }
+            if (clear) HIPCHK(hipMemsetAsync(wk->d_xch, 0, wk->xch_cap, h->stream));
+            cf.xch = wk->d_xch; cf.xch_epoch = wk->xch_epoch;
+        }
         HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
         if (collect) HIPCHK(hipMemsetAsync(wk->d_retry, 0, sizeof(int), h->stream));
         HIPCHK(hipEventRecord(wk->ev0, h->stream));
@@ -2015,7 +2069,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
-        if (armour_trace_p1()) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
+        if (armour_trace_p1()) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s)%s (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, two_cu ? ", two CUs per item" : "", per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
         return ARMOUR_OK;
     };
     auto other_errors = [&]() -> int {
@@ -2182,6 +2236,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     }
     while (n_items > 0) {
         if ((rc = launch(cap_raw, d_items, n_items, false)) != ARMOUR_OK) return rc;
+        if ((st[ST_ERR] & (unsigned)ERR_HELPER) && !h->p1_two_cu_off) {   // a time step on two CUs lost its helper: again on one CU per step, and this handle stays there
+            if (armour_trace_p1()) fprintf(stderr, "[P1] a helper block's results did not arrive (flags 0x%x): building again on one CU per time step\n", st[ST_ERR]);
+            h->p1_two_cu_off = true;
+            continue;
+        }
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
             if (cap_raw < 16384) { cap_raw <<= 1; h->p1_step_cap_hint = cap_raw; continue; }  // retry with larger LDS sort buffers (and start there next time)
             armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);

@@ -63,6 +63,7 @@ struct TChain {
     typedef TPZ PZT;
     static constexpr bool kWalkHelpers = true;   // pz_tv.h "One walk on two waves"; used by run_rnea_free in four-wave blocks
     static constexpr bool kPairs = false;        // (the per-step chain's two-waves-per-operator backward pass; this chain shares its walks instead)
+    static constexpr bool kTwoCu = false;        // (a time step on two CUs: the per-step chain's, p1_free.inc.h)
     static constexpr bool kFusedCross = true;    // run_rnea_free: (a + cross(w, b)) + c with the constant cross product taken inside the sum's walk (sum3x)
     TW w;
     const P1Cfg* cf;
