@@ -190,10 +190,10 @@ __device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail
 // same XCD: two CUs; different, or no sign of the helper: everything itself, as before -- and publishes the decision for the helper.  Block
 // b's helper is block helper0 + b with helper0 a multiple of 8 (blocks are dealt round-robin to the XCDs: observed, not promised -- hence the check).
 // A take that never sees its flag (cut off after ~0.1 s) raises ERR_HELPER; the host then builds again on one CU per step and keeps the handle there.
-enum { XK_C3L = 0, XK_C3C = 1, XK_CRN = 2, XK_KINDS = 3 };
+enum { XK_C3L = 0, XK_C3C = 1, XK_CRN = 2, XK_C4 = 3, XK_KINDS = 4 };
 constexpr int kXchSlots = ARMOUR_MAX_JOINTS + 1;
-constexpr size_t kXchFlags = 128, kXchRecs = 256, kXchRecBytes = 128, kXchBytes = 4096;   // control line | flag words | records
-static_assert(XK_KINDS * kXchSlots * sizeof(unsigned) <= 128 && kXchRecs + XK_KINDS * kXchSlots * kXchRecBytes <= kXchBytes, "exchange area");
+constexpr size_t kXchFlags = 128, kXchRecs = 384, kXchRecBytes = 128, kXchBytes = 8192;   // control line | flag words | records
+static_assert(XK_KINDS * kXchSlots * sizeof(unsigned) <= kXchRecs - kXchFlags && kXchRecs + XK_KINDS * kXchSlots * kXchRecBytes <= kXchBytes, "exchange area");
 __device__ inline unsigned xch_xcc() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return (v & 0xfu) + 1u; }
 __device__ inline void xch_st(GLB_AS unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline unsigned xch_ld(const GLB_AS unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -289,18 +289,30 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
         TPZ waux = c.allocV(); set_const(w, waux, nullptr, nullptr); t3_post(c, T3_ST + 2, waux);
     }
     c.bar();
+    const bool c4h = c.two_level >= 3;   // R_t w_aux_s x (qd_s e_axis), the cross product of the angular-acceleration step (RT/Dynamics.cu:119-121), as a fourth family
     if (c.wid == 3) {
         c.role = 3;
         if (publish) {
+            int freed_na = 0;   // (c4h) R_t w_aux_k, k < freed_na, have been given back
             for (int s = 0; s < J; s++) {   // w_{s+1} = R_t w_s + qd_s, w_aux_{s+1} = R_t w_aux_s + qda_s: as the main block's fourth wave runs them (run_rnea_free)
                 const int ax = abs(cf.rb.axes[s]) - 1;
+                while (c4h && freed_na + 3 < s) {   // at most four of them alive: read by the second product wave at its step k
+                    t3_wait(c, T3_C1, freed_na + 1);
+                    if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_NA + freed_na));
+                    freed_na++;
+                }
+                TPZ na = c.mulMV(c.Rt(s), t3_take(c, T3_ST + 3 * s + 2));   // (first: the angular step of the main block waits for what is made of it)
+                if (c4h) t3_post(c, T3_NA + s, na);
+                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(na, c.qda(s), ax); if (!c4h) c.freeVs(na); na = t2; }
+                t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+                if (c4h) t3_signal(c, T3_C3, s + 1);   // R_t w_aux_s is posted
                 TPZ nw = c.mulMV(c.Rt(s), t3_take(c, T3_ST + 3 * s));
                 if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(nw, c.qd(s), ax); c.freeVs(nw); nw = t2; }
                 t3_post(c, T3_ST + 3 * (s + 1), nw);
-                TPZ na = c.mulMV(c.Rt(s), t3_take(c, T3_ST + 3 * s + 2));
-                if (cf.rb.axes[s] != 0) { TPZ t2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = t2; }
-                t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
                 t3_signal(c, T3_CA, s + 1);
+            }
+            if (c4h) {
+                for (; freed_na < J; freed_na++) { t3_wait(c, T3_C1, freed_na + 1); if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_NA + freed_na)); }
             }
         }
         FkStateT<TPZ> fk;
@@ -311,6 +323,16 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
         c.role = c.wid;
         const int s0 = c.wid == 0 ? 0 : 1, s1 = c.wid == 0 ? J - 1 : J;
         for (int s = s0; s <= s1; s++) {
+            if (c4h && c.wid == 1) {   // the angular step s - 1 of the main block waits for this one: before the moment's product of link s - 1
+                const int q = s - 1;
+                t3_wait(c, T3_C3, q + 1);
+                if (cf.rb.axes[q] != 0) {
+                    TPZ temp = c.embedOneDim(c.qd(q), abs(cf.rb.axes[q]) - 1);
+                    TPZ c4 = c.crossPzPz(t3_take(c, T3_NA + q), temp); c.freeVs(temp);
+                    xch_publish(c, XK_C4, q, c4);
+                }
+                t3_signal(c, T3_C1, q + 1);   // (the fourth wave may give R_t w_aux_q back)
+            }
             t3_wait(c, T3_CA, s);
             const TPZ wv = t3_take(c, T3_ST + 3 * s), waux = t3_take(c, T3_ST + 3 * s + 2);
             if (c.wid == 0) {
@@ -366,7 +388,10 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // mailbox.  Same operators on the same operands: same bits.  (cf.tail_cross: 0 off | links | 10 + links: on wave 1)
     // a time step on two CUs: the three families of velocity-only cross products come from the item's helper block (xch_take)
     bool two = false;
-    if constexpr (CH::kTwoCu) two = c.two_cu;
+    int two_lvl = 0;
+    if constexpr (CH::kTwoCu) { two = c.two_cu; two_lvl = two ? c.two_level : 0; }
+    const bool two2 = two_lvl >= 2;   // nobody in this block reads w: no w recursion here; the linear-acceleration wave takes wdot x p itself
+    const bool two3 = two_lvl >= 3;   // ... nor w_aux: the angular step's cross product comes from the helper too, the fourth wave has no recursion left
     auto take_x = [&](int kind, int idx) -> TPZ { if constexpr (CH::kTwoCu) return xch_take(c, kind, idx); else return TPZ(); };
     const int tc_opt = two ? 0 : cf.tail_cross % 100;
     const int tc_wave = fk_wave && aux3 && tc_opt > 0 ? (tc_opt >= 10 ? 1 : 3) : -1;
@@ -452,9 +477,13 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (!aux3) na = c.mulMV(Rt, t3_take(c, T3_ST + 3 * s + 2));
             TPZ nd = c.mulMV(Rt, wdot);
             if (cf.rb.axes[s] != 0) {
-                TPZ temp = c.embedOneDim(c.qd(s), ax);   // addOneDimPZ(0, qd_s, axis) (RT/Dynamics.cu:119-120)
-                if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_NA + s); }   // R_t w_aux_s from the forward-kinematics wave
-                TPZ c4 = c.crossPzPz(na, temp); c.freeVs(temp);
+                TPZ c4;
+                if (two3) c4 = take_x(XK_C4, s);
+                else {
+                    TPZ temp = c.embedOneDim(c.qd(s), ax);   // addOneDimPZ(0, qd_s, axis) (RT/Dynamics.cu:119-120)
+                    if (aux3) { t3_wait(c, T3_CA, s + 1); na = t3_take(c, T3_NA + s); }   // R_t w_aux_s from the forward-kinematics wave
+                    c4 = c.crossPzPz(na, temp); c.freeVs(temp);
+                }
                 TPZ nd2 = c.sum3(nd, c4, c.qdda(s), ax); c.freeVs(c4); c.freeVs(nd); nd = nd2;
                 if (!aux3) { TPZ na2 = c.addOneDim(na, c.qda(s), ax); c.freeVs(na); na = na2; }
             }
@@ -464,7 +493,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         if (tc_wave == 1) tail_cross();   // (first: the F / N wave is waiting for these)
         for (int s = J; s > J - n_tail; s--) {   // N = I * wdot + cross(w_aux, I * w) of link s - 1
-            t3_wait(c, T3_CA, s);
+            if (!two2) t3_wait(c, T3_CA, s);
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
             const TPZ I = c.inertia(s - 1);
             TPZ t1 = c.mulMV(I, wdot);
@@ -484,7 +513,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         int freed = 0;
         for (int s = 0; s < J; s++) {
             t3_wait(c, T3_C1, s);   // state_s
-            t3_wait(c, T3_CA, s);
+            if (!two2) t3_wait(c, T3_CA, s);
             while (freed + K < s + 1) {   // lacc_k: read by wave 2 at step k (>= 1), by this wave at step k (done)
                 const int k = freed;
                 if (k >= 1) t3_wait(c, T3_CC2, k);
@@ -494,18 +523,19 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2), lacc = t3_take(c, T3_LA + s);
             const double* tr = &cf.rb.trans[3 * s];
             TPZ c1 = wdot, c2 = waux;
-            if (fk_wave) {   // wdot x p, w_aux x p: from the forward-kinematics wave (wdot x p only where it is a PZ of its own)
+            const bool own_cross = !fk_wave || (two2 && !two3);   // (two CUs, level 2: wdot x p is this wave's own -- the fourth wave's copy made it wait for a wave that waits for the angular one; level 3: the fourth wave has nothing else to do and builds it the moment wdot_s is posted)
+            if (!own_cross) {   // wdot x p, w_aux x p: from the forward-kinematics wave (wdot x p only where it is a PZ of its own)
                 t3_wait(c, T3_C3, s + 1);
                 if constexpr (!fused_cross) c1 = t3_take(c, T3_X1 + s);
                 if (!two) c2 = t3_take(c, T3_X2 + s);
             } else {
                 if constexpr (!fused_cross) c1 = c.crossPzMat(wdot, tr);
-                c2 = c.crossPzMat(waux, tr);
+                if (!two) c2 = c.crossPzMat(waux, tr);
             }
-            TPZ c3 = two ? take_x(XK_C3L, s) : c.crossPzPz(wv, c2); if (!fk_wave) c.freeVs(c2);
+            TPZ c3 = two ? take_x(XK_C3L, s) : c.crossPzPz(wv, c2); if (own_cross && !two) c.freeVs(c2);
             TPZ s2;
             if constexpr (fused_cross) s2 = c.sum3x(lacc, wdot, tr, c3);   // (lacc + wdot x p) + c3, the cross product inside the sum
-            else { s2 = c.sum3(lacc, c1, c3); if (!fk_wave) c.freeVs(c1); }
+            else { s2 = c.sum3(lacc, c1, c3); if (own_cross) c.freeVs(c1); }
             c.freeVs(c3);
             TPZ nl = c.mulMV(c.Rt(s), s2); c.freeVs(s2);
             t3_post(c, T3_LA + s + 1, nl);
@@ -513,6 +543,42 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         c.prof_forward_done(); c.bar();   // (A)
         for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
+    } else if (c.wid == 3 && two2) {
+        // Two CUs, level 2: of this wave's forward pass only the w_aux recursion is left (R_t w_aux_s for the angular step); level 3: nothing.
+        c.role = 3;
+        if (!two3) {
+            int freed_na = 0;
+            for (int s = 0; s < J; s++) {
+                while (freed_na + 1 < s) {   // R_t w_aux_k: read by the angular wave at step k
+                    t3_wait(c, T3_C1, freed_na + 1);
+                    if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_NA + freed_na));
+                    freed_na++;
+                }
+                const TPZ waux = t3_take(c, T3_ST + 3 * s + 2);
+                TPZ na = c.mulMV(c.Rt(s), waux); c.freeVs(waux);   // (w_aux_s has no other reader left)
+                t3_post(c, T3_NA + s, na);
+                if (cf.rb.axes[s] != 0) na = c.addOneDim(na, c.qda(s), abs(cf.rb.axes[s]) - 1);
+                t3_post(c, T3_ST + 3 * (s + 1) + 2, na);
+                t3_signal(c, T3_CA, s + 1);
+            }
+            c.prof_forward_done(); c.bar();   // (A)
+            c.freeVs(t3_take(c, T3_ST + 3 * J + 2));
+            for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_NA + k));
+        } else {
+            c.freeVs(t3_take(c, T3_ST + 2));
+            if constexpr (!fused_cross) {
+                for (int s = 0; s < J; s++) {   // wdot x p for the linear-acceleration step s
+                    if (s >= 2) { t3_wait(c, T3_C0, s - 1); c.freeVs(t3_take(c, T3_X1 + s - 2)); }
+                    t3_wait(c, T3_C1, s);
+                    TPZ x1 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 1), &cf.rb.trans[3 * s]);
+                    t3_post(c, T3_X1 + s, x1);
+                    t3_signal(c, T3_C3, s + 1);
+                }
+            }
+            c.prof_forward_done(); c.bar();   // (A)
+            if constexpr (!fused_cross) for (int s = J >= 2 ? J - 2 : 0; s < J; s++) c.freeVs(t3_take(c, T3_X1 + s));
+        }
+        c.freeVs(t3_take(c, T3_ST + 0));   // (the constant w_0 this wave posted before the pass)
     } else if (c.wid == 3) {
         // the forward kinematics shares nothing with the recursion but the JRS rotations: wave 2 was the last to finish the
         // forward pass while it carried it (14.1 M cycles against 9.4 / 10.1 M of the other two)
@@ -576,7 +642,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (it waits for nobody)
             if (s >= 1) {
                 t3_wait(c, T3_C1, s);
-                t3_wait(c, T3_CA, s);
+                if (!two2) t3_wait(c, T3_CA, s);
                 const TPZ wv = t3_take(c, T3_ST + 3 * s), wdot = t3_take(c, T3_ST + 3 * s + 1), waux = t3_take(c, T3_ST + 3 * s + 2);
                 if (s <= J - n_tail) {   // N = I * wdot + cross(w_aux, I * w)   (the state alone: no need to wait for the linear acceleration yet)
                     const TPZ I = c.inertia(s - 1);

@@ -43,8 +43,10 @@ constexpr int kPartFirst[kRoles] = {0, 12, 34}, kPartCount[kRoles] = {12, 22, 28
 // as the time-vectorised kernel's four-wave blocks have had since round 2: p1_tv.inc.h kTvPart4First)
 constexpr int kPart4First[4] = {0, 8, 23, 43}, kPart4Count[4] = {8, 15, 20, 20};   // (63 slots: the free mask is one 64-bit word, built as (1 << nV) - 1)
 // ... and of the HELPER block of a time step on two CUs (p1_free.inc.h): J products + one temporary on each product wave; 2 (J + 1) states + the forward kinematics on the fourth
+// (level 3, J <= 7: the second product wave also builds the angular step's cross product, 2 J products + three temporaries -- Chain::helper_parts)
 constexpr int kPartHFirst[4] = {0, 10, 20, 30}, kPartHCount[4] = {10, 10, 10, 33};
-static_assert(ARMOUR_MAX_JOINTS + 1 <= 10 && 2 * (ARMOUR_MAX_JOINTS + 1) + 8 <= 33, "helper pool");
+static_assert(ARMOUR_MAX_JOINTS + 1 <= 10 && 2 * (ARMOUR_MAX_JOINTS + 1) + 12 <= 33, "helper pool");
+constexpr int kTwoCuC4MaxJ = 7;   // 4 J + 4 + 2 (J + 1) + 10 <= 63
 // Sort-buffer KEY entries for `cap` raw terms.  A wave's LDS sort buffers are skey[cap_key] (monomial keys) + sidx[cap_raw] (permutation, 2 B each).
 // The 64-bit build gives both `cap` entries; with 128-bit keys (pz_key.h, -DARMOUR_KEY128) the same bytes hold half as many keys -- and the
 // sorters ask for cap_key and cap_raw separately (pz_wave.h sort_terms: the tree merge needs 2 N keys, the ranked merge the two operands' key
@@ -314,6 +316,12 @@ struct Chain {
     static constexpr bool kPairs = true;          // run_rnea_free: two waves per operator in the backward pass of a four-wave block
     static constexpr bool kTwoCu = true;          // a time step on two CUs (p1_free.inc.h)
     bool helper = false, two_cu = false;          // this block is the helper of its item | this item runs on two CUs (decided per item: xch_decide)
+    int two_level = 0;                            // 1: the three families of velocity-only products | 2: + the main block drops its own w recursion and the fourth wave's cross products | 3: + the angular step's cross product from the helper, no velocity recursion left in the main block
+    int hpf[4] = {0, 10, 20, 30}, hpc[4] = {10, 10, 10, 33};   // the helper block's pool parts
+    __device__ void helper_parts(int lvl) {
+        if (lvl >= 3) { hpf[0] = 0; hpc[0] = J + 1; hpf[1] = J + 1; hpc[1] = 2 * J + 3; hpf[2] = 3 * J + 4; hpc[2] = J + 1; hpf[3] = 4 * J + 5; hpc[3] = L.nV - (4 * J + 5); }
+        else for (int r = 0; r < 4; r++) { hpf[r] = kPartHFirst[r]; hpc[r] = kPartHCount[r]; }
+    }
     GLB_AS unsigned char* xch = nullptr;          // the item's exchange area
     GLB_AS unsigned char* peer_arena = nullptr;   // main block: the helper's arena
     int xch_epoch = 0;
@@ -391,7 +399,7 @@ struct Chain {
     __device__ PairState solo_begin() { PairState st{w.lane2, w.nl, w.half, w.pair}; solo(w); return st; }
     __device__ void solo_end(const PairState& st) { w.lane2 = st.lane2; w.nl = st.nl; w.half = st.half; w.pair = st.pair; }
     __device__ unsigned long long part_mask(int r) const {
-        if (helper) return ((1ull << kPartHCount[r]) - 1ull) << kPartHFirst[r];
+        if (helper) return ((1ull << hpc[r]) - 1ull) << hpf[r];
         return L.nroles == 1 ? ~0ull : L.nroles == kRoles ? ((1ull << kPartCount[r]) - 1ull) << kPartFirst[r] : ((1ull << kPart4Count[r]) - 1ull) << kPart4First[r];
     }
 
@@ -399,7 +407,7 @@ struct Chain {
     __device__ PZ allocV() {
         const unsigned long long part = part_mask(role);
         const int i = __ffsll((long long)(freeV & part)) - 1;
-        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 100 + role; return V(helper ? kPartHFirst[role] : L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
+        if (i < 0) { flag(w, ERR_SLOT_OVERFLOW); if (w.lane == 0) w.lstat[3] = 100 + role; return V(helper ? hpf[role] : L.nroles == 1 ? 0 : L.nroles == kRoles ? kPartFirst[role] : kPart4First[role]); }
         freeV &= ~(1ull << i);
         return V(i);
     }
@@ -1172,6 +1180,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         margin_reset(c.w);
         c.helper = helper_block; c.two_cu = false;
+        c.two_level = cf.two_cu >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu;
+        if (helper_block) c.helper_parts(c.two_level);
         if constexpr (NW == 4) {
             if (cf.two_cu) {
                 c.xch = (GLB_AS unsigned char*)cf.xch + (size_t)it0 * kXchBytes;
@@ -1989,7 +1999,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         // A time step on two CUs (p1_free.inc.h): every item gets a helper block on a CU of its own, which also runs the item's forward kinematics.
         // Block k builds item k, block helper0 + k helps it; helper0 a multiple of 8 puts the two on one XCD (checked on the device, item by item).
         const int helper0 = (n_items + 7) & ~7;
-        const bool two_cu = four && split && !collect && !d_items && cf_two_cu_env && !h->p1_two_cu_off && h->mode == ARMOUR_MODE_ARMOUR && helper0 + n_items <= prop.multiProcessorCount * per_cu;
+        const bool two_cu = four && split && !collect && !d_items && cf_two_cu_env && !h->p1_two_cu_off && h->mode == ARMOUR_MODE_ARMOUR && helper0 + n_items <= prop.multiProcessorCount * per_cu
+                            && h->tune(ARMOUR_OPT_P1_STEP_FREE) && h->tune(ARMOUR_OPT_P1_STEP_AUX3);   // (the choreography it changes is the free-running one with the w_aux recursion on the fourth wave)
         const int waves = two_cu ? helper0 + n_items : std::min(n_items + fk_items, prop.multiProcessorCount * per_cu);
         if ((size_t)waves * L.total > wk->arena_total) {
             if (wk->arena) (void)hipFree(wk->arena);
@@ -2023,7 +2034,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
-        cf.two_cu = two_cu ? 1 : 0; cf.helper0 = helper0;
+        cf.two_cu = two_cu ? cf_two_cu_env : 0; cf.helper0 = helper0;
         if (two_cu) {
             const size_t need = (size_t)n_items * kXchBytes;
             bool clear = false;

@@ -2,7 +2,7 @@
 fresh builds each, the tables compared bit for bit, the device's trace lines (ARMOUR_P1_TRACE) for which shape ran.  GPU box."""
 import os, sys, hashlib
 sys.path.insert(0, os.getcwd())
-os.environ["ARMOUR_P1_TRACE"] = "1"
+if os.environ.get("TWO_CU_TRACE"): os.environ["ARMOUR_P1_TRACE"] = "1"
 import numpy as np
 from armour_amd.planner import ArmourNLP
 from armour_amd.worlds import random_batch, random_k
@@ -16,19 +16,20 @@ def tables(nlp, ks):
                 h.update(b"".join(np.ascontiguousarray(a).tobytes() for a in nlp.pz(which, i, t, b=0)))
     return h.hexdigest()[:16]
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+T = 100
+variants = [[kv for kv in v.split(",") if kv] for v in sys.argv[1:]] or [["123=0"], ["123=1"], ["123=2"], ["123=3"]]
 res = {}
 for seed in (5, 11):
     bp = random_batch(seed, 1, 20); ks = random_k(3, 1)
-    for two in (0, 1, 0, 1):
+    for two in variants + variants:
         nlp = ArmourNLP(T=T)
-        nlp.set_option(123, two)
+        for kv in two: nlp.set_option(int(kv.split('=')[0]), float(kv.split('=')[1]))
         ms = []
-        for _ in range(4):
+        for _ in range(6):
             nlp.set_parameters(bp["q0"], bp["qd0"], bp["qdd0"], bp["q_des"], bp["obstacles"])
             ms.append(nlp.build_ms)
         d = tables(nlp, ks)
-        print("TWO_CU", two, "seed", seed, "build ms", " ".join("%.3f" % m for m in ms), "digest", d, "margin", nlp.prune_margin(), flush=True)
+        print("TWO_CU", two, "seed", seed, "build ms best %.3f |" % min(ms), " ".join("%.3f" % m for m in ms), "digest", d, "margin", nlp.prune_margin(), flush=True)
         res.setdefault(seed, set()).add(d)
         nlp.close()
 print("digests equal:", all(len(v) == 1 for v in res.values()))
