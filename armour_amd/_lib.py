@@ -79,6 +79,8 @@ OPT_P1_TWO_PASS = 106
 OPT_P1_STEP_PAIRS = 107
 OPT_P1_STEP_QUEUE = 109
 OPT_P1_STEP_TAIL_CROSS = 108
+OPT_P1_STEP_TWO_CU = 123     # 3 (default) | 0..2: a lone problem's time step on two compute units (include/armour_hip.h); 10 + level: the fall-back's test hook
+OPT_P1_STEP_LEAN_BACK = 124  # 1 (default) | 0: with level 3, the backward pass's f-recursion on the helper block as well
 OPT_P1_TV_TAIL_CROSS = 121
 OPT_P1_TV_MIN_GROUPS = 110
 OPT_P1_TV_WAVES = 111

@@ -17,7 +17,9 @@
 enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX_JOINTS + 1, T3_F = T3_N + ARMOUR_MAX_JOINTS, T3_C2 = T3_F + ARMOUR_MAX_JOINTS,
        T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS, T3_NA = T3_X2 + ARMOUR_MAX_JOINTS,
        T3_X3 = T3_NA + ARMOUR_MAX_JOINTS,   // w x (w_aux x com) of a late link, built by a wave that is through with its recursion (tail_cross)
-       T3_CNT = T3_X3 + ARMOUR_MAX_JOINTS + 1, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_C3P, T3_U = T3_CNT + 8, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
+       T3_CNT = T3_X3 + ARMOUR_MAX_JOINTS + 1, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_C3P,
+       T3_NB, T3_UB,   // run_backward_lean: joints the n-recursion is through with | joints whose torque sum is built (both counted from the last joint)
+       T3_NCNT = 12, T3_U = T3_CNT + T3_NCNT, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 // LDS mailbox of run_rnea / run_rnea_free, followed by the two walk-helper channels of the time-vectorised four-wave blocks
 // (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
 constexpr int kHelpBase = MB_WORDS > T3_WORDS ? MB_WORDS : T3_WORDS;
@@ -190,9 +192,13 @@ __device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail
 // same XCD: two CUs; different, or no sign of the helper: everything itself, as before -- and publishes the decision for the helper.  Block
 // b's helper is block helper0 + b with helper0 a multiple of 8 (blocks are dealt round-robin to the XCDs: observed, not promised -- hence the check).
 // A take that never sees its flag (cut off after ~0.1 s) raises ERR_HELPER; the host then builds again on one CU per step and keeps the handle there.
-enum { XK_C3L = 0, XK_C3C = 1, XK_CRN = 2, XK_C4 = 3, XK_KINDS = 4 };
+enum { XK_C3L = 0, XK_C3C = 1, XK_CRN = 2, XK_C4 = 3,
+       XK_F = 4,      // main -> helper: F_i, for the f-recursion of the backward pass (run_backward_remote)
+       XK_C2 = 5,     // helper -> main: p x (R f) of joint i
+       XK_MISC = 6,   // flags without a record: [0] main -> helper, the forward pass is over here (every product has been taken); [1] helper -> main, the f-recursion is through (the F_i may go)
+       XK_KINDS = 7 };
 constexpr int kXchSlots = ARMOUR_MAX_JOINTS + 1;
-constexpr size_t kXchFlags = 128, kXchRecs = 384, kXchRecBytes = 128, kXchBytes = 8192;   // control line | flag words | records
+constexpr size_t kXchFlags = 128, kXchRecs = 512, kXchRecBytes = 128, kXchBytes = 12288;   // control line | flag words | records
 static_assert(XK_KINDS * kXchSlots * sizeof(unsigned) <= kXchRecs - kXchFlags && kXchRecs + XK_KINDS * kXchSlots * kXchRecBytes <= kXchBytes, "exchange area");
 __device__ inline unsigned xch_xcc() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return (v & 0xfu) + 1u; }
 __device__ inline void xch_st(GLB_AS unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -222,6 +228,28 @@ __device__ inline bool xch_decide(CH& c, bool helper) {
     return two;
 }
 template <class CH>
+__device__ inline void xch_raise(CH& c, int kind, int idx) {   // a flag alone (this wave's stores drained first)
+    WSYNC();
+    if (w_lane0(c)) xch_st((GLB_AS unsigned*)(c.xch + kXchFlags) + kind * kXchSlots + idx, (unsigned)c.xch_epoch);
+}
+template <class CH>
+__device__ inline bool xch_await(CH& c, int kind, int idx) {
+    LDS_AS int* broken = c.mb + kMbWords - 3;
+    const GLB_AS unsigned* fl = (const GLB_AS unsigned*)(c.xch + kXchFlags) + kind * kXchSlots + idx;
+    const long long tw0 = c.prof_clock();
+    bool ok = t3_ld(broken) == 0;
+    if (ok) {
+        int spins = 0;
+        while (xch_ld(fl) != (unsigned)c.xch_epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 17)) { ok = false; break; }
+        }
+    }
+    c.prof_waited(tw0);
+    if (!ok) { flag(c.wave(), ERR_HELPER); if (w_lane0(c)) *broken = 1; }
+    return ok;
+}
+template <class CH>
 __device__ inline void xch_publish(CH& c, int kind, int idx, const typename CH::PZT& p) {
     auto& w = c.wave();
     WSYNC();   // the product's rows have left this CU
@@ -240,25 +268,9 @@ template <class CH>
 __device__ inline typename CH::PZT xch_take(CH& c, int kind, int idx) {
     typedef typename CH::PZT TPZ;
     auto& w = c.wave();
-    LDS_AS int* broken = c.mb + kMbWords - 3;   // (one lost take: the others of this item do not wait again)
-    const GLB_AS unsigned* fl = (const GLB_AS unsigned*)(c.xch + kXchFlags) + kind * kXchSlots + idx;
-    const long long tw0 = c.prof_clock();
-    bool ok = t3_ld(broken) == 0;
-    if (ok) {
-        int spins = 0;
-        while (xch_ld(fl) != (unsigned)c.xch_epoch) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 17)) { ok = false; break; }
-        }
-    }
-    c.prof_waited(tw0);
+    const bool ok = xch_await(c, kind, idx);   // (one lost take: the others of this item do not wait again)
     TPZ r = c.allocV();
-    if (!ok) {
-        flag(w, ERR_HELPER);
-        if (w.lane == 0) *broken = 1;
-        set_const(w, r, nullptr, nullptr);
-        return r;
-    }
+    if (!ok) { set_const(w, r, nullptr, nullptr); return r; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 holds nothing older than the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GLB_AS unsigned long long* rec = (const GLB_AS unsigned long long*)(c.xch + kXchRecs + (size_t)(kind * kXchSlots + idx) * kXchRecBytes);
@@ -274,6 +286,153 @@ __device__ inline typename CH::PZT xch_take(CH& c, int kind, int idx) {
     WSYNC();
     return r;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// The backward pass with the f-recursion on the HELPER block (round 6; a time step on two CUs, level 3).
+// With two waves on every operator (run_backward_pairs) the pass is as long as the n-recursion -- R n (pair), com x F_i on one half beside
+// p x (R f) on the other, the four-term sum (pair), the 1x1 torque sum on one half: 7 x 107 k cycles -- and the f-recursion's pair (R f,
+// R f + F: 7 x 73 k) cannot take the side products without becoming the slower chain itself (built and measured: the pass 2 % longer,
+// docs/experiments/r06_lean_backward_local.inc.txt).  The helper block's product waves are through before the forward pass ends, so:
+//   * the main block publishes every F_i as the forward pass builds it, and a flag when the pass is over (every product of the helper has
+//     been taken by then: the helper's product waves give their slots back);
+//   * the helper runs the f-recursion on a pair of waves (R f, R f + F_i) and p x (R f) on a third, which publishes it;
+//   * com x F_i is built in the main block's FORWARD pass by its fourth wave (idle there at level 3), all but the last link's;
+//   * the main block's n-pair does R n and the four-term sum, nothing else; its second wave builds the torque sums u_j as the n_j appear
+//     (n_j is posted in the mailbox and given back one step late, after its sum); its third wave waits for the helper's last word, after
+//     which the F_i may be given back.
+// Same operators on the same operands: same bits.
+template <class CH>
+__device__ inline void run_backward_remote(CH& c, typename CH::PZT* u, int n_tail) {
+    typedef typename CH::PZT TPZ;
+    const P1Cfg& cf = *c.cf;
+    auto& w = c.w;
+    const int J = c.J;
+    LDS_AS int* px = c.mb + kHelpBase;
+    LDS_AS int* fvx = px + 2 * pzw::PW_WORDS;
+    if (threadIdx.x < 2 * pzw::PW_WORDS) px[threadIdx.x] = 0;
+    if (c.wid == 0 && w_lane0(c)) { fvx[0] = (int)(unsigned)(c.freeV & 0xffffffffull); fvx[1] = (int)(unsigned)(c.freeV >> 32); }
+    if (c.wid == 0) xch_raise(c, XK_MISC, 0);   // (behind barrier (A): every wave of this block is through with the helper's products)
+    c.bar();   // (A2)
+    if (c.wid == 0 || c.wid == 3) {
+        const unsigned long long saved = c.freeV, pf = c.part_mask(0);
+        if (c.wid == 3) {
+            const unsigned long long fv = (unsigned long long)(unsigned)t3_ld(&fvx[0]) | ((unsigned long long)(unsigned)t3_ld(&fvx[1]) << 32);
+            c.freeV = (c.freeV & ~pf) | (fv & pf);
+        }
+        c.pair_begin(0, px + pzw::PW_WORDS);
+        const bool h0 = w.half == 0;
+        c.role = 0;
+        TPZ nn = c.allocV();
+        if (h0) set_const(w, nn, nullptr, nullptr);
+        psync(w);
+        TPZ pend = nn; int pend_joint = -1;   // n of joint pend_joint: given back once its torque sum is built
+        for (int i = J - 1; i >= 0; i--) {
+            const TPZ Rn = c.R(i + 1), Fi = t3_take(c, T3_F + i), Ni = t3_take(c, T3_N + i);
+            TPZ a1 = c.mulMV(Rn, nn);
+            TPZ c1;
+            const bool own_c1 = i == J - 1;   // (F of the last link ends the forward pass: its product is built here)
+            if (own_c1) {
+                if (h0) c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi); else c1 = c.allocV();
+                psync(w);
+            } else c1 = t3_take(c, T3_X2 + i);
+            TPZ c2 = xch_take(c, XK_C2, i);   // (both halves: the same record into the same slot)
+            psync(w);
+            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c2); if (own_c1) c.freeVs(c1);  // ((N + a1) + c1) + c2
+            if (pend_joint >= 0) {
+                if (cf.rb.axes[pend_joint] != 0) t3_wait(c, T3_UB, J - pend_joint);
+                c.freeVs(pend);
+            }
+            if (i == J - 1) { c.freeVs(nn); pend_joint = -1; } else { pend = nn; pend_joint = i + 1; }
+            nn = n2;
+            if (h0) { t3_post(c, T3_ST + i, n2); t3_signal(c, T3_NB, J - i); }
+        }
+        if (pend_joint >= 0) {
+            if (cf.rb.axes[pend_joint] != 0) t3_wait(c, T3_UB, J - pend_joint);
+            c.freeVs(pend);
+        }
+        t3_wait(c, T3_UB, J);   // every torque sum is built (n_0 is read last)
+        c.freeVs(nn);
+        c.pair_end();
+        if (c.wid == 3) { const unsigned long long own = c.part_mask(3); c.freeV = (c.freeV & own) | (saved & ~own); }
+        c.role = c.wid;
+    } else if (c.wid == 1) {
+        c.role = 1;
+        for (int j = J - 1; j >= 0; j--) {
+            if (cf.rb.axes[j] != 0) {
+                t3_wait(c, T3_NB, J - j);
+                const TPZ nj = t3_take(c, T3_ST + j);
+                const int ax = abs(cf.rb.axes[j]) - 1;
+                u[j] = c.comb3(elem(w, nj, ax), 1.0, view(w, c.qdda(j)), cf.rb.armature[j], view(w, c.qd(j)), cf.rb.damping[j]);
+                if (w_lane0(c)) c.mb[T3_U + j] = u[j].id - c.L.idS;
+            }
+            t3_signal(c, T3_UB, J - j);
+        }
+    } else {
+        (void)xch_await(c, XK_MISC, 1);   // the helper has read the last F_i
+    }
+    c.bar();   // (B) the n-recursion is through, nobody reads N_i, F_i, com x F_i any more
+    if (c.wid == 1) {
+        for (int i = J - n_tail; i < J; i++) c.freeVs(t3_take(c, T3_N + i));
+    } else if (c.wid == 3) {
+        for (int i = 0; i < J - 1; i++) c.freeVs(t3_take(c, T3_X2 + i));
+    } else if (c.wid == 2) {
+        for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
+    }
+}
+// ... and the helper block's side of it: waves 1 + 2 the f-recursion as a pair, wave 0 the cross products p x (R f).  (Wave 3 is in its
+// forward kinematics: no block barrier in here -- the three waves meet through the mailbox.)
+template <class CH>
+__device__ inline void helper_backward(CH& c) {
+    typedef typename CH::PZT TPZ;
+    const P1Cfg& cf = *c.cf;
+    auto& w = c.w;
+    const int J = c.J;
+    LDS_AS int* px = c.mb + kHelpBase;
+    LDS_AS int* fvx = px + 2 * pzw::PW_WORDS;
+    if (c.wid == 3) return;
+    (void)xch_await(c, XK_MISC, 0);          // the main block has taken every product: this wave's part of the pool is free again
+    c.freeV |= c.part_mask(c.wid);
+    if (c.wid == 0) {
+        c.role = 0;
+        for (int i = J - 1; i >= 0; i--) {
+            t3_wait(c, T3_B1, J - i);
+            TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
+            xch_publish(c, XK_C2, i, c2);
+        }
+        return;
+    }
+    // the pair: wave 1 leads (its part of the pool), wave 2 follows
+    if (c.wid == 1) {
+        if (w.lane < 2 * pzw::PW_WORDS) px[w.lane] = 0;
+        if (w.lane == 0) { fvx[2] = (int)(unsigned)(c.freeV & 0xffffffffull); fvx[3] = (int)(unsigned)(c.freeV >> 32); }
+        t3_signal(c, T3_B2, 1);
+    } else {
+        t3_wait(c, T3_B2, 1);
+        const unsigned long long pf = c.part_mask(1);
+        const unsigned long long fv = (unsigned long long)(unsigned)t3_ld(&fvx[2]) | ((unsigned long long)(unsigned)t3_ld(&fvx[3]) << 32);
+        c.freeV = (c.freeV & ~pf) | (fv & pf);
+    }
+    c.pair_begin(1, px);
+    const bool h0 = w.half == 0;
+    c.role = 1;
+    TPZ f = c.allocV();
+    if (h0) set_const(w, f, nullptr, nullptr);
+    psync(w);
+    TPZ Fs[ARMOUR_MAX_JOINTS];
+    for (int i = J - 1; i >= 0; i--) Fs[i] = xch_take(c, XK_F, i);   // (both halves; all of them are there by now: one wait, one invalidate each, off the recursion's chain)
+    psync(w);
+    for (int i = J - 1; i >= 0; i--) {
+        const TPZ Rn = c.R(i + 1);
+        const TPZ Fi = Fs[i];
+        TPZ a2 = c.mulMV(Rn, f);
+        if (h0) { t3_post(c, T3_A2 + i, a2); t3_signal(c, T3_B1, J - i); }
+        TPZ f2 = c.add(a2, Fi); c.freeVs(f); c.freeVs(Fi);
+        f = f2;
+    }
+    c.freeVs(f);
+    if (h0) xch_raise(c, XK_MISC, 1);
+    c.pair_end();
+    c.role = c.wid;
+}
 // The helper block's item: the two velocity recursions and the forward kinematics on wave 3, one family of products on each of the others.
 template <class CH>
 __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publish) {
@@ -282,7 +441,7 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
     const P1Cfg& cf = *c.cf;
     auto& w = c.w;
     const int J = c.J;
-    if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
+    if (threadIdx.x < T3_NCNT) c.mb[T3_CNT + threadIdx.x] = 0;
     if (c.wid == 3) {
         c.role = 3;
         TPZ wv = c.allocV(); set_const(w, wv, nullptr, nullptr); t3_post(c, T3_ST + 0, wv);
@@ -351,6 +510,7 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
         }
     }
     c.prof_forward_done();
+    if (publish && c.two_level >= 3 && cf.step_pairs != 0 && cf.lean_back != 0) helper_backward(c);
     c.bar();
 }
 
@@ -392,6 +552,8 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     if constexpr (CH::kTwoCu) { two = c.two_cu; two_lvl = two ? c.two_level : 0; }
     const bool two2 = two_lvl >= 2;   // nobody in this block reads w: no w recursion here; the linear-acceleration wave takes wdot x p itself
     const bool two3 = two_lvl >= 3;   // ... nor w_aux: the angular step's cross product comes from the helper too, the fourth wave has no recursion left
+    bool lean_back = false;           // run_backward_remote: level 3 with paired waves -- the f-recursion of the backward pass on the helper block (the fourth wave builds com x F_i in this pass)
+    if constexpr (CH::kPairs) lean_back = two3 && cf.step_pairs != 0 && cf.lean_back != 0;
     auto take_x = [&](int kind, int idx) -> TPZ { if constexpr (CH::kTwoCu) return xch_take(c, kind, idx); else return TPZ(); };
     const int tc_opt = two ? 0 : cf.tail_cross % 100;
     const int tc_wave = fk_wave && aux3 && tc_opt > 0 ? (tc_opt >= 10 ? 1 : 3) : -1;
@@ -407,7 +569,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
     };
     auto tail_cross_free = [&]() { for (int s = J - tc_links + 1; s <= J; s++) c.freeVs(t3_take(c, T3_X3 + s)); };
-    if (threadIdx.x < 8) c.mb[T3_CNT + threadIdx.x] = 0;
+    if (threadIdx.x < T3_NCNT) c.mb[T3_CNT + threadIdx.x] = 0;
     // walk helpers (four-wave blocks of the time-vectorised kernel, backward pass): both channels start empty, every wave's job count at 0
     bool walk_helpers = CH::kWalkHelpers && fk_wave && cf.tv_walk_helpers != 0;
     if constexpr (CH::kWalkHelpers) {
@@ -567,13 +729,24 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         } else {
             c.freeVs(t3_take(c, T3_ST + 2));
             if constexpr (!fused_cross) {
+                int pc = 0;   // (lean backward pass) com x F_i, i < pc, are built
+                auto com_cross = [&](bool all) {
+                    while (lean_back && pc < J - 1) {
+                        if (t3_ld(&c.mb[T3_CC2]) < pc + 1) { if (!all) return; t3_wait(c, T3_CC2, pc + 1); }
+                        TPZ c1 = c.crossMatPz(&cf.rb.com[3 * pc], t3_take(c, T3_F + pc));
+                        t3_post(c, T3_X2 + pc, c1);
+                        pc++;
+                    }
+                };
                 for (int s = 0; s < J; s++) {   // wdot x p for the linear-acceleration step s
                     if (s >= 2) { t3_wait(c, T3_C0, s - 1); c.freeVs(t3_take(c, T3_X1 + s - 2)); }
+                    while (t3_ld(&c.mb[T3_C1]) < s) { com_cross(false); __builtin_amdgcn_s_sleep(8); }
                     t3_wait(c, T3_C1, s);
                     TPZ x1 = c.crossPzMat(t3_take(c, T3_ST + 3 * s + 1), &cf.rb.trans[3 * s]);
                     t3_post(c, T3_X1 + s, x1);
                     t3_signal(c, T3_C3, s + 1);
                 }
+                com_cross(true);
             }
             c.prof_forward_done(); c.bar();   // (A)
             if constexpr (!fused_cross) for (int s = J >= 2 ? J - 2 : 0; s < J; s++) c.freeVs(t3_take(c, T3_X1 + s));
@@ -670,6 +843,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                     if (!from_tail) c.freeVs(c3);
                     TPZ F = c.mulSV(c.mass(s - 1), s2); c.freeVs(s2);
                     t3_post(c, T3_F + s - 1, F);
+                    if constexpr (CH::kTwoCu) { if (lean_back) xch_publish(c, XK_F, s - 1, F); }   // (the helper's f-recursion reads it where it lies)
                 }
                 t3_signal(c, T3_CC2, s);
             }
@@ -683,7 +857,11 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     // n-recursion needs is a side product of it and goes to a wave that has nothing to do in this pass (wave 3, or wave 2).
     const int helper = fk_wave ? 3 : 2;
     if constexpr (CH::kPairs) {
-        if (fk_wave && cf.step_pairs != 0) { run_backward_pairs(c, u, n_tail); return; }
+        if (fk_wave && cf.step_pairs != 0) {
+            if constexpr (CH::kTwoCu) { if (lean_back) { run_backward_remote(c, u, n_tail); return; } }
+            run_backward_pairs(c, u, n_tail);
+            return;
+        }
     }
     if (c.wid == 1) {
         c.role = 1;

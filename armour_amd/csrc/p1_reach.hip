@@ -104,6 +104,7 @@ struct P1Cfg {
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
     // a time step on two CUs (p1_free.inc.h): block b < n_items builds item b, block helper0 + b is its helper; xch: kXchBytes per item
     int two_cu, helper0, xch_epoch;
+    int lean_back;        // two CUs, level 3: the backward pass with the n-recursion stripped to its chain (p1_free.inc.h run_backward_remote); development switch
     unsigned char* xch;
 };
 
@@ -1180,13 +1181,13 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         margin_reset(c.w);
         c.helper = helper_block; c.two_cu = false;
-        c.two_level = cf.two_cu >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu;
+        c.two_level = (cf.two_cu % 10) >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu % 10;   // (cf.two_cu >= 10: the test of the fall-back -- the helper says yes and hands over nothing)
         if (helper_block) c.helper_parts(c.two_level);
         if constexpr (NW == 4) {
             if (cf.two_cu) {
                 c.xch = (GLB_AS unsigned char*)cf.xch + (size_t)it0 * kXchBytes;
                 c.xch_epoch = cf.xch_epoch;
-                c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(cf.helper0 + it0) * cf.arena_bytes;
+                c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(helper_block ? it0 : cf.helper0 + it0) * cf.arena_bytes;   // (the other block of the item)
                 xch_hello(c, helper_block);
                 if (threadIdx.x == 0) c.mb[kMbWords - 3] = 0;   // (xch_take: no take of this item has been lost)
             }
@@ -1198,15 +1199,21 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #endif
         build_jrs(c, b, t, fk_only, helper_block);
         __syncthreads();
+#if defined(P1_STAMPS)
+        const long long ph_jrs = clock64();
+#endif
         if constexpr (NW == 4) {
             if (cf.two_cu) c.two_cu = xch_decide(c, helper_block);   // same XCD as the other block of the item, and both alive: two CUs; otherwise this block does everything (the helper: the forward kinematics alone)
         }
+#if defined(P1_STAMPS)
+        if (c.w.lane == 0 && t == cf.T - 1 && !fk_only) printf("[t=%d %swave %d] JRS done at %lld, two-CU decision at %lld\n", t, helper_block ? "helper " : "", c.wid, ph_jrs - ph0, (long long)clock64() - ph0);
+#endif
 #ifdef P1_PROFILE
         const long long ph1 = clock64();
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
         if (helper_block) {
-            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu);
+            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu && cf.two_cu < 10);
         } else if (fk_only) {
             // forward kinematics and the link tables, nothing else: the whole ARMTD chain (CMP/armtd_main.cu:141-156), or
             // the forward-kinematics half of a split ARMOUR item.  A single role: one wave works.
@@ -2035,6 +2042,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         cf.two_cu = two_cu ? cf_two_cu_env : 0; cf.helper0 = helper0;
+        cf.lean_back = h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK);
         if (two_cu) {
             const size_t need = (size_t)n_items * kXchBytes;
             bool clear = false;

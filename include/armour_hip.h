@@ -124,7 +124,13 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_STEP_TAIL_CROSS 108     /* 0 off | n | 10 + n: four-wave blocks of a lone problem, w x (w_aux x com) of the last n <= 4 links built by the fourth (n) / the angular (10 + n) wave once its recursion is through */
 #define ARMOUR_OPT_P1_STEP_QUEUE 109          /* 1 (default): the blocks draw their items from a counter, every problem's late time steps first | 2, 3: in index order, early steps first | 0: block k builds items k, k + blocks, ... */
 #define ARMOUR_OPT_P1_STEP_PAIRS 107          /* 1 (default) | 0 | 2: four-wave blocks, backward pass -- the two idle waves join the recursion waves' operators (1: when every item has a block of its own; 2: always) */
-#define ARMOUR_OPT_P1_STEP_TWO_CU 123         /* 1 (default) | 0: a lone problem's time step on TWO compute units -- a helper block per (problem, time step) builds the cross products that read only the angular-velocity recursions (and the step's forward kinematics) and hands them over through the L2 of the XCD the two share; taken when 2 T + 7 blocks fit the device, same tables bit for bit */
+#define ARMOUR_OPT_P1_STEP_TWO_CU 123         /* 3 (default) | 0 | 1 | 2: a lone problem's time step on TWO compute units -- a helper block per (problem, time step) reruns the two
+                                                 angular-velocity recursions, builds the cross products that read nothing else (w x (w_aux x p), w x (w_aux x com), w_aux x (I w); level 3,
+                                                 chains of at most 7 joints: R_t w_aux x (qd e) as well) and the step's forward kinematics, and hands the products over through the L2 of the
+                                                 XCD the two blocks share (checked per item; otherwise, and whenever 2 T + 7 blocks do not fit the device, one CU per step as before).
+                                                 Level 2: the main block drops its own w recursion; level 3: its w_aux recursion too.  Same tables bit for bit at every level.
+                                                 10 + level: a test hook -- the helper agrees and hands over nothing, the build must notice and start again on one CU per step */
+#define ARMOUR_OPT_P1_STEP_LEAN_BACK 124      /* 1 (default) | 0: with a time step on two CUs at level 3, the helper block also runs the backward pass's f-recursion (F_i handed over as the forward pass builds them, p x (R f) handed back), the main block's pair keeps R n and the four-term sum alone */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */
 #define ARMOUR_OPT_P1_TV_MIN_GROUPS 110       /* default 31: automatic choice of ARMOUR_OPT_P1_BUILD takes this kernel from B*T >= 50 * value on */
 #define ARMOUR_OPT_P1_TV_WAVES 111            /* 0 automatic (default) | 1 | 3 | 4 | 8 wavefronts per block (r: 4 and 8 share walks between waves) */
