@@ -18,7 +18,8 @@ enum { T3_ST = 0, T3_LA = 3 * (ARMOUR_MAX_JOINTS + 1), T3_N = T3_LA + ARMOUR_MAX
        T3_A2 = T3_C2 + ARMOUR_MAX_JOINTS, T3_X1 = T3_A2 + ARMOUR_MAX_JOINTS, T3_X2 = T3_X1 + ARMOUR_MAX_JOINTS, T3_NA = T3_X2 + ARMOUR_MAX_JOINTS,
        T3_X3 = T3_NA + ARMOUR_MAX_JOINTS,   // w x (w_aux x com) of a late link, built by a wave that is through with its recursion (tail_cross)
        T3_CNT = T3_X3 + ARMOUR_MAX_JOINTS + 1, T3_C1 = T3_CNT, T3_C0, T3_CC2, T3_B1, T3_B2, T3_CA, T3_C3, T3_C3P,
-       T3_NB, T3_UB,   // run_backward_lean: joints the n-recursion is through with | joints whose torque sum is built (both counted from the last joint)
+       T3_JR2,         // two CUs, level 3: the joints past the fourth have their JRS (jrs_late_joints)
+       T3_NB, T3_UB,   // run_backward_remote: joints the n-recursion is through with | joints whose torque sum is built (both counted from the last joint)
        T3_NCNT = 12, T3_U = T3_CNT + T3_NCNT, T3_WORDS = T3_U + ARMOUR_MAX_FACTORS };   // T3_U: the 1x1 slots of u_nom, for the waves that share the torque tables
 // LDS mailbox of run_rnea / run_rnea_free, followed by the two walk-helper channels of the time-vectorised four-wave blocks
 // (pz_tv.h "One walk on two waves": channel 0 = f-recursion wave -> wave 2, channel 1 = n-recursion wave -> wave 3)
@@ -454,6 +455,7 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
         if (publish) {
             int freed_na = 0;   // (c4h) R_t w_aux_k, k < freed_na, have been given back
             for (int s = 0; s < J; s++) {   // w_{s+1} = R_t w_s + qd_s, w_aux_{s+1} = R_t w_aux_s + qda_s: as the main block's fourth wave runs them (run_rnea_free)
+                if (c.late_jrs && s == 4) t3_wait(c, T3_JR2, 1);
                 const int ax = abs(cf.rb.axes[s]) - 1;
                 while (c4h && freed_na + 3 < s) {   // at most four of them alive: read by the second product wave at its step k
                     t3_wait(c, T3_C1, freed_na + 1);
@@ -474,14 +476,17 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
                 for (; freed_na < J; freed_na++) { t3_wait(c, T3_C1, freed_na + 1); if (cf.rb.axes[freed_na] != 0) c.freeVs(t3_take(c, T3_NA + freed_na)); }
             }
         }
+        if (c.late_jrs) t3_wait(c, T3_JR2, 1);   // (a chain of four joints or fewer never waited above)
         FkStateT<TPZ> fk;
         fk_begin(c, fk);
         for (int s = 0; s < J; s++) fk_step(c, fk, s, b, t_lane);
         c.freeVs(fk.T);
     } else if (publish) {
         c.role = c.wid;
+        if (c.late_jrs && c.wid == 2) { jrs_late_joints(c, c.jl, 4, true); t3_signal(c, T3_JR2, 1); }   // (this wave's products read no JRS slot, and the main block takes them last)
         const int s0 = c.wid == 0 ? 0 : 1, s1 = c.wid == 0 ? J - 1 : J;
         for (int s = s0; s <= s1; s++) {
+            if (c.late_jrs && c.wid == 1 && s == 4) t3_wait(c, T3_JR2, 1);   // (qd_4 for the angular product, I_4 for the moment's)
             if (c4h && c.wid == 1) {   // the angular step s - 1 of the main block waits for this one: before the moment's product of link s - 1
                 const int q = s - 1;
                 t3_wait(c, T3_C3, q + 1);
@@ -552,6 +557,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
     if constexpr (CH::kTwoCu) { two = c.two_cu; two_lvl = two ? c.two_level : 0; }
     const bool two2 = two_lvl >= 2;   // nobody in this block reads w: no w recursion here; the linear-acceleration wave takes wdot x p itself
     const bool two3 = two_lvl >= 3;   // ... nor w_aux: the angular step's cross product comes from the helper too, the fourth wave has no recursion left
+    bool late_jrs = false;            // the JRS of joints 4 .. J - 1 is built by the fourth wave while the others run their first steps: they wait for it before step 4
+    if constexpr (CH::kTwoCu) late_jrs = two3 && c.late_jrs;
+    auto jrs_ready = [&](int s) { if (late_jrs && s == 4) t3_wait(c, T3_JR2, 1); };
     bool lean_back = false;           // run_backward_remote: level 3 with paired waves -- the f-recursion of the backward pass on the helper block (the fourth wave builds com x F_i in this pass)
     if constexpr (CH::kPairs) lean_back = two3 && cf.step_pairs != 0 && cf.lean_back != 0;
     auto take_x = [&](int kind, int idx) -> TPZ { if constexpr (CH::kTwoCu) return xch_take(c, kind, idx); else return TPZ(); };
@@ -632,6 +640,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
                 freed++;
             }
             if (wave_w == 1) omega_step(s, freed_w1);
+            jrs_ready(s);
             const TPZ wdot = t3_take(c, T3_ST + 3 * s + 1);
             const TPZ Rt = c.Rt(s);
             const int ax = abs(cf.rb.axes[s]) - 1;
@@ -674,6 +683,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         c.role = 0;
         int freed = 0;
         for (int s = 0; s < J; s++) {
+            jrs_ready(s);
             t3_wait(c, T3_C1, s);   // state_s
             if (!two2) t3_wait(c, T3_CA, s);
             while (freed + K < s + 1) {   // lacc_k: read by wave 2 at step k (>= 1), by this wave at step k (done)
@@ -728,6 +738,9 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             for (int k = freed_na; k < J; k++) if (cf.rb.axes[k] != 0) c.freeVs(t3_take(c, T3_NA + k));
         } else {
             c.freeVs(t3_take(c, T3_ST + 2));
+            if constexpr (CH::kTwoCu) {
+                if (late_jrs) { jrs_late_joints(c, c.jl, 4, false); t3_signal(c, T3_JR2, 1); }
+            }
             if constexpr (!fused_cross) {
                 int pc = 0;   // (lean backward pass) com x F_i, i < pc, are built
                 auto com_cross = [&](bool all) {
@@ -813,6 +826,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         for (int s = 0; s <= J; s++) {
             if (s < J && wave_w == 2) omega_step(s, freed_w);   // (first: wave 0 waits for it)
             if (s < J && with_fk) fk_step(c, fk, s, b, t_lane);   // (it waits for nobody)
+            jrs_ready(s);
             if (s >= 1) {
                 t3_wait(c, T3_C1, s);
                 if (!two2) t3_wait(c, T3_CA, s);

@@ -104,6 +104,7 @@ struct P1Cfg {
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
     // a time step on two CUs (p1_free.inc.h): block b < n_items builds item b, block helper0 + b is its helper; xch: kXchBytes per item
     int two_cu, helper0, xch_epoch;
+    int late_jrs;         // two CUs, level 3: the JRS of joints 4 .. J - 1 behind the start of the roles (development switch)
     int lean_back;        // two CUs, level 3: the backward pass with the n-recursion stripped to its chain (p1_free.inc.h run_backward_remote); development switch
     unsigned char* xch;
 };
@@ -221,6 +222,7 @@ struct JrsScalars {
     double cos_c, cos_k, cos_e, sin_c, sin_k, sin_e;          // centre, k coefficient, error coefficient
     double qd_c, qd_k, qd_e, qda_e, qdd_c, qdd_k, qdd_e;
 };
+struct JrsLane { double rp[9]; JrsScalars js; };   // lane i: the fixed rotation and the scalars of joint i (jrs_lane)
 
 __device__ PZW_NOINLINE JrsScalars jrs_scalars(const P1Cfg& cf, double q0, double a, double b, int i, int s_ind) {
     PZ_KEEP_RETURN_ADDRESS();
@@ -317,6 +319,8 @@ struct Chain {
     static constexpr bool kPairs = true;          // run_rnea_free: two waves per operator in the backward pass of a four-wave block
     static constexpr bool kTwoCu = true;          // a time step on two CUs (p1_free.inc.h)
     bool helper = false, two_cu = false;          // this block is the helper of its item | this item runs on two CUs (decided per item: xch_decide)
+    JrsLane jl;                                   // (late_jrs) this wave's copy of the per-lane JRS scalars, for the joints built after the roles have begun
+    bool late_jrs = false;                        // two CUs, level 3: joints 4 .. J - 1 are built by one wave of the block while the recursions run their first steps (jrs_late_joints)
     int two_level = 0;                            // 1: the three families of velocity-only products | 2: + the main block drops its own w recursion and the fourth wave's cross products | 3: + the angular step's cross product from the helper, no velocity recursion left in the main block
     int hpf[4] = {0, 10, 20, 30}, hpc[4] = {10, 10, 10, 33};   // the helper block's pool parts
     __device__ void helper_parts(int lvl) {
@@ -692,68 +696,92 @@ __device__ inline void jrs_mass_inertia_direct(Chain& c, int i) {
 // read is not built: a chain that stops at the forward kinematics has no velocity polynomials, an RNEA item whose forward kinematics runs
 // as an item of its own no link boxes.
 // The caller follows with a block barrier.
-__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only, bool with_boxes = false) {
+// the per-lane half of it: lane i holds the scalars of joint i (the other lanes shadow the last joint)
+__device__ PZW_NOINLINE JrsLane jrs_lane(Chain& c, int b, int t) {
     PZ_KEEP_RETURN_ADDRESS();
     const P1Cfg& cf = *c.cf;
     const int n = c.n, J = c.J;
     const double* bz = cf.bez + (size_t)b * 3 * n;
-    const bool boxes = kin_only || cf.fk_items == 0 || with_boxes;   // (with_boxes: the helper block of a time step on two CUs -- velocity polynomials for its recursions AND link boxes for the forward kinematics)
     // The scalar work of a joint -- the trigonometry of its fixed rotation (14 k cycles) and jrs_scalars (19 k) -- is the same in all 64 lanes
     // of the per-step wave: lane i does it for joint i instead, all of this wave's joints at once, and the joint loop below reads lane i's
     // results.  Same functions on the same arguments: same bits.
     const int lane = c.w.lane;
     const int il = lane < J ? lane : J - 1;   // (the other lanes shadow the last joint)
     const bool il_actuated = il < n && cf.rb.axes[il] != 0;
-    double rp_l[9];
-    rpy_matrix(cf.rb.rots[3 * il], cf.rb.rots[3 * il + 1], cf.rb.rots[3 * il + 2], rp_l);
-    JrsScalars js_l;
-    {
-        const int ia = il_actuated ? il : 0;   // (a lane without an actuated joint of its own computes joint 0's: never read)
-        if (cf.mode == ARMOUR_MODE_ARMTD) js_l = armtd_jrs_scalars(cf, bz[ia], b, ia, t);
-        else js_l = jrs_scalars(cf, bz[ia], bz[n + ia], bz[2 * n + ia], ia, t);
-    }
+    JrsLane o;
+    rpy_matrix(cf.rb.rots[3 * il], cf.rb.rots[3 * il + 1], cf.rb.rots[3 * il + 2], o.rp);
+    const int ia = il_actuated ? il : 0;   // (a lane without an actuated joint of its own computes joint 0's: never read)
+    if (cf.mode == ARMOUR_MODE_ARMTD) o.js = armtd_jrs_scalars(cf, bz[ia], b, ia, t);
+    else o.js = jrs_scalars(cf, bz[ia], bz[n + ia], bz[2 * n + ia], ia, t);
+    return o;
+}
+// joint i from lane i's scalars, by the calling wave (with the scratch slots of the role it is in)
+__device__ PZW_NOINLINE void jrs_joint(Chain& c, const JrsLane& jl, int i, bool kin_only, bool boxes) {
+    PZ_KEEP_RETURN_ADDRESS();
+    const P1Cfg& cf = *c.cf;
+    const int n = c.n;
     auto bcast = [&](double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
-    for (int i = 0; i < J; i++) {
+    const bool actuated = i < n && cf.rb.axes[i] != 0;
+    JrsScalars js;
+    const pzkey_t kk = pzkey_bit(2 * i);
+    js.cos_c = bcast(jl.js.cos_c, i); js.cos_k = bcast(jl.js.cos_k, i); js.cos_e = bcast(jl.js.cos_e, i);
+    js.sin_c = bcast(jl.js.sin_c, i); js.sin_k = bcast(jl.js.sin_k, i); js.sin_e = bcast(jl.js.sin_e, i);
+    js.qd_c = bcast(jl.js.qd_c, i); js.qd_k = bcast(jl.js.qd_k, i); js.qd_e = bcast(jl.js.qd_e, i); js.qda_e = bcast(jl.js.qda_e, i);
+    js.qdd_c = bcast(jl.js.qdd_c, i); js.qdd_k = bcast(jl.js.qdd_k, i); js.qdd_e = bcast(jl.js.qdd_e, i);
+    {
+        double rp[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) rp[e] = bcast(jl.rp[e], i);
+        if (actuated) {
+            jrs_rotation_direct(c, i, js, rp);   // R_i and its transpose (:129-134)
+        } else {
+            set_const(c.w, c.R(i), rp, nullptr);
+            transpose33(c.w, c.Rt(i), c.R(i));
+        }
+        set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
+    }
+    if (!kin_only) {
+        // qd_des, qda_des, qdda_des (:176-243)
+        if (actuated) {
+            jrs_scalar_direct(c, c.qd(i), js.qd_c, kk, js.qd_k, pzkey_bit(2 * n + i), js.qd_e);
+            jrs_scalar_direct(c, c.qda(i), js.qd_c, kk, js.qd_k, pzkey_bit(3 * n + i), js.qda_e);
+            jrs_scalar_direct(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, pzkey_bit(4 * n + i), js.qdd_e);
+        }
+        jrs_mass_inertia_direct(c, i);   // radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
+    }
+    if (boxes) {
+        jrs_linkbox_direct(c, i);   // three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
+    }
+}
+// (i_end < J, `keep`: a time step on two CUs at level 3 -- the first joints here, one per wave, the others by ONE wave that has time to spare
+//  once the roles have begun: jrs_late_joints; the recursions start a round of joints earlier)
+__device__ PZW_NOINLINE void build_jrs(Chain& c, int b, int t, bool kin_only, bool with_boxes = false, int i_end = ARMOUR_MAX_JOINTS, JrsLane* keep = nullptr) {
+    PZ_KEEP_RETURN_ADDRESS();
+    const P1Cfg& cf = *c.cf;
+    const int J = c.J;
+    const bool boxes = kin_only || cf.fk_items == 0 || with_boxes;   // (with_boxes: the helper block of a time step on two CUs -- velocity polynomials for its recursions AND link boxes for the forward kinematics)
+    const JrsLane jl = jrs_lane(c, b, t);
+    c.prof_signal(10200, 0);   // (-DP1_STAMPS: the scalars are done)
+    for (int i = 0; i < J && i < i_end; i++) {
         const int role = c.nw == 1 ? 0 : i % c.nw;   // the wave that builds joint i, with its own scratch slots
         if (!c.is(role)) continue;
-        const bool actuated = i < n && cf.rb.axes[i] != 0;
-        JrsScalars js;
-        const pzkey_t kk = pzkey_bit(2 * i);
-        js.cos_c = bcast(js_l.cos_c, i); js.cos_k = bcast(js_l.cos_k, i); js.cos_e = bcast(js_l.cos_e, i);
-        js.sin_c = bcast(js_l.sin_c, i); js.sin_k = bcast(js_l.sin_k, i); js.sin_e = bcast(js_l.sin_e, i);
-        js.qd_c = bcast(js_l.qd_c, i); js.qd_k = bcast(js_l.qd_k, i); js.qd_e = bcast(js_l.qd_e, i); js.qda_e = bcast(js_l.qda_e, i);
-        js.qdd_c = bcast(js_l.qdd_c, i); js.qdd_k = bcast(js_l.qdd_k, i); js.qdd_e = bcast(js_l.qdd_e, i);
-        {
-            double rp[9];
-#pragma unroll
-            for (int e = 0; e < 9; e++) rp[e] = bcast(rp_l[e], i);
-            if (actuated) {
-                jrs_rotation_direct(c, i, js, rp);   // R_i and its transpose (:129-134)
-            } else {
-                set_const(c.w, c.R(i), rp, nullptr);
-                transpose33(c.w, c.Rt(i), c.R(i));
-            }
-            set_const(c.w, c.Ptr(i), &cf.rb.trans[3 * i], nullptr);
-        }
-        if (!kin_only) {
-            // qd_des, qda_des, qdda_des (:176-243)
-            if (actuated) {
-                jrs_scalar_direct(c, c.qd(i), js.qd_c, kk, js.qd_k, pzkey_bit(2 * n + i), js.qd_e);
-                jrs_scalar_direct(c, c.qda(i), js.qd_c, kk, js.qd_k, pzkey_bit(3 * n + i), js.qda_e);
-                jrs_scalar_direct(c, c.qdda(i), js.qdd_c, kk, js.qdd_k, pzkey_bit(4 * n + i), js.qdd_e);
-            }
-            jrs_mass_inertia_direct(c, i);   // radius 0 for the nominal pass, uncertainty * |centre| for the interval pass (RT/Dynamics.cu:27-40)
-        }
-        if (boxes) {
-            jrs_linkbox_direct(c, i);   // three 1x1 PZs with pseudo-variables at key fields n, 2n, 3n, stacked (RT/Dynamics.cu:49-61)
-        }
+        jrs_joint(c, jl, i, kin_only, boxes);
     }
     WSYNC();   // lane 0's slot writes are visible to the wave (the caller's block barrier does the same for the block)
+    c.prof_signal(10202, 0);   // (the joints are done)
     if (c.is(0)) {
         double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // R(NUM_JOINTS) = PZsparse(0,0,0) (:253)
         set_const(c.w, c.R(J), id, nullptr);
         set_const(c.w, c.Ptr(J), &cf.rb.trans[3 * J], nullptr);
     }
+    if (keep) *keep = jl;
+}
+// the joints build_jrs left out, on the calling wave alone
+__device__ PZW_NOINLINE void jrs_late_joints(Chain& c, const JrsLane& jl, int i_begin, bool with_boxes) {
+    PZ_KEEP_RETURN_ADDRESS();
+    const bool boxes = c.cf->fk_items == 0 || with_boxes;
+    for (int i = i_begin; i < c.J; i++) jrs_joint(c, jl, i, false, boxes);
+    WSYNC();
 }
 
 // RT/PZsparse.cu:370-402 reduce_link_PZ + write of the final link table entry
@@ -1197,7 +1225,9 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         const long long ph0 = clock64();
         c.ph_item = ph0; c.n_log = 0;
 #endif
-        build_jrs(c, b, t, fk_only, helper_block);
+        bool late = false;   // a round of joints later: see Chain::late_jrs
+        if constexpr (NW == 4) late = cf.two_cu != 0 && c.two_level >= 3 && cf.late_jrs != 0 && c.J > NW && !fk_only;
+        build_jrs(c, b, t, fk_only, helper_block, late ? NW : ARMOUR_MAX_JOINTS, late ? &c.jl : nullptr);
         __syncthreads();
 #if defined(P1_STAMPS)
         const long long ph_jrs = clock64();
@@ -1208,6 +1238,12 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #if defined(P1_STAMPS)
         if (c.w.lane == 0 && t == cf.T - 1 && !fk_only) printf("[t=%d %swave %d] JRS done at %lld, two-CU decision at %lld\n", t, helper_block ? "helper " : "", c.wid, ph_jrs - ph0, (long long)clock64() - ph0);
 #endif
+        c.late_jrs = late && c.two_cu;
+        if (late && !c.two_cu) {   // (no helper after all: the other joints the way build_jrs deals them)
+            for (int i = NW; i < c.J; i++) if (c.wid == i % NW) jrs_joint(c, c.jl, i, false, cf.fk_items == 0 || helper_block);
+            WSYNC();
+            __syncthreads();
+        }
 #ifdef P1_PROFILE
         const long long ph1 = clock64();
 #endif
@@ -2042,7 +2078,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
         cf.two_cu = two_cu ? cf_two_cu_env : 0; cf.helper0 = helper0;
-        cf.lean_back = h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK);
+        cf.lean_back = h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 1; cf.late_jrs = (h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 2) == 0;   // (development: + 2 builds every joint before the roles begin)
         if (two_cu) {
             const size_t need = (size_t)n_items * kXchBytes;
             bool clear = false;

@@ -19,11 +19,12 @@ def _opts(level, lean=1, **kw):
     return {**_shape(build=1, **kw), _lib.OPT_P1_STEP_TWO_CU: level, _lib.OPT_P1_STEP_LEAN_BACK: lean}
 
 
-@pytest.mark.parametrize("T", [100, 120, 40])
+@pytest.mark.parametrize("T", [100, 128, 40])
 def test_every_level_leaves_the_tables_of_the_one_cu_build(T):
     ref, ex0, rad0, info0 = _tables_digest(1, _opts(0), T=T)
     assert info0 == {"kernel": "per_step", "waves": 4, "sort_entries": info0["sort_entries"], "launches": 1}
-    for level, lean, kw in [(1, 1, {}), (2, 1, {}), (3, 0, {}), (3, 1, {}), (3, 1, dict(step_pairs=0)), (3, 1, dict(step_tail_cross=300)), (2, 1, dict(step_pairs=0))]:
+    # (lean: bit 0 the f-recursion on the helper, bit 1 set = every joint's JRS before the roles begin; T = 128: 2 T = 256 blocks, the whole device)
+    for level, lean, kw in [(1, 1, {}), (2, 1, {}), (3, 0, {}), (3, 1, {}), (3, 2, {}), (3, 3, {}), (3, 1, dict(step_pairs=0)), (3, 1, dict(step_tail_cross=300)), (2, 1, dict(step_pairs=0))]:
         d, ex, rad, info = _tables_digest(1, _opts(level, lean, **kw), T=T)
         assert info["launches"] == 1 and info["waves"] == 4, (level, lean, kw, info)   # (no fall-back: the helper delivered)
         assert np.array_equal(ex, ex0) and np.array_equal(rad, rad0) and d == ref, (T, level, lean, kw)
