@@ -131,8 +131,8 @@ struct ArmourPlanner {
     double* d_jrs = nullptr;        // ARMTD mode: [B][n][6][T] c/g/r of cos, then of sin (the order of armtd.in)
     size_t jrs_cap = 0;
     // page-locked host scratch of armour_solve (k, g, jac mirrors), grown on demand and kept across solves
-    void* solve_pin[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows; [6] k and [7] records of armour_eval_violations; [8] the reach-set build's read-back
-    size_t solve_pin_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void* solve_pin[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // k, g, jac mirrors; violation sums, row counts, compact rows; [6] k and [7] records of armour_eval_violations; [8] the reach-set build's read-back, [9] its status words
+    size_t solve_pin_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool stats_fresh = false;       // armour_p1_build has read the table statistics back itself (armour_refresh_table_stats has nothing to do)
     int opt_p1_build = 0;           // ARMOUR_OPT_P1_BUILD: 0 automatic, 1 per time step, 2 time-vectorised
     double opt_p1_work_mb = 0;      // ARMOUR_OPT_P1_WORK_MEMORY_MB: cap on the time-vectorised build's arena, MiB (0: none)

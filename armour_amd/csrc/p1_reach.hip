@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 #include "common.h"
@@ -1801,7 +1802,7 @@ struct P1Work {
     unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
     unsigned long long* d_margin = nullptr; size_t margin_cap = 0;   // [B]: the prune margin word of every problem (P1Cfg::margin)
     unsigned char* d_xch = nullptr; size_t xch_cap = 0; int xch_epoch = 0;   // a time step on two CUs: kXchBytes per item, flags tagged with the launch's epoch (cleared when allocated and when the epoch wraps)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // around the reach-set kernel | around the half-space kernels
 };
 
 #endif  // P1_TV_VARIANT
@@ -1862,6 +1863,8 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_retry) (void)hipFree(wk->d_retry);
     if (wk->ev0) (void)hipEventDestroy(wk->ev0);
     if (wk->ev1) (void)hipEventDestroy(wk->ev1);
+    if (wk->ev2) (void)hipEventDestroy(wk->ev2);
+    if (wk->ev3) (void)hipEventDestroy(wk->ev3);
     delete wk;
     h->p1 = nullptr;
 }
@@ -1973,6 +1976,8 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipMalloc((void**)&nw->d_status, (ST_WORDS + 64) * sizeof(unsigned)));
         HIPCHK(hipEventCreate(&nw->ev0));
         HIPCHK(hipEventCreate(&nw->ev1));
+        HIPCHK(hipEventCreate(&nw->ev2));
+        HIPCHK(hipEventCreate(&nw->ev3));
     }
     P1Work* wk = (P1Work*)h->p1;
     const int B = h->B, T = h->T, J = h->J, n = h->n, O = h->O;
@@ -2006,7 +2011,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     unsigned st[ST_WORDS];
     // one launch of the chain kernel over `n_items` work items (d_items == nullptr: all of them) with sort buffers of `cap`
     // entries; with `collect` the items that overflow them are listed in wk->d_retry instead of failing the launch
-    auto launch = [&](int cap, const int* d_items, int n_items, bool collect) -> int {
+    // (`defer`: the launch is queued and NOT waited for -- the caller queues the half-space kernels and the read-back behind it, waits once and
+    //  calls launch_done(); the status words then come back through a page-locked block, a copy into pageable memory would wait by itself)
+    unsigned* st_pin = reinterpret_cast<unsigned*>(armour_handle_pinned(h, 9, 64));
+    if (!st_pin) { armour_set_error("page-locked status block"); return ARMOUR_EDEVICE; }
+    std::function<int()> launch_done = [] { return ARMOUR_OK; };
+    auto launch = [&](int cap, const int* d_items, int n_items, bool collect, bool defer = false) -> int {
         // few items (at most one per CU): three waves per item, the roles of a time step run concurrently (latency);
         // otherwise one wave per item and as many items per CU as the LDS holds (throughput)
         const int nw_env = h->tune(ARMOUR_OPT_P1_STEP_WAVES);   // (0: automatic)
@@ -2106,10 +2116,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
-        HIPCHK(hipMemcpyAsync(st, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(st_pin, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         armour_build_stamp("launch-queued");
-        HIPCHK(p1_wait_stream(h->stream));
-        armour_build_stamp("reach-set-kernel-waited");
+        launch_done = [&, cap, n_items, waves, nw, two_cu, per_cu, smem]() -> int {
+        memcpy(st, st_pin, sizeof(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
         total_ms += ms;
@@ -2126,6 +2136,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
 #endif
         if (armour_trace_p1()) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s)%s (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, two_cu ? ", two CUs per item" : "", per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
         return ARMOUR_OK;
+        };
+        if (defer) return ARMOUR_OK;
+        HIPCHK(p1_wait_stream(h->stream));
+        armour_build_stamp("reach-set-kernel-waited");
+        return launch_done();
     };
     auto other_errors = [&]() -> int {
         if (st[ST_ERR] & (unsigned)ERR_PAIR) {   // not a capacity limit: two waves that share an operator lost each other (psync), their barriers went off
@@ -2289,24 +2304,20 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         d_items = wk->d_retry + 1;
         n_items = nretry;
     }
-    while (n_items > 0) {
-        if ((rc = launch(cap_raw, d_items, n_items, false)) != ARMOUR_OK) return rc;
-        if ((st[ST_ERR] & (unsigned)ERR_HELPER) && !h->p1_two_cu_off) {   // a time step on two CUs lost its helper: again on one CU per step, and this handle stays there
-            if (armour_trace_p1()) fprintf(stderr, "[P1] a helper block's results did not arrive (flags 0x%x): building again on one CU per time step\n", st[ST_ERR]);
-            h->p1_two_cu_off = true;
-            continue;
-        }
-        if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
-            if (cap_raw < 16384) { cap_raw <<= 1; h->p1_step_cap_hint = cap_raw; continue; }  // retry with larger LDS sort buffers (and start there next time)
-            armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
-            return ARMOUR_ECAPACITY;
-        }
-        if ((rc = other_errors()) != ARMOUR_OK) return rc;
-        break;
-    }
+    // The per-step kernel is queued and NOT waited for: the half-space kernels, the bounds kernel and the read-back of everything the host keeps go
+    // into the stream behind it, and ONE wait ends the build (round 6: the wait for the kernel's status words in between cost the launch latency
+    // of five kernels on a device that had gone idle, ~40 us of a lone problem's 0.8 ms).  A launch that reports a capacity flag or a lost helper
+    // is rare: everything is queued again behind the next one.
+    const size_t n_tr = (size_t)B * n * T, n_lg = (size_t)B * T * J * 18, n_lc = (size_t)B * J * T, n_tc = (size_t)B * n * T;
+    const size_t off_lg = n_tr * sizeof(double), off_lc = off_lg + n_lg * sizeof(double), off_tc = off_lc + n_lc * sizeof(int),
+                 off_ps = (off_tc + n_tc * sizeof(int) + 7) & ~(size_t)7, off_mg = off_ps + (size_t)B * sizeof(unsigned long long), rb_bytes = off_mg + (size_t)B * sizeof(unsigned long long);
+    unsigned char* rb = rb_bytes <= ((size_t)4 << 20) ? reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 8, rb_bytes)) : nullptr;
+    for (;;) {
+    const bool chain = n_items > 0;
+    if (chain && (rc = launch(cap_raw, d_items, n_items, false, true)) != ARMOUR_OK) return rc;
     if (O > 0) {
         const int Q = J * T * O;
-        HIPCHK(hipEventRecord(wk->ev0, h->stream));
+        HIPCHK(hipEventRecord(wk->ev2, h->stream));
         const int nbx = (Q + 63) / 64, nbc = (Q + 255) / 256;
         // [B][nbx][4] per-wave masks of the planes kernel | [B][nbc] per-block masks of the class pre-pass | [B] its result | [B] planes a sampled row needs
         const size_t part_words = (size_t)B * nbx * 4, pre_words = (size_t)B * nbc;
@@ -2339,7 +2350,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         h->ll_shared = 1; h->d_from_center = 1;
         h->planes_lean = lean ? 1 : 0; h->planes_have_d = (!lean || store_d) ? 1 : 0;
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(wk->ev1, h->stream));
+        HIPCHK(hipEventRecord(wk->ev3, h->stream));
     }
     // the constraint bounds of this problem set (torque limits -+ the radii just built, collision and joint-limit constants: RT/NLPclass.cu:87-165),
     // filled on the device behind the build's kernels: the first armour_solve / armour_eval_violations of the set finds them there
@@ -2347,10 +2358,6 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     // What the host keeps of a build -- torque radii, link generators, the monomial counts behind the table statistics, the plane masks -- comes
     // back through ONE page-locked block, queued behind the half-space kernels and waited for once (five blocking copies from pageable memory
     // and a wait of their own before: 0.1 ms of a lone problem's 1.2 ms call).  Large batches keep the plain copies.
-    const size_t n_tr = (size_t)B * n * T, n_lg = (size_t)B * T * J * 18, n_lc = (size_t)B * J * T, n_tc = (size_t)B * n * T;
-    const size_t off_lg = n_tr * sizeof(double), off_lc = off_lg + n_lg * sizeof(double), off_tc = off_lc + n_lc * sizeof(int),
-                 off_ps = (off_tc + n_tc * sizeof(int) + 7) & ~(size_t)7, off_mg = off_ps + (size_t)B * sizeof(unsigned long long), rb_bytes = off_mg + (size_t)B * sizeof(unsigned long long);
-    unsigned char* rb = rb_bytes <= ((size_t)4 << 20) ? reinterpret_cast<unsigned char*>(armour_handle_pinned(h, 8, rb_bytes)) : nullptr;
     if (rb) {
         HIPCHK(hipMemcpyAsync(rb, wk->d_torque_radius, n_tr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(rb + off_lg, wk->d_link_gens, n_lg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2364,11 +2371,27 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
     armour_build_stamp("planes+bounds+readback-queued");
     HIPCHK(p1_wait_stream(h->stream));
     armour_build_stamp("planes-waited");
+    if (chain) {
+        if ((rc = launch_done()) != ARMOUR_OK) return rc;
+        if ((st[ST_ERR] & (unsigned)ERR_HELPER) && !h->p1_two_cu_off) {   // a time step on two CUs lost its helper: again on one CU per step, and this handle stays there
+            if (armour_trace_p1()) fprintf(stderr, "[P1] a helper block's results did not arrive (flags 0x%x): building again on one CU per time step\n", st[ST_ERR]);
+            h->p1_two_cu_off = true;
+            continue;
+        }
+        if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
+            if (cap_raw < 16384) { cap_raw <<= 1; h->p1_step_cap_hint = cap_raw; continue; }  // retry with larger LDS sort buffers (and start there next time)
+            armour_set_error("a PZ product produced more than %d raw terms (raise ArmourLimits.raw_terms)", cap_raw);
+            return ARMOUR_ECAPACITY;
+        }
+        if ((rc = other_errors()) != ARMOUR_OK) return rc;
+    }
     if (O > 0) {
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, wk->ev2, wk->ev3));
         total_ms += ms;
         h->planes_ms = ms;
+    }
+    break;
     }
     h->build_ms = total_ms;  // device time of every launch of this build, retries included
 
