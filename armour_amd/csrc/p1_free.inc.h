@@ -160,6 +160,7 @@ __device__ inline void run_backward_pairs(CH& c, typename CH::PZT* u, int n_tail
     if (c.wid == 3) { const unsigned long long own = c.part_mask(3); c.freeV = (c.freeV & own) | (saved & ~own); }
     c.role = c.wid;
     c.bar();   // (B) both recursions are through
+    if constexpr (CH::kTwoCu) c.phase(4);
     if (c.wid == 1) {
         for (int i = 0; i < J; i++) c.freeVs(t3_take(c, T3_A2 + i));
         for (int i = J - n_tail; i < J; i++) c.freeVs(t3_take(c, T3_N + i));
@@ -247,6 +248,7 @@ __device__ inline bool xch_await(CH& c, int kind, int idx) {
         }
     }
     c.prof_waited(tw0);
+    c.prof_signal(T3_CNT + 300 + 16 * kind + idx, (int)((c.prof_clock() - tw0) >> 10));   // (-DP1_STAMPS: how long this take waited, in 1024 cycles)
     if (!ok) { flag(c.wave(), ERR_HELPER); if (w_lane0(c)) *broken = 1; }
     return ok;
 }
@@ -331,13 +333,31 @@ __device__ inline void run_backward_remote(CH& c, typename CH::PZT* u, int n_tai
             TPZ a1 = c.mulMV(Rn, nn);
             TPZ c1;
             const bool own_c1 = i == J - 1;   // (F of the last link ends the forward pass: its product is built here)
+            TPZ c2;
             if (own_c1) {
-                if (h0) c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi); else c1 = c.allocV();
+                // ... and p x (R_J f_J) with f_J = 0 beside it, on the second half: the helper's first step builds the same constant, but its
+                // recursion only starts when this pass does -- waiting for it cost the n-recursion its first 60 k cycles
+                if (h0) c1 = c.crossMatPz(&cf.rb.com[3 * i], Fi);
+                else {
+                    c1 = c.allocV();
+                    c.role = 3;
+                    const auto st = c.solo_begin();
+                    TPZ z = c.allocV();
+                    set_const(w, z, nullptr, nullptr);
+                    TPZ a2 = c.mulMV(Rn, z); c.freeVs(z);
+                    TPZ cl = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], a2); c.freeVs(a2);
+                    t3_post(c, T3_C2 + i, cl);
+                    c.solo_end(st);
+                    c.role = 0;
+                }
                 psync(w);
-            } else c1 = t3_take(c, T3_X2 + i);
-            TPZ c2 = xch_take(c, XK_C2, i);   // (both halves: the same record into the same slot)
-            psync(w);
-            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); c.freeVs(c2); if (own_c1) c.freeVs(c1);  // ((N + a1) + c1) + c2
+                c2 = t3_take(c, T3_C2 + i);
+            } else {
+                c1 = t3_take(c, T3_X2 + i);
+                c2 = xch_take(c, XK_C2, i);   // (both halves: the same record into the same slot)
+                psync(w);
+            }
+            TPZ n2 = c.sum4(Ni, a1, c1, c2); c.freeVs(a1); if (own_c1) c.freeVs(c1); else c.freeVs(c2);  // ((N + a1) + c1) + c2
             if (pend_joint >= 0) {
                 if (cf.rb.axes[pend_joint] != 0) t3_wait(c, T3_UB, J - pend_joint);
                 c.freeVs(pend);
@@ -371,10 +391,12 @@ __device__ inline void run_backward_remote(CH& c, typename CH::PZT* u, int n_tai
         (void)xch_await(c, XK_MISC, 1);   // the helper has read the last F_i
     }
     c.bar();   // (B) the n-recursion is through, nobody reads N_i, F_i, com x F_i any more
+    c.phase(4);
     if (c.wid == 1) {
         for (int i = J - n_tail; i < J; i++) c.freeVs(t3_take(c, T3_N + i));
     } else if (c.wid == 3) {
         for (int i = 0; i < J - 1; i++) c.freeVs(t3_take(c, T3_X2 + i));
+        c.freeVs(t3_take(c, T3_C2 + J - 1));
     } else if (c.wid == 2) {
         for (int i = 0; i < J; i++) { if (i < J - n_tail) c.freeVs(t3_take(c, T3_N + i)); c.freeVs(t3_take(c, T3_F + i)); }
     }
@@ -397,7 +419,7 @@ __device__ inline void helper_backward(CH& c) {
         for (int i = J - 1; i >= 0; i--) {
             t3_wait(c, T3_B1, J - i);
             TPZ c2 = c.crossMatPz(&cf.rb.trans[3 * (i + 1)], t3_take(c, T3_A2 + i));
-            xch_publish(c, XK_C2, i, c2);
+            if (i < J - 1) xch_publish(c, XK_C2, i, c2);   // (the last joint's is p x (R 0): the main block builds that constant itself instead of waiting for this one)
         }
         return;
     }
@@ -515,7 +537,9 @@ __device__ PZW_NOINLINE void run_helper_free(CH& c, int b, int t_lane, bool publ
         }
     }
     c.prof_forward_done();
+    c.phase(3);
     if (publish && c.two_level >= 3 && cf.step_pairs != 0 && cf.lean_back != 0) helper_backward(c);
+    c.phase(4);
     c.bar();
 }
 
@@ -714,6 +738,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             t3_signal(c, T3_C0, s + 1);
         }
         c.prof_forward_done(); c.bar();   // (A)
+        if constexpr (CH::kTwoCu) c.phase(3);
         for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
     } else if (c.wid == 3 && two2) {
         // Two CUs, level 2: of this wave's forward pass only the w_aux recursion is left (R_t w_aux_s for the angular step); level 3: nothing.

@@ -105,6 +105,7 @@ struct P1Cfg {
     int step_pairs;       // per-step kernel, four-wave blocks: in the backward pass the two idle waves join the recursion waves' operators (pz_wave.h psync)
     // a time step on two CUs (p1_free.inc.h): block b < n_items builds item b, block helper0 + b is its helper; xch: kXchBytes per item
     int two_cu, helper0, xch_epoch;
+    long long* phase_log; // ARMOUR_P1_TRACE: [blocks][8] clock of wave 0 at the phase boundaries of its (last) item -- start, JRS, decision, forward pass, backward pass, end (release build: one test of a pointer per boundary)
     int late_jrs;         // two CUs, level 3: the JRS of joints 4 .. J - 1 behind the start of the roles (development switch)
     int lean_back;        // two CUs, level 3: the backward pass with the n-recursion stripped to its chain (p1_free.inc.h run_backward_remote); development switch
     unsigned char* xch;
@@ -320,6 +321,8 @@ struct Chain {
     static constexpr bool kPairs = true;          // run_rnea_free: two waves per operator in the backward pass of a four-wave block
     static constexpr bool kTwoCu = true;          // a time step on two CUs (p1_free.inc.h)
     bool helper = false, two_cu = false;          // this block is the helper of its item | this item runs on two CUs (decided per item: xch_decide)
+    long long* phase_log = nullptr;               // (ARMOUR_P1_TRACE) this block's row of P1Cfg::phase_log
+    __device__ void phase(int k) const { if (phase_log != nullptr && wid == 0 && w.lane == 0) phase_log[k] = clock64(); }
     JrsLane jl;                                   // (late_jrs) this wave's copy of the per-lane JRS scalars, for the joints built after the roles have begun
     bool late_jrs = false;                        // two CUs, level 3: joints 4 .. J - 1 are built by one wave of the block while the recursions run their first steps (jrs_late_joints)
     int two_level = 0;                            // 1: the three families of velocity-only products | 2: + the main block drops its own w recursion and the fourth wave's cross products | 3: + the angular step's cross product from the helper, no velocity recursion left in the main block
@@ -1210,6 +1213,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NW) c.w.cnt[i] = 0;
         margin_reset(c.w);
         c.helper = helper_block; c.two_cu = false;
+        c.phase_log = cf.phase_log ? cf.phase_log + (size_t)blockIdx.x * 8 : nullptr;
+        c.phase(0);
         c.two_level = (cf.two_cu % 10) >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu % 10;   // (cf.two_cu >= 10: the test of the fall-back -- the helper says yes and hands over nothing)
         if (helper_block) c.helper_parts(c.two_level);
         if constexpr (NW == 4) {
@@ -1230,6 +1235,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         if constexpr (NW == 4) late = cf.two_cu != 0 && c.two_level >= 3 && cf.late_jrs != 0 && c.J > NW && !fk_only;
         build_jrs(c, b, t, fk_only, helper_block, late ? NW : ARMOUR_MAX_JOINTS, late ? &c.jl : nullptr);
         __syncthreads();
+        c.phase(1);
 #if defined(P1_STAMPS)
         const long long ph_jrs = clock64();
 #endif
@@ -1239,6 +1245,8 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #if defined(P1_STAMPS)
         if (c.w.lane == 0 && t == cf.T - 1 && !fk_only) printf("[t=%d %swave %d] JRS done at %lld, two-CU decision at %lld\n", t, helper_block ? "helper " : "", c.wid, ph_jrs - ph0, (long long)clock64() - ph0);
 #endif
+        c.phase(2);
+        if (c.phase_log != nullptr && threadIdx.x == 0) { c.phase_log[6] = c.two_cu ? 1 : 2; c.phase_log[7] = (long long)(xch_xcc() - 1u); }
         c.late_jrs = late && c.two_cu;
         if (late && !c.two_cu) {   // (no helper after all: the other joints the way build_jrs deals them)
             for (int i = NW; i < c.J; i++) if (c.wid == i % NW) jrs_joint(c, c.jl, i, false, cf.fk_items == 0 || helper_block);
@@ -1275,6 +1283,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
                 finish_torque(c, u_nom, b, t, c.wid, NW);
             } else if (c.is(0)) finish_torque(c, u_nom, b, t);
         }
+        c.phase(5);
         if (((c.w.lstat[ST_ERR] & ~err_before)) == 0) margin_item_end(c.w, cf.margin ? cf.margin + (size_t)b : nullptr);   // (not an item this wave flagged: it is built again -- here with larger buffers, or the whole launch, which then starts from cleared words)
         __syncthreads();
         if (cf.retry_list && ((c.w.lstat[ST_ERR] & ~err_before) & ERR_RAW_OVERFLOW)) {
@@ -2087,6 +2096,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
+        static thread_local long long* d_phase = nullptr; static thread_local int phase_blocks = 0;
+        if (armour_trace_p1() && nw == 4 && waves <= 1024) {
+            if (!d_phase) HIPCHK(hipMalloc((void**)&d_phase, 1024 * 8 * sizeof(long long)));
+            HIPCHK(hipMemsetAsync(d_phase, 0, 1024 * 8 * sizeof(long long), h->stream));
+            cf.phase_log = d_phase; phase_blocks = waves;
+        }
         cf.two_cu = two_cu ? cf_two_cu_env : 0; cf.helper0 = helper0;
         cf.lean_back = h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 1; cf.late_jrs = (h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 2) == 0;   // (development: + 2 builds every joint before the roles begin)
         if (two_cu) {
@@ -2118,7 +2133,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st_pin, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         armour_build_stamp("launch-queued");
-        launch_done = [&, cap, n_items, waves, nw, two_cu, per_cu, smem]() -> int {
+        launch_done = [&, cap, n_items, waves, nw, two_cu, per_cu, smem, helper0]() -> int {
         memcpy(st, st_pin, sizeof(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
@@ -2134,6 +2149,29 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
+        if (armour_trace_p1() && nw == 4 && d_phase && phase_blocks > 0) {   // where the blocks' time went (wave 0 of each): median / max over the main blocks, then over the helpers
+            std::vector<long long> ph((size_t)phase_blocks * 8);
+            HIPCHK(hipMemcpy(ph.data(), d_phase, ph.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            const char* names[5] = {"JRS", "decision", "forward pass", "backward pass", "tables"};
+            for (int grp = 0; grp < (two_cu ? 2 : 1); grp++) {
+                const int b0 = grp == 0 ? 0 : helper0, b1 = grp == 0 ? n_items : helper0 + n_items;
+                fprintf(stderr, "[P1 phases, %s blocks, cycles median / max]", grp == 0 ? "main" : "helper");
+                for (int k = 0; k < 5; k++) {
+                    std::vector<long long> d;
+                    for (int bl = b0; bl < b1 && bl < phase_blocks; bl++) { const long long* r = &ph[(size_t)bl * 8]; if (r[k + 1] > 0 && r[k] > 0) d.push_back(r[k + 1] - r[k]); }
+                    if (d.empty()) continue;
+                    std::sort(d.begin(), d.end());
+                    fprintf(stderr, " %s %lld / %lld", names[k], d[d.size() / 2], d.back());
+                }
+                std::vector<long long> tot;
+                long long first = 0, last = 0;
+                for (int bl = b0; bl < b1 && bl < phase_blocks; bl++) { const long long* r = &ph[(size_t)bl * 8]; if (r[5] > 0) { tot.push_back(r[5] - r[0]); if (!first || r[0] < first) first = r[0]; if (r[5] > last) last = r[5]; } }
+                if (!tot.empty()) { std::sort(tot.begin(), tot.end()); fprintf(stderr, " | item %lld / %lld", tot[tot.size() / 2], tot.back()); }
+                int local = 0, xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int bl = b0; bl < b1 && bl < phase_blocks; bl++) { const long long* r = &ph[(size_t)bl * 8]; if (r[6] == 2) { local++; fprintf(stderr, " [block %d on XCD %lld: one CU]", bl, r[7]); } xcd[r[7] & 7]++; }
+                fprintf(stderr, " | %d of %d on their own; blocks per XCD %d %d %d %d %d %d %d %d\n", local, b1 - b0, xcd[0], xcd[1], xcd[2], xcd[3], xcd[4], xcd[5], xcd[6], xcd[7]);
+            }
+        }
         if (armour_trace_p1()) fprintf(stderr, "[P1] %d items, cap_raw %d: %d blocks of %d wave(s)%s (%d per CU, %zu B LDS), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", n_items, cap, waves, nw, two_cu ? ", two CUs per item" : "", per_cu, smem, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
         return ARMOUR_OK;
         };

@@ -13,7 +13,7 @@ for l in sig[-n:]:
     m = re.match(r'\[t=(\d+) (helper )?wave (\d) signal\] word (-?\d+) value (\d+) at (\d+)', l)
     t, h, wv, word, val, at = m.groups()
     word = int(word)
-    nm = names.get(word, 'X%d.%d' % ((word - 100) // 16, (word - 100) % 16) if word >= 100 else str(word))
+    nm = names.get(word, ('take%d.%d waited(k)' % ((word - 300) // 16, (word - 300) % 16)) if 300 <= word < 1000 else ('X%d.%d' % ((word - 100) // 16, (word - 100) % 16) if 100 <= word < 300 else str(word)))
     rows.append((int(at), ('H' if h else 'M') + wv, nm, int(val)))
 rows.sort()
 for r in rows: print("%8d %s %s %d" % r)
