@@ -287,9 +287,11 @@ __device__ inline int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; retu
 __device__ inline void flag(const Wave& w, int bit) { if (w.lane == 0) w.lstat[ST_ERR] |= bit; }
 
 // 64-lane bitonic sort of (skey, sidx)[0, P) ascending by (key, idx); P is a power of two >= 64.
-__device__ inline void bitonic_sort(const Wave& w, int P) {
+// (k_first > 2: the blocks of k_first / 2 entries are sorted already, alternately ascending and descending -- only the network's last stages run;
+//  k_first = P is the merge of one ascending and one descending half: MulEval::split_merge)
+__device__ inline void bitonic_sort(const Wave& w, int P, int k_first = 2) {
     const int half = P >> 1;
-    for (int k = 2; k <= P; k <<= 1) {
+    for (int k = k_first; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             // four compare-exchanges per lane in flight: all LDS reads of a group are issued before the first compare
             // (the pairs of one pass are disjoint); the loop is LDS-latency bound otherwise
@@ -1054,6 +1056,22 @@ struct MulEval {
     }
     __device__ inline bool can_tree(const Wave& w, int N) const { return 2 * N <= w.cap_key && 2 * N <= w.cap_raw; }
     __device__ inline bool can_merge(const Wave& w, int N) const { return can_tree(w, N) || can_rank(w); }
+    // The split of the runs at the tree's last level: runs [0, r0) and [r0, nr), r0 = the largest power of two below nr.  (round 6)
+    struct Split { int levels, q0, N1, N2, P; bool ok; };
+    __device__ inline Split split_of(const Wave& w, int N) const {
+        Split sp;
+        const int na1 = a.cnt + 1;
+        const bool by_a = na1 <= mb1;
+        const int nr = by_a ? na1 : mb1, d1 = by_a ? mb1 : na1;
+        sp.levels = 0;
+        while ((1 << sp.levels) < nr) sp.levels++;
+        sp.P = next_pow2(N);
+        const int C = min(w.cap_key, w.cap_raw);
+        sp.q0 = sp.levels >= 1 ? (d1 << (sp.levels - 1)) - 1 : 0;
+        sp.N1 = sp.q0; sp.N2 = N - sp.q0;
+        sp.ok = sp.levels >= 1 && sp.N2 > 0 && sp.P <= C && sp.N1 <= sp.P / 2 && sp.N2 <= sp.P / 2 && 2 * sp.N1 <= C && sp.N1 + 2 * sp.N2 <= sp.P;
+        return sp;
+    }
     __device__ inline bool try_merge(Wave& w, int N, bool& indirect) const {
 #ifdef DBG_NO_MERGE_MUL
         return false;
@@ -1064,7 +1082,13 @@ struct MulEval {
 #ifdef DBG_NO_RANK
         return false;
 #endif
-        if (!can_rank(w)) return false;  // too long for the tree's two buffers and too many runs to rank: the bitonic network
+        if (!can_rank(w)) {   // too long for the tree's two buffers and too many runs to rank
+#ifndef DBG_NO_SPLIT
+            const Split sp = split_of(w, N);
+            if (sp.ok) { indirect = false; split_merge(w, N, sp); return true; }
+#endif
+            return false;     // ... and no split that fits: the bitonic network
+        }
         indirect = true;
         return rank_merge(w, N);
     }
@@ -1200,6 +1224,75 @@ struct MulEval {
             cur ^= 1;
         }
         PROF_ADD(PR_SORT) PROF_ADD(PR_S_MULMERGE)
+    }
+    // Levels [0, nlev) of the tree over the positions [q_lo, q_hi) alone -- a group of runs that the first nlev levels never merge with a run
+    // outside it -- between two buffers of their own: position q of buffer k sits at entry base[k] + q - q_lo.  The result is in buffer 0.
+    __device__ inline void tree_group(Wave& w, int q_lo, int q_hi, int nlev, int base0, int base1) const {
+        const int na1 = a.cnt + 1;
+        const bool by_a = na1 <= mb1;
+        const int d1 = by_a ? mb1 : na1;
+        const unsigned long long magic = magic_u32(d1);
+        const int nl = w.nl, Ng = q_hi - q_lo;
+        int cur = nlev & 1;
+        LDS_AS pzkey_t* kb[2] = {w.skey + base0 - q_lo, w.skey + base1 - q_lo};
+        LDS_AS uint16_t* vb[2] = {w.sidx + base0 - q_lo, w.sidx + base1 - q_lo};
+        constexpr int KF = 4;
+        for (int q0 = q_lo + w.lane2; q0 < q_hi; q0 += KF * nl) {
+            pzkey_t kk[KF];
+            int gi[KF];
+#pragma unroll
+            for (int u = 0; u < KF; u++) {
+                const int q = min(q0 + u * nl, q_hi - 1);
+                if (by_a) { kk[u] = key(q); gi[u] = q; }
+                else {
+                    const int j = (int)(((unsigned long long)(q + 1) * magic) >> 32), i = q + 1 - j * na1;
+                    kk[u] = (i ? a.keys[i - 1] : 0ull) + (j ? b.keys[j - 1] : 0ull);
+                    gi[u] = i * mb1 + j - 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KF; u++) { const int q = q0 + u * nl; if (q < q_hi) { kb[cur][q] = kk[u]; vb[cur][q] = (uint16_t)gi[u]; } }
+        }
+        psync(w);
+        for (int lv = 0; lv < nlev; lv++) {
+            const int rl = d1 << lv, pl = 2 * rl;
+            const int E = ((Ng + nl - 1) / nl) | 1;
+            int c = q_lo + w.lane2 * E;
+            const int cend = min(c + E, q_hi);
+            while (c < cend) {
+                const int pr = (int)(((unsigned long long)(c + 1) * magic) >> 32) >> (lv + 1);
+                const int ps = max(pr * pl - 1, 0);
+                const int am = min(pr * pl + rl - 1, q_hi), pe = min((pr + 1) * pl - 1, q_hi);
+                const int c9 = min(cend, pe);
+                merge_span(kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], ps, am, pe, c, c9, by_a, q_hi);
+                c = c9;
+            }
+            psync(w);
+            cur ^= 1;
+        }
+    }
+    // A product a little too long for the tree's two buffers (2 N entries) with too many runs to rank went to the bitonic network over all
+    // next_pow2(N) entries: 78 stages for 2 049 .. 4 096 raw terms, 0.2 M cycles and more where the tree takes 0.06 M -- and a cross product of the
+    // last links is 2 050 .. 2 250 raw terms in a good part of the worlds (4 of the reference's 107: their builds took 1.0 ms instead of 0.8).
+    // Here the two halves the tree's LAST level would merge are sorted by the tree's other levels, each between buffers that fit (the second
+    // half's in the space the first leaves), laid out as one ascending and one descending half of next_pow2(N) entries with the padding in
+    // the middle -- a bitonic sequence -- and merged by the LAST stage of the network alone: log2 P passes.  The order is the one every path
+    // produces: by (key, generation index).
+    __device__ inline void split_merge(Wave& w, int N, const Split& sp) const {
+        PROF_T0
+        const int nl = w.nl, P = sp.P, N1 = sp.N1, N2 = sp.N2;
+        tree_group(w, 0, sp.q0, sp.levels - 1, 0, N1);                 // -> [0, N1) ascending
+        tree_group(w, sp.q0, N, sp.levels - 1, N1, N1 + N2);           // -> [N1, N1 + N2) ascending
+        for (int t = w.lane2; t < N2; t += nl) {                       // the second half reversed into the END of the array ([N1 + N2, P) holds nothing: N1 + 2 N2 <= P)
+            w.skey[P - 1 - t] = w.skey[N1 + t];
+            w.sidx[P - 1 - t] = w.sidx[N1 + t];
+        }
+        psync(w);
+        for (int t = N1 + w.lane2; t < P - N2; t += nl) { w.skey[t] = PZKEY_MAX; w.sidx[t] = (uint16_t)0xffffu; }   // the padding, between the two
+        psync(w);
+        if (w.half == 0) bitonic_sort(w, P, P);
+        psync(w);
+        PROF_ADD(PR_SORT) PROF_ADD(PR_S_BITONIC)
     }
     __device__ inline bool rank_merge(Wave& w, int N) const {
         const bool a_short = a.cnt <= b.cnt;

@@ -118,6 +118,9 @@ CASES = [
     (5, [(3, 250), (3, 250)], "sub merge"), (6, [(3, 140), (1, 2)], "addOneDim"), (7, [(1, 90), (1, 70), (1, 110)], "stack 3-way merge"),
     (7, [(1, 10), (1, 0), (1, 12)], "stack with an empty entry"), (8, [(3, 333)], "cross(a, const)"), (9, [(3, 64)], "cross(const, a)"),
     (10, [(3, 30), (3, 25)], "cross(a, b) bitonic"), (10, [(3, 6), (3, 90)], "cross(a, b) merge"),
+    # round 6: 2 049 .. ~3 000 raw terms in more than eight runs -- the two halves of the tree's last level sorted apart, then one bitonic merge (MulEval::split_merge)
+    (10, [(3, 36), (3, 59)], "cross(a, b) split merge 2219 raw"), (10, [(3, 46), (3, 45)], "cross(a, b) split merge, runs along b"), (2, [(1, 40), (1, 60)], "SS split merge 2500 raw"),
+    (0, [(9, 10), (3, 230)], "MV split merge 2540 raw"), (2, [(1, 55), (1, 62)], "SS 3527 raw: no split fits, the whole network"),
     (10, [(3, 6), (3, 7)], "cross(a, b) <= 64 raw"), (10, [(3, 0), (3, 40)], "cross(constant a, b)"), (10, [(3, 25), (3, 0)], "cross(a, constant b)"), (11, [(1, 200), (1, 190)], "s1*a + s2*b"),
 ]
 
@@ -128,6 +131,8 @@ def test_device_operator_matches_oracle(dev, op, shapes, label):
     rng = np.random.default_rng(abs(hash(label)) % (2**31))
     for trial in range(3):
         ops = [rand_pz(rng, sz, cnt, scale=float(rng.choice([1.0, 0.05]))) for sz, cnt in shapes]
+        if "split merge" in label or "no split fits" in label:   # thousands of raw terms: coefficients small enough that most products are pruned and the result fits a work slot (1024 monomials)
+            ops = [rand_pz(rng, sz, cnt, scale=0.008 if op == 0 else 0.02) for sz, cnt in shapes]
         if op in (5, 11) and trial == 0:
             ops[1]["keys"] = ops[0]["keys"][:len(ops[1]["keys"])].copy() if len(ops[0]["keys"]) >= len(ops[1]["keys"]) else ops[1]["keys"]
         consts = rng.normal(size=4)
