@@ -263,7 +263,7 @@ extern "C" void armour_destroy(ArmourPlanner* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_step_graphs(h);
-    for (int i = 0; i < 9; i++) armour_free_pinned(h->solve_pin[i]);
+    for (void* pin : h->solve_pin) armour_free_pinned(pin);
     dev_free(&h->d_bounds); dev_free(&h->d_viol);
     armour_relevance_free(h);
     if (h->d_tr_stage) (void)hipFree(h->d_tr_stage);
