@@ -127,3 +127,43 @@ def test_a_point_outside_the_box_is_not_answered_from_the_lists():
             assert rec[b].feasible == full[b]["feasible"] and rec[b].l1_violation == full[b]["l1_violation"] and rec[b].n_violated == full[b]["n_violated"]
             assert full_in[b]["l1_violation"] == full[b]["l1_violation"]      # (problems are independent)
     nlp.close(); culled.close()
+
+
+@pytest.mark.parametrize("world", ["random, 12 boxes", "reference scene"])
+def test_the_device_list_contains_the_list_of_the_matlab_rule(world):
+    """the device keeps a collision row unless ONE half-space of its 36-plane table separates the link's hull over k from
+    the obstacle -- a sufficient test -- where KSI/uarmtd_planner.m:577-583 tests the zonotope itself: the obstacle buffered by EVERY generator of the
+    link's occupancy (sliceable and not), turned into its full half-space form (PZM/utility/polytope_PH.m: the normals of all generator pairs), must
+    contain the occupancy's centre.  That rule, restated in numpy (armour_amd/cora_mode.py: polytope_PH) and applied to the DEVICE's own reach sets,
+    is the oracle here: every (link, time step, obstacle) it keeps the device keeps too (the device's normals are a subset of its normals and the bound
+    over k is the same sum of |A . generator|), and the device's list is not much longer."""
+    from armour_amd.cora_mode import polytope_PH
+    from armour_amd.planner import ArmourNLP
+    if world.startswith("random"):
+        from armour_amd.worlds import random_problem
+        p = random_problem(77, 12)
+    else:
+        from armour_amd.scenes import reference_worlds
+        p = dict(reference_worlds())["scene_037_004"]
+    T = 40
+    nlp = ArmourNLP(T=T).set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    rel, cnt, _ = nlp.row_relevance()
+    n, J = nlp.n, nlp.J
+    obs = np.asarray(p["obstacles"], dtype=float).reshape(-1, 12)
+    O = len(obs)
+    gens = nlp.link_generators()[0]   # [T][J][3][6]: the link box's three generators | the independent radius per axis
+    keep_matlab = np.zeros((J, T, O), bool)
+    for l in range(J):
+        for t in range(T):
+            cen, _, _, co = nlp.pz("link", l, t)
+            G = np.hstack([np.asarray(co, dtype=float).reshape(-1, 3).T, gens[t, l]])   # sliceable generators (one per k-monomial) | the rest
+            for o in range(O):
+                Zo = obs[o].reshape(4, 3).T
+                A, b = polytope_PH(np.hstack([Zo, G]))
+                keep_matlab[l, t, o] = bool(np.all(A @ cen - b <= 0))
+    keep_device = rel[0, n * T:n * T + J * T * O].reshape(J, T, O)
+    assert not (keep_matlab & ~keep_device).any(), np.argwhere(keep_matlab & ~keep_device)[:5]
+    nm, nd = int(keep_matlab.sum()), int(keep_device.sum())
+    print(f"{world}: the MATLAB rule keeps {nm} of {J * T * O} collision rows, the device {nd}")
+    assert nd == int(cnt[0]) and nd <= max(3 * nm, nm + 0.02 * J * T * O), (nm, nd)
+    nlp.close()
