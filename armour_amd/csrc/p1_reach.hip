@@ -245,18 +245,20 @@ __device__ PZW_NOINLINE JrsScalars jrs_scalars(const P1Cfg& cf, double q0, doubl
     const double q_c = (ki_lb + ki_ub) * 0.5;
     const Itv q_rad = iv(-kd_r - ki_r - cf.ub.qe, kd_r + ki_r + cf.ub.qe);
     const Itv kint = imuls(kd_c, iv(-kr, kr));
+    const double sin_qc = sin(q_c), cos_qc = cos(q_c);   // (once each; the shared interval terms once as well: same values, same bits)
+    const Itv q_all = iadd(iadds(q_c, kint), q_rad), sq_all = isqr(iadd(q_rad, kint));
     {
-        Itv rad = isub(imul(ineg(q_rad), iv(sin(q_c), sin(q_c))), imul(imuls(0.5, icos(iadd(iadds(q_c, kint), q_rad))), isqr(iadd(q_rad, kint))));
-        o.cos_c = cos(q_c) + icen(rad);
+        Itv rad = isub(imul(ineg(q_rad), iv(sin_qc, sin_qc)), imul(imuls(0.5, icos(q_all)), sq_all));
+        o.cos_c = cos_qc + icen(rad);
         rad = isubs(rad, icen(rad));
-        o.cos_k = -kd_c * kr * sin(q_c);
+        o.cos_k = -kd_c * kr * sin_qc;
         o.cos_e = irad(rad);
     }
     {
-        Itv rad = isub(imul(q_rad, iv(cos(q_c), cos(q_c))), imul(imuls(0.5, isin(iadd(iadds(q_c, kint), q_rad))), isqr(iadd(q_rad, kint))));
-        o.sin_c = sin(q_c) + icen(rad);
+        Itv rad = isub(imul(q_rad, iv(cos_qc, cos_qc)), imul(imuls(0.5, isin(q_all)), sq_all));
+        o.sin_c = sin_qc + icen(rad);
         rad = isubs(rad, icen(rad));
-        o.sin_k = kd_c * kr * cos(q_c);
+        o.sin_k = kd_c * kr * cos_qc;
         o.sin_e = irad(rad);
     }
     // Part 2: qd_des
@@ -302,15 +304,17 @@ __device__ inline void make_rotation(double* R, double c, double s, int axis, bo
     else if (axis == 3) { R[0] = c; R[1] = ns; R[3] = s; R[4] = c; }
 }
 __device__ inline void rpy_matrix(double roll, double pitch, double yaw, double* c) {  // RT/PZsparse.cu:160-176
-    c[0] = cos(pitch) * cos(yaw);
-    c[1] = -cos(pitch) * sin(yaw);
-    c[2] = sin(pitch);
-    c[3] = cos(roll) * sin(yaw) + cos(yaw) * sin(pitch) * sin(roll);
-    c[4] = cos(roll) * cos(yaw) - sin(pitch) * sin(roll) * sin(yaw);
-    c[5] = -cos(pitch) * sin(roll);
-    c[6] = sin(roll) * sin(yaw) - cos(roll) * cos(yaw) * sin(pitch);
-    c[7] = cos(yaw) * sin(roll) + cos(roll) * sin(pitch) * sin(yaw);
-    c[8] = cos(pitch) * cos(roll);
+    // (each of the six values once: the same function of the same argument gives the same bits, and 22 calls were 14 k cycles of every item's start)
+    const double cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw), cr = cos(roll), sr = sin(roll);
+    c[0] = cp * cy;
+    c[1] = -cp * sy;
+    c[2] = sp;
+    c[3] = cr * sy + cy * sp * sr;
+    c[4] = cr * cy - sp * sr * sy;
+    c[5] = -cp * sr;
+    c[6] = sr * sy - cr * cy * sp;
+    c[7] = cy * sr + cr * sp * sy;
+    c[8] = cp * cr;
 }
 
 // ------------------------------------------------------------------ per-wave state and slot pools
