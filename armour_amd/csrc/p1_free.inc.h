@@ -221,6 +221,7 @@ __device__ inline bool xch_decide(CH& c, bool helper) {
         for (int spins = 0; spins < limit; spins++) { v = xch_ld(src); if ((v >> 8) == ep) break; __builtin_amdgcn_s_sleep(16); }
         int mode = 2;
         if ((v >> 8) == ep) mode = helper ? (int)(v & 0xffu) : ((v & 0xffu) == xch_xcc() ? 1 : 2);
+        else if (!helper) flag(c.wave(), ERR_HELPER_LATE);   // (1.5 ms spent waiting: the host keeps this handle off two CUs from now on)
         if (!helper && w_lane0(c)) xch_st((GLB_AS unsigned*)c.xch + 2, (ep << 8) | (unsigned)mode);
         if (w_lane0(c)) *word = mode;
     }

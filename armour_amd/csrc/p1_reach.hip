@@ -1219,14 +1219,14 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
         c.helper = helper_block; c.two_cu = false;
         c.phase_log = cf.phase_log ? cf.phase_log + (size_t)blockIdx.x * 8 : nullptr;
         c.phase(0);
-        c.two_level = (cf.two_cu % 10) >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu % 10;   // (cf.two_cu >= 10: the test of the fall-back -- the helper says yes and hands over nothing)
+        c.two_level = (cf.two_cu % 10) >= 3 && c.J > kTwoCuC4MaxJ ? 2 : cf.two_cu % 10;   // (cf.two_cu >= 10: the tests of the fall-backs -- 10 + level: the helper says yes and hands over nothing; 20 + level: it never says it has started)
         if (helper_block) c.helper_parts(c.two_level);
         if constexpr (NW == 4) {
             if (cf.two_cu) {
                 c.xch = (GLB_AS unsigned char*)cf.xch + (size_t)it0 * kXchBytes;
                 c.xch_epoch = cf.xch_epoch;
                 c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(helper_block ? it0 : cf.helper0 + it0) * cf.arena_bytes;   // (the other block of the item)
-                xch_hello(c, helper_block);
+                if (!(helper_block && cf.two_cu >= 20)) xch_hello(c, helper_block);   // (cf.two_cu >= 20: the test of a helper that starts late -- it never says so)
                 if (threadIdx.x == 0) c.mb[kMbWords - 3] = 0;   // (xch_take: no take of this item has been lost)
             }
         }
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
         if (helper_block) {
-            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu && cf.two_cu < 10);
+            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu && cf.two_cu < 10);   // (20 + level: the main block has decided against two CUs by itself)
         } else if (fk_only) {
             // forward kinematics and the link tables, nothing else: the whole ARMTD chain (CMP/armtd_main.cu:141-156), or
             // the forward-kinematics half of a split ARMOUR item.  A single role: one wave works.
@@ -2418,7 +2418,14 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if ((st[ST_ERR] & (unsigned)ERR_HELPER) && !h->p1_two_cu_off) {   // a time step on two CUs lost its helper: again on one CU per step, and this handle stays there
             if (armour_trace_p1()) fprintf(stderr, "[P1] a helper block's results did not arrive (flags 0x%x): building again on one CU per time step\n", st[ST_ERR]);
             h->p1_two_cu_off = true;
+            h->tuning[ARMOUR_OPT_P1_STEP_TWO_CU - ARMOUR_OPT_FIRST_TUNING] = 0;   // (armour_get_option shows it; armour_set_option switches it on again)
             continue;
+        }
+        if (st[ST_ERR] & (unsigned)ERR_HELPER_LATE) {   // good tables, built late: some main block waited 1.5 ms for a helper that had not started (a shared device, fewer CUs than reported)
+            if (armour_trace_p1()) fprintf(stderr, "[P1] a helper block started too late for its item (flags 0x%x): one CU per time step from the next build on\n", st[ST_ERR]);
+            h->p1_two_cu_off = true;
+            h->tuning[ARMOUR_OPT_P1_STEP_TWO_CU - ARMOUR_OPT_FIRST_TUNING] = 0;
+            st[ST_ERR] &= ~(unsigned)ERR_HELPER_LATE;
         }
         if (st[ST_ERR] & ERR_RAW_OVERFLOW) {
             if (cap_raw < 16384) { cap_raw <<= 1; h->p1_step_cap_hint = cap_raw; continue; }  // retry with larger LDS sort buffers (and start there next time)

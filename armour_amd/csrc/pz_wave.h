@@ -71,7 +71,8 @@ enum { PR_FILL = 0, PR_SORT = 1, PR_EMIT = 2, PR_ABS = 3, PR_CALLS = 4, PR_TERMS
 #define PROF_CALL_END(N)
 #endif
 enum { ERR_RAW_OVERFLOW = 1, ERR_SLOT_OVERFLOW = 2, ERR_TABLE_OVERFLOW = 4, ERR_LINK_GENS = 8, ERR_PAIR = 32, ERR_DBG_BOUNDS = 128,
-       ERR_HELPER = 256 /* a time step on two CUs (p1_free.inc.h): the helper block's results did not arrive -- the host builds again on one CU per step */ };
+       ERR_HELPER = 256 /* a time step on two CUs (p1_free.inc.h): the helper block's results did not arrive -- the host builds again on one CU per step */,
+       ERR_HELPER_LATE = 512 /* not an error: a main block gave up waiting for its helper to START (the device is shared, or holds fewer CUs than it reports) and built its item alone -- the tables are good, the handle goes back to one CU per step */ };
 // -DDBG_BOUNDS (root-cause tooling, tools/dev/gpu_fault_hunt.py): every LDS / arena index of the product merge and of the reduce
 // pass is range-checked BEFORE the access; a violation is recorded (flag 128, lstat[3] = code * 2^20 + the offending value's
 // low 20 bits, first one wins) and the index clamped to 0, so that a genuine out-of-range index shows up as a report

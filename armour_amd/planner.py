@@ -404,6 +404,12 @@ class ArmourNLP:
         check(self.L.armour_set_option(self.h, option, float(value)))
         return self
 
+    def get_option(self, option):
+        """armour_get_option: the handle's current value (a fall-back the library took by itself shows here, e.g. OPT_P1_STEP_TWO_CU = 0)."""
+        v = C.c_double()
+        check(self.L.armour_get_option(self.h, option, C.byref(v)))
+        return v.value
+
     def eval_violations(self, x):
         """Reduced outputs: one record per problem -- the row test of finalize_solution (RT/NLPclass.cu:422-538) applied on
         the device, g never leaves it.  Returns a list of dicts."""

@@ -94,8 +94,36 @@ def test_a_helper_that_never_delivers_is_noticed():
         for i in range(nlp.n):
             for a, b in zip(nlp.pz("torque", i, 50), ref.pz("torque", i, 50)):
                 assert np.array_equal(a, b)
+        assert nlp.get_option(_lib.OPT_P1_STEP_TWO_CU) == 0          # (the caller can see where the handle is)
         nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
         assert nlp.build_info()["launches"] == 1, nlp.build_info()   # (one CU per step from the start)
         assert np.array_equal(nlp.torque_radius(), ref.torque_radius())
         nlp.close()
     ref.close()
+
+
+def test_a_helper_that_starts_late_costs_one_slow_build():
+    """ARMOUR_OPT_P1_STEP_TWO_CU = 20 + level: the helper blocks never say they have started -- what a main block sees when the device is shared or
+    holds fewer CUs than it reports and its helper is queued behind other work.  Each main block gives up after ~1.5 ms and builds its item alone
+    (the helper, whenever it runs, still does the forward kinematics): ONE launch, good tables, and the handle stays on one CU per step until the
+    option is set again."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    p = random_problem(4, 6)
+    ref = ArmourNLP(T=100)
+    ref.set_option(_lib.OPT_P1_STEP_TWO_CU, 0)
+    ref.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    nlp = ArmourNLP(T=100)
+    nlp.set_option(_lib.OPT_P1_STEP_TWO_CU, 23)
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert nlp.build_info()["launches"] == 1 and nlp.build_ms > 1.5, (nlp.build_info(), nlp.build_ms)
+    assert np.array_equal(nlp.torque_radius(), ref.torque_radius()) and np.array_equal(nlp.link_generators(), ref.link_generators())
+    assert nlp.get_option(_lib.OPT_P1_STEP_TWO_CU) == 0
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert nlp.build_ms < 1.5 and np.array_equal(nlp.torque_radius(), ref.torque_radius())
+    nlp.set_option(_lib.OPT_P1_STEP_TWO_CU, 3)                       # two CUs again
+    nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    assert nlp.get_option(_lib.OPT_P1_STEP_TWO_CU) == 3 and nlp.build_ms < 1.5
+    assert np.array_equal(nlp.torque_radius(), ref.torque_radius()) and np.array_equal(nlp.link_generators(), ref.link_generators())
+    nlp.close(); ref.close()
