@@ -3,10 +3,12 @@
 Round 5 found the mechanism of the memory-aperture violations (the controller's non-inlined form of round 3, the time-vectorised kernel's one-wave
 blocks on narrow rows): ROCm 7.2's clang relaxes branches over more than 128 KB through s[30:31] -- the return address -- in functions that make no
 calls, without saving it.  Every non-inlined device function now keeps its return address elsewhere (pz_wave.h PZ_KEEP_RETURN_ADDRESS) and `make`
-runs tools/check_long_branches.py on every library it links.  Two hazards are still unexplained and stay fenced; the fences are under test here:
+runs tools/check_long_branches.py on every library it links.  Two hazards are still unexplained; what holds them is under test here:
 
   * reach-set operators (round 1: a memory fault under interprocedural register allocation; round 2: wrong tables with two waves per SIMD):
-    the shipped objects are built with -enable-ipra=false and pinned to one wave per SIMD, `make` fails otherwise (tools/check_p1_occupancy.py),
+    the shipped objects are pinned to one wave per SIMD, `make` fails otherwise (tools/check_p1_occupancy.py); they were built with
+    -enable-ipra=false until the end of round 6 -- that fence is gone (profiles/r06_ipra.txt: the compiler collects a callee's register usage AFTER
+    branch relaxation, and today's source passes everything below with IPRA on),
     and HERE the same source with every LDS / arena index of the product merge and of the reduce passes range-checked (-DDBG_BOUNDS,
     armour_amd/lib/libarmour_hip_checked.so) runs a fuzz set in every launch shape: no check fires (a firing check fails the build call with
     flag 128) and the tables equal the shipped library's bit for bit; the two-waves-per-SIMD build of today's source (`make occ2`) must

@@ -8,7 +8,7 @@ set -e
 name=$1; shift
 src=/root/repo
 if [ "${1:-}" = "-s" ]; then src=$2; shift 2; fi
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -mllvm -enable-ipra=false"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function"   # (the shipped flags of both reach-set units: armour_amd/csrc/Makefile HIPFLAGS + P1FLAGS; pass -mllvm -enable-ipra=false for the fenced form of rounds 1-5)
 A=(); B=()
 for f in "$@"; do case "$f" in -DROWS=*) A+=("-DP1_TV_NARROW=${f#-DROWS=}"); B+=("-DTV_GROW=${f#-DROWS=}");; *) A+=("$f"); B+=("$f");; esac; done
 O=/tmp/variant_$name; mkdir -p $O
