@@ -2314,6 +2314,12 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int tv_aux3_env = h->tune(ARMOUR_OPT_P1_TV_AUX3);
             cf.tv_aux_on_fk_wave = tv_aux3_env;
             cf.tail_cross = h->tune(ARMOUR_OPT_P1_TV_TAIL_CROSS);
+            static thread_local long long* d_tvphase = nullptr;
+            if (armour_trace_p1() && blocks <= 1024) {   // when each block's (last) item began and ended: the spread between the groups
+                if (!d_tvphase) HIPCHK(hipMalloc((void**)&d_tvphase, 1024 * 8 * sizeof(long long)));
+                HIPCHK(hipMemsetAsync(d_tvphase, 0, 1024 * 8 * sizeof(long long), h->stream));
+                cf.phase_log = d_tvphase;
+            }
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
             {
@@ -2327,6 +2333,15 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
             total_ms += ms;
             h->build_info[0] = ARMOUR_P1_KERNEL_TIME_VECTORISED; h->build_info[1] = nw_launch; h->build_info[2] = cap; h->build_info[3]++;
+            if (cf.phase_log) {
+                std::vector<long long> ph((size_t)blocks * 8);
+                HIPCHK(hipMemcpy(ph.data(), cf.phase_log, ph.size() * sizeof(long long), hipMemcpyDeviceToHost));
+                std::vector<std::vector<long long>> byg((size_t)G);
+                for (int bl = 0; bl < blocks; bl++) { const long long* r = &ph[(size_t)bl * 8]; if (r[5] > r[0] && r[0] > 0 && r[6] < (long long)rnea_items) byg[(size_t)(r[6] % G)].push_back(r[5] - r[0]); }
+                fprintf(stderr, "[P1 tv phases, cycles of a block's item by group of time steps, median / max]");
+                for (int g2 = 0; g2 < G; g2++) { auto& d = byg[(size_t)g2]; if (d.empty()) continue; std::sort(d.begin(), d.end()); fprintf(stderr, " group %d: %lld / %lld (%zu)", g2, d[d.size() / 2], d.back(), d.size()); }
+                fprintf(stderr, "\n");
+            }
             if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each, rows of %d), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, gr, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);
             if (st[ST_ERR] == 0) { built = true; h->p1_tv_shape_hint = si; }
             else if (!(st[ST_ERR] == (unsigned)ERR_RAW_OVERFLOW)) break;  // only the sort buffers can be helped by the next shape

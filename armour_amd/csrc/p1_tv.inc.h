@@ -714,6 +714,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
         c.role = 0;
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NP) c.w.w.cnt[i] = 0;
         c.bar();
+        if (cf.phase_log != nullptr && threadIdx.x == 0) { cf.phase_log[(size_t)blockIdx.x * 8 + 0] = clock64(); cf.phase_log[(size_t)blockIdx.x * 8 + 6] = it; }   // (ARMOUR_P1_TRACE: when this block's item began and ended)
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
         c.w.c_wait = c.w.c_sort = c.w.c_walk = c.w.c_cc = c.w.n_raw = c.w.n_calls = c.w.n_emit = 0;
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
         }
         pzw::margin_reduce_store(c.w.w.mabs, lane, cf.margin ? cf.margin + (size_t)b : nullptr);
         c.bar();
+        if (cf.phase_log != nullptr && threadIdx.x == 0) cf.phase_log[(size_t)blockIdx.x * 8 + 5] = clock64();
         if constexpr (NW == 8) tv::hj_post_ctl(c.w, tv::HK_EXIT);
 #ifdef TV_PROFILE
         if (lane == 0 && blockIdx.x == 0) printf("[tv item %d wave %d] walks by type: mul %lld cycles / %lld raw, cross %lld / %lld, sums %lld / %lld\n", it, c.wid, c.w.c_type[0], c.w.n_type[0], c.w.c_type[1], c.w.n_type[1], c.w.c_type[2], c.w.n_type[2]);
