@@ -823,7 +823,7 @@ extern "C" int armour_set_option(ArmourPlanner* h, int32_t option, double value)
             ok = (lo2 <= 4 || (lo2 >= 10 && lo2 <= 14)) && hi2 <= 5;
         }
         if (ok && option == ARMOUR_OPT_P1_TV_ROW_WIDTH) ok = value == 0.0 || value == 50.0 || value == 64.0;
-        if (ok && option == ARMOUR_OPT_P1_STEP_TWO_CU) { const int lv = (int)value % 10; ok = lv <= 3 && (value < 10.0 || lv >= 1); h->p1_two_cu_off = false; }   // (setting it again undoes a fall-back the handle had taken)
+        if (ok && option == ARMOUR_OPT_P1_STEP_TWO_CU) { const int lv = (int)value % 10; ok = lv <= 3 && (value < 10.0 || lv >= 1); if (ok) h->p1_two_cu_off = false; }   // (setting it again undoes a fall-back the handle had taken)
         if (ok) {
             h->tuning[option - ARMOUR_OPT_FIRST_TUNING] = value;
             h->p1_step_cap_hint = 0; h->p1_tv_shape_hint = 0;   // (an option may re-enable a block shape the hints had moved past)

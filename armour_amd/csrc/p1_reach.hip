@@ -1814,6 +1814,7 @@ struct P1Work {
     int* d_retry = nullptr; size_t retry_cap = 0;  // [1 + B*T]: count, then item indices
     unsigned long long* d_skip_part = nullptr; size_t skip_part_cap = 0;  // [B][blocks per problem][4 waves]: the planes kernel's masks before the AND
     unsigned long long* d_margin = nullptr; size_t margin_cap = 0;   // [B]: the prune margin word of every problem (P1Cfg::margin)
+    long long* d_phase = nullptr;   // ARMOUR_P1_TRACE: [1024][8] phase clocks of the last launch's blocks (P1Cfg::phase_log), allocated on first use
     unsigned char* d_xch = nullptr; size_t xch_cap = 0; int xch_epoch = 0;   // a time step on two CUs: kXchBytes per item, flags tagged with the launch's epoch (cleared when allocated and when the epoch wraps)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // around the reach-set kernel | around the half-space kernels
 };
@@ -1871,6 +1872,7 @@ void armour_p1_free(ArmourPlanner* h) {
     if (wk->d_torque_radius) (void)hipFree(wk->d_torque_radius);
     if (wk->d_margin) (void)hipFree(wk->d_margin);
     if (wk->d_xch) (void)hipFree(wk->d_xch);
+    if (wk->d_phase) (void)hipFree(wk->d_phase);
     if (wk->d_obstacles) (void)hipFree(wk->d_obstacles);
     if (wk->d_skip_part) (void)hipFree(wk->d_skip_part);
     if (wk->d_retry) (void)hipFree(wk->d_retry);
@@ -2100,11 +2102,11 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         if (cf.queue) HIPCHK(hipMemsetAsync(cf.queue, 0, sizeof(unsigned), h->stream));
         cf.tail_cross = split ? h->tune(ARMOUR_OPT_P1_STEP_TAIL_CROSS) : 0;   // (with its forward kinematics to do the fourth wave has no time to spare)
         cf.retry_list = collect ? wk->d_retry + 1 : nullptr; cf.retry_count = reinterpret_cast<unsigned*>(wk->d_retry);
-        static thread_local long long* d_phase = nullptr; static thread_local int phase_blocks = 0;
+        int phase_blocks = 0;
         if (armour_trace_p1() && nw == 4 && waves <= 1024) {
-            if (!d_phase) HIPCHK(hipMalloc((void**)&d_phase, 1024 * 8 * sizeof(long long)));
-            HIPCHK(hipMemsetAsync(d_phase, 0, 1024 * 8 * sizeof(long long), h->stream));
-            cf.phase_log = d_phase; phase_blocks = waves;
+            if (!wk->d_phase) HIPCHK(hipMalloc((void**)&wk->d_phase, 1024 * 8 * sizeof(long long)));
+            HIPCHK(hipMemsetAsync(wk->d_phase, 0, 1024 * 8 * sizeof(long long), h->stream));
+            cf.phase_log = wk->d_phase; phase_blocks = waves;
         }
         cf.two_cu = two_cu ? cf_two_cu_env : 0; cf.helper0 = helper0;
         cf.lean_back = h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 1; cf.late_jrs = (h->tune(ARMOUR_OPT_P1_STEP_LEAN_BACK) & 2) == 0;   // (development: + 2 builds every joint before the roles begin)
@@ -2137,7 +2139,7 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
         HIPCHK(hipEventRecord(wk->ev1, h->stream));
         HIPCHK(hipMemcpyAsync(st_pin, wk->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
         armour_build_stamp("launch-queued");
-        launch_done = [&, cap, n_items, waves, nw, two_cu, per_cu, smem, helper0]() -> int {
+        launch_done = [&, cap, n_items, waves, nw, two_cu, per_cu, smem, helper0, phase_blocks]() -> int {
         memcpy(st, st_pin, sizeof(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, wk->ev0, wk->ev1));
@@ -2153,9 +2155,9 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                     pr[PR_CYC64], pr[PR_CYC512], pr[PR_N512], pr[PR_TERMS512], pr[PR_CYCBIG], pr[PR_NBIG], pr[PR_TERMSBIG]);
         }
 #endif
-        if (armour_trace_p1() && nw == 4 && d_phase && phase_blocks > 0) {   // where the blocks' time went (wave 0 of each): median / max over the main blocks, then over the helpers
+        if (armour_trace_p1() && nw == 4 && wk->d_phase && phase_blocks > 0) {   // where the blocks' time went (wave 0 of each): median / max over the main blocks, then over the helpers
             std::vector<long long> ph((size_t)phase_blocks * 8);
-            HIPCHK(hipMemcpy(ph.data(), d_phase, ph.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ph.data(), wk->d_phase, ph.size() * sizeof(long long), hipMemcpyDeviceToHost));
             const char* names[5] = {"JRS", "decision", "forward pass", "backward pass", "tables"};
             for (int grp = 0; grp < (two_cu ? 2 : 1); grp++) {
                 const int b0 = grp == 0 ? 0 : helper0, b1 = grp == 0 ? n_items : helper0 + n_items;
@@ -2314,11 +2316,10 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
             const int tv_aux3_env = h->tune(ARMOUR_OPT_P1_TV_AUX3);
             cf.tv_aux_on_fk_wave = tv_aux3_env;
             cf.tail_cross = h->tune(ARMOUR_OPT_P1_TV_TAIL_CROSS);
-            static thread_local long long* d_tvphase = nullptr;
             if (armour_trace_p1() && blocks <= 1024) {   // when each block's (last) item began and ended: the spread between the groups
-                if (!d_tvphase) HIPCHK(hipMalloc((void**)&d_tvphase, 1024 * 8 * sizeof(long long)));
-                HIPCHK(hipMemsetAsync(d_tvphase, 0, 1024 * 8 * sizeof(long long), h->stream));
-                cf.phase_log = d_tvphase;
+                if (!wk->d_phase) HIPCHK(hipMalloc((void**)&wk->d_phase, 1024 * 8 * sizeof(long long)));
+                HIPCHK(hipMemsetAsync(wk->d_phase, 0, 1024 * 8 * sizeof(long long), h->stream));
+                cf.phase_log = wk->d_phase;
             }
             HIPCHK(hipMemsetAsync(wk->d_status, 0, ST_WORDS * sizeof(unsigned), h->stream));
             HIPCHK(hipEventRecord(wk->ev0, h->stream));
