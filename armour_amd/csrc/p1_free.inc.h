@@ -739,7 +739,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
             t3_signal(c, T3_C0, s + 1);
         }
         c.prof_forward_done(); c.bar();   // (A)
-        if constexpr (CH::kTwoCu) c.phase(3);
+        c.phase(3);
         for (int k = freed; k <= J; k++) c.freeVs(t3_take(c, T3_LA + k));
     } else if (c.wid == 3 && two2) {
         // Two CUs, level 2: of this wave's forward pass only the w_aux recursion is left (R_t w_aux_s for the angular step); level 3: nothing.
@@ -939,6 +939,7 @@ __device__ PZW_NOINLINE void run_rnea_free(CH& c, typename CH::PZT* u, int b, in
         }
         c.freeVs(nn);
         c.bar();   // (B)
+        c.phase(4);
     }
     if (c.wid == helper) {
         c.role = helper;

@@ -2338,9 +2338,23 @@ int armour_p1_build(ArmourPlanner* h, const double* obstacles) {
                 std::vector<long long> ph((size_t)blocks * 8);
                 HIPCHK(hipMemcpy(ph.data(), cf.phase_log, ph.size() * sizeof(long long), hipMemcpyDeviceToHost));
                 std::vector<std::vector<long long>> byg((size_t)G);
-                for (int bl = 0; bl < blocks; bl++) { const long long* r = &ph[(size_t)bl * 8]; if (r[5] > r[0] && r[0] > 0 && r[6] < (long long)rnea_items) byg[(size_t)(r[6] % G)].push_back(r[5] - r[0]); }
+                std::vector<std::vector<long long>> fw((size_t)G), bw((size_t)G);
+                for (int bl = 0; bl < blocks; bl++) {
+                    const long long* r = &ph[(size_t)bl * 8];
+                    if (!(r[5] > r[0] && r[0] > 0 && r[6] < (long long)rnea_items)) continue;
+                    const size_t g2 = (size_t)(r[6] % G);
+                    byg[g2].push_back(r[5] - r[0]);
+                    if (r[3] > r[0] && r[4] > r[3]) { fw[g2].push_back(r[3] - r[0]); bw[g2].push_back(r[4] - r[3]); }
+                }
                 fprintf(stderr, "[P1 tv phases, cycles of a block's item by group of time steps, median / max]");
-                for (int g2 = 0; g2 < G; g2++) { auto& d = byg[(size_t)g2]; if (d.empty()) continue; std::sort(d.begin(), d.end()); fprintf(stderr, " group %d: %lld / %lld (%zu)", g2, d[d.size() / 2], d.back(), d.size()); }
+                for (int g2 = 0; g2 < G; g2++) {
+                    auto& d = byg[(size_t)g2];
+                    if (d.empty()) continue;
+                    std::sort(d.begin(), d.end());
+                    fprintf(stderr, " group %d: %lld / %lld (%zu)", g2, d[d.size() / 2], d.back(), d.size());
+                    auto& f = fw[(size_t)g2]; auto& bk = bw[(size_t)g2];
+                    if (!f.empty()) { std::sort(f.begin(), f.end()); std::sort(bk.begin(), bk.end()); fprintf(stderr, " [JRS + forward %lld / %lld, backward %lld / %lld]", f[f.size() / 2], f.back(), bk[bk.size() / 2], bk.back()); }
+                }
                 fprintf(stderr, "\n");
             }
             if (armour_trace_p1()) fprintf(stderr, "[P1 tv] %d groups of <= %d steps%s, sort cap %d: %d blocks of %d wave(s) (%d per CU, %zu B LDS, %d / %d staging rows, %.1f MB arena each, rows of %d), %.2f ms, flags 0x%x, max raw terms %u, max monomials %u\n", groups, LG, fk_items ? " (+ as many forward-kinematics items)" : "", cap, blocks, nw_launch, per_cu, smem, stage_rows, stage_other, TL.total / 1048576.0, gr, ms, st[ST_ERR], st[ST_MAX_RAW], st[ST_MAX_OUT]);

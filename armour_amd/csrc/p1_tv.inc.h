@@ -65,6 +65,8 @@ struct TChain {
     static constexpr bool kPairs = false;        // (the per-step chain's two-waves-per-operator backward pass; this chain shares its walks instead)
     static constexpr bool kTwoCu = false;        // (a time step on two CUs: the per-step chain's, p1_free.inc.h)
     static constexpr bool kFusedCross = true;    // run_rnea_free: (a + cross(w, b)) + c with the constant cross product taken inside the sum's walk (sum3x)
+    long long* phase_log = nullptr;              // (ARMOUR_P1_TRACE) this block's row of P1Cfg::phase_log
+    __device__ void phase(int k) const { if (phase_log != nullptr && wid == 0 && (threadIdx.x & 63) == 0) phase_log[k] = clock64(); }
     TW w;
     const P1Cfg* cf;
     GLB_AS unsigned char* arena;
@@ -714,6 +716,7 @@ __global__ __launch_bounds__(64 * NW) P1_TV_OCC void armour_p1_tv_kernel(P1Cfg c
         c.role = 0;
         for (int i = threadIdx.x; i < kMaxSlots; i += 64 * NP) c.w.w.cnt[i] = 0;
         c.bar();
+        c.phase_log = cf.phase_log ? cf.phase_log + (size_t)blockIdx.x * 8 : nullptr;
         if (cf.phase_log != nullptr && threadIdx.x == 0) { cf.phase_log[(size_t)blockIdx.x * 8 + 0] = clock64(); cf.phase_log[(size_t)blockIdx.x * 8 + 6] = it; }   // (ARMOUR_P1_TRACE: when this block's item began and ended)
 #ifdef TV_PROFILE
         const long long tvp_start = clock64();
