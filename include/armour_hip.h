@@ -144,7 +144,7 @@ void armour_free_pinned(void* p);
 #define ARMOUR_OPT_P1_TV_HELP_MIN 117         /* (r) default 192: walks with fewer sorted terms stay on one wave */
 #define ARMOUR_OPT_P1_TV_HELP_N 118           /* (r) 1 (default) | 0: the n-recursion shares its walks as well */
 #define ARMOUR_OPT_P1_TV_AUX3 119             /* 1 (default) | 0: as ARMOUR_OPT_P1_STEP_AUX3 */
-#define ARMOUR_OPT_P1_TV_TAIL_CROSS 121       /* as ARMOUR_OPT_P1_STEP_TAIL_CROSS, for the four-wave blocks of the time-vectorised kernel */
+#define ARMOUR_OPT_P1_TV_TAIL_CROSS 121       /* as ARMOUR_OPT_P1_STEP_TAIL_CROSS, for the four-wave blocks of the time-vectorised kernel; default 111 since the end of round 6 (the cross product of the last link on the angular wave, every moment N on the F / N wave, which waited a fifth of the forward pass: B = 128 -1 %); + 100 (n + 1): the angular wave builds the moments of the last n links */
 #define ARMOUR_OPT_P1_TV_ROW_WIDTH 122        /* 0 automatic (default) | 50 | 64: doubles per row of the kernel's work slots.  Automatic = 50 when a group of time steps fits (T = 100: two groups of 50; the rows are packed, -19 % of the build's L2-miss traffic), 64 otherwise; 50 with longer groups is refused.  Every bit of every table is the same for both. */
 #define ARMOUR_OPT_P1_FULL_PLANES 120         /* 0 (default) the lean half-space table | 1 every plane and component resident (armour_get_hyperplanes builds it on demand otherwise) */
 /* fused evaluation (p2_eval.hip) and its host entries (api.hip) */
