@@ -160,7 +160,7 @@ struct TuningSpec { int option; double def, lo, hi; };
 // default and accepted range of every option (an option id without an entry is unknown)
 const TuningSpec kTuning[] = {
     {ARMOUR_OPT_P1_STEP_WAVES, 0, 0, 4}, {ARMOUR_OPT_P1_STEP_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_SPLIT_FK, -1, -1, 1}, {ARMOUR_OPT_P1_STEP_AUX3, 1, 0, 1},
-    {ARMOUR_OPT_P1_MAX_WAVES_PER_CU, 4, 1, 8}, {ARMOUR_OPT_P1_TWO_PASS, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_PAIRS, 1, 0, 2}, {ARMOUR_OPT_P1_STEP_QUEUE, 1, 0, 3}, {ARMOUR_OPT_P1_STEP_TAIL_CROSS, 0, 0, 514}, {ARMOUR_OPT_P1_STEP_TWO_CU, 3, 0, 23}, {ARMOUR_OPT_P1_STEP_LEAN_BACK, 1, 0, 3}, {ARMOUR_OPT_P1_TV_TAIL_CROSS, 111, 0, 514} /* (set_option refuses the values without a meaning) */,
+    {ARMOUR_OPT_P1_MAX_WAVES_PER_CU, 4, 1, 8}, {ARMOUR_OPT_P1_TWO_PASS, 1, 0, 1}, {ARMOUR_OPT_P1_STEP_PAIRS, 1, 0, 2}, {ARMOUR_OPT_P1_STEP_QUEUE, 1, 0, 3}, {ARMOUR_OPT_P1_STEP_TAIL_CROSS, 0, 0, 514}, {ARMOUR_OPT_P1_STEP_TWO_CU, 3, 0, 33}, {ARMOUR_OPT_P1_STEP_LEAN_BACK, 1, 0, 3}, {ARMOUR_OPT_P1_TV_TAIL_CROSS, 111, 0, 514} /* (set_option refuses the values without a meaning) */,
     {ARMOUR_OPT_P1_TV_MIN_GROUPS, 31, 1, 1e6}, {ARMOUR_OPT_P1_TV_WAVES, 0, 0, 8}, {ARMOUR_OPT_P1_TV_FREE, 1, 0, 1}, {ARMOUR_OPT_P1_TV_SPLIT_FK, -1, -1, 1},
     {ARMOUR_OPT_P1_TV_DEDICATED, 1, 0, 1}, {ARMOUR_OPT_P1_TV_HELP_SHIFT, 0, 0, 3}, {ARMOUR_OPT_P1_TV_HELPERS, 1, 0, 31}, {ARMOUR_OPT_P1_TV_HELP_MIN, 192, 1, 1e6},
     {ARMOUR_OPT_P1_TV_HELP_N, 1, 0, 1}, {ARMOUR_OPT_P1_TV_AUX3, 1, 0, 1}, {ARMOUR_OPT_P1_TV_ROW_WIDTH, 0, 0, 64}, {ARMOUR_OPT_P1_FULL_PLANES, 0, 0, 1},

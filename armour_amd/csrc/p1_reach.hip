@@ -1189,7 +1189,9 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
     bool helper_block = false;   // a time step on two CUs (p1_free.inc.h): block helper0 + k is the helper of item k, the blocks between the two ranges have nothing to do
     if constexpr (NW == 4) {
         if (cf.two_cu) {
-            if ((int)blockIdx.x >= cf.helper0) { helper_block = true; it0 = (int)blockIdx.x - cf.helper0; }
+            // (cf.two_cu >= 30, a test hook: block helper0 + k helps item k + 1 -- the two blocks of an item then sit on DIFFERENT XCDs, what HIP is free to do)
+            const int shift = cf.two_cu >= 30 ? 1 : 0;
+            if ((int)blockIdx.x >= cf.helper0) { helper_block = true; it0 = ((int)blockIdx.x - cf.helper0 + shift) % cf.n_items; }
             else if ((int)blockIdx.x >= cf.n_items) it0 = cf.n_items + cf.fk_items;
         }
     }
@@ -1225,8 +1227,9 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
             if (cf.two_cu) {
                 c.xch = (GLB_AS unsigned char*)cf.xch + (size_t)it0 * kXchBytes;
                 c.xch_epoch = cf.xch_epoch;
-                c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(helper_block ? it0 : cf.helper0 + it0) * cf.arena_bytes;   // (the other block of the item)
-                if (!(helper_block && cf.two_cu >= 20)) xch_hello(c, helper_block);   // (cf.two_cu >= 20: the test of a helper that starts late -- it never says so)
+                const int shift = cf.two_cu >= 30 ? 1 : 0;
+                c.peer_arena = (GLB_AS unsigned char*)cf.arena + (size_t)(helper_block ? it0 : cf.helper0 + (it0 - shift + cf.n_items) % cf.n_items) * cf.arena_bytes;   // (the other block of the item)
+                if (!(helper_block && cf.two_cu >= 20 && cf.two_cu < 30)) xch_hello(c, helper_block);   // (cf.two_cu >= 20: the test of a helper that starts late -- it never says so)
                 if (threadIdx.x == 0) c.mb[kMbWords - 3] = 0;   // (xch_take: no take of this item has been lost)
             }
         }
@@ -1262,7 +1265,7 @@ __global__ __launch_bounds__(64 * NW) P1_OCC void armour_p1_chain_kernel(P1Cfg c
 #endif
         PZ u_nom[ARMOUR_MAX_FACTORS];
         if (helper_block) {
-            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu && cf.two_cu < 10);   // (20 + level: the main block has decided against two CUs by itself)
+            if constexpr (NW == 4) run_helper_free(c, b, t, c.two_cu && (cf.two_cu < 10 || cf.two_cu >= 30));   // (20 + level: the main block has decided against two CUs by itself)
         } else if (fk_only) {
             // forward kinematics and the link tables, nothing else: the whole ARMTD chain (CMP/armtd_main.cu:141-156), or
             // the forward-kinematics half of a split ARMOUR item.  A single role: one wave works.

@@ -130,7 +130,8 @@ void armour_free_pinned(void* p);
                                                  XCD the two blocks share (checked per item; otherwise, and whenever 2 T + 7 blocks do not fit the device, one CU per step as before).
                                                  Level 2: the main block drops its own w recursion; level 3: its w_aux recursion too.  Same tables bit for bit at every level.
                                                  10 + level, 20 + level: test hooks -- the helper agrees and hands over nothing (the build must notice and start again on one CU per step) /
-                                                 the helper never says it has started (the main blocks give up after ~1.5 ms and build alone: good tables, late).  After either event the handle
+                                                 the helper never says it has started (the main blocks give up after ~1.5 ms and build alone: good tables, late).  30 + level: the helper of an item is placed on
+                                                 another XCD than its main block (every item must then decide against two CUs: one launch, good tables, no fall-back of the handle).  After either event the handle
                                                  stays on one CU per step and armour_get_option reads 0; setting the option again re-enables it */
 #define ARMOUR_OPT_P1_STEP_LEAN_BACK 124      /* 1 (default) | 0 | 2 | 3: with a time step on two CUs at level 3 -- bit 0: the helper block also runs the backward pass's f-recursion (F_i handed over as the forward pass builds them, p x (R f) handed back), the main block's pair keeps R n and the four-term sum alone; bit 1 CLEAR: the JRS of the joints past the fourth is built by one wave of each block while the recursions run their first steps */
 /* time-vectorised reach-set kernel (p1_tv.inc.h: armour_p1_tv_kernel) */

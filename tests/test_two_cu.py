@@ -127,3 +127,35 @@ def test_a_helper_that_starts_late_costs_one_slow_build():
     assert nlp.get_option(_lib.OPT_P1_STEP_TWO_CU) == 3 and nlp.build_ms < 1.5
     assert np.array_equal(nlp.torque_radius(), ref.torque_radius()) and np.array_equal(nlp.link_generators(), ref.link_generators())
     nlp.close(); ref.close()
+
+
+
+def test_blocks_of_an_item_on_different_xcds_build_alone():
+    """ARMOUR_OPT_P1_STEP_TWO_CU = 30 + level: block helper0 + k helps item k + 1, so the two blocks of every item sit on different XCDs -- a placement HIP
+    is free to choose, under which a plain store of one block is not visible to the other through an L2.  Both publish their XCC_ID at the start of the item;
+    every main block must decide against two CUs and build its item alone (the helper keeps the forward kinematics, and with level 3 the joints past the
+    fourth get their JRS the way a one-block build deals them): ONE launch, the one-CU tables bit for bit, and no fall-back of the handle -- the placement of
+    the next launch may be another."""
+    from armour_amd import _lib
+    from armour_amd.planner import ArmourNLP
+    from armour_amd.worlds import random_problem
+    p = random_problem(6, 8)
+    ref = ArmourNLP(T=100)
+    ref.set_option(_lib.OPT_P1_STEP_TWO_CU, 0)
+    ref.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+    for level in (33, 32, 31):
+        nlp = ArmourNLP(T=100)
+        nlp.set_option(_lib.OPT_P1_STEP_TWO_CU, level)
+        for _ in range(2):
+            nlp.set_parameters(p["q0"], p["qd0"], p["qdd0"], p["q_des"], p["obstacles"])
+            assert nlp.build_info()["launches"] == 1 and nlp.get_option(_lib.OPT_P1_STEP_TWO_CU) == level
+            assert np.array_equal(nlp.torque_radius(), ref.torque_radius()) and np.array_equal(nlp.link_generators(), ref.link_generators())
+            for i in range(nlp.n):
+                for a, b in zip(nlp.pz("torque", i, 63), ref.pz("torque", i, 63)):
+                    assert np.array_equal(a, b)
+            for i in range(nlp.J):
+                for a, b in zip(nlp.pz("link", i, 17), ref.pz("link", i, 17)):
+                    assert np.array_equal(a, b)
+        assert float(nlp.prune_margin()[0]) == float(ref.prune_margin()[0])
+        nlp.close()
+    ref.close()
