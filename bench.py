@@ -272,6 +272,22 @@ def p1_accounting(device, T, O, p1_ms_b1, count_pairs):
             e["prune_margin"] = {"min": float(margins.min()), "world": int(margins.argmin()), "below_1e-9": int((margins < 1e-9).sum()),
                                  "note": "smallest |norm - SIMPLIFY_THRESHOLD| / threshold over every simplify() verdict of the 128 builds, from the device (DESIGN.md 4.11): the parity tolerances hold while it stays above ~1e-9"}
         out[tag] = e
+    # round 6: a lone problem's build runs every time step on two compute units -- the same world with the option as shipped and held to one CU
+    from armour_amd import _lib
+    p0 = random_problem(0, O)
+    ab = {}
+    for tag, opt in (("as_shipped", None), ("one_cu_per_time_step", 0)):
+        nl = _opts(ArmourNLP(T=T, device=device))
+        if opt is not None:
+            nl.set_option(_lib.OPT_P1_STEP_TWO_CU, opt)
+        t_ms = []
+        for _ in range(5):
+            nl.set_parameters(p0["q0"], p0["qd0"], p0["qdd0"], p0["q_des"], p0["obstacles"])
+            t_ms.append(nl.build_ms)
+        ab[tag] = {"set_problems_ms": min(t_ms[1:]), "ARMOUR_OPT_P1_STEP_TWO_CU": nl.get_option(_lib.OPT_P1_STEP_TWO_CU)}
+        nl.close()
+    out["B=1"]["two_cus_per_time_step"] = dict(ab, world="random_problem(0, O = %d)" % O,
+                                               note="the option reads 0 after a build if the handle fell back to one CU per step (a helper block that did not deliver or started late)")
     out["note"] = ("set_problems_ms: HIP events around every kernel of the build (reach-set kernel + half-space kernels), best of the warm builds; "
                    "pair_products: counted by the CPU oracle on the same worlds (seeds 0..B-1, O = %d); traffic: L2-miss bytes of the same kernels from the "
                    "committed counter profile; no roofline is claimed for P1 beyond that fraction (irregular, latency-bound: DESIGN.md 4.2)" % O)
